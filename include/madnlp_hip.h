@@ -1,0 +1,194 @@
+/*
+ * madnlp_hip.h -- C ABI of libmadnlp_hip.so: the MI355X (gfx950) implementation of
+ * MadNLP's per-iteration KKT hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces a function (or a
+ * group of functions) of MadNLP.jl v0.10.1; the reference file:line each one stands
+ * in for is cited next to it.  A Julia maintainer binds these with `ccall`
+ * exactly as `src/LinearSolvers/lapack.jl:50-139` binds LAPACK and
+ * `src/LinearSolvers/mumps.jl:148-165` binds MUMPS.
+ *
+ * Conventions
+ *   - plain C types only: int32/int64/double pointers and sizes, opaque handles.
+ *   - return value: 0 = OK; < 0 = bad argument / HIP runtime error (text via
+ *     mnk_last_error_string(); the Julia glue throws SymbolicException /
+ *     FactorizationException / SolveException, reference
+ *     `src/LinearSolvers/linearsolvers.jl:133-137`).  A *numerically* failed
+ *     factorization is NOT an error: it is reported through `info` / the
+ *     inertia, as `src/LinearSolvers/lapack_common.jl:96-102` does, so that the
+ *     IPM regularizes and refactorizes.
+ *   - `loc` arguments say where a caller buffer lives: MNK_HOST (pageable or
+ *     pinned host memory, copied over PCIe on the context's stream) or
+ *     MNK_DEVICE (HBM of the context's device; no copy).
+ *   - index arrays passed in use `index_base` 0 or 1 (Julia passes 1); arrays
+ *     handed back are 0-based unless stated.
+ *   - all matrices are column-major Float64, symmetric matrices use the lower
+ *     triangle ('L'), as everywhere in the reference.
+ *   - all work is enqueued on the context's stream; entry points that return
+ *     scalars to the host (info, inertia, host-destination copies) synchronize
+ *     that stream, everything else is asynchronous.
+ *   - one context / KKT system / solver per MadNLPSolver, driven from one
+ *     thread; distinct handles may be used concurrently from distinct threads.
+ */
+#ifndef MADNLP_HIP_H
+#define MADNLP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNK_VERSION 100 /* 0.1.0 */
+
+enum { MNK_HOST = 0, MNK_DEVICE = 1 };
+
+/* Same order as the reference's `@enum LinearFactorization`
+ * (`src/LinearSolvers/linearsolvers.jl:139-147`): BUNCHKAUFMAN LU QR CHOLESKY LDL EVD.
+ * Implemented on device: CHOLESKY (dpotrf semantics) and LDL (static-pivot
+ * LDL^T, inertia from sign(D); stands in for BUNCHKAUFMAN = dsytrf). */
+enum { MNK_BUNCHKAUFMAN = 1, MNK_LU = 2, MNK_QR = 3, MNK_CHOLESKY = 4, MNK_LDL = 5, MNK_EVD = 6 };
+
+typedef struct mnk_ctx mnk_ctx; /* device, stream(s), scratch */
+typedef struct mnk_sc mnk_sc;   /* SparseCondensedKKTSystem device state */
+typedef struct mnk_dc mnk_dc;   /* DenseCondensedKKTSystem / DenseKKTSystem device state */
+typedef struct mnk_ls mnk_ls;   /* AbstractLinearSolver device state */
+
+/* ---------------------------------------------------------------- context -- */
+int mnk_version(void);
+const char* mnk_last_error_string(void);
+/* `stream`: an existing hipStream_t to enqueue on (e.g. the caller's current
+ * stream), or NULL to let the context create its own. */
+int mnk_ctx_create(int device, void* stream, mnk_ctx** out);
+int mnk_ctx_destroy(mnk_ctx* ctx);
+int mnk_ctx_synchronize(mnk_ctx* ctx);
+void* mnk_ctx_stream(mnk_ctx* ctx);
+
+/* ------------------------------------------- SparseCondensedKKTSystem (sc) -- */
+/* Replaces the constructor `create_kkt_system(::Type{SparseCondensedKKTSystem}, ...)`
+ * reference `src/KKT/Sparse/condensed.jl:55-133`:
+ *   force_lower_triangular! (`src/matrixtools.jl:129-137`), coo_to_csc + get_mapping
+ *   for J^T and tril(H) (`src/matrixtools.jl:55-95`) and the one-time symbolic
+ *   analysis build_condensed_aug_symbolic (`condensed.jl:201-301`), all on the host
+ *   in C++ (integer work), then uploads the maps.
+ * jac_I/jac_J: COO pattern of the Jacobian (row = constraint, col = variable),
+ * hess_I/hess_J: COO pattern of the Lagrangian Hessian (either triangle).
+ * All m constraints are inequalities (the reference errors otherwise, `:68-70`).
+ * ctx may be NULL: the handle is then host-only (symbolic analysis and the structure
+ * getters work, nothing is allocated on a device) -- used by CPU-side tests. */
+int mnk_sc_create(mnk_ctx* ctx, int64_t n, int64_t m,
+                  int64_t nnzj, const int32_t* jac_I, const int32_t* jac_J,
+                  int64_t nnzh, const int32_t* hess_I, const int32_t* hess_J,
+                  int index_base, mnk_sc** out);
+int mnk_sc_destroy(mnk_sc* sc);
+
+/* Sizes of the derived structures: nnz(jt_csc), nnz(hess_com), nnz(aug_com), length(jptr). */
+int mnk_sc_sizes(mnk_sc* sc, int64_t* nnz_jt, int64_t* nnz_hess, int64_t* nnz_aug, int64_t* len_jptr);
+/* Derived CSC structures (0-based), so the host mirror can build `jt_csc`,
+ * `hess_com`, `aug_com` (`condensed.jl:110-119`). which: 0 = jt_csc (n x m),
+ * 1 = hess_com (n x n lower), 2 = aug_com (n x n lower). colptr has ncol+1 entries. */
+enum { MNK_SC_JT = 0, MNK_SC_HESS = 1, MNK_SC_AUG = 2, MNK_SC_DIAGBUF = 3 };
+int mnk_sc_get_structure(mnk_sc* sc, int which, int32_t* colptr, int32_t* rowval);
+/* COO -> CSC slot maps `jt_csc_map` / `hess_csc_map` (0-based; which = MNK_SC_JT / MNK_SC_HESS). */
+int mnk_sc_get_map(mnk_sc* sc, int which, int64_t* map);
+/* dptr/hptr/jptr of `build_condensed_aug_symbolic` (0-based), in the reference's order:
+ * dptr: dst[n], src[n]; hptr: dst[nnzH], src[nnzH]; jptr: dst[L], c[L], k[L], l[L].
+ * Any output pointer may be NULL. */
+int mnk_sc_get_ptrs(mnk_sc* sc, int32_t* d_dst, int32_t* d_src, int32_t* h_dst, int32_t* h_src,
+                    int32_t* j_dst, int32_t* j_c, int32_t* j_k, int32_t* j_l);
+
+/* compress_jacobian!(::SparseCondensedKKTSystem) `condensed.jl:145-148` = transfer!
+ * (`src/matrixtools.jl:79-88`) of the nnzj COO values into jt_csc.nzval. */
+int mnk_sc_compress_jacobian(mnk_sc* sc, const double* jac_coo, int loc);
+/* compress_hessian!(::AbstractSparseKKTSystem) `src/KKT/Sparse/utils.jl:48-50`. */
+int mnk_sc_compress_hessian(mnk_sc* sc, const double* hess_coo, int loc);
+/* build_kkt!(::SparseCondensedKKTSystem) `condensed.jl:354-366` +
+ * _build_condensed_aug_coord! `:328-345`.  pr_diag has n+m entries, du_diag m. */
+int mnk_sc_build(mnk_sc* sc, const double* pr_diag, const double* du_diag, int loc);
+/* Read back nzval of jt_csc / hess_com / aug_com, or diag_buffer (which = MNK_SC_*). */
+int mnk_sc_get_values(mnk_sc* sc, int which, double* out, int loc);
+
+/* Device-side pieces of solve_kkt!/mul! for the sparse condensed system (reference
+ * `src/IPM/factorization.jl:143-167,278-299`): y = alpha*op(A)*x + beta*y with
+ * A = jt_csc (which = MNK_SC_JT; trans = 0: n<-m, trans = 1: m<-n) or
+ * Symmetric(hess_com, :L) (which = MNK_SC_HESS).  x, y in device memory. */
+int mnk_sc_spmv(mnk_sc* sc, int which, int trans, double alpha, const double* x, double beta, double* y);
+
+/* ------------------- DenseCondensedKKTSystem / DenseKKTSystem (dc) ---------- */
+/* Replaces `create_kkt_system(::Type{DenseCondensedKKTSystem}, ...)`
+ * `src/KKT/Dense/condensed.jl:52-111` (condensed = 1, order n + n_eq) and
+ * `create_kkt_system(::Type{DenseKKTSystem}, ...)` `src/KKT/Dense/augmented.jl:41-94`
+ * (condensed = 0, order n + ns + m).  ind_ineq has ns entries, ind_eq m - ns. */
+int mnk_dc_create(mnk_ctx* ctx, int condensed, int64_t n, int64_t m,
+                  int64_t ns, const int64_t* ind_ineq, const int64_t* ind_eq,
+                  int index_base, mnk_dc** out);
+int mnk_dc_destroy(mnk_dc* dc);
+/* The callbacks write kkt.hess (n x n) / kkt.jac (m x n) in place in the reference
+ * (`get_hessian/get_jacobian`); here they are uploaded (or copied device to device). */
+int mnk_dc_set_hess(mnk_dc* dc, const double* hess, int64_t ld, int loc);
+int mnk_dc_set_jac(mnk_dc* dc, const double* jac, int64_t ld, int loc);
+/* build_kkt!(::DenseCondensedKKTSystem) `condensed.jl:157-186` (_build_ineq_jac!,
+ * the J_i' D J_i product, _build_condensed_kkt_system!) or, for condensed = 0,
+ * compress_hessian! + build_kkt!(::DenseKKTSystem) `augmented.jl:116-161`.
+ * pr_diag has n+ns entries, du_diag m.  Both triangles of aug_com are written. */
+int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int loc);
+int64_t mnk_dc_order(mnk_dc* dc);
+/* Copy aug_com (order x order, column-major, ld = order) out. */
+int mnk_dc_get_aug(mnk_dc* dc, double* out, int loc);
+
+/* ------------------------------------------------- linear solver (ls) ------- */
+/* Replaces `LapackCPUSolver(A; opt)` `src/LinearSolvers/lapack.jl:21-43` /
+ * `LapackROCmSolver` `lib/MadNLPGPU/ext/MadNLPGPUAMDGPUExt/rocsolver.jl`:
+ * allocates the private N x N factor buffer.  algo = MNK_CHOLESKY or MNK_LDL
+ * (MNK_BUNCHKAUFMAN is accepted as an alias of MNK_LDL). */
+int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out);
+int mnk_ls_destroy(mnk_ls* ls);
+/* Options: "pivot_tol" (LDL: |d| <= pivot_tol counts as a zero pivot; default 0),
+ * "outer_block" (outer panel width, multiple of 64; default 512),
+ * "lookahead" (0/1). */
+int mnk_ls_set_option(mnk_ls* ls, const char* key, double value);
+
+/* factorize!(M) `src/LinearSolvers/lapack_common.jl:54-66` = transfer_matrix!
+ * (`:28`; CSC -> dense zero-fill + scatter, device twin
+ * `lib/MadNLPGPU/src/utils.jl:12-23`) + dpotrf('L') / dsytrf('L')
+ * (`lapack.jl:145-148,164-167`).  The source is named explicitly:
+ *   _sc    : aug_com of a sparse condensed system (CSC on device);
+ *   _dc    : aug_com of a dense system (on device);
+ *   _dense : caller's dense N x N matrix (host or device), lower triangle read;
+ *   _csc   : caller's lower-triangular CSC (host), 0/1-based.
+ * *info = 0 on success, k > 0 if pivot k (1-based) is not positive (CHOLESKY) or
+ * is zero (LDL).  Synchronizes the stream (info is read back). */
+int mnk_ls_factorize_sc(mnk_ls* ls, mnk_sc* sc, int* info);
+int mnk_ls_factorize_dc(mnk_ls* ls, mnk_dc* dc, int* info);
+int mnk_ls_factorize_dense(mnk_ls* ls, const double* A, int64_t lda, int loc, int* info);
+int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowval,
+                         const double* nzval, int index_base, int* info);
+/* Asynchronous variants: enqueue only, info/inertia are fetched later with
+ * mnk_ls_inertia (which synchronizes). */
+int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc);
+int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc);
+
+/* inertia(M) `lapack_common.jl:96-109`, `lapack.jl:240-268`: (num_pos, num_zero, num_neg).
+ * CHOLESKY: info == 0 ? (N,0,0) : (0,N,0).  LDL: signs of D. */
+int mnk_ls_inertia(mnk_ls* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg);
+/* solve_linear_system!(M, x) `lapack_common.jl:75-81` (dpotrs / dsytrs): in place,
+ * nrhs right-hand sides with leading dimension ldx (the reference loops over
+ * columns, `src/LinearSolvers/linearsolvers.jl:102-110`). */
+int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc);
+/* Debug / tests: copy the factor (N x N, ld = N; L in the lower triangle, for
+ * LDL unit-lower L with D returned separately) and D (N entries, may be NULL). */
+int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc);
+
+/* ----------------------------------------------------------- utilities ------ */
+/* C (M x N) = / -= A (M x K) * B (N x K)^T on the fp64 MFMA tile kernel used by the
+ * factorization's trailing update; exposed for unit tests and microbenchmarks.
+ * mode 0: C -= A*B^T, 1: C = A*B^T, 2: as 0 but only tiles on/below the diagonal.
+ * All pointers are device memory; M, N multiples of 64, K multiple of 16. */
+int mnk_gemm_nt(mnk_ctx* ctx, int mode, int64_t M, int64_t N, int64_t K,
+                const double* A, int64_t lda, const double* B, int64_t ldb,
+                double* C, int64_t ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADNLP_HIP_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of libmadnlp_hip.so (the C ABI in include/madnlp_hip.h).
+
+The library is built in-tree by `build()` (hipcc, gfx950 only).  There is no CPU
+fallback: if the shared object is missing or cannot be loaded, importing the
+bindings raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
+SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip"]
+HEADERS = ["common.h", "ls.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
+
+MNK_HOST, MNK_DEVICE = 0, 1
+MNK_BUNCHKAUFMAN, MNK_LU, MNK_QR, MNK_CHOLESKY, MNK_LDL, MNK_EVD = 1, 2, 3, 4, 5, 6
+MNK_SC_JT, MNK_SC_HESS, MNK_SC_AUG, MNK_SC_DIAGBUF = 0, 1, 2, 3
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIBPATH):
+        return True
+    t = os.path.getmtime(LIBPATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into madnlp.jl_amd/lib/libmadnlp_hip.so."""
+    if not force and not _stale():
+        return LIBPATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-mllvm", "-amdgpu-mfma-vgpr-form",
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIBPATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIBPATH
+
+
+_lib = None
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/madnlp_hip.h
+SIGNATURES = {
+    "mnk_version": (C.c_int, []),
+    "mnk_last_error_string": (C.c_char_p, []),
+    "mnk_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "mnk_ctx_destroy": (C.c_int, [_vp]),
+    "mnk_ctx_synchronize": (C.c_int, [_vp]),
+    "mnk_ctx_stream": (_vp, [_vp]),
+    "mnk_sc_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, C.c_int64, _vp, _vp,
+                                C.c_int, C.POINTER(_vp)]),
+    "mnk_sc_destroy": (C.c_int, [_vp]),
+    "mnk_sc_sizes": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "mnk_sc_get_structure": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "mnk_sc_get_map": (C.c_int, [_vp, C.c_int, _vp]),
+    "mnk_sc_get_ptrs": (C.c_int, [_vp] + [_vp] * 8),
+    "mnk_sc_compress_jacobian": (C.c_int, [_vp, _vp, C.c_int]),
+    "mnk_sc_compress_hessian": (C.c_int, [_vp, _vp, C.c_int]),
+    "mnk_sc_build": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "mnk_sc_get_values": (C.c_int, [_vp, C.c_int, _vp, C.c_int]),
+    "mnk_sc_spmv": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_double, _vp]),
+    "mnk_dc_create": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, C.c_int,
+                                C.POINTER(_vp)]),
+    "mnk_dc_destroy": (C.c_int, [_vp]),
+    "mnk_dc_set_hess": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "mnk_dc_set_jac": (C.c_int, [_vp, _vp, C.c_int64, C.c_int]),
+    "mnk_dc_build": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "mnk_dc_order": (C.c_int64, [_vp]),
+    "mnk_dc_get_aug": (C.c_int, [_vp, _vp, C.c_int]),
+    "mnk_ls_create": (C.c_int, [_vp, C.c_int64, C.c_int, C.POINTER(_vp)]),
+    "mnk_ls_destroy": (C.c_int, [_vp]),
+    "mnk_ls_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "mnk_ls_factorize_sc": (C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
+    "mnk_ls_factorize_dc": (C.c_int, [_vp, _vp, C.POINTER(C.c_int)]),
+    "mnk_ls_factorize_dense": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
+    "mnk_ls_factorize_csc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.POINTER(C.c_int)]),
+    "mnk_ls_factorize_sc_async": (C.c_int, [_vp, _vp]),
+    "mnk_ls_factorize_dc_async": (C.c_int, [_vp, _vp]),
+    "mnk_ls_inertia": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
+    "mnk_ls_solve": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int]),
+    "mnk_ls_get_factor": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "mnk_gemm_nt": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp,
+                              C.c_int64, _vp, C.c_int64]),
+}
+
+
+def lib():
+    """Load libmadnlp_hip.so (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise ImportError(
+            f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the KKT hot path.")
+    l = C.CDLL(LIBPATH)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(l, name)  # AttributeError if the symbol is not exported
+        f.restype = res
+        f.argtypes = args
+    _lib = l
+    return l
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().mnk_last_error_string()
+        raise HipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,101 @@
+// Shared declarations for libmadnlp_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/madnlp_hip.h"
+
+namespace mnk {
+
+void set_error(const char* fmt, ...);
+
+#define MNK_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            mnk::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return -2;                                                                  \
+        }                                                                               \
+    } while (0)
+
+#define MNK_REQUIRE(cond, msg)                                                          \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            mnk::set_error("%s:%d: %s", __FILE__, __LINE__, msg);                       \
+            return -1;                                                                  \
+        }                                                                               \
+    } while (0)
+
+// Factorization granularity: every dense buffer is padded to a multiple of PAD
+// rows/columns (unit diagonal in the padding) so that tile kernels never see a
+// ragged edge; NBI is the width of one inner panel (one diagonal-block kernel).
+constexpr int NBI = 64;
+constexpr int PAD = 128;
+// Rows of slack behind every dense operand buffer: tile loads may run up to one
+// wave tile past the last row (values are discarded, memory must be mapped).
+constexpr int SLACK = 256;
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return -2;
+        }
+        n = count;
+        return 0;
+    }
+    int upload(const std::vector<T>& h, hipStream_t s) {
+        int rc = alloc(h.size());
+        if (rc) return rc;
+        if (!h.empty()) {
+            hipError_t e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); return -2; }
+            e = hipStreamSynchronize(s);
+            if (e != hipSuccess) { set_error("upload sync failed: %s", hipGetErrorString(e)); return -2; }
+        }
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace mnk
+
+struct mnk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // second stream + events for the factorization's look-ahead
+    hipStream_t side = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    int num_cu = 256;
+};
+
+// ---- kernels / launchers shared between translation units -------------------
+namespace mnk {
+
+// C (MxN) op= A (MxK) * B (NxK)^T on fp64 MFMA tiles.  mode: 0 sub, 1 set, 2 sub-lower, 4 add-lower.
+// `colscale`/`C2`: optional LDL epilogue (C2 = acc, C = acc * colscale[n]); mode 1 only.
+int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K,
+                   const double* A, int64_t lda, const double* B, int64_t ldb,
+                   double* C, int64_t ldc, const double* colscale, double* C2, int64_t ldc2,
+                   const int* info_flag);
+
+}  // namespace mnk

@@ -1,0 +1,280 @@
+// DenseCondensedKKTSystem / DenseKKTSystem assembly on the device (mnk_dc_*).
+//
+// build_kkt!(::DenseCondensedKKTSystem), reference src/KKT/Dense/condensed.jl:157-186:
+//     D   = Sigma_s ./ (1 - Sigma_d[ineq] .* Sigma_s)
+//     K   = [ H + diag(pr_diag[1:n]) + J_i' D J_i   J_eq' ;  J_eq   diag(du_diag[eq]) ]
+// The reference scales J_i by sqrt(D) (`_build_ineq_jac!` :146-155), calls dgemm (:178) and
+// then runs a scalar scatter loop (`_build_condensed_kkt_system!` :120-144; device twins
+// lib/MadNLPGPU/src/KKT/kernels_dense.jl:81-119).  Here:
+//   1. scale_transpose_kernel  : A = (sqrt(D) J_i)^T, n x ns, zero padded      (HBM-bound)
+//   2. init_condensed_kernel   : lower(K) = H + diag + equality rows, rest 0    (HBM-bound)
+//   3. gemm_nt mode 4          : lower tiles of K += A A^T  (fp64 MFMA, SYRK flop count)
+//   4. mirror_kernel           : upper(K) = lower(K)^T (the reference writes both triangles)
+// build_kkt!(::DenseKKTSystem), reference src/KKT/Dense/augmented.jl:116-161, is a pure
+// scatter (one thread per entry).
+#pragma clang fp contract(off)
+
+#include "ls.h"
+
+namespace mnk {
+
+__global__ void dc_diag_buffer_kernel(double* __restrict__ D, const double* __restrict__ pr_s,
+                                      const double* __restrict__ du, const int64_t* __restrict__ ind_ineq,
+                                      int64_t ns) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < ns) D[i] = pr_s[i] / (1.0 - du[ind_ineq[i]] * pr_s[i]);
+}
+
+// A[i + k*lda] = jac[ind_ineq[k] + i*m] * sqrt(D[k]); zero outside (i < n, k < ns).
+__global__ __launch_bounds__(256) void scale_transpose_kernel(double* __restrict__ A, int64_t lda, int64_t npad,
+                                                              int64_t kpad, const double* __restrict__ jac,
+                                                              int64_t m, int64_t n, int64_t ns,
+                                                              const int64_t* __restrict__ ind_ineq,
+                                                              const double* __restrict__ D) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t k0 = (int64_t)blockIdx.x * 32, i0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t k = k0 + tx, i = i0 + ty + 8 * q;
+        double v = 0.0;
+        if (k < ns && i < n) v = jac[ind_ineq[k] + i * m] * sqrt(D[k]);
+        tile[ty + 8 * q][tx] = v;  // tile[i][k]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = i0 + tx, k = k0 + ty + 8 * q;
+        if (i < npad && k < kpad) A[i + k * lda] = tile[tx][ty + 8 * q];
+    }
+}
+
+// Lower part (row >= first row of the column's 128-tile ... simply all rows >= col) of K:
+// Hessian + primal diagonal, equality Jacobian rows, dual regularization; zero elsewhere.
+__global__ __launch_bounds__(256) void init_condensed_kernel(double* __restrict__ K, int64_t ldk, int64_t ordpad,
+                                                             const double* __restrict__ hess,
+                                                             const double* __restrict__ jac, int64_t m, int64_t n,
+                                                             int64_t n_eq, const int64_t* __restrict__ ind_eq,
+                                                             const double* __restrict__ pr_diag,
+                                                             const double* __restrict__ du_diag) {
+    const int64_t j = blockIdx.x;
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    if (i >= ordpad) return;
+    double v = 0.0;
+    const int64_t order = n + n_eq;
+    if (i < order && j < order && i >= j) {
+        if (i < n) {  // j <= i < n
+            v = hess[i + j * n];
+            if (i == j) v = pr_diag[i] + v;
+        } else if (j < n) {
+            v = jac[ind_eq[i - n] + j * m];
+        } else if (i == j) {
+            v = du_diag[ind_eq[i - n]];
+        }
+    }
+    K[i + j * ldk] = v;
+}
+
+// upper(K) = lower(K)^T on 32x32 tiles (tile row > tile col are read and written transposed;
+// diagonal tiles mirror themselves).
+__global__ __launch_bounds__(256) void mirror_kernel(double* __restrict__ K, int64_t ldk, int64_t order) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t bi = blockIdx.x, bj = blockIdx.y;
+    if (bi < bj) return;
+    const int64_t i0 = bi * 32, j0 = bj * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t i = i0 + tx, j = j0 + ty + 8 * q;
+        tile[ty + 8 * q][tx] = (i < order && j < order) ? K[i + j * ldk] : 0.0;  // tile[j][i]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // write element (row = j0 + tx, col = i0 + ty + 8q) = K[i0 + ty + 8q, j0 + tx]
+        const int64_t r = j0 + tx, c = i0 + ty + 8 * q;
+        if (r < order && c < order && r < c) K[r + c * ldk] = tile[tx][ty + 8 * q];
+    }
+}
+
+// DenseKKTSystem: one thread per entry of the (n+ns+m)^2 augmented matrix.
+__global__ __launch_bounds__(256) void dense_aug_kernel(double* __restrict__ K, int64_t ldk, int64_t ordpad,
+                                                        const double* __restrict__ hess,
+                                                        const double* __restrict__ jac, int64_t m, int64_t n,
+                                                        int64_t ns, const int64_t* __restrict__ ind_ineq,
+                                                        const int32_t* __restrict__ ineq_slot,
+                                                        const double* __restrict__ pr_diag,
+                                                        const double* __restrict__ du_diag) {
+    const int64_t j = blockIdx.x;
+    const int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    if (i >= ordpad) return;
+    const int64_t order = n + ns + m;
+    double v = 0.0;
+    if (i < order && j < order) {
+        const int64_t a = i > j ? i : j, b = i > j ? j : i;  // a >= b
+        if (a < n) {
+            v = (a == b) ? pr_diag[a] + hess[a + a * n] : hess[i + j * n];
+        } else if (a < n + ns) {
+            if (a == b) v = pr_diag[a];
+        } else {
+            const int64_t r = a - n - ns;  // constraint row
+            if (b < n) v = jac[r + b * m];
+            else if (b < n + ns) v = (ineq_slot[r] == (int32_t)(b - n)) ? -1.0 : 0.0;
+            else if (a == b) v = du_diag[r];
+        }
+    }
+    K[i + j * ldk] = v;
+}
+
+}  // namespace mnk
+
+using namespace mnk;
+
+struct mnk_dc_extra {
+    DevBuf<int32_t> ineq_slot;
+};
+static std::vector<std::pair<mnk_dc*, mnk_dc_extra*>> g_dcx;
+static mnk_dc_extra* extra_of(mnk_dc* dc) {
+    for (auto& p : g_dcx)
+        if (p.first == dc) return p.second;
+    return nullptr;
+}
+
+extern "C" {
+
+int mnk_dc_create(mnk_ctx* ctx, int condensed, int64_t n, int64_t m, int64_t ns, const int64_t* ind_ineq,
+                  const int64_t* ind_eq, int index_base, mnk_dc** out) {
+    MNK_REQUIRE(ctx && out, "mnk_dc_create: NULL argument");
+    MNK_REQUIRE(n > 0 && m >= 0 && ns >= 0 && ns <= m, "mnk_dc_create: bad sizes");
+    MNK_REQUIRE(ns == 0 || ind_ineq, "mnk_dc_create: ind_ineq is NULL");
+    MNK_REQUIRE(m - ns == 0 || ind_eq || !condensed, "mnk_dc_create: ind_eq is NULL");
+    MNK_HIP(hipSetDevice(ctx->device));
+    mnk_dc* dc = new mnk_dc();
+    dc->ctx = ctx;
+    dc->condensed = condensed ? 1 : 0;
+    dc->n = n; dc->m = m; dc->ns = ns; dc->n_eq = m - ns;
+    dc->order = condensed ? n + dc->n_eq : n + ns + m;
+    dc->ind_ineq.resize(ns);
+    std::vector<int32_t> slot(std::max<int64_t>(m, 1), -1);
+    for (int64_t k = 0; k < ns; ++k) {
+        dc->ind_ineq[k] = ind_ineq[k] - index_base;
+        MNK_REQUIRE(dc->ind_ineq[k] >= 0 && dc->ind_ineq[k] < m, "mnk_dc_create: ind_ineq out of range");
+        slot[dc->ind_ineq[k]] = (int32_t)k;
+    }
+    dc->ind_eq.resize(dc->n_eq);
+    if (condensed)
+        for (int64_t k = 0; k < dc->n_eq; ++k) {
+            dc->ind_eq[k] = ind_eq[k] - index_base;
+            MNK_REQUIRE(dc->ind_eq[k] >= 0 && dc->ind_eq[k] < m, "mnk_dc_create: ind_eq out of range");
+        }
+    const int64_t ordpad = round_up(dc->order, PAD);
+    dc->npad = round_up(n, 64);
+    dc->kpad = round_up(std::max<int64_t>(ns, 1), 16);
+    dc->ld_jis = dc->npad;
+    hipStream_t s = ctx->stream;
+    mnk_dc_extra* ex = new mnk_dc_extra();
+    int rc = 0;
+    rc |= dc->d_ind_ineq.upload(dc->ind_ineq, s);
+    rc |= dc->d_ind_eq.upload(dc->ind_eq, s);
+    rc |= ex->ineq_slot.upload(slot, s);
+    rc |= dc->hess.alloc((size_t)n * n);
+    rc |= dc->jac.alloc((size_t)std::max<int64_t>(m, 1) * n);
+    rc |= dc->aug.alloc((size_t)ordpad * ordpad + SLACK);
+    rc |= dc->pr_diag.alloc(n + ns);
+    rc |= dc->du_diag.alloc(std::max<int64_t>(m, 1));
+    rc |= dc->diag_buffer.alloc(std::max<int64_t>(ns, 1));
+    if (condensed) rc |= dc->jis.alloc((size_t)dc->ld_jis * dc->kpad + SLACK);
+    if (rc) { delete ex; delete dc; return -2; }
+    MNK_HIP(hipMemsetAsync(dc->hess.p, 0, dc->hess.n * sizeof(double), s));
+    MNK_HIP(hipMemsetAsync(dc->jac.p, 0, dc->jac.n * sizeof(double), s));
+    MNK_HIP(hipMemsetAsync(dc->aug.p, 0, dc->aug.n * sizeof(double), s));
+    g_dcx.emplace_back(dc, ex);
+    *out = dc;
+    return 0;
+}
+
+int mnk_dc_destroy(mnk_dc* dc) {
+    if (!dc) return 0;
+    (void)hipSetDevice(dc->ctx->device);
+    (void)hipStreamSynchronize(dc->ctx->stream);
+    for (size_t i = 0; i < g_dcx.size(); ++i)
+        if (g_dcx[i].first == dc) { delete g_dcx[i].second; g_dcx.erase(g_dcx.begin() + i); break; }
+    delete dc;
+    return 0;
+}
+
+int64_t mnk_dc_order(mnk_dc* dc) { return dc ? dc->order : -1; }
+
+static int copy_in_2d(mnk_ctx* ctx, double* dst, int64_t rows, int64_t cols, const double* src, int64_t ld, int loc) {
+    if (rows == 0 || cols == 0) return 0;
+    MNK_REQUIRE(ld >= rows, "leading dimension smaller than the number of rows");
+    MNK_HIP(hipMemcpy2DAsync(dst, rows * sizeof(double), src, ld * sizeof(double), rows * sizeof(double), cols,
+                             loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int mnk_dc_set_hess(mnk_dc* dc, const double* hess, int64_t ld, int loc) {
+    MNK_REQUIRE(dc && hess, "mnk_dc_set_hess: NULL argument");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    return copy_in_2d(dc->ctx, dc->hess.p, dc->n, dc->n, hess, ld, loc);
+}
+
+int mnk_dc_set_jac(mnk_dc* dc, const double* jac, int64_t ld, int loc) {
+    MNK_REQUIRE(dc && (jac || dc->m == 0), "mnk_dc_set_jac: NULL argument");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    return copy_in_2d(dc->ctx, dc->jac.p, dc->m, dc->n, jac, ld, loc);
+}
+
+int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int loc) {
+    MNK_REQUIRE(dc && pr_diag && (du_diag || dc->m == 0), "mnk_dc_build: NULL argument");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    hipStream_t s = dc->ctx->stream;
+    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    MNK_HIP(hipMemcpyAsync(dc->pr_diag.p, pr_diag, (dc->n + dc->ns) * sizeof(double), kind, s));
+    if (dc->m > 0) MNK_HIP(hipMemcpyAsync(dc->du_diag.p, du_diag, dc->m * sizeof(double), kind, s));
+    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    const int64_t ordpad = round_up(dc->order, PAD);
+    const int64_t ldk = ordpad;
+    dim3 egrid((unsigned)ordpad, (unsigned)((ordpad + 255) / 256));
+    if (!dc->condensed) {
+        mnk_dc_extra* ex = extra_of(dc);
+        MNK_REQUIRE(ex != nullptr, "mnk_dc_build: unknown handle");
+        hipLaunchKernelGGL(dense_aug_kernel, egrid, dim3(256), 0, s, dc->aug.p, ldk, ordpad, dc->hess.p, dc->jac.p,
+                           dc->m, dc->n, dc->ns, dc->d_ind_ineq.p, ex->ineq_slot.p, dc->pr_diag.p, dc->du_diag.p);
+        MNK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (dc->ns > 0) {
+        hipLaunchKernelGGL(dc_diag_buffer_kernel, dim3((unsigned)((dc->ns + 255) / 256)), dim3(256), 0, s,
+                           dc->diag_buffer.p, dc->pr_diag.p + dc->n, dc->du_diag.p, dc->d_ind_ineq.p, dc->ns);
+    }
+    dim3 tgrid((unsigned)(dc->kpad + 31) / 32, (unsigned)(dc->npad + 31) / 32);
+    hipLaunchKernelGGL(scale_transpose_kernel, tgrid, dim3(256), 0, s, dc->jis.p, dc->ld_jis, dc->npad, dc->kpad,
+                       dc->jac.p, dc->m, dc->n, dc->ns, dc->d_ind_ineq.p, dc->diag_buffer.p);
+    hipLaunchKernelGGL(init_condensed_kernel, egrid, dim3(256), 0, s, dc->aug.p, ldk, ordpad, dc->hess.p, dc->jac.p,
+                       dc->m, dc->n, dc->n_eq, dc->d_ind_eq.p, dc->pr_diag.p, dc->du_diag.p);
+    MNK_HIP(hipGetLastError());
+    if (dc->ns > 0) {
+        int rc = launch_gemm_nt(s, 4, dc->npad, dc->npad, dc->kpad, dc->jis.p, dc->ld_jis, dc->jis.p, dc->ld_jis,
+                                dc->aug.p, ldk, nullptr, nullptr, 0, nullptr);
+        if (rc) return rc;
+    }
+    dim3 mgrid((unsigned)((dc->order + 31) / 32), (unsigned)((dc->order + 31) / 32));
+    hipLaunchKernelGGL(mirror_kernel, mgrid, dim3(256), 0, s, dc->aug.p, ldk, dc->order);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_dc_get_aug(mnk_dc* dc, double* out, int loc) {
+    MNK_REQUIRE(dc && out, "mnk_dc_get_aug: NULL argument");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    const int64_t ldk = round_up(dc->order, PAD);
+    MNK_HIP(hipMemcpy2DAsync(out, dc->order * sizeof(double), dc->aug.p, ldk * sizeof(double),
+                             dc->order * sizeof(double), dc->order,
+                             loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, dc->ctx->stream));
+    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(dc->ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+// fp64 MFMA tile kernel:  C (MxN) op= A (MxK) * B (NxK)^T, everything column-major.
+//
+// This is the trailing-update / panel-solve workhorse of the blocked right-looking
+// Cholesky / LDL^T factorization that stands in for LAPACK dpotrf / dsytrf
+// (reference src/LinearSolvers/lapack.jl:145-148,164-167) and of the J_i' D J_i
+// product of build_kkt!(::DenseCondensedKKTSystem) (reference
+// src/KKT/Dense/condensed.jl:178).
+//
+// gfx950 mapping
+//   * v_mfma_f64_16x16x4_f64: one wave owns a 64x64 block of C as 4x4 MFMA tiles
+//     (16 accumulators x 4 f64 = 128 VGPRs); a workgroup is WM x WN waves.
+//   * We compute C^T tiles (MFMA "A" operand = B fragment, "B" operand = A fragment)
+//     so that a lane's 16 lanes-in-a-row hold 16 consecutive rows of one column
+//     of C: the epilogue touches C in 128-byte column segments.
+//   * Both operands are "row index contiguous", so an LDS tile is [BK][rows+16]:
+//     a fragment read (ds_read_b64) has lanes 0-15 on 16 consecutive rows of
+//     k, lanes 16-31 on k+1, ...; the +16 pad makes the row pitch = 16 mod 32
+//     doubles so the two 16-lane halves of a 32-lane LDS group hit disjoint banks.
+//   * Global -> LDS staging goes through registers in 16-byte pieces, double
+//     buffered: the loads of k-tile t+1 are issued before the MFMAs of k-tile t.
+#include "common.h"
+
+namespace mnk {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+
+template <int WM, int WN, int MODE, bool LDL_EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
+    int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
+    const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
+    const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
+    const int* __restrict__ info_flag) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
+    constexpr int APIECES = (BM / 2) * BK / NT;  // 16-byte pieces per thread per k-tile
+    constexpr int BPIECES = (BN / 2) * BK / NT;
+    static_assert(APIECES >= 1 && BPIECES >= 1, "tile too small for the thread count");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* As = reinterpret_cast<double*>(smem_raw);           // [2][BK][LDA_S]
+    double* Bs = As + 2 * BK * LDA_S;                           // [2][BK][LDB_S]
+
+    if (info_flag != nullptr && *info_flag != 0) return;
+
+    // XCD-aware remap: hardware places consecutive workgroup ids round-robin on the
+    // 8 XCDs; give each XCD a contiguous run of logical tiles so that tiles sharing
+    // an A row-block / B column-block share one L2.
+    int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    int per = nblk >> 3;
+    int logical = (per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid;
+    const int tm = logical % ntm;
+    const int tn = logical / ntm;
+    const int64_t row0 = (int64_t)tm * BM;
+    const int64_t col0 = (int64_t)tn * BN;
+    if ((MODE == 2 || MODE == 4) && row0 + BM <= col0) return;  // tile entirely above the diagonal
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    const double* Ag = A + row0;
+    const double* Bg = B + col0;
+
+    v2f64 ra[APIECES], rb[BPIECES];
+
+    auto gload = [&](int kt) {
+        const int64_t k0 = (int64_t)kt * BK;
+#pragma unroll
+        for (int q = 0; q < APIECES; ++q) {
+            int p = tid + NT * q;
+            int k = p / (BM / 2), r = (p % (BM / 2)) * 2;
+            ra[q] = *reinterpret_cast<const v2f64*>(Ag + r + (k0 + k) * lda);
+        }
+#pragma unroll
+        for (int q = 0; q < BPIECES; ++q) {
+            int p = tid + NT * q;
+            int k = p / (BN / 2), r = (p % (BN / 2)) * 2;
+            rb[q] = *reinterpret_cast<const v2f64*>(Bg + r + (k0 + k) * ldb);
+        }
+    };
+    auto sstore = [&](int buf) {
+        double* as = As + buf * BK * LDA_S;
+        double* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+        for (int q = 0; q < APIECES; ++q) {
+            int p = tid + NT * q;
+            int k = p / (BM / 2), r = (p % (BM / 2)) * 2;
+            *reinterpret_cast<v2f64*>(as + k * LDA_S + r) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < BPIECES; ++q) {
+            int p = tid + NT * q;
+            int k = p / (BN / 2), r = (p % (BN / 2)) * 2;
+            *reinterpret_cast<v2f64*>(bs + k * LDB_S + r) = rb[q];
+        }
+    };
+
+    v4f64 acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (int)(K / BK);
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const double* as = As + cur * BK * LDA_S + wm * 64 + l15;
+        const double* bs = Bs + cur * BK * LDB_S + wn * 64 + l15;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = as[(kk * 4 + l4) * LDA_S + i * 16];
+                bf[i] = bs[(kk * 4 + l4) * LDB_S + i * 16];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane (l15, l4), reg r of acc[ni][mi] is C[row0+wm*64+mi*16+l15, col0+wn*64+ni*16+l4+4r]
+    const int64_t wrow = row0 + wm * 64, wcol = col0 + wn * 64;
+    if (wrow >= M || wcol >= N) return;
+    if ((MODE == 2 || MODE == 4) && wrow + 64 <= wcol) return;  // wave tile entirely above the diagonal
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t n = wcol + ni * 16 + l4 + 4 * r;
+            double* cp = C + n * ldc + wrow + l15;
+            if (MODE == 1) {
+                if (LDL_EPI) {
+                    const double sc = colscale[n];
+                    double* c2p = C2 + n * ldc2 + wrow + l15;
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        c2p[mi * 16] = acc[ni][mi][r];
+                        cp[mi * 16] = acc[ni][mi][r] * sc;
+                    }
+                } else {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) cp[mi * 16] = acc[ni][mi][r];
+                }
+            } else {
+                double cv[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) cv[mi] = cp[mi * 16];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) cp[mi * 16] = MODE == 4 ? cv[mi] + acc[ni][mi][r] : cv[mi] - acc[ni][mi][r];
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MODE, bool LDL_EPI>
+static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                    const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
+                    double* C2, int64_t ldc2, const int* info_flag) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
+    const size_t smem = 2 * BK * ((BM + 16) + (BN + 16)) * sizeof(double);
+    auto kern = gemm_nt_kernel<WM, WN, MODE, LDL_EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), smem, s, M, N, K, A, lda, B, ldb, C,
+                       ldc, colscale, C2, ldc2, ntm, info_flag);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                   const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
+                   double* C2, int64_t ldc2, const int* info_flag) {
+    if (M <= 0 || N <= 0) return 0;
+    MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
+    if (mode == 1) {
+        // panel solve shape: N is one or two inner blocks wide; use a tall 256 x 64 tile
+        if (N <= 64) {
+            if (colscale)
+                return launch_t<4, 1, 1, true>(s, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, info_flag);
+            return launch_t<4, 1, 1, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        }
+        if (colscale)
+            return launch_t<2, 2, 1, true>(s, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, info_flag);
+        return launch_t<2, 2, 1, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+    }
+    if (mode == 0) {
+        if (N <= 64) return launch_t<4, 1, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        return launch_t<2, 2, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+    }
+    if (mode == 2) {
+        return launch_t<2, 2, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+    }
+    if (mode == 4) {
+        return launch_t<2, 2, 4, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+    }
+    set_error("gemm_nt: bad mode %d", mode);
+    return -1;
+}
+
+}  // namespace mnk

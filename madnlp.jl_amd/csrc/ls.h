@@ -1,0 +1,54 @@
+// Internal layout of the opaque handles (shared by factor.hip, solve.hip, ls.hip, kkt units).
+#pragma once
+#include <algorithm>
+
+#include "common.h"
+
+struct mnk_sc {
+    mnk_ctx* ctx = nullptr;
+    int64_t n = 0, m = 0, nnzj = 0, nnzh = 0;
+    int64_t nnz_jt = 0, nnz_hess = 0, nnz_aug = 0, len_jptr = 0;
+    // host copies of the derived structures (0-based)
+    std::vector<int32_t> jt_colptr, jt_rowval, h_colptr, h_rowval, aug_colptr, aug_rowval;
+    std::vector<int64_t> jt_map, h_map;
+    std::vector<int32_t> d_dst, d_src, hp_dst, hp_src, j_dst, j_c, j_k, j_l;
+    // device: COO -> CSC segmented transfer (sources grouped by destination slot)
+    mnk::DevBuf<int32_t> jt_seg_ptr, jt_seg_src, h_seg_ptr, h_seg_src;
+    // device: condensation lists grouped by aug_com slot
+    mnk::DevBuf<int32_t> aug_hptr, aug_hsrc;   // per slot: range into hsrc (H.nz indices)
+    mnk::DevBuf<int32_t> aug_dsrc;             // per slot: pr_diag index or -1
+    mnk::DevBuf<int32_t> aug_jptr, aug_jc, aug_jk, aug_jl;
+    mnk::DevBuf<int32_t> aug_row, aug_col;     // coordinates of every aug_com slot (densify)
+    mnk::DevBuf<int32_t> d_jt_colptr, d_jt_rowval, d_jt_colidx, d_h_colptr, d_h_rowval, d_h_colidx;
+    // device values
+    mnk::DevBuf<double> jac_coo, hess_coo, jt_nz, h_nz, aug_nz, diag_buffer, pr_diag, du_diag;
+};
+
+struct mnk_dc {
+    mnk_ctx* ctx = nullptr;
+    int condensed = 1;
+    int64_t n = 0, m = 0, ns = 0, n_eq = 0, order = 0;
+    std::vector<int64_t> ind_ineq, ind_eq;
+    mnk::DevBuf<int64_t> d_ind_ineq, d_ind_eq;
+    mnk::DevBuf<double> hess, jac, aug, pr_diag, du_diag, diag_buffer;
+    mnk::DevBuf<double> jis;  // sqrt(D)-scaled, zero-padded inequality Jacobian^T workspace
+    int64_t ld_jis = 0, kpad = 0, npad = 0;
+};
+
+struct mnk_ls {
+    mnk_ctx* ctx = nullptr;
+    int64_t N = 0, Np = 0, ld = 0, ldw = 0, nbo = 512;
+    int algo = MNK_LDL;
+    double pivot_tol = 0.0;
+    int lookahead = 0;
+    mnk::DevBuf<double> fact, wbuf, linv, dvec, dinv, xwork;
+    mnk::DevBuf<int> info_dev;
+    mnk::DevBuf<unsigned long long> inertia_dev;
+    bool factorized = false, info_valid = false;
+    int info = 0;
+    int64_t npos = 0, nzero = 0, nneg = 0;
+};
+
+int mnk_ls_run_factorization(mnk_ls* ls);
+int mnk_ls_fetch_info(mnk_ls* ls);
+int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);

@@ -1,0 +1,338 @@
+// C-ABI of the linear solver handle (mnk_ls_*): allocation, `transfer_matrix!`
+// (reference src/LinearSolvers/lapack_common.jl:28 and its device twin
+// lib/MadNLPGPU/src/utils.jl:12-23 / kernels_sparse.jl:27-33), factorize / inertia /
+// solve entry points.  See include/madnlp_hip.h for the per-function citations.
+#include <cstdarg>
+
+#include "ls.h"
+
+namespace mnk {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// Zero the (padded) factor buffer and put a unit diagonal on the padding rows.
+// Only column blocks on/below the diagonal tile row are touched: nothing in the
+// factorization or the solves ever reads above the 128-row tile containing the diagonal.
+__global__ __launch_bounds__(256) void fill_lower_kernel(double* __restrict__ F, int64_t ld, int64_t N, int64_t Np) {
+    const int64_t col = blockIdx.x;
+    const int64_t first = (col / PAD) * PAD;  // first row of the diagonal tile of this column
+    const int64_t r = first + ((int64_t)blockIdx.y * 256 + threadIdx.x) * 2;
+    if (r >= Np) return;
+    double2 v = make_double2(0.0, 0.0);
+    if (col >= N) {
+        if (r == col) v.x = 1.0;
+        if (r + 1 == col) v.y = 1.0;
+    }
+    *reinterpret_cast<double2*>(F + r + col * ld) = v;
+}
+
+// aug_com (lower CSC) -> dense: one thread per stored entry (coordinates precomputed).
+__global__ void scatter_csc_kernel(double* __restrict__ F, int64_t ld, const int32_t* __restrict__ row,
+                                   const int32_t* __restrict__ col, const double* __restrict__ nz, int64_t nnz) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k < nnz) F[row[k] + (int64_t)col[k] * ld] = nz[k];
+}
+
+// dense source -> factor buffer, rows >= first row of the diagonal tile of each column.
+__global__ __launch_bounds__(256) void copy_lower_kernel(double* __restrict__ F, int64_t ld,
+                                                         const double* __restrict__ A, int64_t lda, int64_t N,
+                                                         int64_t Np) {
+    const int64_t col = blockIdx.x;
+    const int64_t first = (col / PAD) * PAD;
+    const int64_t r = first + (int64_t)blockIdx.y * 256 + threadIdx.x;
+    if (r >= Np) return;
+    double v = 0.0;
+    if (col < N && r < N) v = A[r + col * lda];
+    else if (r == col) v = 1.0;
+    F[r + col * ld] = v;
+}
+
+__global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t N, int64_t Np) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k < Np) dst[k] = k < N ? src[k] : 0.0;
+}
+
+}  // namespace mnk
+
+using namespace mnk;
+
+extern "C" {
+
+int mnk_version(void) { return MNK_VERSION; }
+const char* mnk_last_error_string(void) { return g_err.c_str(); }
+
+int mnk_ctx_create(int device, void* stream, mnk_ctx** out) {
+    MNK_REQUIRE(out != nullptr, "mnk_ctx_create: out is NULL");
+    int ndev = 0;
+    MNK_HIP(hipGetDeviceCount(&ndev));
+    MNK_REQUIRE(device >= 0 && device < ndev, "mnk_ctx_create: no such device");
+    MNK_HIP(hipSetDevice(device));
+    mnk_ctx* c = new mnk_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        MNK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    MNK_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+    MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+    hipDeviceProp_t prop;
+    MNK_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    *out = c;
+    return 0;
+}
+
+int mnk_ctx_destroy(mnk_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int mnk_ctx_synchronize(mnk_ctx* c) {
+    MNK_REQUIRE(c != nullptr, "ctx is NULL");
+    MNK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void* mnk_ctx_stream(mnk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
+    MNK_REQUIRE(ctx && out, "mnk_ls_create: NULL argument");
+    MNK_REQUIRE(N > 0, "mnk_ls_create: N must be positive");
+    if (algo == MNK_BUNCHKAUFMAN) algo = MNK_LDL;
+    MNK_REQUIRE(algo == MNK_CHOLESKY || algo == MNK_LDL,
+                "mnk_ls_create: only CHOLESKY and LDL (alias BUNCHKAUFMAN) are implemented on device");
+    MNK_HIP(hipSetDevice(ctx->device));
+    mnk_ls* ls = new mnk_ls();
+    ls->ctx = ctx;
+    ls->N = N;
+    ls->algo = algo;
+    ls->Np = round_up(N, PAD);
+    ls->ld = ls->Np;
+    ls->ldw = ls->Np;
+    int rc = 0;
+    rc |= ls->fact.alloc((size_t)ls->ld * ls->Np + SLACK);
+    rc |= ls->linv.alloc((size_t)(ls->Np / NBI) * NBI * NBI);
+    rc |= ls->dvec.alloc(ls->Np);
+    rc |= ls->dinv.alloc(ls->Np);
+    rc |= ls->xwork.alloc(2 * ls->Np);
+    rc |= ls->info_dev.alloc(1);
+    rc |= ls->inertia_dev.alloc(3);
+    if (rc) { delete ls; return -2; }
+    MNK_HIP(hipMemsetAsync(ls->fact.p, 0, ((size_t)ls->ld * ls->Np + SLACK) * sizeof(double), ctx->stream));
+    *out = ls;
+    return 0;
+}
+
+int mnk_ls_destroy(mnk_ls* ls) {
+    if (!ls) return 0;
+    (void)hipSetDevice(ls->ctx->device);
+    (void)hipStreamSynchronize(ls->ctx->stream);
+    delete ls;
+    return 0;
+}
+
+int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
+    MNK_REQUIRE(ls && key, "mnk_ls_set_option: NULL argument");
+    if (!strcmp(key, "pivot_tol")) { ls->pivot_tol = value; return 0; }
+    if (!strcmp(key, "outer_block")) {
+        int64_t v = (int64_t)value;
+        MNK_REQUIRE(v >= NBI && v % NBI == 0, "outer_block must be a positive multiple of 64");
+        ls->nbo = v;
+        ls->wbuf.release();
+        return 0;
+    }
+    if (!strcmp(key, "lookahead")) { ls->lookahead = value != 0.0; return 0; }
+    set_error("mnk_ls_set_option: unknown option '%s'", key);
+    return -1;
+}
+
+static int ensure_wbuf(mnk_ls* ls) {
+    if (ls->algo != MNK_LDL || ls->wbuf.p) return 0;
+    return ls->wbuf.alloc((size_t)ls->ldw * std::min<int64_t>(ls->nbo, ls->Np) + SLACK);
+}
+
+static int prepare_fill(mnk_ls* ls) {
+    hipStream_t s = ls->ctx->stream;
+    dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np / 2 + 255) / 256));
+    hipLaunchKernelGGL(fill_lower_kernel, grid, dim3(256), 0, s, ls->fact.p, ls->ld, ls->N, ls->Np);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
+    MNK_REQUIRE(ls && sc && sc->ctx, "mnk_ls_factorize_sc: NULL argument or host-only handle");
+    MNK_REQUIRE(sc->n == ls->N, "mnk_ls_factorize_sc: order mismatch");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    int rc = ensure_wbuf(ls);
+    if (rc) return rc;
+    rc = prepare_fill(ls);
+    if (rc) return rc;
+    const int64_t nnz = sc->nnz_aug;
+    hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
+                       ls->fact.p, ls->ld, sc->aug_row.p, sc->aug_col.p, sc->aug_nz.p, nnz);
+    MNK_HIP(hipGetLastError());
+    return mnk_ls_run_factorization(ls);
+}
+
+static int factorize_dense_dev(mnk_ls* ls, const double* Adev, int64_t lda) {
+    int rc = ensure_wbuf(ls);
+    if (rc) return rc;
+    dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np + 255) / 256));
+    hipLaunchKernelGGL(copy_lower_kernel, grid, dim3(256), 0, ls->ctx->stream, ls->fact.p, ls->ld, Adev, lda,
+                       ls->N, ls->Np);
+    MNK_HIP(hipGetLastError());
+    return mnk_ls_run_factorization(ls);
+}
+
+int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc) {
+    MNK_REQUIRE(ls && dc, "mnk_ls_factorize_dc: NULL argument");
+    MNK_REQUIRE(dc->order == ls->N, "mnk_ls_factorize_dc: order mismatch");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    return factorize_dense_dev(ls, dc->aug.p, round_up(dc->order, PAD));
+}
+
+static int finish_info(mnk_ls* ls, int* info) {
+    int rc = mnk_ls_fetch_info(ls);
+    if (rc) return rc;
+    if (info) *info = ls->info;
+    return 0;
+}
+
+int mnk_ls_factorize_sc(mnk_ls* ls, mnk_sc* sc, int* info) {
+    int rc = mnk_ls_factorize_sc_async(ls, sc);
+    return rc ? rc : finish_info(ls, info);
+}
+
+int mnk_ls_factorize_dc(mnk_ls* ls, mnk_dc* dc, int* info) {
+    int rc = mnk_ls_factorize_dc_async(ls, dc);
+    return rc ? rc : finish_info(ls, info);
+}
+
+int mnk_ls_factorize_dense(mnk_ls* ls, const double* A, int64_t lda, int loc, int* info) {
+    MNK_REQUIRE(ls && A, "mnk_ls_factorize_dense: NULL argument");
+    MNK_REQUIRE(lda >= ls->N, "mnk_ls_factorize_dense: lda < N");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    int rc;
+    if (loc == MNK_DEVICE) {
+        rc = factorize_dense_dev(ls, A, lda);
+    } else {
+        DevBuf<double> tmp;
+        rc = tmp.alloc((size_t)ls->N * ls->N);
+        if (rc) return rc;
+        MNK_HIP(hipMemcpy2DAsync(tmp.p, ls->N * sizeof(double), A, lda * sizeof(double), ls->N * sizeof(double),
+                                 ls->N, hipMemcpyHostToDevice, ls->ctx->stream));
+        rc = factorize_dense_dev(ls, tmp.p, ls->N);
+        MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+    }
+    return rc ? rc : finish_info(ls, info);
+}
+
+int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowval, const double* nzval,
+                         int index_base, int* info) {
+    MNK_REQUIRE(ls && colptr && rowval && nzval, "mnk_ls_factorize_csc: NULL argument");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    const int64_t N = ls->N;
+    const int64_t nnz = colptr[N] - index_base;
+    std::vector<int32_t> row(nnz), col(nnz);
+    for (int64_t c = 0; c < N; ++c)
+        for (int64_t k = colptr[c] - index_base; k < colptr[c + 1] - index_base; ++k) {
+            row[k] = rowval[k] - index_base;
+            col[k] = (int32_t)c;
+            MNK_REQUIRE(row[k] >= c && row[k] < N, "mnk_ls_factorize_csc: matrix must be lower triangular");
+        }
+    DevBuf<int32_t> drow, dcol;
+    DevBuf<double> dnz;
+    std::vector<double> nzv(nzval, nzval + nnz);
+    int rc = drow.upload(row, ls->ctx->stream);
+    rc |= dcol.upload(col, ls->ctx->stream);
+    rc |= dnz.upload(nzv, ls->ctx->stream);
+    if (rc) return -2;
+    rc = ensure_wbuf(ls);
+    if (rc) return rc;
+    rc = prepare_fill(ls);
+    if (rc) return rc;
+    if (nnz > 0)
+        hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
+                           ls->fact.p, ls->ld, drow.p, dcol.p, dnz.p, nnz);
+    MNK_HIP(hipGetLastError());
+    rc = mnk_ls_run_factorization(ls);
+    if (rc) return rc;
+    MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+    return finish_info(ls, info);
+}
+
+int mnk_ls_inertia(mnk_ls* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg) {
+    MNK_REQUIRE(ls, "mnk_ls_inertia: NULL argument");
+    MNK_REQUIRE(ls->factorized, "mnk_ls_inertia: factorize first");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    int rc = mnk_ls_fetch_info(ls);
+    if (rc) return rc;
+    if (num_pos) *num_pos = ls->npos;
+    if (num_zero) *num_zero = ls->nzero;
+    if (num_neg) *num_neg = ls->nneg;
+    return 0;
+}
+
+int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
+    MNK_REQUIRE(ls && x, "mnk_ls_solve: NULL argument");
+    MNK_REQUIRE(ls->factorized, "mnk_ls_solve: factorize first");
+    MNK_REQUIRE(nrhs >= 1 && ldx >= ls->N, "mnk_ls_solve: bad nrhs/ldx");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    hipStream_t s = ls->ctx->stream;
+    const int64_t N = ls->N, Np = ls->Np;
+    double* w = ls->xwork.p;
+    for (int64_t k = 0; k < nrhs; ++k) {
+        double* xk = x + k * ldx;
+        if (loc == MNK_DEVICE) {
+            hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, s, w, xk, N, Np);
+        } else {
+            MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
+            MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        int rc = mnk_ls_run_solve(ls, w);
+        if (rc) return rc;
+        MNK_HIP(hipMemcpyAsync(xk, w, N * sizeof(double),
+                               loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
+    MNK_REQUIRE(ls && L, "mnk_ls_get_factor: NULL argument");
+    MNK_REQUIRE(ls->factorized, "mnk_ls_get_factor: factorize first");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    hipStream_t s = ls->ctx->stream;
+    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    MNK_HIP(hipMemcpy2DAsync(L, ls->N * sizeof(double), ls->fact.p, ls->ld * sizeof(double),
+                             ls->N * sizeof(double), ls->N, kind, s));
+    if (D) MNK_HIP(hipMemcpyAsync(D, ls->dvec.p, ls->N * sizeof(double), kind, s));
+    MNK_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int mnk_gemm_nt(mnk_ctx* ctx, int mode, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                const double* B, int64_t ldb, double* C, int64_t ldc) {
+    MNK_REQUIRE(ctx && A && B && C, "mnk_gemm_nt: NULL argument");
+    MNK_HIP(hipSetDevice(ctx->device));
+    return launch_gemm_nt(ctx->stream, mode, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,439 @@
+// SparseCondensedKKTSystem on the device (mnk_sc_*).
+//
+// Host side (C++, integer work, once per problem): force_lower_triangular!,
+// coo_to_csc + get_mapping (reference src/matrixtools.jl:55-95,129-137) and
+// build_condensed_aug_symbolic (reference src/KKT/Sparse/condensed.jl:158-301).
+// Device side (per IPM iteration, HBM-bound gather kernels):
+//   compress_*      = transfer! (reference src/matrixtools.jl:79-88; device twin
+//                     lib/MadNLPGPU/src/KKT/kernels_sparse.jl:161-167): segmented COO->CSC sum
+//   build_kkt!      = diag_buffer + _build_condensed_aug_coord! (reference
+//                     src/KKT/Sparse/condensed.jl:328-366; device twins kernels_sparse.jl:127-139)
+// Every sum is accumulated in the reference's order (see DESIGN.md "bit-exact assembly"),
+// and FMA contraction is disabled so results equal the CPU restatement bit for bit.
+#pragma clang fp contract(off)
+
+#include <algorithm>
+#include <numeric>
+
+#include "ls.h"
+
+namespace mnk {
+
+// dst[s] = sum_{k in [ptr[s], ptr[s+1])} src[idx[k]]   (idx ascending inside a segment)
+__global__ void segsum_kernel(double* __restrict__ dst, const double* __restrict__ src,
+                              const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx, int64_t nseg) {
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    double acc = 0.0;
+    for (int32_t k = ptr[s]; k < ptr[s + 1]; ++k) acc += src[idx[k]];
+    dst[s] = acc;
+}
+
+// diag_buffer = Sigma_s ./ (1 - Sigma_d .* Sigma_s)   (reference condensed.jl:364)
+__global__ void diag_buffer_kernel(double* __restrict__ D, const double* __restrict__ pr_s,
+                                   const double* __restrict__ du, int64_t m) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < m) D[i] = pr_s[i] / (1.0 - du[i] * pr_s[i]);
+}
+
+// One thread per aug_com slot: K.nz[s] = ((sum_h H.nz) + pr_diag) + sum_j D[c]*Jt[k]*Jt[l].
+__global__ void condense_kernel(double* __restrict__ K, const double* __restrict__ Hnz,
+                                const double* __restrict__ pr_diag, const double* __restrict__ D,
+                                const double* __restrict__ Jt, const int32_t* __restrict__ hptr,
+                                const int32_t* __restrict__ hsrc, const int32_t* __restrict__ dsrc,
+                                const int32_t* __restrict__ jptr, const int32_t* __restrict__ jc,
+                                const int32_t* __restrict__ jk, const int32_t* __restrict__ jl, int64_t nslot) {
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= nslot) return;
+    double acc = 0.0;
+    for (int32_t k = hptr[s]; k < hptr[s + 1]; ++k) acc += Hnz[hsrc[k]];
+    const int32_t d = dsrc[s];
+    if (d >= 0) acc += pr_diag[d];
+    for (int32_t k = jptr[s]; k < jptr[s + 1]; ++k) acc += (D[jc[k]] * Jt[jk[k]]) * Jt[jl[k]];
+    K[s] = acc;
+}
+
+// y[i] = alpha * sum_k val[perm[k]] * x[idx[k]] + beta * y[i]
+__global__ void gather_spmv_kernel(double* __restrict__ y, const double* __restrict__ x,
+                                   const double* __restrict__ val, const int32_t* __restrict__ ptr,
+                                   const int32_t* __restrict__ idx, const int32_t* __restrict__ perm,
+                                   double alpha, double beta, int64_t nrow) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nrow) return;
+    double acc = 0.0;
+    for (int32_t k = ptr[i]; k < ptr[i + 1]; ++k) acc += val[perm ? perm[k] : k] * x[idx[k]];
+    y[i] = beta == 0.0 ? alpha * acc : alpha * acc + beta * y[i];
+}
+
+// ---- host symbolic ---------------------------------------------------------------------
+struct CscPattern {
+    std::vector<int32_t> colptr, rowval;
+    std::vector<int64_t> map;  // COO entry -> slot
+};
+
+// reference coo_to_csc + get_mapping (src/matrixtools.jl:55-95): structure of sparse(I,J,1).
+static CscPattern coo_to_csc(int64_t nrow, int64_t ncol, const std::vector<int32_t>& I,
+                             const std::vector<int32_t>& J) {
+    const int64_t nnz = (int64_t)I.size();
+    std::vector<int64_t> order(nnz);
+    std::iota(order.begin(), order.end(), 0);
+    auto key = [&](int64_t k) { return (int64_t)J[k] * nrow + I[k]; };
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        const int64_t ka = key(a), kb = key(b);
+        return ka != kb ? ka < kb : a < b;
+    });
+    CscPattern out;
+    out.colptr.assign(ncol + 1, 0);
+    out.map.assign(nnz, 0);
+    int64_t slot = -1, prev = -1;
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int64_t k = order[t], kk = key(k);
+        if (kk != prev) {
+            ++slot;
+            prev = kk;
+            out.rowval.push_back(I[k]);
+            out.colptr[J[k] + 1]++;
+        }
+        out.map[k] = slot;
+    }
+    for (int64_t c = 0; c < ncol; ++c) out.colptr[c + 1] += out.colptr[c];
+    return out;
+}
+
+// group COO sources by destination slot: ptr[nslot+1], src (ascending inside each slot)
+static void group_by_slot(const std::vector<int64_t>& map, int64_t nslot, std::vector<int32_t>& ptr,
+                          std::vector<int32_t>& src) {
+    ptr.assign(nslot + 1, 0);
+    for (int64_t v : map) ptr[v + 1]++;
+    for (int64_t s = 0; s < nslot; ++s) ptr[s + 1] += ptr[s];
+    src.assign(map.size(), 0);
+    std::vector<int32_t> cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t k = 0; k < (int64_t)map.size(); ++k) src[cur[map[k]]++] = (int32_t)k;
+}
+
+static std::vector<int32_t> col_index(const std::vector<int32_t>& colptr) {
+    std::vector<int32_t> ci(colptr.back());
+    for (int64_t c = 0; c + 1 < (int64_t)colptr.size(); ++c)
+        for (int32_t k = colptr[c]; k < colptr[c + 1]; ++k) ci[k] = (int32_t)c;
+    return ci;
+}
+
+}  // namespace mnk
+
+using namespace mnk;
+
+// extra device structures for spmv (kept out of ls.h: only this unit uses them)
+struct mnk_sc_spmv_data {
+    DevBuf<int32_t> jtr_ptr, jtr_idx, jtr_perm;   // CSR of Jt (rows = variables)
+    DevBuf<int32_t> hs_ptr, hs_idx, hs_perm;      // rows of Symmetric(hess_com, :L)
+};
+static std::vector<std::pair<mnk_sc*, mnk_sc_spmv_data*>> g_spmv;  // tiny registry
+static mnk_sc_spmv_data* spmv_of(mnk_sc* sc) {
+    for (auto& p : g_spmv)
+        if (p.first == sc) return p.second;
+    return nullptr;
+}
+
+extern "C" {
+
+int mnk_sc_create(mnk_ctx* ctx, int64_t n, int64_t m, int64_t nnzj, const int32_t* jac_I, const int32_t* jac_J,
+                  int64_t nnzh, const int32_t* hess_I, const int32_t* hess_J, int index_base, mnk_sc** out) {
+    MNK_REQUIRE(out, "mnk_sc_create: NULL argument");
+    MNK_REQUIRE(n > 0 && m >= 0 && nnzj >= 0 && nnzh >= 0, "mnk_sc_create: bad sizes");
+    MNK_REQUIRE(index_base == 0 || index_base == 1, "mnk_sc_create: index_base must be 0 or 1");
+    MNK_REQUIRE((nnzj == 0 || (jac_I && jac_J)) && (nnzh == 0 || (hess_I && hess_J)), "mnk_sc_create: NULL pattern");
+    // ctx == NULL: host-only handle (symbolic analysis only; structure getters work, no device state)
+    if (ctx) MNK_HIP(hipSetDevice(ctx->device));
+    // jt_coo = J': rows = variable (jac_J), cols = constraint (jac_I)   (condensed.jl:104-109)
+    std::vector<int32_t> jtI(nnzj), jtJ(nnzj), hI(nnzh), hJ(nnzh);
+    for (int64_t k = 0; k < nnzj; ++k) {
+        jtI[k] = jac_J[k] - index_base;
+        jtJ[k] = jac_I[k] - index_base;
+        MNK_REQUIRE(jtI[k] >= 0 && jtI[k] < n && jtJ[k] >= 0 && jtJ[k] < m, "mnk_sc_create: Jacobian index out of range");
+    }
+    for (int64_t k = 0; k < nnzh; ++k) {
+        int32_t i = hess_I[k] - index_base, j = hess_J[k] - index_base;
+        MNK_REQUIRE(i >= 0 && i < n && j >= 0 && j < n, "mnk_sc_create: Hessian index out of range");
+        if (j > i) std::swap(i, j);  // force_lower_triangular! (matrixtools.jl:129-137)
+        hI[k] = i;
+        hJ[k] = j;
+    }
+    mnk_sc* sc = new mnk_sc();
+    sc->ctx = ctx;
+    sc->n = n; sc->m = m; sc->nnzj = nnzj; sc->nnzh = nnzh;
+    CscPattern jt = coo_to_csc(n, m, jtI, jtJ);
+    CscPattern hh = coo_to_csc(n, n, hI, hJ);
+    sc->jt_colptr = jt.colptr; sc->jt_rowval = jt.rowval; sc->jt_map = jt.map;
+    sc->h_colptr = hh.colptr; sc->h_rowval = hh.rowval; sc->h_map = hh.map;
+    sc->nnz_jt = (int64_t)jt.rowval.size();
+    sc->nnz_hess = (int64_t)hh.rowval.size();
+
+    // ---- build_condensed_aug_symbolic (condensed.jl:201-301) ----
+    int64_t L = 0;  // _sym_length (condensed.jl:158-165)
+    for (int64_t c = 0; c < m; ++c) {
+        const int64_t k = jt.colptr[c + 1] - jt.colptr[c];
+        L += k * (k + 1) / 2;
+    }
+    const int64_t T = n + sc->nnz_hess + L;
+    MNK_REQUIRE(T < (int64_t)2000000000, "mnk_sc_create: symbolic structure exceeds int32 range");
+    std::vector<int64_t> key(T);
+    std::vector<int8_t> kind(T);          // -1 diag, 0 hess, 1 jt
+    std::vector<int32_t> sa(T), sb(T), scc(T);
+    int64_t t = 0;
+    for (int64_t i = 0; i < n; ++i, ++t) { key[t] = i * n + i; kind[t] = -1; sa[t] = (int32_t)i; sb[t] = 0; scc[t] = 0; }
+    {
+        std::vector<int32_t> hcol = col_index(hh.colptr);
+        for (int64_t k = 0; k < sc->nnz_hess; ++k, ++t) {
+            key[t] = (int64_t)hcol[k] * n + hh.rowval[k]; kind[t] = 0; sa[t] = (int32_t)k; sb[t] = 0; scc[t] = 0;
+        }
+    }
+    for (int64_t c = 0; c < m; ++c)
+        for (int32_t j = jt.colptr[c]; j < jt.colptr[c + 1]; ++j)
+            for (int32_t k = j; k < jt.colptr[c + 1]; ++k, ++t) {
+                const int64_t c1 = jt.rowval[j], c2 = jt.rowval[k];  // c2 >= c1: rows sorted in a column
+                key[t] = c1 * n + c2;  // (row, col) = (c2, c1), sorted by (col, row)
+                kind[t] = 1; sa[t] = (int32_t)c; sb[t] = j; scc[t] = k;
+            }
+    std::vector<int64_t> ord(T);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return key[a] < key[b]; });
+
+    std::vector<int32_t> a_hptr, a_hsrc, a_dsrc, a_jptr, a_jc, a_jk, a_jl, a_row, a_col;
+    sc->aug_colptr.assign(n + 1, 0);
+    int64_t slot = -1, prev = -1;
+    for (int64_t q = 0; q < T; ++q) {
+        const int64_t e = ord[q];
+        if (key[e] != prev) {
+            prev = key[e];
+            ++slot;
+            const int32_t col = (int32_t)(key[e] / n), row = (int32_t)(key[e] % n);
+            a_row.push_back(row); a_col.push_back(col);
+            sc->aug_rowval.push_back(row);
+            sc->aug_colptr[col + 1]++;
+            a_hptr.push_back((int32_t)a_hsrc.size());
+            a_jptr.push_back((int32_t)a_jc.size());
+            a_dsrc.push_back(-1);
+        }
+        if (kind[e] == -1) {
+            a_dsrc[slot] = sa[e];
+            sc->d_dst.push_back((int32_t)slot); sc->d_src.push_back(sa[e]);
+        } else if (kind[e] == 0) {
+            a_hsrc.push_back(sa[e]);
+            sc->hp_dst.push_back((int32_t)slot); sc->hp_src.push_back(sa[e]);
+        } else {
+            a_jc.push_back(sa[e]); a_jk.push_back(sb[e]); a_jl.push_back(scc[e]);
+            sc->j_dst.push_back((int32_t)slot); sc->j_c.push_back(sa[e]); sc->j_k.push_back(sb[e]); sc->j_l.push_back(scc[e]);
+        }
+    }
+    a_hptr.push_back((int32_t)a_hsrc.size());
+    a_jptr.push_back((int32_t)a_jc.size());
+    for (int64_t c = 0; c < n; ++c) sc->aug_colptr[c + 1] += sc->aug_colptr[c];
+    sc->nnz_aug = slot + 1;
+    sc->len_jptr = L;
+
+    if (!ctx) { *out = sc; return 0; }
+    // ---- upload ----
+    hipStream_t s = ctx->stream;
+    std::vector<int32_t> ptr, src;
+    int rc = 0;
+    group_by_slot(jt.map, sc->nnz_jt, ptr, src);
+    rc |= sc->jt_seg_ptr.upload(ptr, s); rc |= sc->jt_seg_src.upload(src, s);
+    group_by_slot(hh.map, sc->nnz_hess, ptr, src);
+    rc |= sc->h_seg_ptr.upload(ptr, s); rc |= sc->h_seg_src.upload(src, s);
+    rc |= sc->aug_hptr.upload(a_hptr, s); rc |= sc->aug_hsrc.upload(a_hsrc, s);
+    rc |= sc->aug_dsrc.upload(a_dsrc, s);
+    rc |= sc->aug_jptr.upload(a_jptr, s); rc |= sc->aug_jc.upload(a_jc, s);
+    rc |= sc->aug_jk.upload(a_jk, s); rc |= sc->aug_jl.upload(a_jl, s);
+    rc |= sc->aug_row.upload(a_row, s); rc |= sc->aug_col.upload(a_col, s);
+    rc |= sc->d_jt_colptr.upload(sc->jt_colptr, s); rc |= sc->d_jt_rowval.upload(sc->jt_rowval, s);
+    rc |= sc->d_h_colptr.upload(sc->h_colptr, s); rc |= sc->d_h_rowval.upload(sc->h_rowval, s);
+    rc |= sc->jac_coo.alloc(nnzj); rc |= sc->hess_coo.alloc(nnzh);
+    rc |= sc->jt_nz.alloc(sc->nnz_jt); rc |= sc->h_nz.alloc(sc->nnz_hess); rc |= sc->aug_nz.alloc(sc->nnz_aug);
+    rc |= sc->diag_buffer.alloc(m); rc |= sc->pr_diag.alloc(n + m); rc |= sc->du_diag.alloc(m);
+
+    // spmv structures: CSR of Jt and the row lists of Symmetric(hess_com, :L)
+    mnk_sc_spmv_data* sp = new mnk_sc_spmv_data();
+    {
+        std::vector<int32_t> rp(n + 1, 0), ri(sc->nnz_jt), rperm(sc->nnz_jt);
+        for (int32_t r : jt.rowval) rp[r + 1]++;
+        for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+        std::vector<int32_t> cur(rp.begin(), rp.end() - 1);
+        for (int64_t c = 0; c < m; ++c)
+            for (int32_t k = jt.colptr[c]; k < jt.colptr[c + 1]; ++k) {
+                const int32_t p = cur[jt.rowval[k]]++;
+                ri[p] = (int32_t)c; rperm[p] = k;
+            }
+        rc |= sp->jtr_ptr.upload(rp, s); rc |= sp->jtr_idx.upload(ri, s); rc |= sp->jtr_perm.upload(rperm, s);
+    }
+    {
+        // row i of Symmetric(H,:L): entries (r, i) of column i (r >= i) with x_r, and entries (i, c), c < i, with x_c
+        std::vector<int32_t> cnt(n + 1, 0);
+        std::vector<int32_t> hcol = col_index(hh.colptr);
+        for (int64_t k = 0; k < sc->nnz_hess; ++k) {
+            cnt[hcol[k] + 1]++;
+            if (hh.rowval[k] != hcol[k]) cnt[hh.rowval[k] + 1]++;
+        }
+        for (int64_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+        std::vector<int32_t> idx(cnt[n]), perm(cnt[n]), cur(cnt.begin(), cnt.end() - 1);
+        // strictly-lower row entries first (ascending column), then the column part: order of
+        // Symmetric(H,:L)*x in ascending index = row part (cols < i), then column part (rows >= i)
+        for (int64_t k = 0; k < sc->nnz_hess; ++k)
+            if (hh.rowval[k] != hcol[k]) { const int32_t p = cur[hh.rowval[k]]++; idx[p] = hcol[k]; perm[p] = (int32_t)k; }
+        for (int64_t k = 0; k < sc->nnz_hess; ++k) { const int32_t p = cur[hcol[k]]++; idx[p] = hh.rowval[k]; perm[p] = (int32_t)k; }
+        rc |= sp->hs_ptr.upload(cnt, s); rc |= sp->hs_idx.upload(idx, s); rc |= sp->hs_perm.upload(perm, s);
+    }
+    if (rc) { delete sp; delete sc; return -2; }
+    MNK_HIP(hipMemsetAsync(sc->jt_nz.p, 0, sc->jt_nz.n * sizeof(double), s));
+    MNK_HIP(hipMemsetAsync(sc->h_nz.p, 0, sc->h_nz.n * sizeof(double), s));
+    MNK_HIP(hipMemsetAsync(sc->aug_nz.p, 0, sc->aug_nz.n * sizeof(double), s));
+    g_spmv.emplace_back(sc, sp);
+    *out = sc;
+    return 0;
+}
+
+int mnk_sc_destroy(mnk_sc* sc) {
+    if (!sc) return 0;
+    if (sc->ctx) {
+        (void)hipSetDevice(sc->ctx->device);
+        (void)hipStreamSynchronize(sc->ctx->stream);
+    }
+    for (size_t i = 0; i < g_spmv.size(); ++i)
+        if (g_spmv[i].first == sc) { delete g_spmv[i].second; g_spmv.erase(g_spmv.begin() + i); break; }
+    delete sc;
+    return 0;
+}
+
+int mnk_sc_sizes(mnk_sc* sc, int64_t* nnz_jt, int64_t* nnz_hess, int64_t* nnz_aug, int64_t* len_jptr) {
+    MNK_REQUIRE(sc, "mnk_sc_sizes: NULL argument");
+    if (nnz_jt) *nnz_jt = sc->nnz_jt;
+    if (nnz_hess) *nnz_hess = sc->nnz_hess;
+    if (nnz_aug) *nnz_aug = sc->nnz_aug;
+    if (len_jptr) *len_jptr = sc->len_jptr;
+    return 0;
+}
+
+int mnk_sc_get_structure(mnk_sc* sc, int which, int32_t* colptr, int32_t* rowval) {
+    MNK_REQUIRE(sc && colptr && rowval, "mnk_sc_get_structure: NULL argument");
+    const std::vector<int32_t>*cp, *rv;
+    if (which == MNK_SC_JT) { cp = &sc->jt_colptr; rv = &sc->jt_rowval; }
+    else if (which == MNK_SC_HESS) { cp = &sc->h_colptr; rv = &sc->h_rowval; }
+    else if (which == MNK_SC_AUG) { cp = &sc->aug_colptr; rv = &sc->aug_rowval; }
+    else { set_error("mnk_sc_get_structure: bad selector %d", which); return -1; }
+    std::copy(cp->begin(), cp->end(), colptr);
+    std::copy(rv->begin(), rv->end(), rowval);
+    return 0;
+}
+
+int mnk_sc_get_map(mnk_sc* sc, int which, int64_t* map) {
+    MNK_REQUIRE(sc && map, "mnk_sc_get_map: NULL argument");
+    const std::vector<int64_t>* mp = which == MNK_SC_JT ? &sc->jt_map : which == MNK_SC_HESS ? &sc->h_map : nullptr;
+    MNK_REQUIRE(mp != nullptr, "mnk_sc_get_map: bad selector");
+    std::copy(mp->begin(), mp->end(), map);
+    return 0;
+}
+
+int mnk_sc_get_ptrs(mnk_sc* sc, int32_t* d_dst, int32_t* d_src, int32_t* h_dst, int32_t* h_src, int32_t* j_dst,
+                    int32_t* j_c, int32_t* j_k, int32_t* j_l) {
+    MNK_REQUIRE(sc, "mnk_sc_get_ptrs: NULL argument");
+    auto cp = [](const std::vector<int32_t>& v, int32_t* o) { if (o) std::copy(v.begin(), v.end(), o); };
+    cp(sc->d_dst, d_dst); cp(sc->d_src, d_src); cp(sc->hp_dst, h_dst); cp(sc->hp_src, h_src);
+    cp(sc->j_dst, j_dst); cp(sc->j_c, j_c); cp(sc->j_k, j_k); cp(sc->j_l, j_l);
+    return 0;
+}
+
+static int stage_in(mnk_ctx* ctx, double* dev, const double* src, int64_t n, int loc, const double** use) {
+    if (loc == MNK_DEVICE) { *use = src; return 0; }
+    if (n > 0) {
+        MNK_HIP(hipMemcpyAsync(dev, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        MNK_HIP(hipStreamSynchronize(ctx->stream));  // caller's buffer is only valid for the duration of the call
+    }
+    *use = dev;
+    return 0;
+}
+
+int mnk_sc_compress_jacobian(mnk_sc* sc, const double* jac_coo, int loc) {
+    MNK_REQUIRE(sc && sc->ctx && (jac_coo || sc->nnzj == 0), "mnk_sc_compress_jacobian: NULL argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    const double* src;
+    int rc = stage_in(sc->ctx, sc->jac_coo.p, jac_coo, sc->nnzj, loc, &src);
+    if (rc) return rc;
+    if (sc->nnz_jt > 0)
+        hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((sc->nnz_jt + 255) / 256)), dim3(256), 0, sc->ctx->stream,
+                           sc->jt_nz.p, src, sc->jt_seg_ptr.p, sc->jt_seg_src.p, sc->nnz_jt);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_sc_compress_hessian(mnk_sc* sc, const double* hess_coo, int loc) {
+    MNK_REQUIRE(sc && sc->ctx && (hess_coo || sc->nnzh == 0), "mnk_sc_compress_hessian: NULL argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    const double* src;
+    int rc = stage_in(sc->ctx, sc->hess_coo.p, hess_coo, sc->nnzh, loc, &src);
+    if (rc) return rc;
+    if (sc->nnz_hess > 0)
+        hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)((sc->nnz_hess + 255) / 256)), dim3(256), 0, sc->ctx->stream,
+                           sc->h_nz.p, src, sc->h_seg_ptr.p, sc->h_seg_src.p, sc->nnz_hess);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_sc_build(mnk_sc* sc, const double* pr_diag, const double* du_diag, int loc) {
+    MNK_REQUIRE(sc && sc->ctx && pr_diag && (du_diag || sc->m == 0), "mnk_sc_build: NULL argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    hipStream_t s = sc->ctx->stream;
+    const double *pr, *du;
+    int rc = stage_in(sc->ctx, sc->pr_diag.p, pr_diag, sc->n + sc->m, loc, &pr);
+    rc |= stage_in(sc->ctx, sc->du_diag.p, du_diag, sc->m, loc, &du);
+    if (rc) return rc;
+    if (sc->m > 0)
+        hipLaunchKernelGGL(diag_buffer_kernel, dim3((unsigned)((sc->m + 255) / 256)), dim3(256), 0, s,
+                           sc->diag_buffer.p, pr + sc->n, du, sc->m);
+    hipLaunchKernelGGL(condense_kernel, dim3((unsigned)((sc->nnz_aug + 255) / 256)), dim3(256), 0, s, sc->aug_nz.p,
+                       sc->h_nz.p, pr, sc->diag_buffer.p, sc->jt_nz.p, sc->aug_hptr.p, sc->aug_hsrc.p,
+                       sc->aug_dsrc.p, sc->aug_jptr.p, sc->aug_jc.p, sc->aug_jk.p, sc->aug_jl.p, sc->nnz_aug);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_sc_get_values(mnk_sc* sc, int which, double* out, int loc) {
+    MNK_REQUIRE(sc && sc->ctx && out, "mnk_sc_get_values: NULL argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    const double* src; int64_t cnt;
+    if (which == MNK_SC_JT) { src = sc->jt_nz.p; cnt = sc->nnz_jt; }
+    else if (which == MNK_SC_HESS) { src = sc->h_nz.p; cnt = sc->nnz_hess; }
+    else if (which == MNK_SC_AUG) { src = sc->aug_nz.p; cnt = sc->nnz_aug; }
+    else if (which == MNK_SC_DIAGBUF) { src = sc->diag_buffer.p; cnt = sc->m; }
+    else { set_error("mnk_sc_get_values: bad selector %d", which); return -1; }
+    if (cnt > 0)
+        MNK_HIP(hipMemcpyAsync(out, src, cnt * sizeof(double),
+                               loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, sc->ctx->stream));
+    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(sc->ctx->stream));
+    return 0;
+}
+
+int mnk_sc_spmv(mnk_sc* sc, int which, int trans, double alpha, const double* x, double beta, double* y) {
+    MNK_REQUIRE(sc && sc->ctx && x && y, "mnk_sc_spmv: NULL argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    MNK_REQUIRE(sp != nullptr, "mnk_sc_spmv: unknown handle");
+    hipStream_t s = sc->ctx->stream;
+    if (which == MNK_SC_JT && trans == 0) {
+        hipLaunchKernelGGL(gather_spmv_kernel, dim3((unsigned)((sc->n + 255) / 256)), dim3(256), 0, s, y, x,
+                           sc->jt_nz.p, sp->jtr_ptr.p, sp->jtr_idx.p, sp->jtr_perm.p, alpha, beta, sc->n);
+    } else if (which == MNK_SC_JT) {
+        if (sc->m > 0)
+            hipLaunchKernelGGL(gather_spmv_kernel, dim3((unsigned)((sc->m + 255) / 256)), dim3(256), 0, s, y, x,
+                               sc->jt_nz.p, sc->d_jt_colptr.p, sc->d_jt_rowval.p, (const int32_t*)nullptr, alpha,
+                               beta, sc->m);
+    } else if (which == MNK_SC_HESS) {
+        hipLaunchKernelGGL(gather_spmv_kernel, dim3((unsigned)((sc->n + 255) / 256)), dim3(256), 0, s, y, x,
+                           sc->h_nz.p, sp->hs_ptr.p, sp->hs_idx.p, sp->hs_perm.p, alpha, beta, sc->n);
+    } else {
+        set_error("mnk_sc_spmv: bad selector %d", which);
+        return -1;
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,234 @@
+"""Synthetic inputs of the KKT hot path (numpy only).
+
+Real PGLib cases / ExaModels are not available offline, so the sparse systems are
+*OPF-shaped*: the variable/constraint counts and sparsity pattern of the polar AC-OPF
+model (va, vm per bus; pg, qg per generator; p, q per arc), random values.  The dense
+system is shaped like the reference's `DenseDummyQP`
+(`lib/MadNLPTests/src/Instances/dummy_qp.jl:79-151`): P = R R' + 100 I, bidiagonal +-1 A.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+OPF_CASES = {
+    # name: (nbus, ngen, nbranch)  -- public PGLib case metadata
+    "case1354pegase": (1354, 260, 1991),
+    "case9241pegase": (9241, 1445, 16049),
+    "case118": (118, 54, 186),
+    "case30": (30, 6, 41),
+}
+
+
+@dataclass
+class SparseKKTProblem:
+    name: str
+    n: int
+    m: int
+    jac_I: np.ndarray
+    jac_J: np.ndarray
+    hess_I: np.ndarray
+    hess_J: np.ndarray
+    jac: np.ndarray
+    hess: np.ndarray
+    ind_ineq: np.ndarray
+    ind_lb: np.ndarray
+    ind_ub: np.ndarray
+    reg: np.ndarray
+    l_diag: np.ndarray
+    u_diag: np.ndarray
+    l_lower: np.ndarray
+    u_lower: np.ndarray
+    du_diag: np.ndarray
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def pr_diag(self):
+        """`_set_aug_diagonal!` (reference src/IPM/kernels.jl:22-27)."""
+        p = self.reg.copy()
+        p[self.ind_lb] -= self.l_lower / self.l_diag
+        p[self.ind_ub] -= self.u_lower / self.u_diag
+        return p
+
+
+def _random_connected_graph(rng, nbus, nbranch, max_deg=12):
+    """Spanning tree + extra edges; degrees capped (power-grid-like sparse graph)."""
+    deg = np.zeros(nbus, dtype=np.int64)
+    fr = np.empty(nbranch, dtype=np.int64)
+    to = np.empty(nbranch, dtype=np.int64)
+    for i in range(1, nbus):
+        # attach to a recent bus (locality) whose degree is still small
+        lo = max(0, i - 50)
+        for _ in range(20):
+            j = int(rng.integers(lo, i))
+            if deg[j] < max_deg - 1:
+                break
+        fr[i - 1], to[i - 1] = j, i
+        deg[i] += 1
+        deg[j] += 1
+    k = nbus - 1
+    seen = set(zip(fr[:k].tolist(), to[:k].tolist()))
+    while k < nbranch:
+        a = int(rng.integers(0, nbus))
+        b = a + int(rng.integers(1, 60))
+        if b >= nbus or deg[a] >= max_deg or deg[b] >= max_deg or (a, b) in seen:
+            if nbranch > 4 * nbus:  # dense request: relax locality
+                b = int(rng.integers(0, nbus))
+                if b == a or (min(a, b), max(a, b)) in seen:
+                    continue
+                a, b = min(a, b), max(a, b)
+            else:
+                continue
+        seen.add((a, b))
+        fr[k], to[k] = a, b
+        deg[a] += 1
+        deg[b] += 1
+        k += 1
+    return fr, to
+
+
+def opf_shaped(case="case1354pegase", seed=None, sigma_s_decades=8.0, du=0.0, indefinite=False):
+    """OPF-shaped sparse condensed KKT inputs (all constraints are inequalities, as under
+    MadNLP's RelaxEquality preset for SparseCondensedKKTSystem, reference
+    src/IPM/options.jl:146-147)."""
+    nbus, ngen, nbr = OPF_CASES[case] if isinstance(case, str) else case
+    name = case if isinstance(case, str) else f"opf{nbus}"
+    if seed is None:
+        seed = nbus
+    rng = np.random.default_rng(seed)
+    fr, to = _random_connected_graph(rng, nbus, nbr)
+    gen_bus = rng.integers(0, nbus, ngen)
+    # variable layout
+    va = np.arange(nbus)
+    vm = nbus + np.arange(nbus)
+    pg = 2 * nbus + np.arange(ngen)
+    qg = 2 * nbus + ngen + np.arange(ngen)
+    narc = 2 * nbr
+    p = 2 * nbus + 2 * ngen + np.arange(narc)
+    q = 2 * nbus + 2 * ngen + narc + np.arange(narc)
+    n = 2 * nbus + 2 * ngen + 2 * narc
+    arc_f = np.concatenate((fr, to))  # arc a: from-bus
+    arc_t = np.concatenate((to, fr))
+
+    rows, cols = [], []
+    r = 0
+    # reference angle
+    rows.append(np.array([r])); cols.append(np.array([va[0]])); r += 1
+    # flow definitions: p and q of every arc (4 rows per branch, 5 nz each)
+    for own in (p, q):
+        rr = r + np.arange(narc)
+        rows.append(np.repeat(rr, 5))
+        cols.append(np.stack((own, vm[arc_f], vm[arc_t], va[arc_f], va[arc_t]), axis=1).ravel())
+        r += narc
+    # angle difference limits
+    rr = r + np.arange(nbr)
+    rows.append(np.repeat(rr, 2)); cols.append(np.stack((va[fr], va[to]), axis=1).ravel()); r += nbr
+    # thermal limits on both arc directions
+    rr = r + np.arange(narc)
+    rows.append(np.repeat(rr, 2)); cols.append(np.stack((p, q), axis=1).ravel()); r += narc
+    # active / reactive balance per bus: vm + incident arcs + generators
+    for own_arc, own_gen in ((p, pg), (q, qg)):
+        rr0 = r
+        rows.append(rr0 + np.arange(nbus)); cols.append(vm)
+        rows.append(rr0 + arc_f); cols.append(own_arc)
+        rows.append(rr0 + gen_bus); cols.append(own_gen)
+        r += nbus
+    m = r
+    jac_I = np.concatenate(rows).astype(np.int32)
+    jac_J = np.concatenate(cols).astype(np.int32)
+    jac = np.clip(rng.standard_normal(len(jac_I)), -100, 100)
+
+    # Hessian of the Lagrangian: per flow row a rank-one PSD clique on (vm_f, vm_t, va_f, va_t)
+    # (COO with duplicates across the 4 rows of a branch, like an AD back-end emits), thermal
+    # p^2/q^2, shunt vm^2 and generation-cost diagonals.
+    hI, hJ, hV = [], [], []
+    il, jl = np.tril_indices(4)
+    for own in (p, q):
+        clique = np.stack((vm[arc_f], vm[arc_t], va[arc_f], va[arc_t]), axis=1)  # narc x 4
+        a = rng.standard_normal((narc, 4))
+        vals = a[:, il] * a[:, jl]
+        hI.append(clique[:, il].ravel()); hJ.append(clique[:, jl].ravel()); hV.append(vals.ravel())
+    hI.append(p); hJ.append(p); hV.append(rng.random(narc) + 0.1)
+    hI.append(q); hJ.append(q); hV.append(rng.random(narc) + 0.1)
+    hI.append(vm); hJ.append(vm); hV.append(rng.random(nbus) + 0.1)
+    hI.append(pg); hJ.append(pg); hV.append(rng.random(ngen) + 0.1)
+    hess_I = np.concatenate(hI).astype(np.int32)
+    hess_J = np.concatenate(hJ).astype(np.int32)
+    hess = np.concatenate(hV)
+    if indefinite:
+        # negative curvature on a few generator / angle variables
+        hess_I = np.concatenate((hess_I, va[: max(1, nbus // 50)].astype(np.int32)))
+        hess_J = np.concatenate((hess_J, va[: max(1, nbus // 50)].astype(np.int32)))
+        hess = np.concatenate((hess, -50.0 * np.ones(max(1, nbus // 50))))
+
+    # IPM-like diagonals: every slack has both bounds, a third of x has a lower bound
+    ind_lb = np.concatenate((np.arange(0, n, 3), n + np.arange(m)))
+    ind_ub = np.concatenate((np.arange(1, n, 3), n + np.arange(m)))
+    nlb, nub = len(ind_lb), len(ind_ub)
+    dec = sigma_s_decades
+    l_diag = -(10.0 ** rng.uniform(-dec / 2, 1, nlb))   # xl - x < 0
+    u_diag = -(10.0 ** rng.uniform(-dec / 2, 1, nub))   # x - xu < 0
+    l_lower = 10.0 ** rng.uniform(-dec / 2, 1, nlb)     # zl > 0
+    u_lower = 10.0 ** rng.uniform(-dec / 2, 1, nub)
+    reg = np.full(n + m, 1e-8)
+    du_diag = np.full(m, -abs(du))
+    return SparseKKTProblem(name, n, m, jac_I, jac_J, hess_I, hess_J, jac, hess, np.arange(m), ind_lb, ind_ub,
+                            reg, l_diag, u_diag, l_lower, u_lower, du_diag,
+                            meta=dict(nbus=nbus, ngen=ngen, nbranch=nbr, seed=seed))
+
+
+@dataclass
+class DenseKKTProblem:
+    name: str
+    n: int
+    m: int
+    hess: np.ndarray
+    jac: np.ndarray
+    ind_ineq: np.ndarray
+    ind_eq: np.ndarray
+    ind_lb: np.ndarray
+    ind_ub: np.ndarray
+    reg: np.ndarray
+    l_diag: np.ndarray
+    u_diag: np.ndarray
+    l_lower: np.ndarray
+    u_lower: np.ndarray
+    du_diag: np.ndarray
+    q: np.ndarray
+
+    @property
+    def pr_diag(self):
+        p = self.reg.copy()
+        p[self.ind_lb] -= self.l_lower / self.l_diag
+        p[self.ind_ub] -= self.u_lower / self.u_diag
+        return p
+
+
+def dense_dummy_qp(n=2048, m=512, n_eq=0, seed=1, du_eq=-1e-8):
+    """DenseDummyQP-shaped system (reference lib/MadNLPTests/src/Instances/dummy_qp.jl:79-151):
+    P = R R' + 100 I (here R is n x n/8 + the 100 I shift keeps P well conditioned and the
+    generator fast), A[i,i] = 1, A[i,i+1] = -1, bounds 0 <= x <= 1, 0 <= A x <= 1; the first
+    `n_eq` constraints are equalities."""
+    rng = np.random.default_rng(seed)
+    R = rng.standard_normal((n, max(1, n // 8)))
+    P = np.asfortranarray(R @ R.T + 100.0 * np.eye(n))
+    A = np.zeros((m, n), order="F")
+    i = np.arange(m)
+    A[i, i] = 1.0
+    A[i, i + 1] = -1.0
+    q = rng.standard_normal(n)
+    ind_eq = np.arange(n_eq)
+    ind_ineq = np.arange(n_eq, m)
+    ns = m - n_eq
+    ind_lb = np.arange(n + ns)
+    ind_ub = np.arange(n + ns)
+    l_diag = -(10.0 ** rng.uniform(-4, 0, n + ns))
+    u_diag = -(10.0 ** rng.uniform(-4, 0, n + ns))
+    l_lower = 10.0 ** rng.uniform(-6, 1, n + ns)
+    u_lower = 10.0 ** rng.uniform(-6, 1, n + ns)
+    reg = np.zeros(n + ns)
+    du_diag = np.zeros(m)
+    du_diag[ind_eq] = du_eq
+    return DenseKKTProblem(f"dense_dummy_qp_{n}_{m}_{n_eq}", n, m, P, A, ind_ineq, ind_eq, ind_lb, ind_ub, reg,
+                           l_diag, u_diag, l_lower, u_lower, du_diag, q)
