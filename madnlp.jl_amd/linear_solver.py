@@ -158,7 +158,7 @@ class HipLinearSolver:
                                           C.byref(info))
         else:
             p, loc = _ptr(A)
-            lda = A.shape[0] if isinstance(A, np.ndarray) else A.stride(1)
+            lda = A.shape[0] if isinstance(A, np.ndarray) else max(A.stride())  # torch: symmetric, either layout
             if isinstance(A, np.ndarray) and not A.flags.f_contiguous:
                 raise FactorizationException("dense matrices must be column-major (order='F')")
             rc = lib.mnk_ls_factorize_dense(self._h, p, lda, loc, C.byref(info))

@@ -1,0 +1,447 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Tolerances (fp64, stated per test):
+  * assembly kernels (compress, condensation, densify)      bit-exact
+  * dense-condensed build (MFMA Gram product)                1e-12 relative to |K|max per entry
+  * factorization                                            backward error |A - L L'| <= 1e-13 |A|
+  * solves                                                   backward error <= 1e-13 (cond-free)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import madnlp_jl_amd as mj  # noqa: E402
+from madnlp_jl_amd import _lib as L  # noqa: E402
+from madnlp_jl_amd.problems import dense_dummy_qp, opf_shaped  # noqa: E402
+from oracle import hs15  # noqa: E402
+from oracle import dense as odense  # noqa: E402
+from oracle import kernels as okern  # noqa: E402
+from oracle import sparse_condensed as osc  # noqa: E402
+from oracle.lapack_cpu import BUNCHKAUFMAN, CHOLESKY, LapackCPUSolver  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    c = mj.HipContext(0)
+    yield c
+    c.close()
+
+
+def solcmp(x, sol, atol=1e-4, rtol=1e-4):
+    aerr = np.linalg.norm(x - sol, np.inf)
+    return aerr < atol or aerr / np.linalg.norm(sol, np.inf) < rtol
+
+
+# --------------------------------------------------------------------------- MFMA tile kernel
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (128, 128, 64), (320, 192, 48), (576, 576, 512), (256, 64, 64)])
+def test_gemm_nt_tiles(ctx, mode, M, N, K):
+    """Asymmetric random operands (a transposed or row/col-swapped MFMA fragment map cannot pass)."""
+    if mode in (2, 4) and M != N:
+        pytest.skip("lower-only modes are for square diagonal-aligned C")
+    rng = np.random.default_rng(M * 7 + N * 3 + K + mode)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K)) + 0.5
+    C0 = rng.standard_normal((M, N))
+    # +256 rows of slack behind every operand, as the library's own buffers have
+    def dev(a):
+        t = torch.zeros(a.size + 256, dtype=torch.float64, device="cuda")
+        t[:a.size] = torch.from_numpy(np.asfortranarray(a).ravel(order="F")).cuda()
+        return t
+    dA, dB, dC = dev(A), dev(B), dev(C0)
+    L.check(mj.lib().mnk_gemm_nt(ctx.handle, mode, M, N, K, dA.data_ptr(), M, dB.data_ptr(), N, dC.data_ptr(), M))
+    ctx.synchronize()
+    got = dC[:M * N].cpu().numpy().reshape((M, N), order="F")
+    P = A @ B.T
+    if mode == 0:
+        ref = C0 - P
+    elif mode == 1:
+        ref = P
+    else:
+        ref = C0 - P if mode == 2 else C0 + P
+        # only 64x64 wave tiles touching the lower triangle are defined
+        bi, bj = np.arange(M)[:, None] // 64, np.arange(N)[None, :] // 64
+        mask = bi >= bj
+        got, ref = np.where(mask, got, 0.0), np.where(mask, ref, 0.0)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * K)
+
+
+# --------------------------------------------------------------------------- linear solver
+@pytest.mark.parametrize("alg", [mj.CHOLESKY, mj.LDL, mj.BUNCHKAUFMAN])
+@pytest.mark.parametrize("as_csc", [False, True])
+def test_linear_solver_known_answer(ctx, alg, as_csc):
+    """reference test/matrix_test.jl:21-30, MadNLPTests.test_linear_solver (:24-51)."""
+    dense = np.array([[1.0, 0.0], [0.1, 2.0]], order="F")  # Array(sparse(row,col,val)): lower stored
+    A = (np.array([0, 2, 3]), np.array([0, 1, 1]), np.array([1.0, 0.1, 2.0])) if as_csc else dense
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
+    assert "HIP" in M.introduce()
+    assert M.improve() is False
+    M.factorize()
+    assert M.is_inertia() and M.inertia() == (2, 0, 0)
+    x = M.solve_linear_system(np.array([1.0, 3.0]))
+    assert solcmp(x, np.array([0.8542713567839195, 1.4572864321608041]))
+    np.testing.assert_allclose(x, [0.8542713567839195, 1.4572864321608041], rtol=1e-14)
+    M.close()
+
+
+def _spd(rng, N, cond_decades=6):
+    Q, _ = np.linalg.qr(rng.standard_normal((N, N)))
+    w = 10.0 ** rng.uniform(-cond_decades / 2, cond_decades / 2, N)
+    A = (Q * w) @ Q.T
+    return np.asfortranarray((A + A.T) / 2)
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 128, 200, 577, 1100])
+def test_cholesky_vs_lapack(ctx, N):
+    rng = np.random.default_rng(N)
+    A = _spd(rng, N)
+    A_upper_garbage = A.copy(order="F")
+    A_upper_garbage[np.triu_indices(N, 1)] = np.nan  # 'L' storage: the upper triangle must never be read
+    M = mj.HipLinearSolver(A_upper_garbage, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY, outer_block=256))
+    M.factorize()
+    assert M.info == 0 and M.inertia() == (N, 0, 0)
+    Lg, _ = M.get_factor()
+    Lg = np.tril(Lg)
+    ref = LapackCPUSolver(A, CHOLESKY).factorize()
+    Lr = np.tril(ref.fact)
+    # backward error of the factorization (tolerance 1e-13 * |A|)
+    assert np.abs(Lg @ Lg.T - A).max() <= 1e-13 * np.abs(A).max() * max(1, N / 64)
+    # and agreement with LAPACK's factor, conditioning-scaled
+    assert np.abs(Lg - Lr).max() <= 1e-9 * np.abs(Lr).max()
+    b = rng.standard_normal(N)
+    x = M.solve_linear_system(b.copy())
+    xr = ref.solve_linear_system(b.copy())
+    res = np.abs(A @ x - b).max() / (np.abs(A).max() * np.abs(x).max() + np.abs(b).max())
+    res_ref = np.abs(A @ xr - b).max() / (np.abs(A).max() * np.abs(xr).max() + np.abs(b).max())
+    assert res <= 1e-13 and res <= 50 * res_ref + 1e-15
+    # multiple right-hand sides (reference loops over columns, linearsolvers.jl:102-110)
+    Bm = np.asfortranarray(rng.standard_normal((N, 3)))
+    X = M.solve_linear_system(Bm.copy(order="F"))
+    assert np.abs(A @ X - Bm).max() / (np.abs(A).max() * np.abs(X).max()) <= 1e-13
+    M.close()
+
+
+def test_cholesky_not_positive_definite_reports_inertia_not_exception(ctx):
+    """reference lapack_common.jl:96-98: failed Cholesky => inertia (0, N, 0), no throw."""
+    rng = np.random.default_rng(3)
+    N = 300
+    A = _spd(rng, N)
+    A[150, 150] = -1.0
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY))
+    M.factorize()
+    assert M.info > 0 and M.info <= 151
+    assert M.inertia() == (0, N, 0)
+    ref = LapackCPUSolver(A, CHOLESKY).factorize()
+    assert ref.info == M.info  # same failing pivot as dpotrf
+    M.close()
+
+
+@pytest.mark.parametrize("N,nneg", [(5, 2), (130, 17), (700, 300)])
+def test_ldl_inertia_vs_bunch_kaufman(ctx, N, nneg):
+    """Quasi-definite matrices [[H, J'],[J, -D]] (the shape of a regularized KKT system):
+    LDL' without pivoting exists and sign(D) is the inertia Bunch-Kaufman reports."""
+    rng = np.random.default_rng(N + nneg)
+    npos = N - nneg
+    H = _spd(rng, npos, 4)
+    J = rng.standard_normal((nneg, npos))
+    A = np.zeros((N, N), order="F")
+    A[:npos, :npos] = H
+    A[npos:, :npos] = J
+    A[:npos, npos:] = J.T
+    A[npos:, npos:] = -np.diag(10.0 ** rng.uniform(-6, 0, nneg))
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN, outer_block=128))
+    M.factorize()
+    ref = LapackCPUSolver(A, BUNCHKAUFMAN).factorize()
+    assert M.inertia() == ref.inertia() == (npos, 0, nneg)
+    Lg, D = M.get_factor()
+    Lg = np.tril(Lg, -1) + np.eye(N)
+    assert np.abs((Lg * D) @ Lg.T - A).max() <= 1e-11 * np.abs(A).max()
+    b = rng.standard_normal(N)
+    x = M.solve_linear_system(b.copy())
+    xr = ref.solve_linear_system(b.copy())
+    res = np.abs(A @ x - b).max() / (np.abs(A).max() * np.abs(x).max() + np.abs(b).max())
+    assert res <= 1e-11
+    assert np.abs(x - xr).max() <= 1e-7 * np.abs(xr).max()
+    M.close()
+
+
+def test_ldl_zero_pivot_is_reported_as_num_zero(ctx):
+    """A singular (2,2) block (du_diag = 0 with dependent equality rows) must surface as
+    num_zero > 0 so that the IPM adds delta_c (reference src/IPM/solver.jl:636-666)."""
+    A = np.zeros((4, 4), order="F")
+    A[:2, :2] = np.eye(2)
+    A[2, 0] = A[0, 2] = 1.0
+    A[3, 0] = A[0, 3] = 1.0  # two identical equality rows -> Schur complement [[-1,-1],[-1,-1]]
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
+    M.factorize()
+    pos, zero, neg = M.inertia()
+    assert zero == 1 and pos == 2 and neg == 1
+    M.close()
+
+
+# --------------------------------------------------------------------------- KKT systems, HS15
+def _make(kind, ctx):
+    if kind == "sparse_condensed":
+        return mj.SparseCondensedKKTSystem(hs15.N, hs15.M, hs15.JAC_I, hs15.JAC_J, hs15.HESS_I, hs15.HESS_J,
+                                           hs15.IND_INEQ, hs15.IND_LB, hs15.IND_UB, ctx=ctx)
+    if kind == "dense_condensed":
+        return mj.DenseCondensedKKTSystem(hs15.N, hs15.M, hs15.IND_INEQ, hs15.IND_EQ, hs15.IND_LB, hs15.IND_UB,
+                                          ctx=ctx)
+    return mj.DenseKKTSystem(hs15.N, hs15.M, hs15.IND_INEQ, hs15.IND_LB, hs15.IND_UB, ctx=ctx)
+
+
+@pytest.mark.parametrize("kind", ["sparse_condensed", "dense_condensed", "dense"])
+def test_kkt_system_hs15(ctx, kind):
+    """reference test/kkt_test.jl:27-48 -> MadNLPTests.test_kkt_system (:53-110), on the HIP path."""
+    kkt = _make(kind, ctx)
+    m, p = kkt.size()
+    assert m == p
+    kkt.initialize()
+    x0, y0 = np.zeros(2), np.zeros(2)
+    if kind == "sparse_condensed":
+        kkt.get_jacobian()[:] = hs15.jac_coord(x0)
+        kkt.get_hessian()[:] = hs15.hess_coord(x0, y0)
+    else:
+        kkt.get_jacobian()[...] = hs15.jac_dense(x0)
+        kkt.get_hessian()[...] = hs15.hess_dense(x0, y0)
+    kkt.compress_jacobian()
+    kkt.compress_hessian()
+    kkt.l_lower[:] = 1e-3
+    kkt.u_lower[:] = 1e-3
+    kkt.set_aug_diagonal()
+    kkt.build_kkt()
+    kkt.linear_solver.factorize()
+    x = mj.UnreducedKKTVector.from_kkt(kkt)
+    x.values[:] = 1.0
+    assert kkt.solve_kkt(x) is x
+    y = x.copy()
+    y.values[:] = 0.0
+    assert kkt.mul(y, x) is y
+    np.testing.assert_allclose(y.values, np.ones(len(x.values)), rtol=0, atol=1e-13)
+    ni, mi, pi = kkt.linear_solver.inertia()
+    assert kkt.is_inertia_correct(ni, mi, pi)
+    gold = json.load(open(os.path.join(GOLDEN, "hs15_kkt.json")))
+    np.testing.assert_allclose(x.values, gold["solve_kkt_ones"], rtol=1e-12, atol=1e-14)
+    if kind == "dense_condensed":
+        np.testing.assert_allclose(kkt.aug_com.to_host(), np.diag(gold["K_condensed_diag"]), rtol=1e-15)
+    if kind == "sparse_condensed":
+        np.testing.assert_allclose(kkt.aug_com.to_dense(), np.diag(gold["K_condensed_diag"]), rtol=1e-15)
+    kkt.regularize_diagonal(1.0, 1.0)
+    kkt.close()
+
+
+# --------------------------------------------------------------------------- sparse condensed
+def _oracle_sc(P, alg=CHOLESKY):
+    k = osc.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb,
+                                     P.ind_ub, lambda A: LapackCPUSolver(A, alg))
+    for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+        getattr(k, f)[:] = getattr(P, f)
+    k.jac[:] = P.jac
+    k.hess[:] = P.hess
+    return k
+
+
+def _hip_sc(P, ctx, alg=mj.CHOLESKY, **opt):
+    k = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub,
+                                    ctx=ctx, opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=alg, **opt))
+    for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+        getattr(k, f)[:] = getattr(P, f)
+    k.jac[:] = P.jac
+    k.hess[:] = P.hess
+    return k
+
+
+@pytest.mark.parametrize("case,du", [("case30", 0.0), ("case118", 1e-8), ("case1354pegase", 1e-8)])
+def test_sparse_condensed_assembly_bit_exact(ctx, case, du):
+    P = opf_shaped(case, du=du)
+    ko, kh = _oracle_sc(P), _hip_sc(P, ctx)
+    for k in (ko, kh):
+        k.compress_jacobian()
+        k.compress_hessian()
+        okern.set_aug_diagonal(k) if k is ko else k.set_aug_diagonal()
+        k.build_kkt()
+    np.testing.assert_array_equal(kh.pr_diag, ko.pr_diag)
+    np.testing.assert_array_equal(kh._values(L.MNK_SC_JT, kh.nnz_jt), ko.jt_csc.nzval)
+    np.testing.assert_array_equal(kh._values(L.MNK_SC_HESS, kh.nnz_hess), ko.hess_com.nzval)
+    np.testing.assert_array_equal(kh.diag_buffer, ko.diag_buffer)
+    np.testing.assert_array_equal(kh.aug_com.nzval, ko.aug_com.nzval)   # bit-exact condensation
+    # device inputs (values already resident in HBM) give the same bits
+    dj = torch.from_numpy(P.jac).cuda()
+    dh = torch.from_numpy(P.hess).cuda()
+    dp = torch.from_numpy(ko.pr_diag).cuda()
+    dd = torch.from_numpy(ko.du_diag).cuda()
+    kh.compress_jacobian(dj); kh.compress_hessian(dh); kh.build_kkt(dp, dd)
+    np.testing.assert_array_equal(kh.aug_com.nzval, ko.aug_com.nzval)
+    kh.close()
+
+
+@pytest.mark.parametrize("case,alg", [("case30", "CHOLESKY"), ("case118", "CHOLESKY"), ("case118", "BUNCHKAUFMAN"),
+                                      ("case1354pegase", "CHOLESKY")])
+def test_sparse_condensed_factorize_solve(ctx, case, alg):
+    P = opf_shaped(case, du=1e-8)
+    ko, kh = _oracle_sc(P, alg), _hip_sc(P, ctx, alg)
+    for k in (ko, kh):
+        k.compress_jacobian(); k.compress_hessian()
+        okern.set_aug_diagonal(k) if k is ko else k.set_aug_diagonal()
+        k.build_kkt()
+        k.linear_solver.factorize()
+    assert kh.linear_solver.inertia() == ko.linear_solver.inertia() == (P.n, 0, 0)
+    assert kh.is_inertia_correct(*kh.linear_solver.inertia())
+    # densified matrix == oracle's (factor of the same bits): compare the solve through residuals
+    Kd = ko.aug_com.to_dense()
+    Kfull = Kd + np.tril(Kd, -1).T
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(P.n)
+    xh = kh.linear_solver.solve_linear_system(b.copy())
+    xo = ko.linear_solver.solve_linear_system(b.copy())
+    nrm = np.abs(Kfull).sum(axis=1).max()
+    rh = np.abs(Kfull @ xh - b).max() / (nrm * np.abs(xh).max() + np.abs(b).max())
+    ro = np.abs(Kfull @ xo - b).max() / (nrm * np.abs(xo).max() + np.abs(b).max())
+    assert rh <= 1e-13, (rh, ro)
+    # full solve_kkt! + mul! identity (MadNLPTests.jl:85-98) on the IPM-like diagonals
+    for k, V in ((ko, okern.UnreducedKKTVector), (kh, mj.UnreducedKKTVector)):
+        x = V.from_kkt(k)
+        x.values[:] = 1.0
+        k.solve_kkt(x)
+        y = x.copy(); y.values[:] = 0.0
+        k.mul(y, x)
+        k._res = np.abs(y.values - 1.0).max() / max(1.0, np.abs(x.values).max())
+        k._x = x.values.copy()
+    assert kh._res <= max(1e-9, 10 * ko._res), (kh._res, ko._res)
+    # Richardson refinement converges to the same acceptable tolerance on both paths
+    from oracle.backsolve import RichardsonIterator as ORich
+    for k, R, V in ((ko, ORich, okern.UnreducedKKTVector), (kh, mj.RichardsonIterator, mj.UnreducedKKTVector)):
+        it = R(k, tol=1e-8)
+        bb = V.from_kkt(k); bb.values[:] = np.random.default_rng(9).standard_normal(len(bb.values))
+        xx, ww = V.from_kkt(k), V.from_kkt(k)
+        k._ok = it.solve_refine(xx, bb, ww)
+        k._rr = it.residual_ratio
+    assert kh._ok == ko._ok
+    assert kh._rr <= max(1e-10, 100 * ko._rr), (kh._rr, ko._rr)
+    kh.close()
+
+
+def test_sparse_condensed_indefinite_hessian_triggers_regularization(ctx):
+    """Negative curvature: both paths must report wrong inertia, then accept after
+    regularize_diagonal! with the same delta_w (reference src/IPM/solver.jl:636-666)."""
+    P = opf_shaped("case118", indefinite=True)
+    ko, kh = _oracle_sc(P, BUNCHKAUFMAN), _hip_sc(P, ctx, mj.BUNCHKAUFMAN)
+    outcomes = []
+    for k in (ko, kh):
+        k.compress_jacobian(); k.compress_hessian()
+        okern.set_aug_diagonal(k) if k is ko else k.set_aug_diagonal()
+        seq = []
+        dw_prev = 0.0
+        for dw in (0.0, 1e-4, 1e-2, 1.0, 1e2):
+            okern.regularize_diagonal(k, dw - dw_prev, 0.0) if k is ko else k.regularize_diagonal(dw - dw_prev, 0.0)
+            dw_prev = dw
+            k.build_kkt()
+            k.linear_solver.factorize()
+            ok = k.is_inertia_correct(*k.linear_solver.inertia())
+            seq.append(ok)
+            if ok:
+                break
+        outcomes.append(seq)
+    assert outcomes[0] == outcomes[1] and outcomes[0][0] is False and outcomes[0][-1] is True
+    kh.close()
+
+
+# --------------------------------------------------------------------------- dense condensed
+def _dense_pair(P, ctx, alg_o, alg_h, condensed=True):
+    fac = lambda A: LapackCPUSolver(A, alg_o)  # noqa: E731
+    opt = mj.HipSolverOptions(lapack_algorithm=alg_h, outer_block=256)
+    if condensed:
+        ko = odense.DenseCondensedKKTSystem(P.n, P.m, P.ind_ineq, P.ind_eq, P.ind_lb, P.ind_ub, fac)
+        kh = mj.DenseCondensedKKTSystem(P.n, P.m, P.ind_ineq, P.ind_eq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                        opt_linear_solver=opt)
+    else:
+        ko = odense.DenseKKTSystem(P.n, P.m, P.ind_ineq, P.ind_lb, P.ind_ub, fac)
+        kh = mj.DenseKKTSystem(P.n, P.m, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx, opt_linear_solver=opt)
+    for k in (ko, kh):
+        for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+            getattr(k, f)[:] = getattr(P, f)
+        k.hess[...] = P.hess
+        k.jac[...] = P.jac
+    return ko, kh
+
+
+@pytest.mark.parametrize("n,m,n_eq", [(10, 5, 0), (50, 10, 0), (20, 15, 2), (300, 100, 0), (333, 77, 13),
+                                      (2048, 512, 0), (2048, 512, 64)])
+def test_dense_condensed_build_and_solve(ctx, n, m, n_eq):
+    """Sizes from reference test/madnlp_dense.jl:8-53 plus BASELINE.json config C2."""
+    P = dense_dummy_qp(n, m, n_eq)
+    ko, kh = _dense_pair(P, ctx, BUNCHKAUFMAN, mj.BUNCHKAUFMAN)
+    for k in (ko, kh):
+        okern.set_aug_diagonal(k) if k is ko else k.set_aug_diagonal()
+        k.compress_hessian(); k.compress_jacobian()
+        k.build_kkt()
+    Ko, Kh = ko.aug_com, kh.aug_com.to_host()
+    # entries are sums of <= m products: 1e-12 relative to the largest entry
+    assert np.abs(Kh - Ko).max() <= 1e-12 * np.abs(Ko).max()
+    assert np.array_equal(Kh, Kh.T)  # both triangles written, exactly mirrored
+    for k in (ko, kh):
+        k.linear_solver.factorize()
+    assert kh.linear_solver.inertia() == ko.linear_solver.inertia() == (n, 0, n_eq)
+    assert kh.is_inertia_correct(*kh.linear_solver.inertia())
+    for k, V in ((ko, okern.UnreducedKKTVector), (kh, mj.UnreducedKKTVector)):
+        x = V.from_kkt(k)
+        x.values[:] = 1.0
+        k.solve_kkt(x)
+        y = x.copy(); y.values[:] = 0.0
+        k.mul(y, x)
+        k._res = np.abs(y.values - 1.0).max() / max(1.0, np.abs(x.values).max())
+    assert kh._res <= max(1e-10, 10 * ko._res), (kh._res, ko._res)
+    kh.close()
+
+
+@pytest.mark.parametrize("n,m", [(10, 5), (50, 10), (120, 40)])
+def test_dense_augmented_build_and_solve(ctx, n, m):
+    P = dense_dummy_qp(n, m, 0)
+    ko, kh = _dense_pair(P, ctx, BUNCHKAUFMAN, mj.BUNCHKAUFMAN, condensed=False)
+    for k in (ko, kh):
+        okern.set_aug_diagonal(k) if k is ko else k.set_aug_diagonal()
+        k.compress_hessian(); k.compress_jacobian()
+        k.build_kkt()
+    np.testing.assert_array_equal(kh.aug_com.to_host(), ko.aug_com)  # pure scatter: bit-exact
+    for k in (ko, kh):
+        k.linear_solver.factorize()
+    assert kh.linear_solver.inertia() == ko.linear_solver.inertia() == (n + m, 0, m)
+    for k, V in ((ko, okern.UnreducedKKTVector), (kh, mj.UnreducedKKTVector)):
+        x = V.from_kkt(k)
+        x.values[:] = 1.0
+        k.solve_kkt(x)
+        y = x.copy(); y.values[:] = 0.0
+        k.mul(y, x)
+        k._res = np.abs(y.values - 1.0).max() / max(1.0, np.abs(x.values).max())
+    assert kh._res <= max(1e-10, 10 * ko._res), (kh._res, ko._res)
+    kh.close()
+
+
+def test_spmv_pieces(ctx):
+    """Device SpMV building blocks of solve_kkt!/mul! (reference src/IPM/factorization.jl:157-160,289-293)."""
+    P = opf_shaped("case118")
+    ko, kh = _oracle_sc(P), _hip_sc(P, ctx)
+    for k in (ko, kh):
+        k.compress_jacobian(); k.compress_hessian()
+    rng = np.random.default_rng(2)
+    xm, xn = rng.standard_normal(P.m), rng.standard_normal(P.n)
+    lib = mj.lib()
+    def run(which, trans, x, ny, alpha=1.0, beta=0.0, y0=None):
+        dx = torch.from_numpy(x).cuda()
+        dy = torch.from_numpy(y0 if y0 is not None else np.zeros(ny)).cuda()
+        L.check(lib.mnk_sc_spmv(kh._h, which, trans, alpha, dx.data_ptr(), beta, dy.data_ptr()))
+        ctx.synchronize()
+        return dy.cpu().numpy()
+    np.testing.assert_allclose(run(L.MNK_SC_JT, 0, xm, P.n), ko.jt_csc.matvec(xm), rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(run(L.MNK_SC_JT, 1, xn, P.m), ko.jt_csc.rmatvec(xn), rtol=1e-13, atol=1e-13)
+    y0 = rng.standard_normal(P.n)
+    np.testing.assert_allclose(run(L.MNK_SC_HESS, 0, xn, P.n, -1.0, 1.0, y0),
+                               y0 - ko.hess_com.symmetric_lower_matvec(xn), rtol=1e-12, atol=1e-12)
+    kh.close()
