@@ -82,9 +82,10 @@ struct mnk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // second stream + events for the factorization's look-ahead
-    hipStream_t side = nullptr;
+    // look-ahead of the factorization: panel stream (high priority), update stream, fork/join events
+    hipStream_t sp = nullptr, su = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    std::vector<hipEvent_t> ev_panel, ev_next;
     int num_cu = 256;
 };
 

@@ -6,13 +6,18 @@
 // lib/MadNLPGPU/ext/MadNLPGPUAMDGPUExt/rocsolver.jl:47-229).
 //
 // Structure (two-level blocking, everything in HBM, column-major, lower):
-//   for each outer panel of NBO columns
-//     for each inner block of NBI=64 columns inside it
-//        diag64_kernel    : factor the 64x64 diagonal block in one workgroup
-//                           (registers + LDS), also emits inv(L_jj)
-//        gemm_nt mode 1   : panel solve  X = A_panel * inv(L_jj)^T  (* D^-1 for LDL)
-//        gemm_nt mode 0/2 : update the remaining columns of the outer panel (K = 64)
-//     gemm_nt mode 2      : trailing update with K = NBO (fp64 MFMA, lower tiles only)
+//   for each outer panel of NBO columns                      [panel stream, high priority]
+//     for each inner block of NBI = 64 columns inside it
+//        panel64_kernel  : every workgroup re-factors the 64x64 diagonal block in
+//                          registers/LDS (redundantly) and carries two 64-row tiles of the
+//                          panel below it through the same eliminations, which IS the
+//                          triangular solve X = A L^-T (D^-1): no separate TRSM launch,
+//                          no inverse on the critical path.
+//        gemm_nt mode 2  : update the remaining columns of the outer panel (K = 64)
+//   trailing update with K = NBO on the fp64 MFMA tile kernel  [update stream]
+//        (a) the columns of the next outer panel first, then (b) the rest, so that the
+//        next panel is factored (look-ahead) while (b) keeps the matrix cores busy.
+//   linv64_kernel (batched, once): inv(L_jj) of every diagonal block for the solves.
 // A device-side `info` word makes every later kernel a no-op once a pivot fails
 // (LAPACK stops at the failing column; we cannot stop the host without a sync).
 #include <cfloat>
@@ -22,107 +27,173 @@
 
 namespace mnk {
 
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    // v_rsq_f64 seed + two Newton steps: ~1 ulp, no division / software sqrt on the pivot chain
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------
-// 64x64 diagonal block: thread (row i = tid & 63, wave w = tid >> 6) owns row i of the
-// columns c = 4*cl + w.  One barrier per pivot: the pivot column is published through a
-// double-buffered LDS vector, every thread rescales it by the pivot itself.
+// Fused diagonal-block factorization + panel solve.
+// Thread (row i = tid & 63, wave w = tid >> 6) owns row i of the columns c = 4*cl + w of
+// T row tiles: tile 0 is the 64x64 diagonal block (every workgroup holds a private copy),
+// tiles 1..T-1 are 64-row tiles of the panel below it.  One barrier per pivot: the pivot
+// column of every tile is published through a double-buffered LDS vector and every thread
+// rescales it by the pivot itself.
 // ---------------------------------------------------------------------------------------
-template <bool LDL>
-__global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ Ablk, int64_t ld,
-                                                      double* __restrict__ Linv, double* __restrict__ dvec,
-                                                      double* __restrict__ dinv, int* __restrict__ info,
-                                                      int gj, double pivot_tol) {
-    __shared__ double colbuf[2][64];
-    __shared__ double Lt[64 * 64];  // Lt[k*64 + i] = L[i][k]; later reused to transpose inv(L)
-    __shared__ double rd[64];
+template <bool LDL, int T>
+__global__ __launch_bounds__(256) void panel64_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
+                                                       double* __restrict__ W, int64_t ldw, int64_t wcol,
+                                                       double* __restrict__ dvec, double* __restrict__ dinv,
+                                                       int* __restrict__ info, double pivot_tol) {
+    __shared__ double colbuf[2][T][64];
     if (*info != 0) return;
 
     const int tid = threadIdx.x;
     const int i = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool lead = blockIdx.x == 0;
 
-    double a[16];
+    // row tiles of this workgroup; a tile past the end aliases the diagonal tile (loaded,
+    // carried along, never stored) so that the elimination loop is branch-free.
+    int64_t trow[T];
+    bool valid[T];
+    trow[0] = j0;
+    valid[0] = true;
 #pragma unroll
-    for (int cl = 0; cl < 16; ++cl) a[cl] = Ablk[i + (int64_t)(4 * cl + w) * ld];
+    for (int q = 1; q < T; ++q) {
+        const int64_t r = j0 + 64 * ((int64_t)blockIdx.x * (T - 1) + q);
+        valid[q] = r < Np;
+        trow[q] = valid[q] ? r : j0;
+    }
 
-    bool failed = false;
+    double a[T][16];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        const int wo = j & 3, clj = j >> 2;
-        if (w == wo) colbuf[j & 1][i] = a[clj];
-        __syncthreads();
-        const double piv = colbuf[j & 1][j];
-        double scale, ldiag;
-        if (LDL) {
-            double p = piv;
-            const bool zero = !(fabs(p) > pivot_tol) || !(fabs(p) <= DBL_MAX);
-            if (zero) p = 1.0;  // keep going with a harmless pivot; dvec records the zero
-            scale = 1.0 / p;
-            ldiag = zero ? 0.0 : p;  // value recorded in dvec
-        } else {
-            // not positive definite (also catches NaN/Inf): record the first failing pivot and
-            // let the remaining (fully unrolled) steps run on harmless values.
-            const bool bad = !(piv > 0.0) || !(piv <= DBL_MAX);
-            if (bad && !failed) {
-                failed = true;
-                if (tid == 0) atomicCAS(info, 0, gj + j + 1);
-            }
-            ldiag = bad ? 1.0 : sqrt(piv);
-            scale = 1.0 / ldiag;
-        }
-        // my_l = L[i][j] (for LDL: w_ij / d_j)
-        const double my_w = colbuf[j & 1][i];
-        const double my_l = my_w * scale;
+    for (int q = 0; q < T; ++q)
 #pragma unroll
-        for (int cl = 0; cl < 16; ++cl) {
-            const int c = 4 * cl + w;
-            if (c > j) {
-                const double wc = colbuf[j & 1][c];
-                // Cholesky: a_ic -= l_ij * l_cj ; LDL: a_ic -= l_ij * w_cj
-                a[cl] -= my_l * (LDL ? wc : wc * scale);
+        for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
+
+    // Columns are processed in 16 groups of 4 (one column per wave); the register array is
+    // rotated after every group so that the live column group always sits at index 0 (static
+    // register indices with a rolled loop: the fully unrolled 64-step body spills badly).
+    // Slots that have rotated past column 63 hold dead values and are never stored.
+#pragma unroll 1
+    for (int g = 0; g < 16; ++g) {
+#pragma unroll
+        for (int wo = 0; wo < 4; ++wo) {
+            const int j = 4 * g + wo;
+            const bool owner = w == wo;
+            if (owner) {
+#pragma unroll
+                for (int q = 0; q < T; ++q) colbuf[wo & 1][q][i] = a[q][0];
+            }
+            __syncthreads();
+            const double (*cb)[64] = colbuf[wo & 1];
+            const double piv = cb[0][j];
+            double scale, dval;
+            if (LDL) {
+                const bool zero = !(fabs(piv) > pivot_tol) || !(fabs(piv) <= DBL_MAX);
+                const double p = zero ? 1.0 : piv;  // harmless pivot; dvec records the zero
+                scale = fast_rcp(p);
+                dval = zero ? 0.0 : piv;
+            } else {
+                // not positive definite (also catches NaN/Inf): flag the first failing pivot; the
+                // remaining steps run on harmless values and every later kernel is a no-op.
+                const bool bad = !(piv > 0.0) || !(piv <= DBL_MAX);
+                if (bad && lead && tid == 0) atomicCAS(info, 0, (int)(j0 + j + 1));
+                const double rs = fast_rsqrt(bad ? 1.0 : piv);
+                scale = rs;
+                dval = bad ? 1.0 : piv * rs;  // L[j][j]
+            }
+            // second factor of the rank-one update, shared by all tiles: L[c][j] (Cholesky) or
+            // W[c][j] (LDL) for the live columns c = 4*(g+cl)+w > j of this wave.
+            double wc[16];
+#pragma unroll
+            for (int cl = 0; cl < 16; ++cl) {
+                const int c = (4 * (g + cl) + w) & 63;
+                const double v = cb[0][c];
+                const double sv = LDL ? v : v * scale;
+                wc[cl] = (cl > 0 || w > wo) ? sv : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < T; ++q) {
+                const double my_w = cb[q][i];
+                // rows at/above the pivot of the diagonal tile take no part (their entries of column
+                // j are upper-triangle values that may be anything, including NaN)
+                const double my_l = (q == 0 && i <= j) ? 0.0 : my_w * scale;  // L[row][j]
+#pragma unroll
+                for (int cl = 0; cl < 16; ++cl) a[q][cl] = fma(-my_l, wc[cl], a[q][cl]);
+                const double fin = (q == 0 && i == j) ? (LDL ? 1.0 : dval) : my_l;
+                a[q][0] = (owner && (q > 0 || i >= j)) ? fin : a[q][0];
+                if (LDL && q > 0) {
+                    if (owner && valid[q]) W[trow[q] + i + (wcol + j) * ldw] = my_w;
+                }
+            }
+            if (lead && owner && i == j) {
+                dvec[j0 + j] = dval;
+                dinv[j0 + j] = LDL ? scale : 1.0;
+                F[j0 + j + (j0 + j) * ld] = dval;  // L[j][j], or d_j for LDL (as LAPACK stores it)
             }
         }
-        if (w == wo) {
-            a[clj] = (i == j) ? (LDL ? 1.0 : ldiag) : my_l;
-            if (i == j) {
-                dvec[j] = ldiag;
-                dinv[j] = LDL ? scale : 1.0;
-                rd[j] = LDL ? 1.0 : scale;
-            }
+        // column group g is final: store it (diagonal tile: strictly lower part, by the leader), rotate
+        const int c = 4 * g + w;
+        if (lead && i > c) F[j0 + i + (j0 + c) * ld] = a[0][0];
+#pragma unroll
+        for (int q = 1; q < T; ++q)
+            if (valid[q]) F[trow[q] + i + (j0 + c) * ld] = a[q][0];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+#pragma unroll
+            for (int cl = 0; cl < 15; ++cl) a[q][cl] = a[q][cl + 1];
+            a[q][15] = 0.0;
         }
     }
-    if (failed) return;
+}
 
-    // write L back (lower part only; LDL keeps d on the diagonal like LAPACK) and stage L^T in LDS
-#pragma unroll
-    for (int cl = 0; cl < 16; ++cl) {
-        const int c = 4 * cl + w;
-        if (i > c) Ablk[i + (int64_t)c * ld] = a[cl];
-        if (i == c) Ablk[i + (int64_t)c * ld] = LDL ? dvec[c] : a[cl];
-        Lt[c * 64 + i] = (i >= c) ? a[cl] : 0.0;
+// inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
+// One workgroup (one wave) per block: lane c solves L x = e_c by column-oriented substitution.
+template <bool LDL>
+__global__ __launch_bounds__(64) void linv64_kernel(const double* __restrict__ F, int64_t ld,
+                                                     double* __restrict__ Linv, const int* __restrict__ info) {
+    __shared__ double Lt[64 * 64];  // Lt[k*64 + r] = L[r][k]
+    __shared__ double rd[64];
+    if (*info != 0) return;
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    const int lane = threadIdx.x;
+    const double* A = F + j0 + j0 * ld;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) {
+        const double v = A[lane + (int64_t)c * ld];
+        Lt[c * 64 + lane] = lane > c ? v : (lane == c ? (LDL ? 1.0 : v) : 0.0);
+        if (lane == c) rd[c] = LDL ? 1.0 : 1.0 / v;
     }
     __syncthreads();
-
-    // inv(L): wave 0, lane c solves L x = e_c by column-oriented forward substitution.
-    if (w == 0) {
-        double s[64];
+    double s[64];
 #pragma unroll
-        for (int r = 0; r < 64; ++r) s[r] = (r == i) ? 1.0 : 0.0;
+    for (int r = 0; r < 64; ++r) s[r] = (r == lane) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            const double x = s[k] * rd[k];
-            s[k] = x;
+    for (int k = 0; k < 64; ++k) {
+        const double x = s[k] * rd[k];
+        s[k] = x;
 #pragma unroll
-            for (int r = k + 1; r < 64; ++r) s[r] -= Lt[k * 64 + r] * x;
-        }
-        // same wave: all reads of Lt above are issued before these writes (LDS is in-order per wave)
-#pragma unroll
-        for (int r = 0; r < 64; ++r) Lt[i * 64 + r] = s[r];  // Lt[c*64 + r] = inv(L)[r][c]
+        for (int r = k + 1; r < 64; ++r) s[r] -= Lt[k * 64 + r] * x;
     }
     __syncthreads();
-    // Linv is stored column-major 64x64: Linv[r + 64*c] = inv(L)[r][c]  (= Lt layout) -> coalesced copy
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Linv[tid + 256 * q] = Lt[tid + 256 * q];
+    for (int r = 0; r < 64; ++r) Lt[lane * 64 + r] = s[r];  // Lt[c*64 + r] = inv(L)[r][c]
+    __syncthreads();
+    double* out = Linv + (int64_t)blockIdx.x * 4096;  // column-major 64x64: out[r + 64 c]
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) out[lane + 64 * q] = Lt[lane + 64 * q];
 }
 
 // Count signs of D over the first N pivots: out[0]=pos, out[1]=zero, out[2]=neg.
@@ -150,55 +221,124 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 
 using namespace mnk;
 
+constexpr int PANEL_T = 3;  // diagonal tile + 2 panel tiles (128 rows) per workgroup
+
+// factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
+static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase) {
+    const int64_t Np = ls->Np, ld = ls->ld;
+    const bool ldl = ls->algo == MNK_LDL;
+    double* F = ls->fact.p;
+    for (int64_t j = ko; j < kend; j += NBI) {
+        const int64_t r0 = j + NBI;
+        const int64_t Mr = Np - r0;
+        const int64_t ntile = Mr / 64;
+        const int grid = (int)std::max<int64_t>(1, (ntile + PANEL_T - 2) / (PANEL_T - 1));
+        if (ldl)
+            hipLaunchKernelGGL((panel64_kernel<true, PANEL_T>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, wbase,
+                               ls->ldw, j - ko, ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+        else
+            hipLaunchKernelGGL((panel64_kernel<false, PANEL_T>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,
+                               (double*)nullptr, (int64_t)0, (int64_t)0, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
+                               ls->pivot_tol);
+        const int64_t Nc = kend - r0;  // remaining columns of the outer panel
+        if (Mr > 0 && Nc > 0) {
+            const double* Wp = ldl ? wbase + r0 + (j - ko) * ls->ldw : F + r0 + j * ld;
+            int rc = launch_gemm_nt(s, 2, Mr, Nc, NBI, Wp, ldl ? ls->ldw : ld, F + r0 + j * ld, ld,
+                                    F + r0 + r0 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+            if (rc) return rc;
+        }
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
-// factorization driver (host orchestration; every launch is asynchronous on ls->ctx->stream)
+// factorization driver (host orchestration; asynchronous)
 // ---------------------------------------------------------------------------------------
 int mnk_ls_run_factorization(mnk_ls* ls) {
-    hipStream_t s = ls->ctx->stream;
+    mnk_ctx* ctx = ls->ctx;
+    hipStream_t s = ctx->stream;
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
     const int64_t NBO = ls->nbo;
     MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));
+    const int64_t npanel = (Np + NBO - 1) / NBO;
+    const bool la = ls->lookahead && npanel > 1;
 
-    for (int64_t ko = 0; ko < Np; ko += NBO) {
-        const int64_t nbo = std::min<int64_t>(NBO, Np - ko);
-        const int64_t kend = ko + nbo;
-        for (int64_t j = ko; j < kend; j += NBI) {
-            double* Ajj = F + j + j * ld;
-            double* Linv = ls->linv.p + (j / NBI) * (NBI * NBI);
-            if (ldl)
-                hipLaunchKernelGGL(diag64_kernel<true>, dim3(1), dim3(256), 0, s, Ajj, ld, Linv,
-                                   ls->dvec.p + j, ls->dinv.p + j, ls->info_dev.p, (int)j, ls->pivot_tol);
-            else
-                hipLaunchKernelGGL(diag64_kernel<false>, dim3(1), dim3(256), 0, s, Ajj, ld, Linv,
-                                   ls->dvec.p + j, ls->dinv.p + j, ls->info_dev.p, (int)j, ls->pivot_tol);
-            const int64_t r0 = j + NBI;
-            const int64_t Mr = Np - r0;
-            if (Mr <= 0) continue;
-            double* Apanel = F + r0 + j * ld;  // Mr x 64
-            // W (= L*D for LDL) lives in the workspace, at the same row and at column (j - ko)
-            double* Wpanel = ldl ? ls->wbuf.p + r0 + (j - ko) * ls->ldw : Apanel;
-            int rc = launch_gemm_nt(s, 1, Mr, NBI, NBI, Apanel, ld, Linv, NBI, Apanel, ld,
-                                    ldl ? ls->dinv.p + j : nullptr, ldl ? Wpanel : nullptr, ls->ldw,
-                                    ls->info_dev.p);
+    if (!la) {
+        for (int64_t ko = 0; ko < Np; ko += NBO) {
+            const int64_t kend = std::min<int64_t>(ko + NBO, Np);
+            int rc = factor_outer_panel(ls, s, ko, kend, ls->wbuf[0].p);
             if (rc) return rc;
-            // LDL epilogue indexes colscale by the tile-local column: pass dinv + j (done above).
-            const int64_t Nc = kend - r0;  // remaining columns of the outer panel
-            if (Nc > 0) {
-                rc = launch_gemm_nt(s, 2, Mr, Nc, NBI, Wpanel, ldl ? ls->ldw : ld, Apanel, ld,
-                                    F + r0 + r0 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+            const int64_t Mt = Np - kend;
+            if (Mt > 0) {
+                const double* Wsrc = ldl ? ls->wbuf[0].p + kend : F + kend + ko * ld;
+                rc = launch_gemm_nt(s, 2, Mt, Mt, kend - ko, Wsrc, ldl ? ls->ldw : ld, F + kend + ko * ld, ld,
+                                    F + kend + kend * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
                 if (rc) return rc;
             }
         }
-        const int64_t Mt = Np - kend;
-        if (Mt > 0) {
-            const double* Wsrc = ldl ? ls->wbuf.p + kend : F + kend + ko * ld;
-            int rc = launch_gemm_nt(s, 2, Mt, Mt, nbo, Wsrc, ldl ? ls->ldw : ld, F + kend + ko * ld, ld,
-                                    F + kend + kend * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
-            if (rc) return rc;
+    } else {
+        // look-ahead: panel stream sp (high priority) factors panel k+1 while the update
+        // stream su applies panel k to the rest of the trailing matrix.
+        hipStream_t sp = ctx->sp, su = ctx->su;
+        if ((int64_t)ctx->ev_panel.size() < npanel + 1) {
+            const size_t old = ctx->ev_panel.size();
+            ctx->ev_panel.resize(npanel + 1);
+            ctx->ev_next.resize(npanel + 1);
+            for (size_t e = old; e < ctx->ev_panel.size(); ++e) {
+                MNK_HIP(hipEventCreateWithFlags(&ctx->ev_panel[e], hipEventDisableTiming));
+                MNK_HIP(hipEventCreateWithFlags(&ctx->ev_next[e], hipEventDisableTiming));
+            }
         }
+        MNK_HIP(hipEventRecord(ctx->ev_a, s));
+        MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
+        MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
+        int rc = factor_outer_panel(ls, sp, 0, std::min<int64_t>(NBO, Np), ls->wbuf[0].p);
+        if (rc) return rc;
+        MNK_HIP(hipEventRecord(ctx->ev_panel[0], sp));
+        for (int64_t k = 0; k < npanel; ++k) {
+            const int64_t ko = k * NBO, kend = std::min<int64_t>(ko + NBO, Np);
+            const int64_t Mt = Np - kend;
+            if (Mt <= 0) break;
+            const int64_t nnext = std::min<int64_t>(NBO, Mt);
+            double* wk = ls->wbuf[k & 1].p;
+            const double* Wsrc = ldl ? wk + kend : F + kend + ko * ld;
+            const int64_t ldws = ldl ? ls->ldw : ld;
+            MNK_HIP(hipStreamWaitEvent(su, ctx->ev_panel[k], 0));
+            // (a) columns of the next outer panel
+            rc = launch_gemm_nt(su, 2, Mt, nnext, kend - ko, Wsrc, ldws, F + kend + ko * ld, ld,
+                                F + kend + kend * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+            if (rc) return rc;
+            MNK_HIP(hipEventRecord(ctx->ev_next[k], su));
+            // (b) the rest of the trailing matrix
+            const int64_t Mb = Mt - nnext;
+            if (Mb > 0) {
+                rc = launch_gemm_nt(su, 2, Mb, Mb, kend - ko, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
+                                    F + (kend + nnext) + (kend + nnext) * ld, ld, nullptr, nullptr, 0,
+                                    ls->info_dev.p);
+                if (rc) return rc;
+            }
+            // panel k+1 on the panel stream, as soon as (a) is done
+            MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_next[k], 0));
+            rc = factor_outer_panel(ls, sp, kend, kend + nnext, ls->wbuf[(k + 1) & 1].p);
+            if (rc) return rc;
+            MNK_HIP(hipEventRecord(ctx->ev_panel[k + 1], sp));
+        }
+        MNK_HIP(hipEventRecord(ctx->ev_a, sp));
+        MNK_HIP(hipEventRecord(ctx->ev_b, su));
+        MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
+        MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
     }
+    // inverses of the diagonal blocks for the solves (batched, off the critical path of the panels)
+    if (ldl)
+        hipLaunchKernelGGL(linv64_kernel<true>, dim3((unsigned)(Np / NBI)), dim3(64), 0, s, F, ld, ls->linv.p,
+                           ls->info_dev.p);
+    else
+        hipLaunchKernelGGL(linv64_kernel<false>, dim3((unsigned)(Np / NBI)), dim3(64), 0, s, F, ld, ls->linv.p,
+                           ls->info_dev.p);
+    MNK_HIP(hipGetLastError());
     ls->factorized = true;
     ls->info_valid = false;
     return 0;

@@ -53,11 +53,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     int bid = blockIdx.x;
     int per = nblk >> 3;
     int logical = (per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid;
-    const int tm = logical % ntm;
-    const int tn = logical / ntm;
+    int tm, tn;
+    if (MODE == 2 || MODE == 4) {
+        // Only tiles on/below the diagonal are launched (tile column tn holds rows tn..ntm-1),
+        // enumerated column by column so every XCD gets the same number of tiles:
+        // first(tn) = tn*ntm - tn*(tn-1)/2.
+        const double bq = 2.0 * ntm + 1.0;
+        int c = (int)((bq - sqrt(bq * bq - 8.0 * (double)logical)) * 0.5);
+        if (c < 0) c = 0;
+        while (c > 0 && c * ntm - c * (c - 1) / 2 > logical) --c;
+        while ((c + 1) * ntm - (c + 1) * c / 2 <= logical) ++c;
+        tn = c;
+        tm = tn + (logical - (c * ntm - c * (c - 1) / 2));
+    } else {
+        tm = logical % ntm;
+        tn = logical / ntm;
+    }
     const int64_t row0 = (int64_t)tm * BM;
     const int64_t col0 = (int64_t)tn * BN;
-    if ((MODE == 2 || MODE == 4) && row0 + BM <= col0) return;  // tile entirely above the diagonal
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -176,6 +189,12 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
                     double* C2, int64_t ldc2, const int* info_flag) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
+    int ntiles = ntm * ntn;
+    if (MODE == 2 || MODE == 4) {
+        static_assert(MODE == 0 || MODE == 1 || WM == WN, "lower-only modes need square tiles");
+        const int nc = ntn < ntm ? ntn : ntm;  // tile columns that contain a lower tile
+        ntiles = nc * ntm - nc * (nc - 1) / 2;
+    }
     const size_t smem = 2 * BK * ((BM + 16) + (BN + 16)) * sizeof(double);
     auto kern = gemm_nt_kernel<WM, WN, MODE, LDL_EPI>;
     static bool attr_set = false;
@@ -183,7 +202,7 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
         MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(64 * WM * WN), smem, s, M, N, K, A, lda, B, ldb, C,
+    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, s, M, N, K, A, lda, B, ldb, C,
                        ldc, colscale, C2, ldc2, ntm, info_flag);
     MNK_HIP(hipGetLastError());
     return 0;

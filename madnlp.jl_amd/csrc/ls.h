@@ -37,11 +37,11 @@ struct mnk_dc {
 
 struct mnk_ls {
     mnk_ctx* ctx = nullptr;
-    int64_t N = 0, Np = 0, ld = 0, ldw = 0, nbo = 512;
+    int64_t N = 0, Np = 0, ld = 0, ldw = 0, nbo = 256;
     int algo = MNK_LDL;
     double pivot_tol = 0.0;
-    int lookahead = 0;
-    mnk::DevBuf<double> fact, wbuf, linv, dvec, dinv, xwork;
+    int lookahead = 1;
+    mnk::DevBuf<double> fact, wbuf[2], linv, dvec, dinv, xwork;
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
     bool factorized = false, info_valid = false;

@@ -83,7 +83,10 @@ int mnk_ctx_create(int device, void* stream, mnk_ctx** out) {
         MNK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    MNK_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
+    MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    MNK_HIP(hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, prio_hi));
+    MNK_HIP(hipStreamCreateWithPriority(&c->su, hipStreamNonBlocking, prio_lo));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
     hipDeviceProp_t prop;
@@ -98,7 +101,10 @@ int mnk_ctx_destroy(mnk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
-    if (c->side) (void)hipStreamDestroy(c->side);
+    for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
+    if (c->sp) (void)hipStreamDestroy(c->sp);
+    if (c->su) (void)hipStreamDestroy(c->su);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -155,7 +161,8 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         int64_t v = (int64_t)value;
         MNK_REQUIRE(v >= NBI && v % NBI == 0, "outer_block must be a positive multiple of 64");
         ls->nbo = v;
-        ls->wbuf.release();
+        ls->wbuf[0].release();
+        ls->wbuf[1].release();
         return 0;
     }
     if (!strcmp(key, "lookahead")) { ls->lookahead = value != 0.0; return 0; }
@@ -164,8 +171,11 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
 }
 
 static int ensure_wbuf(mnk_ls* ls) {
-    if (ls->algo != MNK_LDL || ls->wbuf.p) return 0;
-    return ls->wbuf.alloc((size_t)ls->ldw * std::min<int64_t>(ls->nbo, ls->Np) + SLACK);
+    if (ls->algo != MNK_LDL || ls->wbuf[0].p) return 0;
+    const size_t cnt = (size_t)ls->ldw * std::min<int64_t>(ls->nbo, ls->Np) + SLACK;
+    int rc = ls->wbuf[0].alloc(cnt);
+    if (!rc) rc = ls->wbuf[1].alloc(cnt);  // double buffered: panel k+1 is factored while panel k is applied
+    return rc;
 }
 
 static int prepare_fill(mnk_ls* ls) {

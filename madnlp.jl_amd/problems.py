@@ -157,10 +157,11 @@ def opf_shaped(case="case1354pegase", seed=None, sigma_s_decades=8.0, du=0.0, in
     hess_J = np.concatenate(hJ).astype(np.int32)
     hess = np.concatenate(hV)
     if indefinite:
-        # negative curvature on a few generator / angle variables
-        hess_I = np.concatenate((hess_I, va[: max(1, nbus // 50)].astype(np.int32)))
-        hess_J = np.concatenate((hess_J, va[: max(1, nbus // 50)].astype(np.int32)))
-        hess = np.concatenate((hess, -50.0 * np.ones(max(1, nbus // 50))))
+        # negative curvature on the generator injections (each touches one balance row only, so
+        # J'DJ cannot mask it when Sigma_s is moderate): K is indefinite until delta_w > ~50.
+        hess_I = np.concatenate((hess_I, pg.astype(np.int32)))
+        hess_J = np.concatenate((hess_J, pg.astype(np.int32)))
+        hess = np.concatenate((hess, -50.0 * np.ones(ngen)))
 
     # IPM-like diagonals: every slack has both bounds, a third of x has a lower bound
     ind_lb = np.concatenate((np.arange(0, n, 3), n + np.arange(m)))

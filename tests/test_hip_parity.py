@@ -331,7 +331,7 @@ def test_sparse_condensed_factorize_solve(ctx, case, alg):
 def test_sparse_condensed_indefinite_hessian_triggers_regularization(ctx):
     """Negative curvature: both paths must report wrong inertia, then accept after
     regularize_diagonal! with the same delta_w (reference src/IPM/solver.jl:636-666)."""
-    P = opf_shaped("case118", indefinite=True)
+    P = opf_shaped("case118", indefinite=True, sigma_s_decades=2.0)
     ko, kh = _oracle_sc(P, BUNCHKAUFMAN), _hip_sc(P, ctx, mj.BUNCHKAUFMAN)
     outcomes = []
     for k in (ko, kh):

@@ -29,8 +29,9 @@ def ev_time(fn, reps=5, warm=2):
 
 
 def main():
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = mj.HipContext(0, stream=stream)
+    st = torch.cuda.Stream()   # a non-default stream: its handle is non-NULL and torch events see it
+    torch.cuda.set_stream(st)
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
     lib = mj.lib()
     print("device:", torch.cuda.get_device_name(0))
     # ---- gemm_nt rate -------------------------------------------------------------
