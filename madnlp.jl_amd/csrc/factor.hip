@@ -28,17 +28,19 @@
 namespace mnk {
 
 __device__ __forceinline__ double fast_rsqrt(double x) {
-    // v_rsq_f64 seed + two Newton steps: ~1 ulp, no division / software sqrt on the pivot chain
+    // v_rsq_f64 seed + two Newton steps in fma form: ~1 ulp, no division / software sqrt on
+    // the pivot chain
     double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
+    double e = fma(-(x * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(x * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
     return y;
 }
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
-    r = r * (2.0 - x * r);
-    r = r * (2.0 - x * r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
 
@@ -47,15 +49,102 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // Thread (row i = tid & 63, wave w = tid >> 6) owns row i of the columns c = 4*cl + w of
 // T row tiles: tile 0 is the 64x64 diagonal block (every workgroup holds a private copy),
 // tiles 1..T-1 are 64-row tiles of the panel below it.  One barrier per pivot: the pivot
-// column of every tile is published through a double-buffered LDS vector and every thread
-// rescales it by the pivot itself.
+// column of every tile is published through a double-buffered LDS vector (stored permuted so
+// that the 16 entries a wave needs are contiguous) and every thread applies the rank-one
+// update a_ic -= (w_i / piv) * w_c to its own rows and columns.
+//
+// Columns are processed in 16 groups of 4 (one column per wave); the register array is
+// rotated after every group so that the live column group always sits at index 0 (static
+// register indices with a rolled loop).  NL = live slots per wave during a phase of 4 groups.
 // ---------------------------------------------------------------------------------------
+constexpr int CB_LD = 72;  // 64 + slack: a wave reads up to 3 dead slots past its 16
+
+template <bool LDL, int T, int NL>
+__device__ __forceinline__ void panel_phase(double (&a)[T][16], double (*colbuf)[T][CB_LD], const int g0,
+                                            const int i, const int w, const bool lead, const bool (&valid)[T],
+                                            const int64_t (&trow)[T], double* __restrict__ F, const int64_t ld,
+                                            const int64_t j0, double* __restrict__ W, const int64_t ldw,
+                                            const int64_t wcol, double* __restrict__ dvec,
+                                            double* __restrict__ dinv, int* __restrict__ info,
+                                            const double pivot_tol) {
+    const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row/column index i
+#pragma unroll 1
+    for (int g = g0; g < g0 + 4; ++g) {
+#pragma unroll
+        for (int wo = 0; wo < 4; ++wo) {
+            const int j = 4 * g + wo;
+            const bool owner = w == wo;
+            if (owner) {
+#pragma unroll
+                for (int q = 0; q < T; ++q) colbuf[wo & 1][q][pos_i] = a[q][0];
+            }
+            __syncthreads();
+            const double (*cb)[CB_LD] = colbuf[wo & 1];
+            const double piv = cb[0][wo * 16 + g];
+            double inv, lscale, dval;  // update factor 1/piv, column scale, recorded diagonal
+            if (LDL) {
+                const bool zero = !(fabs(piv) > pivot_tol) || !(fabs(piv) <= DBL_MAX);
+                inv = fast_rcp(zero ? 1.0 : piv);  // harmless pivot; dvec records the zero
+                lscale = inv;
+                dval = zero ? 0.0 : piv;
+            } else {
+                // not positive definite (also catches NaN/Inf): flag the first failing pivot; the
+                // remaining steps run on harmless values and every later kernel is a no-op.
+                const bool bad = !(piv > 0.0) || !(piv <= DBL_MAX);
+                if (bad && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + j + 1));
+                const double rs = fast_rsqrt(bad ? 1.0 : piv);
+                lscale = rs;
+                inv = rs * rs;
+                dval = bad ? 1.0 : piv * rs;  // L[j][j]
+            }
+            // w_c of the live columns of this wave: c = 4*(g+cl)+w  <->  slot w*16 + g + cl
+            double wc[NL];
+#pragma unroll
+            for (int cl = 0; cl < NL; ++cl) wc[cl] = cb[0][w * 16 + g + cl];
+#pragma unroll
+            for (int q = 0; q < T; ++q) {
+                const double my_w = cb[q][pos_i];
+                // rows at/above the pivot of the diagonal tile take no part (their entries of column
+                // j are upper-triangle values that may be anything, including NaN)
+                const double my_u = (q == 0 && i <= j) ? 0.0 : my_w * inv;
+                if (w > wo) a[q][0] = fma(-my_u, wc[0], a[q][0]);
+#pragma unroll
+                for (int cl = 1; cl < NL; ++cl) a[q][cl] = fma(-my_u, wc[cl], a[q][cl]);
+                if (owner) {
+                    const double fin = LDL ? my_u : my_w * lscale;  // L[row][j]
+                    if (q == 0)
+                        a[0][0] = (i > j) ? fin : ((i == j) ? (LDL ? 1.0 : dval) : a[0][0]);
+                    else {
+                        a[q][0] = fin;
+                        if (LDL && valid[q]) W[trow[q] + i + (wcol + j) * ldw] = my_w;
+                    }
+                }
+            }
+            if (lead && owner && i == j) {
+                dvec[j0 + j] = dval;
+                dinv[j0 + j] = LDL ? inv : 1.0;
+                F[j0 + j + (j0 + j) * ld] = dval;  // L[j][j], or d_j for LDL (as LAPACK stores it)
+            }
+        }
+        // column group g is final: store it (diagonal tile: strictly lower part, by the leader), rotate
+        const int c = 4 * g + w;
+        if (lead && i > c) F[j0 + i + (j0 + c) * ld] = a[0][0];
+#pragma unroll
+        for (int q = 1; q < T; ++q)
+            if (valid[q]) F[trow[q] + i + (j0 + c) * ld] = a[q][0];
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+#pragma unroll
+            for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
+    }
+}
+
 template <bool LDL, int T>
 __global__ __launch_bounds__(256) void panel64_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
                                                        double* __restrict__ W, int64_t ldw, int64_t wcol,
                                                        double* __restrict__ dvec, double* __restrict__ dinv,
                                                        int* __restrict__ info, double pivot_tol) {
-    __shared__ double colbuf[2][T][64];
+    __shared__ double colbuf[2][T][CB_LD];
     if (*info != 0) return;
 
     const int tid = threadIdx.x;
@@ -82,81 +171,10 @@ __global__ __launch_bounds__(256) void panel64_kernel(double* __restrict__ F, in
 #pragma unroll
         for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
 
-    // Columns are processed in 16 groups of 4 (one column per wave); the register array is
-    // rotated after every group so that the live column group always sits at index 0 (static
-    // register indices with a rolled loop: the fully unrolled 64-step body spills badly).
-    // Slots that have rotated past column 63 hold dead values and are never stored.
-#pragma unroll 1
-    for (int g = 0; g < 16; ++g) {
-#pragma unroll
-        for (int wo = 0; wo < 4; ++wo) {
-            const int j = 4 * g + wo;
-            const bool owner = w == wo;
-            if (owner) {
-#pragma unroll
-                for (int q = 0; q < T; ++q) colbuf[wo & 1][q][i] = a[q][0];
-            }
-            __syncthreads();
-            const double (*cb)[64] = colbuf[wo & 1];
-            const double piv = cb[0][j];
-            double scale, dval;
-            if (LDL) {
-                const bool zero = !(fabs(piv) > pivot_tol) || !(fabs(piv) <= DBL_MAX);
-                const double p = zero ? 1.0 : piv;  // harmless pivot; dvec records the zero
-                scale = fast_rcp(p);
-                dval = zero ? 0.0 : piv;
-            } else {
-                // not positive definite (also catches NaN/Inf): flag the first failing pivot; the
-                // remaining steps run on harmless values and every later kernel is a no-op.
-                const bool bad = !(piv > 0.0) || !(piv <= DBL_MAX);
-                if (bad && lead && tid == 0) atomicCAS(info, 0, (int)(j0 + j + 1));
-                const double rs = fast_rsqrt(bad ? 1.0 : piv);
-                scale = rs;
-                dval = bad ? 1.0 : piv * rs;  // L[j][j]
-            }
-            // second factor of the rank-one update, shared by all tiles: L[c][j] (Cholesky) or
-            // W[c][j] (LDL) for the live columns c = 4*(g+cl)+w > j of this wave.
-            double wc[16];
-#pragma unroll
-            for (int cl = 0; cl < 16; ++cl) {
-                const int c = (4 * (g + cl) + w) & 63;
-                const double v = cb[0][c];
-                const double sv = LDL ? v : v * scale;
-                wc[cl] = (cl > 0 || w > wo) ? sv : 0.0;
-            }
-#pragma unroll
-            for (int q = 0; q < T; ++q) {
-                const double my_w = cb[q][i];
-                // rows at/above the pivot of the diagonal tile take no part (their entries of column
-                // j are upper-triangle values that may be anything, including NaN)
-                const double my_l = (q == 0 && i <= j) ? 0.0 : my_w * scale;  // L[row][j]
-#pragma unroll
-                for (int cl = 0; cl < 16; ++cl) a[q][cl] = fma(-my_l, wc[cl], a[q][cl]);
-                const double fin = (q == 0 && i == j) ? (LDL ? 1.0 : dval) : my_l;
-                a[q][0] = (owner && (q > 0 || i >= j)) ? fin : a[q][0];
-                if (LDL && q > 0) {
-                    if (owner && valid[q]) W[trow[q] + i + (wcol + j) * ldw] = my_w;
-                }
-            }
-            if (lead && owner && i == j) {
-                dvec[j0 + j] = dval;
-                dinv[j0 + j] = LDL ? scale : 1.0;
-                F[j0 + j + (j0 + j) * ld] = dval;  // L[j][j], or d_j for LDL (as LAPACK stores it)
-            }
-        }
-        // column group g is final: store it (diagonal tile: strictly lower part, by the leader), rotate
-        const int c = 4 * g + w;
-        if (lead && i > c) F[j0 + i + (j0 + c) * ld] = a[0][0];
-#pragma unroll
-        for (int q = 1; q < T; ++q)
-            if (valid[q]) F[trow[q] + i + (j0 + c) * ld] = a[q][0];
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-#pragma unroll
-            for (int cl = 0; cl < 15; ++cl) a[q][cl] = a[q][cl + 1];
-            a[q][15] = 0.0;
-        }
-    }
+    panel_phase<LDL, T, 16>(a, colbuf, 0, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase<LDL, T, 12>(a, colbuf, 4, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase<LDL, T, 8>(a, colbuf, 8, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
 }
 
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
@@ -221,7 +239,12 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 
 using namespace mnk;
 
-constexpr int PANEL_T = 3;  // diagonal tile + 2 panel tiles (128 rows) per workgroup
+template <bool LDL, int T>
+static void launch_panel(mnk_ls* ls, hipStream_t s, int64_t j, int64_t ntile, double* wbase, int64_t wcol) {
+    const int grid = (int)std::max<int64_t>(1, (ntile + T - 2) / (T - 1));
+    hipLaunchKernelGGL((panel64_kernel<LDL, T>), dim3(grid), dim3(256), 0, s, ls->fact.p, ls->ld, j, ls->Np, wbase,
+                       ls->ldw, wcol, ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+}
 
 // factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
 static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase) {
@@ -232,14 +255,18 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         const int64_t r0 = j + NBI;
         const int64_t Mr = Np - r0;
         const int64_t ntile = Mr / 64;
-        const int grid = (int)std::max<int64_t>(1, (ntile + PANEL_T - 2) / (PANEL_T - 1));
-        if (ldl)
-            hipLaunchKernelGGL((panel64_kernel<true, PANEL_T>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, wbase,
-                               ls->ldw, j - ko, ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
-        else
-            hipLaunchKernelGGL((panel64_kernel<false, PANEL_T>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,
-                               (double*)nullptr, (int64_t)0, (int64_t)0, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
-                               ls->pivot_tol);
+        // one panel tile per workgroup while that still fits one wave of workgroups on the chip,
+        // more rows per workgroup (fewer redundant diagonal factorizations) for very tall panels
+        if (ntile <= 512) {
+            if (ldl) launch_panel<true, 2>(ls, s, j, ntile, wbase, j - ko);
+            else launch_panel<false, 2>(ls, s, j, ntile, nullptr, 0);
+        } else if (ntile <= 1024) {
+            if (ldl) launch_panel<true, 3>(ls, s, j, ntile, wbase, j - ko);
+            else launch_panel<false, 3>(ls, s, j, ntile, nullptr, 0);
+        } else {
+            if (ldl) launch_panel<true, 5>(ls, s, j, ntile, wbase, j - ko);
+            else launch_panel<false, 5>(ls, s, j, ntile, nullptr, 0);
+        }
         const int64_t Nc = kend - r0;  // remaining columns of the outer panel
         if (Mr > 0 && Nc > 0) {
             const double* Wp = ldl ? wbase + r0 + (j - ko) * ls->ldw : F + r0 + j * ld;
