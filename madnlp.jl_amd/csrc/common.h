@@ -84,6 +84,7 @@ struct mnk_ctx {
     bool own_stream = false;
     // look-ahead of the factorization: panel stream (high priority), update stream, fork/join events
     hipStream_t sp = nullptr, su = nullptr;
+    int panel_cus = 0;  // > 0: sp is restricted to this many CUs and su to the others (CU masks)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_next;
     int num_cu = 256;

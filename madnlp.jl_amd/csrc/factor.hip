@@ -255,18 +255,22 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         const int64_t r0 = j + NBI;
         const int64_t Mr = Np - r0;
         const int64_t ntile = Mr / 64;
-        // one panel tile per workgroup while that still fits one wave of workgroups on the chip,
-        // more rows per workgroup (fewer redundant diagonal factorizations) for very tall panels
-        if (ntile <= 512) {
-            if (ldl) launch_panel<true, 2>(ls, s, j, ntile, wbase, j - ko);
-            else launch_panel<false, 2>(ls, s, j, ntile, nullptr, 0);
-        } else if (ntile <= 1024) {
-            if (ldl) launch_panel<true, 3>(ls, s, j, ntile, wbase, j - ko);
-            else launch_panel<false, 3>(ls, s, j, ntile, nullptr, 0);
-        } else {
-            if (ldl) launch_panel<true, 5>(ls, s, j, ntile, wbase, j - ko);
-            else launch_panel<false, 5>(ls, s, j, ntile, nullptr, 0);
-        }
+        // Tiles per workgroup: few (little redundant diagonal work, short steps) when the whole chip
+        // is available, many when the panel stream owns only `panel_cus` CUs (look-ahead): one
+        // workgroup per CU, the extra rank-one work hides behind the next pivot's latency chain.
+        const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp) ? ls->ctx->panel_cus : 512;
+        int T = 2;
+        while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
+#define MNK_LAUNCH_PANEL(TT)                                                      \
+    do {                                                                          \
+        if (ldl) launch_panel<true, TT>(ls, s, j, ntile, wbase, j - ko);          \
+        else launch_panel<false, TT>(ls, s, j, ntile, nullptr, 0);                \
+    } while (0)
+        if (T == 2) MNK_LAUNCH_PANEL(2);
+        else if (T == 3) MNK_LAUNCH_PANEL(3);
+        else if (T == 5) MNK_LAUNCH_PANEL(5);
+        else MNK_LAUNCH_PANEL(7);
+#undef MNK_LAUNCH_PANEL
         const int64_t Nc = kend - r0;  // remaining columns of the outer panel
         if (Mr > 0 && Nc > 0) {
             const double* Wp = ldl ? wbase + r0 + (j - ko) * ls->ldw : F + r0 + j * ld;

@@ -3,6 +3,7 @@
 // lib/MadNLPGPU/src/utils.jl:12-23 / kernels_sparse.jl:27-33), factorize / inertia /
 // solve entry points.  See include/madnlp_hip.h for the per-function citations.
 #include <cstdarg>
+#include <cstdlib>
 
 #include "ls.h"
 
@@ -83,15 +84,38 @@ int mnk_ctx_create(int device, void* stream, mnk_ctx** out) {
         MNK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
-    MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    MNK_HIP(hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, prio_hi));
-    MNK_HIP(hipStreamCreateWithPriority(&c->su, hipStreamNonBlocking, prio_lo));
-    MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
-    MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
     hipDeviceProp_t prop;
     MNK_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
+    // Look-ahead streams.  The panel stream runs small latency-bound kernels; sharing SIMDs
+    // with the MFMA-saturating trailing update slows them 4-5x (measured), so the two streams
+    // get disjoint CU sets: the panel stream the first `panel_cus` mask bits (bits are dealt
+    // round-robin over the 8 XCDs), the update stream all the others.  Fallback: stream priorities.
+    int want = 0;
+    if (const char* e = getenv("MNK_PANEL_CUS")) want = atoi(e);
+    else want = c->num_cu >= 128 ? 32 : 0;
+    if (want > 0 && want < c->num_cu) {
+        const int words = (c->num_cu + 31) / 32;
+        std::vector<uint32_t> mp(words, 0u), mu(words, 0u);
+        for (int b = 0; b < c->num_cu; ++b) (b < want ? mp : mu)[b / 32] |= 1u << (b % 32);
+        hipError_t e1 = hipExtStreamCreateWithCUMask(&c->sp, (uint32_t)words, mp.data());
+        hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&c->su, (uint32_t)words, mu.data()) : e1;
+        if (e1 == hipSuccess && e2 == hipSuccess) {
+            c->panel_cus = want;
+        } else {
+            (void)hipGetLastError();
+            if (c->sp) { (void)hipStreamDestroy(c->sp); c->sp = nullptr; }
+            c->su = nullptr;
+        }
+    }
+    if (!c->sp) {
+        int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
+        MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MNK_HIP(hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, prio_hi));
+        MNK_HIP(hipStreamCreateWithPriority(&c->su, hipStreamNonBlocking, prio_lo));
+    }
+    MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+    MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
     *out = c;
     return 0;
 }
