@@ -48,7 +48,9 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // Fused diagonal-block factorization + panel solve.
 // Thread (row i = tid & 63, wave w = tid >> 6) owns row i of the columns c = 4*cl + w of
 // T row tiles: tile 0 is the 64x64 diagonal block (every workgroup holds a private copy),
-// tiles 1..T-1 are 64-row tiles of the panel below it.  One barrier per pivot: the pivot
+// tiles 1..T-1 are 64-row tiles of the panel below it.  The factored diagonal block is written
+// to a separate 64x64 buffer (Dout), never in place: other workgroups of the same launch may
+// still be loading the unfactored block.  One barrier per pivot: the pivot
 // column of every tile is published through a double-buffered LDS vector (stored permuted so
 // that the 16 entries a wave needs are contiguous) and every thread applies the rank-one
 // update a_ic -= (w_i / piv) * w_c to its own rows and columns.
@@ -63,7 +65,8 @@ template <bool LDL, int T, int NL>
 __device__ __forceinline__ void panel_phase(double (&a)[T][16], double (*colbuf)[T][CB_LD], const int g0,
                                             const int i, const int w, const bool lead, const bool (&valid)[T],
                                             const int64_t (&trow)[T], double* __restrict__ F, const int64_t ld,
-                                            const int64_t j0, double* __restrict__ W, const int64_t ldw,
+                                            const int64_t j0, double* __restrict__ Dout,
+                                            double* __restrict__ W, const int64_t ldw,
                                             const int64_t wcol, double* __restrict__ dvec,
                                             double* __restrict__ dinv, int* __restrict__ info,
                                             const double pivot_tol) {
@@ -123,12 +126,12 @@ __device__ __forceinline__ void panel_phase(double (&a)[T][16], double (*colbuf)
             if (lead && owner && i == j) {
                 dvec[j0 + j] = dval;
                 dinv[j0 + j] = LDL ? inv : 1.0;
-                F[j0 + j + (j0 + j) * ld] = dval;  // L[j][j], or d_j for LDL (as LAPACK stores it)
+                Dout[j + 64 * j] = dval;  // L[j][j], or d_j for LDL (as LAPACK stores it)
             }
         }
         // column group g is final: store it (diagonal tile: strictly lower part, by the leader), rotate
         const int c = 4 * g + w;
-        if (lead && i > c) F[j0 + i + (j0 + c) * ld] = a[0][0];
+        if (lead && i > c) Dout[i + 64 * c] = a[0][0];
 #pragma unroll
         for (int q = 1; q < T; ++q)
             if (valid[q]) F[trow[q] + i + (j0 + c) * ld] = a[q][0];
@@ -141,7 +144,8 @@ __device__ __forceinline__ void panel_phase(double (&a)[T][16], double (*colbuf)
 
 template <bool LDL, int T>
 __global__ __launch_bounds__(256) void panel64_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
-                                                       double* __restrict__ W, int64_t ldw, int64_t wcol,
+                                                       double* __restrict__ Dout, double* __restrict__ W,
+                                                       int64_t ldw, int64_t wcol,
                                                        double* __restrict__ dvec, double* __restrict__ dinv,
                                                        int* __restrict__ info, double pivot_tol) {
     __shared__ double colbuf[2][T][CB_LD];
@@ -171,26 +175,29 @@ __global__ __launch_bounds__(256) void panel64_kernel(double* __restrict__ F, in
 #pragma unroll
         for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
 
-    panel_phase<LDL, T, 16>(a, colbuf, 0, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase<LDL, T, 12>(a, colbuf, 4, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase<LDL, T, 8>(a, colbuf, 8, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase<LDL, T, 16>(a, colbuf, 0, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase<LDL, T, 12>(a, colbuf, 4, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase<LDL, T, 8>(a, colbuf, 8, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
 }
 
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
 // One workgroup (one wave) per block: lane c solves L x = e_c by column-oriented substitution.
 template <bool LDL>
-__global__ __launch_bounds__(64) void linv64_kernel(const double* __restrict__ F, int64_t ld,
+__global__ __launch_bounds__(64) void linv64_kernel(double* __restrict__ F, int64_t ld,
+                                                     const double* __restrict__ Dblk,
                                                      double* __restrict__ Linv, const int* __restrict__ info) {
     __shared__ double Lt[64 * 64];  // Lt[k*64 + r] = L[r][k]
     __shared__ double rd[64];
     if (*info != 0) return;
     const int64_t j0 = (int64_t)blockIdx.x * 64;
     const int lane = threadIdx.x;
-    const double* A = F + j0 + j0 * ld;
+    const double* A = Dblk + (int64_t)blockIdx.x * 4096;  // factored diagonal block, column-major 64x64
+    double* Fd = F + j0 + j0 * ld;
 #pragma unroll 8
     for (int c = 0; c < 64; ++c) {
-        const double v = A[lane + (int64_t)c * ld];
+        const double v = lane >= c ? A[lane + 64 * c] : 0.0;
+        if (lane >= c) Fd[lane + (int64_t)c * ld] = v;  // put the block back into the factor (lower part)
         Lt[c * 64 + lane] = lane > c ? v : (lane == c ? (LDL ? 1.0 : v) : 0.0);
         if (lane == c) rd[c] = LDL ? 1.0 : 1.0 / v;
     }
@@ -242,8 +249,9 @@ using namespace mnk;
 template <bool LDL, int T>
 static void launch_panel(mnk_ls* ls, hipStream_t s, int64_t j, int64_t ntile, double* wbase, int64_t wcol) {
     const int grid = (int)std::max<int64_t>(1, (ntile + T - 2) / (T - 1));
-    hipLaunchKernelGGL((panel64_kernel<LDL, T>), dim3(grid), dim3(256), 0, s, ls->fact.p, ls->ld, j, ls->Np, wbase,
-                       ls->ldw, wcol, ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+    hipLaunchKernelGGL((panel64_kernel<LDL, T>), dim3(grid), dim3(256), 0, s, ls->fact.p, ls->ld, j, ls->Np,
+                       ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, wcol, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
+                       ls->pivot_tol);
 }
 
 // factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
@@ -252,6 +260,15 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
     for (int64_t j = ko; j < kend; j += NBI) {
+        // left-looking inside the outer panel: bring block column j up to date with the inner
+        // blocks [ko, j) already factored (one K = j-ko product on 64 columns instead of several
+        // K = 64 right-looking updates of the whole remaining panel: 3x less traffic, deeper K)
+        if (j > ko) {
+            const double* Wp = ldl ? wbase + j : F + j + ko * ld;
+            int rc = launch_gemm_nt(s, 0, Np - j, NBI, j - ko, Wp, ldl ? ls->ldw : ld, F + j + ko * ld, ld,
+                                    F + j + j * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+            if (rc) return rc;
+        }
         const int64_t r0 = j + NBI;
         const int64_t Mr = Np - r0;
         const int64_t ntile = Mr / 64;
@@ -271,14 +288,11 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         else if (T == 5) MNK_LAUNCH_PANEL(5);
         else MNK_LAUNCH_PANEL(7);
 #undef MNK_LAUNCH_PANEL
-        const int64_t Nc = kend - r0;  // remaining columns of the outer panel
-        if (Mr > 0 && Nc > 0) {
-            const double* Wp = ldl ? wbase + r0 + (j - ko) * ls->ldw : F + r0 + j * ld;
-            int rc = launch_gemm_nt(s, 2, Mr, Nc, NBI, Wp, ldl ? ls->ldw : ld, F + r0 + j * ld, ld,
-                                    F + r0 + r0 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
-            if (rc) return rc;
-        }
     }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -364,11 +378,11 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     }
     // inverses of the diagonal blocks for the solves (batched, off the critical path of the panels)
     if (ldl)
-        hipLaunchKernelGGL(linv64_kernel<true>, dim3((unsigned)(Np / NBI)), dim3(64), 0, s, F, ld, ls->linv.p,
-                           ls->info_dev.p);
+        hipLaunchKernelGGL(linv64_kernel<true>, dim3((unsigned)(Np / NBI)), dim3(64), 0, s, F, ld, ls->dblk.p,
+                           ls->linv.p, ls->info_dev.p);
     else
-        hipLaunchKernelGGL(linv64_kernel<false>, dim3((unsigned)(Np / NBI)), dim3(64), 0, s, F, ld, ls->linv.p,
-                           ls->info_dev.p);
+        hipLaunchKernelGGL(linv64_kernel<false>, dim3((unsigned)(Np / NBI)), dim3(64), 0, s, F, ld, ls->dblk.p,
+                           ls->linv.p, ls->info_dev.p);
     MNK_HIP(hipGetLastError());
     ls->factorized = true;
     ls->info_valid = false;

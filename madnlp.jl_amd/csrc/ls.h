@@ -41,7 +41,7 @@ struct mnk_ls {
     int algo = MNK_LDL;
     double pivot_tol = 0.0;
     int lookahead = 1;
-    mnk::DevBuf<double> fact, wbuf[2], linv, dvec, dinv, xwork;
+    mnk::DevBuf<double> fact, wbuf[2], linv, dblk, dvec, dinv, xwork;
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
     bool factorized = false, info_valid = false;
