@@ -156,8 +156,11 @@ def main():
     from madnlp_jl_amd.problems import OPF_CASES, opf_shaped
 
     dev = torch.device("cuda", local)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = mj.HipContext(local, stream=stream)
+    # a non-default stream: its handle is non-NULL, the library enqueues on it and torch's
+    # events (HIP events on that same stream) bracket the kernels
+    tstream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(tstream)
+    ctx = mj.HipContext(local, stream=tstream.cuda_stream)
     seed = OPF_CASES[args.case][0] + rank           # independent instance per rank
     P = opf_shaped(args.case, seed=seed, du=1e-8)
     kkt = mj.SparseCondensedKKTSystem(
@@ -172,28 +175,14 @@ def main():
     d_rhs = torch.from_numpy(np.random.default_rng(seed).standard_normal(P.n)).to(dev)
     d_x = torch.empty_like(d_rhs)
 
-    ev = {k: [] for k in ("assemble", "factorize", "solve")}
-    record = {"on": False}
-
     def step():
-        marks = None
-        if record["on"]:
-            marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            marks[0].record()
         kkt.compress_jacobian(d_jac)
         kkt.compress_hessian(d_hess)
         kkt.build_kkt(d_pr, d_du)
-        if marks:
-            marks[1].record()
         ls.factorize_async()
-        if marks:
-            marks[2].record()
         for _ in range(args.nsolve):
             d_x.copy_(d_rhs)
             ls.solve_linear_system(d_x)
-        if marks:
-            marks[3].record()
-            ev["_pending"] = ev.get("_pending", []) + [marks]
 
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
     dt = lambda v: torch.tensor(v, dtype=torch.float64, device=dev)  # noqa: E731
@@ -205,14 +194,34 @@ def main():
     if not kkt.is_inertia_correct(*inertia):
         raise SystemExit(f"unexpected inertia {inertia} on the benchmark system")
 
-    record["on"] = True
     elapsed = timed_region(step, args.steps, args.warmup, sync, dist, dt)
-    record["on"] = False
-    for marks in ev.pop("_pending", [])[args.warmup:]:
-        ev["assemble"].append(marks[0].elapsed_time(marks[1]))
-        ev["factorize"].append(marks[1].elapsed_time(marks[2]))
-        ev["solve"].append(marks[2].elapsed_time(marks[3]) / max(args.nsolve, 1))
-    ms = {k: float(np.mean(v)) for k, v in ev.items()}
+
+    # per-phase breakdown, the reference's `timing_linear_solver` protocol (src/utils.jl:185-197):
+    # each phase alone between device synchronizations, HIP events on the launch stream.
+    def phase_ms(fn, reps):
+        out = []
+        for _ in range(reps):
+            sync()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            sync()
+            out.append(a.elapsed_time(b))
+        return float(np.mean(out))
+
+    def assemble():
+        kkt.compress_jacobian(d_jac)
+        kkt.compress_hessian(d_hess)
+        kkt.build_kkt(d_pr, d_du)
+
+    def one_solve():
+        d_x.copy_(d_rhs)
+        ls.solve_linear_system(d_x)
+
+    reps = max(3, min(10, args.steps))
+    ms = {"assemble": phase_ms(assemble, reps), "factorize": phase_ms(ls.factorize_async, reps),
+          "solve": phase_ms(one_solve, reps)}
     allms = gather_stats([ms["assemble"], ms["factorize"], ms["solve"]], dist, world, dt)
 
     out = None
