@@ -293,10 +293,6 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
     return 0;
 }
 
-    MNK_HIP(hipGetLastError());
-    return 0;
-}
-
 // ---------------------------------------------------------------------------------------
 // factorization driver (host orchestration; asynchronous)
 // ---------------------------------------------------------------------------------------

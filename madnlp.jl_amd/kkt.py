@@ -21,7 +21,8 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _lib as L
-from .linear_solver import DeviceCSC, DeviceDense, HipContext, HipLinearSolver, HipSolverOptions, _ptr
+from .linear_solver import (DeviceCSC, DeviceDense, HipContext, HipLinearSolver, HipSolverOptions, _ptr,
+                            _LIVE_OBJECTS)
 
 
 # ------------------------------------------------------------------ KKT vectors
@@ -174,6 +175,7 @@ class SparseCondensedKKTSystem(_KKTCommon):
         self._host_h = None
         self._diag_buffer = None
         self.linear_solver = linear_solver(self.aug_com, ctx=self.ctx, opt=opt_linear_solver)
+        _LIVE_OBJECTS.add(self)
 
     # -- helpers -----------------------------------------------------------------------
     def _structure(self, which, ncol, nnz):
@@ -338,6 +340,7 @@ class _DenseBase(_KKTCommon):
                                       ii.ctypes.data if len(ii) else None,
                                       ie.ctypes.data if len(ie) else None, 0, C.byref(self._h)), "mnk_dc_create")
         self._order = L.lib().mnk_dc_order(self._h)
+        _LIVE_OBJECTS.add(self)
 
     def compress_jacobian(self):
         """no-op, reference `src/KKT/Dense/utils.jl:25-27`."""

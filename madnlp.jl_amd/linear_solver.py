@@ -9,7 +9,9 @@ parity tests drive.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -40,6 +42,26 @@ class InertiaException(LinearSolverException):
     pass
 
 
+# Every live handle is closed explicitly before interpreter teardown (device memory must be
+# released while the HIP runtime is still alive): solvers and KKT systems first, contexts last.
+_LIVE_OBJECTS = weakref.WeakSet()
+_LIVE_CONTEXTS = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    for obj in list(_LIVE_OBJECTS):
+        try:
+            obj.close()
+        except Exception:
+            pass
+    for ctx in list(_LIVE_CONTEXTS):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
 class HipContext:
     """One device + stream; wraps `mnk_ctx_*`.  `stream` may be a raw hipStream_t
     (e.g. `torch.cuda.current_stream().cuda_stream`) so that callers can time the
@@ -50,6 +72,7 @@ class HipContext:
         L.check(L.lib().mnk_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)),
                 "mnk_ctx_create")
         self.device = device
+        _LIVE_CONTEXTS.add(self)
 
     @property
     def handle(self):
@@ -117,6 +140,7 @@ class HipLinearSolver:
                          ("lookahead", float(self.opt.lookahead))):
             L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(val)), "mnk_ls_set_option")
         self.info = 0
+        _LIVE_OBJECTS.add(self)
 
     # -- AbstractLinearSolver interface (reference linearsolvers.jl:13-110) ----------
     def introduce(self) -> str:
