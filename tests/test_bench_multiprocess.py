@@ -1,0 +1,38 @@
+"""The N>1 launch contract of bench.py (one process per GPU, barrier, MAX over ranks, one
+all-gather of timings) exercised on CPU with the gloo backend, world_size 2."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(nproc, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(nproc), "--steps", "5", "--warmup", "1", "--cpu-dry-run"]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 must print exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_two_ranks_gloo():
+    out = _run(2, 29641)
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak"
+    # per-step sleep is 2 ms on rank 0 and 4 ms on rank 1: MAX over ranks must see the slow one
+    assert out["ms_per_step"] >= 3.9
+    # whole-job aggregate: both ranks' units over the max time
+    assert abs(out["value"] - 2 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
+    assert out["per_rank_ms"] == [[1.0, 2.0, 3.0], [2.0, 3.0, 4.0]]  # the single timing all-gather
+
+
+def test_single_rank_no_process_group():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-dry-run", "--steps", "3",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["metric"].startswith("IP iterations/sec")
