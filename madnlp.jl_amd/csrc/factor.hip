@@ -181,6 +181,185 @@ __global__ __launch_bounds__(256) void panel64_kernel(double* __restrict__ F, in
     panel_phase<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
 }
 
+// ---------------------------------------------------------------------------------------
+// Rank-4 variant of the fused panel kernel (the one used): ONE barrier per group of 4 pivots.
+// The four waves publish their raw current columns together; every thread then factors the
+// 4x4 pivot block redundantly in registers (4 dependent rsqrt/rcp chains, no LDS round trip
+// between them), forward-substitutes its own row (per tile) and its own live columns, and
+// applies the rank-4 update.  Compared with the rank-1 kernel above this removes 3 of every 4
+// LDS-publish/barrier/read round trips from the pivot chain.
+//   Cf[r][k] : coefficient of the substitution = L[r][k] (Cholesky) or d_k L[r][k] (LDL)
+//   s[k]     : 1/L[k][k] (Cholesky) or 1/d_k (LDL)
+//   x_k = (w_k - sum_{m<k} x_m Cf[k][m]) * s_k ,  v_k = the same before scaling
+// ---------------------------------------------------------------------------------------
+struct Piv4 {
+    double c10, c20, c30, c21, c31, c32, s0, s1, s2, s3;
+};
+
+template <bool LDL>
+__device__ __forceinline__ void sub4(const Piv4& P, double w0, double w1, double w2, double w3, double (&x)[4],
+                                     double (&v)[4]) {
+    v[0] = w0;
+    x[0] = v[0] * P.s0;
+    v[1] = fma(-x[0], P.c10, w1);
+    x[1] = v[1] * P.s1;
+    v[2] = fma(-x[1], P.c21, fma(-x[0], P.c20, w2));
+    x[2] = v[2] * P.s2;
+    v[3] = fma(-x[2], P.c32, fma(-x[1], P.c31, fma(-x[0], P.c30, w3)));
+    x[3] = v[3] * P.s3;
+}
+
+template <bool LDL, int T, int NL>
+__device__ __forceinline__ void panel_phase4(double (&a)[T][16], double (*colbuf)[4][CB_LD], const int g0,
+                                             const int i, const int w, const bool lead, const bool (&valid)[T],
+                                             const int64_t (&trow)[T], double* __restrict__ F, const int64_t ld,
+                                             const int64_t j0, double* __restrict__ Dout,
+                                             double* __restrict__ W, const int64_t ldw, const int64_t wcol,
+                                             double* __restrict__ dvec, double* __restrict__ dinv,
+                                             int* __restrict__ info, const double pivot_tol) {
+    const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row index i
+#pragma unroll 1
+    for (int g = g0; g < g0 + 4; ++g) {
+        double (*cb)[4][CB_LD] = colbuf + (g & 1) * T;  // [q][k][slot]
+#pragma unroll
+        for (int q = 0; q < T; ++q) cb[q][w][pos_i] = a[q][0];
+        __syncthreads();
+        // ---- 4x4 pivot block: rows/cols 4g..4g+3 of the diagonal tile; slot(4g+r) = r*16 + g
+        const double p00 = cb[0][0][0 * 16 + g];
+        const double p10 = cb[0][0][1 * 16 + g], p11 = cb[0][1][1 * 16 + g];
+        const double p20 = cb[0][0][2 * 16 + g], p21 = cb[0][1][2 * 16 + g], p22 = cb[0][2][2 * 16 + g];
+        const double p30 = cb[0][0][3 * 16 + g], p31 = cb[0][1][3 * 16 + g], p32 = cb[0][2][3 * 16 + g];
+        const double p33 = cb[0][3][3 * 16 + g];
+        Piv4 P;
+        double dg[4];  // recorded diagonal: L[k][k] (Cholesky) or d_k (LDL, 0 for a zero pivot)
+        int fail = 0;
+        if (LDL) {
+            auto piv = [&](double d, double& sc, double& rec) {
+                const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
+                sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
+                rec = zero ? 0.0 : d;
+            };
+            piv(p00, P.s0, dg[0]);
+            P.c10 = p10; P.c20 = p20; P.c30 = p30;
+            const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
+            piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
+            P.c21 = fma(-x20, P.c10, p21);
+            P.c31 = fma(-x30, P.c10, p31);
+            const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
+            piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
+            P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
+            const double x32 = P.c32 * P.s2;
+            piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
+        } else {
+            auto piv = [&](double t, double& sc, double& rec, int k) {
+                // not positive definite (also catches NaN/Inf): remember the first failing pivot
+                const bool bad = !(t > 0.0) || !(t <= DBL_MAX);
+                fail = (bad && fail == 0) ? k + 1 : fail;
+                sc = fast_rsqrt(bad ? 1.0 : t);
+                rec = bad ? 1.0 : t * sc;
+            };
+            piv(p00, P.s0, dg[0], 0);
+            P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
+            piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
+            P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
+            P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
+            piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
+            P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
+            piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
+            // flag the failure; remaining work runs on harmless values, later kernels are no-ops
+            if (fail != 0 && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + 4 * g + fail));
+        }
+        // ---- second factors for the live columns of this wave: rows c = 4*(g+cl)+w, slot w*16+g+cl
+        double y[NL][4];
+#pragma unroll
+        for (int cl = 1; cl < NL; ++cl) {
+            const int sl = w * 16 + g + cl;
+            double x[4], v[4];
+            sub4<LDL>(P, cb[0][0][sl], cb[0][1][sl], cb[0][2][sl], cb[0][3][sl], x, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[cl][k] = LDL ? v[k] : x[k];
+        }
+        // ---- own rows
+        const int c0 = 4 * g + w;  // the column this wave finishes in this group
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            double x[4], v[4];
+            sub4<LDL>(P, cb[q][0][pos_i], cb[q][1][pos_i], cb[q][2][pos_i], cb[q][3][pos_i], x, v);
+            if (q == 0) {
+                // rows above the pivot block of the diagonal tile hold upper-triangle values: no part
+                const bool above = i < 4 * g;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = above ? 0.0 : x[k];
+            }
+#pragma unroll
+            for (int cl = 1; cl < NL; ++cl) {
+                double acc = a[q][cl];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = fma(-x[k], y[cl][k], acc);
+                a[q][cl] = acc;
+            }
+            const double xw = w == 0 ? x[0] : (w == 1 ? x[1] : (w == 2 ? x[2] : x[3]));  // L[row][c0]
+            if (q == 0) {
+                if (lead) {
+                    if (i > c0) Dout[i + 64 * c0] = xw;
+                    if (i == c0) {
+                        const double d = w == 0 ? dg[0] : (w == 1 ? dg[1] : (w == 2 ? dg[2] : dg[3]));
+                        const double sc = w == 0 ? P.s0 : (w == 1 ? P.s1 : (w == 2 ? P.s2 : P.s3));
+                        Dout[i + 64 * c0] = d;  // L[c][c], or d_c for LDL (as LAPACK stores it)
+                        dvec[j0 + c0] = d;
+                        dinv[j0 + c0] = LDL ? sc : 1.0;
+                    }
+                }
+            } else if (valid[q]) {
+                F[trow[q] + i + (j0 + c0) * ld] = xw;
+                if (LDL) {
+                    const double vw = w == 0 ? v[0] : (w == 1 ? v[1] : (w == 2 ? v[2] : v[3]));
+                    W[trow[q] + i + (wcol + c0) * ldw] = vw;
+                }
+            }
+        }
+        // rotate: the next column group moves to slot 0
+#pragma unroll
+        for (int q = 0; q < T; ++q)
+#pragma unroll
+            for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
+    }
+}
+
+template <bool LDL, int T>
+__global__ __launch_bounds__(256) void panel64r4_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
+                                                         double* __restrict__ Dout, double* __restrict__ W,
+                                                         int64_t ldw, int64_t wcol, double* __restrict__ dvec,
+                                                         double* __restrict__ dinv, int* __restrict__ info,
+                                                         double pivot_tol) {
+    __shared__ double colbuf[2 * T][4][CB_LD];
+    if (*info != 0) return;
+    const int tid = threadIdx.x;
+    const int i = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool lead = blockIdx.x == 0;
+    int64_t trow[T];
+    bool valid[T];
+    trow[0] = j0;
+    valid[0] = true;
+#pragma unroll
+    for (int q = 1; q < T; ++q) {
+        const int64_t r = j0 + 64 * ((int64_t)blockIdx.x * (T - 1) + q);
+        valid[q] = r < Np;
+        trow[q] = valid[q] ? r : j0;  // a tile past the end aliases the diagonal tile (never stored)
+    }
+    double a[T][16];
+#pragma unroll
+    for (int q = 0; q < T; ++q)
+#pragma unroll
+        for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
+
+    panel_phase4<LDL, T, 16>(a, colbuf, 0, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase4<LDL, T, 12>(a, colbuf, 4, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase4<LDL, T, 8>(a, colbuf, 8, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+    panel_phase4<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
+}
+
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
 // One workgroup (one wave) per block: lane c solves L x = e_c by column-oriented substitution.
 template <bool LDL>
@@ -249,7 +428,7 @@ using namespace mnk;
 template <bool LDL, int T>
 static void launch_panel(mnk_ls* ls, hipStream_t s, int64_t j, int64_t ntile, double* wbase, int64_t wcol) {
     const int grid = (int)std::max<int64_t>(1, (ntile + T - 2) / (T - 1));
-    hipLaunchKernelGGL((panel64_kernel<LDL, T>), dim3(grid), dim3(256), 0, s, ls->fact.p, ls->ld, j, ls->Np,
+    hipLaunchKernelGGL((panel64r4_kernel<LDL, T>), dim3(grid), dim3(256), 0, s, ls->fact.p, ls->ld, j, ls->Np,
                        ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, wcol, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
                        ls->pivot_tol);
 }
