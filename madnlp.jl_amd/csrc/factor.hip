@@ -22,6 +22,7 @@
 // (LAPACK stops at the failing column; we cannot stop the host without a sync).
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "ls.h"
 
@@ -360,6 +361,176 @@ __global__ __launch_bounds__(256) void panel64r4_kernel(double* __restrict__ F, 
     panel_phase4<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
 }
 
+// ---------------------------------------------------------------------------------------
+// Wave-group variant (the one launched): G groups of 4 waves per workgroup, each group owns TG
+// row tiles (group 0's first tile is the diagonal block).  More resident waves per SIMD hide
+// the fp64 latencies, fewer registers per wave avoid AGPR shuffling, and the second factors
+// y_k(c) of the rank-4 update are computed ONCE (they are the substituted rows of the diagonal
+// tile) and shared through LDS instead of being recomputed by every wave.
+// ---------------------------------------------------------------------------------------
+template <bool LDL, int G, int TG, int NL>
+__device__ __forceinline__ void panel_phase_g(double (&a)[TG][16], double (*raw)[4][CB_LD], double (*ybuf)[CB_LD],
+                                              const int g0, const int i, const int w, const int gidx,
+                                              const bool lead, const bool (&valid)[TG], const int64_t (&trow)[TG],
+                                              double* __restrict__ F, const int64_t ld, const int64_t j0,
+                                              double* __restrict__ Dout, double* __restrict__ W, const int64_t ldw,
+                                              const int64_t wcol, double* __restrict__ dvec,
+                                              double* __restrict__ dinv, int* __restrict__ info,
+                                              const double pivot_tol) {
+    constexpr int TT = G * TG;
+    const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row index i
+#pragma unroll 1
+    for (int g = g0; g < g0 + 4; ++g) {
+        double (*cb)[4][CB_LD] = raw + (g & 1) * TT;  // [tile][k][slot]
+        double (*yb)[CB_LD] = ybuf + (g & 1) * 4;     // [k][slot]
+#pragma unroll
+        for (int q = 0; q < TG; ++q) cb[gidx * TG + q][w][pos_i] = a[q][0];
+        __syncthreads();
+        // ---- 4x4 pivot block: rows/cols 4g..4g+3 of the diagonal tile; slot(4g+r) = r*16 + g
+        const double p00 = cb[0][0][0 * 16 + g];
+        const double p10 = cb[0][0][1 * 16 + g], p11 = cb[0][1][1 * 16 + g];
+        const double p20 = cb[0][0][2 * 16 + g], p21 = cb[0][1][2 * 16 + g], p22 = cb[0][2][2 * 16 + g];
+        const double p30 = cb[0][0][3 * 16 + g], p31 = cb[0][1][3 * 16 + g], p32 = cb[0][2][3 * 16 + g];
+        const double p33 = cb[0][3][3 * 16 + g];
+        Piv4 P;
+        double dg[4];  // recorded diagonal: L[k][k] (Cholesky) or d_k (LDL, 0 for a zero pivot)
+        int fail = 0;
+        if (LDL) {
+            auto piv = [&](double d, double& sc, double& rec) {
+                const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
+                sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
+                rec = zero ? 0.0 : d;
+            };
+            piv(p00, P.s0, dg[0]);
+            P.c10 = p10; P.c20 = p20; P.c30 = p30;
+            const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
+            piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
+            P.c21 = fma(-x20, P.c10, p21);
+            P.c31 = fma(-x30, P.c10, p31);
+            const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
+            piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
+            P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
+            const double x32 = P.c32 * P.s2;
+            piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
+        } else {
+            auto piv = [&](double t, double& sc, double& rec, int k) {
+                const bool bad = !(t > 0.0) || !(t <= DBL_MAX);  // not positive definite / NaN / Inf
+                fail = (bad && fail == 0) ? k + 1 : fail;
+                sc = fast_rsqrt(bad ? 1.0 : t);
+                rec = bad ? 1.0 : t * sc;
+            };
+            piv(p00, P.s0, dg[0], 0);
+            P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
+            piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
+            P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
+            P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
+            piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
+            P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
+            piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
+            if (fail != 0 && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + 4 * g + fail));
+        }
+        // ---- own rows: forward substitution against the pivot block
+        double x[TG][4], v[TG][4];
+#pragma unroll
+        for (int q = 0; q < TG; ++q) {
+            const int tq = gidx * TG + q;
+            sub4<LDL>(P, cb[tq][0][pos_i], cb[tq][1][pos_i], cb[tq][2][pos_i], cb[tq][3][pos_i], x[q], v[q]);
+        }
+        // the substituted rows of the diagonal tile are everybody's second factors: share them
+        if (gidx == 0 && w == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yb[k][pos_i] = LDL ? v[0][k] : x[0][k];
+        }
+        __syncthreads();
+        if (gidx == 0) {
+            // rows above the pivot block of the diagonal tile hold upper-triangle values: no part
+            const bool above = i < 4 * g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[0][k] = above ? 0.0 : x[0][k];
+        }
+        // ---- rank-4 update of the live columns of this wave: c = 4*(g+cl)+w, slot w*16+g+cl
+#pragma unroll
+        for (int cl = 1; cl < NL; ++cl) {
+            const int sl = w * 16 + g + cl;
+            const double y0 = yb[0][sl], y1 = yb[1][sl], y2 = yb[2][sl], y3 = yb[3][sl];
+#pragma unroll
+            for (int q = 0; q < TG; ++q)
+                a[q][cl] = fma(-x[q][3], y3, fma(-x[q][2], y2, fma(-x[q][1], y1, fma(-x[q][0], y0, a[q][cl]))));
+            // keep the scheduler from hoisting every slot's LDS loads at once (register pressure)
+            if ((cl & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- the column this wave finishes in this group
+        const int c0 = 4 * g + w;
+#pragma unroll
+        for (int q = 0; q < TG; ++q) {
+            const double xw = w == 0 ? x[q][0] : (w == 1 ? x[q][1] : (w == 2 ? x[q][2] : x[q][3]));  // L[row][c0]
+            if (q == 0 && gidx == 0) {
+                if (lead) {
+                    if (i > c0) Dout[i + 64 * c0] = xw;
+                    if (i == c0) {
+                        const double d = w == 0 ? dg[0] : (w == 1 ? dg[1] : (w == 2 ? dg[2] : dg[3]));
+                        const double sc = w == 0 ? P.s0 : (w == 1 ? P.s1 : (w == 2 ? P.s2 : P.s3));
+                        Dout[i + 64 * c0] = d;  // L[c][c], or d_c for LDL (as LAPACK stores it)
+                        dvec[j0 + c0] = d;
+                        dinv[j0 + c0] = LDL ? sc : 1.0;
+                    }
+                }
+            } else if (valid[q]) {
+                F[trow[q] + i + (j0 + c0) * ld] = xw;
+                if (LDL) {
+                    const double vw = w == 0 ? v[q][0] : (w == 1 ? v[q][1] : (w == 2 ? v[q][2] : v[q][3]));
+                    W[trow[q] + i + (wcol + c0) * ldw] = vw;
+                }
+            }
+        }
+        // rotate: the next column group moves to slot 0
+#pragma unroll
+        for (int q = 0; q < TG; ++q)
+#pragma unroll
+            for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
+    }
+}
+
+template <bool LDL, int G, int TG>
+__global__ __launch_bounds__(256 * G) void panel64g_kernel(double* __restrict__ F, int64_t ld, int64_t j0,
+                                                            int64_t Np, double* __restrict__ Dout,
+                                                            double* __restrict__ W, int64_t ldw, int64_t wcol,
+                                                            double* __restrict__ dvec, double* __restrict__ dinv,
+                                                            int* __restrict__ info, double pivot_tol) {
+    constexpr int TT = G * TG;
+    __shared__ double raw[2 * TT][4][CB_LD];
+    __shared__ double ybuf[2 * 4][CB_LD];
+    if (*info != 0) return;
+    const int tid = threadIdx.x;
+    const int i = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wv & 3, gidx = wv >> 2;
+    const bool lead = blockIdx.x == 0;
+    int64_t trow[TG];
+    bool valid[TG];
+#pragma unroll
+    for (int q = 0; q < TG; ++q) {
+        const int tq = gidx * TG + q;  // tile index inside the workgroup; tile 0 = diagonal block
+        const int64_t r = tq == 0 ? j0 : j0 + 64 * ((int64_t)blockIdx.x * (TT - 1) + tq);
+        valid[q] = r < Np;
+        trow[q] = valid[q] ? r : j0;  // a tile past the end aliases the diagonal tile (never stored)
+    }
+    double a[TG][16];
+#pragma unroll
+    for (int q = 0; q < TG; ++q)
+#pragma unroll
+        for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
+
+#define MNK_PHASE(NLV, G0)                                                                                       \
+    panel_phase_g<LDL, G, TG, NLV>(a, raw, ybuf, G0, i, w, gidx, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, \
+                                   dvec, dinv, info, pivot_tol)
+    MNK_PHASE(16, 0);
+    MNK_PHASE(12, 4);
+    MNK_PHASE(8, 8);
+    MNK_PHASE(4, 12);
+#undef MNK_PHASE
+}
+
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
 // One workgroup (one wave) per block: lane c solves L x = e_c by column-oriented substitution.
 template <bool LDL>
@@ -425,12 +596,13 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 
 using namespace mnk;
 
-template <bool LDL, int T>
+template <bool LDL, int G, int TG>
 static void launch_panel(mnk_ls* ls, hipStream_t s, int64_t j, int64_t ntile, double* wbase, int64_t wcol) {
-    const int grid = (int)std::max<int64_t>(1, (ntile + T - 2) / (T - 1));
-    hipLaunchKernelGGL((panel64r4_kernel<LDL, T>), dim3(grid), dim3(256), 0, s, ls->fact.p, ls->ld, j, ls->Np,
-                       ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, wcol, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
-                       ls->pivot_tol);
+    constexpr int TT = G * TG;
+    const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));
+    hipLaunchKernelGGL((panel64g_kernel<LDL, G, TG>), dim3(grid), dim3(256 * G), 0, s, ls->fact.p, ls->ld, j,
+                       ls->Np, ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, wcol, ls->dvec.p, ls->dinv.p,
+                       ls->info_dev.p, ls->pivot_tol);
 }
 
 // factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
@@ -455,17 +627,18 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // is available, many when the panel stream owns only `panel_cus` CUs (look-ahead): one
         // workgroup per CU, the extra rank-one work hides behind the next pivot's latency chain.
         const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp) ? ls->ctx->panel_cus : 512;
-        int T = 2;
-        while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
-#define MNK_LAUNCH_PANEL(TT)                                                      \
+        // tiles per workgroup (incl. the diagonal tile): 2, 4 or 8
+        int TT = 2;
+        while (TT < 8 && (ntile + TT - 2) / (TT - 1) > wgs) TT *= 2;
+        if (const char* e = getenv("MNK_PANEL_TT")) TT = atoi(e);
+#define MNK_LAUNCH_PANEL(GG, TG)                                                  \
     do {                                                                          \
-        if (ldl) launch_panel<true, TT>(ls, s, j, ntile, wbase, j - ko);          \
-        else launch_panel<false, TT>(ls, s, j, ntile, nullptr, 0);                \
+        if (ldl) launch_panel<true, GG, TG>(ls, s, j, ntile, wbase, j - ko);      \
+        else launch_panel<false, GG, TG>(ls, s, j, ntile, nullptr, 0);            \
     } while (0)
-        if (T == 2) MNK_LAUNCH_PANEL(2);
-        else if (T == 3) MNK_LAUNCH_PANEL(3);
-        else if (T == 5) MNK_LAUNCH_PANEL(5);
-        else MNK_LAUNCH_PANEL(7);
+        if (TT <= 2) MNK_LAUNCH_PANEL(1, 2);
+        else if (TT <= 4) MNK_LAUNCH_PANEL(2, 2);
+        else MNK_LAUNCH_PANEL(2, 4);
 #undef MNK_LAUNCH_PANEL
     }
     MNK_HIP(hipGetLastError());
