@@ -627,18 +627,35 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // is available, many when the panel stream owns only `panel_cus` CUs (look-ahead): one
         // workgroup per CU, the extra rank-one work hides behind the next pivot's latency chain.
         const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp) ? ls->ctx->panel_cus : 512;
-        // tiles per workgroup (incl. the diagonal tile): 2, 4 or 8
-        int TT = 2;
-        while (TT < 8 && (ntile + TT - 2) / (TT - 1) > wgs) TT *= 2;
-        if (const char* e = getenv("MNK_PANEL_TT")) TT = atoi(e);
+        // tiles per workgroup (incl. the diagonal tile)
+        int T = 2;
+        while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
+        // MNK_PANEL_WG=g selects the wave-group variant (2 groups of 4 waves, 2 tiles each): measured
+        // slower than the single-group rank-4 kernel on gfx950 (profiles/), kept for experiments.
+        static const bool use_groups = getenv("MNK_PANEL_WG") != nullptr;
+#define MNK_LAUNCH_R4(TT)                                                                                     \
+    do {                                                                                                      \
+        const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));                              \
+        if (ldl)                                                                                              \
+            hipLaunchKernelGGL((panel64r4_kernel<true, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,       \
+                               ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, j - ko, ls->dvec.p,             \
+                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                                    \
+        else                                                                                                  \
+            hipLaunchKernelGGL((panel64r4_kernel<false, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,      \
+                               ls->dblk.p + (j / NBI) * 4096, (double*)nullptr, (int64_t)0, (int64_t)0,       \
+                               ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                        \
+    } while (0)
 #define MNK_LAUNCH_PANEL(GG, TG)                                                  \
     do {                                                                          \
         if (ldl) launch_panel<true, GG, TG>(ls, s, j, ntile, wbase, j - ko);      \
         else launch_panel<false, GG, TG>(ls, s, j, ntile, nullptr, 0);            \
     } while (0)
-        if (TT <= 2) MNK_LAUNCH_PANEL(1, 2);
-        else if (TT <= 4) MNK_LAUNCH_PANEL(2, 2);
-        else MNK_LAUNCH_PANEL(2, 4);
+        if (use_groups) MNK_LAUNCH_PANEL(2, 2);
+        else if (T == 2) MNK_LAUNCH_R4(2);
+        else if (T == 3) MNK_LAUNCH_R4(3);
+        else if (T == 5) MNK_LAUNCH_R4(5);
+        else MNK_LAUNCH_R4(7);
+#undef MNK_LAUNCH_R4
 #undef MNK_LAUNCH_PANEL
     }
     MNK_HIP(hipGetLastError());

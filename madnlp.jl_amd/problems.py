@@ -233,3 +233,124 @@ def dense_dummy_qp(n=2048, m=512, n_eq=0, seed=1, du_eq=-1e-8):
     du_diag[ind_eq] = du_eq
     return DenseKKTProblem(f"dense_dummy_qp_{n}_{m}_{n_eq}", n, m, P, A, ind_ineq, ind_eq, ind_lb, ind_ub, reg,
                            l_diag, u_diag, l_lower, u_lower, du_diag, q)
+
+
+# ---------------------------------------------------------------------------- NLP models for the IPM driver
+class HS15Model:
+    """Hock-Schittkowski 15 exactly as the reference's test instance
+    (lib/MadNLPTests/src/Instances/hs15.jl:1-103); optimum (0.5, 2), objective 306.5."""
+    n, m = 2, 2
+    x0 = np.zeros(2)
+    y0 = np.zeros(2)
+    lvar = np.array([-np.inf, -np.inf])
+    uvar = np.array([0.5, np.inf])
+    lcon = np.array([1.0, 0.0])
+    ucon = np.array([np.inf, np.inf])
+    jac_I = np.array([0, 0, 1, 1])
+    jac_J = np.array([0, 1, 0, 1])
+    hess_I = np.array([0, 1, 1])
+    hess_J = np.array([0, 0, 1])
+
+    def obj(self, x):
+        return 100.0 * (x[1] - x[0] ** 2) ** 2 + (1.0 - x[0]) ** 2
+
+    def grad(self, x):
+        z = x[1] - x[0] ** 2
+        return np.array([-400.0 * z * x[0] - 2.0 * (1.0 - x[0]), 200.0 * z])
+
+    def cons(self, x):
+        return np.array([x[0] * x[1], x[0] + x[1] ** 2])
+
+    def jac_coord(self, x):
+        return np.array([x[1], x[0], 1.0, 2 * x[1]])
+
+    def jac_dense(self, x):
+        return np.array([[x[1], x[0]], [1.0, 2 * x[1]]], order="F")
+
+    def hess_coord(self, x, y, w=1.0):
+        return np.array([w * (-400.0 * x[1] + 1200.0 * x[0] ** 2 + 2.0), w * (-400.0 * x[0]) + y[0],
+                         w * 200.0 + 2.0 * y[1]])
+
+    def hess_dense(self, x, y, w=1.0):
+        h = self.hess_coord(x, y, w)
+        return np.array([[h[0], h[1]], [h[1], h[2]]], order="F")
+
+
+class DenseQPModel:
+    """min 0.5 x'Px + q'x  s.t. 0 <= x <= 1, gl <= Ax <= gu -- the reference's DenseDummyQP
+    (lib/MadNLPTests/src/Instances/dummy_qp.jl) with our own seeded RNG."""
+
+    def __init__(self, n=50, m=10, n_eq=0, seed=1):
+        P = dense_dummy_qp(n, m, n_eq, seed)
+        self.n, self.m = n, m
+        # scaled so that gradients stay below nlp_scaling_max_gradient (the reference would scale)
+        self.P, self.A, self.q = P.hess / 10.0, P.jac, P.q / 10.0
+        self.x0, self.y0 = np.zeros(n), np.zeros(m)
+        self.lvar, self.uvar = np.zeros(n), np.ones(n)
+        self.lcon, self.ucon = np.zeros(m), np.ones(m)
+        self.ucon[:n_eq] = 0.0
+        il, jl = np.tril_indices(n)
+        self.hess_I, self.hess_J = il, jl
+        ji, jj = np.nonzero(self.A)
+        self.jac_I, self.jac_J = ji, jj
+
+    def obj(self, x):
+        return 0.5 * x @ self.P @ x + self.q @ x
+
+    def grad(self, x):
+        return self.P @ x + self.q
+
+    def cons(self, x):
+        return self.A @ x
+
+    def jac_dense(self, x):
+        return self.A
+
+    def jac_coord(self, x):
+        return self.A[self.jac_I, self.jac_J]
+
+    def hess_dense(self, x, y, w=1.0):
+        return w * self.P
+
+    def hess_coord(self, x, y, w=1.0):
+        return w * self.P[self.hess_I, self.hess_J]
+
+
+class SparseQPModel:
+    """Convex QP with the OPF-shaped sparsity of `opf_shaped`: min 0.5 x'Hx + q'x s.t. cl <= Jx <= cu,
+    xl <= x <= xu.  Drives the sparse-condensed path through a full IPM run (inertia correction,
+    refinement, line search) at BASELINE config sizes."""
+
+    def __init__(self, case="case118", seed=None):
+        P = opf_shaped(case, seed=seed)
+        rng = np.random.default_rng((seed or P.meta["seed"]) + 17)
+        self.n, self.m = P.n, P.m
+        self.jac_I, self.jac_J, self.hess_I, self.hess_J = P.jac_I, P.jac_J, P.hess_I, P.hess_J
+        self.jv = P.jac / 4.0
+        self.hv = P.hess
+        import scipy.sparse as sp
+        self.J = sp.csr_matrix((self.jv, (P.jac_I, P.jac_J)), shape=(P.m, P.n))
+        lo_i, lo_j = np.maximum(P.hess_I, P.hess_J), np.minimum(P.hess_I, P.hess_J)
+        L = sp.csr_matrix((self.hv, (lo_i, lo_j)), shape=(P.n, P.n))
+        self.H = L + sp.tril(L, -1).T
+        self.q = rng.standard_normal(P.n)
+        xs = rng.uniform(-0.5, 0.5, P.n)            # a strictly feasible point defines the bounds
+        cs = self.J @ xs
+        self.lvar, self.uvar = xs - rng.uniform(0.5, 2, P.n), xs + rng.uniform(0.5, 2, P.n)
+        self.lcon, self.ucon = cs - rng.uniform(0.1, 2, P.m), cs + rng.uniform(0.1, 2, P.m)
+        self.x0, self.y0 = np.zeros(P.n), np.zeros(P.m)
+
+    def obj(self, x):
+        return 0.5 * x @ (self.H @ x) + self.q @ x
+
+    def grad(self, x):
+        return self.H @ x + self.q
+
+    def cons(self, x):
+        return self.J @ x
+
+    def jac_coord(self, x):
+        return self.jv
+
+    def hess_coord(self, x, y, w=1.0):
+        return w * self.hv

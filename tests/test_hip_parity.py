@@ -445,3 +445,78 @@ def test_spmv_pieces(ctx):
     np.testing.assert_allclose(run(L.MNK_SC_HESS, 0, xn, P.n, -1.0, 1.0, y0),
                                y0 - ko.hess_com.symmetric_lower_matvec(xn), rtol=1e-12, atol=1e-12)
     kh.close()
+
+
+# --------------------------------------------------------------------------- end-to-end IPM parity
+def _ipm_pair(kind, nlp, ctx, tol):
+    """Run the same IPM driver twice from identical inputs: CPU oracle back-end (LAPACK
+    Bunch-Kaufman) and HIP back-end (static-pivot LDL^T)."""
+    from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver
+    from tests.test_ipm_oracle import oracle_factory
+    sparse = kind == "sparse_condensed"
+
+    def hip_factory(info):
+        opt = mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN)
+        if kind == "sparse_condensed":
+            return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J,
+                                               info["ind_ineq"], info["ind_lb"], info["ind_ub"], ctx=ctx,
+                                               opt_linear_solver=opt)
+        if kind == "dense_condensed":
+            return mj.DenseCondensedKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_eq"], info["ind_lb"],
+                                              info["ind_ub"], ctx=ctx, opt_linear_solver=opt)
+        return mj.DenseKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_lb"], info["ind_ub"], ctx=ctx,
+                                 opt_linear_solver=opt)
+
+    out = []
+    for fac in (oracle_factory(kind, nlp), hip_factory):
+        opt = IPMOptions(tol=tol)
+        if sparse:
+            opt.relax_equality, opt.dual_initialization = True, "zero"
+        s = MadNLPSolver(nlp, fac, opt, sparse=sparse)
+        s.solve()
+        out.append(s)
+    return out
+
+
+def _assert_ipm_parity(so, sh, n):
+    """CPU == GPU acceptance of the reference (lib/MadNLPGPU/test/densekkt_rocm.jl:31-37): same
+    iteration count, objective, solution and multipliers atol 1e-6 -- plus per-iteration residual
+    parity (primal/dual infeasibility, complementarity, mu, delta_w), rtol 1e-5 above 1e-9."""
+    assert sh.status == so.status == "SOLVE_SUCCEEDED", (so.status, sh.status)
+    assert sh.cnt.k == so.cnt.k
+    assert sh.cnt.factorization_cnt == so.cnt.factorization_cnt
+    np.testing.assert_allclose(sh.x[:n], so.x[:n], atol=1e-6)
+    np.testing.assert_allclose(sh.y, so.y, atol=1e-6)
+    assert abs(sh.obj_val - so.obj_val) <= 1e-6 * max(1.0, abs(so.obj_val))
+    for a, b in zip(so.history, sh.history):
+        assert a.mu == b.mu and a.del_w == b.del_w
+        for fld in ("inf_pr", "inf_du", "inf_compl"):
+            va, vb = getattr(a, fld), getattr(b, fld)
+            assert abs(va - vb) <= 1e-5 * max(abs(va), 1e-9) + 1e-12, (a.k, fld, va, vb)
+
+
+@pytest.mark.parametrize("kind", ["dense", "dense_condensed", "sparse_condensed"])
+def test_ipm_hs15_cpu_vs_hip(ctx, kind):
+    from madnlp_jl_amd.problems import HS15Model
+    so, sh = _ipm_pair(kind, HS15Model(), ctx, 1e-8 if kind != "sparse_condensed" else 1e-6)
+    _assert_ipm_parity(so, sh, 2)
+    sh.kkt.close()
+
+
+@pytest.mark.parametrize("n,m,n_eq", [(10, 5, 0), (50, 10, 0), (20, 15, 2)])
+@pytest.mark.parametrize("kind", ["dense", "dense_condensed"])
+def test_ipm_dense_qp_cpu_vs_hip(ctx, kind, n, m, n_eq):
+    """reference lib/MadNLPGPU/test/densekkt_rocm.jl:4-40 on the DenseDummyQP sizes of test/madnlp_dense.jl."""
+    from madnlp_jl_amd.problems import DenseQPModel
+    so, sh = _ipm_pair(kind, DenseQPModel(n, m, n_eq), ctx, 1e-8)
+    _assert_ipm_parity(so, sh, n)
+    sh.kkt.close()
+
+
+@pytest.mark.parametrize("case", ["case30", "case118"])
+def test_ipm_sparse_qp_cpu_vs_hip(ctx, case):
+    from madnlp_jl_amd.problems import SparseQPModel
+    nlp = SparseQPModel(case)
+    so, sh = _ipm_pair("sparse_condensed", nlp, ctx, 1e-6)
+    _assert_ipm_parity(so, sh, nlp.n)
+    sh.kkt.close()
