@@ -106,6 +106,12 @@ def lib():
         raise ImportError(
             f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the KKT hot path.")
+    # PyTorch-ROCm bundles its own HIP runtime; if it is going to be used in this process it must be
+    # loaded first so that both share ONE runtime (two runtimes -> "no ROCm-capable device").
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     l = C.CDLL(LIBPATH)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(l, name)  # AttributeError if the symbol is not exported
