@@ -141,6 +141,19 @@ def cpu_baseline(P, algorithm, nsolve):
     }
 
 
+def pmc_traffic(N, args):
+    """HBM bytes per factorize! call from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, profiles/r01_pmc_traffic_factorize_N11192.md); counters cannot be
+    collected inside the timed run, so this is the value measured for the same shape, or null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if N == 11192 and os.path.exists(path):
+        try:
+            return json.load(open(path))["traffic_bytes"]
+        except Exception:
+            return None
+    return None
+
+
 # ---------------------------------------------------------------------------- main
 def main():
     args = parse_args()
@@ -245,7 +258,7 @@ def main():
             "ms_assemble": float(np.mean([a[0] for a in allms])),
             "per_rank_ms": allms,
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_FP64_TFLOPS, "traffic": pmc_traffic(N, args),
                          "kernel": "factorize! (densify + blocked LDL^T/Cholesky; N^3/3 flop per call, "
                                    "HIP-event timed on the launch stream)"},
         }

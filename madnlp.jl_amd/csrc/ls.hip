@@ -153,6 +153,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     ls->ctx = ctx;
     ls->N = N;
     ls->algo = algo;
+    if (const char* e = getenv("MNK_LOOKAHEAD")) ls->lookahead = atoi(e) != 0;  // tuning override
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
     ls->ldw = ls->Np;

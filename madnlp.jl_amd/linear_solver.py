@@ -136,8 +136,11 @@ class HipLinearSolver:
         rc = L.lib().mnk_ls_create(self.ctx.handle, self.n, _ALGO[self.opt.lapack_algorithm], C.byref(self._h))
         if rc:
             raise SymbolicException(L.lib().mnk_last_error_string().decode())
-        for key, val in (("pivot_tol", self.opt.pivot_tol), ("outer_block", self.opt.outer_block),
-                         ("lookahead", float(self.opt.lookahead))):
+        import os
+        settings = [("pivot_tol", self.opt.pivot_tol), ("outer_block", self.opt.outer_block)]
+        if "MNK_LOOKAHEAD" not in os.environ:  # tuning override handled inside the library
+            settings.append(("lookahead", float(self.opt.lookahead)))
+        for key, val in settings:
             L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(val)), "mnk_ls_set_option")
         self.info = 0
         _LIVE_OBJECTS.add(self)
