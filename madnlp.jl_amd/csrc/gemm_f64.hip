@@ -27,14 +27,15 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16;
 
-template <int WM, int WN, int MODE, bool LDL_EPI>
+template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
     const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
     const int* __restrict__ info_flag) {
     constexpr int NT = 64 * WM * WN;
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int WS = 16 * WT;  // wave tile edge (WT x WT MFMA 16x16 tiles per wave)
+    constexpr int BM = WS * WM, BN = WS * WN;
     constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
     constexpr int APIECES = (BM / 2) * BK / NT;  // 16-byte pieces per thread per k-tile
     constexpr int BPIECES = (BN / 2) * BK / NT;
@@ -115,11 +116,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
         }
     };
 
-    v4f64 acc[4][4];  // [ni][mi]
+    v4f64 acc[WT][WT];  // [ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < WT; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
 
     const int nk = (int)(K / BK);
     gload(0);
@@ -129,20 +130,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) gload(kt + 1);
-        const double* as = As + cur * BK * LDA_S + wm * 64 + l15;
-        const double* bs = Bs + cur * BK * LDB_S + wn * 64 + l15;
+        const double* as = As + cur * BK * LDA_S + wm * WS + l15;
+        const double* bs = Bs + cur * BK * LDB_S + wn * WS + l15;
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            double af[4], bf[4];
+            double af[WT], bf[WT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < WT; ++i) {
                 af[i] = as[(kk * 4 + l4) * LDA_S + i * 16];
                 bf[i] = bs[(kk * 4 + l4) * LDB_S + i * 16];
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < WT; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < WT; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
         if (kt + 1 < nk) sstore(cur ^ 1);
@@ -150,11 +151,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     }
 
     // epilogue: lane (l15, l4), reg r of acc[ni][mi] is C[row0+wm*64+mi*16+l15, col0+wn*64+ni*16+l4+4r]
-    const int64_t wrow = row0 + wm * 64, wcol = col0 + wn * 64;
+    const int64_t wrow = row0 + wm * WS, wcol = col0 + wn * WS;
     if (wrow >= M || wcol >= N) return;
-    if ((MODE == 2 || MODE == 4) && wrow + 64 <= wcol) return;  // wave tile entirely above the diagonal
+    if ((MODE == 2 || MODE == 4) && wrow + WS <= wcol) return;  // wave tile entirely above the diagonal
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < WT; ++ni) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t n = wcol + ni * 16 + l4 + 4 * r;
@@ -164,30 +165,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
                     const double sc = colscale[n];
                     double* c2p = C2 + n * ldc2 + wrow + l15;
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
+                    for (int mi = 0; mi < WT; ++mi) {
                         c2p[mi * 16] = acc[ni][mi][r];
                         cp[mi * 16] = acc[ni][mi][r] * sc;
                     }
                 } else {
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) cp[mi * 16] = acc[ni][mi][r];
+                    for (int mi = 0; mi < WT; ++mi) cp[mi * 16] = acc[ni][mi][r];
                 }
             } else {
-                double cv[4];
+                double cv[WT];
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) cv[mi] = cp[mi * 16];
+                for (int mi = 0; mi < WT; ++mi) cv[mi] = cp[mi * 16];
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) cp[mi * 16] = MODE == 4 ? cv[mi] + acc[ni][mi][r] : cv[mi] - acc[ni][mi][r];
+                for (int mi = 0; mi < WT; ++mi) cp[mi * 16] = MODE == 4 ? cv[mi] + acc[ni][mi][r] : cv[mi] - acc[ni][mi][r];
             }
         }
     }
 }
 
-template <int WM, int WN, int MODE, bool LDL_EPI>
+template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
 static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                     const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
                     double* C2, int64_t ldc2, const int* info_flag) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 16 * WT * WM, BN = 16 * WT * WN;
     const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
     int ntiles = ntm * ntn;
     if (MODE == 2 || MODE == 4) {
@@ -196,7 +197,7 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
         ntiles = nc * ntm - nc * (nc - 1) / 2;
     }
     const size_t smem = 2 * BK * ((BM + 16) + (BN + 16)) * sizeof(double);
-    auto kern = gemm_nt_kernel<WM, WN, MODE, LDL_EPI>;
+    auto kern = gemm_nt_kernel<WM, WN, WT, MODE, LDL_EPI>;
     static bool attr_set = false;
     if (!attr_set) {
         MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -217,22 +218,26 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, con
         // panel solve shape: N is one or two inner blocks wide; use a tall 256 x 64 tile
         if (N <= 64) {
             if (colscale)
-                return launch_t<4, 1, 1, true>(s, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, info_flag);
-            return launch_t<4, 1, 1, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+                return launch_t<4, 1, 4, 1, true>(s, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, info_flag);
+            return launch_t<4, 1, 4, 1, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
         }
         if (colscale)
-            return launch_t<2, 2, 1, true>(s, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, info_flag);
-        return launch_t<2, 2, 1, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+            return launch_t<2, 2, 4, 1, true>(s, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, info_flag);
+        return launch_t<2, 2, 4, 1, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
     }
     if (mode == 0) {
-        if (N <= 64) return launch_t<4, 1, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
-        return launch_t<2, 2, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        // skinny left-looking updates: 64x64 workgroup tiles of 4 waves x (32x32) keep the per-wave
+        // MFMA chain short and put >= M/64 workgroups on the chip (latency-bound shape)
+        if (N <= 64 && M >= 1024)
+            return launch_t<2, 2, 2, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        if (N <= 64) return launch_t<4, 1, 4, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        return launch_t<2, 2, 4, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
     }
     if (mode == 2) {
-        return launch_t<2, 2, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        return launch_t<2, 2, 4, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
     }
     if (mode == 4) {
-        return launch_t<2, 2, 4, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        return launch_t<2, 2, 4, 4, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
     }
     set_error("gemm_nt: bad mode %d", mode);
     return -1;

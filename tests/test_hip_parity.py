@@ -41,7 +41,8 @@ def solcmp(x, sol, atol=1e-4, rtol=1e-4):
 
 # --------------------------------------------------------------------------- MFMA tile kernel
 @pytest.mark.parametrize("mode", [0, 1, 2, 4])
-@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (128, 128, 64), (320, 192, 48), (576, 576, 512), (256, 64, 64)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (128, 128, 64), (320, 192, 48), (576, 576, 512), (256, 64, 64),
+                                   (1088, 64, 192)])
 def test_gemm_nt_tiles(ctx, mode, M, N, K):
     """Asymmetric random operands (a transposed or row/col-swapped MFMA fragment map cannot pass)."""
     if mode in (2, 4) and M != N:
