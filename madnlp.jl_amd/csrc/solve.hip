@@ -21,18 +21,6 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double* __restrict_
     __shared__ double part[4][64];
     __shared__ double xj[64];
     const int t = threadIdx.x, row = t & 63, p = t >> 6;
-    // the panel entries of this thread's row do not depend on x_j: fetch them first so that the
-    // step costs one memory round trip, not two
-    const int64_t r = j0 + 64 + (int64_t)blockIdx.x * 256 + t;
-    const bool live = r < Np;
-    double fr[64];
-    double br = 0.0;
-    {
-        const double* Fr = F + (live ? r : j0) + j0 * ld;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) fr[c] = Fr[(int64_t)c * ld];
-        if (live) br = b[r];
-    }
     double acc = 0.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -47,16 +35,18 @@ __global__ __launch_bounds__(256) void fwd_step_kernel(const double* __restrict_
         if (blockIdx.x == 0) y[j0 + row] = ldl ? v * dinv[j0 + row] : v;
     }
     __syncthreads();
-    if (live) {
+    const int64_t r = j0 + 64 + (int64_t)blockIdx.x * 256 + t;
+    if (r < Np) {
+        const double* Fr = F + r + j0 * ld;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
         for (int c = 0; c < 64; c += 4) {
-            s0 += fr[c + 0] * xj[c + 0];
-            s1 += fr[c + 1] * xj[c + 1];
-            s2 += fr[c + 2] * xj[c + 2];
-            s3 += fr[c + 3] * xj[c + 3];
+            s0 += Fr[(int64_t)(c + 0) * ld] * xj[c + 0];
+            s1 += Fr[(int64_t)(c + 1) * ld] * xj[c + 1];
+            s2 += Fr[(int64_t)(c + 2) * ld] * xj[c + 2];
+            s3 += Fr[(int64_t)(c + 3) * ld] * xj[c + 3];
         }
-        b[r] = br - ((s0 + s1) + (s2 + s3));
+        b[r] -= (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -67,19 +57,6 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double* __restrict_
     __shared__ double part[4][64];
     __shared__ double xj[64];
     const int t = threadIdx.x, c = t & 63, p = t >> 6;
-    // prefetch this thread's entries of the row panel L[j-rows, cols before] (independent of x_j)
-    const int64_t cb = (int64_t)blockIdx.x * 64;
-    const bool live = cb < j0;
-    const int lane = t & 63, w = t >> 6;
-    const int sub = lane & 15, colq = lane >> 4;
-    double fp[4][4];
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int64_t col = live ? cb + pass * 16 + w * 4 + colq : 0;
-        const double* Fp = F + j0 + 4 * sub + col * ld;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) fp[pass][q] = Fp[q];
-    }
     // xj[c] = sum_r inv(L)[r][c] * z[j0 + r]
     double acc = 0.0;
 #pragma unroll
@@ -95,12 +72,16 @@ __global__ __launch_bounds__(256) void bwd_step_kernel(const double* __restrict_
         if (blockIdx.x == 0) x[j0 + c] = v;
     }
     __syncthreads();
-    if (!live) return;
+    const int64_t cb = (int64_t)blockIdx.x * 64;
+    if (cb >= j0) return;
+    const int lane = t & 63, w = t >> 6;
+    const int sub = lane & 15, colq = lane >> 4;
     const double x0 = xj[4 * sub], x1 = xj[4 * sub + 1], x2 = xj[4 * sub + 2], x3 = xj[4 * sub + 3];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int64_t col = cb + pass * 16 + w * 4 + colq;
-        double s = (fp[pass][0] * x0 + fp[pass][1] * x1) + (fp[pass][2] * x2 + fp[pass][3] * x3);
+        const double* Fp = F + j0 + 4 * sub + col * ld;
+        double s = (Fp[0] * x0 + Fp[1] * x1) + (Fp[2] * x2 + Fp[3] * x3);
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
