@@ -41,7 +41,7 @@ struct mnk_ls {
     int algo = MNK_LDL;
     double pivot_tol = 0.0;
     int lookahead = 1;
-    mnk::DevBuf<double> fact, wbuf[2], linv, dblk, dvec, dinv, xwork;
+    mnk::DevBuf<double> fact, wbuf[2], linv, dblk, linv256, linv256t, dvec, dinv, xwork;
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
     bool factorized = false, info_valid = false;
@@ -52,3 +52,4 @@ struct mnk_ls {
 int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);
+int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s);

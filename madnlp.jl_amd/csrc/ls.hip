@@ -161,6 +161,8 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     rc |= ls->fact.alloc((size_t)ls->ld * ls->Np + SLACK);
     rc |= ls->linv.alloc((size_t)(ls->Np / NBI) * NBI * NBI);
     rc |= ls->dblk.alloc((size_t)(ls->Np / NBI) * NBI * NBI);
+    rc |= ls->linv256.alloc((size_t)((ls->Np + 255) / 256) * 65536);
+    rc |= ls->linv256t.alloc((size_t)((ls->Np + 255) / 256) * 65536);
     rc |= ls->dvec.alloc(ls->Np);
     rc |= ls->dinv.alloc(ls->Np);
     rc |= ls->xwork.alloc(2 * ls->Np);
