@@ -610,13 +610,23 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
+    constexpr int64_t NBM = 256;  // middle level: left-looking inside 256 columns, right-looking between them
     for (int64_t j = ko; j < kend; j += NBI) {
-        // left-looking inside the outer panel: bring block column j up to date with the inner
-        // blocks [ko, j) already factored (one K = j-ko product on 64 columns instead of several
-        // K = 64 right-looking updates of the whole remaining panel: 3x less traffic, deeper K)
-        if (j > ko) {
-            const double* Wp = ldl ? wbase + j : F + j + ko * ld;
-            int rc = launch_gemm_nt(s, 0, Np - j, NBI, j - ko, Wp, ldl ? ls->ldw : ld, F + j + ko * ld, ld,
+        const int64_t mo = ko + ((j - ko) / NBM) * NBM;  // start of the 256-column middle panel of block j
+        // middle level, right-looking: when a 256-column middle panel is complete, apply it to the
+        // remaining columns of the outer panel with one K = 256 product (MFMA tiles, lower part)
+        if (j == mo && j > ko) {
+            const int64_t pm = mo - NBM;  // the middle panel just finished: columns [pm, mo)
+            const double* Wp = ldl ? wbase + mo + (pm - ko) * ls->ldw : F + mo + pm * ld;
+            int rc = launch_gemm_nt(s, 2, Np - mo, kend - mo, NBM, Wp, ldl ? ls->ldw : ld, F + mo + pm * ld, ld,
+                                    F + mo + mo * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+            if (rc) return rc;
+        }
+        // inner level, left-looking inside the middle panel: bring block column j up to date with the
+        // blocks [mo, j) already factored (one K = j-mo product on 64 columns)
+        if (j > mo) {
+            const double* Wp = ldl ? wbase + j + (mo - ko) * ls->ldw : F + j + mo * ld;
+            int rc = launch_gemm_nt(s, 0, Np - j, NBI, j - mo, Wp, ldl ? ls->ldw : ld, F + j + mo * ld, ld,
                                     F + j + j * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
             if (rc) return rc;
         }

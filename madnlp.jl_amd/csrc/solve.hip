@@ -126,24 +126,32 @@ __global__ __launch_bounds__(256) void linv256_kernel(const double* __restrict__
     }
 }
 
-// x = M b for the 256x256 (column-major, ld 256) matrix M of one diagonal step: one workgroup.
-__global__ __launch_bounds__(256) void diag256_kernel(const double* __restrict__ M, const double* __restrict__ b,
-                                                      double* __restrict__ x, const double* __restrict__ dinv,
-                                                      int scale, int nrow) {
+// x = M b for the 256x256 (column-major, ld 256) triangular matrix M of one diagonal step: one
+// workgroup of 1024 threads, 4 column quarters per row (quarters that are structurally zero are
+// skipped: M is lower triangular in the forward sweep, upper in the backward one).
+__global__ __launch_bounds__(1024) void diag256_kernel(const double* __restrict__ M, const double* __restrict__ b,
+                                                       double* __restrict__ x, int upper, int nrow) {
     __shared__ double bs[SB];
-    const int t = threadIdx.x;
-    bs[t] = t < nrow ? b[t] : 0.0;
+    __shared__ double part[4][SB];
+    const int t = threadIdx.x, r = t & 255, p = t >> 8;
+    if (t < SB) bs[t] = t < nrow ? b[t] : 0.0;
     __syncthreads();
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int rb = r >> 6;
+    if (upper ? p >= rb : p <= rb) {
+        const double* Mr = M + r + (int64_t)(64 * p) * SB;
+        const double* bp = bs + 64 * p;
 #pragma unroll 8
-    for (int c = 0; c < SB; c += 4) {
-        a0 += M[t + (int64_t)(c + 0) * SB] * bs[c + 0];
-        a1 += M[t + (int64_t)(c + 1) * SB] * bs[c + 1];
-        a2 += M[t + (int64_t)(c + 2) * SB] * bs[c + 2];
-        a3 += M[t + (int64_t)(c + 3) * SB] * bs[c + 3];
+        for (int c = 0; c < 64; c += 4) {
+            a0 += Mr[(int64_t)(c + 0) * SB] * bp[c + 0];
+            a1 += Mr[(int64_t)(c + 1) * SB] * bp[c + 1];
+            a2 += Mr[(int64_t)(c + 2) * SB] * bp[c + 2];
+            a3 += Mr[(int64_t)(c + 3) * SB] * bp[c + 3];
+        }
     }
-    const double v = (a0 + a1) + (a2 + a3);
-    if (t < nrow) x[t] = scale ? v * dinv[t] : v;
+    part[p][r] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (p == 0 && r < nrow) x[r] = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
 }
 
 __global__ void scale_vec_kernel(double* __restrict__ y, const double* __restrict__ dinv, int64_t n) {
@@ -234,8 +242,8 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
     for (int64_t k = 0; k < nsteps; ++k) {
         const int64_t j0 = k * SB;
         const int ncol = (int)std::min<int64_t>(SB, Np - j0);
-        hipLaunchKernelGGL(diag256_kernel, dim3(1), dim3(256), 0, s, ls->linv256.p + k * (int64_t)(SB * SB), b + j0,
-                           y + j0, (const double*)nullptr, 0, ncol);
+        hipLaunchKernelGGL(diag256_kernel, dim3(1), dim3(1024), 0, s, ls->linv256.p + k * (int64_t)(SB * SB), b + j0,
+                           y + j0, 0, ncol);
         const int64_t below = Np - j0 - ncol;
         if (below > 0)
             hipLaunchKernelGGL(fwd_panel_kernel, dim3((unsigned)((below + 63) / 64)), dim3(256), 0, s, ls->fact.p, ld,
@@ -247,8 +255,8 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
     for (int64_t k = nsteps - 1; k >= 0; --k) {
         const int64_t j0 = k * SB;
         const int nrow = (int)std::min<int64_t>(SB, Np - j0);
-        hipLaunchKernelGGL(diag256_kernel, dim3(1), dim3(256), 0, s, ls->linv256t.p + k * (int64_t)(SB * SB), y + j0,
-                           b + j0, (const double*)nullptr, 0, nrow);
+        hipLaunchKernelGGL(diag256_kernel, dim3(1), dim3(1024), 0, s, ls->linv256t.p + k * (int64_t)(SB * SB), y + j0,
+                           b + j0, 1, nrow);
         if (j0 > 0)
             hipLaunchKernelGGL(bwd_panel_kernel, dim3((unsigned)(j0 / 64)), dim3(256), 0, s, ls->fact.p, ld, b, y, j0,
                                nrow);
