@@ -62,126 +62,6 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // ---------------------------------------------------------------------------------------
 constexpr int CB_LD = 72;  // 64 + slack: a wave reads up to 3 dead slots past its 16
 
-template <bool LDL, int T, int NL>
-__device__ __forceinline__ void panel_phase(double (&a)[T][16], double (*colbuf)[T][CB_LD], const int g0,
-                                            const int i, const int w, const bool lead, const bool (&valid)[T],
-                                            const int64_t (&trow)[T], double* __restrict__ F, const int64_t ld,
-                                            const int64_t j0, double* __restrict__ Dout,
-                                            double* __restrict__ W, const int64_t ldw,
-                                            const int64_t wcol, double* __restrict__ dvec,
-                                            double* __restrict__ dinv, int* __restrict__ info,
-                                            const double pivot_tol) {
-    const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row/column index i
-#pragma unroll 1
-    for (int g = g0; g < g0 + 4; ++g) {
-#pragma unroll
-        for (int wo = 0; wo < 4; ++wo) {
-            const int j = 4 * g + wo;
-            const bool owner = w == wo;
-            if (owner) {
-#pragma unroll
-                for (int q = 0; q < T; ++q) colbuf[wo & 1][q][pos_i] = a[q][0];
-            }
-            __syncthreads();
-            const double (*cb)[CB_LD] = colbuf[wo & 1];
-            const double piv = cb[0][wo * 16 + g];
-            double inv, lscale, dval;  // update factor 1/piv, column scale, recorded diagonal
-            if (LDL) {
-                const bool zero = !(fabs(piv) > pivot_tol) || !(fabs(piv) <= DBL_MAX);
-                inv = fast_rcp(zero ? 1.0 : piv);  // harmless pivot; dvec records the zero
-                lscale = inv;
-                dval = zero ? 0.0 : piv;
-            } else {
-                // not positive definite (also catches NaN/Inf): flag the first failing pivot; the
-                // remaining steps run on harmless values and every later kernel is a no-op.
-                const bool bad = !(piv > 0.0) || !(piv <= DBL_MAX);
-                if (bad && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + j + 1));
-                const double rs = fast_rsqrt(bad ? 1.0 : piv);
-                lscale = rs;
-                inv = rs * rs;
-                dval = bad ? 1.0 : piv * rs;  // L[j][j]
-            }
-            // w_c of the live columns of this wave: c = 4*(g+cl)+w  <->  slot w*16 + g + cl
-            double wc[NL];
-#pragma unroll
-            for (int cl = 0; cl < NL; ++cl) wc[cl] = cb[0][w * 16 + g + cl];
-#pragma unroll
-            for (int q = 0; q < T; ++q) {
-                const double my_w = cb[q][pos_i];
-                // rows at/above the pivot of the diagonal tile take no part (their entries of column
-                // j are upper-triangle values that may be anything, including NaN)
-                const double my_u = (q == 0 && i <= j) ? 0.0 : my_w * inv;
-                if (w > wo) a[q][0] = fma(-my_u, wc[0], a[q][0]);
-#pragma unroll
-                for (int cl = 1; cl < NL; ++cl) a[q][cl] = fma(-my_u, wc[cl], a[q][cl]);
-                if (owner) {
-                    const double fin = LDL ? my_u : my_w * lscale;  // L[row][j]
-                    if (q == 0)
-                        a[0][0] = (i > j) ? fin : ((i == j) ? (LDL ? 1.0 : dval) : a[0][0]);
-                    else {
-                        a[q][0] = fin;
-                        if (LDL && valid[q]) W[trow[q] + i + (wcol + j) * ldw] = my_w;
-                    }
-                }
-            }
-            if (lead && owner && i == j) {
-                dvec[j0 + j] = dval;
-                dinv[j0 + j] = LDL ? inv : 1.0;
-                Dout[j + 64 * j] = dval;  // L[j][j], or d_j for LDL (as LAPACK stores it)
-            }
-        }
-        // column group g is final: store it (diagonal tile: strictly lower part, by the leader), rotate
-        const int c = 4 * g + w;
-        if (lead && i > c) Dout[i + 64 * c] = a[0][0];
-#pragma unroll
-        for (int q = 1; q < T; ++q)
-            if (valid[q]) F[trow[q] + i + (j0 + c) * ld] = a[q][0];
-#pragma unroll
-        for (int q = 0; q < T; ++q)
-#pragma unroll
-            for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
-    }
-}
-
-template <bool LDL, int T>
-__global__ __launch_bounds__(256) void panel64_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
-                                                       double* __restrict__ Dout, double* __restrict__ W,
-                                                       int64_t ldw, int64_t wcol,
-                                                       double* __restrict__ dvec, double* __restrict__ dinv,
-                                                       int* __restrict__ info, double pivot_tol) {
-    __shared__ double colbuf[2][T][CB_LD];
-    if (*info != 0) return;
-
-    const int tid = threadIdx.x;
-    const int i = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool lead = blockIdx.x == 0;
-
-    // row tiles of this workgroup; a tile past the end aliases the diagonal tile (loaded,
-    // carried along, never stored) so that the elimination loop is branch-free.
-    int64_t trow[T];
-    bool valid[T];
-    trow[0] = j0;
-    valid[0] = true;
-#pragma unroll
-    for (int q = 1; q < T; ++q) {
-        const int64_t r = j0 + 64 * ((int64_t)blockIdx.x * (T - 1) + q);
-        valid[q] = r < Np;
-        trow[q] = valid[q] ? r : j0;
-    }
-
-    double a[T][16];
-#pragma unroll
-    for (int q = 0; q < T; ++q)
-#pragma unroll
-        for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
-
-    panel_phase<LDL, T, 16>(a, colbuf, 0, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase<LDL, T, 12>(a, colbuf, 4, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase<LDL, T, 8>(a, colbuf, 8, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-}
-
 // ---------------------------------------------------------------------------------------
 // Rank-4 variant of the fused panel kernel (the one used): ONE barrier per group of 4 pivots.
 // The four waves publish their raw current columns together; every thread then factors the
@@ -362,109 +242,129 @@ __global__ __launch_bounds__(256) void panel64r4_kernel(double* __restrict__ F, 
 }
 
 // ---------------------------------------------------------------------------------------
-// Wave-group variant (the one launched): G groups of 4 waves per workgroup, each group owns TG
-// row tiles (group 0's first tile is the diagonal block).  More resident waves per SIMD hide
-// the fp64 latencies, fewer registers per wave avoid AGPR shuffling, and the second factors
-// y_k(c) of the rank-4 update are computed ONCE (they are the substituted rows of the diagonal
-// tile) and shared through LDS instead of being recomputed by every wave.
+// Software-pipelined rank-4 panel kernel (the one launched).  Same arithmetic as
+// panel64r4_kernel, different schedule: after the own-row substitution of group g every wave
+// first updates only the column it contributes to the NEXT pivot block, publishes it and reads
+// the next raw 4x4 block; the dependent rsqrt/rcp chain of group g+1 then sits in the same
+// basic block as the bulk rank-4 update of group g, so the compiler interleaves the two
+// independent instruction streams and the chain latency hides behind the FMAs.  The second
+// factors y_k(c) are the substituted rows of the diagonal tile, which every wave already holds
+// lane-wise: they are fetched with v_readlane (uniform operands) instead of being recomputed.
 // ---------------------------------------------------------------------------------------
-template <bool LDL, int G, int TG, int NL>
-__device__ __forceinline__ void panel_phase_g(double (&a)[TG][16], double (*raw)[4][CB_LD], double (*ybuf)[CB_LD],
-                                              const int g0, const int i, const int w, const int gidx,
-                                              const bool lead, const bool (&valid)[TG], const int64_t (&trow)[TG],
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool LDL>
+__device__ __forceinline__ void factor_piv4(const double (*cb0)[CB_LD], const int g, const double pivot_tol, Piv4& P,
+                                            double (&dg)[4], int& fail) {
+    // 4x4 pivot block: rows/cols 4g..4g+3 of the diagonal tile; slot(4g+r) = r*16 + g
+    const double p00 = cb0[0][0 * 16 + g];
+    const double p10 = cb0[0][1 * 16 + g], p11 = cb0[1][1 * 16 + g];
+    const double p20 = cb0[0][2 * 16 + g], p21 = cb0[1][2 * 16 + g], p22 = cb0[2][2 * 16 + g];
+    const double p30 = cb0[0][3 * 16 + g], p31 = cb0[1][3 * 16 + g], p32 = cb0[2][3 * 16 + g];
+    const double p33 = cb0[3][3 * 16 + g];
+    fail = 0;
+    if (LDL) {
+        auto piv = [&](double d, double& sc, double& rec) {
+            const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
+            sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
+            rec = zero ? 0.0 : d;
+        };
+        piv(p00, P.s0, dg[0]);
+        P.c10 = p10; P.c20 = p20; P.c30 = p30;
+        const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
+        piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
+        P.c21 = fma(-x20, P.c10, p21);
+        P.c31 = fma(-x30, P.c10, p31);
+        const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
+        piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
+        P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
+        const double x32 = P.c32 * P.s2;
+        piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
+    } else {
+        auto piv = [&](double t, double& sc, double& rec, int k) {
+            const bool bad = !(t > 0.0) || !(t <= DBL_MAX);  // not positive definite / NaN / Inf
+            fail = (bad && fail == 0) ? k + 1 : fail;
+            sc = fast_rsqrt(bad ? 1.0 : t);
+            rec = bad ? 1.0 : t * sc;
+        };
+        piv(p00, P.s0, dg[0], 0);
+        P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
+        piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
+        P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
+        P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
+        piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
+        P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
+        piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
+    }
+}
+
+template <bool LDL, int T, int NL>
+__device__ __forceinline__ void panel_phase_p(double (&a)[T][16], double (*raw)[4][CB_LD], const int g0, Piv4& P,
+                                              double (&dg)[4], const int i, const int w, const bool lead,
+                                              const bool (&valid)[T], const int64_t (&trow)[T],
                                               double* __restrict__ F, const int64_t ld, const int64_t j0,
                                               double* __restrict__ Dout, double* __restrict__ W, const int64_t ldw,
                                               const int64_t wcol, double* __restrict__ dvec,
                                               double* __restrict__ dinv, int* __restrict__ info,
                                               const double pivot_tol) {
-    constexpr int TT = G * TG;
     const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row index i
 #pragma unroll 1
     for (int g = g0; g < g0 + 4; ++g) {
-        double (*cb)[4][CB_LD] = raw + (g & 1) * TT;  // [tile][k][slot]
-        double (*yb)[CB_LD] = ybuf + (g & 1) * 4;     // [k][slot]
+        double (*cb)[4][CB_LD] = raw + (g & 1) * T;  // raw columns of group g: [tile][k][slot]
+        // ---- own rows: forward substitution against the factored pivot block of group g
+        double x[T][4], v[T][4];
 #pragma unroll
-        for (int q = 0; q < TG; ++q) cb[gidx * TG + q][w][pos_i] = a[q][0];
-        __syncthreads();
-        // ---- 4x4 pivot block: rows/cols 4g..4g+3 of the diagonal tile; slot(4g+r) = r*16 + g
-        const double p00 = cb[0][0][0 * 16 + g];
-        const double p10 = cb[0][0][1 * 16 + g], p11 = cb[0][1][1 * 16 + g];
-        const double p20 = cb[0][0][2 * 16 + g], p21 = cb[0][1][2 * 16 + g], p22 = cb[0][2][2 * 16 + g];
-        const double p30 = cb[0][0][3 * 16 + g], p31 = cb[0][1][3 * 16 + g], p32 = cb[0][2][3 * 16 + g];
-        const double p33 = cb[0][3][3 * 16 + g];
-        Piv4 P;
-        double dg[4];  // recorded diagonal: L[k][k] (Cholesky) or d_k (LDL, 0 for a zero pivot)
-        int fail = 0;
-        if (LDL) {
-            auto piv = [&](double d, double& sc, double& rec) {
-                const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
-                sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
-                rec = zero ? 0.0 : d;
-            };
-            piv(p00, P.s0, dg[0]);
-            P.c10 = p10; P.c20 = p20; P.c30 = p30;
-            const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
-            piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
-            P.c21 = fma(-x20, P.c10, p21);
-            P.c31 = fma(-x30, P.c10, p31);
-            const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
-            piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
-            P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
-            const double x32 = P.c32 * P.s2;
-            piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
-        } else {
-            auto piv = [&](double t, double& sc, double& rec, int k) {
-                const bool bad = !(t > 0.0) || !(t <= DBL_MAX);  // not positive definite / NaN / Inf
-                fail = (bad && fail == 0) ? k + 1 : fail;
-                sc = fast_rsqrt(bad ? 1.0 : t);
-                rec = bad ? 1.0 : t * sc;
-            };
-            piv(p00, P.s0, dg[0], 0);
-            P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
-            piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
-            P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
-            P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
-            piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
-            P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
-            piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
-            if (fail != 0 && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + 4 * g + fail));
-        }
-        // ---- own rows: forward substitution against the pivot block
-        double x[TG][4], v[TG][4];
-#pragma unroll
-        for (int q = 0; q < TG; ++q) {
-            const int tq = gidx * TG + q;
-            sub4<LDL>(P, cb[tq][0][pos_i], cb[tq][1][pos_i], cb[tq][2][pos_i], cb[tq][3][pos_i], x[q], v[q]);
-        }
-        // the substituted rows of the diagonal tile are everybody's second factors: share them
-        if (gidx == 0 && w == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) yb[k][pos_i] = LDL ? v[0][k] : x[0][k];
-        }
-        __syncthreads();
-        if (gidx == 0) {
+        for (int q = 0; q < T; ++q)
+            sub4<LDL>(P, cb[q][0][pos_i], cb[q][1][pos_i], cb[q][2][pos_i], cb[q][3][pos_i], x[q], v[q]);
+        {
             // rows above the pivot block of the diagonal tile hold upper-triangle values: no part
             const bool above = i < 4 * g;
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[0][k] = above ? 0.0 : x[0][k];
         }
-        // ---- rank-4 update of the live columns of this wave: c = 4*(g+cl)+w, slot w*16+g+cl
+        // second factors y_k(c) = substituted row c of the diagonal tile (lane c of x[0] / v[0])
+        auto second = [&](int c, double (&y)[4]) {
 #pragma unroll
-        for (int cl = 1; cl < NL; ++cl) {
-            const int sl = w * 16 + g + cl;
-            const double y0 = yb[0][sl], y1 = yb[1][sl], y2 = yb[2][sl], y3 = yb[3][sl];
+            for (int k = 0; k < 4; ++k) y[k] = readlane_f64(LDL ? v[0][k] : x[0][k], c);
+        };
+        Piv4 Pn = P;
+        double dgn[4] = {dg[0], dg[1], dg[2], dg[3]};
+        const bool has_next = g < 15;
+        if (has_next) {
+            // early: the column this wave contributes to the next pivot block (slot 1), then publish it
+            double y[4];
+            second((4 * (g + 1) + w) & 63, y);
 #pragma unroll
-            for (int q = 0; q < TG; ++q)
-                a[q][cl] = fma(-x[q][3], y3, fma(-x[q][2], y2, fma(-x[q][1], y1, fma(-x[q][0], y0, a[q][cl]))));
-            // keep the scheduler from hoisting every slot's LDS loads at once (register pressure)
-            if ((cl & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < T; ++q)
+                a[q][1] = fma(-x[q][3], y[3], fma(-x[q][2], y[2], fma(-x[q][1], y[1], fma(-x[q][0], y[0], a[q][1]))));
+            double (*nb)[4][CB_LD] = raw + ((g + 1) & 1) * T;
+#pragma unroll
+            for (int q = 0; q < T; ++q) nb[q][w][pos_i] = a[q][1];
+            __syncthreads();
+            // ---- dependent chain of group g+1 (independent of the bulk update below)
+            int fail;
+            factor_piv4<LDL>(nb[0], g + 1, pivot_tol, Pn, dgn, fail);
+            if (!LDL && fail != 0 && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + 4 * (g + 1) + fail));
         }
-        // ---- the column this wave finishes in this group
+        // ---- bulk rank-4 update of the remaining live columns of this wave (slots 2..NL-1)
+#pragma unroll
+        for (int cl = 2; cl < NL; ++cl) {
+            double y[4];
+            second((4 * (g + cl) + w) & 63, y);
+#pragma unroll
+            for (int q = 0; q < T; ++q)
+                a[q][cl] = fma(-x[q][3], y[3], fma(-x[q][2], y[2], fma(-x[q][1], y[1], fma(-x[q][0], y[0], a[q][cl]))));
+        }
+        // ---- the column this wave finishes in this group (slot 0)
         const int c0 = 4 * g + w;
 #pragma unroll
-        for (int q = 0; q < TG; ++q) {
+        for (int q = 0; q < T; ++q) {
             const double xw = w == 0 ? x[q][0] : (w == 1 ? x[q][1] : (w == 2 ? x[q][2] : x[q][3]));  // L[row][c0]
-            if (q == 0 && gidx == 0) {
+            if (q == 0) {
                 if (lead) {
                     if (i > c0) Dout[i + 64 * c0] = xw;
                     if (i == c0) {
@@ -485,45 +385,58 @@ __device__ __forceinline__ void panel_phase_g(double (&a)[TG][16], double (*raw)
         }
         // rotate: the next column group moves to slot 0
 #pragma unroll
-        for (int q = 0; q < TG; ++q)
+        for (int q = 0; q < T; ++q)
 #pragma unroll
             for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
+        P = Pn;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dg[k] = dgn[k];
     }
 }
 
-template <bool LDL, int G, int TG>
-__global__ __launch_bounds__(256 * G) void panel64g_kernel(double* __restrict__ F, int64_t ld, int64_t j0,
-                                                            int64_t Np, double* __restrict__ Dout,
-                                                            double* __restrict__ W, int64_t ldw, int64_t wcol,
-                                                            double* __restrict__ dvec, double* __restrict__ dinv,
-                                                            int* __restrict__ info, double pivot_tol) {
-    constexpr int TT = G * TG;
-    __shared__ double raw[2 * TT][4][CB_LD];
-    __shared__ double ybuf[2 * 4][CB_LD];
+template <bool LDL, int T>
+__global__ __launch_bounds__(256) void panel64p_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
+                                                        double* __restrict__ Dout, double* __restrict__ W,
+                                                        int64_t ldw, int64_t wcol, double* __restrict__ dvec,
+                                                        double* __restrict__ dinv, int* __restrict__ info,
+                                                        double pivot_tol) {
+    __shared__ double raw[2 * T][4][CB_LD];
     if (*info != 0) return;
     const int tid = threadIdx.x;
     const int i = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wv & 3, gidx = wv >> 2;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool lead = blockIdx.x == 0;
-    int64_t trow[TG];
-    bool valid[TG];
+    int64_t trow[T];
+    bool valid[T];
+    trow[0] = j0;
+    valid[0] = true;
 #pragma unroll
-    for (int q = 0; q < TG; ++q) {
-        const int tq = gidx * TG + q;  // tile index inside the workgroup; tile 0 = diagonal block
-        const int64_t r = tq == 0 ? j0 : j0 + 64 * ((int64_t)blockIdx.x * (TT - 1) + tq);
+    for (int q = 1; q < T; ++q) {
+        const int64_t r = j0 + 64 * ((int64_t)blockIdx.x * (T - 1) + q);
         valid[q] = r < Np;
         trow[q] = valid[q] ? r : j0;  // a tile past the end aliases the diagonal tile (never stored)
     }
-    double a[TG][16];
+    double a[T][16];
 #pragma unroll
-    for (int q = 0; q < TG; ++q)
+    for (int q = 0; q < T; ++q)
 #pragma unroll
         for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
 
-#define MNK_PHASE(NLV, G0)                                                                                       \
-    panel_phase_g<LDL, G, TG, NLV>(a, raw, ybuf, G0, i, w, gidx, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, \
-                                   dvec, dinv, info, pivot_tol)
+    // prologue: raw columns of group 0, first pivot block
+    const int pos_i = (i & 3) * 16 + (i >> 2);
+#pragma unroll
+    for (int q = 0; q < T; ++q) raw[q][w][pos_i] = a[q][0];
+    __syncthreads();
+    Piv4 P;
+    double dg[4];
+    {
+        int fail;
+        factor_piv4<LDL>(raw[0], 0, pivot_tol, P, dg, fail);
+        if (!LDL && fail != 0 && lead && tid == 0) atomicCAS(info, 0, (int)(j0 + fail));
+    }
+#define MNK_PHASE(NLV, G0)                                                                                      \
+    panel_phase_p<LDL, T, NLV>(a, raw, G0, P, dg, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, \
+                               dinv, info, pivot_tol)
     MNK_PHASE(16, 0);
     MNK_PHASE(12, 4);
     MNK_PHASE(8, 8);
@@ -596,15 +509,6 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 
 using namespace mnk;
 
-template <bool LDL, int G, int TG>
-static void launch_panel(mnk_ls* ls, hipStream_t s, int64_t j, int64_t ntile, double* wbase, int64_t wcol) {
-    constexpr int TT = G * TG;
-    const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));
-    hipLaunchKernelGGL((panel64g_kernel<LDL, G, TG>), dim3(grid), dim3(256 * G), 0, s, ls->fact.p, ls->ld, j,
-                       ls->Np, ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, wcol, ls->dvec.p, ls->dinv.p,
-                       ls->info_dev.p, ls->pivot_tol);
-}
-
 // factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
 static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase) {
     const int64_t Np = ls->Np, ld = ls->ld;
@@ -640,9 +544,8 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // tiles per workgroup (incl. the diagonal tile)
         int T = 2;
         while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
-        // MNK_PANEL_WG=g selects the wave-group variant (2 groups of 4 waves, 2 tiles each): measured
-        // slower than the single-group rank-4 kernel on gfx950 (profiles/), kept for experiments.
-        static const bool use_groups = getenv("MNK_PANEL_WG") != nullptr;
+        // MNK_PANEL_R4=1 selects the non-pipelined rank-4 kernel (kept for A/B measurements)
+        static const bool use_r4 = getenv("MNK_PANEL_R4") != nullptr;
 #define MNK_LAUNCH_R4(TT)                                                                                     \
     do {                                                                                                      \
         const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));                              \
@@ -655,16 +558,30 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
                                ls->dblk.p + (j / NBI) * 4096, (double*)nullptr, (int64_t)0, (int64_t)0,       \
                                ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                        \
     } while (0)
-#define MNK_LAUNCH_PANEL(GG, TG)                                                  \
-    do {                                                                          \
-        if (ldl) launch_panel<true, GG, TG>(ls, s, j, ntile, wbase, j - ko);      \
-        else launch_panel<false, GG, TG>(ls, s, j, ntile, nullptr, 0);            \
+#define MNK_LAUNCH_P(TT)                                                                                      \
+    do {                                                                                                      \
+        const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));                              \
+        if (ldl)                                                                                              \
+            hipLaunchKernelGGL((panel64p_kernel<true, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,        \
+                               ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, j - ko, ls->dvec.p,             \
+                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                                    \
+        else                                                                                                  \
+            hipLaunchKernelGGL((panel64p_kernel<false, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,       \
+                               ls->dblk.p + (j / NBI) * 4096, (double*)nullptr, (int64_t)0, (int64_t)0,       \
+                               ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                        \
     } while (0)
-        if (use_groups) MNK_LAUNCH_PANEL(2, 2);
-        else if (T == 2) MNK_LAUNCH_R4(2);
-        else if (T == 3) MNK_LAUNCH_R4(3);
-        else if (T == 5) MNK_LAUNCH_R4(5);
-        else MNK_LAUNCH_R4(7);
+        if (use_r4) {
+            if (T == 2) MNK_LAUNCH_R4(2);
+            else if (T == 3) MNK_LAUNCH_R4(3);
+            else if (T == 5) MNK_LAUNCH_R4(5);
+            else MNK_LAUNCH_R4(7);
+        } else {
+            if (T == 2) MNK_LAUNCH_P(2);
+            else if (T == 3) MNK_LAUNCH_P(3);
+            else if (T == 5) MNK_LAUNCH_P(5);
+            else MNK_LAUNCH_P(7);
+        }
+#undef MNK_LAUNCH_P
 #undef MNK_LAUNCH_R4
 #undef MNK_LAUNCH_PANEL
     }
