@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--case", default="case1354pegase")
     ap.add_argument("--algorithm", default="BUNCHKAUFMAN", choices=["BUNCHKAUFMAN", "CHOLESKY", "LDL"])
     ap.add_argument("--nsolve", type=int, default=2)
-    ap.add_argument("--outer-block", type=int, default=256)
+    ap.add_argument("--outer-block", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="test-only: exercise the multi-process harness on CPU (gloo) without any kernel")

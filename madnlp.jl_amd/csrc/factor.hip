@@ -544,8 +544,9 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // tiles per workgroup (incl. the diagonal tile)
         int T = 2;
         while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
-        // MNK_PANEL_R4=1 selects the non-pipelined rank-4 kernel (kept for A/B measurements)
-        static const bool use_r4 = getenv("MNK_PANEL_R4") != nullptr;
+        // MNK_PANEL_PIPE=1 selects the software-pipelined variant: measured 15-20 % SLOWER than the plain
+        // rank-4 kernel on gfx950 (v_readlane traffic outweighs the hidden chain), kept for A/B runs.
+        static const bool use_r4 = getenv("MNK_PANEL_PIPE") == nullptr;
 #define MNK_LAUNCH_R4(TT)                                                                                     \
     do {                                                                                                      \
         const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));                              \

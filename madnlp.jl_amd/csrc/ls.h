@@ -37,7 +37,7 @@ struct mnk_dc {
 
 struct mnk_ls {
     mnk_ctx* ctx = nullptr;
-    int64_t N = 0, Np = 0, ld = 0, ldw = 0, nbo = 256;
+    int64_t N = 0, Np = 0, ld = 0, ldw = 0, nbo = 512;
     int algo = MNK_LDL;
     double pivot_tol = 0.0;
     int lookahead = 1;

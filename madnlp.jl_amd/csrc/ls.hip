@@ -93,7 +93,7 @@ int mnk_ctx_create(int device, void* stream, mnk_ctx** out) {
     // round-robin over the 8 XCDs), the update stream all the others.  Fallback: stream priorities.
     int want = 0;
     if (const char* e = getenv("MNK_PANEL_CUS")) want = atoi(e);
-    else want = c->num_cu >= 128 ? 32 : 0;
+    else want = c->num_cu >= 128 ? 64 : 0;
     if (want > 0 && want < c->num_cu) {
         const int words = (c->num_cu + 31) / 32;
         std::vector<uint32_t> mp(words, 0u), mu(words, 0u);

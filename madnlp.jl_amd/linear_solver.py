@@ -112,7 +112,7 @@ class HipSolverOptions:
     BUNCHKAUFMAN (the reference default) maps to the static-pivot LDL^T."""
     lapack_algorithm: str = BUNCHKAUFMAN
     pivot_tol: float = 0.0
-    outer_block: int = 256
+    outer_block: int = 512
     lookahead: bool = True
 
 
