@@ -540,7 +540,9 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // Tiles per workgroup: few (little redundant diagonal work, short steps) when the whole chip
         // is available, many when the panel stream owns only `panel_cus` CUs (look-ahead): one
         // workgroup per CU, the extra rank-one work hides behind the next pivot's latency chain.
-        const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp) ? ls->ctx->panel_cus : 512;
+        const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp)           ? ls->ctx->panel_cus
+                            : (ls->lookahead && ls->ctx->panel_cus_big > 0 && s == ls->ctx->sp_big) ? ls->ctx->panel_cus_big
+                                                                                                      : 512;
         // tiles per workgroup (incl. the diagonal tile)
         int T = 2;
         while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
@@ -620,7 +622,8 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     } else {
         // look-ahead: panel stream sp (high priority) factors panel k+1 while the update
         // stream su applies panel k to the rest of the trailing matrix.
-        hipStream_t sp = ctx->sp, su = ctx->su;
+        const bool big = ls->N >= 24000 && ctx->sp_big != nullptr;
+        hipStream_t sp = big ? ctx->sp_big : ctx->sp, su = big ? ctx->su_big : ctx->su;
         if ((int64_t)ctx->ev_panel.size() < npanel + 1) {
             const size_t old = ctx->ev_panel.size();
             ctx->ev_panel.resize(npanel + 1);

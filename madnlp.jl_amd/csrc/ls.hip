@@ -91,22 +91,27 @@ int mnk_ctx_create(int device, void* stream, mnk_ctx** out) {
     // with the MFMA-saturating trailing update slows them 4-5x (measured), so the two streams
     // get disjoint CU sets: the panel stream the first `panel_cus` mask bits (bits are dealt
     // round-robin over the 8 XCDs), the update stream all the others.  Fallback: stream priorities.
-    int want = 0;
-    if (const char* e = getenv("MNK_PANEL_CUS")) want = atoi(e);
-    else want = c->num_cu >= 128 ? 64 : 0;
-    if (want > 0 && want < c->num_cu) {
+    auto make_pair = [&](int want, hipStream_t& sp, hipStream_t& su) -> bool {
+        if (want <= 0 || want >= c->num_cu) return false;
         const int words = (c->num_cu + 31) / 32;
         std::vector<uint32_t> mp(words, 0u), mu(words, 0u);
         for (int b = 0; b < c->num_cu; ++b) (b < want ? mp : mu)[b / 32] |= 1u << (b % 32);
-        hipError_t e1 = hipExtStreamCreateWithCUMask(&c->sp, (uint32_t)words, mp.data());
-        hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&c->su, (uint32_t)words, mu.data()) : e1;
-        if (e1 == hipSuccess && e2 == hipSuccess) {
-            c->panel_cus = want;
-        } else {
-            (void)hipGetLastError();
-            if (c->sp) { (void)hipStreamDestroy(c->sp); c->sp = nullptr; }
-            c->su = nullptr;
-        }
+        hipError_t e1 = hipExtStreamCreateWithCUMask(&sp, (uint32_t)words, mp.data());
+        hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&su, (uint32_t)words, mu.data()) : e1;
+        if (e1 == hipSuccess && e2 == hipSuccess) return true;
+        (void)hipGetLastError();
+        if (sp) { (void)hipStreamDestroy(sp); sp = nullptr; }
+        su = nullptr;
+        return false;
+    };
+    // default partitions (measured, profiles/): 64 panel CUs while the panel chain is the bottleneck
+    // (N ~ 1e4), 32 once the trailing update dominates (N >~ 3e4); MNK_PANEL_CUS forces one value.
+    if (const char* e = getenv("MNK_PANEL_CUS")) {
+        const int want = atoi(e);
+        if (make_pair(want, c->sp, c->su)) c->panel_cus = want;
+    } else if (c->num_cu >= 128) {
+        if (make_pair(64, c->sp, c->su)) c->panel_cus = 64;
+        if (make_pair(32, c->sp_big, c->su_big)) c->panel_cus_big = 32;
     }
     if (!c->sp) {
         int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
@@ -129,6 +134,8 @@ int mnk_ctx_destroy(mnk_ctx* c) {
     for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
+    if (c->sp_big) (void)hipStreamDestroy(c->sp_big);
+    if (c->su_big) (void)hipStreamDestroy(c->su_big);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
