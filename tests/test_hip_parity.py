@@ -521,3 +521,52 @@ def test_ipm_sparse_qp_cpu_vs_hip(ctx, case):
     so, sh = _ipm_pair("sparse_condensed", nlp, ctx, 1e-6)
     _assert_ipm_parity(so, sh, nlp.n)
     sh.kkt.close()
+
+
+# --------------------------------------------------------------------------- orchestration stress
+@pytest.mark.parametrize("N", [2500, 4672])
+@pytest.mark.parametrize("alg", [mj.CHOLESKY, mj.LDL])
+@pytest.mark.parametrize("nbo,la", [(128, False), (256, True), (512, True), (1024, False), (192, True)])
+def test_factorization_schedules_agree(ctx, N, alg, nbo, la):
+    """Every blocking / look-ahead schedule must produce the same factor (to rounding) and the same
+    solve: several outer panels, a ragged last panel, outer widths that are not multiples of the
+    256-column middle level, with and without the two-stream look-ahead."""
+    rng = np.random.default_rng(N)
+    R = rng.standard_normal((N, 96))
+    A = np.asfortranarray(R @ R.T + np.diag(10.0 ** rng.uniform(-2, 3, N)))
+    if alg == mj.LDL:  # make it quasi-definite: negate a trailing block (LDL^T without pivoting exists)
+        k = N // 5
+        A[N - k:, N - k:] *= -1.0
+        A[N - k:, N - k:] -= np.eye(k) * 5.0
+        A = np.asfortranarray((A + A.T) / 2)
+    dA = torch.from_numpy(A).cuda()  # column-major view of a symmetric matrix
+    M = mj.HipLinearSolver(dA, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, outer_block=nbo, lookahead=la))
+    M.factorize()
+    ref_alg = CHOLESKY if alg == mj.CHOLESKY else BUNCHKAUFMAN
+    ref = LapackCPUSolver(A, ref_alg).factorize()
+    assert M.inertia() == ref.inertia()
+    b = rng.standard_normal(N)
+    x = M.solve_linear_system(b.copy())
+    nrm = np.abs(A).sum(axis=1).max()
+    res = np.abs(A @ x - b).max() / (nrm * np.abs(x).max() + np.abs(b).max())
+    assert res <= 1e-13, res
+    xr = ref.solve_linear_system(b.copy())
+    assert np.abs(x - xr).max() <= 1e-8 * np.abs(xr).max()
+    M.close()
+
+
+def test_repeated_factorizations_are_deterministic(ctx):
+    """Refactorizing the same matrix (the IPM does it every iteration) gives bit-identical factors:
+    no race between the look-ahead streams, no stale state between calls."""
+    rng = np.random.default_rng(11)
+    N = 3000
+    R = rng.standard_normal((N, 64))
+    A = np.asfortranarray(R @ R.T + N * np.eye(N))
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY))
+    M.factorize()
+    L0, _ = M.get_factor()
+    for _ in range(4):
+        M.factorize()
+        L1, _ = M.get_factor()
+        assert np.array_equal(np.tril(L0), np.tril(L1))
+    M.close()
