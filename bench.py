@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1,
                     help="independent NLP instances per GPU, each on its own context/stream (BASELINE config 5 "
                          "uses 16 per GPU); a step advances every instance by one iteration")
+    ap.add_argument("--concurrency", type=int, default=4,
+                    help="contexts (stream sets) the batch is spread over; more than ~4 oversubscribes the "
+                         "hardware queues (measured: 16 contexts run 2.6x slower than 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="test-only: exercise the multi-process harness on CPU (gloo) without any kernel")
@@ -180,12 +183,13 @@ def main():
     # independent instances: seed = base + rank * batch + b; instance 0 uses the bench stream
     base_seed = OPF_CASES[args.case][0] + rank * args.batch
     insts = []
+    ctxs = [(ctx, tstream)]
     for bidx in range(args.batch):
-        if bidx == 0:
-            ictx, istream = ctx, tstream
-        else:
-            istream = torch.cuda.Stream(dev)
-            ictx = mj.HipContext(local, stream=istream.cuda_stream)
+        slot = bidx % max(1, args.concurrency)
+        if slot >= len(ctxs):
+            st = torch.cuda.Stream(dev)
+            ctxs.append((mj.HipContext(local, stream=st.cuda_stream), st))
+        ictx, istream = ctxs[slot]
         Pb = opf_shaped(args.case, seed=base_seed + bidx, du=1e-8)
         kb = mj.SparseCondensedKKTSystem(
             Pb.n, Pb.m, Pb.jac_I, Pb.jac_J, Pb.hess_I, Pb.hess_J, Pb.ind_ineq, Pb.ind_lb, Pb.ind_ub, ctx=ictx,
