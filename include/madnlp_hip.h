@@ -188,6 +188,11 @@ int mnk_gemm_nt(mnk_ctx* ctx, int mode, int64_t M, int64_t N, int64_t K,
                 const double* A, int64_t lda, const double* B, int64_t ldb,
                 double* C, int64_t ldc);
 
+/* Diagnostics (tools/microbench_update.py): time `reps` lower-tile trailing updates C -= A*A^T under the
+ * schedules the factorization uses (static tiling / tile queue; context, update, update+panel streams). */
+int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const double* A, int64_t lda,
+                     double* C, double* C2, int64_t ldc, int reps, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

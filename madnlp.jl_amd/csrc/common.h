@@ -89,7 +89,7 @@ struct mnk_ctx {
     hipStream_t sp_big = nullptr, su_big = nullptr;
     int panel_cus_big = 0;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    std::vector<hipEvent_t> ev_panel, ev_next;
+    std::vector<hipEvent_t> ev_panel, ev_next, ev_next2;
     int num_cu = 256;
 };
 
@@ -102,5 +102,16 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K,
                    const double* A, int64_t lda, const double* B, int64_t ldb,
                    double* C, int64_t ldc, const double* colscale, double* C2, int64_t ldc2,
                    const int* info_flag);
+int launch_gemm_nt_lower_small(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag);
+int gemm_nt_lower_tiles(int64_t M, int64_t N);
+int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double* C, int64_t ldc);
+int launch_gemm_nt_lower_range(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag,
+                               int tile_begin, int tile_count);
+int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                         const double* B, int64_t ldb, double* C, int64_t ldc, int* counter, int nwg,
+                         const int* info_flag);
 
 }  // namespace mnk

@@ -510,7 +510,10 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 using namespace mnk;
 
 // factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
-static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase) {
+// `second_half_ready` (optional): event to wait for before the first kernel that touches the columns
+// beyond the first middle panel (the look-ahead delivers the outer panel's columns in two pieces).
+static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
+                              hipEvent_t second_half_ready = nullptr) {
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
@@ -520,9 +523,15 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // middle level, right-looking: when a 256-column middle panel is complete, apply it to the
         // remaining columns of the outer panel with one K = 256 product (MFMA tiles, lower part)
         if (j == mo && j > ko) {
+            if (second_half_ready != nullptr && j == ko + NBM) MNK_HIP(hipStreamWaitEvent(s, second_half_ready, 0));
             const int64_t pm = mo - NBM;  // the middle panel just finished: columns [pm, mo)
             const double* Wp = ldl ? wbase + mo + (pm - ko) * ls->ldw : F + mo + pm * ld;
-            int rc = launch_gemm_nt(s, 2, Np - mo, kend - mo, NBM, Wp, ldl ? ls->ldw : ld, F + mo + pm * ld, ld,
+            int rc;
+            if (gemm_nt_lower_tiles(Np - mo, kend - mo) < ls->small_tiles_mid)
+                rc = launch_gemm_nt_lower_small(s, Np - mo, kend - mo, NBM, Wp, ldl ? ls->ldw : ld, F + mo + pm * ld,
+                                                ld, F + mo + mo * ld, ld, ls->info_dev.p);
+            else
+                rc = launch_gemm_nt(s, 2, Np - mo, kend - mo, NBM, Wp, ldl ? ls->ldw : ld, F + mo + pm * ld, ld,
                                     F + mo + mo * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
             if (rc) return rc;
         }
@@ -628,10 +637,26 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             const size_t old = ctx->ev_panel.size();
             ctx->ev_panel.resize(npanel + 1);
             ctx->ev_next.resize(npanel + 1);
+            ctx->ev_next2.resize(npanel + 1);
             for (size_t e = old; e < ctx->ev_panel.size(); ++e) {
                 MNK_HIP(hipEventCreateWithFlags(&ctx->ev_panel[e], hipEventDisableTiming));
                 MNK_HIP(hipEventCreateWithFlags(&ctx->ev_next[e], hipEventDisableTiming));
+                MNK_HIP(hipEventCreateWithFlags(&ctx->ev_next2[e], hipEventDisableTiming));
             }
+        }
+        // Work sharing: while the trailing update is the longer leg, the panel stream's CUs would
+        // idle once panel k+1 is factored; (b) is then launched as a tile queue on both streams
+        // (update stream right after (a), panel stream after the panel) and the two launches drain
+        // one counter.  Estimated leg lengths only decide whether the second launch is worth it.
+        const int pcus = big ? ctx->panel_cus_big : ctx->panel_cus;
+        const int ucus = pcus > 0 ? ctx->num_cu - pcus : ctx->num_cu;
+        const bool share = ls->share != 0;
+        if (share) {
+            if (ls->tile_ctr.n < 8 * ((size_t)npanel + 1)) {
+                int rc0 = ls->tile_ctr.alloc(8 * ((size_t)npanel + 1));
+                if (rc0) return rc0;
+            }
+            MNK_HIP(hipMemsetAsync(ls->tile_ctr.p, 0, 8 * ((size_t)npanel + 1) * sizeof(int), s));
         }
         MNK_HIP(hipEventRecord(ctx->ev_a, s));
         MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
@@ -647,24 +672,61 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             double* wk = ls->wbuf[k & 1].p;
             const double* Wsrc = ldl ? wk + kend : F + kend + ko * ld;
             const int64_t ldws = ldl ? ls->ldw : ld;
+            const int64_t Kw = kend - ko;
+            // ev_panel[k] is recorded after panel k and after the panel stream's share of (b)_{k-1}
             MNK_HIP(hipStreamWaitEvent(su, ctx->ev_panel[k], 0));
-            // (a) columns of the next outer panel
-            rc = launch_gemm_nt(su, 2, Mt, nnext, kend - ko, Wsrc, ldws, F + kend + ko * ld, ld,
-                                F + kend + kend * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+            // (a) columns of the next outer panel, delivered in two pieces: its first 256-column middle
+            // panel (the panel stream starts on it at once), then the remaining columns (needed only when
+            // that middle panel is finished)
+            auto update_a = [&](int64_t c0, int64_t c1) -> int {
+                const int64_t Mp = Mt - c0, Nn = c1 - c0;
+                double* Cp = F + (kend + c0) + (kend + c0) * ld;
+                if (gemm_nt_lower_tiles(Mp, Nn) < ls->small_tiles)
+                    return launch_gemm_nt_lower_small(su, Mp, Nn, Kw, Wsrc + c0, ldws, F + kend + c0 + ko * ld, ld, Cp,
+                                                      ld, ls->info_dev.p);
+                return launch_gemm_nt(su, 2, Mp, Nn, Kw, Wsrc + c0, ldws, F + kend + c0 + ko * ld, ld, Cp, ld, nullptr,
+                                      nullptr, 0, ls->info_dev.p);
+            };
+            const int64_t n1 = std::min<int64_t>(256, nnext);
+            const bool split_a = ls->split_a && nnext > n1;
+            rc = update_a(0, split_a ? n1 : nnext);
             if (rc) return rc;
             MNK_HIP(hipEventRecord(ctx->ev_next[k], su));
+            if (split_a) {
+                rc = update_a(n1, nnext);
+                if (rc) return rc;
+                MNK_HIP(hipEventRecord(ctx->ev_next2[k], su));
+            }
             // (b) the rest of the trailing matrix
             const int64_t Mb = Mt - nnext;
+            bool shared_b = false;
             if (Mb > 0) {
-                rc = launch_gemm_nt(su, 2, Mb, Mb, kend - ko, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
-                                    F + (kend + nnext) + (kend + nnext) * ld, ld, nullptr, nullptr, 0,
-                                    ls->info_dev.p);
+                const int ntiles = gemm_nt_lower_tiles(Mb, Mb);
+                // CU-us per 128x128xKw tile at ~80 % of the MFMA rate; ~55 us of panel stream per 64 columns
+                const double t_upd = ntiles * (68.0 * (double)Kw / 512.0) / ucus;
+                const double t_pan = 55.0 * (double)nnext / 64.0 * (pcus > 0 ? 64.0 / pcus : 1.0);
+                shared_b = share && pcus > 0 && (t_upd > t_pan || ls->share == 2);
+                if (shared_b)
+                    rc = launch_gemm_nt_queue(su, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
+                                              F + (kend + nnext) + (kend + nnext) * ld, ld, ls->tile_ctr.p + 8 * k,
+                                              2 * ucus, ls->info_dev.p);
+                else
+                    rc = launch_gemm_nt(su, 2, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
+                                        F + (kend + nnext) + (kend + nnext) * ld, ld, nullptr, nullptr, 0,
+                                        ls->info_dev.p);
                 if (rc) return rc;
             }
             // panel k+1 on the panel stream, as soon as (a) is done
             MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_next[k], 0));
-            rc = factor_outer_panel(ls, sp, kend, kend + nnext, ls->wbuf[(k + 1) & 1].p);
+            rc = factor_outer_panel(ls, sp, kend, kend + nnext, ls->wbuf[(k + 1) & 1].p,
+                                    split_a ? ctx->ev_next2[k] : nullptr);
             if (rc) return rc;
+            if (shared_b) {
+                rc = launch_gemm_nt_queue(sp, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
+                                          F + (kend + nnext) + (kend + nnext) * ld, ld, ls->tile_ctr.p + 8 * k,
+                                          2 * pcus, ls->info_dev.p);
+                if (rc) return rc;
+            }
             MNK_HIP(hipEventRecord(ctx->ev_panel[k + 1], sp));
         }
         MNK_HIP(hipEventRecord(ctx->ev_a, sp));

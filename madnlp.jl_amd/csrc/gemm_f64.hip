@@ -18,6 +18,8 @@
 //     doubles so the two 16-lane halves of a 32-lane LDS group hit disjoint banks.
 //   * Global -> LDS staging goes through registers in 16-byte pieces, double
 //     buffered: the loads of k-tile t+1 are issued before the MFMAs of k-tile t.
+#include <algorithm>
+
 #include "common.h"
 
 namespace mnk {
@@ -27,38 +29,11 @@ typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16;
 
-template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
-    int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
-    const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
-    const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
-    const int* __restrict__ info_flag) {
-    constexpr int NT = 64 * WM * WN;
-    constexpr int WS = 16 * WT;  // wave tile edge (WT x WT MFMA 16x16 tiles per wave)
-    constexpr int BM = WS * WM, BN = WS * WN;
-    constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
-    constexpr int APIECES = (BM / 2) * BK / NT;  // 16-byte pieces per thread per k-tile
-    constexpr int BPIECES = (BN / 2) * BK / NT;
-    static_assert(APIECES >= 1 && BPIECES >= 1, "tile too small for the thread count");
-
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* As = reinterpret_cast<double*>(smem_raw);           // [2][BK][LDA_S]
-    double* Bs = As + 2 * BK * LDA_S;                           // [2][BK][LDB_S]
-
-    if (info_flag != nullptr && *info_flag != 0) return;
-
-    // XCD-aware remap: hardware places consecutive workgroup ids round-robin on the
-    // 8 XCDs; give each XCD a contiguous run of logical tiles so that tiles sharing
-    // an A row-block / B column-block share one L2.
-    int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    int per = nblk >> 3;
-    int logical = (per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid;
-    int tm, tn;
+// Decode a logical tile index into (tm, tn).  Lower-only modes enumerate the tiles on/below the
+// diagonal column by column (tile column tn holds rows tn..ntm-1): first(tn) = tn*ntm - tn*(tn-1)/2.
+template <int MODE>
+__device__ __forceinline__ void decode_tile(int logical, int ntm, int& tm, int& tn) {
     if (MODE == 2 || MODE == 4) {
-        // Only tiles on/below the diagonal are launched (tile column tn holds rows tn..ntm-1),
-        // enumerated column by column so every XCD gets the same number of tiles:
-        // first(tn) = tn*ntm - tn*(tn-1)/2.
         const double bq = 2.0 * ntm + 1.0;
         int c = (int)((bq - sqrt(bq * bq - 8.0 * (double)logical)) * 0.5);
         if (c < 0) c = 0;
@@ -70,6 +45,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
         tm = logical % ntm;
         tn = logical / ntm;
     }
+}
+
+// One workgroup tile of C.  Every thread of the workgroup must call it with the same (tm, tn).
+template <int WM, int WN, int WT, int MODE, bool LDL_EPI, bool DBG_SHARED_AB = false>
+__device__ __forceinline__ void gemm_nt_tile(
+    int tm, int tn, int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
+    const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
+    const double* __restrict__ colscale, double* C2, int64_t ldc2, char* smem_raw) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int WS = 16 * WT;  // wave tile edge (WT x WT MFMA 16x16 tiles per wave)
+    constexpr int BM = WS * WM, BN = WS * WN;
+    constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
+    constexpr int APIECES = (BM / 2) * BK / NT;  // 16-byte pieces per thread per k-tile
+    constexpr int BPIECES = (BN / 2) * BK / NT;
+    static_assert(APIECES >= 1 && BPIECES >= 1, "tile too small for the thread count");
+
+    double* As = reinterpret_cast<double*>(smem_raw);           // [2][BK][LDA_S]
+    double* Bs = As + 2 * BK * LDA_S;                           // [2][BK][LDB_S]
+
     const int64_t row0 = (int64_t)tm * BM;
     const int64_t col0 = (int64_t)tn * BN;
 
@@ -79,8 +73,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     const int wm = wave % WM, wn = wave / WM;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    const double* Ag = A + row0;
-    const double* Bg = B + col0;
+    // DBG_SHARED_AB (diagnostics only): every tile reads the same two operand blocks, i.e. perfect
+    // cache reuse, to separate the memory-side cost of the update from its MFMA/LDS cost
+    const double* Ag = A + (DBG_SHARED_AB ? (int64_t)(tm & 1) * BM : row0);
+    const double* Bg = B + (DBG_SHARED_AB ? (int64_t)(tn & 1) * BN : col0);
 
     v2f64 ra[APIECES], rb[BPIECES];
 
@@ -154,6 +150,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     const int64_t wrow = row0 + wm * WS, wcol = col0 + wn * WS;
     if (wrow >= M || wcol >= N) return;
     if ((MODE == 2 || MODE == 4) && wrow + WS <= wcol) return;  // wave tile entirely above the diagonal
+    // (Measured on gfx950: replacing this load/subtract/store sequence by no-return L2 atomics or by
+    // batching all loads ahead of the stores does not change the kernel time -- with two workgroups
+    // per CU the epilogue of one hides behind the k-loop of the other.)
 #pragma unroll
     for (int ni = 0; ni < WT; ++ni) {
 #pragma unroll
@@ -185,9 +184,75 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
 }
 
 template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
+    int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
+    const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
+    const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
+    const int* __restrict__ info_flag, int tile_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (info_flag != nullptr && *info_flag != 0) return;
+
+    // XCD-aware remap: hardware places consecutive workgroup ids round-robin on the
+    // 8 XCDs; give each XCD a contiguous run of logical tiles so that tiles sharing
+    // an A row-block / B column-block share one L2.
+    int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    int per = nblk >> 3;
+    int logical = tile_off + ((per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid);
+    int tm, tn;
+    decode_tile<MODE>(logical, ntm, tm, tn);
+    gemm_nt_tile<WM, WN, WT, MODE, LDL_EPI>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, smem_raw);
+}
+
+template <int WM, int WN, int WT, int MODE, bool SHARED>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dbg_kernel(
+    int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
+    const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc, int ntm) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int nblk = gridDim.x, bid = blockIdx.x, per = nblk >> 3;
+    int logical = (per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid;
+    int tm, tn;
+    decode_tile<MODE>(logical, ntm, tm, tn);
+    gemm_nt_tile<WM, WN, WT, MODE, false, SHARED>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
+}
+
+// Work-queue variant: the workgroups of one or more launches (possibly on different streams with
+// different CU masks) pull logical tile indices from device counters until `ntiles` are taken.
+// Used to let the panel stream's CUs join the trailing update once the next panel is factored.
+// The tile range is cut into 8 contiguous chunks, one per XCD, each with its own counter: a
+// workgroup drains the chunk of the XCD it runs on first (tiles of one chunk share A/B blocks in
+// that XCD's L2, like the static remap of gemm_nt_kernel) and then steals from the other chunks.
+template <int WM, int WN, int WT, int MODE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_queue_kernel(
+    int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
+    const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc, int ntm, int ntiles,
+    int* __restrict__ counters /* [8] */, const int* __restrict__ info_flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int s_tile;
+    if (info_flag != nullptr && *info_flag != 0) return;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int home = (int)(xcc & 7u);
+    int probe = 0;
+    while (probe < 8) {
+        const int q = (home + probe) & 7;
+        const int lo = (int)(((int64_t)ntiles * q) >> 3), hi = (int)(((int64_t)ntiles * (q + 1)) >> 3);
+        if (threadIdx.x == 0) s_tile = atomicAdd(counters + q, 1);
+        __syncthreads();
+        const int logical = lo + s_tile;
+        __syncthreads();  // everyone has read s_tile before the next round overwrites it
+        if (logical >= hi) { ++probe; continue; }
+        int tm, tn;
+        decode_tile<MODE>(logical, ntm, tm, tn);
+        gemm_nt_tile<WM, WN, WT, MODE, false>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
+        __syncthreads();  // LDS tiles are reused by the next round
+    }
+}
+
+template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
 static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                     const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
-                    double* C2, int64_t ldc2, const int* info_flag) {
+                    double* C2, int64_t ldc2, const int* info_flag, int tile_begin = 0, int tile_count = -1) {
     constexpr int BM = 16 * WT * WM, BN = 16 * WT * WN;
     const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
     int ntiles = ntm * ntn;
@@ -203,8 +268,10 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
         MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
+    if (tile_count >= 0) ntiles = std::min(ntiles - tile_begin, tile_count);
+    if (ntiles <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, s, M, N, K, A, lda, B, ldb, C,
-                       ldc, colscale, C2, ldc2, ntm, info_flag);
+                       ldc, colscale, C2, ldc2, ntm, info_flag, tile_begin);
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -241,6 +308,76 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, con
     }
     set_error("gemm_nt: bad mode %d", mode);
     return -1;
+}
+
+// C(lower tiles) -= A * B^T with 64x64 workgroup tiles: four times the workgroups of the default
+// 128x128 tiling, for updates with too few tiles to fill the chip (latency-bound tail of the
+// factorization).
+int launch_gemm_nt_lower_small(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag) {
+    if (M <= 0 || N <= 0) return 0;
+    MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
+    return launch_t<2, 2, 2, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+}
+
+// a contiguous range of the lower tiles of the 128x128 tiling (mode 2), for chunked launches
+int launch_gemm_nt_lower_range(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag,
+                               int tile_begin, int tile_count) {
+    if (M <= 0 || N <= 0) return 0;
+    MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
+    return launch_t<2, 2, 4, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag, tile_begin,
+                                       tile_count);
+}
+
+int gemm_nt_lower_tiles(int64_t M, int64_t N);
+int gemm_nt_lower_tiles(int64_t M, int64_t N);
+int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double* C, int64_t ldc) {
+    const int ntm = (int)((M + 127) / 128);
+    const int ntiles = gemm_nt_lower_tiles(M, N);
+    const size_t smem = 2 * BK * ((128 + 16) + (128 + 16)) * sizeof(double);
+    if (shared_ab) {
+        auto kern = gemm_nt_dbg_kernel<2, 2, 4, 2, true>;
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm);
+    } else {
+        auto kern = gemm_nt_dbg_kernel<2, 2, 4, 2, false>;
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm);
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int gemm_nt_lower_tiles(int64_t M, int64_t N) {
+    const int ntm = (int)((M + 127) / 128), ntn = (int)((N + 127) / 128);
+    const int nc = ntn < ntm ? ntn : ntm;
+    return nc * ntm - nc * (nc - 1) / 2;
+}
+
+// Work-queue launch of the lower-tile update (mode 2, 128x128 tiles): `nwg` workgroups pull tiles
+// from *counter (zeroed by the caller before the first launch that shares it).
+int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                         const double* B, int64_t ldb, double* C, int64_t ldc, int* counter, int nwg,
+                         const int* info_flag) {
+    if (M <= 0 || N <= 0) return 0;
+    MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
+    constexpr int BM = 128;
+    const int ntm = (int)((M + BM - 1) / BM);
+    const int ntiles = gemm_nt_lower_tiles(M, N);
+    if (nwg > ntiles) nwg = ntiles;
+    const size_t smem = 2 * BK * ((BM + 16) + (BM + 16)) * sizeof(double);
+    auto kern = gemm_nt_queue_kernel<2, 2, 4, 2>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm, ntiles, counter,
+                       info_flag);
+    MNK_HIP(hipGetLastError());
+    return 0;
 }
 
 }  // namespace mnk

@@ -132,6 +132,7 @@ int mnk_ctx_destroy(mnk_ctx* c) {
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_next2) (void)hipEventDestroy(e);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
     if (c->sp_big) (void)hipStreamDestroy(c->sp_big);
@@ -160,7 +161,11 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     ls->ctx = ctx;
     ls->N = N;
     ls->algo = algo;
-    if (const char* e = getenv("MNK_LOOKAHEAD")) ls->lookahead = atoi(e) != 0;  // tuning override
+    if (const char* e = getenv("MNK_LOOKAHEAD")) ls->lookahead = atoi(e) != 0;  // tuning overrides
+    if (const char* e = getenv("MNK_SHARE")) ls->share = atoi(e) != 0;
+    if (const char* e = getenv("MNK_SMALL_TILES")) ls->small_tiles = atoi(e);
+    if (const char* e = getenv("MNK_SMALL_TILES_MID")) ls->small_tiles_mid = atoi(e);
+    if (const char* e = getenv("MNK_SPLIT_A")) ls->split_a = atoi(e);
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
     ls->ldw = ls->Np;
@@ -201,6 +206,10 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         return 0;
     }
     if (!strcmp(key, "lookahead")) { ls->lookahead = value != 0.0; return 0; }
+    // 0: no work sharing, 1: the panel stream joins the trailing update when that is the longer leg,
+    // 2: always (used by the schedule tests)
+    if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
+    if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
     set_error("mnk_ls_set_option: unknown option '%s'", key);
     return -1;
 }
@@ -378,6 +387,96 @@ int mnk_gemm_nt(mnk_ctx* ctx, int mode, int64_t M, int64_t N, int64_t K, const d
     MNK_REQUIRE(ctx && A && B && C, "mnk_gemm_nt: NULL argument");
     MNK_HIP(hipSetDevice(ctx->device));
     return launch_gemm_nt(ctx->stream, mode, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, nullptr);
+}
+
+// Clock probe: one wave runs a fixed dependent chain of fp64 FMAs and reports the elapsed constant-rate
+// (100 MHz) timer ticks; run beside a load, the ratio to the idle value is the shader-clock ratio.
+__global__ void clock_probe_kernel(unsigned long long* out, int iters, double a, double b) {
+    double x = (double)threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x = __builtin_fma(x, a, b);
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (threadIdx.x == 0) out[0] = t1 - t0;
+    if (x == 1.2345) out[1] = 1;
+}
+
+// Diagnostics: time `reps` lower-tile updates C -= A*A^T (M x M, depth K) under one of the
+// schedules the factorization uses.  variant 0: static tiling on the context stream (all CUs);
+// 1: tile queue on the context stream; 2: static on the update stream (its CU mask); 3: queue on the
+// update stream; 4: queue drained by update + panel streams together; 5: static on the update
+// stream while the panel stream runs the same product on a second matrix C2 (interference probe);
+// 6-8: static in chunks of 512/1024/256 tiles; 9/10: every tile reads the same operand blocks
+// (context / update stream); 20: clock probe alone, 21: clock probe beside an update (ms <- ticks).
+int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const double* A, int64_t lda, double* C,
+                     double* C2, int64_t ldc, int reps, double* ms) {
+    MNK_REQUIRE(ctx && A && C && ms, "mnk_debug_update: NULL argument");
+    MNK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream, su = ctx->su, sp = ctx->sp;
+    MNK_REQUIRE(su && sp, "mnk_debug_update: no look-ahead streams");
+    DevBuf<int> ctr;
+    int rc = ctr.alloc(8 * (size_t)reps);
+    if (rc) return rc;
+    MNK_HIP(hipMemsetAsync(ctr.p, 0, 8 * (size_t)reps * sizeof(int), s));
+    hipEvent_t e0, e1;
+    MNK_HIP(hipEventCreate(&e0));
+    MNK_HIP(hipEventCreate(&e1));
+    const int pcus = ctx->panel_cus, ucus = ctx->num_cu - pcus;
+    MNK_HIP(hipEventRecord(e0, s));
+    MNK_HIP(hipEventRecord(ctx->ev_a, s));
+    MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
+    MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
+    for (int r = 0; r < reps && !rc; ++r) {
+        switch (variant) {
+        case 0: rc = launch_gemm_nt(s, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr); break;
+        case 1: rc = launch_gemm_nt_queue(s, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * ctx->num_cu, nullptr); break;
+        case 2: rc = launch_gemm_nt(su, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr); break;
+        case 3: rc = launch_gemm_nt_queue(su, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * ucus, nullptr); break;
+        case 4:
+            rc = launch_gemm_nt_queue(su, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * ucus, nullptr);
+            if (!rc) rc = launch_gemm_nt_queue(sp, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * pcus, nullptr);
+            break;
+        case 20: break;  // probe only
+        case 21: rc = launch_gemm_nt(su, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr); break;
+        case 9: rc = launch_gemm_nt_dbg(s, 1, M, M, K, A, lda, A, lda, C, ldc); break;
+        case 10: rc = launch_gemm_nt_dbg(su, 1, M, M, K, A, lda, A, lda, C, ldc); break;
+        case 6: case 7: case 8: {  // static tiling on the context stream, one launch per `chunk` tiles
+            const int chunk = variant == 6 ? 2 * ctx->num_cu : variant == 7 ? 4 * ctx->num_cu : ctx->num_cu;
+            const int nt = gemm_nt_lower_tiles(M, M);
+            for (int t = 0; t < nt && !rc; t += chunk)
+                rc = launch_gemm_nt_lower_range(s, M, M, K, A, lda, A, lda, C, ldc, nullptr, t, chunk);
+            break;
+        }
+        default:
+            rc = launch_gemm_nt(su, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr);
+            if (!rc && C2) rc = launch_gemm_nt(sp, 2, M / 2, M / 2, K, A, lda, A, lda, C2, ldc, nullptr, nullptr, 0, nullptr);
+            break;
+        }
+    }
+    DevBuf<unsigned long long> probe;
+    if (variant == 20 || variant == 21) {
+        rc |= probe.alloc(2);
+        if (!rc) hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, sp, probe.p, 12000, 0.999999, 1e-9);
+    }
+    MNK_HIP(hipEventRecord(ctx->ev_a, sp));
+    MNK_HIP(hipEventRecord(ctx->ev_b, su));
+    MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
+    MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
+    MNK_HIP(hipEventRecord(e1, s));
+    MNK_HIP(hipStreamSynchronize(s));
+    float t = 0.f;
+    MNK_HIP(hipEventElapsedTime(&t, e0, e1));
+    *ms = (double)t;
+    if (variant == 20 || variant == 21) {  // report the probe's ticks (10 ns each) instead
+        unsigned long long h = 0;
+        MNK_HIP(hipMemcpy(&h, probe.p, sizeof(h), hipMemcpyDeviceToHost));
+        *ms = (double)h;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 }  // extern "C"

@@ -114,6 +114,8 @@ class HipSolverOptions:
     pivot_tol: float = 0.0
     outer_block: int = 512
     lookahead: bool = True
+    share: int = 1          # 0 off, 1 adaptive, 2 always: panel-stream CUs join the trailing update
+    small_tiles: int = 400  # (a)-updates with fewer 128x128 tiles use 64x64 workgroup tiles
 
 
 class HipLinearSolver:
@@ -140,6 +142,10 @@ class HipLinearSolver:
         settings = [("pivot_tol", self.opt.pivot_tol), ("outer_block", self.opt.outer_block)]
         if "MNK_LOOKAHEAD" not in os.environ:  # tuning override handled inside the library
             settings.append(("lookahead", float(self.opt.lookahead)))
+        if "MNK_SHARE" not in os.environ:
+            settings.append(("share", float(self.opt.share)))
+        if "MNK_SMALL_TILES" not in os.environ:
+            settings.append(("small_tiles", float(self.opt.small_tiles)))
         for key, val in settings:
             L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(val)), "mnk_ls_set_option")
         self.info = 0

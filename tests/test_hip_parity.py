@@ -555,6 +555,40 @@ def test_factorization_schedules_agree(ctx, N, alg, nbo, la):
     M.close()
 
 
+@pytest.mark.parametrize("alg", [mj.CHOLESKY, mj.LDL])
+@pytest.mark.parametrize("nbo", [256, 512])
+@pytest.mark.parametrize("small", [0, 100000])
+def test_shared_tile_queue_schedule_is_bit_identical(ctx, alg, nbo, small):
+    """With share=2 every trailing update is drained through the tile queue by both look-ahead streams;
+    the factor must be bit-identical to the static schedule (each tile is computed by exactly one
+    workgroup with the same arithmetic, whichever stream pulls it), also with the 64x64-tile variant
+    of the next-panel update switched on/off (that one changes the summation tiling, not the sums)."""
+    rng = np.random.default_rng(5)
+    N = 3200
+    R = rng.standard_normal((N, 80))
+    A = np.asfortranarray(R @ R.T + np.diag(10.0 ** rng.uniform(-1, 3, N)))
+    if alg == mj.LDL:
+        k = N // 4
+        A[N - k:, N - k:] *= -1.0
+        A[N - k:, N - k:] -= np.eye(k) * 5.0
+        A = np.asfortranarray((A + A.T) / 2)
+    dA = torch.from_numpy(A).cuda()
+    facs = []
+    for share in (0, 2, 2):
+        M = mj.HipLinearSolver(dA, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, outer_block=nbo,
+                                                                   share=share, small_tiles=small))
+        M.factorize()
+        Lf, d = M.get_factor()
+        facs.append((np.tril(Lf).copy(), None if d is None else np.array(d)))
+        inert = M.inertia()
+        M.close()
+    assert inert == ((N, 0, 0) if alg == mj.CHOLESKY else (N - N // 4, 0, N // 4))
+    for Lf, d in facs[1:]:
+        assert np.array_equal(facs[0][0], Lf)
+        if d is not None:
+            assert np.array_equal(facs[0][1], d)
+
+
 def test_repeated_factorizations_are_deterministic(ctx):
     """Refactorizing the same matrix (the IPM does it every iteration) gives bit-identical factors:
     no race between the look-ahead streams, no stale state between calls."""
