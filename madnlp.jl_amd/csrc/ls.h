@@ -47,6 +47,8 @@ struct mnk_ls {
     int small_tiles_mid = 400;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, linv256, linv256t, dvec, dinv, xwork;
+    int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
+    mnk::DevBuf<int> solve_abort;
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
     bool factorized = false, info_valid = false;

@@ -166,6 +166,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_SMALL_TILES")) ls->small_tiles = atoi(e);
     if (const char* e = getenv("MNK_SMALL_TILES_MID")) ls->small_tiles_mid = atoi(e);
     if (const char* e = getenv("MNK_SPLIT_A")) ls->split_a = atoi(e);
+    if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
     ls->ldw = ls->Np;
@@ -177,7 +178,8 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     rc |= ls->linv256t.alloc((size_t)((ls->Np + 255) / 256) * 65536);
     rc |= ls->dvec.alloc(ls->Np);
     rc |= ls->dinv.alloc(ls->Np);
-    rc |= ls->xwork.alloc(2 * ls->Np);
+    rc |= ls->xwork.alloc(6 * ls->Np);
+    rc |= ls->solve_abort.alloc(1);
     rc |= ls->info_dev.alloc(1);
     rc |= ls->inertia_dev.alloc(3);
     if (rc) { delete ls; return -2; }
@@ -210,6 +212,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // 2: always (used by the schedule tests)
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
+    if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
     set_error("mnk_ls_set_option: unknown option '%s'", key);
     return -1;
 }
@@ -364,7 +367,17 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
         if (rc) return rc;
         MNK_HIP(hipMemcpyAsync(xk, w, N * sizeof(double),
                                loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-        if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+        if (loc != MNK_DEVICE) {
+            int aborted = 0;
+            if (ls->persistent_solve)
+                MNK_HIP(hipMemcpyAsync(&aborted, ls->solve_abort.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            MNK_HIP(hipStreamSynchronize(s));
+            if (aborted) {
+                set_error("mnk_ls_solve: the persistent solve kernel gave up waiting for a peer workgroup "
+                          "(device oversubscribed?); set option persistent_solve = 0");
+                return -3;
+            }
+        }
     }
     return 0;
 }

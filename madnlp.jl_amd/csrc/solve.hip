@@ -16,6 +16,7 @@
 namespace mnk {
 
 constexpr int SB = 256;
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 // ---- explicit inverse of every 256x256 diagonal triangle (unit diagonal for LDL) ----------------
 // One workgroup per (diagonal block, 64-column block q of the inverse):
@@ -218,6 +219,274 @@ __global__ __launch_bounds__(256) void bwd_panel_kernel(const double* __restrict
     }
 }
 
+
+// ================================================================================================
+// Persistent solve: both sweeps in ONE launch.
+//
+// The multi-kernel path above spends 4*N/256 dependent launches of a few microseconds each, i.e. it
+// is bound by launch/drain latency, not by HBM (1.6 ms for a 1 GB factor).  Here every 64-row block
+// i of the right-hand side is owned by workgroup i mod G (G <= #CUs, so all workgroups are resident
+// together) and the blocks talk through global memory, value by value:
+//   * a published value is an 8-byte agent-scope store; a consumer polls the very element it needs
+//     until it differs from the sentinel (all-ones NaN) the host wrote before the launch.  One hop is
+//     ~0.6 us on gfx950 (tools/hop_latency.hip); there are no separate flags or fences.
+//   * forward, 256-column step k (blocks b0..b0+3):  the owner of block i in the step publishes its
+//     final right-hand side bfin[i], gathers bfin of the blocks above it inside the step and applies
+//     its 64 rows of inv(L_kk) (explicit inverse, no substitution chain) -> publishes y[i].  Owners of
+//     the blocks below poll y[b0..b0+3] and subtract L[i, step k] * y_k from their running block,
+//     which lives in LDS for the whole solve.
+//   * the 64x256 slice a workgroup is going to multiply (of L or of inv(L_kk)) is loaded into
+//     registers BEFORE it starts polling, so the memory latency overlaps the wait and the critical
+//     path per step is two hops plus two in-register 64-term dot products.
+//   * backward is the mirror image with column blocks (the same owners: z = D^-1 y stays in LDS),
+//     stepping from the last block to the first with inv(L_kk)^T.
+// Every workgroup walks its tasks in the global order (sweep, step, diagonal role before update role);
+// each wait is on a task earlier in that order, so with all workgroups resident there is no deadlock.
+// A wait that exceeds the spin budget raises the abort flag and every workgroup leaves (the host
+// reports a SolveException instead of hanging the device).
+// ================================================================================================
+constexpr int PS_MAXOWN = 12;            // owned blocks per workgroup: Np <= 12 * 64 * G
+constexpr long PS_SPIN_LIMIT = 6000000;  // polls (~0.5 us each) before giving up
+
+__device__ __forceinline__ void ps_publish(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// threads t < n poll src[t] into dst[t]; returns false (uniformly) if the solve was aborted
+__device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst, int* abort_flag) {
+    const int t = threadIdx.x;
+    int bad = 0;
+    if (t < n) {
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(src + t);
+        unsigned long long u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (u == ~0ull) {
+            // back off: short naps while the value is probably about to land, long ones for the
+            // workgroups that wait for a distant step (keeps their polling off the memory fabric)
+            if (spins < 64) __builtin_amdgcn_s_sleep(1);
+            else __builtin_amdgcn_s_sleep(24);
+            if ((++spins & 1023) == 0) {
+                if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
+                if (spins > PS_SPIN_LIMIT) {
+                    __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bad = 1;
+                    break;
+                }
+            }
+            u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        dst[t] = __longlong_as_double((long long)u);
+    }
+    return __syncthreads_or(bad) == 0;
+}
+
+__global__ void ps_reset_kernel(unsigned long long* pub, int64_t n, int* abort_flag) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) pub[i] = ~0ull;
+    if (i == 0) *abort_flag = 0;
+}
+
+template <bool LDL>
+__global__ __launch_bounds__(256) void persistent_solve_kernel(
+    const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv, const double* __restrict__ InvT,
+    const double* __restrict__ dinv, double* __restrict__ xio /* Np: rhs in, solution out */,
+    double* __restrict__ pub /* 4*Np sentinel-filled: bfin | y | zfin | x */, int64_t Np, int* abort_flag,
+    const int* __restrict__ info) {
+    __shared__ double run[PS_MAXOWN][64];   // running rhs of the owned blocks (forward: b, backward: z)
+    __shared__ double ysol[PS_MAXOWN][64];  // forward solution of the owned blocks
+    __shared__ double xs[256];              // the step's published vector
+    __shared__ double part[16][64];         // partial sums
+    if (*info != 0) return;
+    const int t = threadIdx.x, r = t & 63, q = t >> 6;
+    const int G = gridDim.x, g = blockIdx.x;
+    const int nb = (int)(Np / 64);
+    const int nsteps = (nb + 3) / 4;
+    const int nown = g < nb ? (nb - g + G - 1) / G : 0;
+    if (nown == 0) return;
+    double* bfin = pub;
+    double* ypub = pub + Np;
+    double* zfin = pub + 2 * Np;
+    double* xpub = pub + 3 * Np;
+    for (int e = t; e < nown * 64; e += 256) run[e >> 6][e & 63] = xio[(int64_t)(g + (e >> 6) * G) * 64 + (e & 63)];
+    __syncthreads();
+
+    double a[64];
+    // ------------------------------------------------------------------ forward: L y = b
+    int m0 = 0;  // first owned block whose forward solution is not yet known
+    for (int k = 0; k < nsteps && m0 < nown; ++k) {
+        const int b0 = 4 * k, nbk = nb - b0 < 4 ? nb - b0 : 4;
+        int i = g + m0 * G;
+        if (i < b0 + nbk) {
+            // diagonal role: y_i = sum_{c <= li} inv(L_kk)[li, c] * bfin[b0 + c]
+            const int li = i - b0;
+            const double* Mk = Inv + (int64_t)k * (SB * SB) + (li * 64 + r) + (int64_t)(q * 64) * SB;
+            if (q <= li) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) a[j] = Mk[(int64_t)j * SB];
+            }
+            if (t < 64) {
+                const double v = run[m0][t];
+                ps_publish(bfin + (int64_t)i * 64 + t, v);
+                xs[li * 64 + t] = v;
+            }
+            if (!ps_gather(bfin + (int64_t)b0 * 64, li * 64, xs, abort_flag)) return;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            if (q <= li) {
+                const double* xq = xs + q * 64;
+#pragma unroll
+                for (int j = 0; j < 64; j += 4) {
+                    s0 = fma(a[j], xq[j], s0);
+                    s1 = fma(a[j + 1], xq[j + 1], s1);
+                    s2 = fma(a[j + 2], xq[j + 2], s2);
+                    s3 = fma(a[j + 3], xq[j + 3], s3);
+                }
+            }
+            part[q][r] = (s0 + s1) + (s2 + s3);
+            __syncthreads();
+            if (t < 64) {
+                const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+                ps_publish(ypub + (int64_t)i * 64 + t, v);
+                ysol[m0][t] = v;
+            }
+            __syncthreads();
+            ++m0;
+            if (m0 >= nown) break;
+            i = g + m0 * G;
+        }
+        // update role: run_i -= L[i, step k] * y_k for the owned blocks below the step
+        {
+            const double* Fs = F + ((int64_t)i * 64 + r) + ((int64_t)b0 * 64 + q * 64) * ld;
+            if (q < nbk) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) a[j] = Fs[(int64_t)j * ld];
+            }
+        }
+        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag)) return;
+        for (int m = m0; m < nown; ++m) {
+            const int im = g + m * G;
+            if (m > m0 && q < nbk) {
+                const double* Fs = F + ((int64_t)im * 64 + r) + ((int64_t)b0 * 64 + q * 64) * ld;
+#pragma unroll
+                for (int j = 0; j < 64; ++j) a[j] = Fs[(int64_t)j * ld];
+            }
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            if (q < nbk) {
+                const double* xq = xs + q * 64;
+#pragma unroll
+                for (int j = 0; j < 64; j += 4) {
+                    s0 = fma(a[j], xq[j], s0);
+                    s1 = fma(a[j + 1], xq[j + 1], s1);
+                    s2 = fma(a[j + 2], xq[j + 2], s2);
+                    s3 = fma(a[j + 3], xq[j + 3], s3);
+                }
+            }
+            part[q][r] = (s0 + s1) + (s2 + s3);
+            __syncthreads();
+            if (t < 64) run[m][t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------------ backward: L^T x = D^-1 y
+    for (int e = t; e < nown * 64; e += 256) {
+        const int m = e >> 6, c = e & 63;
+        const double y = ysol[m][c];
+        run[m][c] = LDL ? y * dinv[(int64_t)(g + m * G) * 64 + c] : y;
+    }
+    __syncthreads();
+    const int lane = t & 63, sub = lane & 15, colq = lane >> 4;
+    int m1 = nown - 1;  // last owned block whose solution is not yet known
+    for (int k = nsteps - 1; k >= 0 && m1 >= 0; --k) {
+        const int b0 = 4 * k, nbk = nb - b0 < 4 ? nb - b0 : 4;
+        int i = g + m1 * G;
+        if (i >= b0) {
+            // diagonal role: x_i = sum_{rc >= li} inv(L_kk)^T[li, rc] * zfin[b0 + rc]
+            const int li = i - b0;
+            const bool act = q >= li && q < nbk;
+            const double* Mk = InvT + (int64_t)k * (SB * SB) + (li * 64 + r) + (int64_t)(q * 64) * SB;
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) a[j] = Mk[(int64_t)j * SB];
+            }
+            if (t < 64) {
+                const double v = run[m1][t];
+                ps_publish(zfin + (int64_t)i * 64 + t, v);
+                xs[li * 64 + t] = v;
+            }
+            // blocks li+1 .. nbk-1 of the step come from their owners
+            {
+                const int n = (nbk - 1 - li) * 64;
+                if (!ps_gather(zfin + (int64_t)(i + 1) * 64, n, xs + (li + 1) * 64, abort_flag)) return;
+            }
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            if (act) {
+                const double* xq = xs + q * 64;
+#pragma unroll
+                for (int j = 0; j < 64; j += 4) {
+                    s0 = fma(a[j], xq[j], s0);
+                    s1 = fma(a[j + 1], xq[j + 1], s1);
+                    s2 = fma(a[j + 2], xq[j + 2], s2);
+                    s3 = fma(a[j + 3], xq[j + 3], s3);
+                }
+            }
+            part[q][r] = (s0 + s1) + (s2 + s3);
+            __syncthreads();
+            if (t < 64) {
+                const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+                ps_publish(xpub + (int64_t)i * 64 + t, v);
+                xio[(int64_t)i * 64 + t] = v;
+            }
+            __syncthreads();
+            --m1;
+            if (m1 < 0) break;
+            i = g + m1 * G;
+        }
+        // update role: run_i -= L[step k rows, block i columns]^T * x_k for the owned blocks before the step.
+        // Wave q takes the 64 rows b0*64 + 64q ..; lane (sub, colq): rows 4*sub..4*sub+3, columns 4p + colq.
+        auto load_slice = [&](int im) {
+            const double* Fs = F + ((int64_t)b0 * 64 + 64 * q + 4 * sub) + ((int64_t)im * 64 + colq) * ld;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const v2d lo = *reinterpret_cast<const v2d*>(Fs + (int64_t)(4 * p) * ld);
+                const v2d hi = *reinterpret_cast<const v2d*>(Fs + (int64_t)(4 * p) * ld + 2);
+                a[4 * p] = lo[0];
+                a[4 * p + 1] = lo[1];
+                a[4 * p + 2] = hi[0];
+                a[4 * p + 3] = hi[1];
+            }
+        };
+        if (q < nbk) load_slice(i);
+        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag)) return;
+        for (int m = m1; m >= 0; --m) {
+            const int im = g + m * G;
+            if (m < m1 && q < nbk) load_slice(im);
+            if (q < nbk) {
+                const double x0 = xs[64 * q + 4 * sub], x1 = xs[64 * q + 4 * sub + 1], x2 = xs[64 * q + 4 * sub + 2],
+                             x3 = xs[64 * q + 4 * sub + 3];
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    double sp = (a[4 * p] * x0 + a[4 * p + 1] * x1) + (a[4 * p + 2] * x2 + a[4 * p + 3] * x3);
+                    sp += __shfl_xor(sp, 1);
+                    sp += __shfl_xor(sp, 2);
+                    if ((sub & 3) == 0) part[q * 4 + (sub >> 2)][4 * p + colq] = sp;
+                }
+            } else {
+                // idle row chunks contribute zeros
+                for (int e = lane; e < 4 * 64; e += 64) part[q * 4 + (e >> 6)][e & 63] = 0.0;
+            }
+            __syncthreads();
+            if (t < 64) {
+                double sm = 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sm += part[u][t];
+                run[m][t] -= sm;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace mnk
 
 using namespace mnk;
@@ -231,11 +500,27 @@ int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s) {
     return 0;
 }
 
-// xdev: 2*Np doubles; on entry xdev[0:Np] = rhs (zero padded); on exit xdev[0:Np] = solution.
+// xdev: 6*Np doubles; on entry xdev[0:Np] = rhs (zero padded); on exit xdev[0:Np] = solution.
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
     hipStream_t s = ls->ctx->stream;
     const int64_t Np = ls->Np, ld = ls->ld;
     const int ldl = ls->algo == MNK_LDL;
+    const int64_t nb64 = Np / 64;
+    const int G = (int)std::min<int64_t>(nb64, ls->ctx->num_cu);
+    if (ls->persistent_solve && G >= 1 && (nb64 + G - 1) / G <= PS_MAXOWN && (G >= 4 || nb64 <= G)) {
+        double* pub = xdev + 2 * Np;
+        hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<unsigned long long*>(pub), 4 * Np, ls->solve_abort.p);
+        if (ldl)
+            hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(256), 0, s, ls->fact.p, ld, ls->linv256.p,
+                               ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort.p, ls->info_dev.p);
+        else
+            hipLaunchKernelGGL(persistent_solve_kernel<false>, dim3(G), dim3(256), 0, s, ls->fact.p, ld,
+                               ls->linv256.p, ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort.p,
+                               ls->info_dev.p);
+        MNK_HIP(hipGetLastError());
+        return 0;
+    }
     double* b = xdev;       // forward: running right-hand side; backward: solution
     double* y = xdev + Np;  // forward: solution of L y = b (scaled by D^-1 for LDL); backward: running rhs
     const int64_t nsteps = (Np + SB - 1) / SB;
