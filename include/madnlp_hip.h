@@ -188,6 +188,10 @@ int mnk_gemm_nt(mnk_ctx* ctx, int mode, int64_t M, int64_t N, int64_t K,
                 const double* A, int64_t lda, const double* B, int64_t ldb,
                 double* C, int64_t ldc);
 
+/* Diagnostics: with option "solve_trace" = 1 the persistent solve kernel stamps the forward sweep's critical
+ * path (8 x 100 MHz timer values per 64-row block); this copies them out (n = number of uint64 to copy). */
+int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);
+
 /* Diagnostics (tools/microbench_update.py): time `reps` lower-tile trailing updates C -= A*A^T under the
  * schedules the factorization uses (static tiling / tile queue; context, update, update+panel streams). */
 int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const double* A, int64_t lda,

@@ -213,6 +213,16 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
+    if (!strcmp(key, "solve_trace")) {  // diagnostics: time stamps of the forward sweep's critical path
+        if (value != 0.0) {
+            int rc = ls->solve_trace.alloc((size_t)(ls->Np / 64) * 8);
+            if (rc) return rc;
+            MNK_HIP(hipMemset(ls->solve_trace.p, 0, (size_t)(ls->Np / 64) * 8 * sizeof(unsigned long long)));
+        } else {
+            ls->solve_trace.release();
+        }
+        return 0;
+    }
     set_error("mnk_ls_set_option: unknown option '%s'", key);
     return -1;
 }
@@ -379,6 +389,15 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
             }
         }
     }
+    return 0;
+}
+
+int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n) {
+    MNK_REQUIRE(ls && out && ls->solve_trace.p, "mnk_ls_debug_solve_trace: tracing is off (option solve_trace)");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+    const int64_t cnt = std::min<int64_t>(n, (ls->Np / 64) * 8);
+    MNK_HIP(hipMemcpy(out, ls->solve_trace.p, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -11,6 +11,8 @@
 //   backward: x_j = inv(L_jj)^T z_j             ; z[before] -= L[j, before]^T x_j (16 lanes per
 //             column, 4 rows each = 512-byte column segments, shuffle reduction)
 // Launches per solve: 4 * N/256.
+#include <mutex>
+
 #include "ls.h"
 
 namespace mnk {
@@ -247,14 +249,19 @@ __global__ __launch_bounds__(256) void bwd_panel_kernel(const double* __restrict
 // ================================================================================================
 constexpr int PS_MAXOWN = 12;            // owned blocks per workgroup: Np <= 12 * 64 * G
 constexpr long PS_SPIN_LIMIT = 6000000;  // polls (~0.5 us each) before giving up
+constexpr int PS_NEAR = 3;               // blocks within this many steps of the front poll eagerly
 
 __device__ __forceinline__ void ps_publish(double* p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// threads t < n poll src[t] into dst[t]; returns false (uniformly) if the solve was aborted
-__device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst, int* abort_flag) {
+// threads t < n poll src[t] into dst[t]; returns false (uniformly) if the solve was aborted.
+// `relaxed`: the caller is several steps away from the critical path -- nap between polls, so that the
+// ~170 workgroups that merely follow the front do not hammer the 16 cache lines the front is
+// publishing into (their polls queue in front of the critical stores and loads on the same channel).
+__device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst, int* abort_flag,
+                                          bool relaxed = false) {
     const int t = threadIdx.x;
     int bad = 0;
     if (t < n) {
@@ -264,7 +271,8 @@ __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst,
         while (u == ~0ull) {
             // back off: short naps while the value is probably about to land, long ones for the
             // workgroups that wait for a distant step (keeps their polling off the memory fabric)
-            if (spins < 64) __builtin_amdgcn_s_sleep(1);
+            if (relaxed) __builtin_amdgcn_s_sleep(48);
+            else if (spins < 256) __builtin_amdgcn_s_sleep(1);
             else __builtin_amdgcn_s_sleep(24);
             if ((++spins & 1023) == 0) {
                 if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
@@ -287,16 +295,21 @@ __global__ void ps_reset_kernel(unsigned long long* pub, int64_t n, int* abort_f
     if (i == 0) *abort_flag = 0;
 }
 
+constexpr int PS_NT = 1024;          // threads per workgroup: a 64 x 256 slice is 16 values per thread
+constexpr int PS_NQ = PS_NT / 64;    // 16-column chunks of a step (forward) / waves (backward)
+constexpr int PS_CW = 256 / PS_NQ;   // columns per chunk
+
 template <bool LDL>
-__global__ __launch_bounds__(256) void persistent_solve_kernel(
+__global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv, const double* __restrict__ InvT,
     const double* __restrict__ dinv, double* __restrict__ xio /* Np: rhs in, solution out */,
     double* __restrict__ pub /* 4*Np sentinel-filled: bfin | y | zfin | x */, int64_t Np, int* abort_flag,
-    const int* __restrict__ info) {
+    const int* __restrict__ info, unsigned long long* __restrict__ trace /* optional: 8 stamps per block */) {
+#define PS_STAMP(blk, slot) do { if (trace != nullptr && t == 0) trace[(int64_t)(blk) * 8 + (slot)] = wall_clock64(); } while (0)
     __shared__ double run[PS_MAXOWN][64];   // running rhs of the owned blocks (forward: b, backward: z)
     __shared__ double ysol[PS_MAXOWN][64];  // forward solution of the owned blocks
     __shared__ double xs[256];              // the step's published vector
-    __shared__ double part[16][64];         // partial sums
+    __shared__ double part[PS_NQ][64];      // partial sums
     if (*info != 0) return;
     const int t = threadIdx.x, r = t & 63, q = t >> 6;
     const int G = gridDim.x, g = blockIdx.x;
@@ -308,146 +321,158 @@ __global__ __launch_bounds__(256) void persistent_solve_kernel(
     double* ypub = pub + Np;
     double* zfin = pub + 2 * Np;
     double* xpub = pub + 3 * Np;
-    for (int e = t; e < nown * 64; e += 256) run[e >> 6][e & 63] = xio[(int64_t)(g + (e >> 6) * G) * 64 + (e & 63)];
+    for (int e = t; e < nown * 64; e += PS_NT) run[e >> 6][e & 63] = xio[(int64_t)(g + (e >> 6) * G) * 64 + (e & 63)];
     __syncthreads();
 
-    double a[64];
+    double a[PS_CW];  // slice of L the next update multiplies
+    double d[PS_CW];  // slice of inv(L_kk) / inv(L_kk)^T the next diagonal role multiplies
+    // dot product of a register slice with chunk q of xs, and the 16-way reduction over the chunks
+    auto dot_chunk = [&](const double (&v)[PS_CW], bool active) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (active) {
+            const double* xq = xs + q * PS_CW;
+#pragma unroll
+            for (int j = 0; j < PS_CW; j += 4) {
+                s0 = fma(v[j], xq[j], s0);
+                s1 = fma(v[j + 1], xq[j + 1], s1);
+                s2 = fma(v[j + 2], xq[j + 2], s2);
+                s3 = fma(v[j + 3], xq[j + 3], s3);
+            }
+        }
+        part[q][r] = (s0 + s1) + (s2 + s3);
+    };
+    auto reduce_parts = [&](int c) {
+        double sm = 0.0;
+#pragma unroll
+        for (int u = 0; u < PS_NQ; ++u) sm += part[u][c];
+        return sm;
+    };
+    const int qb = (q * PS_CW) >> 6;  // 64-block (within the step) that column chunk q belongs to
+
     // ------------------------------------------------------------------ forward: L y = b
-    int m0 = 0;  // first owned block whose forward solution is not yet known
+    int m0 = 0;           // first owned block whose forward solution is not yet known
+    bool have_d = false;  // d holds the slice for block own[m0] and its bfin is already published
     for (int k = 0; k < nsteps && m0 < nown; ++k) {
         const int b0 = 4 * k, nbk = nb - b0 < 4 ? nb - b0 : 4;
         int i = g + m0 * G;
         if (i < b0 + nbk) {
             // diagonal role: y_i = sum_{c <= li} inv(L_kk)[li, c] * bfin[b0 + c]
             const int li = i - b0;
-            const double* Mk = Inv + (int64_t)k * (SB * SB) + (li * 64 + r) + (int64_t)(q * 64) * SB;
-            if (q <= li) {
+            if (!have_d) {  // first step, or a block that was never "next" (tiny systems)
+                const double* Mk = Inv + (int64_t)k * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
+                if (qb <= li) {
 #pragma unroll
-                for (int j = 0; j < 64; ++j) a[j] = Mk[(int64_t)j * SB];
-            }
-            if (t < 64) {
-                const double v = run[m0][t];
-                ps_publish(bfin + (int64_t)i * 64 + t, v);
-                xs[li * 64 + t] = v;
-            }
-            if (!ps_gather(bfin + (int64_t)b0 * 64, li * 64, xs, abort_flag)) return;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            if (q <= li) {
-                const double* xq = xs + q * 64;
-#pragma unroll
-                for (int j = 0; j < 64; j += 4) {
-                    s0 = fma(a[j], xq[j], s0);
-                    s1 = fma(a[j + 1], xq[j + 1], s1);
-                    s2 = fma(a[j + 2], xq[j + 2], s2);
-                    s3 = fma(a[j + 3], xq[j + 3], s3);
+                    for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
                 }
+                if (t < 64) ps_publish(bfin + (int64_t)i * 64 + t, run[m0][t]);
             }
-            part[q][r] = (s0 + s1) + (s2 + s3);
+            if (t < 64) xs[li * 64 + t] = run[m0][t];
+            if (!ps_gather(bfin + (int64_t)b0 * 64, li * 64, xs, abort_flag)) return;
+            PS_STAMP(i, 3);
+            dot_chunk(d, qb <= li);
             __syncthreads();
             if (t < 64) {
-                const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+                const double v = reduce_parts(t);
                 ps_publish(ypub + (int64_t)i * 64 + t, v);
                 ysol[m0][t] = v;
             }
+            PS_STAMP(i, 4);
             __syncthreads();
+            have_d = false;
             ++m0;
             if (m0 >= nown) break;
             i = g + m0 * G;
         }
-        // update role: run_i -= L[i, step k] * y_k for the owned blocks below the step
+        // update role: run_i -= L[i, step k] * y_k for the owned blocks below the step.  Everything the
+        // critical block needs next is requested before the wait: its slice of L for this step and, if
+        // it sits in the next diagonal step, its slice of that step's inverse.
+        const bool diag_next = i < b0 + nbk + 4;
         {
-            const double* Fs = F + ((int64_t)i * 64 + r) + ((int64_t)b0 * 64 + q * 64) * ld;
-            if (q < nbk) {
+            const double* Fs = F + ((int64_t)i * 64 + r) + ((int64_t)b0 * 64 + q * PS_CW) * ld;
+            if (qb < nbk) {
 #pragma unroll
-                for (int j = 0; j < 64; ++j) a[j] = Fs[(int64_t)j * ld];
+                for (int j = 0; j < PS_CW; ++j) a[j] = Fs[(int64_t)j * ld];
             }
-        }
-        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag)) return;
-        for (int m = m0; m < nown; ++m) {
-            const int im = g + m * G;
-            if (m > m0 && q < nbk) {
-                const double* Fs = F + ((int64_t)im * 64 + r) + ((int64_t)b0 * 64 + q * 64) * ld;
+            if (diag_next) {
+                const int li = i - (b0 + nbk);
+                const double* Mk = Inv + (int64_t)(k + 1) * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
+                if (qb <= li) {
 #pragma unroll
-                for (int j = 0; j < 64; ++j) a[j] = Fs[(int64_t)j * ld];
-            }
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            if (q < nbk) {
-                const double* xq = xs + q * 64;
-#pragma unroll
-                for (int j = 0; j < 64; j += 4) {
-                    s0 = fma(a[j], xq[j], s0);
-                    s1 = fma(a[j + 1], xq[j + 1], s1);
-                    s2 = fma(a[j + 2], xq[j + 2], s2);
-                    s3 = fma(a[j + 3], xq[j + 3], s3);
+                    for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
                 }
             }
-            part[q][r] = (s0 + s1) + (s2 + s3);
+        }
+        if (diag_next) PS_STAMP(i, 0);
+        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i >= b0 + nbk + 4 * PS_NEAR)) return;
+        if (diag_next) PS_STAMP(i, 1);
+        for (int m = m0; m < nown; ++m) {
+            const int im = g + m * G;
+            if (m > m0 && qb < nbk) {
+                const double* Fs = F + ((int64_t)im * 64 + r) + ((int64_t)b0 * 64 + q * PS_CW) * ld;
+#pragma unroll
+                for (int j = 0; j < PS_CW; ++j) a[j] = Fs[(int64_t)j * ld];
+            }
+            dot_chunk(a, qb < nbk);
             __syncthreads();
-            if (t < 64) run[m][t] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+            if (t < 64) {
+                const double v = run[m][t] - reduce_parts(t);
+                run[m][t] = v;
+                if (m == m0 && diag_next) ps_publish(bfin + (int64_t)im * 64 + t, v);  // final: hand it on at once
+            }
+            if (m == m0 && diag_next) PS_STAMP(im, 2);
             __syncthreads();
         }
+        have_d = diag_next;
     }
 
     // ------------------------------------------------------------------ backward: L^T x = D^-1 y
-    for (int e = t; e < nown * 64; e += 256) {
+    for (int e = t; e < nown * 64; e += PS_NT) {
         const int m = e >> 6, c = e & 63;
         const double y = ysol[m][c];
         run[m][c] = LDL ? y * dinv[(int64_t)(g + m * G) * 64 + c] : y;
     }
     __syncthreads();
-    const int lane = t & 63, sub = lane & 15, colq = lane >> 4;
+    // update-role mapping: wave q -> row chunk rc = q & 3 (64 rows of the step), column group cg = q >> 2
+    // (16 columns of the block); lane (sub, colq): rows 4*sub..4*sub+3, columns cg*16 + 4p + colq, p < 4.
+    const int lane = t & 63, sub = lane & 15, colq = lane >> 4, rc = q & 3, cg = q >> 2;
     int m1 = nown - 1;  // last owned block whose solution is not yet known
+    have_d = false;
     for (int k = nsteps - 1; k >= 0 && m1 >= 0; --k) {
         const int b0 = 4 * k, nbk = nb - b0 < 4 ? nb - b0 : 4;
         int i = g + m1 * G;
         if (i >= b0) {
             // diagonal role: x_i = sum_{rc >= li} inv(L_kk)^T[li, rc] * zfin[b0 + rc]
             const int li = i - b0;
-            const bool act = q >= li && q < nbk;
-            const double* Mk = InvT + (int64_t)k * (SB * SB) + (li * 64 + r) + (int64_t)(q * 64) * SB;
-            if (act) {
+            const bool act = qb >= li && qb < nbk;
+            if (!have_d) {
+                const double* Mk = InvT + (int64_t)k * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
+                if (act) {
 #pragma unroll
-                for (int j = 0; j < 64; ++j) a[j] = Mk[(int64_t)j * SB];
-            }
-            if (t < 64) {
-                const double v = run[m1][t];
-                ps_publish(zfin + (int64_t)i * 64 + t, v);
-                xs[li * 64 + t] = v;
-            }
-            // blocks li+1 .. nbk-1 of the step come from their owners
-            {
-                const int n = (nbk - 1 - li) * 64;
-                if (!ps_gather(zfin + (int64_t)(i + 1) * 64, n, xs + (li + 1) * 64, abort_flag)) return;
-            }
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            if (act) {
-                const double* xq = xs + q * 64;
-#pragma unroll
-                for (int j = 0; j < 64; j += 4) {
-                    s0 = fma(a[j], xq[j], s0);
-                    s1 = fma(a[j + 1], xq[j + 1], s1);
-                    s2 = fma(a[j + 2], xq[j + 2], s2);
-                    s3 = fma(a[j + 3], xq[j + 3], s3);
+                    for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
                 }
+                if (t < 64) ps_publish(zfin + (int64_t)i * 64 + t, run[m1][t]);
             }
-            part[q][r] = (s0 + s1) + (s2 + s3);
+            if (t < 64) xs[li * 64 + t] = run[m1][t];
+            // blocks li+1 .. nbk-1 of the step come from their owners
+            if (!ps_gather(zfin + (int64_t)(i + 1) * 64, (nbk - 1 - li) * 64, xs + (li + 1) * 64, abort_flag)) return;
+            dot_chunk(d, act);
             __syncthreads();
             if (t < 64) {
-                const double v = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+                const double v = reduce_parts(t);
                 ps_publish(xpub + (int64_t)i * 64 + t, v);
                 xio[(int64_t)i * 64 + t] = v;
             }
             __syncthreads();
+            have_d = false;
             --m1;
             if (m1 < 0) break;
             i = g + m1 * G;
         }
-        // update role: run_i -= L[step k rows, block i columns]^T * x_k for the owned blocks before the step.
-        // Wave q takes the 64 rows b0*64 + 64q ..; lane (sub, colq): rows 4*sub..4*sub+3, columns 4p + colq.
+        // update role: run_i -= L[step k rows, block i columns]^T * x_k for the owned blocks before the step
         auto load_slice = [&](int im) {
-            const double* Fs = F + ((int64_t)b0 * 64 + 64 * q + 4 * sub) + ((int64_t)im * 64 + colq) * ld;
+            const double* Fs = F + ((int64_t)b0 * 64 + 64 * rc + 4 * sub) + ((int64_t)im * 64 + cg * 16 + colq) * ld;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < 4; ++p) {
                 const v2d lo = *reinterpret_cast<const v2d*>(Fs + (int64_t)(4 * p) * ld);
                 const v2d hi = *reinterpret_cast<const v2d*>(Fs + (int64_t)(4 * p) * ld + 2);
                 a[4 * p] = lo[0];
@@ -456,35 +481,47 @@ __global__ __launch_bounds__(256) void persistent_solve_kernel(
                 a[4 * p + 3] = hi[1];
             }
         };
-        if (q < nbk) load_slice(i);
-        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag)) return;
+        const bool diag_next = i >= b0 - 4;  // the critical block sits in the step right before this one
+        if (rc < nbk) load_slice(i);
+        if (diag_next) {
+            const int li = i - (b0 - 4);
+            const double* Mk = InvT + (int64_t)(k - 1) * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
+            if (qb >= li) {  // step k-1 is a full step (4 blocks)
+#pragma unroll
+                for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
+            }
+        }
+        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i < b0 - 4 * PS_NEAR)) return;
         for (int m = m1; m >= 0; --m) {
             const int im = g + m * G;
-            if (m < m1 && q < nbk) load_slice(im);
-            if (q < nbk) {
-                const double x0 = xs[64 * q + 4 * sub], x1 = xs[64 * q + 4 * sub + 1], x2 = xs[64 * q + 4 * sub + 2],
-                             x3 = xs[64 * q + 4 * sub + 3];
+            if (m < m1 && rc < nbk) load_slice(im);
+            // part[rc * 4 + (sub >> 2)][col]: 16 partial sums per column
+            if (rc < nbk) {
+                const double x0 = xs[64 * rc + 4 * sub], x1 = xs[64 * rc + 4 * sub + 1],
+                             x2 = xs[64 * rc + 4 * sub + 2], x3 = xs[64 * rc + 4 * sub + 3];
 #pragma unroll
-                for (int p = 0; p < 16; ++p) {
+                for (int p = 0; p < 4; ++p) {
                     double sp = (a[4 * p] * x0 + a[4 * p + 1] * x1) + (a[4 * p + 2] * x2 + a[4 * p + 3] * x3);
                     sp += __shfl_xor(sp, 1);
                     sp += __shfl_xor(sp, 2);
-                    if ((sub & 3) == 0) part[q * 4 + (sub >> 2)][4 * p + colq] = sp;
+                    if ((sub & 3) == 0) part[rc * 4 + (sub >> 2)][cg * 16 + 4 * p + colq] = sp;
                 }
-            } else {
-                // idle row chunks contribute zeros
-                for (int e = lane; e < 4 * 64; e += 64) part[q * 4 + (e >> 6)][e & 63] = 0.0;
+            } else if (lane < 16) {
+                // idle row chunks contribute zeros to their 4 rows of `part` (16 columns per wave)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) part[rc * 4 + u][cg * 16 + lane] = 0.0;
             }
             __syncthreads();
             if (t < 64) {
-                double sm = 0.0;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) sm += part[u][t];
-                run[m][t] -= sm;
+                const double v = run[m][t] - reduce_parts(t);
+                run[m][t] = v;
+                if (m == m1 && diag_next) ps_publish(zfin + (int64_t)im * 64 + t, v);
             }
             __syncthreads();
         }
+        have_d = diag_next;
     }
+#undef PS_STAMP
 }
 
 }  // namespace mnk
@@ -508,17 +545,28 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
     const int64_t nb64 = Np / 64;
     const int G = (int)std::min<int64_t>(nb64, ls->ctx->num_cu);
     if (ls->persistent_solve && G >= 1 && (nb64 + G - 1) / G <= PS_MAXOWN && (G >= 4 || nb64 <= G)) {
+        // The kernel needs all its workgroups resident at once (one per CU).  Two of them launched
+        // from different contexts could each grab part of the chip and wait for the rest forever, so
+        // persistent solves of one process are chained on the device through an event.
+        static std::mutex ps_mutex;
+        static hipEvent_t ps_last[64] = {};
+        std::lock_guard<std::mutex> lock(ps_mutex);
+        hipEvent_t& last = ps_last[ls->ctx->device & 63];
+        if (last == nullptr) MNK_HIP(hipEventCreateWithFlags(&last, hipEventDisableTiming));
+        else MNK_HIP(hipStreamWaitEvent(s, last, 0));
         double* pub = xdev + 2 * Np;
         hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<unsigned long long*>(pub), 4 * Np, ls->solve_abort.p);
         if (ldl)
-            hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(256), 0, s, ls->fact.p, ld, ls->linv256.p,
-                               ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort.p, ls->info_dev.p);
+            hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv256.p,
+                               ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort.p, ls->info_dev.p,
+                               ls->solve_trace.p);
         else
-            hipLaunchKernelGGL(persistent_solve_kernel<false>, dim3(G), dim3(256), 0, s, ls->fact.p, ld,
+            hipLaunchKernelGGL(persistent_solve_kernel<false>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld,
                                ls->linv256.p, ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort.p,
-                               ls->info_dev.p);
+                               ls->info_dev.p, ls->solve_trace.p);
         MNK_HIP(hipGetLastError());
+        MNK_HIP(hipEventRecord(last, s));
         return 0;
     }
     double* b = xdev;       // forward: running right-hand side; backward: solution
