@@ -375,19 +375,24 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
         }
         int rc = mnk_ls_run_solve(ls, w);
         if (rc) return rc;
-        MNK_HIP(hipMemcpyAsync(xk, w, N * sizeof(double),
-                               loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-        if (loc != MNK_DEVICE) {
+        if (loc != MNK_DEVICE && ls->persistent_solve) {
+            // The one-launch solve gives up (instead of hanging the device) if its workgroups cannot all become
+            // resident, e.g. another process saturates the GPU with its own persistent kernels.  The host still
+            // owns the right-hand side here: redo this and all later solves with one launch per step.
             int aborted = 0;
-            if (ls->persistent_solve)
-                MNK_HIP(hipMemcpyAsync(&aborted, ls->solve_abort.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            MNK_HIP(hipMemcpyAsync(&aborted, ls->solve_abort.p, sizeof(int), hipMemcpyDeviceToHost, s));
             MNK_HIP(hipStreamSynchronize(s));
             if (aborted) {
-                set_error("mnk_ls_solve: the persistent solve kernel gave up waiting for a peer workgroup "
-                          "(device oversubscribed?); set option persistent_solve = 0");
-                return -3;
+                ls->persistent_solve = 0;
+                MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
+                MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
+                rc = mnk_ls_run_solve(ls, w);
+                if (rc) return rc;
             }
         }
+        MNK_HIP(hipMemcpyAsync(xk, w, N * sizeof(double),
+                               loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
     }
     return 0;
 }

@@ -116,6 +116,7 @@ class HipSolverOptions:
     lookahead: bool = True
     share: int = 1          # 0 off, 1 adaptive, 2 always: panel-stream CUs join the trailing update
     small_tiles: int = 400  # (a)-updates with fewer 128x128 tiles use 64x64 workgroup tiles
+    persistent_solve: bool = True  # both triangular sweeps in one launch (False: one launch per 256-column step)
 
 
 class HipLinearSolver:
@@ -146,6 +147,8 @@ class HipLinearSolver:
             settings.append(("share", float(self.opt.share)))
         if "MNK_SMALL_TILES" not in os.environ:
             settings.append(("small_tiles", float(self.opt.small_tiles)))
+        if "MNK_PERSISTENT_SOLVE" not in os.environ:
+            settings.append(("persistent_solve", float(self.opt.persistent_solve)))
         for key, val in settings:
             L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(val)), "mnk_ls_set_option")
         self.info = 0
