@@ -48,7 +48,7 @@ __device__ __forceinline__ void decode_tile(int logical, int ntm, int& tm, int& 
 }
 
 // One workgroup tile of C.  Every thread of the workgroup must call it with the same (tm, tn).
-template <int WM, int WN, int WT, int MODE, bool LDL_EPI, bool DBG_SHARED_AB = false>
+template <int WM, int WN, int WT, int MODE, bool LDL_EPI, int DBG = 0>
 __device__ __forceinline__ void gemm_nt_tile(
     int tm, int tn, int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
@@ -73,10 +73,11 @@ __device__ __forceinline__ void gemm_nt_tile(
     const int wm = wave % WM, wn = wave / WM;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // DBG_SHARED_AB (diagnostics only): every tile reads the same two operand blocks, i.e. perfect
-    // cache reuse, to separate the memory-side cost of the update from its MFMA/LDS cost
-    const double* Ag = A + (DBG_SHARED_AB ? (int64_t)(tm & 1) * BM : row0);
-    const double* Bg = B + (DBG_SHARED_AB ? (int64_t)(tn & 1) * BN : col0);
+    // DBG (diagnostics only, results are wrong for DBG >= 2): 1 = every tile reads the same two operand
+    // blocks (perfect cache reuse: separates the memory-side cost from the MFMA/LDS cost); 2 = no barrier in
+    // the k-loop; 3 = no global loads / LDS stores in the k-loop (MFMA + LDS-read loop alone)
+    const double* Ag = A + (DBG == 1 ? (int64_t)(tm & 1) * BM : row0);
+    const double* Bg = B + (DBG == 1 ? (int64_t)(tn & 1) * BN : col0);
 
     v2f64 ra[APIECES], rb[BPIECES];
 
@@ -112,6 +113,26 @@ __device__ __forceinline__ void gemm_nt_tile(
         }
     };
 
+    // 128x128 tiles stage through the LDS-DMA path (global_load_lds_dwordx4: one wave instruction moves one
+    // 128-row k-column, 1 KiB, straight into its LDS row; no staging registers, no ds_write pass):
+    // measured +3 % (192 CUs) / +5 % (256 CUs) on the trailing update, bit-identical results.
+    // DBG == 5 (diagnostics) forces the register-staged path for A/B runs.
+    constexpr bool DMA = BM == 128 && BN == 128 && (DBG == 0 || DBG == 1 || DBG == 4);
+    constexpr int NW = NT / 64;
+    auto gl_lds = [&](int kt, int buf) {
+        const int64_t k0 = (int64_t)kt * BK;
+        double* as = As + buf * BK * LDA_S;
+        double* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+        for (int i = 0; i < BK / NW; ++i) {
+            const int k = wave * (BK / NW) + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + (k0 + k) * lda + lane * 2),
+                                             (__attribute__((address_space(3))) void*)(as + k * LDA_S), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + (k0 + k) * ldb + lane * 2),
+                                             (__attribute__((address_space(3))) void*)(bs + k * LDB_S), 16, 0, 0);
+        }
+    };
+
     v4f64 acc[WT][WT];  // [ni][mi]
 #pragma unroll
     for (int i = 0; i < WT; ++i)
@@ -119,13 +140,22 @@ __device__ __forceinline__ void gemm_nt_tile(
         for (int j = 0; j < WT; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
 
     const int nk = (int)(K / BK);
-    gload(0);
-    sstore(0);
+    if (DMA) {
+        gl_lds(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        gload(0);
+        sstore(0);
+    }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
+        if (DMA) {
+            if (kt + 1 < nk) gl_lds(kt + 1, cur ^ 1);
+        } else if (DBG != 3 && kt + 1 < nk) {
+            gload(kt + 1);
+        }
         const double* as = As + cur * BK * LDA_S + wm * WS + l15;
         const double* bs = Bs + cur * BK * LDB_S + wn * WS + l15;
 #pragma unroll
@@ -142,8 +172,14 @@ __device__ __forceinline__ void gemm_nt_tile(
                 for (int mi = 0; mi < WT; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
-        if (kt + 1 < nk) sstore(cur ^ 1);
-        __syncthreads();
+        if (DMA) {
+            // the DMA writes are ordered for the readers by this wave's vmcnt followed by the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            if (DBG != 3 && kt + 1 < nk) sstore(cur ^ 1);
+            if (DBG != 2 && DBG != 3) __syncthreads();
+        }
     }
 
     // epilogue: lane (l15, l4), reg r of acc[ni][mi] is C[row0+wm*64+mi*16+l15, col0+wn*64+ni*16+l4+4r]
@@ -204,7 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     gemm_nt_tile<WM, WN, WT, MODE, LDL_EPI>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, smem_raw);
 }
 
-template <int WM, int WN, int WT, int MODE, bool SHARED>
+template <int WM, int WN, int WT, int MODE, int DBG>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dbg_kernel(
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc, int ntm) {
@@ -213,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dbg_kernel(
     int logical = (per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid;
     int tm, tn;
     decode_tile<MODE>(logical, ntm, tm, tn);
-    gemm_nt_tile<WM, WN, WT, MODE, false, SHARED>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
+    gemm_nt_tile<WM, WN, WT, MODE, false, DBG>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
 }
 
 // Work-queue variant: the workgroups of one or more launches (possibly on different streams with
@@ -337,15 +373,19 @@ int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64
     const int ntm = (int)((M + 127) / 128);
     const int ntiles = gemm_nt_lower_tiles(M, N);
     const size_t smem = 2 * BK * ((128 + 16) + (128 + 16)) * sizeof(double);
-    if (shared_ab) {
-        auto kern = gemm_nt_dbg_kernel<2, 2, 4, 2, true>;
-        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm);
-    } else {
-        auto kern = gemm_nt_dbg_kernel<2, 2, 4, 2, false>;
-        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm);
-    }
+#define MNK_DBG_LAUNCH(D)                                                                                        \
+    do {                                                                                                         \
+        auto kern = gemm_nt_dbg_kernel<2, 2, 4, 2, D>;                                                           \
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm);        \
+    } while (0)
+    if (shared_ab == 1) MNK_DBG_LAUNCH(1);
+    else if (shared_ab == 2) MNK_DBG_LAUNCH(2);
+    else if (shared_ab == 3) MNK_DBG_LAUNCH(3);
+    else if (shared_ab == 4) MNK_DBG_LAUNCH(4);
+    else if (shared_ab == 5) MNK_DBG_LAUNCH(5);
+    else MNK_DBG_LAUNCH(0);
+#undef MNK_DBG_LAUNCH
     MNK_HIP(hipGetLastError());
     return 0;
 }

@@ -479,6 +479,10 @@ int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const doub
         case 21: rc = launch_gemm_nt(su, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr); break;
         case 9: rc = launch_gemm_nt_dbg(s, 1, M, M, K, A, lda, A, lda, C, ldc); break;
         case 10: rc = launch_gemm_nt_dbg(su, 1, M, M, K, A, lda, A, lda, C, ldc); break;
+        case 11: rc = launch_gemm_nt_dbg(su, 2, M, M, K, A, lda, A, lda, C, ldc); break;  // no k-loop barrier
+        case 12: rc = launch_gemm_nt_dbg(su, 3, M, M, K, A, lda, A, lda, C, ldc); break;  // MFMA + LDS reads only
+        case 13: rc = launch_gemm_nt_dbg(su, 5, M, M, K, A, lda, A, lda, C, ldc); break;  // register staging
+        case 14: rc = launch_gemm_nt_dbg(s, 5, M, M, K, A, lda, A, lda, C, ldc); break;
         case 6: case 7: case 8: {  // static tiling on the context stream, one launch per `chunk` tiles
             const int chunk = variant == 6 ? 2 * ctx->num_cu : variant == 7 ? 4 * ctx->num_cu : ctx->num_cu;
             const int nt = gemm_nt_lower_tiles(M, M);

@@ -21,9 +21,11 @@ with torch.cuda.stream(s):
     s.synchronize()
     names = ["static/ctx", "queue/ctx", "static/su", "queue/su", "queue/su+sp", "static/su + half-size static/sp",
              "static/ctx chunks of 512 tiles", "static/ctx chunks of 1024 tiles", "static/ctx chunks of 256 tiles",
-             "static/ctx, all tiles read the same A/B blocks", "static/su, all tiles read the same A/B blocks"]
+             "static/ctx, all tiles read the same A/B blocks", "static/su, all tiles read the same A/B blocks",
+             "static/su, k-loop without barriers (wrong results)", "static/su, k-loop without global loads / LDS stores",
+             "static/su, register staging instead of LDS-DMA", "static/ctx, register staging instead of LDS-DMA"]
     ntiles = (M // 128) * (M // 128 + 1) // 2
-    for v in [0, 2, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]:
+    for v in [0, 2, 0, 2, 13, 14, 2, 13, 0, 14]:
         for it in range(2):
             ms = C.c_double()
             L.check(L.lib().mnk_debug_update(ctx.handle, v, M, K, A.data_ptr(), M, Cm.data_ptr(), C2.data_ptr(), M, reps,
@@ -31,6 +33,16 @@ with torch.cuda.stream(s):
         t = ms.value / reps
         print(f"{names[v]:36s} {t*1e3:9.1f} us/update  {ntiles*128*128*K*2/t/1e9:7.2f} TFLOP/s (lower tiles)")
 
+    # LDS-DMA staging (default) against register staging: one update from C = 0
+    for v, Cx in ((2, Cm), (13, C2)):
+        Cx.zero_()
+        s.synchronize()
+        ms = C.c_double()
+        L.check(L.lib().mnk_debug_update(ctx.handle, v, M, K, A.data_ptr(), M, Cx.data_ptr(), Cx.data_ptr(), M, 1,
+                                         C.byref(ms)), "mnk_debug_update")
+    s.synchronize()
+    print("LDS-DMA staging == register staging (lower triangle):", bool(torch.equal(torch.triu(Cm), torch.triu(C2))),
+          float((torch.triu(Cm) - torch.triu(C2)).abs().max()))
     # shader clock under load: a fixed dependent FMA chain timed with the constant-rate timer
     for v, name in ((20, "probe alone"), (20, "probe alone"), (21, "probe beside update on su"), (21, "probe beside update on su"),
                     (20, "probe alone")):
