@@ -709,7 +709,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                 if (shared_b)
                     rc = launch_gemm_nt_queue(su, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
                                               F + (kend + nnext) + (kend + nnext) * ld, ld, ls->tile_ctr.p + 8 * k,
-                                              2 * ucus, ls->info_dev.p);
+                                              ucus, ls->info_dev.p);
                 else
                     rc = launch_gemm_nt(su, 2, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
                                         F + (kend + nnext) + (kend + nnext) * ld, ld, nullptr, nullptr, 0,
@@ -724,7 +724,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             if (shared_b) {
                 rc = launch_gemm_nt_queue(sp, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
                                           F + (kend + nnext) + (kend + nnext) * ld, ld, ls->tile_ctr.p + 8 * k,
-                                          2 * pcus, ls->info_dev.p);
+                                          pcus, ls->info_dev.p);
                 if (rc) return rc;
             }
             MNK_HIP(hipEventRecord(ctx->ev_panel[k + 1], sp));

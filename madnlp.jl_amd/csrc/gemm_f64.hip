@@ -28,6 +28,12 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16;
+// k-tile depth and workgroups per CU of a tile shape.  The 128x128 tile (4 waves x 64x64) runs BK = 8:
+// 36.9 KB of LDS and <= 168 VGPRs let three workgroups share a CU (three waves per SIMD hide the
+// barrier / LDS-DMA stalls of one another): measured +4 % over BK = 16 with two workgroups, same sums.
+constexpr bool tile_big(int wm, int wn, int wt) { return wm == 2 && wn == 2 && wt == 4; }
+constexpr int tile_bk(int wm, int wn, int wt) { return tile_big(wm, wn, wt) ? 8 : BK; }
+constexpr int tile_occ(int wm, int wn, int wt) { return tile_big(wm, wn, wt) ? 3 : 2; }
 
 // Decode a logical tile index into (tm, tn).  Lower-only modes enumerate the tiles on/below the
 // diagonal column by column (tile column tn holds rows tn..ntm-1): first(tn) = tn*ntm - tn*(tn-1)/2.
@@ -48,7 +54,7 @@ __device__ __forceinline__ void decode_tile(int logical, int ntm, int& tm, int& 
 }
 
 // One workgroup tile of C.  Every thread of the workgroup must call it with the same (tm, tn).
-template <int WM, int WN, int WT, int MODE, bool LDL_EPI, int DBG = 0>
+template <int WM, int WN, int WT, int MODE, bool LDL_EPI, int DBG = 0, int BKT = BK>
 __device__ __forceinline__ void gemm_nt_tile(
     int tm, int tn, int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
@@ -57,12 +63,12 @@ __device__ __forceinline__ void gemm_nt_tile(
     constexpr int WS = 16 * WT;  // wave tile edge (WT x WT MFMA 16x16 tiles per wave)
     constexpr int BM = WS * WM, BN = WS * WN;
     constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
-    constexpr int APIECES = (BM / 2) * BK / NT;  // 16-byte pieces per thread per k-tile
-    constexpr int BPIECES = (BN / 2) * BK / NT;
+    constexpr int APIECES = (BM / 2) * BKT / NT;  // 16-byte pieces per thread per k-tile
+    constexpr int BPIECES = (BN / 2) * BKT / NT;
     static_assert(APIECES >= 1 && BPIECES >= 1, "tile too small for the thread count");
 
-    double* As = reinterpret_cast<double*>(smem_raw);           // [2][BK][LDA_S]
-    double* Bs = As + 2 * BK * LDA_S;                           // [2][BK][LDB_S]
+    double* As = reinterpret_cast<double*>(smem_raw);           // [2][BKT][LDA_S]
+    double* Bs = As + 2 * BKT * LDA_S;                           // [2][BKT][LDB_S]
 
     const int64_t row0 = (int64_t)tm * BM;
     const int64_t col0 = (int64_t)tn * BN;
@@ -82,7 +88,7 @@ __device__ __forceinline__ void gemm_nt_tile(
     v2f64 ra[APIECES], rb[BPIECES];
 
     auto gload = [&](int kt) {
-        const int64_t k0 = (int64_t)kt * BK;
+        const int64_t k0 = (int64_t)kt * BKT;
 #pragma unroll
         for (int q = 0; q < APIECES; ++q) {
             int p = tid + NT * q;
@@ -97,8 +103,8 @@ __device__ __forceinline__ void gemm_nt_tile(
         }
     };
     auto sstore = [&](int buf) {
-        double* as = As + buf * BK * LDA_S;
-        double* bs = Bs + buf * BK * LDB_S;
+        double* as = As + buf * BKT * LDA_S;
+        double* bs = Bs + buf * BKT * LDB_S;
 #pragma unroll
         for (int q = 0; q < APIECES; ++q) {
             int p = tid + NT * q;
@@ -120,12 +126,12 @@ __device__ __forceinline__ void gemm_nt_tile(
     constexpr bool DMA = BM == 128 && BN == 128 && (DBG == 0 || DBG == 1 || DBG == 4);
     constexpr int NW = NT / 64;
     auto gl_lds = [&](int kt, int buf) {
-        const int64_t k0 = (int64_t)kt * BK;
-        double* as = As + buf * BK * LDA_S;
-        double* bs = Bs + buf * BK * LDB_S;
+        const int64_t k0 = (int64_t)kt * BKT;
+        double* as = As + buf * BKT * LDA_S;
+        double* bs = Bs + buf * BKT * LDB_S;
 #pragma unroll
-        for (int i = 0; i < BK / NW; ++i) {
-            const int k = wave * (BK / NW) + i;
+        for (int i = 0; i < BKT / NW; ++i) {
+            const int k = wave * (BKT / NW) + i;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + (k0 + k) * lda + lane * 2),
                                              (__attribute__((address_space(3))) void*)(as + k * LDA_S), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + (k0 + k) * ldb + lane * 2),
@@ -139,7 +145,7 @@ __device__ __forceinline__ void gemm_nt_tile(
 #pragma unroll
         for (int j = 0; j < WT; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
 
-    const int nk = (int)(K / BK);
+    const int nk = (int)(K / BKT);
     if (DMA) {
         gl_lds(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -156,10 +162,10 @@ __device__ __forceinline__ void gemm_nt_tile(
         } else if (DBG != 3 && kt + 1 < nk) {
             gload(kt + 1);
         }
-        const double* as = As + cur * BK * LDA_S + wm * WS + l15;
-        const double* bs = Bs + cur * BK * LDB_S + wn * WS + l15;
+        const double* as = As + cur * BKT * LDA_S + wm * WS + l15;
+        const double* bs = Bs + cur * BKT * LDB_S + wn * WS + l15;
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
+        for (int kk = 0; kk < BKT / 4; ++kk) {
             double af[WT], bf[WT];
 #pragma unroll
             for (int i = 0; i < WT; ++i) {
@@ -220,7 +226,7 @@ __device__ __forceinline__ void gemm_nt_tile(
 }
 
 template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
+__global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_kernel(
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
     const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
@@ -237,11 +243,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(
     int logical = tile_off + ((per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid);
     int tm, tn;
     decode_tile<MODE>(logical, ntm, tm, tn);
-    gemm_nt_tile<WM, WN, WT, MODE, LDL_EPI>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, colscale, C2, ldc2, smem_raw);
+    gemm_nt_tile<WM, WN, WT, MODE, LDL_EPI, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, colscale,
+                                                                       C2, ldc2, smem_raw);
 }
 
 template <int WM, int WN, int WT, int MODE, int DBG>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dbg_kernel(
+__global__ __launch_bounds__(64 * WM * WN, DBG == 6 ? 2 : tile_occ(WM, WN, WT)) void gemm_nt_dbg_kernel(
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc, int ntm) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dbg_kernel(
     int logical = (per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid;
     int tm, tn;
     decode_tile<MODE>(logical, ntm, tm, tn);
-    gemm_nt_tile<WM, WN, WT, MODE, false, DBG>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
+    gemm_nt_tile<WM, WN, WT, MODE, false, DBG == 6 ? 0 : DBG, DBG == 6 ? 16 : tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
 }
 
 // Work-queue variant: the workgroups of one or more launches (possibly on different streams with
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dbg_kernel(
 // workgroup drains the chunk of the XCD it runs on first (tiles of one chunk share A/B blocks in
 // that XCD's L2, like the static remap of gemm_nt_kernel) and then steals from the other chunks.
 template <int WM, int WN, int WT, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_queue_kernel(
+__global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_queue_kernel(
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc, int ntm, int ntiles,
     int* __restrict__ counters /* [8] */, const int* __restrict__ info_flag) {
@@ -280,7 +287,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_queue_kernel(
         if (logical >= hi) { ++probe; continue; }
         int tm, tn;
         decode_tile<MODE>(logical, ntm, tm, tn);
-        gemm_nt_tile<WM, WN, WT, MODE, false>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
+        gemm_nt_tile<WM, WN, WT, MODE, false, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr,
+                                                                          nullptr, 0, smem_raw);
         __syncthreads();  // LDS tiles are reused by the next round
     }
 }
@@ -297,7 +305,7 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
         const int nc = ntn < ntm ? ntn : ntm;  // tile columns that contain a lower tile
         ntiles = nc * ntm - nc * (nc - 1) / 2;
     }
-    const size_t smem = 2 * BK * ((BM + 16) + (BN + 16)) * sizeof(double);
+    const size_t smem = 2 * tile_bk(WM, WN, WT) * ((BM + 16) + (BN + 16)) * sizeof(double);
     auto kern = gemm_nt_kernel<WM, WN, WT, MODE, LDL_EPI>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -372,18 +380,20 @@ int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64
                        const double* B, int64_t ldb, double* C, int64_t ldc) {
     const int ntm = (int)((M + 127) / 128);
     const int ntiles = gemm_nt_lower_tiles(M, N);
-    const size_t smem = 2 * BK * ((128 + 16) + (128 + 16)) * sizeof(double);
+    const size_t smem = 2 * tile_bk(2, 2, 4) * ((128 + 16) + (128 + 16)) * sizeof(double);
 #define MNK_DBG_LAUNCH(D)                                                                                        \
     do {                                                                                                         \
         auto kern = gemm_nt_dbg_kernel<2, 2, 4, 2, D>;                                                           \
-        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm);        \
+        const size_t smem_d = D == 6 ? smem * 2 : smem; /* variant 6 runs BK = 16 */                             \
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_d)); \
+        hipLaunchKernelGGL(kern, dim3(ntiles), dim3(256), smem_d, s, M, N, K, A, lda, B, ldb, C, ldc, ntm);      \
     } while (0)
     if (shared_ab == 1) MNK_DBG_LAUNCH(1);
     else if (shared_ab == 2) MNK_DBG_LAUNCH(2);
     else if (shared_ab == 3) MNK_DBG_LAUNCH(3);
     else if (shared_ab == 4) MNK_DBG_LAUNCH(4);
     else if (shared_ab == 5) MNK_DBG_LAUNCH(5);
+    else if (shared_ab == 6) MNK_DBG_LAUNCH(6);  // BK = 16, two workgroups per CU (the earlier configuration)
     else MNK_DBG_LAUNCH(0);
 #undef MNK_DBG_LAUNCH
     MNK_HIP(hipGetLastError());
@@ -396,18 +406,19 @@ int gemm_nt_lower_tiles(int64_t M, int64_t N) {
     return nc * ntm - nc * (nc - 1) / 2;
 }
 
-// Work-queue launch of the lower-tile update (mode 2, 128x128 tiles): `nwg` workgroups pull tiles
-// from *counter (zeroed by the caller before the first launch that shares it).
+// Work-queue launch of the lower-tile update (mode 2, 128x128 tiles): as many workgroups as fit on `cus`
+// CUs pull tiles from counter[0..7] (zeroed by the caller before the first launch that shares them).
 int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
-                         const double* B, int64_t ldb, double* C, int64_t ldc, int* counter, int nwg,
+                         const double* B, int64_t ldb, double* C, int64_t ldc, int* counter, int cus,
                          const int* info_flag) {
+    int nwg = cus * tile_occ(2, 2, 4);
     if (M <= 0 || N <= 0) return 0;
     MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
     constexpr int BM = 128;
     const int ntm = (int)((M + BM - 1) / BM);
     const int ntiles = gemm_nt_lower_tiles(M, N);
     if (nwg > ntiles) nwg = ntiles;
-    const size_t smem = 2 * BK * ((BM + 16) + (BM + 16)) * sizeof(double);
+    const size_t smem = 2 * tile_bk(2, 2, 4) * ((BM + 16) + (BM + 16)) * sizeof(double);
     auto kern = gemm_nt_queue_kernel<2, 2, 4, 2>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -468,12 +468,12 @@ int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const doub
     for (int r = 0; r < reps && !rc; ++r) {
         switch (variant) {
         case 0: rc = launch_gemm_nt(s, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr); break;
-        case 1: rc = launch_gemm_nt_queue(s, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * ctx->num_cu, nullptr); break;
+        case 1: rc = launch_gemm_nt_queue(s, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, ctx->num_cu, nullptr); break;
         case 2: rc = launch_gemm_nt(su, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr); break;
-        case 3: rc = launch_gemm_nt_queue(su, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * ucus, nullptr); break;
+        case 3: rc = launch_gemm_nt_queue(su, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, ucus, nullptr); break;
         case 4:
-            rc = launch_gemm_nt_queue(su, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * ucus, nullptr);
-            if (!rc) rc = launch_gemm_nt_queue(sp, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, 2 * pcus, nullptr);
+            rc = launch_gemm_nt_queue(su, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, ucus, nullptr);
+            if (!rc) rc = launch_gemm_nt_queue(sp, M, M, K, A, lda, A, lda, C, ldc, ctr.p + 8 * r, pcus, nullptr);
             break;
         case 20: break;  // probe only
         case 21: rc = launch_gemm_nt(su, 2, M, M, K, A, lda, A, lda, C, ldc, nullptr, nullptr, 0, nullptr); break;
@@ -483,6 +483,8 @@ int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const doub
         case 12: rc = launch_gemm_nt_dbg(su, 3, M, M, K, A, lda, A, lda, C, ldc); break;  // MFMA + LDS reads only
         case 13: rc = launch_gemm_nt_dbg(su, 5, M, M, K, A, lda, A, lda, C, ldc); break;  // register staging
         case 14: rc = launch_gemm_nt_dbg(s, 5, M, M, K, A, lda, A, lda, C, ldc); break;
+        case 15: rc = launch_gemm_nt_dbg(su, 6, M, M, K, A, lda, A, lda, C, ldc); break;  // BK = 16, 2 workgroups/CU
+        case 16: rc = launch_gemm_nt_dbg(s, 6, M, M, K, A, lda, A, lda, C, ldc); break;
         case 6: case 7: case 8: {  // static tiling on the context stream, one launch per `chunk` tiles
             const int chunk = variant == 6 ? 2 * ctx->num_cu : variant == 7 ? 4 * ctx->num_cu : ctx->num_cu;
             const int nt = gemm_nt_lower_tiles(M, M);

@@ -559,10 +559,10 @@ def test_factorization_schedules_agree(ctx, N, alg, nbo, la):
 @pytest.mark.parametrize("nbo", [256, 512])
 @pytest.mark.parametrize("small", [0, 100000])
 def test_shared_tile_queue_schedule_is_bit_identical(ctx, alg, nbo, small):
-    """With share=2 every trailing update is drained through the tile queue by both look-ahead streams;
-    the factor must be bit-identical to the static schedule (each tile is computed by exactly one
-    workgroup with the same arithmetic, whichever stream pulls it), also with the 64x64-tile variant
-    of the next-panel update switched on/off (that one changes the summation tiling, not the sums)."""
+    """When the trailing update is drained through the tile queue by both look-ahead streams the factor
+    must be bit-identical to the unshared schedule: each tile is computed by exactly one workgroup with
+    the same arithmetic, whichever stream pulls it.  Also with the 64x64-tile variant of the next-panel
+    update switched on/off (that one changes the tiling, not the sums)."""
     rng = np.random.default_rng(5)
     N = 3200
     R = rng.standard_normal((N, 80))
@@ -574,7 +574,7 @@ def test_shared_tile_queue_schedule_is_bit_identical(ctx, alg, nbo, small):
         A = np.asfortranarray((A + A.T) / 2)
     dA = torch.from_numpy(A).cuda()
     facs = []
-    for share in (0, 2, 2):
+    for share in (0, 1, 2, 2):  # off, adaptive, forced (every trailing update goes through the queue)
         M = mj.HipLinearSolver(dA, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, outer_block=nbo,
                                                                    share=share, small_tiles=small))
         M.factorize()

@@ -23,9 +23,10 @@ with torch.cuda.stream(s):
              "static/ctx chunks of 512 tiles", "static/ctx chunks of 1024 tiles", "static/ctx chunks of 256 tiles",
              "static/ctx, all tiles read the same A/B blocks", "static/su, all tiles read the same A/B blocks",
              "static/su, k-loop without barriers (wrong results)", "static/su, k-loop without global loads / LDS stores",
-             "static/su, register staging instead of LDS-DMA", "static/ctx, register staging instead of LDS-DMA"]
+             "static/su, register staging instead of LDS-DMA", "static/ctx, register staging instead of LDS-DMA",
+             "static/su, BK=16 and 2 workgroups per CU", "static/ctx, BK=16 and 2 workgroups per CU"]
     ntiles = (M // 128) * (M // 128 + 1) // 2
-    for v in [0, 2, 0, 2, 13, 14, 2, 13, 0, 14]:
+    for v in [0, 2, 0, 2, 15, 16, 2, 3, 4, 1, 0]:
         for it in range(2):
             ms = C.c_double()
             L.check(L.lib().mnk_debug_update(ctx.handle, v, M, K, A.data_ptr(), M, Cm.data_ptr(), C2.data_ptr(), M, reps,
@@ -34,7 +35,7 @@ with torch.cuda.stream(s):
         print(f"{names[v]:36s} {t*1e3:9.1f} us/update  {ntiles*128*128*K*2/t/1e9:7.2f} TFLOP/s (lower tiles)")
 
     # LDS-DMA staging (default) against register staging: one update from C = 0
-    for v, Cx in ((2, Cm), (13, C2)):
+    for v, Cx in ((2, Cm), (15, C2)):
         Cx.zero_()
         s.synchronize()
         ms = C.c_double()
