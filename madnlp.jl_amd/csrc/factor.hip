@@ -631,7 +631,10 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     } else {
         // look-ahead: panel stream sp (high priority) factors panel k+1 while the update
         // stream su applies panel k to the rest of the trailing matrix.
-        const bool big = ls->N >= 24000 && ctx->sp_big != nullptr;
+        // the trailing update outweighs the panel chain above N ~ 24000 on 256 CUs; the crossover moves with sqrt(#CUs)
+        const bool want_big = (double)ls->N * ls->N >= 24000.0 * 24000.0 * ctx->num_cu / 256.0;
+        if (want_big) (void)mnk_ctx_ensure_big_pair(ctx);
+        const bool big = want_big && ctx->sp_big != nullptr;
         hipStream_t sp = big ? ctx->sp_big : ctx->sp, su = big ? ctx->su_big : ctx->su;
         if ((int64_t)ctx->ev_panel.size() < npanel + 1) {
             const size_t old = ctx->ev_panel.size();

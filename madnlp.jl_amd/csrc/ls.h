@@ -57,6 +57,7 @@ struct mnk_ls {
     int64_t npos = 0, nzero = 0, nneg = 0;
 };
 
+extern "C" int mnk_ctx_ensure_big_pair(mnk_ctx* c);
 int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);

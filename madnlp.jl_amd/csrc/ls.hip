@@ -70,48 +70,84 @@ extern "C" {
 int mnk_version(void) { return MNK_VERSION; }
 const char* mnk_last_error_string(void) { return g_err.c_str(); }
 
-int mnk_ctx_create(int device, void* stream, mnk_ctx** out) {
+// A stream restricted to the listed CU-mask bits (bit b is CU b/8 of XCD b%8 on this part).
+static bool make_masked_stream(int num_cu_total, const int* bits, int count, hipStream_t& out) {
+    const int words = (num_cu_total + 31) / 32;
+    std::vector<uint32_t> m(words, 0u);
+    for (int i = 0; i < count; ++i)
+        if (bits[i] >= 0 && bits[i] < num_cu_total) m[bits[i] / 32] |= 1u << (bits[i] % 32);
+    if (hipExtStreamCreateWithCUMask(&out, (uint32_t)words, m.data()) == hipSuccess) return true;
+    (void)hipGetLastError();
+    out = nullptr;
+    return false;
+}
+
+// `part_first/part_count` confine the context to a contiguous range of CU-mask bits.  Kept for experiments
+// only (no public entry point): partitions run MFMA-bound kernels side by side at full rate, but the
+// latency-bound panel chain of one instance slows ~2x next to the updates of the others -- every partition
+// has CUs on every XCD and shares all L2s, and masks that differ between XCDs are not honoured
+// (tools/cumask_probe.hip, tools/partition_probe.py) -- so 16 instances per GPU run faster time-sharing the
+// whole chip (bench.py --batch) than on 2/4/8 partitions (72 vs 58/45/26 it/s).
+static int ctx_create_common(int device, void* stream, int part_first, int part_count, mnk_ctx** out) {
     MNK_REQUIRE(out != nullptr, "mnk_ctx_create: out is NULL");
     int ndev = 0;
     MNK_HIP(hipGetDeviceCount(&ndev));
     MNK_REQUIRE(device >= 0 && device < ndev, "mnk_ctx_create: no such device");
     MNK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MNK_HIP(hipGetDeviceProperties(&prop, device));
+    const int total = prop.multiProcessorCount;
+    const bool part = part_count > 0;
+    if (part)
+        MNK_REQUIRE(part_first >= 0 && part_count >= 16 && part_first + part_count <= total && stream == nullptr,
+                    "mnk_ctx_create_partition: need 16 <= cu_count, the range inside the device, and a library-owned stream");
     mnk_ctx* c = new mnk_ctx();
     c->device = device;
+    c->cu_first = part ? part_first : 0;
+    c->partitioned = part;
+    c->total_cu = total;
+    c->num_cu = part ? part_count : total;
+    // The CU-mask bits this context owns: a contiguous range (bits are dealt round-robin over the XCDs, so every
+    // XCD contributes the same number of CUs).  Masks that differ between XCDs are not honoured by the runtime
+    // (tools/cumask_probe.hip: a strided mask runs on all 256 CUs), so partitions cannot be whole XCDs.
+    std::vector<int> bits;
+    for (int b = 0; b < c->num_cu; ++b) bits.push_back(c->cu_first + b);
     if (stream) {
         c->stream = (hipStream_t)stream;
+    } else if (part) {
+        if (!make_masked_stream(total, bits.data(), part_count, c->stream)) {
+            delete c;
+            set_error("mnk_ctx_create_partition: CU-masked streams are not available on this device");
+            return -2;
+        }
+        c->own_stream = true;
     } else {
         MNK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    hipDeviceProp_t prop;
-    MNK_HIP(hipGetDeviceProperties(&prop, device));
-    c->num_cu = prop.multiProcessorCount;
     // Look-ahead streams.  The panel stream runs small latency-bound kernels; sharing SIMDs
     // with the MFMA-saturating trailing update slows them 4-5x (measured), so the two streams
-    // get disjoint CU sets: the panel stream the first `panel_cus` mask bits (bits are dealt
-    // round-robin over the 8 XCDs), the update stream all the others.  Fallback: stream priorities.
+    // get disjoint CU sets: the panel stream the first `panel_cus` mask bits of the context's
+    // range, the update stream all the others.  Fallback: stream priorities.
     auto make_pair = [&](int want, hipStream_t& sp, hipStream_t& su) -> bool {
         if (want <= 0 || want >= c->num_cu) return false;
-        const int words = (c->num_cu + 31) / 32;
-        std::vector<uint32_t> mp(words, 0u), mu(words, 0u);
-        for (int b = 0; b < c->num_cu; ++b) (b < want ? mp : mu)[b / 32] |= 1u << (b % 32);
-        hipError_t e1 = hipExtStreamCreateWithCUMask(&sp, (uint32_t)words, mp.data());
-        hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&su, (uint32_t)words, mu.data()) : e1;
-        if (e1 == hipSuccess && e2 == hipSuccess) return true;
-        (void)hipGetLastError();
+        if (make_masked_stream(total, bits.data(), want, sp) &&
+            make_masked_stream(total, bits.data() + want, c->num_cu - want, su))
+            return true;
         if (sp) { (void)hipStreamDestroy(sp); sp = nullptr; }
         su = nullptr;
         return false;
     };
-    // default partitions (measured, profiles/): 64 panel CUs while the panel chain is the bottleneck
-    // (N ~ 1e4), 32 once the trailing update dominates (N >~ 3e4); MNK_PANEL_CUS forces one value.
+    // default partitions (measured, profiles/): a quarter of the CUs for the panel stream while the panel
+    // chain is the bottleneck (N ~ 1e4), an eighth once the trailing update dominates (N >~ 3e4);
+    // MNK_PANEL_CUS forces one value.
     if (const char* e = getenv("MNK_PANEL_CUS")) {
         const int want = atoi(e);
         if (make_pair(want, c->sp, c->su)) c->panel_cus = want;
-    } else if (c->num_cu >= 128) {
-        if (make_pair(64, c->sp, c->su)) c->panel_cus = 64;
-        if (make_pair(32, c->sp_big, c->su_big)) c->panel_cus_big = 32;
+    } else if (c->num_cu >= 16) {
+        const int q4 = std::max(4, c->num_cu / 4), q8 = std::max(4, c->num_cu / 8);
+        if (make_pair(q4, c->sp, c->su)) c->panel_cus = q4;
+        c->panel_cus_big_want = q8;  // second pair is created on first use (every masked stream is a hardware queue)
     }
     if (!c->sp) {
         int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
@@ -124,6 +160,25 @@ int mnk_ctx_create(int device, void* stream, mnk_ctx** out) {
     *out = c;
     return 0;
 }
+
+// second look-ahead pair (fewer panel CUs, for systems whose trailing update dominates), created on first use
+int mnk_ctx_ensure_big_pair(mnk_ctx* c) {
+    if (c->sp_big != nullptr || c->panel_cus_big_want <= 0 || c->panel_cus <= 0) return 0;
+    const int want = c->panel_cus_big_want;
+    c->panel_cus_big_want = 0;
+    std::vector<int> bits;
+    for (int b = 0; b < c->num_cu; ++b) bits.push_back(c->cu_first + b);
+    if (make_masked_stream(c->total_cu, bits.data(), want, c->sp_big) &&
+        make_masked_stream(c->total_cu, bits.data() + want, c->num_cu - want, c->su_big)) {
+        c->panel_cus_big = want;
+    } else {
+        if (c->sp_big) { (void)hipStreamDestroy(c->sp_big); c->sp_big = nullptr; }
+        c->su_big = nullptr;
+    }
+    return 0;
+}
+
+int mnk_ctx_create(int device, void* stream, mnk_ctx** out) { return ctx_create_common(device, stream, 0, 0, out); }
 
 int mnk_ctx_destroy(mnk_ctx* c) {
     if (!c) return 0;
