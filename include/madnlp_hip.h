@@ -188,6 +188,22 @@ int mnk_gemm_nt(mnk_ctx* ctx, int mode, int64_t M, int64_t N, int64_t K,
                 const double* A, int64_t lda, const double* B, int64_t ldb,
                 double* C, int64_t ldc);
 
+/* ---- device-side solve_kkt! / mul! of the sparse condensed system -----------------------------
+ * The primal-dual vector w = [x (n); s (m); z (m); zl (nlb); zu (nub)] (UnreducedKKTVector layout, reference
+ * src/KKT/rhs.jl:119-129) stays on the device across reduce_rhs! / condensation / solve / expansion /
+ * finish_aug_solve!, so one call replaces the host-side vector algebra and the per-solve round trips.
+ *   mnk_sc_set_bounds         ind_lb / ind_ub: positions of the bounded entries in the primal block [0, n+m)
+ *   mnk_sc_set_barrier_terms  reg (n+m), l_diag, u_diag, l_lower, u_lower of the current iterate
+ *                             (pr_diag / du_diag come with mnk_sc_build)
+ *   mnk_sc_solve_kkt          solve_kkt!(::SparseCondensedKKTSystem, w)  reference src/IPM/factorization.jl:143-167
+ *   mnk_sc_mul                mul!(w, kkt, x, alpha, beta)               reference :289-308 + _kktmul! kernels.jl:161-180 */
+int mnk_sc_set_bounds(mnk_sc* sc, int64_t nlb, const int64_t* ind_lb, int64_t nub, const int64_t* ind_ub,
+                      int index_base);
+int mnk_sc_set_barrier_terms(mnk_sc* sc, const double* reg, const double* l_diag, const double* u_diag,
+                             const double* l_lower, const double* u_lower, int loc);
+int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc);
+int mnk_sc_mul(mnk_sc* sc, double* w, const double* x, double alpha, double beta, int loc);
+
 /* Diagnostics: with option "solve_trace" = 1 the persistent solve kernel stamps the forward sweep's critical
  * path (8 x 100 MHz timer values per 64-row block); this copies them out (n = number of uint64 to copy). */
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);

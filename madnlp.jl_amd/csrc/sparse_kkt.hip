@@ -65,6 +65,69 @@ __global__ void gather_spmv_kernel(double* __restrict__ y, const double* __restr
     y[i] = beta == 0.0 ? alpha * acc : alpha * acc + beta * y[i];
 }
 
+// ---- device-side solve_kkt! / mul! pieces (reference src/IPM/kernels.jl:161-204, factorization.jl:143-167,289-308)
+// reduce_rhs!: xp_lr -= wl ./ l_diag (one launch per bound side: a variable may carry both bounds)
+__global__ void reduce_rhs_kernel(double* __restrict__ w, const int64_t* __restrict__ ind, const double* __restrict__ wb,
+                                  const double* __restrict__ diag, int64_t nb) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < nb) w[ind[i]] -= wb[i] / diag[i];
+}
+// buffer = diag_buffer .* (wz .+ ws ./ Sigma_s)
+__global__ void condense_rhs_kernel(double* __restrict__ buffer, const double* __restrict__ D, const double* __restrict__ ws,
+                                    const double* __restrict__ wz, const double* __restrict__ Ss, int64_t m) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c < m) buffer[c] = D[c] * (wz[c] + ws[c] / Ss[c]);
+}
+// wz = -buffer + diag_buffer .* buffer2 ; ws = (ws + wz) ./ Sigma_s
+__global__ void expand_sol_kernel(double* __restrict__ ws, double* __restrict__ wz, const double* __restrict__ buffer,
+                                  const double* __restrict__ buffer2, const double* __restrict__ D,
+                                  const double* __restrict__ Ss, int64_t m) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c < m) {
+        const double z = -buffer[c] + D[c] * buffer2[c];
+        wz[c] = z;
+        ws[c] = (ws[c] + z) / Ss[c];
+    }
+}
+// finish_aug_solve!: dlb = (-dlb + l_lower .* xp_lr) ./ l_diag ; dub = (dub - u_lower .* xp_ur) ./ u_diag
+__global__ void finish_aug_kernel(double* __restrict__ db, const double* __restrict__ w, const int64_t* __restrict__ ind,
+                                  const double* __restrict__ lower, const double* __restrict__ diag, int64_t nb, int upper) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < nb) db[i] = upper ? (db[i] - lower[i] * w[ind[i]]) / diag[i] : (-db[i] + lower[i] * w[ind[i]]) / diag[i];
+}
+// mul!, slack/dual coupling: wz -= alpha xs ; ws = beta ws - alpha xz ; then _kktmul!'s diagonal part
+//   primal(w) += alpha reg .* primal(x) ; dual(w) += alpha du_diag .* dual(x)
+__global__ void kktmul_diag_kernel(double* __restrict__ w, const double* __restrict__ x, const double* __restrict__ reg,
+                                   const double* __restrict__ du, double alpha, double beta, int64_t n, int64_t m) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        w[i] += alpha * reg[i] * x[i];
+    } else if (i < n + m) {  // slack block
+        const int64_t c = i - n;
+        w[i] = (beta * w[i] - alpha * x[n + m + c]) + alpha * reg[i] * x[i];
+    } else if (i < n + 2 * m) {  // dual block (already holds alpha Jt' xx + beta wz)
+        const int64_t c = i - n - m;
+        w[i] = (w[i] - alpha * x[n + c]) + alpha * du[c] * x[i];
+    }
+}
+// _kktmul!, bound part.  side 0: xp_lr -= alpha dlb(x) ; dlb(w) = beta dlb(w) + alpha (x_lr l_lower - dlb(x) l_diag)
+//                        side 1: xp_ur += alpha dub(x) ; dub(w) = beta dub(w) + alpha (x_ur u_lower + dub(x) u_diag)
+__global__ void kktmul_bound_kernel(double* __restrict__ w, double* __restrict__ wb, const double* __restrict__ x,
+                                    const double* __restrict__ xb, const int64_t* __restrict__ ind,
+                                    const double* __restrict__ lower, const double* __restrict__ diag, double alpha,
+                                    double beta, int64_t nb, int upper) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int64_t p = ind[i];
+    if (upper) {
+        w[p] += alpha * xb[i];
+        wb[i] = beta * wb[i] + alpha * (x[p] * lower[i] + xb[i] * diag[i]);
+    } else {
+        w[p] -= alpha * xb[i];
+        wb[i] = beta * wb[i] + alpha * (x[p] * lower[i] - xb[i] * diag[i]);
+    }
+}
+
 // ---- host symbolic ---------------------------------------------------------------------
 struct CscPattern {
     std::vector<int32_t> colptr, rowval;
@@ -126,6 +189,12 @@ using namespace mnk;
 struct mnk_sc_spmv_data {
     DevBuf<int32_t> jtr_ptr, jtr_idx, jtr_perm;   // CSR of Jt (rows = variables)
     DevBuf<int32_t> hs_ptr, hs_idx, hs_perm;      // rows of Symmetric(hess_com, :L)
+    // device-side solve_kkt! / mul!: bound structure, barrier terms, work vectors
+    int64_t nlb = 0, nub = 0;
+    DevBuf<int64_t> ind_lb, ind_ub;               // positions in the primal block [0, n+m)
+    DevBuf<double> reg, l_diag, u_diag, l_lower, u_lower;
+    DevBuf<double> buffer, buffer2, wdev, xdev;   // m, m, len(w), len(w)
+    bool have_bounds = false, have_terms = false;
 };
 static std::vector<std::pair<mnk_sc*, mnk_sc_spmv_data*>> g_spmv;  // tiny registry
 static mnk_sc_spmv_data* spmv_of(mnk_sc* sc) {
@@ -385,6 +454,10 @@ int mnk_sc_build(mnk_sc* sc, const double* pr_diag, const double* du_diag, int l
     int rc = stage_in(sc->ctx, sc->pr_diag.p, pr_diag, sc->n + sc->m, loc, &pr);
     rc |= stage_in(sc->ctx, sc->du_diag.p, du_diag, sc->m, loc, &du);
     if (rc) return rc;
+    if (loc == MNK_DEVICE) {  // keep our own copies: the device-side solve_kkt!/mul! read Sigma_s and du_diag later
+        MNK_HIP(hipMemcpyAsync(sc->pr_diag.p, pr, (sc->n + sc->m) * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (sc->m > 0) MNK_HIP(hipMemcpyAsync(sc->du_diag.p, du, sc->m * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     if (sc->m > 0)
         hipLaunchKernelGGL(diag_buffer_kernel, dim3((unsigned)((sc->m + 255) / 256)), dim3(256), 0, s,
                            sc->diag_buffer.p, pr + sc->n, du, sc->m);
@@ -435,5 +508,150 @@ int mnk_sc_spmv(mnk_sc* sc, int which, int trans, double alpha, const double* x,
     MNK_HIP(hipGetLastError());
     return 0;
 }
+
+// ---- device-side solve_kkt! / mul! ------------------------------------------------------------------
+int mnk_sc_set_bounds(mnk_sc* sc, int64_t nlb, const int64_t* ind_lb, int64_t nub, const int64_t* ind_ub, int index_base) {
+    MNK_REQUIRE(sc && sc->ctx && nlb >= 0 && nub >= 0 && (nlb == 0 || ind_lb) && (nub == 0 || ind_ub),
+                "mnk_sc_set_bounds: bad argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    MNK_REQUIRE(sp != nullptr, "mnk_sc_set_bounds: unknown handle");
+    const int64_t np = sc->n + sc->m;
+    std::vector<int64_t> lb(nlb), ub(nub);
+    for (int64_t i = 0; i < nlb; ++i) {
+        lb[i] = ind_lb[i] - index_base;
+        MNK_REQUIRE(lb[i] >= 0 && lb[i] < np, "mnk_sc_set_bounds: lower-bound index out of range");
+    }
+    for (int64_t i = 0; i < nub; ++i) {
+        ub[i] = ind_ub[i] - index_base;
+        MNK_REQUIRE(ub[i] >= 0 && ub[i] < np, "mnk_sc_set_bounds: upper-bound index out of range");
+    }
+    hipStream_t s = sc->ctx->stream;
+    int rc = sp->ind_lb.upload(lb, s);
+    rc |= sp->ind_ub.upload(ub, s);
+    rc |= sp->reg.alloc(np);
+    rc |= sp->l_diag.alloc(nlb);
+    rc |= sp->l_lower.alloc(nlb);
+    rc |= sp->u_diag.alloc(nub);
+    rc |= sp->u_lower.alloc(nub);
+    rc |= sp->buffer.alloc(sc->m);
+    rc |= sp->buffer2.alloc(sc->m);
+    const size_t lw = (size_t)(sc->n + 2 * sc->m + nlb + nub);
+    rc |= sp->wdev.alloc(lw);
+    rc |= sp->xdev.alloc(lw);
+    if (rc) return rc;
+    sp->nlb = nlb;
+    sp->nub = nub;
+    sp->have_bounds = true;
+    return 0;
+}
+
+static int copy_in(mnk_ctx* ctx, double* dst, const double* src, int64_t n, int loc) {
+    if (n <= 0) return 0;
+    MNK_REQUIRE(src != nullptr, "NULL vector");
+    MNK_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                           ctx->stream));
+    return 0;
+}
+
+int mnk_sc_set_barrier_terms(mnk_sc* sc, const double* reg, const double* l_diag, const double* u_diag,
+                             const double* l_lower, const double* u_lower, int loc) {
+    MNK_REQUIRE(sc && sc->ctx, "mnk_sc_set_barrier_terms: NULL argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    MNK_REQUIRE(sp != nullptr && sp->have_bounds, "mnk_sc_set_barrier_terms: call mnk_sc_set_bounds first");
+    int rc = copy_in(sc->ctx, sp->reg.p, reg, sc->n + sc->m, loc);
+    rc |= copy_in(sc->ctx, sp->l_diag.p, l_diag, sp->nlb, loc);
+    rc |= copy_in(sc->ctx, sp->u_diag.p, u_diag, sp->nub, loc);
+    rc |= copy_in(sc->ctx, sp->l_lower.p, l_lower, sp->nlb, loc);
+    rc |= copy_in(sc->ctx, sp->u_lower.p, u_lower, sp->nub, loc);
+    if (rc) return rc;
+    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(sc->ctx->stream));  // the host arrays may change after return
+    sp->have_terms = true;
+    return 0;
+}
+
+#define MNK_GRID(cnt) dim3((unsigned)(((cnt) + 255) / 256)), dim3(256), 0, s
+
+int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc) {
+    MNK_REQUIRE(sc && sc->ctx && ls && w, "mnk_sc_solve_kkt: NULL argument or host-only handle");
+    MNK_REQUIRE(ls->ctx == sc->ctx && ls->N == sc->n, "mnk_sc_solve_kkt: the solver does not belong to this system");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    MNK_REQUIRE(sp != nullptr && sp->have_bounds && sp->have_terms,
+                "mnk_sc_solve_kkt: call mnk_sc_set_bounds / mnk_sc_set_barrier_terms / mnk_sc_build first");
+    hipStream_t s = sc->ctx->stream;
+    const int64_t n = sc->n, m = sc->m, nlb = sp->nlb, nub = sp->nub, lw = n + 2 * m + nlb + nub;
+    double* d = w;
+    if (loc != MNK_DEVICE) {
+        d = sp->wdev.p;
+        MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    double *ws = d + n, *wz = d + n + m, *wl = d + n + 2 * m, *wu = wl + nlb;
+    const double* Ss = sc->pr_diag.p + n;
+    if (nlb > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nlb), d, sp->ind_lb.p, wl, sp->l_diag.p, nlb);
+    if (nub > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nub), d, sp->ind_ub.p, wu, sp->u_diag.p, nub);
+    if (m > 0) {
+        hipLaunchKernelGGL(condense_rhs_kernel, MNK_GRID(m), sp->buffer.p, sc->diag_buffer.p, ws, wz, Ss, m);
+        int rc = mnk_sc_spmv(sc, MNK_SC_JT, 0, 1.0, sp->buffer.p, 1.0, d);  // wx += Jt * buffer
+        if (rc) return rc;
+    }
+    int rc = mnk_ls_solve(ls, d, 1, n, MNK_DEVICE);
+    if (rc) return rc;
+    if (m > 0) {
+        rc = mnk_sc_spmv(sc, MNK_SC_JT, 1, 1.0, d, 0.0, sp->buffer2.p);  // buffer2 = Jt' * wx
+        if (rc) return rc;
+        hipLaunchKernelGGL(expand_sol_kernel, MNK_GRID(m), ws, wz, sp->buffer.p, sp->buffer2.p, sc->diag_buffer.p, Ss, m);
+    }
+    if (nlb > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nlb), wl, d, sp->ind_lb.p, sp->l_lower.p, sp->l_diag.p, nlb, 0);
+    if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, sp->ind_ub.p, sp->u_lower.p, sp->u_diag.p, nub, 1);
+    MNK_HIP(hipGetLastError());
+    if (loc != MNK_DEVICE) {
+        MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
+        MNK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int mnk_sc_mul(mnk_sc* sc, double* w, const double* x, double alpha, double beta, int loc) {
+    MNK_REQUIRE(sc && sc->ctx && w && x, "mnk_sc_mul: NULL argument or host-only handle");
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    MNK_REQUIRE(sp != nullptr && sp->have_bounds && sp->have_terms,
+                "mnk_sc_mul: call mnk_sc_set_bounds / mnk_sc_set_barrier_terms first");
+    hipStream_t s = sc->ctx->stream;
+    const int64_t n = sc->n, m = sc->m, nlb = sp->nlb, nub = sp->nub, lw = n + 2 * m + nlb + nub;
+    double* dw = w;
+    const double* dx = x;
+    if (loc != MNK_DEVICE) {
+        dw = sp->wdev.p;
+        MNK_HIP(hipMemcpyAsync(sp->wdev.p, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        MNK_HIP(hipMemcpyAsync(sp->xdev.p, x, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        dx = sp->xdev.p;
+    }
+    // wx = alpha Sym(H) xx + beta wx ; wx += alpha Jt xz ; wz = alpha Jt' xx + beta wz
+    int rc = mnk_sc_spmv(sc, MNK_SC_HESS, 0, alpha, dx, beta, dw);
+    if (rc) return rc;
+    if (m > 0) {
+        rc = mnk_sc_spmv(sc, MNK_SC_JT, 0, alpha, dx + n + m, 1.0, dw);
+        if (rc) return rc;
+        rc = mnk_sc_spmv(sc, MNK_SC_JT, 1, alpha, dx, beta, dw + n + m);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kktmul_diag_kernel, MNK_GRID(n + 2 * m), dw, dx, sp->reg.p, sc->du_diag.p, alpha, beta, n, m);
+    if (nlb > 0)
+        hipLaunchKernelGGL(kktmul_bound_kernel, MNK_GRID(nlb), dw, dw + n + 2 * m, dx, dx + n + 2 * m, sp->ind_lb.p,
+                           sp->l_lower.p, sp->l_diag.p, alpha, beta, nlb, 0);
+    if (nub > 0)
+        hipLaunchKernelGGL(kktmul_bound_kernel, MNK_GRID(nub), dw, dw + n + 2 * m + nlb, dx, dx + n + 2 * m + nlb,
+                           sp->ind_ub.p, sp->u_lower.p, sp->u_diag.p, alpha, beta, nub, 1);
+    MNK_HIP(hipGetLastError());
+    if (loc != MNK_DEVICE) {
+        MNK_HIP(hipMemcpyAsync(w, dw, lw * sizeof(double), hipMemcpyDeviceToHost, s));
+        MNK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+#undef MNK_GRID
 
 }  // extern "C"

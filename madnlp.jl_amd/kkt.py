@@ -132,9 +132,13 @@ class SparseCondensedKKTSystem(_KKTCommon):
 
     def __init__(self, n, m, jac_I, jac_J, hess_I, hess_J, ind_ineq, ind_lb, ind_ub,
                  ctx: HipContext | None = None, linear_solver=HipLinearSolver,
-                 opt_linear_solver: HipSolverOptions | None = None):
+                 opt_linear_solver: HipSolverOptions | None = None, device_kkt_ops: bool = False):
+        """`device_kkt_ops`: run `solve_kkt!` and `mul!` entirely on the device (`mnk_sc_solve_kkt`,
+        `mnk_sc_mul`): the primal-dual vector makes one round trip per call instead of the host doing the
+        vector algebra around a device solve."""
         if len(ind_ineq) != m:
             raise ValueError("SparseCondensedKKTSystem does not support equality constrained NLPs.")
+        self.device_kkt_ops = bool(device_kkt_ops)
         self.ctx = ctx or HipContext()
         self.n, self.m = int(n), int(m)
         jI = np.ascontiguousarray(jac_I, dtype=np.int32)
@@ -175,6 +179,8 @@ class SparseCondensedKKTSystem(_KKTCommon):
         self._host_h = None
         self._diag_buffer = None
         self.linear_solver = linear_solver(self.aug_com, ctx=self.ctx, opt=opt_linear_solver)
+        L.check(lib.mnk_sc_set_bounds(self._h, nlb, self.ind_lb.ctypes.data, nub, self.ind_ub.ctypes.data, 0),
+                "mnk_sc_set_bounds")
         _LIVE_OBJECTS.add(self)
 
     # -- helpers -----------------------------------------------------------------------
@@ -259,6 +265,33 @@ class SparseCondensedKKTSystem(_KKTCommon):
         assert loc == loc2
         L.check(L.lib().mnk_sc_build(self._h, pp, dp, loc), "mnk_sc_build")
         self._diag_buffer = None
+        if self.device_kkt_ops:
+            self.upload_barrier_terms()
+
+    def upload_barrier_terms(self):
+        """reg, l_diag, u_diag, l_lower, u_lower of the current iterate -> device (for the device-side
+        `solve_kkt!` / `mul!`)."""
+        L.check(L.lib().mnk_sc_set_barrier_terms(self._h, self.reg.ctypes.data, self.l_diag.ctypes.data,
+                                                 self.u_diag.ctypes.data, self.l_lower.ctypes.data,
+                                                 self.u_lower.ctypes.data, L.MNK_HOST), "mnk_sc_set_barrier_terms")
+
+    def solve_kkt_device(self, w):
+        """`solve_kkt!` on the device (reference `src/IPM/factorization.jl:143-167`); `w` is an
+        UnreducedKKTVector (host values) or a device tensor holding its values."""
+        p, loc = _ptr(w.values if isinstance(w, UnreducedKKTVector) else w)
+        rc = L.lib().mnk_sc_solve_kkt(self._h, self.linear_solver._h, p, loc)
+        if rc:
+            from .linear_solver import SolveException
+            raise SolveException(L.lib().mnk_last_error_string().decode())
+        return w
+
+    def mul_device(self, w, x, alpha=1.0, beta=0.0):
+        """`mul!(w, kkt, x, alpha, beta)` on the device (reference `src/IPM/factorization.jl:289-308`)."""
+        pw, loc = _ptr(w.values if isinstance(w, UnreducedKKTVector) else w)
+        px, loc2 = _ptr(x.values if isinstance(x, UnreducedKKTVector) else x)
+        assert loc == loc2
+        L.check(L.lib().mnk_sc_mul(self._h, pw, px, float(alpha), float(beta), loc), "mnk_sc_mul")
+        return w
 
     def is_inertia_correct(self, num_pos, num_zero, num_neg):
         """reference `src/KKT/Sparse/condensed.jl:138-140`."""
@@ -275,6 +308,8 @@ class SparseCondensedKKTSystem(_KKTCommon):
 
     def solve_kkt(self, w):
         """reference `src/IPM/factorization.jl:143-167`; the condensed solve runs on the device."""
+        if self.device_kkt_ops:
+            return self.solve_kkt_device(w)
         n, m = self.n, self.m
         full = w.values
         wx, ws, wz = full[:n], full[n:n + m], full[n + m:n + 2 * m]
@@ -292,6 +327,8 @@ class SparseCondensedKKTSystem(_KKTCommon):
 
     def mul(self, w, x, alpha=1.0, beta=0.0):
         """reference `src/IPM/factorization.jl:278-299`."""
+        if self.device_kkt_ops:
+            return self.mul_device(w, x, alpha, beta)
         n, m = self.n, self.m
         xf, wf = x.values, w.values
         xx, xs, xz = xf[:n], xf[n:n + m], xf[n + m:n + 2 * m]

@@ -449,7 +449,7 @@ def test_spmv_pieces(ctx):
 
 
 # --------------------------------------------------------------------------- end-to-end IPM parity
-def _ipm_pair(kind, nlp, ctx, tol):
+def _ipm_pair(kind, nlp, ctx, tol, device_kkt_ops=False):
     """Run the same IPM driver twice from identical inputs: CPU oracle back-end (LAPACK
     Bunch-Kaufman) and HIP back-end (static-pivot LDL^T)."""
     from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver
@@ -461,7 +461,7 @@ def _ipm_pair(kind, nlp, ctx, tol):
         if kind == "sparse_condensed":
             return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J,
                                                info["ind_ineq"], info["ind_lb"], info["ind_ub"], ctx=ctx,
-                                               opt_linear_solver=opt)
+                                               opt_linear_solver=opt, device_kkt_ops=device_kkt_ops)
         if kind == "dense_condensed":
             return mj.DenseCondensedKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_eq"], info["ind_lb"],
                                               info["ind_ub"], ctx=ctx, opt_linear_solver=opt)
@@ -704,3 +704,70 @@ def test_persistent_solves_from_concurrent_contexts(ctx):
         th.join(timeout=120)
     assert not errors, errors
     assert len(results) == 4 and all(v <= 1e-9 * N for v in results.values()), results
+
+
+# --------------------------------------------------------------------------- device-side solve_kkt! / mul!
+@pytest.mark.parametrize("case,du", [("case30", 0.0), ("case118", 1e-8), ("case1354pegase", 1e-8)])
+def test_device_solve_kkt_and_mul_match_oracle(ctx, case, du):
+    """`mnk_sc_solve_kkt` / `mnk_sc_mul` (the whole primal-dual vector stays on the device) against the CPU
+    restatement of `solve_kkt!` / `mul!` (reference src/IPM/factorization.jl:143-167,289-308) on the same
+    IPM-like diagonals and random vectors.  mul!: elementwise relative 1e-12 (same sums, different order);
+    solve_kkt!: the two solutions agree through the KKT residual and to 1e-8 relative (cond-dependent)."""
+    P = opf_shaped(case, du=du)
+    ko, kh = _oracle_sc(P), _hip_sc(P, ctx)
+    for k in (ko, kh):
+        k.compress_jacobian(); k.compress_hessian()
+        okern.set_aug_diagonal(k) if k is ko else k.set_aug_diagonal()
+        k.build_kkt()
+        k.linear_solver.factorize()
+    kh.upload_barrier_terms()
+    rng = np.random.default_rng(21)
+    # mul!(w, kkt, x, alpha, beta) with non-trivial alpha/beta
+    xo, wo = okern.UnreducedKKTVector.from_kkt(ko), okern.UnreducedKKTVector.from_kkt(ko)
+    xh, wh = mj.UnreducedKKTVector.from_kkt(kh), mj.UnreducedKKTVector.from_kkt(kh)
+    xv, wv = rng.standard_normal(len(xo.values)), rng.standard_normal(len(xo.values))
+    for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.75, -0.5)):
+        xo.values[:] = xv; wo.values[:] = wv; xh.values[:] = xv; wh.values[:] = wv
+        ko.mul(wo, xo, alpha, beta)
+        kh.mul_device(wh, xh, alpha, beta)
+        scale = np.abs(wo.values).max()
+        assert np.abs(wh.values - wo.values).max() <= 1e-12 * scale, (alpha, beta)
+    # the host mirror and the device path of the HIP system agree too
+    wh2 = mj.UnreducedKKTVector.from_kkt(kh); wh2.values[:] = wv
+    xh.values[:] = xv
+    kh.mul(wh2, xh, 0.75, -0.5)
+    assert np.abs(wh2.values - wh.values).max() <= 1e-12 * np.abs(wh.values).max()
+    # solve_kkt!
+    bo, bh = okern.UnreducedKKTVector.from_kkt(ko), mj.UnreducedKKTVector.from_kkt(kh)
+    bv = rng.standard_normal(len(bo.values))
+    bo.values[:] = bv; bh.values[:] = bv
+    ko.solve_kkt(bo)
+    kh.solve_kkt_device(bh)
+    assert np.abs(bh.values - bo.values).max() <= 1e-8 * np.abs(bo.values).max()
+    # residual of the device solution through the oracle's mul!: K x = b
+    r = okern.UnreducedKKTVector.from_kkt(ko); r.values[:] = 0.0
+    xs = okern.UnreducedKKTVector.from_kkt(ko); xs.values[:] = bh.values
+    ko.mul(r, xs, 1.0, 0.0)
+    ro = okern.UnreducedKKTVector.from_kkt(ko); ro.values[:] = 0.0
+    ko.mul(ro, bo, 1.0, 0.0)
+    res_h = np.abs(r.values - bv).max() / (np.abs(bv).max() + np.abs(bh.values).max())
+    res_o = np.abs(ro.values - bv).max() / (np.abs(bv).max() + np.abs(bo.values).max())
+    assert res_h <= max(1e-10, 100 * res_o), (res_h, res_o)
+    # a device-resident vector is solved in place without touching the host
+    bd = torch.from_numpy(bv.copy()).cuda()
+    kh.solve_kkt_device(bd)
+    ctx.synchronize()
+    assert np.abs(bd.cpu().numpy() - bh.values).max() == 0.0
+    kh.close()
+
+
+@pytest.mark.parametrize("case", ["case30", "case118"])
+def test_ipm_sparse_qp_with_device_kkt_ops(ctx, case):
+    """The IPM driver with `solve_kkt!`/`mul!` on the device follows the CPU oracle run iteration by iteration
+    (same acceptance as test_ipm_sparse_qp_cpu_vs_hip)."""
+    from madnlp_jl_amd.problems import SparseQPModel
+    nlp = SparseQPModel(case)
+    so, sh = _ipm_pair("sparse_condensed", nlp, ctx, 1e-6, device_kkt_ops=True)
+    assert sh.kkt.device_kkt_ops
+    _assert_ipm_parity(so, sh, nlp.n)
+    sh.kkt.close()
