@@ -145,6 +145,13 @@ MadNLP.is_supported(::Type{<:HipLinearSolver}, ::Type{Float32}) = false
 #                              ccall(:mnk_sc_build, ..., kkt.sc, kkt.pr_diag, kkt.du_diag, MNK_HOST)
 #   kkt.aug_com             -> HipAugCSC(sc, ctx, pattern)   (what `linear_solver(aug_com; opt)` receives)
 #
+#   solve_kkt!(kkt, w)      -> optional device version (keeps [x; s; z; zl; zu] on the device, one round trip):
+#                              constructor: ccall(:mnk_sc_set_bounds, ..., kkt.sc, nlb, ind_lb, nub, ind_ub, 1)
+#                              build_kkt!:  ccall(:mnk_sc_set_barrier_terms, ..., kkt.sc, kkt.reg, kkt.l_diag, kkt.u_diag,
+#                                                 kkt.l_lower, kkt.u_lower, MNK_HOST)
+#                              solve_kkt!:  ccall(:mnk_sc_solve_kkt, ..., kkt.sc, kkt.linear_solver.handle, full(w), MNK_HOST)
+#   mul!(w, kkt, x, a, b)   -> ccall(:mnk_sc_mul, ..., kkt.sc, full(w), full(x), a, b, MNK_HOST)
+#
 # See INTEGRATION.md for the full listing and the dense (DenseCondensedKKTSystem) twin.
 
 end # module
