@@ -204,6 +204,16 @@ int mnk_sc_set_barrier_terms(mnk_sc* sc, const double* reg, const double* l_diag
 int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc);
 int mnk_sc_mul(mnk_sc* sc, double* w, const double* x, double alpha, double beta, int loc);
 
+/* The dense twins: w = [x (n); s (ns); y (m); zl; zu].  solve_kkt!(::DenseCondensedKKTSystem) reference
+ * src/IPM/factorization.jl:190-229, the reduced solve of DenseKKTSystem :41-46, mul!(::AbstractDenseKKTSystem)
+ * :310-330 (symv on the lower triangle of hess, two gemv with jac). */
+int mnk_dc_set_bounds(mnk_dc* dc, int64_t nlb, const int64_t* ind_lb, int64_t nub, const int64_t* ind_ub,
+                      int index_base);
+int mnk_dc_set_barrier_terms(mnk_dc* dc, const double* reg, const double* l_diag, const double* u_diag,
+                             const double* l_lower, const double* u_lower, int loc);
+int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc);
+int mnk_dc_mul(mnk_dc* dc, double* w, const double* x, double alpha, double beta, int loc);
+
 /* Diagnostics: with option "solve_trace" = 1 the persistent solve kernel stamps the forward sweep's critical
  * path (8 x 100 MHz timer values per 64-row block); this copies them out (n = number of uint64 to copy). */
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);

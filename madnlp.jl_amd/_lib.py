@@ -96,6 +96,10 @@ SIGNATURES = {
     "mnk_sc_set_barrier_terms": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mnk_sc_solve_kkt": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mnk_sc_mul": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
+    "mnk_dc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
+    "mnk_dc_set_barrier_terms": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "mnk_dc_solve_kkt": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "mnk_dc_mul": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
     "mnk_ls_debug_solve_trace": (C.c_int, [_vp, _vp, C.c_int64]),
     "mnk_debug_update": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int,
                                    C.POINTER(C.c_double)]),

@@ -15,6 +15,7 @@
 #pragma clang fp contract(off)
 
 #include "ls.h"
+#include "kkt_vec.h"
 
 namespace mnk {
 
@@ -126,12 +127,114 @@ __global__ __launch_bounds__(256) void dense_aug_kernel(double* __restrict__ K, 
     K[i + j * ldk] = v;
 }
 
+
+// ---- device-side solve_kkt! / mul! of the dense systems (reference src/IPM/factorization.jl:41-46,190-229,310-330)
+// y[j] = alpha * dot(A[:, j], x) + beta * y[j]   (A is rows x cols, column-major): one wave per column
+__global__ __launch_bounds__(256) void gemv_t_kernel(double* __restrict__ y, const double* __restrict__ A, int64_t lda,
+                                                     const double* __restrict__ x, int64_t rows, int64_t cols,
+                                                     double alpha, double beta) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= cols) return;
+    const double* a = A + j * lda;
+    double s = 0.0;
+    for (int64_t r = lane; r < rows; r += 64) s += a[r] * x[r];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) y[j] = beta == 0.0 ? alpha * s : alpha * s + beta * y[j];
+}
+// y[r] = alpha * dot(A[r, :], x) + beta * y[r]: 64 rows per workgroup, 4 column quarters, LDS reduction
+__global__ __launch_bounds__(256) void gemv_n_kernel(double* __restrict__ y, const double* __restrict__ A, int64_t lda,
+                                                     const double* __restrict__ x, int64_t rows, int64_t cols,
+                                                     double alpha, double beta) {
+    __shared__ double part[4][64];
+    const int row = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 64 + row;
+    double s = 0.0;
+    if (r < rows) {
+        const int64_t c0 = cols * q / 4, c1 = cols * (q + 1) / 4;
+        for (int64_t c = c0; c < c1; ++c) s += A[r + c * lda] * x[c];
+    }
+    part[q][row] = s;
+    __syncthreads();
+    if (q == 0 && r < rows) {
+        const double t = (part[0][row] + part[1][row]) + (part[2][row] + part[3][row]);
+        y[r] = beta == 0.0 ? alpha * t : alpha * t + beta * y[r];
+    }
+}
+// y[i] = alpha * (Symmetric(H, :L) x)[i] + beta * y[i]: one wave per row
+__global__ __launch_bounds__(256) void symv_l_kernel(double* __restrict__ y, const double* __restrict__ H, int64_t n,
+                                                     const double* __restrict__ x, double alpha, double beta) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int64_t j = lane; j < n; j += 64) s += (j <= i ? H[i + j * n] : H[j + i * n]) * x[j];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) y[i] = beta == 0.0 ? alpha * s : alpha * s + beta * y[i];
+}
+// buffer = 0 ; buffer[ind_ineq] = D .* (wz + ws ./ Sigma_s)      (one thread per constraint)
+__global__ void dc_condense_rhs_kernel(double* __restrict__ buffer, const double* __restrict__ dual,
+                                       const double* __restrict__ ws, const double* __restrict__ D,
+                                       const double* __restrict__ Ss, const int32_t* __restrict__ slot, int64_t m) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int32_t i = slot[r];
+    buffer[r] = i >= 0 ? D[i] * (dual[r] + ws[i] / Ss[i]) : 0.0;
+}
+// pd = [xx + wx ; wy]
+__global__ void dc_pack_kernel(double* __restrict__ pd, const double* __restrict__ wx, const double* __restrict__ dual,
+                               const int64_t* __restrict__ ind_eq, int64_t n, int64_t n_eq) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) pd[i] += wx[i];
+    else if (i < n + n_eq) pd[i] = dual[ind_eq[i - n]];
+}
+// after dual = jac * wx:  wy = xy ; wz = wz .* D - buffer ; ws = (ws + wz) ./ Sigma_s
+__global__ void dc_expand_kernel(double* __restrict__ dual, double* __restrict__ ws, const double* __restrict__ buffer,
+                                 const double* __restrict__ D, const double* __restrict__ Ss,
+                                 const int32_t* __restrict__ slot, const int32_t* __restrict__ eq_slot,
+                                 const double* __restrict__ xy, int64_t m) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int32_t i = slot[r];
+    if (i >= 0) {
+        const double z = dual[r] * D[i] - buffer[r];
+        dual[r] = z;
+        ws[i] = (ws[i] + z) / Ss[i];
+    } else {
+        dual[r] = xy[eq_slot[r]];
+    }
+}
+// mul!: ws = beta ws - alpha xz ; wz -= alpha xs ; primal(w) += alpha reg .* primal(x) ; dual(w) += alpha du .* dual(x)
+__global__ void dc_kktmul_diag_kernel(double* __restrict__ w, const double* __restrict__ x, const double* __restrict__ reg,
+                                      const double* __restrict__ du, const int64_t* __restrict__ ind_ineq,
+                                      const int32_t* __restrict__ slot, double alpha, double beta, int64_t n, int64_t ns,
+                                      int64_t m) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) {
+        w[i] += alpha * reg[i] * x[i];
+    } else if (i < n + ns) {
+        const int64_t c = i - n;
+        w[i] = (beta * w[i] - alpha * x[n + ns + ind_ineq[c]]) + alpha * reg[i] * x[i];
+    } else if (i < n + ns + m) {
+        const int64_t r = i - n - ns;
+        const int32_t c = slot[r];
+        double v = w[i];
+        if (c >= 0) v -= alpha * x[n + c];
+        w[i] = v + alpha * du[r] * x[i];
+    }
+}
 }  // namespace mnk
 
 using namespace mnk;
 
 struct mnk_dc_extra {
-    DevBuf<int32_t> ineq_slot;
+    DevBuf<int32_t> ineq_slot;   // constraint -> inequality slot or -1
+    DevBuf<int32_t> eq_slot;     // constraint -> equality slot or -1
+    // device-side solve_kkt! / mul!
+    int64_t nlb = 0, nub = 0;
+    DevBuf<int64_t> ind_lb, ind_ub;
+    DevBuf<double> reg, l_diag, u_diag, l_lower, u_lower, buffer, pd, wdev, xdev;
+    bool have_bounds = false, have_terms = false;
 };
 static std::vector<std::pair<mnk_dc*, mnk_dc_extra*>> g_dcx;
 static mnk_dc_extra* extra_of(mnk_dc* dc) {
@@ -177,6 +280,11 @@ int mnk_dc_create(mnk_ctx* ctx, int condensed, int64_t n, int64_t m, int64_t ns,
     rc |= dc->d_ind_ineq.upload(dc->ind_ineq, s);
     rc |= dc->d_ind_eq.upload(dc->ind_eq, s);
     rc |= ex->ineq_slot.upload(slot, s);
+    {
+        std::vector<int32_t> eslot(std::max<int64_t>(m, 1), -1);
+        for (int64_t k = 0; k < (int64_t)dc->ind_eq.size(); ++k) eslot[dc->ind_eq[k]] = (int32_t)k;
+        rc |= ex->eq_slot.upload(eslot, s);
+    }
     rc |= dc->hess.alloc((size_t)n * n);
     rc |= dc->jac.alloc((size_t)std::max<int64_t>(m, 1) * n);
     rc |= dc->aug.alloc((size_t)ordpad * ordpad + SLACK);
@@ -276,5 +384,165 @@ int mnk_dc_get_aug(mnk_dc* dc, double* out, int loc) {
     if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(dc->ctx->stream));
     return 0;
 }
+
+
+// ---- device-side solve_kkt! / mul! -------------------------------------------------------------------
+int mnk_dc_set_bounds(mnk_dc* dc, int64_t nlb, const int64_t* ind_lb, int64_t nub, const int64_t* ind_ub, int index_base) {
+    MNK_REQUIRE(dc && nlb >= 0 && nub >= 0 && (nlb == 0 || ind_lb) && (nub == 0 || ind_ub), "mnk_dc_set_bounds: bad argument");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    mnk_dc_extra* ex = extra_of(dc);
+    MNK_REQUIRE(ex != nullptr, "mnk_dc_set_bounds: unknown handle");
+    const int64_t np = dc->n + dc->ns;
+    std::vector<int64_t> lb(nlb), ub(nub);
+    for (int64_t i = 0; i < nlb; ++i) {
+        lb[i] = ind_lb[i] - index_base;
+        MNK_REQUIRE(lb[i] >= 0 && lb[i] < np, "mnk_dc_set_bounds: lower-bound index out of range");
+    }
+    for (int64_t i = 0; i < nub; ++i) {
+        ub[i] = ind_ub[i] - index_base;
+        MNK_REQUIRE(ub[i] >= 0 && ub[i] < np, "mnk_dc_set_bounds: upper-bound index out of range");
+    }
+    hipStream_t s = dc->ctx->stream;
+    const size_t lw = (size_t)(np + dc->m + nlb + nub);
+    int rc = ex->ind_lb.upload(lb, s);
+    rc |= ex->ind_ub.upload(ub, s);
+    rc |= ex->reg.alloc(np);
+    rc |= ex->l_diag.alloc(nlb);
+    rc |= ex->l_lower.alloc(nlb);
+    rc |= ex->u_diag.alloc(nub);
+    rc |= ex->u_lower.alloc(nub);
+    rc |= ex->buffer.alloc(dc->m);
+    rc |= ex->pd.alloc(dc->order);
+    rc |= ex->wdev.alloc(lw);
+    rc |= ex->xdev.alloc(lw);
+    if (rc) return rc;
+    ex->nlb = nlb;
+    ex->nub = nub;
+    ex->have_bounds = true;
+    return 0;
+}
+
+int mnk_dc_set_barrier_terms(mnk_dc* dc, const double* reg, const double* l_diag, const double* u_diag,
+                             const double* l_lower, const double* u_lower, int loc) {
+    MNK_REQUIRE(dc, "mnk_dc_set_barrier_terms: NULL argument");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    mnk_dc_extra* ex = extra_of(dc);
+    MNK_REQUIRE(ex != nullptr && ex->have_bounds, "mnk_dc_set_barrier_terms: call mnk_dc_set_bounds first");
+    hipStream_t s = dc->ctx->stream;
+    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    auto put = [&](double* dst, const double* src, int64_t cnt) -> int {
+        if (cnt <= 0) return 0;
+        MNK_REQUIRE(src != nullptr, "mnk_dc_set_barrier_terms: NULL vector");
+        MNK_HIP(hipMemcpyAsync(dst, src, cnt * sizeof(double), kind, s));
+        return 0;
+    };
+    int rc = put(ex->reg.p, reg, dc->n + dc->ns);
+    rc |= put(ex->l_diag.p, l_diag, ex->nlb);
+    rc |= put(ex->u_diag.p, u_diag, ex->nub);
+    rc |= put(ex->l_lower.p, l_lower, ex->nlb);
+    rc |= put(ex->u_lower.p, u_lower, ex->nub);
+    if (rc) return rc;
+    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    ex->have_terms = true;
+    return 0;
+}
+
+#define MNK_GRID(cnt) dim3((unsigned)(((cnt) + 255) / 256)), dim3(256), 0, s
+
+int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc) {
+    MNK_REQUIRE(dc && ls && w, "mnk_dc_solve_kkt: NULL argument");
+    MNK_REQUIRE(ls->ctx == dc->ctx && ls->N == dc->order, "mnk_dc_solve_kkt: the solver does not belong to this system");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    mnk_dc_extra* ex = extra_of(dc);
+    MNK_REQUIRE(ex != nullptr && ex->have_bounds && ex->have_terms,
+                "mnk_dc_solve_kkt: call mnk_dc_set_bounds / mnk_dc_set_barrier_terms / mnk_dc_build first");
+    hipStream_t s = dc->ctx->stream;
+    const int64_t n = dc->n, ns = dc->ns, m = dc->m, n_eq = dc->n_eq, nlb = ex->nlb, nub = ex->nub;
+    const int64_t lw = n + ns + m + nlb + nub;
+    double* d = w;
+    if (loc != MNK_DEVICE) {
+        d = ex->wdev.p;
+        MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    double *ws = d + n, *dual = d + n + ns, *wl = dual + m, *wu = wl + nlb;
+    if (nlb > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nlb), d, ex->ind_lb.p, wl, ex->l_diag.p, nlb);
+    if (nub > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nub), d, ex->ind_ub.p, wu, ex->u_diag.p, nub);
+    int rc = 0;
+    if (!dc->condensed) {
+        // reduced solve (reference src/IPM/factorization.jl:41-46): the solver acts on primal_dual(w) in place
+        rc = mnk_ls_solve(ls, d, 1, dc->order, MNK_DEVICE);
+        if (rc) return rc;
+    } else {
+        const double* Ss = dc->pr_diag.p + n;
+        if (m > 0) {
+            hipLaunchKernelGGL(dc_condense_rhs_kernel, MNK_GRID(m), ex->buffer.p, dual, ws, dc->diag_buffer.p, Ss,
+                               ex->ineq_slot.p, m);
+            hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, ex->pd.p, dc->jac.p, m,
+                               ex->buffer.p, m, n, 1.0, 0.0);  // xx = jac' * buffer
+        } else {
+            MNK_HIP(hipMemsetAsync(ex->pd.p, 0, n * sizeof(double), s));
+        }
+        hipLaunchKernelGGL(dc_pack_kernel, MNK_GRID(n + n_eq), ex->pd.p, d, dual, dc->d_ind_eq.p, n, n_eq);
+        rc = mnk_ls_solve(ls, ex->pd.p, 1, dc->order, MNK_DEVICE);
+        if (rc) return rc;
+        MNK_HIP(hipMemcpyAsync(d, ex->pd.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));  // wx = xx
+        if (m > 0) {
+            hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, dual, dc->jac.p, m, d, m, n,
+                               1.0, 0.0);  // dual(w) = jac * wx
+            hipLaunchKernelGGL(dc_expand_kernel, MNK_GRID(m), dual, ws, ex->buffer.p, dc->diag_buffer.p, Ss,
+                               ex->ineq_slot.p, ex->eq_slot.p, ex->pd.p + n, m);
+        }
+    }
+    if (nlb > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nlb), wl, d, ex->ind_lb.p, ex->l_lower.p, ex->l_diag.p, nlb, 0);
+    if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, ex->ind_ub.p, ex->u_lower.p, ex->u_diag.p, nub, 1);
+    MNK_HIP(hipGetLastError());
+    if (loc != MNK_DEVICE) {
+        MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
+        MNK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int mnk_dc_mul(mnk_dc* dc, double* w, const double* x, double alpha, double beta, int loc) {
+    MNK_REQUIRE(dc && w && x, "mnk_dc_mul: NULL argument");
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    mnk_dc_extra* ex = extra_of(dc);
+    MNK_REQUIRE(ex != nullptr && ex->have_bounds && ex->have_terms,
+                "mnk_dc_mul: call mnk_dc_set_bounds / mnk_dc_set_barrier_terms first");
+    hipStream_t s = dc->ctx->stream;
+    const int64_t n = dc->n, ns = dc->ns, m = dc->m, nlb = ex->nlb, nub = ex->nub;
+    const int64_t lw = n + ns + m + nlb + nub;
+    double* dw = w;
+    const double* dx = x;
+    if (loc != MNK_DEVICE) {
+        dw = ex->wdev.p;
+        MNK_HIP(hipMemcpyAsync(ex->wdev.p, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        MNK_HIP(hipMemcpyAsync(ex->xdev.p, x, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        dx = ex->xdev.p;
+    }
+    // wx = alpha Sym(H) xx + beta wx ; wx += alpha jac' dual(x) ; dual(w) = alpha jac xx + beta dual(w)
+    hipLaunchKernelGGL(symv_l_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dw, dc->hess.p, n, dx, alpha, beta);
+    if (m > 0) {
+        hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, dw, dc->jac.p, m, dx + n + ns, m, n,
+                           alpha, 1.0);
+        hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, dw + n + ns, dc->jac.p, m, dx, m,
+                           n, alpha, beta);
+    }
+    hipLaunchKernelGGL(dc_kktmul_diag_kernel, MNK_GRID(n + ns + m), dw, dx, ex->reg.p, dc->du_diag.p, dc->d_ind_ineq.p,
+                       ex->ineq_slot.p, alpha, beta, n, ns, m);
+    if (nlb > 0)
+        hipLaunchKernelGGL(kktmul_bound_kernel, MNK_GRID(nlb), dw, dw + n + ns + m, dx, dx + n + ns + m, ex->ind_lb.p,
+                           ex->l_lower.p, ex->l_diag.p, alpha, beta, nlb, 0);
+    if (nub > 0)
+        hipLaunchKernelGGL(kktmul_bound_kernel, MNK_GRID(nub), dw, dw + n + ns + m + nlb, dx, dx + n + ns + m + nlb,
+                           ex->ind_ub.p, ex->u_lower.p, ex->u_diag.p, alpha, beta, nub, 1);
+    MNK_HIP(hipGetLastError());
+    if (loc != MNK_DEVICE) {
+        MNK_HIP(hipMemcpyAsync(w, dw, lw * sizeof(double), hipMemcpyDeviceToHost, s));
+        MNK_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+#undef MNK_GRID
 
 }  // extern "C"

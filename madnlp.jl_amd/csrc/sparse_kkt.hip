@@ -16,6 +16,7 @@
 #include <numeric>
 
 #include "ls.h"
+#include "kkt_vec.h"
 
 namespace mnk {
 
@@ -65,13 +66,6 @@ __global__ void gather_spmv_kernel(double* __restrict__ y, const double* __restr
     y[i] = beta == 0.0 ? alpha * acc : alpha * acc + beta * y[i];
 }
 
-// ---- device-side solve_kkt! / mul! pieces (reference src/IPM/kernels.jl:161-204, factorization.jl:143-167,289-308)
-// reduce_rhs!: xp_lr -= wl ./ l_diag (one launch per bound side: a variable may carry both bounds)
-__global__ void reduce_rhs_kernel(double* __restrict__ w, const int64_t* __restrict__ ind, const double* __restrict__ wb,
-                                  const double* __restrict__ diag, int64_t nb) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < nb) w[ind[i]] -= wb[i] / diag[i];
-}
 // buffer = diag_buffer .* (wz .+ ws ./ Sigma_s)
 __global__ void condense_rhs_kernel(double* __restrict__ buffer, const double* __restrict__ D, const double* __restrict__ ws,
                                     const double* __restrict__ wz, const double* __restrict__ Ss, int64_t m) {
@@ -89,12 +83,6 @@ __global__ void expand_sol_kernel(double* __restrict__ ws, double* __restrict__ 
         ws[c] = (ws[c] + z) / Ss[c];
     }
 }
-// finish_aug_solve!: dlb = (-dlb + l_lower .* xp_lr) ./ l_diag ; dub = (dub - u_lower .* xp_ur) ./ u_diag
-__global__ void finish_aug_kernel(double* __restrict__ db, const double* __restrict__ w, const int64_t* __restrict__ ind,
-                                  const double* __restrict__ lower, const double* __restrict__ diag, int64_t nb, int upper) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < nb) db[i] = upper ? (db[i] - lower[i] * w[ind[i]]) / diag[i] : (-db[i] + lower[i] * w[ind[i]]) / diag[i];
-}
 // mul!, slack/dual coupling: wz -= alpha xs ; ws = beta ws - alpha xz ; then _kktmul!'s diagonal part
 //   primal(w) += alpha reg .* primal(x) ; dual(w) += alpha du_diag .* dual(x)
 __global__ void kktmul_diag_kernel(double* __restrict__ w, const double* __restrict__ x, const double* __restrict__ reg,
@@ -108,23 +96,6 @@ __global__ void kktmul_diag_kernel(double* __restrict__ w, const double* __restr
     } else if (i < n + 2 * m) {  // dual block (already holds alpha Jt' xx + beta wz)
         const int64_t c = i - n - m;
         w[i] = (w[i] - alpha * x[n + c]) + alpha * du[c] * x[i];
-    }
-}
-// _kktmul!, bound part.  side 0: xp_lr -= alpha dlb(x) ; dlb(w) = beta dlb(w) + alpha (x_lr l_lower - dlb(x) l_diag)
-//                        side 1: xp_ur += alpha dub(x) ; dub(w) = beta dub(w) + alpha (x_ur u_lower + dub(x) u_diag)
-__global__ void kktmul_bound_kernel(double* __restrict__ w, double* __restrict__ wb, const double* __restrict__ x,
-                                    const double* __restrict__ xb, const int64_t* __restrict__ ind,
-                                    const double* __restrict__ lower, const double* __restrict__ diag, double alpha,
-                                    double beta, int64_t nb, int upper) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= nb) return;
-    const int64_t p = ind[i];
-    if (upper) {
-        w[p] += alpha * xb[i];
-        wb[i] = beta * wb[i] + alpha * (x[p] * lower[i] + xb[i] * diag[i]);
-    } else {
-        w[p] -= alpha * xb[i];
-        wb[i] = beta * wb[i] + alpha * (x[p] * lower[i] - xb[i] * diag[i]);
     }
 }
 

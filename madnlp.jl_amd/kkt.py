@@ -383,6 +383,35 @@ class _DenseBase(_KKTCommon):
         """no-op, reference `src/KKT/Dense/utils.jl:25-27`."""
         return
 
+    device_kkt_ops = False
+
+    def _setup_device_ops(self, device_kkt_ops):
+        """Upload the bound structure once; with `device_kkt_ops` `solve_kkt!` / `mul!` run on the device
+        (`mnk_dc_solve_kkt`, `mnk_dc_mul`)."""
+        self.device_kkt_ops = bool(device_kkt_ops)
+        L.check(L.lib().mnk_dc_set_bounds(self._h, len(self.ind_lb), self.ind_lb.ctypes.data, len(self.ind_ub),
+                                          self.ind_ub.ctypes.data, 0), "mnk_dc_set_bounds")
+
+    def upload_barrier_terms(self):
+        L.check(L.lib().mnk_dc_set_barrier_terms(self._h, self.reg.ctypes.data, self.l_diag.ctypes.data,
+                                                 self.u_diag.ctypes.data, self.l_lower.ctypes.data,
+                                                 self.u_lower.ctypes.data, L.MNK_HOST), "mnk_dc_set_barrier_terms")
+
+    def solve_kkt_device(self, w):
+        p, loc = _ptr(w.values if isinstance(w, UnreducedKKTVector) else w)
+        rc = L.lib().mnk_dc_solve_kkt(self._h, self.linear_solver._h, p, loc)
+        if rc:
+            from .linear_solver import SolveException
+            raise SolveException(L.lib().mnk_last_error_string().decode())
+        return w
+
+    def mul_device(self, w, x, alpha=1.0, beta=0.0):
+        pw, loc = _ptr(w.values if isinstance(w, UnreducedKKTVector) else w)
+        px, loc2 = _ptr(x.values if isinstance(x, UnreducedKKTVector) else x)
+        assert loc == loc2
+        L.check(L.lib().mnk_dc_mul(self._h, pw, px, float(alpha), float(beta), loc), "mnk_dc_mul")
+        return w
+
     def _upload(self):
         lib = L.lib()
         L.check(lib.mnk_dc_set_hess(self._h, self.hess.ctypes.data, self.hess.shape[0], L.MNK_HOST), "mnk_dc_set_hess")
@@ -395,6 +424,8 @@ class _DenseBase(_KKTCommon):
         self._upload()
         L.check(L.lib().mnk_dc_build(self._h, self.pr_diag.ctypes.data, self.du_diag.ctypes.data, L.MNK_HOST),
                 "mnk_dc_build")
+        if self.device_kkt_ops:
+            self.upload_barrier_terms()
 
     def jtprod(self, y, x):
         """reference `src/KKT/Dense/utils.jl:12-23`."""
@@ -406,6 +437,8 @@ class _DenseBase(_KKTCommon):
 
     def mul(self, w, x, alpha=1.0, beta=0.0):
         """reference `src/IPM/factorization.jl:301-324`."""
+        if self.device_kkt_ops:
+            return self.mul_device(w, x, alpha, beta)
         m, n = self.jac.shape
         wp, xp = w.primal(), x.primal()
         wx, ws = wp[:n], wp[n:]
@@ -447,7 +480,7 @@ class DenseKKTSystem(_DenseBase):
     """reference `src/KKT/Dense/augmented.jl:10-94` (order n + ns + m)."""
 
     def __init__(self, n, m, ind_ineq, ind_lb, ind_ub, ctx=None, linear_solver=HipLinearSolver,
-                 opt_linear_solver=None):
+                 opt_linear_solver=None, device_kkt_ops=False):
         ns = len(ind_ineq)
         self.n, self.m, self.ns = n, m, ns
         self._create(0, n, m, ind_ineq, [], ctx)
@@ -465,6 +498,7 @@ class DenseKKTSystem(_DenseBase):
         self.ind_ub = np.asarray(ind_ub, dtype=np.int64)
         self.aug_com = DeviceDense(self, self._order)
         self.linear_solver = linear_solver(self.aug_com, ctx=self.ctx, opt=opt_linear_solver)
+        self._setup_device_ops(device_kkt_ops)
 
     def num_variables(self):
         return len(self.pr_diag)
@@ -481,6 +515,8 @@ class DenseKKTSystem(_DenseBase):
 
     def solve_kkt(self, w):
         """reference `src/IPM/factorization.jl:41-46`."""
+        if self.device_kkt_ops:
+            return self.solve_kkt_device(w)
         self._reduce_rhs(w)
         self.linear_solver.solve_linear_system(w.primal_dual())
         self._finish_aug_solve(w)
@@ -491,7 +527,7 @@ class DenseCondensedKKTSystem(_DenseBase):
     """reference `src/KKT/Dense/condensed.jl:10-111` (order n + n_eq)."""
 
     def __init__(self, n, m, ind_ineq, ind_eq, ind_lb, ind_ub, ctx=None, linear_solver=HipLinearSolver,
-                 opt_linear_solver=None):
+                 opt_linear_solver=None, device_kkt_ops=False):
         ns = len(ind_ineq)
         self.n, self.m, self.n_ineq, self.n_eq = n, m, ns, m - ns
         assert self.n_eq == len(ind_eq)
@@ -515,6 +551,7 @@ class DenseCondensedKKTSystem(_DenseBase):
         self.ind_ineq_shifted = self.ind_ineq + n + ns
         self.aug_com = DeviceDense(self, self._order)
         self.linear_solver = linear_solver(self.aug_com, ctx=self.ctx, opt=opt_linear_solver)
+        self._setup_device_ops(device_kkt_ops)
 
     def num_variables(self):
         return self.hess.shape[0]
@@ -538,6 +575,8 @@ class DenseCondensedKKTSystem(_DenseBase):
 
     def solve_kkt(self, w):
         """reference `src/IPM/factorization.jl:190-229`."""
+        if self.device_kkt_ops:
+            return self.solve_kkt_device(w)
         n, n_eq, ns = self.n, self.n_eq, self.n_ineq
         full = w.values
         wx, ws = full[:n], full[n:n + ns]

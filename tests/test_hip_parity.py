@@ -464,9 +464,10 @@ def _ipm_pair(kind, nlp, ctx, tol, device_kkt_ops=False):
                                                opt_linear_solver=opt, device_kkt_ops=device_kkt_ops)
         if kind == "dense_condensed":
             return mj.DenseCondensedKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_eq"], info["ind_lb"],
-                                              info["ind_ub"], ctx=ctx, opt_linear_solver=opt)
+                                              info["ind_ub"], ctx=ctx, opt_linear_solver=opt,
+                                              device_kkt_ops=device_kkt_ops)
         return mj.DenseKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_lb"], info["ind_ub"], ctx=ctx,
-                                 opt_linear_solver=opt)
+                                 opt_linear_solver=opt, device_kkt_ops=device_kkt_ops)
 
     out = []
     for fac in (oracle_factory(kind, nlp), hip_factory):
@@ -771,3 +772,42 @@ def test_ipm_sparse_qp_with_device_kkt_ops(ctx, case):
     assert sh.kkt.device_kkt_ops
     _assert_ipm_parity(so, sh, nlp.n)
     sh.kkt.close()
+
+
+@pytest.mark.parametrize("n,m,n_eq", [(10, 5, 0), (50, 10, 0), (20, 15, 2)])
+@pytest.mark.parametrize("kind", ["dense", "dense_condensed"])
+def test_ipm_dense_qp_with_device_kkt_ops(ctx, kind, n, m, n_eq):
+    """Dense twins of the device-side `solve_kkt!`/`mul!` (`mnk_dc_solve_kkt`, `mnk_dc_mul`: symv on the lower
+    triangle of hess, gemv with jac, the condensed right-hand side and its expansion): the IPM driver with them
+    switched on reproduces the CPU oracle's iteration history (DenseDummyQP sizes of test/madnlp_dense.jl)."""
+    from madnlp_jl_amd.problems import DenseQPModel
+    so, sh = _ipm_pair(kind, DenseQPModel(n, m, n_eq), ctx, 1e-8, device_kkt_ops=True)
+    assert sh.kkt.device_kkt_ops
+    _assert_ipm_parity(so, sh, n)
+    sh.kkt.close()
+
+
+@pytest.mark.parametrize("kind", ["dense", "dense_condensed"])
+def test_dense_device_mul_matches_host_mirror(ctx, kind):
+    """`mnk_dc_mul` against the host mirror of `mul!` (itself checked against the oracle) for several (alpha, beta)."""
+    P = dense_dummy_qp(60, 25, 4 if kind == "dense_condensed" else 0)
+    if kind == "dense_condensed":
+        k = mj.DenseCondensedKKTSystem(P.n, P.m, P.ind_ineq, P.ind_eq, P.ind_lb, P.ind_ub, ctx=ctx)
+    else:
+        k = mj.DenseKKTSystem(P.n, P.m, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx)
+    for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+        getattr(k, f)[:] = getattr(P, f)
+    k.hess[...] = P.hess
+    k.jac[...] = P.jac
+    k.set_aug_diagonal()
+    k.build_kkt()
+    k.upload_barrier_terms()
+    rng = np.random.default_rng(4)
+    x, w1, w2 = (mj.UnreducedKKTVector.from_kkt(k) for _ in range(3))
+    xv, wv = rng.standard_normal(len(x.values)), rng.standard_normal(len(x.values))
+    for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.3, -2.0)):
+        x.values[:] = xv; w1.values[:] = wv; w2.values[:] = wv
+        k.mul(w1, x, alpha, beta)
+        k.mul_device(w2, x, alpha, beta)
+        assert np.abs(w1.values - w2.values).max() <= 1e-12 * max(1.0, np.abs(w1.values).max()), (alpha, beta)
+    k.close()
