@@ -236,12 +236,7 @@ struct mnk_dc_extra {
     DevBuf<double> reg, l_diag, u_diag, l_lower, u_lower, buffer, pd, wdev, xdev;
     bool have_bounds = false, have_terms = false;
 };
-static std::vector<std::pair<mnk_dc*, mnk_dc_extra*>> g_dcx;
-static mnk_dc_extra* extra_of(mnk_dc* dc) {
-    for (auto& p : g_dcx)
-        if (p.first == dc) return p.second;
-    return nullptr;
-}
+static mnk_dc_extra* extra_of(mnk_dc* dc) { return static_cast<mnk_dc_extra*>(dc->extra); }
 
 extern "C" {
 
@@ -296,7 +291,7 @@ int mnk_dc_create(mnk_ctx* ctx, int condensed, int64_t n, int64_t m, int64_t ns,
     MNK_HIP(hipMemsetAsync(dc->hess.p, 0, dc->hess.n * sizeof(double), s));
     MNK_HIP(hipMemsetAsync(dc->jac.p, 0, dc->jac.n * sizeof(double), s));
     MNK_HIP(hipMemsetAsync(dc->aug.p, 0, dc->aug.n * sizeof(double), s));
-    g_dcx.emplace_back(dc, ex);
+    dc->extra = ex;
     *out = dc;
     return 0;
 }
@@ -305,8 +300,8 @@ int mnk_dc_destroy(mnk_dc* dc) {
     if (!dc) return 0;
     (void)hipSetDevice(dc->ctx->device);
     (void)hipStreamSynchronize(dc->ctx->stream);
-    for (size_t i = 0; i < g_dcx.size(); ++i)
-        if (g_dcx[i].first == dc) { delete g_dcx[i].second; g_dcx.erase(g_dcx.begin() + i); break; }
+    delete extra_of(dc);
+    dc->extra = nullptr;
     delete dc;
     return 0;
 }

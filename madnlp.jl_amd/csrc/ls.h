@@ -22,6 +22,7 @@ struct mnk_sc {
     mnk::DevBuf<int32_t> d_jt_colptr, d_jt_rowval, d_jt_colidx, d_h_colptr, d_h_rowval, d_h_colidx;
     // device values
     mnk::DevBuf<double> jac_coo, hess_coo, jt_nz, h_nz, aug_nz, diag_buffer, pr_diag, du_diag;
+    void* extra = nullptr;  // unit-private device structures (sparse_kkt.hip), owned by the handle
 };
 
 struct mnk_dc {
@@ -33,6 +34,7 @@ struct mnk_dc {
     mnk::DevBuf<double> hess, jac, aug, pr_diag, du_diag, diag_buffer;
     mnk::DevBuf<double> jis;  // sqrt(D)-scaled, zero-padded inequality Jacobian^T workspace
     int64_t ld_jis = 0, kpad = 0, npad = 0;
+    void* extra = nullptr;  // unit-private device structures (dense_kkt.hip), owned by the handle
 };
 
 struct mnk_ls {

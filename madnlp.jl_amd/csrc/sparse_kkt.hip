@@ -167,12 +167,7 @@ struct mnk_sc_spmv_data {
     DevBuf<double> buffer, buffer2, wdev, xdev;   // m, m, len(w), len(w)
     bool have_bounds = false, have_terms = false;
 };
-static std::vector<std::pair<mnk_sc*, mnk_sc_spmv_data*>> g_spmv;  // tiny registry
-static mnk_sc_spmv_data* spmv_of(mnk_sc* sc) {
-    for (auto& p : g_spmv)
-        if (p.first == sc) return p.second;
-    return nullptr;
-}
+static mnk_sc_spmv_data* spmv_of(mnk_sc* sc) { return static_cast<mnk_sc_spmv_data*>(sc->extra); }
 
 extern "C" {
 
@@ -326,7 +321,7 @@ int mnk_sc_create(mnk_ctx* ctx, int64_t n, int64_t m, int64_t nnzj, const int32_
     MNK_HIP(hipMemsetAsync(sc->jt_nz.p, 0, sc->jt_nz.n * sizeof(double), s));
     MNK_HIP(hipMemsetAsync(sc->h_nz.p, 0, sc->h_nz.n * sizeof(double), s));
     MNK_HIP(hipMemsetAsync(sc->aug_nz.p, 0, sc->aug_nz.n * sizeof(double), s));
-    g_spmv.emplace_back(sc, sp);
+    sc->extra = sp;
     *out = sc;
     return 0;
 }
@@ -337,8 +332,8 @@ int mnk_sc_destroy(mnk_sc* sc) {
         (void)hipSetDevice(sc->ctx->device);
         (void)hipStreamSynchronize(sc->ctx->stream);
     }
-    for (size_t i = 0; i < g_spmv.size(); ++i)
-        if (g_spmv[i].first == sc) { delete g_spmv[i].second; g_spmv.erase(g_spmv.begin() + i); break; }
+    delete spmv_of(sc);
+    sc->extra = nullptr;
     delete sc;
     return 0;
 }
