@@ -90,7 +90,7 @@ struct mnk_ctx {
     int panel_cus_big = 0;
     int panel_cus_big_want = 0;  // > 0: create sp_big/su_big with this many panel CUs when first needed
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    std::vector<hipEvent_t> ev_panel, ev_next, ev_next2;
+    std::vector<hipEvent_t> ev_panel, ev_next, ev_next2, ev_bdone;
     int num_cu = 256;   // CUs this context may use (the whole device, or its partition)
     int cu_first = 0;   // first CU-mask bit of the partition
     int total_cu = 256; // CUs of the device

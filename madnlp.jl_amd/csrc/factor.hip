@@ -510,10 +510,11 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 using namespace mnk;
 
 // factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
-// `second_half_ready` (optional): event to wait for before the first kernel that touches the columns
-// beyond the first middle panel (the look-ahead delivers the outer panel's columns in two pieces).
+// `rest_ready` (optional): event to wait for before the first kernel that touches the columns from
+// `rest_from` on (offset inside the panel, 64 or 256): the look-ahead delivers the outer panel's columns in
+// two pieces.
 static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
-                              hipEvent_t second_half_ready = nullptr) {
+                              hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
@@ -523,7 +524,7 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // middle level, right-looking: when a 256-column middle panel is complete, apply it to the
         // remaining columns of the outer panel with one K = 256 product (MFMA tiles, lower part)
         if (j == mo && j > ko) {
-            if (second_half_ready != nullptr && j == ko + NBM) MNK_HIP(hipStreamWaitEvent(s, second_half_ready, 0));
+            if (rest_ready != nullptr && rest_from == NBM && j == ko + NBM) MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
             const int64_t pm = mo - NBM;  // the middle panel just finished: columns [pm, mo)
             const double* Wp = ldl ? wbase + mo + (pm - ko) * ls->ldw : F + mo + pm * ld;
             int rc;
@@ -537,6 +538,7 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         }
         // inner level, left-looking inside the middle panel: bring block column j up to date with the
         // blocks [mo, j) already factored (one K = j-mo product on 64 columns)
+        if (rest_ready != nullptr && rest_from == NBI && j == ko + NBI) MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
         if (j > mo) {
             const double* Wp = ldl ? wbase + j + (mo - ko) * ls->ldw : F + j + mo * ld;
             int rc = launch_gemm_nt(s, 0, Np - j, NBI, j - mo, Wp, ldl ? ls->ldw : ld, F + j + mo * ld, ld,
@@ -641,10 +643,12 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             ctx->ev_panel.resize(npanel + 1);
             ctx->ev_next.resize(npanel + 1);
             ctx->ev_next2.resize(npanel + 1);
+            ctx->ev_bdone.resize(npanel + 1);
             for (size_t e = old; e < ctx->ev_panel.size(); ++e) {
                 MNK_HIP(hipEventCreateWithFlags(&ctx->ev_panel[e], hipEventDisableTiming));
                 MNK_HIP(hipEventCreateWithFlags(&ctx->ev_next[e], hipEventDisableTiming));
                 MNK_HIP(hipEventCreateWithFlags(&ctx->ev_next2[e], hipEventDisableTiming));
+                MNK_HIP(hipEventCreateWithFlags(&ctx->ev_bdone[e], hipEventDisableTiming));
             }
         }
         // Work sharing: while the trailing update is the longer leg, the panel stream's CUs would
@@ -681,24 +685,38 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             // (a) columns of the next outer panel, delivered in two pieces: its first 256-column middle
             // panel (the panel stream starts on it at once), then the remaining columns (needed only when
             // that middle panel is finished)
-            auto update_a = [&](int64_t c0, int64_t c1) -> int {
+            auto update_a = [&](hipStream_t st, int64_t c0, int64_t c1) -> int {
                 const int64_t Mp = Mt - c0, Nn = c1 - c0;
                 double* Cp = F + (kend + c0) + (kend + c0) * ld;
                 if (gemm_nt_lower_tiles(Mp, Nn) < ls->small_tiles)
-                    return launch_gemm_nt_lower_small(su, Mp, Nn, Kw, Wsrc + c0, ldws, F + kend + c0 + ko * ld, ld, Cp,
+                    return launch_gemm_nt_lower_small(st, Mp, Nn, Kw, Wsrc + c0, ldws, F + kend + c0 + ko * ld, ld, Cp,
                                                       ld, ls->info_dev.p);
-                return launch_gemm_nt(su, 2, Mp, Nn, Kw, Wsrc + c0, ldws, F + kend + c0 + ko * ld, ld, Cp, ld, nullptr,
+                return launch_gemm_nt(st, 2, Mp, Nn, Kw, Wsrc + c0, ldws, F + kend + c0 + ko * ld, ld, Cp, ld, nullptr,
                                       nullptr, 0, ls->info_dev.p);
             };
-            const int64_t n1 = std::min<int64_t>(256, nnext);
+            // split_a == 2: the first 64 columns of the next panel are updated on the PANEL stream itself, right
+            // behind panel k (no cross-stream hand-over before the next pivot block starts); the update stream
+            // delivers the other columns while that block is being factored.  split_a == 1: first 256 columns
+            // on the update stream, then the rest.
+            const bool own_first = ls->split_a == 2 && nnext > NBI;
+            const int64_t n1 = own_first ? NBI : std::min<int64_t>(256, nnext);
             const bool split_a = ls->split_a && nnext > n1;
-            rc = update_a(0, split_a ? n1 : nnext);
-            if (rc) return rc;
-            MNK_HIP(hipEventRecord(ctx->ev_next[k], su));
-            if (split_a) {
-                rc = update_a(n1, nnext);
+            if (own_first) {
+                if (k > 0) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_bdone[k - 1], 0));  // (b)_{k-1} touched these columns
+                rc = update_a(sp, 0, n1);
+                if (rc) return rc;
+                rc = update_a(su, n1, nnext);
                 if (rc) return rc;
                 MNK_HIP(hipEventRecord(ctx->ev_next2[k], su));
+            } else {
+                rc = update_a(su, 0, split_a ? n1 : nnext);
+                if (rc) return rc;
+                MNK_HIP(hipEventRecord(ctx->ev_next[k], su));
+                if (split_a) {
+                    rc = update_a(su, n1, nnext);
+                    if (rc) return rc;
+                    MNK_HIP(hipEventRecord(ctx->ev_next2[k], su));
+                }
             }
             // (b) the rest of the trailing matrix
             const int64_t Mb = Mt - nnext;
@@ -719,10 +737,11 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                                         ls->info_dev.p);
                 if (rc) return rc;
             }
+            if (own_first) MNK_HIP(hipEventRecord(ctx->ev_bdone[k], su));
             // panel k+1 on the panel stream, as soon as (a) is done
-            MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_next[k], 0));
+            if (!own_first) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_next[k], 0));
             rc = factor_outer_panel(ls, sp, kend, kend + nnext, ls->wbuf[(k + 1) & 1].p,
-                                    split_a ? ctx->ev_next2[k] : nullptr);
+                                    split_a ? ctx->ev_next2[k] : nullptr, own_first ? NBI : 256);
             if (rc) return rc;
             if (shared_b) {
                 rc = launch_gemm_nt_queue(sp, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,

@@ -188,6 +188,7 @@ int mnk_ctx_destroy(mnk_ctx* c) {
     for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_next2) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
     if (c->sp_big) (void)hipStreamDestroy(c->sp_big);
