@@ -288,6 +288,15 @@ class DeviceCSC:
         d[self.rowval, ci] = self.nzval
         return d
 
+    def nzval_host(self):
+        """Values of the stored (lower-triangular) entries, copied from the device."""
+        return self.nzval
+
+    def to_scipy(self):
+        """Lower-triangular scipy CSC with the current device values."""
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.nzval, np.asarray(self.rowval), np.asarray(self.colptr)), shape=(self.n, self.n))
+
 
 class DeviceDense:
     """`aug_com` of a dense KKT system living in HBM."""
