@@ -19,6 +19,7 @@
 //   * Global -> LDS staging goes through registers in 16-byte pieces, double
 //     buffered: the loads of k-tile t+1 are issued before the MFMAs of k-tile t.
 #include <algorithm>
+#include <atomic>
 
 #include "common.h"
 
@@ -307,10 +308,13 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
     }
     const size_t smem = 2 * tile_bk(WM, WN, WT) * ((BM + 16) + (BN + 16)) * sizeof(double);
     auto kern = gemm_nt_kernel<WM, WN, WT, MODE, LDL_EPI>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (kernel, device) pair: set it once per device of this process
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    MNK_HIP(hipGetDevice(&dev));
+    if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
         MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+        attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
     }
     if (tile_count >= 0) ntiles = std::min(ntiles - tile_begin, tile_count);
     if (ntiles <= 0) return 0;
@@ -420,10 +424,13 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
     if (nwg > ntiles) nwg = ntiles;
     const size_t smem = 2 * tile_bk(2, 2, 4) * ((BM + 16) + (BM + 16)) * sizeof(double);
     auto kern = gemm_nt_queue_kernel<2, 2, 4, 2>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (kernel, device) pair: set it once per device of this process
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    MNK_HIP(hipGetDevice(&dev));
+    if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
         MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
+        attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm, ntiles, counter,
                        info_flag);
