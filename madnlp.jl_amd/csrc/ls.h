@@ -46,6 +46,8 @@ struct mnk_ls {
     int share = 1;         // look-ahead only: the panel stream's CUs join the trailing update through a tile queue
     int small_tiles = 400;  // (a)-updates with fewer 128x128 tiles than this use 64x64 workgroup tiles
     int split_a = 2;          // 1: next panel delivered in two pieces by the update stream; 2: its first 64 columns by the panel stream itself
+    int64_t tail_rows = 3584;  // > 0: outer panels are tail_nbo wide once this many rows (or fewer) remain (0: never)
+    int64_t tail_nbo = 256;
     int small_tiles_mid = 400;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, linv256, linv256t, dvec, dinv, xwork;

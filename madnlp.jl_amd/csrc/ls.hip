@@ -222,6 +222,8 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_SMALL_TILES")) ls->small_tiles = atoi(e);
     if (const char* e = getenv("MNK_SMALL_TILES_MID")) ls->small_tiles_mid = atoi(e);
     if (const char* e = getenv("MNK_SPLIT_A")) ls->split_a = atoi(e);
+    if (const char* e = getenv("MNK_TAIL_ROWS")) ls->tail_rows = atol(e);
+    if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
