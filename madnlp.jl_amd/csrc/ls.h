@@ -46,6 +46,7 @@ struct mnk_ls {
     int share = 1;         // look-ahead only: the panel stream's CUs join the trailing update through a tile queue
     int small_tiles = 400;  // (a)-updates with fewer 128x128 tiles than this use 64x64 workgroup tiles
     int split_a = 2;          // 1: next panel delivered in two pieces by the update stream; 2: its first 64 columns by the panel stream itself
+    int64_t single_rows = 4608;  // systems up to this (padded) order are factored as ONE outer panel on the whole chip
     int64_t tail_rows = 3584;  // > 0: outer panels are tail_nbo wide once this many rows (or fewer) remain (0: never)
     int64_t tail_nbo = 256;
     int small_tiles_mid = 400;  // same for the middle-level update inside an outer panel
@@ -62,6 +63,7 @@ struct mnk_ls {
 };
 
 extern "C" int mnk_ctx_ensure_big_pair(mnk_ctx* c);
+int64_t mnk_ls_effective_nbo(const mnk_ls* ls);
 int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);

@@ -223,6 +223,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_SMALL_TILES_MID")) ls->small_tiles_mid = atoi(e);
     if (const char* e = getenv("MNK_SPLIT_A")) ls->split_a = atoi(e);
     if (const char* e = getenv("MNK_TAIL_ROWS")) ls->tail_rows = atol(e);
+    if (const char* e = getenv("MNK_SINGLE_ROWS")) ls->single_rows = atol(e);
     if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     ls->Np = round_up(N, PAD);
@@ -265,6 +266,12 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         ls->wbuf[1].release();
         return 0;
     }
+    if (!strcmp(key, "single_rows")) {  // systems up to this order: one outer panel, no look-ahead (0: never)
+        ls->single_rows = (int64_t)value;
+        ls->wbuf[0].release();
+        ls->wbuf[1].release();
+        return 0;
+    }
     if (!strcmp(key, "lookahead")) { ls->lookahead = value != 0.0; return 0; }
     // 0: no work sharing, 1: the panel stream joins the trailing update when that is the longer leg,
     // 2: always (used by the schedule tests)
@@ -287,9 +294,10 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
 
 static int ensure_wbuf(mnk_ls* ls) {
     if (ls->algo != MNK_LDL || ls->wbuf[0].p) return 0;
-    const size_t cnt = (size_t)ls->ldw * std::min<int64_t>(ls->nbo, ls->Np) + SLACK;
+    const size_t cnt = (size_t)ls->ldw * std::min<int64_t>(mnk_ls_effective_nbo(ls), ls->Np) + SLACK;
     int rc = ls->wbuf[0].alloc(cnt);
-    if (!rc) rc = ls->wbuf[1].alloc(cnt);  // double buffered: panel k+1 is factored while panel k is applied
+    // double buffered for the look-ahead: panel k+1 is factored while panel k is applied
+    if (!rc && mnk_ls_effective_nbo(ls) < ls->Np) rc = ls->wbuf[1].alloc(cnt);
     return rc;
 }
 

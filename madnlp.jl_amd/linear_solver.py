@@ -117,6 +117,7 @@ class HipSolverOptions:
     share: int = 1          # 0 off, 1 adaptive, 2 always: panel-stream CUs join the trailing update
     small_tiles: int = 400  # (a)-updates with fewer 128x128 tiles use 64x64 workgroup tiles
     persistent_solve: bool = True  # both triangular sweeps in one launch (False: one launch per 256-column step)
+    single_rows: int = 4608  # systems up to this order are factored as one outer panel on the whole chip (0: never)
 
 
 class HipLinearSolver:
@@ -149,6 +150,8 @@ class HipLinearSolver:
             settings.append(("small_tiles", float(self.opt.small_tiles)))
         if "MNK_PERSISTENT_SOLVE" not in os.environ:
             settings.append(("persistent_solve", float(self.opt.persistent_solve)))
+        if "MNK_SINGLE_ROWS" not in os.environ:
+            settings.append(("single_rows", float(self.opt.single_rows)))
         for key, val in settings:
             L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(val)), "mnk_ls_set_option")
         self.info = 0

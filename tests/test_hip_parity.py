@@ -542,7 +542,8 @@ def test_factorization_schedules_agree(ctx, N, alg, nbo, la):
         A[N - k:, N - k:] -= np.eye(k) * 5.0
         A = np.asfortranarray((A + A.T) / 2)
     dA = torch.from_numpy(A).cuda()  # column-major view of a symmetric matrix
-    M = mj.HipLinearSolver(dA, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, outer_block=nbo, lookahead=la))
+    M = mj.HipLinearSolver(dA, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, outer_block=nbo, lookahead=la,
+                                                                single_rows=0))  # force the multi-panel schedules
     M.factorize()
     ref_alg = CHOLESKY if alg == mj.CHOLESKY else BUNCHKAUFMAN
     ref = LapackCPUSolver(A, ref_alg).factorize()
@@ -578,7 +579,7 @@ def test_shared_tile_queue_schedule_is_bit_identical(ctx, alg, nbo, small):
     facs = []
     for share in (0, 1, 2, 2):  # off, adaptive, forced (every trailing update goes through the queue)
         M = mj.HipLinearSolver(dA, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, outer_block=nbo,
-                                                                   share=share, small_tiles=small))
+                                                                   share=share, small_tiles=small, single_rows=0))
         M.factorize()
         Lf, d = M.get_factor()
         facs.append((np.tril(Lf).copy(), None if d is None else np.array(d)))
@@ -598,7 +599,7 @@ def test_repeated_factorizations_are_deterministic(ctx):
     N = 3000
     R = rng.standard_normal((N, 64))
     A = np.asfortranarray(R @ R.T + N * np.eye(N))
-    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY))
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY, single_rows=0))
     M.factorize()
     L0, _ = M.get_factor()
     for _ in range(4):
