@@ -902,3 +902,64 @@ def test_full_size_case9241_round_trip(ctx):
     res = np.abs(K @ x - b).max() / (np.abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
     assert res <= 1e-12, res
     kh.close()
+
+
+# --------------------------------------------------------------------------- interface contract corners
+def test_solver_contract_errors_and_strided_inputs(ctx):
+    """AbstractLinearSolver contract (reference src/LinearSolvers/linearsolvers.jl:13-137): a solve before a
+    factorization and a short right-hand side raise SolveException, an algorithm the device does not implement
+    raises at construction, a numerically failed factorization does NOT raise; the matrix may live in a larger
+    device buffer (leading dimension > N) and a matrix right-hand side may be a strided device view."""
+    rng = np.random.default_rng(12)
+    N = 300
+    R = rng.standard_normal((N, 20))
+    A = np.asfortranarray(R @ R.T + N * np.eye(N))
+    with pytest.raises(mj.SymbolicException):
+        mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm="LU"))
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY))
+    with pytest.raises(mj.SolveException):
+        M.solve_linear_system(np.ones(N))
+    M.factorize()
+    with pytest.raises(mj.SolveException):
+        M.solve_linear_system(np.ones(N - 1))
+    M.close()
+    # matrix inside a bigger device allocation: leading dimension 384 > N (column-major view via transpose)
+    big = torch.zeros(384, 384, dtype=torch.float64, device="cuda")
+    big[:N, :N] = torch.from_numpy(A).cuda()          # symmetric: row-major view == column-major view
+    view = big[:N, :N]
+    torch.cuda.synchronize()
+    M = mj.HipLinearSolver(view, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY))
+    M.factorize()
+    assert M.inertia() == (N, 0, 0)
+    B = torch.zeros(384, 4, dtype=torch.float64, device="cuda").t().contiguous().t()  # column-major 384 x 4
+    Bh = rng.standard_normal((N, 4))
+    B[:N, :] = torch.from_numpy(Bh).cuda()
+    torch.cuda.synchronize()
+    X = B[:N, :]                                       # strided view: ld 384
+    M.solve_linear_system(X)
+    ctx.synchronize()
+    assert np.abs(A @ X.cpu().numpy() - Bh).max() <= 1e-10 * N
+    M.close()
+    # a factorization that fails numerically reports it through inertia, without raising
+    Aneg = np.asfortranarray(-A)
+    M = mj.HipLinearSolver(Aneg, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY))
+    M.factorize()
+    assert M.inertia() == (0, N, 0)
+    M.close()
+
+
+def test_ldl_pivot_tolerance_reports_tiny_pivots_as_zero(ctx):
+    """`pivot_tol`: a pivot with |d| <= pivot_tol is counted as num_zero (and replaced by 1) so the IPM's inertia
+    correction regularizes, instead of dividing by it."""
+    N = 130
+    d = np.ones(N)
+    d[70] = 1e-13
+    A = np.asfortranarray(np.diag(d))
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL, pivot_tol=1e-10))
+    M.factorize()
+    assert M.inertia() == (N - 1, 1, 0)
+    M.close()
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
+    M.factorize()
+    assert M.inertia() == (N, 0, 0)  # pivot_tol = 0: only an exact zero counts, as in LAPACK
+    M.close()
