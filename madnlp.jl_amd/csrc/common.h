@@ -85,10 +85,6 @@ struct mnk_ctx {
     // look-ahead of the factorization: panel stream (high priority), update stream, fork/join events
     hipStream_t sp = nullptr, su = nullptr;
     int panel_cus = 0;  // > 0: sp is restricted to this many CUs and su to the others (CU masks)
-    // second partition for very large systems (the trailing update dominates: fewer panel CUs)
-    hipStream_t sp_big = nullptr, su_big = nullptr;
-    int panel_cus_big = 0;
-    int panel_cus_big_want = 0;  // > 0: create sp_big/su_big with this many panel CUs when first needed
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_next, ev_next2, ev_bdone;
     int num_cu = 256;   // CUs this context may use (the whole device, or its partition)

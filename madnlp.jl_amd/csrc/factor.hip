@@ -551,9 +551,7 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         // Tiles per workgroup: few (little redundant diagonal work, short steps) when the whole chip
         // is available, many when the panel stream owns only `panel_cus` CUs (look-ahead): one
         // workgroup per CU, the extra rank-one work hides behind the next pivot's latency chain.
-        const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp)           ? ls->ctx->panel_cus
-                            : (ls->lookahead && ls->ctx->panel_cus_big > 0 && s == ls->ctx->sp_big) ? ls->ctx->panel_cus_big
-                                                                                                      : 512;
+        const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp) ? ls->ctx->panel_cus : 512;
         // tiles per workgroup (incl. the diagonal tile)
         int T = 2;
         while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
@@ -649,11 +647,10 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     } else {
         // look-ahead: panel stream sp (high priority) factors panel k+1 while the update
         // stream su applies panel k to the rest of the trailing matrix.
-        // the trailing update outweighs the panel chain above N ~ 24000 on 256 CUs; the crossover moves with sqrt(#CUs)
-        const bool want_big = (double)ls->N * ls->N >= 24000.0 * 24000.0 * ctx->num_cu / 256.0;
-        if (want_big) (void)mnk_ctx_ensure_big_pair(ctx);
-        const bool big = want_big && ctx->sp_big != nullptr;
-        hipStream_t sp = big ? ctx->sp_big : ctx->sp, su = big ? ctx->su_big : ctx->su;
+        // One CU partition for every size: a quarter of the CUs for the panel stream.  (A second pair with an
+        // eighth, for "update-bound" sizes, measured slower at every N once the panel stream's CUs join the
+        // trailing update: N = 30 000 156 vs 178 ms, N = 11 192 +0.5 ms per step taken on it.)
+        hipStream_t sp = ctx->sp, su = ctx->su;
         if ((int64_t)ctx->ev_panel.size() < npanel + 1) {
             const size_t old = ctx->ev_panel.size();
             ctx->ev_panel.resize(npanel + 1);
@@ -671,7 +668,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
         // idle once panel k+1 is factored; (b) is then launched as a tile queue on both streams
         // (update stream right after (a), panel stream after the panel) and the two launches drain
         // one counter.  Estimated leg lengths only decide whether the second launch is worth it.
-        const int pcus = big ? ctx->panel_cus_big : ctx->panel_cus;
+        const int pcus = ctx->panel_cus;
         const int ucus = pcus > 0 ? ctx->num_cu - pcus : ctx->num_cu;
         const bool share = ls->share != 0;
         if (share) {
@@ -753,7 +750,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                                         ls->info_dev.p);
                 if (rc) return rc;
             }
-            if (own_first) MNK_HIP(hipEventRecord(ctx->ev_bdone[k], su));
+            MNK_HIP(hipEventRecord(ctx->ev_bdone[k], su));
             // panel k+1 on the panel stream, as soon as (a) is done
             if (!own_first) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_next[k], 0));
             rc = factor_outer_panel(ls, sp, kend, kend + nnext, ls->wbuf[(k + 1) & 1].p,

@@ -62,7 +62,6 @@ struct mnk_ls {
     int64_t npos = 0, nzero = 0, nneg = 0;
 };
 
-extern "C" int mnk_ctx_ensure_big_pair(mnk_ctx* c);
 int64_t mnk_ls_effective_nbo(const mnk_ls* ls);
 int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_fetch_info(mnk_ls* ls);

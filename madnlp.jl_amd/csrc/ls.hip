@@ -138,16 +138,13 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
         su = nullptr;
         return false;
     };
-    // default partitions (measured, profiles/): a quarter of the CUs for the panel stream while the panel
-    // chain is the bottleneck (N ~ 1e4), an eighth once the trailing update dominates (N >~ 3e4);
-    // MNK_PANEL_CUS forces one value.
+    // default partition (measured, profiles/): a quarter of the CUs for the panel stream; MNK_PANEL_CUS overrides.
     if (const char* e = getenv("MNK_PANEL_CUS")) {
         const int want = atoi(e);
         if (make_pair(want, c->sp, c->su)) c->panel_cus = want;
     } else if (c->num_cu >= 16) {
-        const int q4 = std::max(4, c->num_cu / 4), q8 = std::max(4, c->num_cu / 8);
+        const int q4 = std::max(4, c->num_cu / 4);
         if (make_pair(q4, c->sp, c->su)) c->panel_cus = q4;
-        c->panel_cus_big_want = q8;  // second pair is created on first use (every masked stream is a hardware queue)
     }
     if (!c->sp) {
         int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
@@ -158,23 +155,6 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
     MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
     *out = c;
-    return 0;
-}
-
-// second look-ahead pair (fewer panel CUs, for systems whose trailing update dominates), created on first use
-int mnk_ctx_ensure_big_pair(mnk_ctx* c) {
-    if (c->sp_big != nullptr || c->panel_cus_big_want <= 0 || c->panel_cus <= 0) return 0;
-    const int want = c->panel_cus_big_want;
-    c->panel_cus_big_want = 0;
-    std::vector<int> bits;
-    for (int b = 0; b < c->num_cu; ++b) bits.push_back(c->cu_first + b);
-    if (make_masked_stream(c->total_cu, bits.data(), want, c->sp_big) &&
-        make_masked_stream(c->total_cu, bits.data() + want, c->num_cu - want, c->su_big)) {
-        c->panel_cus_big = want;
-    } else {
-        if (c->sp_big) { (void)hipStreamDestroy(c->sp_big); c->sp_big = nullptr; }
-        c->su_big = nullptr;
-    }
     return 0;
 }
 
@@ -191,8 +171,6 @@ int mnk_ctx_destroy(mnk_ctx* c) {
     for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
-    if (c->sp_big) (void)hipStreamDestroy(c->sp_big);
-    if (c->su_big) (void)hipStreamDestroy(c->su_big);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
