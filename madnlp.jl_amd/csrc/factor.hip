@@ -518,13 +518,18 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
-    constexpr int64_t NBM = 256;  // middle level: left-looking inside 256 columns, right-looking between them
+    // Middle level: right-looking between NBM-column middle panels, left-looking inside one.  64 (= the inner
+    // block: purely right-looking inside the outer panel, no skinny left-looking products) measured best for
+    // N <= 6k (N = 1024 -27 %, 2048 -19 %, 4096 -8 % vs 256) and equal at N >= 11k; MNK_NBM overrides.
+    static const int64_t NBM = getenv("MNK_NBM") ? std::max<int64_t>(64, atol(getenv("MNK_NBM")) / 64 * 64) : 64;
     for (int64_t j = ko; j < kend; j += NBI) {
-        const int64_t mo = ko + ((j - ko) / NBM) * NBM;  // start of the 256-column middle panel of block j
+        // the first kernel that touches columns the caller delivers late: the first middle-level update (it spans
+        // all remaining columns of the panel) or the left-looking update of block column `rest_from`
+        if (rest_ready != nullptr && j == ko + std::min<int64_t>(rest_from, NBM)) MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
+        const int64_t mo = ko + ((j - ko) / NBM) * NBM;  // start of the middle panel of block j
         // middle level, right-looking: when a 256-column middle panel is complete, apply it to the
         // remaining columns of the outer panel with one K = 256 product (MFMA tiles, lower part)
         if (j == mo && j > ko) {
-            if (rest_ready != nullptr && rest_from == NBM && j == ko + NBM) MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
             const int64_t pm = mo - NBM;  // the middle panel just finished: columns [pm, mo)
             const double* Wp = ldl ? wbase + mo + (pm - ko) * ls->ldw : F + mo + pm * ld;
             int rc;
@@ -538,7 +543,6 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         }
         // inner level, left-looking inside the middle panel: bring block column j up to date with the
         // blocks [mo, j) already factored (one K = j-mo product on 64 columns)
-        if (rest_ready != nullptr && rest_from == NBI && j == ko + NBI) MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
         if (j > mo) {
             const double* Wp = ldl ? wbase + j + (mo - ko) * ls->ldw : F + j + mo * ld;
             int rc = launch_gemm_nt(s, 0, Np - j, NBI, j - mo, Wp, ldl ? ls->ldw : ld, F + j + mo * ld, ld,

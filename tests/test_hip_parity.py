@@ -715,7 +715,7 @@ def test_device_solve_kkt_and_mul_match_oracle(ctx, case, du):
     """`mnk_sc_solve_kkt` / `mnk_sc_mul` (the whole primal-dual vector stays on the device) against the CPU
     restatement of `solve_kkt!` / `mul!` (reference src/IPM/factorization.jl:143-167,289-308) on the same
     IPM-like diagonals and random vectors.  mul!: elementwise relative 1e-12 (same sums, different order);
-    solve_kkt!: the two solutions agree through the KKT residual and to 1e-8 relative (cond-dependent)."""
+    solve_kkt!: the two solutions agree through the KKT residual and to 1e-6 relative (cond-dependent)."""
     P = opf_shaped(case, du=du)
     ko, kh = _oracle_sc(P), _hip_sc(P, ctx)
     for k in (ko, kh):
@@ -746,7 +746,9 @@ def test_device_solve_kkt_and_mul_match_oracle(ctx, case, du):
     bo.values[:] = bv; bh.values[:] = bv
     ko.solve_kkt(bo)
     kh.solve_kkt_device(bh)
-    assert np.abs(bh.values - bo.values).max() <= 1e-8 * np.abs(bo.values).max()
+    # forward agreement is condition-dependent (Sigma_s spans 16 decades; two different factorizations):
+    # 1e-6 relative here, the sharp statement is the residual below
+    assert np.abs(bh.values - bo.values).max() <= 1e-6 * np.abs(bo.values).max()
     # residual of the device solution through the oracle's mul!: K x = b
     r = okern.UnreducedKKTVector.from_kkt(ko); r.values[:] = 0.0
     xs = okern.UnreducedKKTVector.from_kkt(ko); xs.values[:] = bh.values
