@@ -47,9 +47,9 @@ struct mnk_ls {
     int small_tiles = 400;  // (a)-updates with fewer 128x128 tiles than this use 64x64 workgroup tiles
     int split_a = 2;          // 1: next panel delivered in two pieces by the update stream; 2: its first 64 columns by the panel stream itself
     int64_t single_rows = 4608;  // systems up to this (padded) order are factored as ONE outer panel on the whole chip
-    int64_t tail_rows = 3584;  // > 0: outer panels are tail_nbo wide once this many rows (or fewer) remain (0: never)
+    int64_t tail_rows = 0;    // > 0: outer panels are tail_nbo wide once this many rows (or fewer) remain (no gain since the inner level is right-looking)
     int64_t tail_nbo = 256;
-    int small_tiles_mid = 400;  // same for the middle-level update inside an outer panel
+    int small_tiles_mid = 1000;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, linv256, linv256t, dvec, dinv, xwork;
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
