@@ -21,109 +21,95 @@ constexpr int SB = 256;
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 // ---- explicit inverse of every 256x256 diagonal triangle (unit diagonal for LDL) ----------------
-// One workgroup per (diagonal block, 64-column block q of the inverse):
 //   X_qq = inv(L_qq);  X_bq = -inv(L_bb) * sum_{q<=b'<b} L_{b,b'} X_{b'q}   for b = q+1..nb-1
-// 64x64x64 products with both operands staged in LDS, 4x4 outputs per thread.
-// Writes Inv (column-major, ld 256) and its transpose (for the backward sweep).
-__device__ __forceinline__ void mm64_acc(const double* As, const double* Bs, double (&c)[4][4], int ty, int tx) {
-    // c[i][j] += sum_k A[4ty+i][k] * B[k][4tx+j];  As[k*64 + r] = A[r][k] ; Bs[j*64 + k] = B[k][j]
-#pragma unroll 4
+// 64x64x16 products with both operands staged in LDS.  Writes Inv (column-major, ld 256) and its
+// transpose (for the backward sweep).
+// c[i] += sum_k A[4ty+i][k] * B[k][tx]  (64 x 16 output slice);  As[k*64 + r] = A[r][k] ; Bs[j*64 + k] = B[k][j]
+__device__ __forceinline__ void mm64x16_acc(const double* As, const double* Bs, double (&c)[4], int ty, int tx) {
+#pragma unroll 8
     for (int k = 0; k < 64; ++k) {
-        double a[4], b[4];
+        const double b = Bs[tx * 64 + k];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = As[k * 64 + 4 * ty + i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = Bs[(4 * tx + j) * 64 + k];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[i][j] = fma(a[i], b[j], c[i][j]);
+        for (int i = 0; i < 4; ++i) c[i] = fma(As[k * 64 + 4 * ty + i], b, c[i]);
     }
 }
 
+// One workgroup per (diagonal 256-block, 64-column block q of its inverse, 16-column slice cs of that block): the
+// columns of an inverse are independent, so 16 workgroups share one 256x256 triangle (102 -> ~30 us critical path).
 __global__ __launch_bounds__(256) void linv256_kernel(const double* __restrict__ F, int64_t ld,
                                                       const double* __restrict__ Linv64, double* __restrict__ Inv,
                                                       double* __restrict__ InvT, int64_t Np,
                                                       const int* __restrict__ info) {
     __shared__ double As[64 * 64];
-    __shared__ double Bs[64 * 64];
+    __shared__ double Bs[16 * 64];
     if (*info != 0) return;
     const int64_t blk = blockIdx.x;      // 256-block
     const int q = blockIdx.y;            // column block of the inverse
+    const int cs = blockIdx.z;           // 16-column slice of that block
     const int64_t j0 = blk * SB;
     const int nb = (int)((Np - j0 < SB ? Np - j0 : SB) / 64);
     double* out = Inv + blk * (int64_t)(SB * SB);
     double* outT = InvT + blk * (int64_t)(SB * SB);
     const int t = threadIdx.x, ty = t & 15, tx = t >> 4;
-    // zero the part of column block q above the diagonal block (rows of earlier blocks)
-    for (int e = t; e < 64 * 64 * q; e += 256) {
-        const int r = e % (64 * q), c = e / (64 * q);
-        out[r + (int64_t)(64 * q + c) * SB] = 0.0;
-        outT[(64 * q + c) + (int64_t)r * SB] = 0.0;
+    const int col = 64 * q + 16 * cs + tx;  // this thread's column of the inverse
+    // zero the part of the slice above the diagonal block (rows of earlier blocks)
+    for (int e = t; e < 64 * q * 16; e += 256) {
+        const int r = e % (64 * q), c = 64 * q + 16 * cs + e / (64 * q);
+        out[r + (int64_t)c * SB] = 0.0;
+        outT[c + (int64_t)r * SB] = 0.0;
     }
-    if (q >= nb) {  // padding block of a short last step: identity-free zeros
-        for (int e = t; e < 64 * SB; e += 256) {
-            const int r = e % SB, c = e / SB;
-            out[r + (int64_t)(64 * q + c) * SB] = 0.0;
-            outT[(64 * q + c) + (int64_t)r * SB] = 0.0;
+    if (q >= nb) {  // padding block of a short last step: zeros
+        for (int e = t; e < 16 * SB; e += 256) {
+            const int r = e % SB, c = 64 * q + 16 * cs + e / SB;
+            out[r + (int64_t)c * SB] = 0.0;
+            outT[c + (int64_t)r * SB] = 0.0;
         }
         return;
     }
     for (int b = q; b < 4; ++b) {
-        double c[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[i][j] = 0.0;
+        double c[4] = {0.0, 0.0, 0.0, 0.0};
         if (b < nb) {
             if (b == q) {
                 // X_qq = inv(L_qq): straight copy
                 const double* Li = Linv64 + ((j0 >> 6) + q) * 4096;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) c[i][j] = Li[(4 * ty + i) + 64 * (4 * tx + j)];
+                for (int i = 0; i < 4; ++i) c[i] = Li[(4 * ty + i) + 64 * (16 * cs + tx)];
             } else {
-                // S = sum_{b'} L_{b,b'} X_{b',q}
+                // S = sum_{b'} L_{b,b'} X_{b',q}   (this slice's 16 columns)
                 for (int bp = q; bp < b; ++bp) {
                     __syncthreads();
                     for (int e = t; e < 4096; e += 256) {
                         const int r = e & 63, k = e >> 6;
-                        As[k * 64 + r] = F[(j0 + 64 * b + r) + (j0 + 64 * bp + k) * ld];   // L_{b,bp}[r][k]
-                        Bs[k * 64 + r] = out[(64 * bp + r) + (int64_t)(64 * q + k) * SB];     // X_{bp,q}[r][k] -> Bs[j*64+k]
+                        As[k * 64 + r] = F[(j0 + 64 * b + r) + (j0 + 64 * bp + k) * ld];  // L_{b,bp}[r][k]
+                    }
+                    for (int e = t; e < 1024; e += 256) {
+                        const int k = e & 63, j = e >> 6;
+                        Bs[j * 64 + k] = out[(64 * bp + k) + (int64_t)(64 * q + 16 * cs + j) * SB];  // X_{bp,q}[k][j]
                     }
                     __syncthreads();
-                    mm64_acc(As, Bs, c, ty, tx);
+                    mm64x16_acc(As, Bs, c, ty, tx);
                 }
                 // X_bq = -inv(L_bb) * S : stage S (as B operand) and inv(L_bb) (as A operand)
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Bs[(4 * tx + j) * 64 + 4 * ty + i] = c[i][j];
+                for (int i = 0; i < 4; ++i) Bs[tx * 64 + 4 * ty + i] = c[i];
                 const double* Li = Linv64 + ((j0 >> 6) + b) * 4096;
                 for (int e = t; e < 4096; e += 256) As[e] = Li[e];  // As[k*64+r] = inv(L_bb)[r][k]
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) c[i] = 0.0;
+                mm64x16_acc(As, Bs, c, ty, tx);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) c[i][j] = 0.0;
-                mm64_acc(As, Bs, c, ty, tx);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) c[i][j] = -c[i][j];
+                for (int i = 0; i < 4; ++i) c[i] = -c[i];
             }
         }
-        // store block (b, q) and its transpose (zeros for the padding rows of a short last step)
+        // store the slice of block (b, q) and its transpose (zeros for the padding rows of a short last step)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 64 * b + 4 * ty + i, cc = 64 * q + 4 * tx + j;
-                out[r + (int64_t)cc * SB] = c[i][j];
-                outT[cc + (int64_t)r * SB] = c[i][j];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int r = 64 * b + 4 * ty + i;
+            out[r + (int64_t)col * SB] = c[i];
+            outT[col + (int64_t)r * SB] = c[i];
+        }
         __threadfence_block();
         __syncthreads();
     }
@@ -531,7 +517,7 @@ using namespace mnk;
 // called at the end of the factorization (after linv64_kernel)
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s) {
     const int64_t nblk = (ls->Np + SB - 1) / SB;
-    hipLaunchKernelGGL(linv256_kernel, dim3((unsigned)nblk, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->linv.p,
+    hipLaunchKernelGGL(linv256_kernel, dim3((unsigned)nblk, 4, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->linv.p,
                        ls->linv256.p, ls->linv256t.p, ls->Np, ls->info_dev.p);
     MNK_HIP(hipGetLastError());
     return 0;
