@@ -53,7 +53,7 @@ struct mnk_ls {
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, linv256, linv256t, dvec, dinv, xwork;
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
-    mnk::DevBuf<int> solve_abort;
+    int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
     mnk::DevBuf<unsigned long long> solve_trace;  // diagnostics: 8 time stamps per 64-row block (option solve_trace)
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;

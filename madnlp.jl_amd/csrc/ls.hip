@@ -216,7 +216,13 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     rc |= ls->dvec.alloc(ls->Np);
     rc |= ls->dinv.alloc(ls->Np);
     rc |= ls->xwork.alloc(6 * ls->Np);
-    rc |= ls->solve_abort.alloc(1);
+    if (hipHostMalloc((void**)&ls->solve_abort, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        ls->solve_abort = nullptr;
+        rc |= -2;
+    } else {
+        *ls->solve_abort = 0;
+    }
     rc |= ls->info_dev.alloc(1);
     rc |= ls->inertia_dev.alloc(3);
     if (rc) { delete ls; return -2; }
@@ -229,6 +235,7 @@ int mnk_ls_destroy(mnk_ls* ls) {
     if (!ls) return 0;
     (void)hipSetDevice(ls->ctx->device);
     (void)hipStreamSynchronize(ls->ctx->stream);
+    if (ls->solve_abort) (void)hipHostFree(ls->solve_abort);
     delete ls;
     return 0;
 }
@@ -406,6 +413,16 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
     MNK_REQUIRE(ls->factorized, "mnk_ls_solve: factorize first");
     MNK_REQUIRE(nrhs >= 1 && ldx >= ls->N, "mnk_ls_solve: bad nrhs/ldx");
     MNK_HIP(hipSetDevice(ls->ctx->device));
+    if (ls->solve_abort && *ls->solve_abort != 0) {
+        // a previous solve on device-resident vectors gave up (its result is invalid): fail loudly now and use
+        // the stepwise solve from here on
+        *ls->solve_abort = 0;
+        ls->persistent_solve = 0;
+        set_error("mnk_ls_solve: an earlier persistent solve on device-resident data gave up waiting for a peer "
+                  "workgroup (device oversubscribed by another process?); its result is invalid -- refactorize/solve "
+                  "again (persistent_solve is now off for this solver)");
+        return -3;
+    }
     hipStream_t s = ls->ctx->stream;
     const int64_t N = ls->N, Np = ls->Np;
     double* w = ls->xwork.p;
@@ -423,10 +440,9 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
             // The one-launch solve gives up (instead of hanging the device) if its workgroups cannot all become
             // resident, e.g. another process saturates the GPU with its own persistent kernels.  The host still
             // owns the right-hand side here: redo this and all later solves with one launch per step.
-            int aborted = 0;
-            MNK_HIP(hipMemcpyAsync(&aborted, ls->solve_abort.p, sizeof(int), hipMemcpyDeviceToHost, s));
             MNK_HIP(hipStreamSynchronize(s));
-            if (aborted) {
+            if (*ls->solve_abort != 0) {
+                *ls->solve_abort = 0;
                 ls->persistent_solve = 0;
                 MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
                 MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));

@@ -275,10 +275,11 @@ __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst,
     return __syncthreads_or(bad) == 0;
 }
 
-__global__ void ps_reset_kernel(unsigned long long* pub, int64_t n, int* abort_flag) {
+// (the abort word is cleared by the host only, after it has dealt with an abort: a solve that follows an
+// aborted one on the same stream must not hide it)
+__global__ void ps_reset_kernel(unsigned long long* pub, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) pub[i] = ~0ull;
-    if (i == 0) *abort_flag = 0;
 }
 
 constexpr int PS_NT = 1024;          // threads per workgroup: a 64 x 256 slice is 16 values per thread
@@ -542,14 +543,14 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
         else MNK_HIP(hipStreamWaitEvent(s, last, 0));
         double* pub = xdev + 2 * Np;
         hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<unsigned long long*>(pub), 4 * Np, ls->solve_abort.p);
+                           reinterpret_cast<unsigned long long*>(pub), 4 * Np);
         if (ldl)
             hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv256.p,
-                               ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort.p, ls->info_dev.p,
+                               ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p,
                                ls->solve_trace.p);
         else
             hipLaunchKernelGGL(persistent_solve_kernel<false>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld,
-                               ls->linv256.p, ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort.p,
+                               ls->linv256.p, ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort,
                                ls->info_dev.p, ls->solve_trace.p);
         MNK_HIP(hipGetLastError());
         MNK_HIP(hipEventRecord(last, s));
