@@ -74,7 +74,10 @@ __device__ __forceinline__ void gemm_nt_tile(
     const int64_t row0 = (int64_t)tm * BM;
     const int64_t col0 = (int64_t)tn * BN;
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    // Opaque to the optimizer: inside the work-queue loop everything derived from the thread id would be
+    // hoisted out of the loop and then spilled (168-VGPR budget); recomputing it per tile costs a few VALU ops.
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
