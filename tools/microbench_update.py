@@ -26,7 +26,7 @@ with torch.cuda.stream(s):
              "static/su, register staging instead of LDS-DMA", "static/ctx, register staging instead of LDS-DMA",
              "static/su, BK=16 and 2 workgroups per CU", "static/ctx, BK=16 and 2 workgroups per CU"]
     ntiles = (M // 128) * (M // 128 + 1) // 2
-    for v in [0, 2, 0, 2, 3, 4, 1, 0, 2, 3]:
+    for v in [0, 2, 0, 1, 2, 3, 4, 9, 10, 11, 12, 13, 15]:
         for it in range(2):
             ms = C.c_double()
             L.check(L.lib().mnk_debug_update(ctx.handle, v, M, K, A.data_ptr(), M, Cm.data_ptr(), C2.data_ptr(), M, reps,
