@@ -247,7 +247,7 @@ __device__ __forceinline__ void ps_publish(double* p, double v) {
 // ~170 workgroups that merely follow the front do not hammer the 16 cache lines the front is
 // publishing into (their polls queue in front of the critical stores and loads on the same channel).
 __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst, int* abort_flag,
-                                          bool relaxed = false) {
+                                          bool relaxed = false, int nap = 6) {
     const int t = threadIdx.x;
     int bad = 0;
     if (t < n) {
@@ -257,7 +257,7 @@ __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst,
         while (u == ~0ull) {
             // back off: short naps while the value is probably about to land, long ones for the
             // workgroups that wait for a distant step (keeps their polling off the memory fabric)
-            if (relaxed) __builtin_amdgcn_s_sleep(48);
+            if (relaxed) { for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(8); }
             else if (spins < 256) __builtin_amdgcn_s_sleep(1);
             else __builtin_amdgcn_s_sleep(24);
             if ((++spins & 1023) == 0) {
@@ -291,7 +291,8 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv, const double* __restrict__ InvT,
     const double* __restrict__ dinv, double* __restrict__ xio /* Np: rhs in, solution out */,
     double* __restrict__ pub /* 4*Np sentinel-filled: bfin | y | zfin | x */, int64_t Np, int* abort_flag,
-    const int* __restrict__ info, unsigned long long* __restrict__ trace /* optional: 8 stamps per block */) {
+    const int* __restrict__ info, unsigned long long* __restrict__ trace /* optional: 8 stamps per block */,
+    int near_steps, int nap) {
 #define PS_STAMP(blk, slot) do { if (trace != nullptr && t == 0) trace[(int64_t)(blk) * 8 + (slot)] = wall_clock64(); } while (0)
     __shared__ double run[PS_MAXOWN][64];   // running rhs of the owned blocks (forward: b, backward: z)
     __shared__ double ysol[PS_MAXOWN][64];  // forward solution of the owned blocks
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
             }
         }
         if (diag_next) PS_STAMP(i, 0);
-        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i >= b0 + nbk + 4 * PS_NEAR)) return;
+        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i >= b0 + nbk + 4 * near_steps, nap)) return;
         if (diag_next) PS_STAMP(i, 1);
         for (int m = m0; m < nown; ++m) {
             const int im = g + m * G;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
                 for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
             }
         }
-        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i < b0 - 4 * PS_NEAR)) return;
+        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i < b0 - 4 * near_steps, nap)) return;
         for (int m = m1; m >= 0; --m) {
             const int im = g + m * G;
             if (m < m1 && rc < nbk) load_slice(im);
@@ -541,17 +542,19 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
         hipEvent_t& last = ps_last[ls->ctx->device & 63];
         if (last == nullptr) MNK_HIP(hipEventCreateWithFlags(&last, hipEventDisableTiming));
         else MNK_HIP(hipStreamWaitEvent(s, last, 0));
+        static const int ps_near = getenv("MNK_PS_NEAR") ? atoi(getenv("MNK_PS_NEAR")) : PS_NEAR;
+        static const int ps_nap = getenv("MNK_PS_NAP") ? atoi(getenv("MNK_PS_NAP")) : 6;
         double* pub = xdev + 2 * Np;
         hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<unsigned long long*>(pub), 4 * Np);
         if (ldl)
             hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv256.p,
                                ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p,
-                               ls->solve_trace.p);
+                               ls->solve_trace.p, ps_near, ps_nap);
         else
             hipLaunchKernelGGL(persistent_solve_kernel<false>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld,
                                ls->linv256.p, ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort,
-                               ls->info_dev.p, ls->solve_trace.p);
+                               ls->info_dev.p, ls->solve_trace.p, ps_near, ps_nap);
         MNK_HIP(hipGetLastError());
         MNK_HIP(hipEventRecord(last, s));
         return 0;
