@@ -365,7 +365,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
                 ysol[m0][t] = v;
             }
             PS_STAMP(i, 4);
-            __syncthreads();
+            // (no trailing barrier: the next touch of xs / part comes behind the barrier of the next gather)
             have_d = false;
             ++m0;
             if (m0 >= nown) break;
@@ -408,12 +408,14 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
                 if (m == m0 && diag_next) ps_publish(bfin + (int64_t)im * 64 + t, v);  // final: hand it on at once
             }
             if (m == m0 && diag_next) PS_STAMP(im, 2);
-            __syncthreads();
+            if (m + 1 < nown) __syncthreads();  // part is rewritten by the next owned block; after the last one the
+                                                // next gather's barrier does it
         }
         have_d = diag_next;
     }
 
     // ------------------------------------------------------------------ backward: L^T x = D^-1 y
+    __syncthreads();  // ysol of the last diagonal role is read by other threads below
     for (int e = t; e < nown * 64; e += PS_NT) {
         const int m = e >> 6, c = e & 63;
         const double y = ysol[m][c];
@@ -450,7 +452,6 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
                 ps_publish(xpub + (int64_t)i * 64 + t, v);
                 xio[(int64_t)i * 64 + t] = v;
             }
-            __syncthreads();
             have_d = false;
             --m1;
             if (m1 < 0) break;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
                 run[m][t] = v;
                 if (m == m1 && diag_next) ps_publish(zfin + (int64_t)im * 64 + t, v);
             }
-            __syncthreads();
+            if (m > 0) __syncthreads();
         }
         have_d = diag_next;
     }
