@@ -36,3 +36,33 @@ def test_single_rank_no_process_group():
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["metric"].startswith("IP iterations/sec")
+
+
+def test_self_spawn_without_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment starts its own two ranks
+    (the command the driver would issue must not exit with "launch with torch.distributed.run")
+    and defaults to BASELINE config C5's 16 instances per GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-dry-run", "--steps", "3",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["batch_per_gpu"] == 16
+    assert out["per_rank_ms"] == [[1.0, 2.0, 3.0], [2.0, 3.0, 4.0]]
+
+
+def test_batch_defaults():
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        assert bench.parse_args().batch == 1
+        sys.argv = ["bench.py", "--gpus", "8"]
+        assert bench.parse_args().batch == 16
+        sys.argv = ["bench.py", "--gpus", "8", "--batch", "4"]
+        assert bench.parse_args().batch == 4
+    finally:
+        sys.argv = old
