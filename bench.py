@@ -56,7 +56,7 @@ def parse_args():
                     help="contexts (stream sets) the batch is spread over; more than ~4 oversubscribes the "
                          "hardware queues (measured: 16 contexts run 2.6x slower than 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-budget", type=float, default=75.0,
+    ap.add_argument("--cpu-baseline-budget", type=float, default=100.0,
                     help="seconds of host time the cpu_baseline leg may spend (it drops the slowest legs first)")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="test-only: exercise the multi-process harness on CPU (gloo) without any kernel")
@@ -149,7 +149,7 @@ def _host_threads():
     return int(phys), int(logical)
 
 
-def cpu_baseline(P, algorithm, nsolve, budget_s=60.0):
+def cpu_baseline(P, algorithm, nsolve, budget_s=100.0):
     """The oracle (CPU restatement: numpy assembly + CSC->dense `transfer_matrix!` + OpenBLAS LAPACK
     dsytrf/dsytrs | dpotrf/dpotrs through scipy -- the routine family MadNLP's LapackCPUSolver calls,
     reference src/LinearSolvers/lapack.jl:145-172) timed on this host's cores on a BOUNDED sample of the
@@ -204,20 +204,21 @@ def cpu_baseline(P, algorithm, nsolve, budget_s=60.0):
                 "blas_threads": int(threads), "ms_per_factorize": 1e3 * tf, "ms_per_solve": 1e3 * ts,
                 "it_per_s": 1.0 / total, "gflops_factorize": P.n ** 3 / 3.0 / tf / 1e9}
 
-    # most informative legs first; the 1-thread legs cost ~10-20 s each at N = 11192
-    plan = [(main_alg, phys), (main_alg, max(1, phys // 2)), (main_alg, 1),
-            (other_alg, phys), (other_alg, max(1, phys // 2)), (other_alg, 1)]
+    # Most informative legs first.  Measured on the MI355X host (2 x 64 cores): OpenBLAS dsytrf does not scale
+    # with threads (its panel factorization dlasyf is level-2 bound: ~37 GFLOP/s at 64 or 128 threads, 12.5 s at
+    # N = 11192) while dpotrf does (385 GFLOP/s, 1.2 s), so a small thread count is tried as well.
+    few = max(2, min(16, phys // 2))
+    plan = [(main_alg, 1), (main_alg, few), (main_alg, phys), (other_alg, phys), (other_alg, 1),
+            (main_alg, max(1, phys // 2)), (other_alg, max(1, phys // 2)), (other_alg, few)]
     runs, skipped, seen = [], [], set()
     for alg, thr in plan:
         if (alg, thr) in seen:
             continue
         seen.add((alg, thr))
-        # predicted cost of a 1-thread leg from the multi-thread legs already run (assume <= 0.7 x linear speed-up)
-        est = 0.0
-        prev = [r for r in runs if r["algorithm"] == alg]
-        if prev:
-            est = 1e-3 * prev[0]["ms_per_factorize"] * max(1.0, 0.5 * prev[0]["blas_threads"] / thr)
-        if time.perf_counter() - t_start + est > budget_s and runs:
+        # predicted cost of this leg: the slowest run of the same algorithm so far (1-thread legs: 40 s if unknown)
+        prev = [r["ms_per_factorize"] for r in runs if r["algorithm"] == alg]
+        est = 1e-3 * max(prev) if prev else (40.0 if thr == 1 else 15.0)
+        if runs and time.perf_counter() - t_start + est > budget_s:
             skipped.append({"algorithm": alg, "blas_threads": int(thr), "reason": "cpu-baseline time budget"})
             continue
         runs.append(one(alg, thr))

@@ -175,6 +175,13 @@ int mnk_ls_inertia(mnk_ls* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num
  * nrhs right-hand sides with leading dimension ldx (the reference loops over
  * columns, `src/LinearSolvers/linearsolvers.jl:102-110`). */
 int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc);
+/* Status of the solves enqueued so far, for callers whose vectors live on the device (loc = MNK_DEVICE):
+ * synchronizes the context stream; 0 if every solve completed, -3 if a one-launch ("persistent") solve gave
+ * up waiting for a peer workgroup -- its result is invalid, the solver has switched to the stepwise solve and
+ * the caller repeats the solve.  Host-resident callers never need it: mnk_ls_solve / mnk_*_solve_kkt with
+ * loc = MNK_HOST detect the condition before copying anything back and redo the solve themselves.
+ * (SolveException of the contract, reference src/LinearSolvers/linearsolvers.jl:133-137.) */
+int mnk_ls_check_solve(mnk_ls* ls);
 /* Debug / tests: copy the factor (N x N, ld = N; L in the lower triangle, for
  * LDL unit-lower L with D returned separately) and D (N entries, may be NULL). */
 int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc);

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
 SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip"]
-HEADERS = ["common.h", "ls.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
+HEADERS = ["common.h", "ls.h", "kkt_vec.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
 
 MNK_HOST, MNK_DEVICE = 0, 1
 MNK_BUNCHKAUFMAN, MNK_LU, MNK_QR, MNK_CHOLESKY, MNK_LDL, MNK_EVD = 1, 2, 3, 4, 5, 6
@@ -91,6 +91,7 @@ SIGNATURES = {
     "mnk_ls_factorize_dc_async": (C.c_int, [_vp, _vp]),
     "mnk_ls_inertia": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
     "mnk_ls_solve": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int]),
+    "mnk_ls_check_solve": (C.c_int, [_vp]),
     "mnk_ls_get_factor": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mnk_sc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
     "mnk_sc_set_barrier_terms": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),

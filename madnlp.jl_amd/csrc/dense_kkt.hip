@@ -454,46 +454,51 @@ int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc) {
     hipStream_t s = dc->ctx->stream;
     const int64_t n = dc->n, ns = dc->ns, m = dc->m, n_eq = dc->n_eq, nlb = ex->nlb, nub = ex->nub;
     const int64_t lw = n + ns + m + nlb + nub;
-    double* d = w;
-    if (loc != MNK_DEVICE) {
-        d = ex->wdev.p;
-        MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
-    }
-    double *ws = d + n, *dual = d + n + ns, *wl = dual + m, *wu = wl + nlb;
-    if (nlb > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nlb), d, ex->ind_lb.p, wl, ex->l_diag.p, nlb);
-    if (nub > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nub), d, ex->ind_ub.p, wu, ex->u_diag.p, nub);
-    int rc = 0;
-    if (!dc->condensed) {
-        // reduced solve (reference src/IPM/factorization.jl:41-46): the solver acts on primal_dual(w) in place
-        rc = mnk_ls_solve(ls, d, 1, dc->order, MNK_DEVICE);
-        if (rc) return rc;
-    } else {
-        const double* Ss = dc->pr_diag.p + n;
-        if (m > 0) {
-            hipLaunchKernelGGL(dc_condense_rhs_kernel, MNK_GRID(m), ex->buffer.p, dual, ws, dc->diag_buffer.p, Ss,
-                               ex->ineq_slot.p, m);
-            hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, ex->pd.p, dc->jac.p, m,
-                               ex->buffer.p, m, n, 1.0, 0.0);  // xx = jac' * buffer
+    // see mnk_sc_solve_kkt: an aborted persistent solve is detected before the copy-back and redone stepwise
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        double* d = w;
+        if (loc != MNK_DEVICE) {
+            d = ex->wdev.p;
+            MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        double *ws = d + n, *dual = d + n + ns, *wl = dual + m, *wu = wl + nlb;
+        if (nlb > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nlb), d, ex->ind_lb.p, wl, ex->l_diag.p, nlb);
+        if (nub > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nub), d, ex->ind_ub.p, wu, ex->u_diag.p, nub);
+        int rc = 0;
+        if (!dc->condensed) {
+            // reduced solve (reference src/IPM/factorization.jl:41-46): the solver acts on primal_dual(w) in place
+            rc = mnk_ls_solve(ls, d, 1, dc->order, MNK_DEVICE);
+            if (rc) return rc;
         } else {
-            MNK_HIP(hipMemsetAsync(ex->pd.p, 0, n * sizeof(double), s));
+            const double* Ss = dc->pr_diag.p + n;
+            if (m > 0) {
+                hipLaunchKernelGGL(dc_condense_rhs_kernel, MNK_GRID(m), ex->buffer.p, dual, ws, dc->diag_buffer.p, Ss,
+                                   ex->ineq_slot.p, m);
+                hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, ex->pd.p, dc->jac.p, m,
+                                   ex->buffer.p, m, n, 1.0, 0.0);  // xx = jac' * buffer
+            } else {
+                MNK_HIP(hipMemsetAsync(ex->pd.p, 0, n * sizeof(double), s));
+            }
+            hipLaunchKernelGGL(dc_pack_kernel, MNK_GRID(n + n_eq), ex->pd.p, d, dual, dc->d_ind_eq.p, n, n_eq);
+            rc = mnk_ls_solve(ls, ex->pd.p, 1, dc->order, MNK_DEVICE);
+            if (rc) return rc;
+            MNK_HIP(hipMemcpyAsync(d, ex->pd.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));  // wx = xx
+            if (m > 0) {
+                hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, dual, dc->jac.p, m, d, m, n,
+                                   1.0, 0.0);  // dual(w) = jac * wx
+                hipLaunchKernelGGL(dc_expand_kernel, MNK_GRID(m), dual, ws, ex->buffer.p, dc->diag_buffer.p, Ss,
+                                   ex->ineq_slot.p, ex->eq_slot.p, ex->pd.p + n, m);
+            }
         }
-        hipLaunchKernelGGL(dc_pack_kernel, MNK_GRID(n + n_eq), ex->pd.p, d, dual, dc->d_ind_eq.p, n, n_eq);
-        rc = mnk_ls_solve(ls, ex->pd.p, 1, dc->order, MNK_DEVICE);
-        if (rc) return rc;
-        MNK_HIP(hipMemcpyAsync(d, ex->pd.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));  // wx = xx
-        if (m > 0) {
-            hipLaunchKernelGGL(gemv_n_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, dual, dc->jac.p, m, d, m, n,
-                               1.0, 0.0);  // dual(w) = jac * wx
-            hipLaunchKernelGGL(dc_expand_kernel, MNK_GRID(m), dual, ws, ex->buffer.p, dc->diag_buffer.p, Ss,
-                               ex->ineq_slot.p, ex->eq_slot.p, ex->pd.p + n, m);
-        }
-    }
-    if (nlb > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nlb), wl, d, ex->ind_lb.p, ex->l_lower.p, ex->l_diag.p, nlb, 0);
-    if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, ex->ind_ub.p, ex->u_lower.p, ex->u_diag.p, nub, 1);
-    MNK_HIP(hipGetLastError());
-    if (loc != MNK_DEVICE) {
+        if (nlb > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nlb), wl, d, ex->ind_lb.p, ex->l_lower.p, ex->l_diag.p, nlb, 0);
+        if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, ex->ind_ub.p, ex->u_lower.p, ex->u_diag.p, nub, 1);
+        MNK_HIP(hipGetLastError());
+        if (loc == MNK_DEVICE) break;
+        MNK_HIP(hipStreamSynchronize(s));
+        if (attempt == 0 && mnk_ls_take_solve_abort(ls)) continue;
         MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
         MNK_HIP(hipStreamSynchronize(s));
+        break;
     }
     return 0;
 }

@@ -54,6 +54,8 @@ struct mnk_ls {
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, linv256, linv256t, dvec, dinv, xwork;
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
+    long ps_spin_limit = 6000000;  // polls (~0.5 us each) a persistent-solve wait may take before it gives up
+    int debug_ps_missing = -1;     // tests only: this workgroup of the persistent solve leaves at once (a peer that never became resident)
     mnk::DevBuf<unsigned long long> solve_trace;  // diagnostics: 8 time stamps per 64-row block (option solve_trace)
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
@@ -67,3 +69,6 @@ int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s);
+// after a stream synchronization: true (and the solver switched to the stepwise solve, abort word cleared) if a
+// persistent solve gave up since the last check
+bool mnk_ls_take_solve_abort(mnk_ls* ls);

@@ -65,6 +65,13 @@ __global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restri
 
 using namespace mnk;
 
+bool mnk_ls_take_solve_abort(mnk_ls* ls) {
+    if (!ls->solve_abort || *ls->solve_abort == 0) return false;
+    *ls->solve_abort = 0;
+    ls->persistent_solve = 0;
+    return true;
+}
+
 extern "C" {
 
 int mnk_version(void) { return MNK_VERSION; }
@@ -263,6 +270,14 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
+    if (!strcmp(key, "ps_spin_limit")) {  // polls a persistent-solve wait may take before it gives up
+        MNK_REQUIRE(value >= 1024.0, "ps_spin_limit must be at least 1024");
+        ls->ps_spin_limit = (long)value;
+        return 0;
+    }
+    // tests only: workgroup `value` of every persistent solve leaves at once, as a peer that never became
+    // resident would (< 0: off); the others must give up after ps_spin_limit polls instead of hanging
+    if (!strcmp(key, "debug_ps_missing")) { ls->debug_ps_missing = (int)value; return 0; }
     if (!strcmp(key, "solve_trace")) {  // diagnostics: time stamps of the forward sweep's critical path
         if (value != 0.0) {
             int rc = ls->solve_trace.alloc((size_t)(ls->Np / 64) * 8);
@@ -408,6 +423,19 @@ int mnk_ls_inertia(mnk_ls* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num
     return 0;
 }
 
+int mnk_ls_check_solve(mnk_ls* ls) {
+    MNK_REQUIRE(ls, "mnk_ls_check_solve: NULL argument");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+    if (mnk_ls_take_solve_abort(ls)) {
+        set_error("mnk_ls_check_solve: a persistent solve on device-resident data gave up waiting for a peer workgroup "
+                  "(device oversubscribed by another process?); its result is invalid -- solve again "
+                  "(persistent_solve is now off for this solver)");
+        return -3;
+    }
+    return 0;
+}
+
 int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
     MNK_REQUIRE(ls && x, "mnk_ls_solve: NULL argument");
     MNK_REQUIRE(ls->factorized, "mnk_ls_solve: factorize first");
@@ -441,9 +469,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
             // resident, e.g. another process saturates the GPU with its own persistent kernels.  The host still
             // owns the right-hand side here: redo this and all later solves with one launch per step.
             MNK_HIP(hipStreamSynchronize(s));
-            if (*ls->solve_abort != 0) {
-                *ls->solve_abort = 0;
-                ls->persistent_solve = 0;
+            if (mnk_ls_take_solve_abort(ls)) {
                 MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
                 MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
                 rc = mnk_ls_run_solve(ls, w);

@@ -234,7 +234,6 @@ __global__ __launch_bounds__(256) void bwd_panel_kernel(const double* __restrict
 // reports a SolveException instead of hanging the device).
 // ================================================================================================
 constexpr int PS_MAXOWN = 12;            // owned blocks per workgroup: Np <= 12 * 64 * G
-constexpr long PS_SPIN_LIMIT = 6000000;  // polls (~0.5 us each) before giving up
 constexpr int PS_NEAR = 3;               // blocks within this many steps of the front poll eagerly
 
 __device__ __forceinline__ void ps_publish(double* p, double v) {
@@ -246,7 +245,7 @@ __device__ __forceinline__ void ps_publish(double* p, double v) {
 // `relaxed`: the caller is several steps away from the critical path -- nap between polls, so that the
 // ~170 workgroups that merely follow the front do not hammer the 16 cache lines the front is
 // publishing into (their polls queue in front of the critical stores and loads on the same channel).
-__device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst, int* abort_flag,
+__device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst, int* abort_flag, long spin_limit,
                                           bool relaxed = false, int nap = 6) {
     const int t = threadIdx.x;
     int bad = 0;
@@ -262,7 +261,7 @@ __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst,
             else __builtin_amdgcn_s_sleep(24);
             if ((++spins & 1023) == 0) {
                 if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
-                if (spins > PS_SPIN_LIMIT) {
+                if (spins > spin_limit) {
                     __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bad = 1;
                     break;
@@ -292,7 +291,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     const double* __restrict__ dinv, double* __restrict__ xio /* Np: rhs in, solution out */,
     double* __restrict__ pub /* 4*Np sentinel-filled: bfin | y | zfin | x */, int64_t Np, int* abort_flag,
     const int* __restrict__ info, unsigned long long* __restrict__ trace /* optional: 8 stamps per block */,
-    int near_steps, int nap) {
+    int near_steps, int nap, long spin_limit, int missing_wg) {
 #define PS_STAMP(blk, slot) do { if (trace != nullptr && t == 0) trace[(int64_t)(blk) * 8 + (slot)] = wall_clock64(); } while (0)
     __shared__ double run[PS_MAXOWN][64];   // running rhs of the owned blocks (forward: b, backward: z)
     __shared__ double ysol[PS_MAXOWN][64];  // forward solution of the owned blocks
@@ -305,6 +304,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     const int nsteps = (nb + 3) / 4;
     const int nown = g < nb ? (nb - g + G - 1) / G : 0;
     if (nown == 0) return;
+    if (g == missing_wg) return;  // tests: a peer that never became resident (everyone else must give up, not hang)
     double* bfin = pub;
     double* ypub = pub + Np;
     double* zfin = pub + 2 * Np;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
                 if (t < 64) ps_publish(bfin + (int64_t)i * 64 + t, run[m0][t]);
             }
             if (t < 64) xs[li * 64 + t] = run[m0][t];
-            if (!ps_gather(bfin + (int64_t)b0 * 64, li * 64, xs, abort_flag)) return;
+            if (!ps_gather(bfin + (int64_t)b0 * 64, li * 64, xs, abort_flag, spin_limit)) return;
             PS_STAMP(i, 3);
             dot_chunk(d, qb <= li);
             __syncthreads();
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
             }
         }
         if (diag_next) PS_STAMP(i, 0);
-        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i >= b0 + nbk + 4 * near_steps, nap)) return;
+        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, spin_limit, i >= b0 + nbk + 4 * near_steps, nap)) return;
         if (diag_next) PS_STAMP(i, 1);
         for (int m = m0; m < nown; ++m) {
             const int im = g + m * G;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
             }
             if (t < 64) xs[li * 64 + t] = run[m1][t];
             // blocks li+1 .. nbk-1 of the step come from their owners
-            if (!ps_gather(zfin + (int64_t)(i + 1) * 64, (nbk - 1 - li) * 64, xs + (li + 1) * 64, abort_flag)) return;
+            if (!ps_gather(zfin + (int64_t)(i + 1) * 64, (nbk - 1 - li) * 64, xs + (li + 1) * 64, abort_flag, spin_limit)) return;
             dot_chunk(d, act);
             __syncthreads();
             if (t < 64) {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
                 for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
             }
         }
-        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, i < b0 - 4 * near_steps, nap)) return;
+        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, spin_limit, i < b0 - 4 * near_steps, nap)) return;
         for (int m = m1; m >= 0; --m) {
             const int im = g + m * G;
             if (m < m1 && rc < nbk) load_slice(im);
@@ -551,11 +551,12 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
         if (ldl)
             hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv256.p,
                                ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p,
-                               ls->solve_trace.p, ps_near, ps_nap);
+                               ls->solve_trace.p, ps_near, ps_nap, ls->ps_spin_limit, ls->debug_ps_missing);
         else
             hipLaunchKernelGGL(persistent_solve_kernel<false>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld,
                                ls->linv256.p, ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort,
-                               ls->info_dev.p, ls->solve_trace.p, ps_near, ps_nap);
+                               ls->info_dev.p, ls->solve_trace.p, ps_near, ps_nap, ls->ps_spin_limit,
+                               ls->debug_ps_missing);
         MNK_HIP(hipGetLastError());
         MNK_HIP(hipEventRecord(last, s));
         return 0;

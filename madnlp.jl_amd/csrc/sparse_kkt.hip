@@ -548,33 +548,40 @@ int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc) {
                 "mnk_sc_solve_kkt: call mnk_sc_set_bounds / mnk_sc_set_barrier_terms / mnk_sc_build first");
     hipStream_t s = sc->ctx->stream;
     const int64_t n = sc->n, m = sc->m, nlb = sp->nlb, nub = sp->nub, lw = n + 2 * m + nlb + nub;
-    double* d = w;
-    if (loc != MNK_DEVICE) {
-        d = sp->wdev.p;
-        MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
-    }
-    double *ws = d + n, *wz = d + n + m, *wl = d + n + 2 * m, *wu = wl + nlb;
-    const double* Ss = sc->pr_diag.p + n;
-    if (nlb > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nlb), d, sp->ind_lb.p, wl, sp->l_diag.p, nlb);
-    if (nub > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nub), d, sp->ind_ub.p, wu, sp->u_diag.p, nub);
-    if (m > 0) {
-        hipLaunchKernelGGL(condense_rhs_kernel, MNK_GRID(m), sp->buffer.p, sc->diag_buffer.p, ws, wz, Ss, m);
-        int rc = mnk_sc_spmv(sc, MNK_SC_JT, 0, 1.0, sp->buffer.p, 1.0, d);  // wx += Jt * buffer
+    // Host-resident caller: the host still owns `w` until the final copy-back, so a persistent solve that gave
+    // up (abort word raised, solve.hip) is detected HERE, after the stream synchronization and before anything
+    // is copied back, and the whole solve_kkt! is redone once with the stepwise solve.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        double* d = w;
+        if (loc != MNK_DEVICE) {
+            d = sp->wdev.p;
+            MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        double *ws = d + n, *wz = d + n + m, *wl = d + n + 2 * m, *wu = wl + nlb;
+        const double* Ss = sc->pr_diag.p + n;
+        if (nlb > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nlb), d, sp->ind_lb.p, wl, sp->l_diag.p, nlb);
+        if (nub > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nub), d, sp->ind_ub.p, wu, sp->u_diag.p, nub);
+        if (m > 0) {
+            hipLaunchKernelGGL(condense_rhs_kernel, MNK_GRID(m), sp->buffer.p, sc->diag_buffer.p, ws, wz, Ss, m);
+            int rc = mnk_sc_spmv(sc, MNK_SC_JT, 0, 1.0, sp->buffer.p, 1.0, d);  // wx += Jt * buffer
+            if (rc) return rc;
+        }
+        int rc = mnk_ls_solve(ls, d, 1, n, MNK_DEVICE);
         if (rc) return rc;
-    }
-    int rc = mnk_ls_solve(ls, d, 1, n, MNK_DEVICE);
-    if (rc) return rc;
-    if (m > 0) {
-        rc = mnk_sc_spmv(sc, MNK_SC_JT, 1, 1.0, d, 0.0, sp->buffer2.p);  // buffer2 = Jt' * wx
-        if (rc) return rc;
-        hipLaunchKernelGGL(expand_sol_kernel, MNK_GRID(m), ws, wz, sp->buffer.p, sp->buffer2.p, sc->diag_buffer.p, Ss, m);
-    }
-    if (nlb > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nlb), wl, d, sp->ind_lb.p, sp->l_lower.p, sp->l_diag.p, nlb, 0);
-    if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, sp->ind_ub.p, sp->u_lower.p, sp->u_diag.p, nub, 1);
-    MNK_HIP(hipGetLastError());
-    if (loc != MNK_DEVICE) {
+        if (m > 0) {
+            rc = mnk_sc_spmv(sc, MNK_SC_JT, 1, 1.0, d, 0.0, sp->buffer2.p);  // buffer2 = Jt' * wx
+            if (rc) return rc;
+            hipLaunchKernelGGL(expand_sol_kernel, MNK_GRID(m), ws, wz, sp->buffer.p, sp->buffer2.p, sc->diag_buffer.p, Ss, m);
+        }
+        if (nlb > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nlb), wl, d, sp->ind_lb.p, sp->l_lower.p, sp->l_diag.p, nlb, 0);
+        if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, sp->ind_ub.p, sp->u_lower.p, sp->u_diag.p, nub, 1);
+        MNK_HIP(hipGetLastError());
+        if (loc == MNK_DEVICE) break;  // device-resident caller: mnk_ls_check_solve() reports an abort
+        MNK_HIP(hipStreamSynchronize(s));
+        if (attempt == 0 && mnk_ls_take_solve_abort(ls)) continue;  // redo with the stepwise solve
         MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
         MNK_HIP(hipStreamSynchronize(s));
+        break;
     }
     return 0;
 }

@@ -248,6 +248,16 @@ class HipLinearSolver:
             raise SolveException(L.lib().mnk_last_error_string().decode())
         return x
 
+    def check_solve(self):
+        """Device-resident callers: synchronize and raise SolveException if a one-launch solve gave up
+        (`mnk_ls_check_solve`); the solver has then switched to the stepwise solve."""
+        rc = L.lib().mnk_ls_check_solve(self._h)
+        if rc:
+            raise SolveException(L.lib().mnk_last_error_string().decode())
+
+    def set_option(self, key: str, value: float):
+        L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(value)), "mnk_ls_set_option")
+
     def get_factor(self):
         """(L, D) on the host, for tests."""
         Lm = np.zeros((self.n, self.n), order="F")
