@@ -1,54 +1,123 @@
-# MadNLPHIP.jl -- Julia glue binding libmadnlp_hip.so into MadNLP (NOT executed in this
-# repository's CI: the build image has no Julia toolchain; the same call sequence is
-# exercised through the ctypes mirror in madnlp.jl_amd/ and tests/).
+# MadNLPHIP.jl -- Julia glue binding libmadnlp_hip.so into MadNLP.jl v0.10.1.
 #
-# It adds two types that plug into MadNLP's own option seam
-#     madnlp(nlp; kkt_system = HipSparseCondensedKKTSystem, linear_solver = HipLinearSolver)
-# (reference src/IPM/options.jl:121-122, consumed at src/IPM/IPM.jl:157-165); nothing else in
-# the IPM loop changes.  Pattern: ccall + finalizer exactly as src/LinearSolvers/mumps.jl:148-165,211
-# and src/LinearSolvers/lapack.jl:50-139.
+# NOT executed in this repository's CI: the build image has no Julia toolchain.  What IS checked
+# here (tests/test_julia_glue.py): every `ccall` in this file names a symbol that include/madnlp_hip.h
+# declares, with the same arity and C types; every option key passed to mnk_ls_set_option is one the
+# library accepts; the option defaults equal the library's.  The same call sequence is exercised on the
+# GPU through the ctypes mirror in madnlp.jl_amd/ (tests/test_hip_parity.py).
+#
+# It adds three types that plug into MadNLP's own option seam
+#     madnlp(nlp; kkt_system = MadNLPHIP.HipSparseCondensedKKTSystem, linear_solver = MadNLPHIP.HipLinearSolver)
+#     madnlp(nlp; kkt_system = MadNLPHIP.HipDenseCondensedKKTSystem,  linear_solver = MadNLPHIP.HipLinearSolver)
+# (reference src/IPM/options.jl:121-122, consumed at src/IPM/IPM.jl:157-165); nothing else in the IPM
+# loop changes.  Pattern: ccall + finalizer as in src/LinearSolvers/mumps.jl:148-165,211 and
+# src/LinearSolvers/lapack.jl:50-139; KKT-system contract as in docs/src/tutorials/diag_kkt.jl:6-215.
 module MadNLPHIP
 
 import MadNLP
-import MadNLP: AbstractLinearSolver, AbstractCondensedKKTSystem, MadNLPLogger, LinearFactorization,
-    SymbolicException, FactorizationException, SolveException, InertiaException,
-    BUNCHKAUFMAN, CHOLESKY, LDL
-import SparseArrays: SparseMatrixCSC
+import MadNLP: AbstractLinearSolver, AbstractCondensedKKTSystem, AbstractKKTVector, MadNLPLogger,
+    LinearFactorization, SymbolicException, FactorizationException, SolveException, InertiaException,
+    BUNCHKAUFMAN, CHOLESKY, LDL, SparseCallback, AbstractCallback, SparseMatrixCOO,
+    ExactHessian, QuasiNewtonOptions, create_quasi_newton, build_hessian_structure, create_array,
+    _jac_sparsity_wrapper!, force_lower_triangular!, transfer!, default_options,
+    full, primal, dual, dual_lb, dual_ub
+import LinearAlgebra: mul!, Symmetric
+import SparseArrays: SparseMatrixCSC, nnz
 
 const libmadnlp_hip = get(ENV, "MADNLP_HIP_LIB", "libmadnlp_hip.so")
 const MNK_HOST = Cint(0)
 const MNK_ALGO = Dict(BUNCHKAUFMAN => Cint(1), CHOLESKY => Cint(4), LDL => Cint(5))
+const MNK_SC_JT, MNK_SC_HESS, MNK_SC_AUG = Cint(0), Cint(1), Cint(2)
 
 lasterr() = unsafe_string(ccall((:mnk_last_error_string, libmadnlp_hip), Cstring, ()))
+check(rc, E) = rc == 0 ? nothing : (@error("libmadnlp_hip: " * lasterr()); throw(E()))
 
-# ------------------------------------------------------------------ context (one per solver)
+# ------------------------------------------------------------------ handles
+# Julia does not order finalizers.  The library therefore reference-counts the context: mnk_ctx_destroy
+# on a context that still has live children (solver / KKT handles) only marks it released, and the last
+# child's destroy frees it -- any finalizer order is safe.  Every wrapper below is additionally
+# idempotent (handle reset to C_NULL).
 mutable struct HipContext
     handle::Ptr{Cvoid}
     function HipContext(device::Integer = 0)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:mnk_ctx_create, libmadnlp_hip), Cint, (Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), device, C_NULL, h)
-        rc == 0 || throw(SymbolicException())
+        check(rc, SymbolicException)
         ctx = new(h[])
-        finalizer(c -> ccall((:mnk_ctx_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), c.handle), ctx)
+        finalizer(ctx) do c
+            c.handle == C_NULL || ccall((:mnk_ctx_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), c.handle)
+            c.handle = C_NULL
+        end
         return ctx
     end
 end
 
+mutable struct HipSC            # mnk_sc*: device state of the sparse condensed system
+    handle::Ptr{Cvoid}
+    ctx::HipContext
+end
+mutable struct HipDC            # mnk_dc*: device state of the dense (condensed) system
+    handle::Ptr{Cvoid}
+    ctx::HipContext
+end
+function release!(h::HipSC)
+    h.handle == C_NULL || ccall((:mnk_sc_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), h.handle)
+    h.handle = C_NULL
+end
+function release!(h::HipDC)
+    h.handle == C_NULL || ccall((:mnk_dc_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), h.handle)
+    h.handle = C_NULL
+end
+
 # ------------------------------------------------------------------ linear solver
+# Defaults = the library's (csrc/ls.h); tests/test_julia_glue.py compares them.
 @kwdef mutable struct HipSolverOptions <: MadNLP.AbstractOptions
-    lapack_algorithm::LinearFactorization = BUNCHKAUFMAN   # served by the static-pivot LDL^T
+    lapack_algorithm::LinearFactorization = BUNCHKAUFMAN   # served by the device LDL^T
     pivot_tol::Float64 = 0.0
-    outer_block::Int = 256
+    outer_block::Int = 512
     lookahead::Bool = true
+    share::Int = 1                  # 0 off / 1 adaptive / 2 always: panel-stream CUs join the trailing update
+    persistent_solve::Bool = true   # both triangular sweeps in one launch
+    single_rows::Int = 4608         # systems up to this order: one outer panel on the whole chip
+end
+
+"aug_com of `HipSparseCondensedKKTSystem`: lower-triangular CSC whose VALUES live in HBM."
+struct HipAugCSC{T} <: AbstractMatrix{T}
+    sc::HipSC
+    structure::SparseMatrixCSC{T, Int32}       # host copy of the pattern (nzval unused)
+end
+Base.size(A::HipAugCSC) = size(A.structure)
+nnz(A::HipAugCSC) = nnz(A.structure)
+Base.getindex(A::HipAugCSC, i::Int, j::Int) = error("HipAugCSC values live on the device; use MadNLPHIP.values(A)")
+"Copy nzval of the device aug_com to the host (diagnostics, tests)."
+function values(A::HipAugCSC{T}) where T
+    out = Vector{T}(undef, nnz(A.structure))
+    rc = ccall((:mnk_sc_get_values, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Cint), A.sc.handle, MNK_SC_AUG, out, MNK_HOST)
+    check(rc, SymbolicException)
+    return out
+end
+
+"aug_com of `HipDenseCondensedKKTSystem`: the (n + n_eq)^2 dense matrix assembled in HBM."
+struct HipAugDense{T} <: AbstractMatrix{T}
+    dc::HipDC
+    order::Int
+end
+Base.size(A::HipAugDense) = (A.order, A.order)
+Base.getindex(A::HipAugDense, i::Int, j::Int) = Matrix(A)[i, j]
+function Base.Matrix(A::HipAugDense{T}) where T
+    out = Matrix{T}(undef, A.order, A.order)
+    rc = ccall((:mnk_dc_get_aug, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), A.dc.handle, out, MNK_HOST)
+    check(rc, SymbolicException)
+    return out
 end
 
 """
     HipLinearSolver(A; opt, logger)
 
-`A` is either the `HipAugCSC` handle owned by a `HipSparseCondensedKKTSystem` (device
-resident; nothing crosses PCIe in `factorize!`), or a host `Matrix{Float64}` /
-`SparseMatrixCSC{Float64,Int32}` (lower triangle), to which the solver keeps a reference
-exactly like `LapackCPUSolver` does (src/LinearSolvers/lapack.jl:5-44).
+`A` is the `aug_com` MadNLP hands to the solver: a device-resident `HipAugCSC` / `HipAugDense` (nothing
+crosses PCIe in `factorize!`), or a host `Matrix{Float64}` / `SparseMatrixCSC{Float64,Int32}` (lower
+triangle) -- the reference's own KKT systems -- to which the solver keeps a reference exactly like
+`LapackCPUSolver` does (src/LinearSolvers/lapack.jl:5-44).
 """
 mutable struct HipLinearSolver{T, MT} <: AbstractLinearSolver{T}
     A::MT
@@ -60,38 +129,52 @@ mutable struct HipLinearSolver{T, MT} <: AbstractLinearSolver{T}
     logger::MadNLPLogger
 end
 
-struct HipAugCSC{T} <: AbstractMatrix{T}      # aug_com of the sparse condensed system, lives in HBM
-    sc::Ptr{Cvoid}                             # mnk_sc*
-    ctx::HipContext
-    structure::SparseMatrixCSC{T, Int32}       # host copy of the pattern (values are on the device)
+context_of(A::HipAugCSC) = A.sc.ctx
+context_of(A::HipAugDense) = A.dc.ctx
+context_of(::AbstractMatrix) = HipContext()
+
+function set_option!(h::Ptr{Cvoid}, key::String, val::Real)
+    rc = ccall((:mnk_ls_set_option, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cstring, Cdouble), h, key, Float64(val))
+    check(rc, SymbolicException)
 end
-Base.size(A::HipAugCSC) = size(A.structure)
 
 function HipLinearSolver(A::MT; opt = HipSolverOptions(), logger = MadNLPLogger(),
-                         ctx = (A isa HipAugCSC ? A.ctx : HipContext())) where {MT <: AbstractMatrix}
+                         ctx::HipContext = context_of(A)) where {MT <: AbstractMatrix}
     n = size(A, 1)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:mnk_ls_create, libmadnlp_hip), Cint, (Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}),
                ctx.handle, n, MNK_ALGO[opt.lapack_algorithm], h)
-    rc == 0 || throw(SymbolicException())
-    for (k, v) in (("pivot_tol", opt.pivot_tol), ("outer_block", Float64(opt.outer_block)), ("lookahead", Float64(opt.lookahead)))
-        ccall((:mnk_ls_set_option, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cstring, Cdouble), h[], k, v)
-    end
+    check(rc, SymbolicException)
+    set_option!(h[], "pivot_tol", opt.pivot_tol)
+    set_option!(h[], "outer_block", opt.outer_block)
+    set_option!(h[], "lookahead", opt.lookahead)
+    set_option!(h[], "share", opt.share)
+    set_option!(h[], "persistent_solve", opt.persistent_solve)
+    set_option!(h[], "single_rows", opt.single_rows)
     M = HipLinearSolver{Float64, MT}(A, h[], ctx, n, Ref{Cint}(0), opt, logger)
-    finalizer(m -> ccall((:mnk_ls_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), m.handle), M)
+    finalizer(M) do m
+        m.handle == C_NULL || ccall((:mnk_ls_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), m.handle)
+        m.handle = C_NULL
+    end
     return M
 end
 
-# factorize!: transfer_matrix! + dsytrf/dpotrf replacement (src/LinearSolvers/lapack_common.jl:54-66)
+# factorize!: transfer_matrix! + dsytrf/dpotrf replacement (src/LinearSolvers/lapack_common.jl:54-66).
+# rc != 0 is a HIP/runtime error only; a bad pivot is NOT an error, it surfaces through `inertia`.
 function MadNLP.factorize!(M::HipLinearSolver{T, <:HipAugCSC}) where T
-    rc = ccall((:mnk_ls_factorize_sc, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}), M.handle, M.A.sc, M.info)
-    rc == 0 || throw(FactorizationException())      # HIP/runtime error only; a bad pivot is NOT an error
+    rc = ccall((:mnk_ls_factorize_sc, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}), M.handle, M.A.sc.handle, M.info)
+    check(rc, FactorizationException)
+    return M
+end
+function MadNLP.factorize!(M::HipLinearSolver{T, <:HipAugDense}) where T
+    rc = ccall((:mnk_ls_factorize_dc, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}), M.handle, M.A.dc.handle, M.info)
+    check(rc, FactorizationException)
     return M
 end
 function MadNLP.factorize!(M::HipLinearSolver{T, <:Matrix}) where T
     rc = ccall((:mnk_ls_factorize_dense, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Cint, Ptr{Cint}),
                M.handle, M.A, size(M.A, 1), MNK_HOST, M.info)
-    rc == 0 || throw(FactorizationException())
+    check(rc, FactorizationException)
     return M
 end
 function MadNLP.factorize!(M::HipLinearSolver{T, <:SparseMatrixCSC}) where T
@@ -99,14 +182,14 @@ function MadNLP.factorize!(M::HipLinearSolver{T, <:SparseMatrixCSC}) where T
     rc = ccall((:mnk_ls_factorize_csc, libmadnlp_hip), Cint,
                (Ptr{Cvoid}, Ptr{Int32}, Ptr{Int32}, Ptr{Cdouble}, Cint, Ptr{Cint}),
                M.handle, A.colptr, A.rowval, A.nzval, 1, M.info)
-    rc == 0 || throw(FactorizationException())
+    check(rc, FactorizationException)
     return M
 end
 
 function MadNLP.solve_linear_system!(M::HipLinearSolver, x::Vector{Float64})
     rc = ccall((:mnk_ls_solve, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cint),
                M.handle, x, 1, length(x), MNK_HOST)
-    rc == 0 || throw(SolveException())
+    check(rc, SolveException)
     return x
 end
 
@@ -114,7 +197,7 @@ MadNLP.is_inertia(::HipLinearSolver) = true
 function MadNLP.inertia(M::HipLinearSolver)
     p = Ref{Int64}(0); z = Ref{Int64}(0); n = Ref{Int64}(0)
     rc = ccall((:mnk_ls_inertia, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), M.handle, p, z, n)
-    rc == 0 || throw(InertiaException())
+    check(rc, InertiaException)
     return (p[], z[], n[])
 end
 MadNLP.improve!(::HipLinearSolver) = false
@@ -125,33 +208,330 @@ MadNLP.is_supported(::Type{<:HipLinearSolver}, ::Type{Float64}) = true
 MadNLP.is_supported(::Type{<:HipLinearSolver}, ::Type{Float32}) = false
 
 # ------------------------------------------------------------------ sparse condensed KKT system
-# The struct keeps every field the generic code touches (src/KKT/KKTsystem.jl:210-234,
-# src/IPM/kernels.jl:4-27, src/KKT/rhs.jl:119-129) on the host; only the assembly
-# (compress_*, build_kkt!) and the factorization/solve go to the device.  `jt_csc` and
-# `hess_com` are host mirrors rebuilt from the structures the library exports
-# (mnk_sc_get_structure / mnk_sc_get_map), so jtprod!/mul!/solve_kkt! of
-# src/KKT/Sparse/condensed.jl:150-156 and src/IPM/factorization.jl:143-167,278-299 run unchanged.
-#
-# create_kkt_system(::Type{HipSparseCondensedKKTSystem}, cb, linear_solver; ...) mirrors
-# src/KKT/Sparse/condensed.jl:55-133 with these substitutions:
-#
-#   coo_to_csc(jt_coo), coo_to_csc(hess_raw), build_condensed_aug_symbolic(...)
-#       -> ccall(:mnk_sc_create, ..., n, m, nnzj, jac_I, jac_J, nnzh, hess_I, hess_J, 1, sc)
-#          + mnk_sc_sizes / mnk_sc_get_structure / mnk_sc_get_map (1-based conversion on the Julia side)
-#   compress_jacobian!(kkt) -> ccall(:mnk_sc_compress_jacobian, ..., kkt.sc, kkt.jac, MNK_HOST)
-#                              (+ transfer!(kkt.jt_csc, kkt.jt_coo, kkt.jt_csc_map) on the host mirror)
-#   compress_hessian!(kkt)  -> ccall(:mnk_sc_compress_hessian, ..., kkt.sc, kkt.hess, MNK_HOST)
-#   build_kkt!(kkt)         -> kkt.diag_buffer .= Ss ./ (1 .- Sd .* Ss)        (host copy for solve_kkt!)
-#                              ccall(:mnk_sc_build, ..., kkt.sc, kkt.pr_diag, kkt.du_diag, MNK_HOST)
-#   kkt.aug_com             -> HipAugCSC(sc, ctx, pattern)   (what `linear_solver(aug_com; opt)` receives)
-#
-#   solve_kkt!(kkt, w)      -> optional device version (keeps [x; s; z; zl; zu] on the device, one round trip):
-#                              constructor: ccall(:mnk_sc_set_bounds, ..., kkt.sc, nlb, ind_lb, nub, ind_ub, 1)
-#                              build_kkt!:  ccall(:mnk_sc_set_barrier_terms, ..., kkt.sc, kkt.reg, kkt.l_diag, kkt.u_diag,
-#                                                 kkt.l_lower, kkt.u_lower, MNK_HOST)
-#                              solve_kkt!:  ccall(:mnk_sc_solve_kkt, ..., kkt.sc, kkt.linear_solver.handle, full(w), MNK_HOST)
-#   mul!(w, kkt, x, a, b)   -> ccall(:mnk_sc_mul, ..., kkt.sc, full(w), full(x), a, b, MNK_HOST)
-#
-# See INTEGRATION.md for the full listing and the dense (DenseCondensedKKTSystem) twin.
+# Field-for-field the reference's SparseCondensedKKTSystem (src/KKT/Sparse/condensed.jl:8-52): every field
+# the generic code touches (src/KKT/KKTsystem.jl:210-234, src/IPM/kernels.jl:4-27, src/KKT/rhs.jl:119-129)
+# stays a host vector; `hess_com` / `jt_csc` are host mirrors (for jtprod! and mul_hess_blk!); the
+# condensation, aug_com, the factorization, solve_kkt! and mul! live on the device behind `sc`.
+struct HipSparseCondensedKKTSystem{T, VT, MT, QN, LS, VI, VI32} <: AbstractCondensedKKTSystem{T, VT, MT, QN}
+    hess::VT
+    hess_raw::SparseMatrixCOO{T, Int32, VT, VI32}
+    hess_com::MT
+    hess_csc_map::VI
+    jac::VT
+    jt_coo::SparseMatrixCOO{T, Int32, VT, VI32}
+    jt_csc::MT
+    jt_csc_map::VI
+    quasi_newton::QN
+    reg::VT
+    pr_diag::VT
+    du_diag::VT
+    l_diag::VT
+    u_diag::VT
+    l_lower::VT
+    u_lower::VT
+    buffer::VT
+    buffer2::VT
+    aug_com::HipAugCSC{T}
+    diag_buffer::VT
+    linear_solver::LS
+    ind_ineq::VI
+    ind_lb::VI
+    ind_ub::VI
+    sc::HipSC
+end
+
+"0-based (colptr, rowval) of a derived structure -> 1-based SparseMatrixCSC with zero values."
+function fetch_structure(sc::HipSC, which::Cint, nrow::Int, ncol::Int, nz::Int)
+    colptr = Vector{Int32}(undef, ncol + 1)
+    rowval = Vector{Int32}(undef, nz)
+    rc = ccall((:mnk_sc_get_structure, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}, Ptr{Int32}), sc.handle, which, colptr, rowval)
+    check(rc, SymbolicException)
+    colptr .+= Int32(1)
+    rowval .+= Int32(1)
+    return SparseMatrixCSC{Float64, Int32}(nrow, ncol, colptr, rowval, zeros(Float64, nz))
+end
+function fetch_map(sc::HipSC, which::Cint, len::Int)
+    map = Vector{Int64}(undef, len)
+    rc = ccall((:mnk_sc_get_map, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), sc.handle, which, map)
+    check(rc, SymbolicException)
+    return Vector{Int}(map .+ 1)
+end
+
+# create_kkt_system: reference src/KKT/Sparse/condensed.jl:55-133.  coo_to_csc (x2) and
+# build_condensed_aug_symbolic are replaced by ONE call, mnk_sc_create (host C++), whose results come back
+# through mnk_sc_sizes / mnk_sc_get_structure / mnk_sc_get_map.
+function MadNLP.create_kkt_system(
+    ::Type{HipSparseCondensedKKTSystem},
+    cb::SparseCallback{T, VT},
+    linear_solver::Type;
+    opt_linear_solver = default_options(linear_solver),
+    hessian_approximation = ExactHessian,
+    qn_options = QuasiNewtonOptions(),
+    device::Integer = 0,
+) where {T, VT}
+    T === Float64 || error("HipSparseCondensedKKTSystem supports Float64 only.")
+    ind_ineq = cb.ind_ineq
+    n = cb.nvar
+    m = cb.ncon
+    length(ind_ineq) == m || error("HipSparseCondensedKKTSystem does not support equality constrained NLPs.")
+
+    jac_sparsity_I = create_array(cb, Int32, cb.nnzj)
+    jac_sparsity_J = create_array(cb, Int32, cb.nnzj)
+    _jac_sparsity_wrapper!(cb, jac_sparsity_I, jac_sparsity_J)
+    quasi_newton = create_quasi_newton(hessian_approximation, cb, n; options = qn_options)
+    hess_sparsity_I, hess_sparsity_J = build_hessian_structure(cb, hessian_approximation)
+    force_lower_triangular!(hess_sparsity_I, hess_sparsity_J)
+    n_jac = length(jac_sparsity_I)
+    n_hess = length(hess_sparsity_I)
+    nlb = length(cb.ind_lb)
+    nub = length(cb.ind_ub)
+
+    reg = VT(undef, n + m); pr_diag = VT(undef, n + m); du_diag = VT(undef, m)
+    l_diag = VT(undef, nlb); u_diag = VT(undef, nub); l_lower = VT(undef, nlb); u_lower = VT(undef, nub)
+    buffer = VT(undef, m); buffer2 = VT(undef, m); diag_buffer = VT(undef, m)
+    hess = VT(undef, n_hess)
+    jac = fill!(VT(undef, n_jac), zero(T))
+    hess_raw = SparseMatrixCOO(n, n, hess_sparsity_I, hess_sparsity_J, hess)
+    jt_coo = SparseMatrixCOO(n, m, jac_sparsity_J, jac_sparsity_I, jac)
+
+    ctx = HipContext(device)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:mnk_sc_create, libmadnlp_hip), Cint,
+               (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Int64, Ptr{Int32}, Ptr{Int32}, Cint, Ptr{Ptr{Cvoid}}),
+               ctx.handle, n, m, n_jac, jac_sparsity_I, jac_sparsity_J, n_hess, hess_sparsity_I, hess_sparsity_J, 1, h)
+    check(rc, SymbolicException)
+    sc = HipSC(h[], ctx)
+    finalizer(release!, sc)
+
+    nz_jt = Ref{Int64}(0); nz_h = Ref{Int64}(0); nz_aug = Ref{Int64}(0); len_jptr = Ref{Int64}(0)
+    rc = ccall((:mnk_sc_sizes, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+               sc.handle, nz_jt, nz_h, nz_aug, len_jptr)
+    check(rc, SymbolicException)
+    jt_csc = fetch_structure(sc, MNK_SC_JT, n, m, Int(nz_jt[]))
+    hess_com = fetch_structure(sc, MNK_SC_HESS, n, n, Int(nz_h[]))
+    jt_csc_map = fetch_map(sc, MNK_SC_JT, n_jac)
+    hess_csc_map = fetch_map(sc, MNK_SC_HESS, n_hess)
+    aug_com = HipAugCSC{T}(sc, fetch_structure(sc, MNK_SC_AUG, n, n, Int(nz_aug[])))
+
+    # device-side solve_kkt!/mul!: the bound index sets go up once
+    ind_lb64 = Vector{Int64}(cb.ind_lb); ind_ub64 = Vector{Int64}(cb.ind_ub)
+    rc = ccall((:mnk_sc_set_bounds, libmadnlp_hip), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Cint),
+               sc.handle, nlb, ind_lb64, nub, ind_ub64, 1)
+    check(rc, SymbolicException)
+
+    _linear_solver = linear_solver(aug_com; opt = opt_linear_solver)
+    return HipSparseCondensedKKTSystem(
+        hess, hess_raw, hess_com, hess_csc_map,
+        jac, jt_coo, jt_csc, jt_csc_map,
+        quasi_newton,
+        reg, pr_diag, du_diag, l_diag, u_diag, l_lower, u_lower,
+        buffer, buffer2, aug_com, diag_buffer,
+        _linear_solver, ind_ineq, cb.ind_lb, cb.ind_ub, sc,
+    )
+end
+
+MadNLP.num_variables(kkt::HipSparseCondensedKKTSystem) = length(kkt.pr_diag)
+MadNLP.is_inertia_correct(kkt::HipSparseCondensedKKTSystem, num_pos, num_zero, num_neg) =
+    (num_zero == 0) && (num_pos == size(kkt.aug_com, 1))                      # condensed.jl:138-140
+MadNLP.should_regularize_dual(::HipSparseCondensedKKTSystem, num_pos, num_zero, num_neg) = true   # :141
+MadNLP.get_jacobian(kkt::HipSparseCondensedKKTSystem) = kkt.jac               # :368
+MadNLP.nnz_jacobian(kkt::HipSparseCondensedKKTSystem) = nnz(kkt.jt_coo)
+Base.size(kkt::HipSparseCondensedKKTSystem, n::Int) = size(kkt.aug_com, n)
+
+function MadNLP.initialize!(kkt::HipSparseCondensedKKTSystem{T}) where T       # src/KKT/Sparse/utils.jl:52-62
+    fill!(kkt.reg, one(T)); fill!(kkt.pr_diag, one(T)); fill!(kkt.du_diag, zero(T)); fill!(kkt.hess, zero(T))
+    fill!(kkt.l_lower, zero(T)); fill!(kkt.u_lower, zero(T)); fill!(kkt.l_diag, one(T)); fill!(kkt.u_diag, one(T))
+    fill!(nonzeros_of(kkt.hess_com), zero(T))
+    return
+end
+nonzeros_of(A::SparseMatrixCSC) = A.nzval
+
+# compress_jacobian! (condensed.jl:145-148): the device does the segmented COO -> CSC sum (mnk_sc_compress_jacobian);
+# the host mirror is kept current for jtprod! (one O(nnz) scatter, as the reference does).
+function MadNLP.compress_jacobian!(kkt::HipSparseCondensedKKTSystem)
+    transfer!(kkt.jt_csc, kkt.jt_coo, kkt.jt_csc_map)
+    rc = ccall((:mnk_sc_compress_jacobian, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), kkt.sc.handle, kkt.jac, MNK_HOST)
+    check(rc, SymbolicException)
+    return
+end
+# compress_hessian! (src/KKT/Sparse/utils.jl:48-50)
+function MadNLP.compress_hessian!(kkt::HipSparseCondensedKKTSystem)
+    transfer!(kkt.hess_com, kkt.hess_raw, kkt.hess_csc_map)
+    rc = ccall((:mnk_sc_compress_hessian, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), kkt.sc.handle, kkt.hess, MNK_HOST)
+    check(rc, SymbolicException)
+    return
+end
+
+# build_kkt! (condensed.jl:354-366): D = Sigma_s ./ (1 - Sigma_d Sigma_s) and the condensation run on the device;
+# the barrier terms of the iterate follow for the device-side solve_kkt!/mul!.
+function MadNLP.build_kkt!(kkt::HipSparseCondensedKKTSystem)
+    rc = ccall((:mnk_sc_build, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+               kkt.sc.handle, kkt.pr_diag, kkt.du_diag, MNK_HOST)
+    check(rc, SymbolicException)
+    rc = ccall((:mnk_sc_set_barrier_terms, libmadnlp_hip), Cint,
+               (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+               kkt.sc.handle, kkt.reg, kkt.l_diag, kkt.u_diag, kkt.l_lower, kkt.u_lower, MNK_HOST)
+    check(rc, SymbolicException)
+    return
+end
+
+function MadNLP.jtprod!(y::AbstractVector, kkt::HipSparseCondensedKKTSystem, x::AbstractVector)   # condensed.jl:150-156
+    n = size(kkt.hess_com, 1)
+    mul!(view(y, 1:n), kkt.jt_csc, x)
+    y[n+1:end] .= .-x
+    return y
+end
+
+# solve_kkt! (src/IPM/factorization.jl:143-167): reduce_rhs!, condensation of the right-hand side, the
+# triangular solves, the expansion and finish_aug_solve! all run on the device; full(w) makes one round trip.
+function MadNLP.solve_kkt!(kkt::HipSparseCondensedKKTSystem, w::AbstractKKTVector)
+    rc = ccall((:mnk_sc_solve_kkt, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint),
+               kkt.sc.handle, kkt.linear_solver.handle, full(w), MNK_HOST)
+    check(rc, SolveException)
+    return w
+end
+# mul!(w, kkt, x, alpha, beta) (src/IPM/factorization.jl:278-299 + _kktmul! src/IPM/kernels.jl:161-180)
+function mul!(w::AbstractKKTVector{T}, kkt::HipSparseCondensedKKTSystem, x::AbstractKKTVector, alpha = one(T), beta = zero(T)) where T
+    rc = ccall((:mnk_sc_mul, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint),
+               kkt.sc.handle, full(w), full(x), Float64(alpha), Float64(beta), MNK_HOST)
+    check(rc, SolveException)
+    return w
+end
+function MadNLP.mul_hess_blk!(wx, kkt::HipSparseCondensedKKTSystem, t)            # factorization.jl:333-338
+    n = size(kkt.hess_com, 1)
+    mul!(@view(wx[1:n]), Symmetric(kkt.hess_com, :L), @view(t[1:n]))
+    fill!(@view(wx[n+1:end]), 0)
+    wx .+= t .* kkt.pr_diag
+end
+
+# ------------------------------------------------------------------ dense condensed KKT system
+# reference src/KKT/Dense/condensed.jl:10-111.  The callbacks write kkt.hess / kkt.jac on the host (get_hessian /
+# get_jacobian return them, src/KKT/KKTsystem.jl:238-239); build_kkt! uploads both and assembles aug_com on the
+# device (scale + fp64-MFMA Gram product + scatter).
+struct HipDenseCondensedKKTSystem{T, VT <: AbstractVector{T}, MT <: AbstractMatrix{T}, QN, LS, VI <: AbstractVector{Int}} <:
+       AbstractCondensedKKTSystem{T, VT, MT, QN}
+    hess::MT
+    jac::MT
+    quasi_newton::QN
+    reg::VT
+    pr_diag::VT
+    du_diag::VT
+    l_diag::VT
+    u_diag::VT
+    l_lower::VT
+    u_lower::VT
+    aug_com::HipAugDense{T}
+    n_eq::Int
+    ind_eq::VI
+    n_ineq::Int
+    ind_ineq::VI
+    ind_lb::VI
+    ind_ub::VI
+    linear_solver::LS
+    dc::HipDC
+end
+
+function MadNLP.create_kkt_system(
+    ::Type{HipDenseCondensedKKTSystem},
+    cb::AbstractCallback{T, VT},
+    linear_solver::Type;
+    opt_linear_solver = default_options(linear_solver),
+    hessian_approximation = ExactHessian,
+    qn_options = QuasiNewtonOptions(),
+    device::Integer = 0,
+) where {T, VT}
+    T === Float64 || error("HipDenseCondensedKKTSystem supports Float64 only.")
+    n = cb.nvar
+    m = cb.ncon
+    ns = length(cb.ind_ineq)
+    n_eq = m - ns
+    nlb = length(cb.ind_lb)
+    nub = length(cb.ind_ub)
+    hess = fill!(create_array(cb, n, n), zero(T))
+    jac = fill!(create_array(cb, m, n), zero(T))
+    reg = VT(undef, n + ns)
+    pr_diag = fill!(VT(undef, n + ns), zero(T))
+    du_diag = fill!(VT(undef, m), zero(T))
+    l_diag = fill!(VT(undef, nlb), one(T)); u_diag = fill!(VT(undef, nub), one(T))
+    l_lower = fill!(VT(undef, nlb), zero(T)); u_lower = fill!(VT(undef, nub), zero(T))
+
+    ctx = HipContext(device)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    ind_ineq64 = Vector{Int64}(cb.ind_ineq); ind_eq64 = Vector{Int64}(cb.ind_eq)
+    rc = ccall((:mnk_dc_create, libmadnlp_hip), Cint,
+               (Ptr{Cvoid}, Cint, Int64, Int64, Int64, Ptr{Int64}, Ptr{Int64}, Cint, Ptr{Ptr{Cvoid}}),
+               ctx.handle, 1, n, m, ns, ind_ineq64, ind_eq64, 1, h)
+    check(rc, SymbolicException)
+    dc = HipDC(h[], ctx)
+    finalizer(release!, dc)
+    ind_lb64 = Vector{Int64}(cb.ind_lb); ind_ub64 = Vector{Int64}(cb.ind_ub)
+    rc = ccall((:mnk_dc_set_bounds, libmadnlp_hip), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Cint),
+               dc.handle, nlb, ind_lb64, nub, ind_ub64, 1)
+    check(rc, SymbolicException)
+    order = Int(ccall((:mnk_dc_order, libmadnlp_hip), Int64, (Ptr{Cvoid},), dc.handle))
+    aug_com = HipAugDense{T}(dc, order)
+
+    quasi_newton = create_quasi_newton(hessian_approximation, cb, n; options = qn_options)
+    _linear_solver = linear_solver(aug_com; opt = opt_linear_solver)
+    return HipDenseCondensedKKTSystem(
+        hess, jac, quasi_newton,
+        reg, pr_diag, du_diag, l_diag, u_diag, l_lower, u_lower,
+        aug_com, n_eq, cb.ind_eq, ns, cb.ind_ineq, cb.ind_lb, cb.ind_ub,
+        _linear_solver, dc,
+    )
+end
+
+MadNLP.num_variables(kkt::HipDenseCondensedKKTSystem) = size(kkt.hess, 1)
+MadNLP.get_slack_regularization(kkt::HipDenseCondensedKKTSystem) =
+    view(kkt.pr_diag, size(kkt.hess, 1)+1:size(kkt.hess, 1)+kkt.n_ineq)
+MadNLP.is_inertia_correct(kkt::HipDenseCondensedKKTSystem, num_pos, num_zero, num_neg) =
+    (num_zero == 0 && num_neg == kkt.n_eq)                                    # Dense/condensed.jl:189-191
+MadNLP.compress_jacobian!(::HipDenseCondensedKKTSystem) = nothing              # Dense/utils.jl:25-27
+MadNLP.nnz_jacobian(kkt::HipDenseCondensedKKTSystem) = length(kkt.jac)
+function MadNLP.jtprod!(y::AbstractVector, kkt::HipDenseCondensedKKTSystem, x::AbstractVector)   # Dense/utils.jl:4-18
+    n = size(kkt.hess, 1)
+    ns = kkt.n_ineq
+    mul!(view(y, 1:n), kkt.jac', x)
+    fill!(view(y, n+1:n+ns), zero(eltype(y)))
+    view(y, n+1:n+ns) .-= view(x, kkt.ind_ineq)
+    return y
+end
+
+# build_kkt! (Dense/condensed.jl:157-186)
+function MadNLP.build_kkt!(kkt::HipDenseCondensedKKTSystem)
+    n = size(kkt.hess, 1); m = size(kkt.jac, 1)
+    rc = ccall((:mnk_dc_set_hess, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Cint), kkt.dc.handle, kkt.hess, n, MNK_HOST)
+    check(rc, SymbolicException)
+    rc = ccall((:mnk_dc_set_jac, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Cint), kkt.dc.handle, kkt.jac, m, MNK_HOST)
+    check(rc, SymbolicException)
+    rc = ccall((:mnk_dc_build, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+               kkt.dc.handle, kkt.pr_diag, kkt.du_diag, MNK_HOST)
+    check(rc, SymbolicException)
+    rc = ccall((:mnk_dc_set_barrier_terms, libmadnlp_hip), Cint,
+               (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+               kkt.dc.handle, kkt.reg, kkt.l_diag, kkt.u_diag, kkt.l_lower, kkt.u_lower, MNK_HOST)
+    check(rc, SymbolicException)
+    return
+end
+
+# solve_kkt! (src/IPM/factorization.jl:190-229) and mul! (:310-330) on the device
+function MadNLP.solve_kkt!(kkt::HipDenseCondensedKKTSystem, w::AbstractKKTVector)
+    rc = ccall((:mnk_dc_solve_kkt, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cdouble}, Cint),
+               kkt.dc.handle, kkt.linear_solver.handle, full(w), MNK_HOST)
+    check(rc, SolveException)
+    return w
+end
+function mul!(w::AbstractKKTVector{T}, kkt::HipDenseCondensedKKTSystem, x::AbstractKKTVector, alpha = one(T), beta = zero(T)) where T
+    rc = ccall((:mnk_dc_mul, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint),
+               kkt.dc.handle, full(w), full(x), Float64(alpha), Float64(beta), MNK_HOST)
+    check(rc, SolveException)
+    return w
+end
+function MadNLP.mul_hess_blk!(wx, kkt::HipDenseCondensedKKTSystem, t)              # factorization.jl:326-331
+    n = size(kkt.hess, 1)
+    mul!(@view(wx[1:n]), Symmetric(kkt.hess, :L), @view(t[1:n]))
+    fill!(@view(wx[n+1:end]), 0)
+    wx .+= t .* kkt.pr_diag
+end
 
 end # module

@@ -91,7 +91,14 @@ struct mnk_ctx {
     int cu_first = 0;   // first CU-mask bit of the partition
     int total_cu = 256; // CUs of the device
     bool partitioned = false;
+    // Handles created on this context (solvers, KKT systems).  Garbage-collected hosts (Julia) run finalizers
+    // in no particular order: destroying a context that still has children only marks it released, and the
+    // last child to go frees it (mnk_ctx_child_gone).
+    int children = 0;
+    bool released = false;
 };
+void mnk_ctx_child_added(mnk_ctx* ctx);
+void mnk_ctx_child_gone(mnk_ctx* ctx);
 
 // ---- kernels / launchers shared between translation units -------------------
 namespace mnk {

@@ -292,6 +292,7 @@ int mnk_dc_create(mnk_ctx* ctx, int condensed, int64_t n, int64_t m, int64_t ns,
     MNK_HIP(hipMemsetAsync(dc->jac.p, 0, dc->jac.n * sizeof(double), s));
     MNK_HIP(hipMemsetAsync(dc->aug.p, 0, dc->aug.n * sizeof(double), s));
     dc->extra = ex;
+    mnk_ctx_child_added(ctx);
     *out = dc;
     return 0;
 }
@@ -302,7 +303,9 @@ int mnk_dc_destroy(mnk_dc* dc) {
     (void)hipStreamSynchronize(dc->ctx->stream);
     delete extra_of(dc);
     dc->extra = nullptr;
+    mnk_ctx* ctx = dc->ctx;
     delete dc;
+    mnk_ctx_child_gone(ctx);
     return 0;
 }
 

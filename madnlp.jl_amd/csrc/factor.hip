@@ -97,7 +97,8 @@ __device__ __forceinline__ void panel_phase4(double (&a)[T][16], double (*colbuf
                                              const int64_t j0, double* __restrict__ Dout,
                                              double* __restrict__ W, const int64_t ldw, const int64_t wcol,
                                              double* __restrict__ dvec, double* __restrict__ dinv,
-                                             int* __restrict__ info, const double pivot_tol) {
+                                             int* __restrict__ info, const double pivot_tol,
+                                             double* Lsh = nullptr /* optional LDS copy of the factored block */) {
     const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row index i
 #pragma unroll 1
     for (int g = g0; g < g0 + 4; ++g) {
@@ -182,11 +183,15 @@ __device__ __forceinline__ void panel_phase4(double (&a)[T][16], double (*colbuf
             const double xw = w == 0 ? x[0] : (w == 1 ? x[1] : (w == 2 ? x[2] : x[3]));  // L[row][c0]
             if (q == 0) {
                 if (lead) {
-                    if (i > c0) Dout[i + 64 * c0] = xw;
+                    if (i > c0) {
+                        Dout[i + 64 * c0] = xw;
+                        if (Lsh != nullptr) Lsh[i + 64 * c0] = xw;
+                    }
                     if (i == c0) {
                         const double d = w == 0 ? dg[0] : (w == 1 ? dg[1] : (w == 2 ? dg[2] : dg[3]));
                         const double sc = w == 0 ? P.s0 : (w == 1 ? P.s1 : (w == 2 ? P.s2 : P.s3));
                         Dout[i + 64 * c0] = d;  // L[c][c], or d_c for LDL (as LAPACK stores it)
+                        if (Lsh != nullptr) Lsh[i + 64 * c0] = d;
                         dvec[j0 + c0] = d;
                         dinv[j0 + c0] = LDL ? sc : 1.0;
                     }
@@ -205,6 +210,129 @@ __device__ __forceinline__ void panel_phase4(double (&a)[T][16], double (*colbuf
 #pragma unroll
             for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Split panel step (the default): potrf64_kernel + trsm64_mfma_kernel replace the fused elimination
+// kernel below.  The fused kernel carries every 64-row tile of the panel through the 64 sequential
+// pivots of the diagonal block on the VALU (23-40 us per block column, 0.8 TFLOP/s); here ONE
+// workgroup factors the 64x64 diagonal block (the unavoidable pivot chain) and also inverts its four
+// 16x16 diagonal sub-blocks, and the triangular solve of all rows below runs as block substitution
+// on the fp64 matrix cores: X^T[cb] = inv(L[cb,cb]) (B^T[cb] - sum_{ib<cb} L[cb,ib] X^T[ib]), every
+// product a chain of v_mfma_f64_16x16x4 on a 16-row strip that never leaves the wave's registers.
+// (Block substitution with 16x16 inverses: backward error indistinguishable from row-by-row
+// substitution on the condensed KKT systems -- tools/emul_block_trsm.py, 2.1e-16 either way.)
+// ---------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <bool LDL>
+__global__ __launch_bounds__(256) void potrf64_kernel(double* __restrict__ F, int64_t ld, int64_t j0,
+                                                       double* __restrict__ Dout, double* __restrict__ inv16,
+                                                       double* __restrict__ dvec, double* __restrict__ dinv,
+                                                       int* __restrict__ info, double pivot_tol) {
+    __shared__ double colbuf[2][4][CB_LD];
+    __shared__ double Ls[64 * 64];  // factored block, column-major (lower part + diagonal are written)
+    if (*info != 0) return;
+    const int tid = threadIdx.x;
+    const int i = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int64_t trow[1] = {j0};
+    bool valid[1] = {true};
+    double a[1][16];
+#pragma unroll
+    for (int cl = 0; cl < 16; ++cl) a[0][cl] = F[j0 + i + (j0 + 4 * cl + w) * ld];
+    panel_phase4<LDL, 1, 16>(a, colbuf, 0, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
+    panel_phase4<LDL, 1, 12>(a, colbuf, 4, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
+    panel_phase4<LDL, 1, 8>(a, colbuf, 8, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
+    panel_phase4<LDL, 1, 4>(a, colbuf, 12, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
+    __syncthreads();
+    // inverse of the 16x16 diagonal sub-block b = wave (unit diagonal for LDL): lane c < 16 solves L x = e_c
+    if (i < 16) {
+        const int c = i, b16 = 16 * w;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) sacc = fma(Ls[(b16 + r) + 64 * (b16 + k)], x[k], sacc);  // x[k] = 0 for k < c
+            const double rd = LDL ? 1.0 : 1.0 / Ls[(b16 + r) + 64 * (b16 + r)];
+            x[r] = r > c ? -sacc * rd : (r == c ? rd : 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) inv16[w * 256 + r + 16 * c] = x[r];
+    }
+}
+
+// X = B L_jj^-T (Cholesky) / V = B L_jj^-T, X = V D^-1 (LDL) for every row below the diagonal block.
+// Wave = NS strips of 16 rows; lane (l15, l4): accumulator register r of column block cb holds
+// X[row0 + l15][16 cb + l4 + 4 r] (the C^T layout of gemm_f64.hip, so register r of X^T[ib] IS the
+// B operand of k-step r in the next product and nothing is ever shuffled).
+template <bool LDL, int NS>
+__global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
+                                                           const double* __restrict__ Dblk,
+                                                           const double* __restrict__ inv16,
+                                                           const double* __restrict__ dinv, double* __restrict__ W,
+                                                           int64_t ldw, int64_t wcol, const int* __restrict__ info) {
+    if (*info != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t r0 = j0 + 64 + ((int64_t)blockIdx.x * 4 + wave) * (16 * NS);
+    if (r0 >= Np) return;
+    // A operands: lane (l15, l4) of k-step s holds M[i = l15][k = 4 s + l4]
+    double Ln[6][4];  // -L_jj[cb, ib] for (cb, ib) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2)
+    double Iv[4][4];  // inv(L_jj[cb, cb])
+    {
+        int p = 0;
+#pragma unroll
+        for (int cb = 1; cb < 4; ++cb)
+#pragma unroll
+            for (int ib = 0; ib < cb; ++ib, ++p)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Ln[p][s] = -Dblk[(16 * cb + l15) + 64 * (16 * ib + 4 * s + l4)];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) Iv[cb][s] = inv16[cb * 256 + l15 + 16 * (4 * s + l4)];
+    }
+    v4d X[NS][4];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[ns][cb][r] = F[(r0 + 16 * ns + l15) + (j0 + 16 * cb + l4 + 4 * r) * ld];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+            v4d t = X[ns][cb];
+#pragma unroll
+            for (int ib = 0; ib < cb; ++ib) {
+                const int p = cb * (cb - 1) / 2 + ib;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[p][s], X[ns][ib][s], t, 0, 0, 0);
+            }
+            v4d x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[cb][s], t[s], x, 0, 0, 0);
+            X[ns][cb] = x;
+        }
+    }
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * cb + l4 + 4 * r;
+                const int64_t row = r0 + 16 * ns + l15;
+                if (LDL) {
+                    W[row + (wcol + c) * ldw] = X[ns][cb][r];
+                    F[row + (j0 + c) * ld] = X[ns][cb][r] * dinv[j0 + c];
+                } else {
+                    F[row + (j0 + c) * ld] = X[ns][cb][r];
+                }
+            }
 }
 
 template <bool LDL, int T>
@@ -444,6 +572,195 @@ __global__ __launch_bounds__(256) void panel64p_kernel(double* __restrict__ F, i
 #undef MNK_PHASE
 }
 
+// ---------------------------------------------------------------------------------------
+// potrf64 on the matrix cores, ONE wave, no LDS, no barriers (the default diagonal-block kernel).
+// The lower triangle of the 64x64 block lives in accumulator registers as ten 16x16 blocks in the
+// transposed ("C^T") layout of gemm_f64.hip: register r of block (cb, b) at lane (l15, l4) holds
+// A[16 cb + l15][16 b + l4 + 4 r].  In this layout register s of a block IS both the A operand
+// (lane (i, k) <-> M[i][4 s + k]) and the B operand (lane (j, k) <-> M^T[4 s + k][j]) of a K = 4
+// v_mfma_f64_16x16x4 product, so the whole factorization proceeds in 16 steps of 4 pivots without
+// ever shuffling data between lanes:
+//   1. the 4x4 pivot block is broadcast (v_readlane, 10 values) and factored redundantly by every
+//      lane -- the same dependent rsqrt/rcp chain as the fused elimination kernel, the only serial part;
+//   2. X_t^T = inv(L44) A_t^T for every block of the block column: one MFMA per block, the 4x4 inverse
+//      supplied as the A operand on the rows of the pivot group;
+//   3. rank-4 update of every trailing block: acc(cb2, cb1) -= X_t[cb1] X_t[cb2]^T, one MFMA per block;
+// and after the four steps of a block column the inverse of its 16x16 diagonal block (needed by
+// trsm64_mfma_kernel) by block forward substitution, again on MFMA (7 products).
+// Measured against the 256-thread LDS/barrier kernel (potrf64_kernel): see DESIGN.md section 5.
+// ---------------------------------------------------------------------------------------
+template <bool LDL>
+__device__ __forceinline__ void factor_piv4_vals(const double p00, const double p10, const double p11,
+                                                 const double p20, const double p21, const double p22,
+                                                 const double p30, const double p31, const double p32,
+                                                 const double p33, const double pivot_tol, Piv4& P, double (&dg)[4],
+                                                 int& fail) {
+    fail = 0;
+    if (LDL) {
+        auto piv = [&](double d, double& sc, double& rec) {
+            const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
+            sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
+            rec = zero ? 0.0 : d;
+        };
+        piv(p00, P.s0, dg[0]);
+        P.c10 = p10; P.c20 = p20; P.c30 = p30;
+        const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
+        piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
+        P.c21 = fma(-x20, P.c10, p21);
+        P.c31 = fma(-x30, P.c10, p31);
+        const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
+        piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
+        P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
+        const double x32 = P.c32 * P.s2;
+        piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
+    } else {
+        auto piv = [&](double t, double& sc, double& rec, int k) {
+            const bool bad = !(t > 0.0) || !(t <= DBL_MAX);  // not positive definite / NaN / Inf
+            fail = (bad && fail == 0) ? k + 1 : fail;
+            sc = fast_rsqrt(bad ? 1.0 : t);
+            rec = bad ? 1.0 : t * sc;
+        };
+        piv(p00, P.s0, dg[0], 0);
+        P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
+        piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
+        P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
+        P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
+        piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
+        P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
+        piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
+    }
+}
+
+template <bool LDL>
+__global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__ F, int64_t ld, int64_t j0,
+                                                       double* __restrict__ Dout, double* __restrict__ inv16,
+                                                       double* __restrict__ dvec, double* __restrict__ dinv,
+                                                       int* __restrict__ info, double pivot_tol) {
+    if (*info != 0) return;
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    v4d Lt[4][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int b = 0; b <= cb; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = F[(j0 + 16 * cb + l15) + (j0 + 16 * b + l4 + 4 * r) * ld];
+                // 'L' storage: the strict upper triangle of the block may hold anything (NaN included)
+                Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v;
+            }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double aopinv[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = 4 * b + tt;
+            // ---- 1. pivot block: A[16b + 4tt + jj][16b + 4tt + kk] sits in register tt of lane (4tt + jj) + 16 kk
+            const double dsrc = Lt[b][b][tt];
+            const double p00 = readlane_f64(dsrc, 4 * tt + 0);
+            const double p10 = readlane_f64(dsrc, 4 * tt + 1), p11 = readlane_f64(dsrc, 4 * tt + 1 + 16);
+            const double p20 = readlane_f64(dsrc, 4 * tt + 2), p21 = readlane_f64(dsrc, 4 * tt + 2 + 16),
+                         p22 = readlane_f64(dsrc, 4 * tt + 2 + 32);
+            const double p30 = readlane_f64(dsrc, 4 * tt + 3), p31 = readlane_f64(dsrc, 4 * tt + 3 + 16),
+                         p32 = readlane_f64(dsrc, 4 * tt + 3 + 32), p33 = readlane_f64(dsrc, 4 * tt + 3 + 48);
+            Piv4 P;
+            double dg[4];
+            int fail;
+            factor_piv4_vals<LDL>(p00, p10, p11, p20, p21, p22, p30, p31, p32, p33, pivot_tol, P, dg, fail);
+            if (!LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
+            if (lane == 0) {
+                const double sc[4] = {P.s0, P.s1, P.s2, P.s3};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    dvec[j0 + 4 * t + k] = dg[k];
+                    dinv[j0 + 4 * t + k] = LDL ? sc[k] : 1.0;
+                }
+            }
+            // entries of the 4x4 factor: l = L (unit lower for LDL), cv = d_k L (LDL) / L (Cholesky)
+            const double l10 = LDL ? P.c10 * P.s0 : P.c10, l20 = LDL ? P.c20 * P.s0 : P.c20,
+                         l30 = LDL ? P.c30 * P.s0 : P.c30, l21 = LDL ? P.c21 * P.s1 : P.c21,
+                         l31 = LDL ? P.c31 * P.s1 : P.c31, l32 = LDL ? P.c32 * P.s2 : P.c32;
+            const double rd0 = LDL ? 1.0 : P.s0, rd1 = LDL ? 1.0 : P.s1, rd2 = LDL ? 1.0 : P.s2, rd3 = LDL ? 1.0 : P.s3;
+            // inverse of the 4x4 factor (forward substitution, uniform values)
+            const double y00 = rd0, y11 = rd1, y22 = rd2, y33 = rd3;
+            const double y10 = -(l10 * y00) * rd1;
+            const double y20 = -fma(l21, y10, l20 * y00) * rd2;
+            const double y30 = -fma(l32, y20, fma(l31, y10, l30 * y00)) * rd3;
+            const double y21 = -(l21 * y11) * rd2;
+            const double y31 = -fma(l32, y21, l31 * y11) * rd3;
+            const double y32 = -(l32 * y22) * rd3;
+            // A operand of step 2: lane (i, k) holds inv(L44)[i - 4tt][k] on the rows of the pivot group, else 0
+            const int ii = l15 - 4 * tt;
+            const double yr0 = l4 == 0 ? y00 : 0.0;
+            const double yr1 = l4 == 0 ? y10 : (l4 == 1 ? y11 : 0.0);
+            const double yr2 = l4 == 0 ? y20 : (l4 == 1 ? y21 : (l4 == 2 ? y22 : 0.0));
+            const double yr3 = l4 == 0 ? y30 : (l4 == 1 ? y31 : (l4 == 2 ? y32 : y33));
+            const double aop = ii == 0 ? yr0 : (ii == 1 ? yr1 : (ii == 2 ? yr2 : (ii == 3 ? yr3 : 0.0)));
+            aopinv[tt] = aop;
+            const double ssel = l4 == 0 ? P.s0 : (l4 == 1 ? P.s1 : (l4 == 2 ? P.s2 : P.s3));
+            // exact entries of the pivot rows of the diagonal block (from the scalar factorization)
+            const double lr0 = l4 == 0 ? dg[0] : 0.0;
+            const double lr1 = l4 == 0 ? l10 : (l4 == 1 ? dg[1] : 0.0);
+            const double lr2 = l4 == 0 ? l20 : (l4 == 1 ? l21 : (l4 == 2 ? dg[2] : 0.0));
+            const double lr3 = l4 == 0 ? l30 : (l4 == 1 ? l31 : (l4 == 2 ? l32 : dg[3]));
+            const double lpiv = ii == 0 ? lr0 : (ii == 1 ? lr1 : (ii == 2 ? lr2 : lr3));
+            const double vr1 = l4 == 0 ? P.c10 : (l4 == 1 ? dg[1] : 0.0);
+            const double vr2 = l4 == 0 ? P.c20 : (l4 == 1 ? P.c21 : (l4 == 2 ? dg[2] : 0.0));
+            const double vr3 = l4 == 0 ? P.c30 : (l4 == 1 ? P.c31 : (l4 == 2 ? P.c32 : dg[3]));
+            const double vpiv = ii == 0 ? lr0 : (ii == 1 ? vr1 : (ii == 2 ? vr2 : vr3));
+            // ---- 2. X_t^T = inv(L44) A_t^T for every block of block column b
+            double X[4], V[4];
+#pragma unroll
+            for (int cb = b; cb < 4; ++cb) {
+                const v4d out = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Lt[cb][b][tt], zero4, 0, 0, 0);
+                double v = out[tt];
+                double x = LDL ? v * ssel : v;
+                if (cb == b) {
+                    // rows above the pivot group: not part of the lower triangle; the pivot rows: exact values
+                    x = ii < 0 ? 0.0 : (ii < 4 ? lpiv : x);
+                    v = ii < 0 ? 0.0 : (ii < 4 ? (LDL ? vpiv : lpiv) : v);
+                }
+                X[cb] = x;
+                V[cb] = v;
+                Lt[cb][b][tt] = x;
+            }
+            // ---- 3. rank-4 update of the trailing blocks: acc(cb2, cb1) -= X[cb1] (V|X)[cb2]^T
+#pragma unroll
+            for (int cb1 = b; cb1 < 4; ++cb1) {
+                // columns up to the pivot group of block column b are final: no update (zero rows of the A operand)
+                const double na = (cb1 == b && l15 < 4 * tt + 4) ? 0.0 : -X[cb1];
+#pragma unroll
+                for (int cb2 = cb1; cb2 < 4; ++cb2)
+                    Lt[cb2][cb1] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, LDL ? V[cb2] : X[cb2], Lt[cb2][cb1], 0, 0, 0);
+            }
+        }
+        // ---- inverse of the 16x16 diagonal block (unit diagonal for LDL): Y = inv(L16), block forward substitution
+        {
+            v4d T, Y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[r] = (l15 == l4 + 4 * r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {
+                const v4d out = __builtin_amdgcn_mfma_f64_16x16x4f64(aopinv[pg], T[pg], zero4, 0, 0, 0);
+                Y[pg] = out[pg];
+                if (pg < 3) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lt[b][b][pg], Y[pg], T, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) inv16[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
+        }
+        // ---- store block column b of the factored block (column-major 64x64, lower part)
+#pragma unroll
+        for (int cb = b; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Lt[cb][b][r];
+                Dout[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
+            }
+    }
+}
+
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
 // One workgroup of 4 waves per block: thread (c, p) solves L x = e_c for the rows r = 4i + p by column-oriented
 // substitution; the owner of row k publishes x_k through LDS (one barrier per pivot, double-buffered), so every
@@ -528,8 +845,8 @@ using namespace mnk;
 // `rest_ready` (optional): event to wait for before the first kernel that touches the columns from
 // `rest_from` on (offset inside the panel, 64 or 256): the look-ahead delivers the outer panel's columns in
 // two pieces.
-static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
-                              hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
+static int factor_outer_panel_fused(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
+                                    hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
@@ -620,6 +937,72 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
     return 0;
 }
 
+// Split panel step (panel_algo = 1, the default), per 64-column block j of the outer panel [ko, kend):
+//   potrf64_kernel      one workgroup: the diagonal block (the pivot chain) + its 16x16 inverses
+//   trsm64_mfma_kernel  every row below it, block substitution on the matrix cores
+//   gemm_nt (lower)     recursive right-looking update inside the outer panel: after jj blocks are done, the next
+//                       w = 64 * lowbit(jj) columns receive the last w columns' contribution in ONE K = w product
+//                       (K = 64, 128, 64, 256, ...: the same flops as updating all remaining columns after every
+//                       block, in fewer, deeper products -- 2.3x less read-modify-write traffic on the panel).
+static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
+                              hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
+    if (ls->panel_algo == 0) return factor_outer_panel_fused(ls, s, ko, kend, wbase, rest_ready, rest_from);
+    const int64_t Np = ls->Np, ld = ls->ld;
+    const bool ldl = ls->algo == MNK_LDL;
+    double* F = ls->fact.p;
+    bool waited = rest_ready == nullptr;
+    for (int64_t j = ko; j < kend; j += NBI) {
+        double* dblk = ls->dblk.p + (j / NBI) * 4096;
+        double* inv16 = ls->inv16.p + (j / NBI) * 1024;
+        if (ls->panel_algo == 2) {  // 256-thread LDS/barrier diagonal-block kernel (A/B runs)
+            if (ldl)
+                hipLaunchKernelGGL(potrf64_kernel<true>, dim3(1), dim3(256), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
+                                   ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+            else
+                hipLaunchKernelGGL(potrf64_kernel<false>, dim3(1), dim3(256), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
+                                   ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+        } else if (ldl) {
+            hipLaunchKernelGGL(potrf64w_kernel<true>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
+                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+        } else {
+            hipLaunchKernelGGL(potrf64w_kernel<false>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
+                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+        }
+        const int64_t M = Np - j - NBI;
+        if (M <= 0) break;
+        // 16-row strips per wave: one while the panel is short (more workgroups, shortest chain), two beyond
+        const bool two = M / 64 > 2 * (int64_t)ls->ctx->num_cu;
+        const unsigned grid = (unsigned)((M / (two ? 32 : 16) + 3) / 4);
+#define MNK_TRSM(LD, NS)                                                                                          \
+    hipLaunchKernelGGL((trsm64_mfma_kernel<LD, NS>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk, inv16,    \
+                       ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0, j - ko, ls->info_dev.p)
+        if (ldl) { if (two) MNK_TRSM(true, 2); else MNK_TRSM(true, 1); }
+        else { if (two) MNK_TRSM(false, 2); else MNK_TRSM(false, 1); }
+#undef MNK_TRSM
+        const int64_t p1 = j + NBI;
+        if (p1 >= kend) break;
+        const int64_t jj = (p1 - ko) / NBI;            // blocks of this outer panel that are finished
+        const int64_t w = NBI * (jj & -jj);             // columns whose contribution is applied now
+        const int64_t p0 = p1 - w;
+        const int64_t ncols = std::min<int64_t>(w, kend - p1);
+        if (!waited && p1 + ncols > ko + rest_from) {  // first kernel that touches columns the caller delivers late
+            MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
+            waited = true;
+        }
+        const double* Wp = ldl ? wbase + p1 + (p0 - ko) * ls->ldw : F + p1 + p0 * ld;
+        int rc;
+        if (gemm_nt_lower_tiles(Np - p1, ncols) < ls->small_tiles_mid)
+            rc = launch_gemm_nt_lower_small(s, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
+                                            F + p1 + p1 * ld, ld, ls->info_dev.p);
+        else
+            rc = launch_gemm_nt(s, 2, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
+                                F + p1 + p1 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+        if (rc) return rc;
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // factorization driver (host orchestration; asynchronous)
 // ---------------------------------------------------------------------------------------
@@ -697,10 +1080,15 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             }
             MNK_HIP(hipMemsetAsync(ls->tile_ctr.p, 0, 8 * ((size_t)npanel + 1) * sizeof(int), s));
         }
+        // Panel 0 has nothing to overlap with: it runs on the caller's stream, i.e. on the whole chip (its
+        // triangular solves and inner updates are throughput-bound at this height), before the fork.
+        int rc = 0;
+        if (ls->panel0_whole) rc = factor_outer_panel(ls, s, 0, bnd[1], ls->wbuf[0].p);
+        if (rc) return rc;
         MNK_HIP(hipEventRecord(ctx->ev_a, s));
         MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
         MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
-        int rc = factor_outer_panel(ls, sp, 0, bnd[1], ls->wbuf[0].p);
+        if (!ls->panel0_whole) rc = factor_outer_panel(ls, sp, 0, bnd[1], ls->wbuf[0].p);
         if (rc) return rc;
         MNK_HIP(hipEventRecord(ctx->ev_panel[0], sp));
         for (int64_t k = 0; k + 1 < npanel; ++k) {

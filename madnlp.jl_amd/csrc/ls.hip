@@ -4,6 +4,7 @@
 // solve entry points.  See include/madnlp_hip.h for the per-function citations.
 #include <cstdarg>
 #include <cstdlib>
+#include <mutex>
 
 #include "ls.h"
 
@@ -64,6 +65,39 @@ __global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restri
 }  // namespace mnk
 
 using namespace mnk;
+
+static std::mutex g_ctx_mutex;
+
+static void ctx_free(mnk_ctx* c) {
+    (void)hipSetDevice(c->device);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_next2) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
+    if (c->sp) (void)hipStreamDestroy(c->sp);
+    if (c->su) (void)hipStreamDestroy(c->su);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void mnk_ctx_child_added(mnk_ctx* ctx) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    ++ctx->children;
+}
+
+void mnk_ctx_child_gone(mnk_ctx* ctx) {
+    if (!ctx) return;
+    bool free_now = false;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        --ctx->children;
+        free_now = ctx->released && ctx->children <= 0;
+    }
+    if (free_now) ctx_free(ctx);
+}
 
 bool mnk_ls_take_solve_abort(mnk_ls* ls) {
     if (!ls->solve_abort || *ls->solve_abort == 0) return false;
@@ -169,19 +203,17 @@ int mnk_ctx_create(int device, void* stream, mnk_ctx** out) { return ctx_create_
 
 int mnk_ctx_destroy(mnk_ctx* c) {
     if (!c) return 0;
-    (void)hipSetDevice(c->device);
-    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
-    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
-    for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_next2) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
-    if (c->sp) (void)hipStreamDestroy(c->sp);
-    if (c->su) (void)hipStreamDestroy(c->su);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-    delete c;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        if (c->children > 0) {  // a solver / KKT handle still points here: the last of them frees the context
+            c->released = true;
+            return 0;
+        }
+    }
+    ctx_free(c);
     return 0;
 }
+
 
 int mnk_ctx_synchronize(mnk_ctx* c) {
     MNK_REQUIRE(c != nullptr, "ctx is NULL");
@@ -211,6 +243,8 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_SINGLE_ROWS")) ls->single_rows = atol(e);
     if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
+    if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
+    if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
     ls->ldw = ls->Np;
@@ -218,6 +252,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     rc |= ls->fact.alloc((size_t)ls->ld * ls->Np + SLACK);
     rc |= ls->linv.alloc((size_t)(ls->Np / NBI) * NBI * NBI);
     rc |= ls->dblk.alloc((size_t)(ls->Np / NBI) * NBI * NBI);
+    rc |= ls->inv16.alloc((size_t)(ls->Np / NBI) * 1024);
     rc |= ls->linv256.alloc((size_t)((ls->Np + 255) / 256) * 65536);
     rc |= ls->linv256t.alloc((size_t)((ls->Np + 255) / 256) * 65536);
     rc |= ls->dvec.alloc(ls->Np);
@@ -234,6 +269,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     rc |= ls->inertia_dev.alloc(3);
     if (rc) { delete ls; return -2; }
     MNK_HIP(hipMemsetAsync(ls->fact.p, 0, ((size_t)ls->ld * ls->Np + SLACK) * sizeof(double), ctx->stream));
+    mnk_ctx_child_added(ctx);
     *out = ls;
     return 0;
 }
@@ -243,7 +279,9 @@ int mnk_ls_destroy(mnk_ls* ls) {
     (void)hipSetDevice(ls->ctx->device);
     (void)hipStreamSynchronize(ls->ctx->stream);
     if (ls->solve_abort) (void)hipHostFree(ls->solve_abort);
+    mnk_ctx* ctx = ls->ctx;
     delete ls;
+    mnk_ctx_child_gone(ctx);
     return 0;
 }
 
@@ -269,6 +307,9 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // 2: always (used by the schedule tests)
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
+    if (!strcmp(key, "small_tiles_mid")) { ls->small_tiles_mid = (int)value; return 0; }
+    // 1 (default): potrf64 + MFMA triangular solve + recursive inner updates; 0: the fused elimination kernel
+    if (!strcmp(key, "panel_algo")) { ls->panel_algo = (int)value; return 0; }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
     if (!strcmp(key, "ps_spin_limit")) {  // polls a persistent-solve wait may take before it gives up
         MNK_REQUIRE(value >= 1024.0, "ps_spin_limit must be at least 1024");

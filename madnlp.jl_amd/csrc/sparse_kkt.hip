@@ -322,6 +322,7 @@ int mnk_sc_create(mnk_ctx* ctx, int64_t n, int64_t m, int64_t nnzj, const int32_
     MNK_HIP(hipMemsetAsync(sc->h_nz.p, 0, sc->h_nz.n * sizeof(double), s));
     MNK_HIP(hipMemsetAsync(sc->aug_nz.p, 0, sc->aug_nz.n * sizeof(double), s));
     sc->extra = sp;
+    mnk_ctx_child_added(ctx);
     *out = sc;
     return 0;
 }
@@ -334,7 +335,9 @@ int mnk_sc_destroy(mnk_sc* sc) {
     }
     delete spmv_of(sc);
     sc->extra = nullptr;
+    mnk_ctx* ctx = sc->ctx;
     delete sc;
+    mnk_ctx_child_gone(ctx);
     return 0;
 }
 

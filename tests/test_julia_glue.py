@@ -1,0 +1,130 @@
+"""Static checks of julia/MadNLPHIP.jl against the C ABI (no Julia toolchain in the build image, so the
+glue cannot be executed here): every `ccall` must name a symbol declared in include/madnlp_hip.h with the
+same arity and the same C types; every option key it sets must be one mnk_ls_set_option accepts; the
+option defaults must equal the library's; INTEGRATION.md may only mention glue types that exist."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = open(os.path.join(ROOT, "julia", "MadNLPHIP.jl")).read()
+HDR = open(os.path.join(ROOT, "include", "madnlp_hip.h")).read()
+
+# Julia ccall type -> C type class
+JL_CLASS = {
+    "Cint": "int", "Int64": "int64", "Cdouble": "double", "Cstring": "cstr",
+    "Ptr{Cvoid}": "handle", "Ptr{Ptr{Cvoid}}": "handle_out", "Ptr{Cdouble}": "double*",
+    "Ptr{Int32}": "int32*", "Ptr{Int64}": "int64*", "Ptr{Cint}": "int*",
+}
+
+
+def c_class(decl: str) -> str:
+    d = re.sub(r"\bconst\b", "", decl).strip()
+    d = re.sub(r"\s+", " ", d)
+    # drop the parameter name
+    m = re.match(r"^(.*?[\*\s])([A-Za-z_][A-Za-z_0-9]*)$", d)
+    t = (m.group(1) if m else d).replace(" ", "")
+    table = {
+        "int": "int", "int64_t": "int64", "double": "double", "char*": "cstr", "void*": "handle",
+        "double*": "double*", "int32_t*": "int32*", "int64_t*": "int64*", "int*": "int*",
+        "unsignedlonglong*": "uint64*",
+    }
+    if re.match(r"^mnk_(ctx|sc|dc|ls)\*\*$", t):
+        return "handle_out"
+    if re.match(r"^mnk_(ctx|sc|dc|ls)\*$", t):
+        return "handle"
+    return table[t]
+
+
+def header_prototypes():
+    text = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(?:^|\n)\s*(const char\*|void\*|int64_t|int)\s+(mnk_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argl = [] if args in ("", "void") else [c_class(a) for a in args.split(",")]
+        protos[name] = ({"int": "int", "int64_t": "int64", "const char*": "cstr", "void*": "handle"}[ret], argl)
+    return protos
+
+
+def julia_ccalls():
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(mnk_[a-z_0-9]+),\s*libmadnlp_hip\),\s*([A-Za-z0-9{}]+),\s*\(([^)]*)\)", JL):
+        name, ret, args = m.group(1), m.group(2), m.group(3)
+        argl = [a.strip() for a in re.findall(r"Ptr\{Ptr\{Cvoid\}\}|Ptr\{[A-Za-z0-9]+\}|[A-Za-z0-9]+", args)]
+        calls.append((name, ret, argl))
+    return calls
+
+
+def test_every_ccall_matches_the_header():
+    protos = header_prototypes()
+    assert len(protos) >= 45, "header parse lost prototypes"
+    calls = julia_ccalls()
+    assert len(calls) >= 25, "ccall parse found too few calls"
+    for name, ret, args in calls:
+        assert name in protos, f"{name} is not declared in include/madnlp_hip.h"
+        cret, cargs = protos[name]
+        assert JL_CLASS[ret] == cret, (name, ret, cret)
+        assert len(args) == len(cargs), f"{name}: arity {len(args)} in Julia vs {len(cargs)} in C"
+        for k, (ja, ca) in enumerate(zip(args, cargs)):
+            assert JL_CLASS[ja] == ca, f"{name} argument {k}: Julia {ja} vs C {ca}"
+
+
+def test_header_prototypes_agree_with_the_ctypes_table():
+    """The same header is what the ctypes mirror binds: arity must agree there too."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, ROOT)
+    from madnlp_jl_amd._lib import SIGNATURES
+    protos = header_prototypes()
+    for name, (cret, cargs) in protos.items():
+        assert name in SIGNATURES, name
+        assert len(SIGNATURES[name][1]) == len(cargs), name
+    assert set(SIGNATURES) == set(protos)
+
+
+def test_glue_covers_the_kkt_contract():
+    """The types INTEGRATION.md advertises exist as real structs with the contract's methods
+    (reference src/KKT/KKTsystem.jl:104-256, docs/src/tutorials/diag_kkt.jl:6-215)."""
+    for t in ("HipSparseCondensedKKTSystem", "HipDenseCondensedKKTSystem"):
+        assert re.search(rf"^struct {t}\{{.*?<:\s*AbstractCondensedKKTSystem", JL, flags=re.M | re.S), t
+        assert re.search(rf"function MadNLP\.create_kkt_system\(\s*::Type\{{{t}\}}", JL), t
+        for meth in ("num_variables", "is_inertia_correct", "build_kkt!", "solve_kkt!", "jtprod!", "mul_hess_blk!",
+                     "nnz_jacobian", "compress_jacobian!"):
+            assert re.search(rf"MadNLP\.{re.escape(meth)}\([^)]*::{t}|MadNLP\.{re.escape(meth)}\([^)]*kkt::{t}", JL), (t, meth)
+        assert re.search(rf"function mul!\(w::AbstractKKTVector\{{T\}}, kkt::{t}", JL), t
+    assert re.search(r"^mutable struct HipLinearSolver\{T, MT\} <: AbstractLinearSolver\{T\}", JL, flags=re.M)
+    for meth in ("factorize!", "solve_linear_system!", "is_inertia", "inertia", "improve!", "introduce", "input_type",
+                 "default_options", "is_supported"):
+        assert f"MadNLP.{meth}(" in JL, meth
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for t in set(re.findall(r"MadNLPHIP\.([A-Z][A-Za-z]+)", integ)):
+        assert re.search(rf"\b(struct|function|const)\s+{t}\b|^{t}\(", JL, flags=re.M), f"INTEGRATION.md mentions MadNLPHIP.{t}"
+
+
+def test_option_keys_and_defaults_match_the_library():
+    ls_hip = open(os.path.join(ROOT, "madnlp.jl_amd", "csrc", "ls.hip")).read()
+    ls_h = open(os.path.join(ROOT, "madnlp.jl_amd", "csrc", "ls.h")).read()
+    accepted = set(re.findall(r'!strcmp\(key, "([a-z_0-9]+)"\)', ls_hip))
+    used = set(re.findall(r'set_option!\(h\[\], "([a-z_0-9]+)"', JL))
+    assert used and used <= accepted, used - accepted
+    # every set_option! result is checked (the helper throws on rc != 0)
+    assert "check(rc, SymbolicException)" in JL.split("function set_option!")[1].split("end")[0]
+    jl_defaults = dict(re.findall(r"^\s+([a-z_]+)::[A-Za-z0-9]+ = ([^\s#]+)", JL.split("struct HipSolverOptions")[1].split("\nend")[0], flags=re.M))
+    lib = {
+        "outer_block": re.search(r"nbo = (\d+)", ls_h).group(1),
+        "pivot_tol": re.search(r"pivot_tol = ([0-9.]+)", ls_h).group(1),
+        "lookahead": re.search(r"int lookahead = (\d)", ls_h).group(1),
+        "share": re.search(r"int share = (\d)", ls_h).group(1),
+        "persistent_solve": re.search(r"int persistent_solve = (\d)", ls_h).group(1),
+        "single_rows": re.search(r"single_rows = (\d+)", ls_h).group(1),
+    }
+    norm = lambda v: {"true": "1", "false": "0"}.get(v, v)  # noqa: E731
+    for k, v in lib.items():
+        assert float(norm(jl_defaults[k])) == float(v), (k, jl_defaults[k], v)
+    # the Python mirror's defaults agree as well
+    import sys
+    sys.path.insert(0, ROOT)
+    from madnlp_jl_amd.linear_solver import HipSolverOptions
+    o = HipSolverOptions()
+    assert (o.outer_block, int(o.lookahead), o.share, int(o.persistent_solve), o.single_rows, o.pivot_tol) == (
+        int(lib["outer_block"]), int(lib["lookahead"]), int(lib["share"]), int(lib["persistent_solve"]),
+        int(lib["single_rows"]), float(lib["pivot_tol"]))
