@@ -186,6 +186,15 @@ int mnk_ls_check_solve(mnk_ls* ls);
  * LDL unit-lower L with D returned separately) and D (N entries, may be NULL). */
 int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc);
 
+/* BUNCHKAUFMAN is served in two tiers: the static-pivot blocked LDL^T (fast path), and -- when that breaks down on
+ * a matrix that is not quasi-definite in the given order -- a Bunch-Kaufman factorization with 1x1 / 2x2 pivots and
+ * global partner search (dsytf2's strategy; option "bk_fallback", default 1), so that `inertia` follows the
+ * reference rule `num_neg_ev` (`src/LinearSolvers/lapack.jl:240-268`) on such systems too.  This reports which tier
+ * produced the current factor: *active = 1 if P A P^T = L D L^T with 2x2 blocks; *count = how many factorizations of
+ * this solver took the pivoted tier; perm (N entries: row i of the permuted matrix is row perm[i] of A, 0-based) and
+ * doff (N entries: sub-diagonal of D, non-zero at the first index of a 2x2 block) may be NULL. */
+int mnk_ls_bk_info(mnk_ls* ls, int* active, int* count, int32_t* perm, double* doff);
+
 /* ----------------------------------------------------------- utilities ------ */
 /* C (M x N) = / -= A (M x K) * B (N x K)^T on the fp64 MFMA tile kernel used by the
  * factorization's trailing update; exposed for unit tests and microbenchmarks.

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
-SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip"]
+SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip"]
 HEADERS = ["common.h", "ls.h", "kkt_vec.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
 
 MNK_HOST, MNK_DEVICE = 0, 1
@@ -93,6 +93,7 @@ SIGNATURES = {
     "mnk_ls_solve": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int]),
     "mnk_ls_check_solve": (C.c_int, [_vp]),
     "mnk_ls_get_factor": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "mnk_ls_bk_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp]),
     "mnk_sc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
     "mnk_sc_set_barrier_terms": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mnk_sc_solve_kkt": (C.c_int, [_vp, _vp, _vp, C.c_int]),

@@ -1191,6 +1191,23 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     }
     ls->factorized = true;
     ls->info_valid = false;
+    ls->bk_active = false;
+    return 0;
+}
+
+// Tier 2 of BUNCHKAUFMAN: fetch the matrix again, factor it with pivoting (bk.hip), rebuild the inverses the solves use.
+static int bk_fallback(mnk_ls* ls) {
+    hipStream_t s = ls->ctx->stream;
+    int rc = ls->retransfer();
+    if (rc) return rc;
+    rc = mnk_ls_run_bunchkaufman(ls);
+    if (rc) return rc;
+    hipLaunchKernelGGL(linv64_kernel<true>, dim3((unsigned)(ls->Np / NBI)), dim3(256), 0, s, ls->fact.p, ls->ld,
+                       ls->dblk.p, ls->linv.p, ls->info_dev.p);
+    MNK_HIP(hipGetLastError());
+    rc = mnk_ls_build_inverses(ls, s);
+    if (rc) return rc;
+    ++ls->bk_count;
     return 0;
 }
 
@@ -1198,6 +1215,23 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     if (ls->info_valid) return 0;
     hipStream_t s = ls->ctx->stream;
     MNK_HIP(hipMemsetAsync(ls->inertia_dev.p, 0, 3 * sizeof(unsigned long long), s));
+    if (ls->bk_active) {
+        // reference rule for a Bunch-Kaufman factor (src/LinearSolvers/lapack.jl:240-268): numzero = info > 0,
+        // numneg from the 1x1 / 2x2 blocks of D (-1 if a block is exactly singular), numpos the rest
+        int rc = mnk_ls_bk_inertia(ls, ls->inertia_dev.p);
+        if (rc) return rc;
+        unsigned long long h[3];
+        int hinfo = 0;
+        MNK_HIP(hipMemcpyAsync(h, ls->inertia_dev.p, sizeof(h), hipMemcpyDeviceToHost, s));
+        MNK_HIP(hipMemcpyAsync(&hinfo, ls->info_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        MNK_HIP(hipStreamSynchronize(s));
+        ls->info = hinfo;
+        ls->nneg = h[1] > 0 ? -1 : (int64_t)h[0];
+        ls->nzero = hinfo > 0 ? 1 : 0;
+        ls->npos = ls->N - ls->nneg - ls->nzero;
+        ls->info_valid = true;
+        return 0;
+    }
     if (ls->algo == MNK_LDL) {
         const int blocks = (int)std::min<int64_t>(256, (ls->N + 255) / 256);
         hipLaunchKernelGGL(inertia_kernel, dim3(blocks), dim3(256), 0, s, ls->dvec.p, ls->N, ls->inertia_dev.p);
@@ -1213,6 +1247,13 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         ls->nzero = (int64_t)h[1];
         ls->nneg = (int64_t)h[2];
         if (ls->nzero > 0 && ls->info == 0) ls->info = 1;  // LAPACK-style "singular D" signal
+        if (ls->nzero > 0 && ls->bk_requested && ls->bk_fallback && ls->retransfer) {
+            // the static-pivot factorization broke down on a matrix that is not quasi-definite in the given order:
+            // BUNCHKAUFMAN means dsytrf semantics, so factor it again with 1x1 / 2x2 pivoting
+            int rc = bk_fallback(ls);
+            if (rc) return rc;
+            return mnk_ls_fetch_info(ls);
+        }
     } else {
         // inertia_cholesky, reference src/LinearSolvers/lapack_common.jl:96-98
         if (hinfo == 0) { ls->npos = ls->N; ls->nzero = 0; ls->nneg = 0; }

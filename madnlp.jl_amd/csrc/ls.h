@@ -1,6 +1,7 @@
 // Internal layout of the opaque handles (shared by factor.hip, solve.hip, ls.hip, kkt units).
 #pragma once
 #include <algorithm>
+#include <functional>
 
 #include "common.h"
 
@@ -61,6 +62,15 @@ struct mnk_ls {
     mnk::DevBuf<unsigned long long> solve_trace;  // diagnostics: 8 time stamps per 64-row block (option solve_trace)
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
+    // Bunch-Kaufman tier (bk.hip): taken when BUNCHKAUFMAN was requested and the static-pivot factorization broke down
+    bool bk_requested = false;   // mnk_ls_create was called with MNK_BUNCHKAUFMAN (MNK_LDL: static pivoting only)
+    int bk_fallback = 1;         // option: 0 = never take the pivoted tier (a breakdown is reported as num_zero)
+    bool bk_active = false;      // the current factor is P A P^T = L D L^T with 2x2 blocks (solves use perm / dcoup)
+    int bk_count = 0;            // how many factorizations took the pivoted tier (diagnostics, tests)
+    std::function<int()> retransfer;  // puts the matrix of the last factorize! call back into `fact`
+    mnk::DevBuf<int> bk_perm, bk_ptype;
+    mnk::DevBuf<double> bk_doff, bk_dcoup;
+    mnk::DevBuf<char> bk_state;
     bool factorized = false, info_valid = false;
     int info = 0;
     int64_t npos = 0, nzero = 0, nneg = 0;
@@ -71,6 +81,10 @@ int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s);
+int mnk_ls_run_bunchkaufman(mnk_ls* ls);                                  // bk.hip
+int mnk_ls_bk_permute(mnk_ls* ls, double* x, double* tmp, bool forward);  // x <- P x (forward) / P^T x
+int mnk_ls_bk_dsolve(mnk_ls* ls, double* y);                              // y <- D^-1 y, 1x1 / 2x2 blocks
+int mnk_ls_bk_inertia(mnk_ls* ls, unsigned long long* out_dev);
 // after a stream synchronization: true (and the solver switched to the stepwise solve, abort word cleared) if a
 // persistent solve gave up since the last check
 bool mnk_ls_take_solve_abort(mnk_ls* ls);

@@ -226,14 +226,17 @@ void* mnk_ctx_stream(mnk_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     MNK_REQUIRE(ctx && out, "mnk_ls_create: NULL argument");
     MNK_REQUIRE(N > 0, "mnk_ls_create: N must be positive");
-    if (algo == MNK_BUNCHKAUFMAN) algo = MNK_LDL;
+    const bool bk_requested = algo == MNK_BUNCHKAUFMAN;
+    if (bk_requested) algo = MNK_LDL;  // tier 1: static-pivot blocked LDL^T; tier 2 on breakdown: bk.hip
     MNK_REQUIRE(algo == MNK_CHOLESKY || algo == MNK_LDL,
-                "mnk_ls_create: only CHOLESKY and LDL (alias BUNCHKAUFMAN) are implemented on device");
+                "mnk_ls_create: CHOLESKY, LDL and BUNCHKAUFMAN are implemented on device");
     MNK_HIP(hipSetDevice(ctx->device));
     mnk_ls* ls = new mnk_ls();
     ls->ctx = ctx;
     ls->N = N;
     ls->algo = algo;
+    ls->bk_requested = bk_requested;
+    if (const char* e = getenv("MNK_BK_FALLBACK")) ls->bk_fallback = atoi(e);
     if (const char* e = getenv("MNK_LOOKAHEAD")) ls->lookahead = atoi(e) != 0;  // tuning overrides
     if (const char* e = getenv("MNK_SHARE")) ls->share = atoi(e) != 0;
     if (const char* e = getenv("MNK_SMALL_TILES")) ls->small_tiles = atoi(e);
@@ -310,6 +313,9 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "small_tiles_mid")) { ls->small_tiles_mid = (int)value; return 0; }
     // 1 (default): potrf64 + MFMA triangular solve + recursive inner updates; 0: the fused elimination kernel
     if (!strcmp(key, "panel_algo")) { ls->panel_algo = (int)value; return 0; }
+    // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
+    // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
+    if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
     if (!strcmp(key, "ps_spin_limit")) {  // polls a persistent-solve wait may take before it gives up
         MNK_REQUIRE(value >= 1024.0, "ps_spin_limit must be at least 1024");
@@ -350,28 +356,44 @@ static int prepare_fill(mnk_ls* ls) {
     return 0;
 }
 
+static int transfer_sc(mnk_ls* ls, mnk_sc* sc) {
+    int rc = prepare_fill(ls);
+    if (rc) return rc;
+    const int64_t nnz = sc->nnz_aug;
+    hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
+                       ls->fact.p, ls->ld, sc->aug_row.p, sc->aug_col.p, sc->aug_nz.p, nnz);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
     MNK_REQUIRE(ls && sc && sc->ctx, "mnk_ls_factorize_sc: NULL argument or host-only handle");
     MNK_REQUIRE(sc->n == ls->N, "mnk_ls_factorize_sc: order mismatch");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     int rc = ensure_wbuf(ls);
     if (rc) return rc;
-    rc = prepare_fill(ls);
+    rc = transfer_sc(ls, sc);
     if (rc) return rc;
-    const int64_t nnz = sc->nnz_aug;
-    hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
-                       ls->fact.p, ls->ld, sc->aug_row.p, sc->aug_col.p, sc->aug_nz.p, nnz);
-    MNK_HIP(hipGetLastError());
+    // (the KKT handle keeps aug_com until the next build_kkt!, so the pivoted tier can fetch the matrix again when
+    // the inertia is asked for)
+    ls->retransfer = [ls, sc]() { return transfer_sc(ls, sc); };
     return mnk_ls_run_factorization(ls);
+}
+
+static int transfer_dense(mnk_ls* ls, const double* Adev, int64_t lda) {
+    dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np + 255) / 256));
+    hipLaunchKernelGGL(copy_lower_kernel, grid, dim3(256), 0, ls->ctx->stream, ls->fact.p, ls->ld, Adev, lda,
+                       ls->N, ls->Np);
+    MNK_HIP(hipGetLastError());
+    return 0;
 }
 
 static int factorize_dense_dev(mnk_ls* ls, const double* Adev, int64_t lda) {
     int rc = ensure_wbuf(ls);
     if (rc) return rc;
-    dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np + 255) / 256));
-    hipLaunchKernelGGL(copy_lower_kernel, grid, dim3(256), 0, ls->ctx->stream, ls->fact.p, ls->ld, Adev, lda,
-                       ls->N, ls->Np);
-    MNK_HIP(hipGetLastError());
+    rc = transfer_dense(ls, Adev, lda);
+    if (rc) return rc;
+    ls->retransfer = [ls, Adev, lda]() { return transfer_dense(ls, Adev, lda); };
     return mnk_ls_run_factorization(ls);
 }
 
@@ -414,8 +436,13 @@ int mnk_ls_factorize_dense(mnk_ls* ls, const double* A, int64_t lda, int loc, in
                                  ls->N, hipMemcpyHostToDevice, ls->ctx->stream));
         rc = factorize_dense_dev(ls, tmp.p, ls->N);
         MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+        if (!rc) rc = finish_info(ls, info);  // (a breakdown is handled while the staging buffer is alive)
+        ls->retransfer = nullptr;
+        return rc;
     }
-    return rc ? rc : finish_info(ls, info);
+    rc = rc ? rc : finish_info(ls, info);
+    ls->retransfer = nullptr;  // the caller's device buffer is only guaranteed for the duration of the call
+    return rc;
 }
 
 int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowval, const double* nzval,
@@ -440,16 +467,25 @@ int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowva
     if (rc) return -2;
     rc = ensure_wbuf(ls);
     if (rc) return rc;
-    rc = prepare_fill(ls);
+    auto transfer = [ls, nnz, &drow, &dcol, &dnz]() -> int {
+        int r = prepare_fill(ls);
+        if (r) return r;
+        if (nnz > 0)
+            hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
+                               ls->fact.p, ls->ld, drow.p, dcol.p, dnz.p, nnz);
+        MNK_HIP(hipGetLastError());
+        return 0;
+    };
+    rc = transfer();
     if (rc) return rc;
-    if (nnz > 0)
-        hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
-                           ls->fact.p, ls->ld, drow.p, dcol.p, dnz.p, nnz);
-    MNK_HIP(hipGetLastError());
+    ls->retransfer = transfer;
     rc = mnk_ls_run_factorization(ls);
-    if (rc) return rc;
-    MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
-    return finish_info(ls, info);
+    if (!rc) {
+        MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+        rc = finish_info(ls, info);
+    }
+    ls->retransfer = nullptr;  // the staging buffers die with this call
+    return rc;
 }
 
 int mnk_ls_inertia(mnk_ls* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg) {
@@ -543,6 +579,24 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
                              ls->N * sizeof(double), ls->N, kind, s));
     if (D) MNK_HIP(hipMemcpyAsync(D, ls->dvec.p, ls->N * sizeof(double), kind, s));
     MNK_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int mnk_ls_bk_info(mnk_ls* ls, int* active, int* count, int32_t* perm, double* doff) {
+    MNK_REQUIRE(ls, "mnk_ls_bk_info: NULL argument");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    if (ls->factorized) {
+        int rc = mnk_ls_fetch_info(ls);  // the tier is decided when the static factorization's pivots are known
+        if (rc) return rc;
+    }
+    if (active) *active = ls->bk_active ? 1 : 0;
+    if (count) *count = ls->bk_count;
+    if (ls->bk_active && (perm || doff)) {
+        hipStream_t s = ls->ctx->stream;
+        if (perm) MNK_HIP(hipMemcpyAsync(perm, ls->bk_perm.p, ls->N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (doff) MNK_HIP(hipMemcpyAsync(doff, ls->bk_doff.p, ls->N * sizeof(double), hipMemcpyDeviceToHost, s));
+        MNK_HIP(hipStreamSynchronize(s));
+    }
     return 0;
 }
 

@@ -533,7 +533,15 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
     const int ldl = ls->algo == MNK_LDL;
     const int64_t nb64 = Np / 64;
     const int G = (int)std::min<int64_t>(nb64, ls->ctx->num_cu);
-    if (ls->persistent_solve && G >= 1 && (nb64 + G - 1) / G <= PS_MAXOWN && (G >= 4 || nb64 <= G)) {
+    // Bunch-Kaufman factor (bk.hip): P A P^T = L D L^T with 2x2 blocks in D -- gather, stepwise unit-lower sweeps,
+    // block-diagonal D^-1, scatter (a 2x2 block may straddle two 64-row blocks, which the one-launch solve's
+    // block ownership does not allow)
+    const bool bk = ls->bk_active;
+    if (bk) {
+        int rc = mnk_ls_bk_permute(ls, xdev, xdev + 2 * Np, true);
+        if (rc) return rc;
+    }
+    if (!bk && ls->persistent_solve && G >= 1 && (nb64 + G - 1) / G <= PS_MAXOWN && (G >= 4 || nb64 <= G)) {
         // The kernel needs all its workgroups resident at once (one per CU).  Two of them launched
         // from different contexts could each grab part of the chip and wait for the rest forever, so
         // persistent solves of one process are chained on the device through an event.
@@ -575,7 +583,10 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
                                y, b, j0, ncol, Np);
     }
     // L D L^T: z = D^-1 y before the backward sweep
-    if (ldl)
+    if (bk) {
+        int rc = mnk_ls_bk_dsolve(ls, y);
+        if (rc) return rc;
+    } else if (ldl)
         hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, s, y, ls->dinv.p, Np);
     for (int64_t k = nsteps - 1; k >= 0; --k) {
         const int64_t j0 = k * SB;
@@ -587,5 +598,6 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
                                nrow);
     }
     MNK_HIP(hipGetLastError());
+    if (bk) return mnk_ls_bk_permute(ls, xdev, xdev + 2 * Np, false);
     return 0;
 }

@@ -255,6 +255,20 @@ class HipLinearSolver:
         if rc:
             raise SolveException(L.lib().mnk_last_error_string().decode())
 
+    def bk_info(self):
+        """Which tier produced the current factor (`mnk_ls_bk_info`): returns (active, count, perm, doff) --
+        `active`: the factor is P A P' = L D L' from the pivoted Bunch-Kaufman tier (2x2 blocks in D);
+        `count`: factorizations of this solver that took that tier; perm/doff are None unless active."""
+        act, cnt = C.c_int(0), C.c_int(0)
+        L.check(L.lib().mnk_ls_bk_info(self._h, C.byref(act), C.byref(cnt), None, None), "mnk_ls_bk_info")
+        if not act.value:
+            return False, cnt.value, None, None
+        perm = np.zeros(self.n, dtype=np.int32)
+        doff = np.zeros(self.n)
+        L.check(L.lib().mnk_ls_bk_info(self._h, C.byref(act), C.byref(cnt), perm.ctypes.data, doff.ctypes.data),
+                "mnk_ls_bk_info")
+        return True, cnt.value, perm, doff
+
     def set_option(self, key: str, value: float):
         L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(value)), "mnk_ls_set_option")
 
