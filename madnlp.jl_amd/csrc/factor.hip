@@ -20,6 +20,7 @@
 //   linv64_kernel (batched, once): inv(L_jj) of every diagonal block for the solves.
 // A device-side `info` word makes every later kernel a no-op once a pivot fails
 // (LAPACK stops at the failing column; we cannot stop the host without a sync).
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -631,12 +632,12 @@ __device__ __forceinline__ void factor_piv4_vals(const double p00, const double 
     }
 }
 
+// (one wave; `Lsh` / `Ish`: optional LDS copies of the factored block and of its four 16x16 inverses)
 template <bool LDL>
-__global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__ F, int64_t ld, int64_t j0,
-                                                       double* __restrict__ Dout, double* __restrict__ inv16,
-                                                       double* __restrict__ dvec, double* __restrict__ dinv,
-                                                       int* __restrict__ info, double pivot_tol) {
-    if (*info != 0) return;
+__device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
+                                              double* __restrict__ Dout, double* __restrict__ inv16,
+                                              double* __restrict__ dvec, double* __restrict__ dinv,
+                                              int* __restrict__ info, double pivot_tol, double* Lsh, double* Ish) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -748,7 +749,10 @@ __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__
                 if (pg < 3) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lt[b][b][pg], Y[pg], T, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) inv16[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
+            for (int r = 0; r < 4; ++r) {
+                inv16[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
+                if (Ish != nullptr) Ish[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
+            }
         }
         // ---- store block column b of the factored block (column-major 64x64, lower part)
 #pragma unroll
@@ -757,8 +761,199 @@ __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__
             for (int r = 0; r < 4; ++r) {
                 const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Lt[cb][b][r];
                 Dout[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
+                if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
             }
     }
+}
+
+template <bool LDL>
+__global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__ F, int64_t ld, int64_t j0,
+                                                       double* __restrict__ Dout, double* __restrict__ inv16,
+                                                       double* __restrict__ dvec, double* __restrict__ dinv,
+                                                       int* __restrict__ info, double pivot_tol) {
+    if (*info != 0) return;
+    potrf64w_body<LDL>(F, ld, j0, Dout, inv16, dvec, dinv, info, pivot_tol, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------
+// 256-column panel step (panel_algo = 3, the default): potrf256_kernel + trsm256_mfma_kernel.
+// One workgroup factors a whole 256x256 diagonal block: wave 0 runs the one-wave potrf64 above on each of its
+// four 64x64 diagonal tiles; between them all four waves do the triangular solves of the tiles below it
+// (block substitution on MFMA, operands from LDS) and the rank-64 updates of the block's trailing tiles
+// (acc -= X V^T on MFMA, the just-solved tiles kept in LDS).  That is four pivot chains and their in-block
+// updates in ONE launch instead of four rounds of {potrf64, trsm64, inner update} launches.
+// The rows below the block are then solved against the whole 256x256 factor in one launch
+// (trsm256_mfma_kernel): per 16-row strip, left-looking block substitution over sixteen 16-column blocks --
+// the K = 64 / 128 inner updates of the 64-column scheme happen inside the strip's registers.
+// ---------------------------------------------------------------------------------------
+constexpr int P256_LDS_BYTES = (4096 + 1024 + 3 * 4096) * 8;  // factored tile, its 16x16 inverses, V tiles of the column
+
+template <bool LDL>
+__global__ __launch_bounds__(256) void potrf256_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int nblk,
+                                                        double* __restrict__ Dblk, double* __restrict__ Inv16,
+                                                        double* __restrict__ W, int64_t ldw, int64_t wcol,
+                                                        double* __restrict__ dvec, double* __restrict__ dinv,
+                                                        int* __restrict__ info, double pivot_tol) {
+    extern __shared__ __attribute__((aligned(16))) char p256_smem[];
+    double* Ls = reinterpret_cast<double*>(p256_smem);   // [64 x 64] factored diagonal tile (L; d on the diagonal for LDL)
+    double* Is = Ls + 4096;                              // [4][16 x 16] inverses of its diagonal 16-blocks
+    double* Vs = Is + 1024;                              // [3][64 x 64] V = L D (LDL) / L (Cholesky) of the tiles below
+    if (*info != 0) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    for (int jb = 0; jb < nblk; ++jb) {
+        const int64_t jc = j0 + 64 * jb;  // first column of this 64-column block
+        if (wave == 0)
+            potrf64w_body<LDL>(F, ld, jc, Dblk + (int64_t)jb * 4096, Inv16 + (int64_t)jb * 1024, dvec, dinv, info,
+                               pivot_tol, Ls, Is);
+        __syncthreads();
+        const int nbel = nblk - 1 - jb;  // tiles below the diagonal tile inside the 256-block
+        if (nbel == 0) break;
+        // ---- triangular solve of the tiles below: strip = 16 rows; 4 * nbel strips over the four waves
+        {
+            double Ln[6][4], Iv[4][4];
+            int p = 0;
+#pragma unroll
+            for (int cb = 1; cb < 4; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < cb; ++ib, ++p)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Ln[p][s] = -Ls[(16 * cb + l15) + 64 * (16 * ib + 4 * s + l4)];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Iv[cb][s] = Is[cb * 256 + l15 + 16 * (4 * s + l4)];
+            for (int st = wave; st < 4 * nbel; st += 4) {
+                const int tile = st >> 2, sub = st & 3;  // tile below (0-based), 16-row strip inside it
+                const int64_t r0 = jc + 64 * (tile + 1) + 16 * sub;
+                v4d X[4];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) X[cb][r] = F[(r0 + l15) + (jc + 16 * cb + l4 + 4 * r) * ld];
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    v4d t = X[cb];
+#pragma unroll
+                    for (int ib = 0; ib < cb; ++ib) {
+                        const int q = cb * (cb - 1) / 2 + ib;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[q][s], X[ib][s], t, 0, 0, 0);
+                    }
+                    v4d x = zero4;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[cb][s], t[s], x, 0, 0, 0);
+                    X[cb] = x;
+                }
+                double* Vt = Vs + tile * 4096;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * cb + l4 + 4 * r;
+                        const double v = X[cb][r];
+                        Vt[(16 * sub + l15) + 64 * c] = v;
+                        if (LDL) {
+                            W[(r0 + l15) + (wcol + 64 * jb + c) * ldw] = v;
+                            F[(r0 + l15) + (jc + c) * ld] = v * dinv[jc + c];
+                        } else {
+                            F[(r0 + l15) + (jc + c) * ld] = v;
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- rank-64 update of the trailing tiles of the block: C(t2, t1) -= X(t1) V(t2)^T, t2 >= t1 (0-based below jb)
+        {
+            int task = 0;
+            for (int t1 = 0; t1 < nbel; ++t1)
+                for (int t2 = t1; t2 < nbel; ++t2)
+                    for (int sub = 0; sub < 4; ++sub, ++task) {
+                        if ((task & 3) != wave) continue;
+                        const int64_t rr = jc + 64 * (t2 + 1) + 16 * sub;  // rows of the strip
+                        const int64_t cc = jc + 64 * (t1 + 1);             // first column of the target tile
+                        v4d C[4];
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) C[cb][r] = F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld];
+                        const double* V1 = Vs + t1 * 4096;
+                        const double* V2 = Vs + t2 * 4096;
+#pragma unroll 4
+                        for (int s = 0; s < 16; ++s) {
+                            const double bop = V2[(16 * sub + l15) + 64 * (4 * s + l4)];
+                            const double sc = LDL ? -dinv[jc + 4 * s + l4] : -1.0;
+#pragma unroll
+                            for (int cb = 0; cb < 4; ++cb) {
+                                const double aop = V1[(16 * cb + l15) + 64 * (4 * s + l4)] * sc;
+                                C[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, C[cb], 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld] = C[cb][r];
+                    }
+        }
+        __syncthreads();
+    }
+}
+
+// Rows below a factored 256-column block: X = B L^-T by left-looking block substitution over NB16 = 4 nblk blocks
+// of 16 columns, one 16-row strip per wave, everything in the strip's registers.  L's 16x16 blocks come from the
+// factored diagonal tiles (Dblk, same 64-tile) or from the factor itself (F, tiles below the diagonal).
+template <bool LDL, int NBK /* 64-column blocks: 1..4 */>
+__global__ __launch_bounds__(256) void trsm256_mfma_kernel(double* __restrict__ F, int64_t ld, int64_t j0,
+                                                            int64_t Np, const double* __restrict__ Dblk,
+                                                            const double* __restrict__ Inv16,
+                                                            const double* __restrict__ dinv, double* __restrict__ W,
+                                                            int64_t ldw, int64_t wcol, const int* __restrict__ info) {
+    if (*info != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t r0 = j0 + 64 * (int64_t)NBK + ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (r0 >= Np) return;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    constexpr int NB16 = 4 * NBK;
+    v4d X[NB16];
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[cb][r] = F[(r0 + l15) + (j0 + 16 * cb + l4 + 4 * r) * ld];
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb) {
+        v4d t = X[cb];
+        const int tb = cb >> 2;  // 64-tile of this column block
+#pragma unroll
+        for (int ib = 0; ib < cb; ++ib) {
+            const int ti = ib >> 2;
+            // L[16 cb + i][16 ib + k]: inside the factored diagonal tile, or in a tile below the diagonal
+            const double* src = (ti == tb) ? Dblk + (int64_t)tb * 4096 + (16 * (cb & 3) + l15) + 64 * (16 * (ib & 3) + l4)
+                                           : F + (j0 + 16 * cb + l15) + (j0 + 16 * ib + l4) * ld;
+            const int64_t pitch = (ti == tb) ? 64 : ld;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                t = __builtin_amdgcn_mfma_f64_16x16x4f64(-src[(int64_t)(4 * s) * pitch], X[ib][s], t, 0, 0, 0);
+        }
+        const double* iv = Inv16 + (int64_t)tb * 1024 + (cb & 3) * 256 + l15 + 16 * l4;
+        v4d x = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[64 * s], t[s], x, 0, 0, 0);
+        X[cb] = x;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NB16; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * cb + l4 + 4 * r;
+            if (LDL) {
+                W[(r0 + l15) + (wcol + c) * ldw] = X[cb][r];
+                F[(r0 + l15) + (j0 + c) * ld] = X[cb][r] * dinv[j0 + c];
+            } else {
+                F[(r0 + l15) + (j0 + c) * ld] = X[cb][r];
+            }
+        }
 }
 
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
@@ -944,9 +1139,85 @@ static int factor_outer_panel_fused(mnk_ls* ls, hipStream_t s, int64_t ko, int64
 //                       w = 64 * lowbit(jj) columns receive the last w columns' contribution in ONE K = w product
 //                       (K = 64, 128, 64, 256, ...: the same flops as updating all remaining columns after every
 //                       block, in fewer, deeper products -- 2.3x less read-modify-write traffic on the panel).
+// 256-column panel step (panel_algo = 3): potrf256_kernel + trsm256_mfma_kernel per 256 columns, recursive
+// right-looking updates between 256-blocks (K = 256, 512, 256, 1024, ...).
+static int factor_outer_panel_256(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
+                                  hipEvent_t rest_ready, int64_t rest_from) {
+    const int64_t Np = ls->Np, ld = ls->ld;
+    const bool ldl = ls->algo == MNK_LDL;
+    double* F = ls->fact.p;
+    {   // 136 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        MNK_HIP(hipGetDevice(&dev));
+        if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+            MNK_HIP(hipFuncSetAttribute((const void*)potrf256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P256_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)potrf256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P256_LDS_BYTES));
+            attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
+    }
+    bool waited = rest_ready == nullptr;
+    for (int64_t j = ko; j < kend;) {
+        const int nblk = (int)std::min<int64_t>(4, (kend - j) / NBI);
+        if (!waited && j + NBI * nblk > ko + rest_from) {
+            MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
+            waited = true;
+        }
+        double* dblk = ls->dblk.p + (j / NBI) * 4096;
+        double* inv16 = ls->inv16.p + (j / NBI) * 1024;
+        if (ldl)
+            hipLaunchKernelGGL(potrf256_kernel<true>, dim3(1), dim3(256), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
+                               wbase, ls->ldw, j - ko, ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+        else
+            hipLaunchKernelGGL(potrf256_kernel<false>, dim3(1), dim3(256), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
+                               (double*)nullptr, (int64_t)0, (int64_t)0, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
+                               ls->pivot_tol);
+        const int64_t p1 = j + NBI * nblk;
+        const int64_t M = Np - p1;
+        if (M <= 0) break;
+        const unsigned grid = (unsigned)((M / 16 + 3) / 4);
+#define MNK_TRSM256(NB)                                                                                             \
+    do {                                                                                                            \
+        if (ldl)                                                                                                    \
+            hipLaunchKernelGGL((trsm256_mfma_kernel<true, NB>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk,   \
+                               inv16, ls->dinv.p, wbase, ls->ldw, j - ko, ls->info_dev.p);                          \
+        else                                                                                                        \
+            hipLaunchKernelGGL((trsm256_mfma_kernel<false, NB>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk,  \
+                               inv16, ls->dinv.p, (double*)nullptr, (int64_t)0, (int64_t)0, ls->info_dev.p);        \
+    } while (0)
+        if (nblk == 4) MNK_TRSM256(4);
+        else if (nblk == 3) MNK_TRSM256(3);
+        else if (nblk == 2) MNK_TRSM256(2);
+        else MNK_TRSM256(1);
+#undef MNK_TRSM256
+        if (p1 >= kend) break;
+        const int64_t q = (p1 - ko) / 256;               // finished 256-blocks (only the last one can be short)
+        const int64_t w = 256 * (q & -q);
+        const int64_t p0 = p1 - w;
+        const int64_t ncols = std::min<int64_t>(w, kend - p1);
+        if (!waited && p1 + ncols > ko + rest_from) {
+            MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
+            waited = true;
+        }
+        const double* Wp = ldl ? wbase + p1 + (p0 - ko) * ls->ldw : F + p1 + p0 * ld;
+        int rc;
+        if (gemm_nt_lower_tiles(Np - p1, ncols) < ls->small_tiles_256)
+            rc = launch_gemm_nt_lower_small(s, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
+                                            F + p1 + p1 * ld, ld, ls->info_dev.p);
+        else
+            rc = launch_gemm_nt(s, 2, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
+                                F + p1 + p1 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+        if (rc) return rc;
+        j = p1;
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
                               hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
     if (ls->panel_algo == 0) return factor_outer_panel_fused(ls, s, ko, kend, wbase, rest_ready, rest_from);
+    if (ls->panel_algo == 3) return factor_outer_panel_256(ls, s, ko, kend, wbase, rest_ready, rest_from);
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
@@ -1118,7 +1389,8 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             // behind panel k (no cross-stream hand-over before the next pivot block starts); the update stream
             // delivers the other columns while that block is being factored.  split_a == 1: first 256 columns
             // on the update stream, then the rest.
-            const bool own_first = ls->split_a == 2 && nnext > NBI;
+            // (the 256-column panel step needs the first 256 columns at once: they come from the update stream)
+            const bool own_first = ls->split_a == 2 && nnext > NBI && ls->panel_algo != 3;
             const int64_t n1 = own_first ? NBI : std::min<int64_t>(256, nnext);
             const bool split_a = ls->split_a && nnext > n1;
             if (own_first) {

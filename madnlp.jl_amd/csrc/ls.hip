@@ -248,6 +248,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
     if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
+    if (const char* e = getenv("MNK_SMALL_TILES_256")) ls->small_tiles_256 = atoi(e);
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
     ls->ldw = ls->Np;
@@ -311,7 +312,8 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
     if (!strcmp(key, "small_tiles_mid")) { ls->small_tiles_mid = (int)value; return 0; }
-    // 1 (default): potrf64 + MFMA triangular solve + recursive inner updates; 0: the fused elimination kernel
+    // 3 (default): potrf256 + trsm256 per 256 columns; 1: one-wave potrf64 + trsm64 + recursive inner updates per 64
+    // columns; 2: the same with the 256-thread LDS potrf64; 0: the fused elimination kernel of round 1
     if (!strcmp(key, "panel_algo")) { ls->panel_algo = (int)value; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
