@@ -776,7 +776,8 @@ __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// 256-column panel step (panel_algo = 3, the default): potrf256_kernel + trsm256_mfma_kernel.
+// 256-column panel step (panel_algo = 3; NOT the default -- measured: potrf256 102 us vs 4 x 16.4 us for the separate
+// potrf64 launches, trsm256 35-118 us; C3 13.2 ms against 12.5 ms for panel_algo = 1): potrf256_kernel + trsm256_mfma_kernel.
 // One workgroup factors a whole 256x256 diagonal block: wave 0 runs the one-wave potrf64 above on each of its
 // four 64x64 diagonal tiles; between them all four waves do the triangular solves of the tiles below it
 // (block substitution on MFMA, operands from LDS) and the rank-64 updates of the block's trailing tiles
@@ -786,32 +787,82 @@ __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__
 // (trsm256_mfma_kernel): per 16-row strip, left-looking block substitution over sixteen 16-column blocks --
 // the K = 64 / 128 inner updates of the 64-column scheme happen inside the strip's registers.
 // ---------------------------------------------------------------------------------------
-constexpr int P256_LDS_BYTES = (4096 + 1024 + 3 * 4096) * 8;  // factored tile, its 16x16 inverses, V tiles of the column
+constexpr int P256_VP = 80;  // pitch of a V tile in LDS: 16 mod 32 doubles, so the lanes of an operand read hit disjoint banks
+constexpr int P256_LDS_BYTES = (4096 + 1024 + 3 * 64 * P256_VP) * 8;  // factored tile, its 16x16 inverses, V tiles (= 160 KiB)
+constexpr int P256_NT = 256;  // 4 waves (512 VGPRs each: the pivot-chain body must not spill): wave 0 owns the pivot chains,
+                              // the other three hide the in-block updates behind them
+
+// one strip task of the in-block update: C(rows rr..rr+15, cols cc..cc+63) -= X(t1) V(t2)^T, operands from LDS
+template <bool LDL>
+__device__ __forceinline__ void p256_update_strip(double* __restrict__ F, int64_t ld, int64_t rr, int64_t cc,
+                                                  const double* V1, const double* V2, int sub,
+                                                  const double* __restrict__ dinvj, int l15, int l4) {
+    v4d C[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[cb][r] = F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld];
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+        const double bop = V2[(16 * sub + l15) + P256_VP * (4 * s + l4)];
+        const double sc = LDL ? -dinvj[4 * s + l4] : -1.0;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const double aop = V1[(16 * cb + l15) + P256_VP * (4 * s + l4)] * sc;
+            C[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, C[cb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld] = C[cb][r];
+}
 
 template <bool LDL>
-__global__ __launch_bounds__(256) void potrf256_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int nblk,
-                                                        double* __restrict__ Dblk, double* __restrict__ Inv16,
-                                                        double* __restrict__ W, int64_t ldw, int64_t wcol,
-                                                        double* __restrict__ dvec, double* __restrict__ dinv,
-                                                        int* __restrict__ info, double pivot_tol) {
+__global__ __launch_bounds__(P256_NT) void potrf256_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int nblk,
+                                                            double* __restrict__ Dblk, double* __restrict__ Inv16,
+                                                            double* __restrict__ W, int64_t ldw, int64_t wcol,
+                                                            double* __restrict__ dvec, double* __restrict__ dinv,
+                                                            int* __restrict__ info, double pivot_tol) {
     extern __shared__ __attribute__((aligned(16))) char p256_smem[];
     double* Ls = reinterpret_cast<double*>(p256_smem);   // [64 x 64] factored diagonal tile (L; d on the diagonal for LDL)
     double* Is = Ls + 4096;                              // [4][16 x 16] inverses of its diagonal 16-blocks
-    double* Vs = Is + 1024;                              // [3][64 x 64] V = L D (LDL) / L (Cholesky) of the tiles below
+    double* Vs = Is + 1024;                              // [3][64 x P256_VP] V = L D (LDL) / L (Cholesky) of the tiles below
     if (*info != 0) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int NW = P256_NT / 64, PRE = NW - 4;
     const int l15 = lane & 15, l4 = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    // Pending non-critical update tasks of the previous block column are finished by waves 1..7 while wave 0 runs the
+    // next pivot chain: (first task, tile count below) of the block column whose updates are still running.
+    int pend_jb = -1;
     for (int jb = 0; jb < nblk; ++jb) {
         const int64_t jc = j0 + 64 * jb;  // first column of this 64-column block
-        if (wave == 0)
+        if (wave == 0) {
             potrf64w_body<LDL>(F, ld, jc, Dblk + (int64_t)jb * 4096, Inv16 + (int64_t)jb * 1024, dvec, dinv, info,
                                pivot_tol, Ls, Is);
-        __syncthreads();
+        } else if (pend_jb >= 0) {
+            // the rest of the previous block column's updates: every tile except its first (done before the barrier)
+            const int pj = pend_jb, nb = nblk - 1 - pj;
+            const int64_t pc = j0 + 64 * pj;
+            int task = 0;
+            for (int t1 = 0; t1 < nb; ++t1)
+                for (int t2 = t1; t2 < nb; ++t2) {
+                    if (t1 == 0 && t2 == 0) continue;
+                    for (int sub = 0; sub < 4; ++sub, ++task) {
+                        // the first PRE tasks of this list were taken by waves 4.. before the barrier (none with 4 waves)
+                        if (task < PRE || (task - PRE) % (NW - 1) != wave - 1) continue;
+                        p256_update_strip<LDL>(F, ld, pc + 64 * (t2 + 1) + 16 * sub, pc + 64 * (t1 + 1),
+                                               Vs + t1 * 64 * P256_VP, Vs + t2 * 64 * P256_VP, sub, dinv + pc, l15, l4);
+                    }
+                }
+        }
+        __syncthreads();  // factored tile jb in LDS; every update of the previous block column is in memory
+        pend_jb = -1;
         const int nbel = nblk - 1 - jb;  // tiles below the diagonal tile inside the 256-block
         if (nbel == 0) break;
-        // ---- triangular solve of the tiles below: strip = 16 rows; 4 * nbel strips over the four waves
-        {
+        // ---- triangular solve of the tiles below: strip = 16 rows; 4 * nbel strips over the eight waves
+        if (wave < 4 * nbel) {
             double Ln[6][4], Iv[4][4];
             int p = 0;
 #pragma unroll
@@ -824,7 +875,7 @@ __global__ __launch_bounds__(256) void potrf256_kernel(double* __restrict__ F, i
             for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) Iv[cb][s] = Is[cb * 256 + l15 + 16 * (4 * s + l4)];
-            for (int st = wave; st < 4 * nbel; st += 4) {
+            for (int st = wave; st < 4 * nbel; st += NW) {
                 const int tile = st >> 2, sub = st & 3;  // tile below (0-based), 16-row strip inside it
                 const int64_t r0 = jc + 64 * (tile + 1) + 16 * sub;
                 v4d X[4];
@@ -846,14 +897,14 @@ __global__ __launch_bounds__(256) void potrf256_kernel(double* __restrict__ F, i
                     for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[cb][s], t[s], x, 0, 0, 0);
                     X[cb] = x;
                 }
-                double* Vt = Vs + tile * 4096;
+                double* Vt = Vs + tile * 64 * P256_VP;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int c = 16 * cb + l4 + 4 * r;
                         const double v = X[cb][r];
-                        Vt[(16 * sub + l15) + 64 * c] = v;
+                        Vt[(16 * sub + l15) + P256_VP * c] = v;
                         if (LDL) {
                             W[(r0 + l15) + (wcol + 64 * jb + c) * ldw] = v;
                             F[(r0 + l15) + (jc + c) * ld] = v * dinv[jc + c];
@@ -864,39 +915,24 @@ __global__ __launch_bounds__(256) void potrf256_kernel(double* __restrict__ F, i
             }
         }
         __syncthreads();
-        // ---- rank-64 update of the trailing tiles of the block: C(t2, t1) -= X(t1) V(t2)^T, t2 >= t1 (0-based below jb)
-        {
+        // ---- rank-64 updates of the block's trailing tiles, C(t2, t1) -= X(t1) V(t2)^T.  The next diagonal tile
+        // (t1 = t2 = 0) is on the critical path: waves 0..3 update its four strips now; waves 4..7 take the first
+        // four other strip tasks meanwhile; everything else overlaps the next pivot chain (top of the loop).
+        if (wave < 4) {
+            p256_update_strip<LDL>(F, ld, jc + 64 + 16 * wave, jc + 64, Vs, Vs, wave, dinv + jc, l15, l4);
+        } else {
             int task = 0;
-            for (int t1 = 0; t1 < nbel; ++t1)
-                for (int t2 = t1; t2 < nbel; ++t2)
-                    for (int sub = 0; sub < 4; ++sub, ++task) {
-                        if ((task & 3) != wave) continue;
-                        const int64_t rr = jc + 64 * (t2 + 1) + 16 * sub;  // rows of the strip
-                        const int64_t cc = jc + 64 * (t1 + 1);             // first column of the target tile
-                        v4d C[4];
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) C[cb][r] = F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld];
-                        const double* V1 = Vs + t1 * 4096;
-                        const double* V2 = Vs + t2 * 4096;
-#pragma unroll 4
-                        for (int s = 0; s < 16; ++s) {
-                            const double bop = V2[(16 * sub + l15) + 64 * (4 * s + l4)];
-                            const double sc = LDL ? -dinv[jc + 4 * s + l4] : -1.0;
-#pragma unroll
-                            for (int cb = 0; cb < 4; ++cb) {
-                                const double aop = V1[(16 * cb + l15) + 64 * (4 * s + l4)] * sc;
-                                C[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, C[cb], 0, 0, 0);
-                            }
-                        }
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld] = C[cb][r];
-                    }
+            for (int t1 = 0; t1 < nbel && task < PRE; ++t1)
+                for (int t2 = t1; t2 < nbel && task < PRE; ++t2) {
+                    if (t1 == 0 && t2 == 0) continue;
+                    for (int sub = 0; sub < 4 && task < PRE; ++sub, ++task)
+                        if (task == wave - 4)
+                            p256_update_strip<LDL>(F, ld, jc + 64 * (t2 + 1) + 16 * sub, jc + 64 * (t1 + 1),
+                                                   Vs + t1 * 64 * P256_VP, Vs + t2 * 64 * P256_VP, sub, dinv + jc, l15, l4);
+                }
         }
-        __syncthreads();
+        pend_jb = jb;
+        __syncthreads();  // the next diagonal tile is complete in memory
     }
 }
 
@@ -1166,10 +1202,10 @@ static int factor_outer_panel_256(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t
         double* dblk = ls->dblk.p + (j / NBI) * 4096;
         double* inv16 = ls->inv16.p + (j / NBI) * 1024;
         if (ldl)
-            hipLaunchKernelGGL(potrf256_kernel<true>, dim3(1), dim3(256), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
+            hipLaunchKernelGGL(potrf256_kernel<true>, dim3(1), dim3(P256_NT), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
                                wbase, ls->ldw, j - ko, ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
         else
-            hipLaunchKernelGGL(potrf256_kernel<false>, dim3(1), dim3(256), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
+            hipLaunchKernelGGL(potrf256_kernel<false>, dim3(1), dim3(P256_NT), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
                                (double*)nullptr, (int64_t)0, (int64_t)0, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
                                ls->pivot_tol);
         const int64_t p1 = j + NBI * nblk;

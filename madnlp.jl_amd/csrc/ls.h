@@ -55,7 +55,7 @@ struct mnk_ls {
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, inv16, linv256, linv256t, dvec, dinv, xwork;
     int panel0_whole = 1;  // look-ahead: the first outer panel is factored on the whole chip before the streams fork
     int small_tiles_256 = 160;  // panel_algo 3: inner K >= 256 updates with fewer 128x128 tiles than this use 64x64 tiles
-    int panel_algo = 3;  // 3: potrf256 + trsm256 per 256 columns; 1: potrf64 + MFMA triangular solve + recursive inner updates; 0: fused elimination kernel (round 1)
+    int panel_algo = 1;  // 3: potrf256 + trsm256 per 256 columns (measured slower, kept for A/B); 1: potrf64 + MFMA triangular solve + recursive inner updates; 0: fused elimination kernel (round 1)
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
     long ps_spin_limit = 6000000;  // polls (~0.5 us each) a persistent-solve wait may take before it gives up

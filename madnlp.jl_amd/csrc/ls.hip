@@ -312,8 +312,8 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
     if (!strcmp(key, "small_tiles_mid")) { ls->small_tiles_mid = (int)value; return 0; }
-    // 3 (default): potrf256 + trsm256 per 256 columns; 1: one-wave potrf64 + trsm64 + recursive inner updates per 64
-    // columns; 2: the same with the 256-thread LDS potrf64; 0: the fused elimination kernel of round 1
+    // 1 (default): one-wave potrf64 + trsm64 + recursive inner updates per 64 columns; 3: potrf256 + trsm256 per 256
+    // columns (one launch per four pivot chains; measured 5 % slower at N = 11192, kept for A/B runs); 2: the same with the 256-thread LDS potrf64; 0: the fused elimination kernel of round 1
     if (!strcmp(key, "panel_algo")) { ls->panel_algo = (int)value; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
