@@ -276,6 +276,52 @@ class HS15Model:
         return np.array([[h[0], h[1]], [h[1], h[2]]], order="F")
 
 
+class LootsmaModel:
+    """The reference's `lootsma` test problem (lib/MadNLPTests/src/MadNLPTests.jl:153-194), the fixed
+    variable par = 6 substituted:  min x1^3 + 11 x1 - 6 sqrt(x1) + x3  s.t.  -sqrt(x1) - sqrt(x2) + sqrt(x3) >= 0,
+    sqrt(x1) + sqrt(x2) + sqrt(x3) >= 4,  0 <= x <= 5,  x0 = 0.  The reference hard-codes the answers its own runs
+    must reproduce (`LOOTSMA_X`, `LOOTSMA_Y`, accepted at atol = rtol = sqrt(tol))."""
+    n, m = 3, 2
+    x0 = np.zeros(3)
+    y0 = np.zeros(2)
+    lvar = np.zeros(3)
+    uvar = 5.0 * np.ones(3)
+    lcon = np.array([0.0, 4.0])
+    ucon = np.array([np.inf, np.inf])
+    jac_I = np.array([0, 0, 0, 1, 1, 1])
+    jac_J = np.array([0, 1, 2, 0, 1, 2])
+    hess_I = np.array([0, 1, 2])
+    hess_J = np.array([0, 1, 2])
+    LOOTSMA_X = np.array([0.07415998565403112, 2.9848713863700236, 4.0000304145340415])   # MadNLPTests.jl:177
+    LOOTSMA_Y = np.array([-2.000024518601535, -2.0000305441119535])                       # MadNLPTests.jl:182
+
+    def obj(self, x):
+        return x[0] ** 3 + 11.0 * x[0] - 6.0 * np.sqrt(x[0]) + x[2]
+
+    def grad(self, x):
+        return np.array([3.0 * x[0] ** 2 + 11.0 - 3.0 / np.sqrt(x[0]), 0.0, 1.0])
+
+    def cons(self, x):
+        r = np.sqrt(x)
+        return np.array([-r[0] - r[1] + r[2], r[0] + r[1] + r[2]])
+
+    def jac_coord(self, x):
+        d = 0.5 / np.sqrt(x)
+        return np.array([-d[0], -d[1], d[2], d[0], d[1], d[2]])
+
+    def jac_dense(self, x):
+        d = 0.5 / np.sqrt(x)
+        return np.array([[-d[0], -d[1], d[2]], [d[0], d[1], d[2]]], order="F")
+
+    def hess_coord(self, x, y, w=1.0):
+        dd = -0.25 * x ** -1.5  # (sqrt)''
+        return np.array([w * (6.0 * x[0] + 1.5 * x[0] ** -1.5) + (-y[0] + y[1]) * dd[0], (-y[0] + y[1]) * dd[1],
+                         (y[0] + y[1]) * dd[2]])
+
+    def hess_dense(self, x, y, w=1.0):
+        return np.asfortranarray(np.diag(self.hess_coord(x, y, w)))
+
+
 class DenseQPModel:
     """min 0.5 x'Px + q'x  s.t. 0 <= x <= 1, gl <= Ax <= gu -- the reference's DenseDummyQP
     (lib/MadNLPTests/src/Instances/dummy_qp.jl) with our own seeded RNG."""

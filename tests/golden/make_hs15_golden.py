@@ -24,6 +24,7 @@ if __name__ == "__main__":
         "_source": "see tests/golden/make_hs15_golden.py",
         "pr_diag": [0.999, 1.0, 0.999, 0.999],
         "K_condensed_diag": [3.998, 201.0],
-        "solve_kkt_ones": [float(v) for v in sols[1]],
+        # NOT reference output: computed by the oracle restatement (see the header); pins HIP == oracle
+        "oracle_solve_kkt_ones": [float(v) for v in sols[1]],
     }
     json.dump(out, open(os.path.join(os.path.dirname(__file__), "hs15_kkt.json"), "w"), indent=1)

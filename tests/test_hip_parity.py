@@ -230,7 +230,7 @@ def test_kkt_system_hs15(ctx, kind):
     ni, mi, pi = kkt.linear_solver.inertia()
     assert kkt.is_inertia_correct(ni, mi, pi)
     gold = json.load(open(os.path.join(GOLDEN, "hs15_kkt.json")))
-    np.testing.assert_allclose(x.values, gold["solve_kkt_ones"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(x.values, gold["oracle_solve_kkt_ones"], rtol=1e-12, atol=1e-14)
     if kind == "dense_condensed":
         np.testing.assert_allclose(kkt.aug_com.to_host(), np.diag(gold["K_condensed_diag"]), rtol=1e-15)
     if kind == "sparse_condensed":

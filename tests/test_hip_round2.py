@@ -389,3 +389,20 @@ def test_dense_kkt_system_with_zero_dual_block_uses_pivoting(ctx):
     x = M.solve_linear_system(b.copy())
     assert np.abs(A @ x - b).max() <= 1e-11 * (np.abs(A).sum(axis=1).max() * np.abs(x).max() + 1)
     M.close()
+
+
+# --------------------------------------------------------------------------- lootsma: the reference's hard-coded answers
+@pytest.mark.parametrize("kind", ["dense", "dense_condensed", "sparse_condensed"])
+def test_ipm_lootsma_hip_reproduces_reference_answers(ctx, kind):
+    """The HIP back-end driven by the IPM mirror reaches the primal solution and multipliers the reference's own
+    test suite hard-codes for `lootsma` (lib/MadNLPTests/src/MadNLPTests.jl:175-194, atol = rtol = sqrt(tol)), with
+    the same iteration history as the CPU oracle (the reference's CPU == GPU acceptance)."""
+    from madnlp_jl_amd.problems import LootsmaModel
+    from tests.test_hip_parity import _assert_ipm_parity, _ipm_pair
+    nlp = LootsmaModel()
+    so, sh = _ipm_pair(kind, nlp, ctx, 1e-8 if kind != "sparse_condensed" else 1e-6)
+    _assert_ipm_parity(so, sh, 3)
+    tol = np.sqrt(sh.opt.tol)
+    cmp = lambda a, b: (np.abs(a - b).max() < tol) or (np.abs(a - b).max() / np.abs(b).max() < tol)  # noqa: E731
+    assert cmp(sh.x[:3], nlp.LOOTSMA_X) and cmp(sh.y, nlp.LOOTSMA_Y), (sh.x[:3], sh.y)
+    sh.kkt.close()

@@ -94,7 +94,7 @@ def test_kkt_system_hs15(kind):
     gold = json.load(open(os.path.join(GOLDEN, "hs15_kkt.json")))
     # pr_diag and condensed K for HS15.
     np.testing.assert_allclose(kkt.pr_diag - 1.0, np.array(gold["pr_diag"]), rtol=1e-15)
-    np.testing.assert_allclose(sol, np.array(gold["solve_kkt_ones"]), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(sol, np.array(gold["oracle_solve_kkt_ones"]), rtol=1e-12, atol=1e-14)
     if kind == "dense_condensed":
         np.testing.assert_allclose(kkt.aug_com, np.diag(gold["K_condensed_diag"]), rtol=1e-15)
     if kind == "sparse_condensed":
