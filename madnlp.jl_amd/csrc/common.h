@@ -84,6 +84,10 @@ struct mnk_ctx {
     bool own_stream = false;
     // look-ahead of the factorization: panel stream (high priority), update stream, fork/join events
     hipStream_t sp = nullptr, su = nullptr;
+    // companion streams for the diagonal-block kernels (potrf64), which overlap the inner updates: sq runs on the
+    // panel stream's CUs, sq0 on the whole chip (panel 0 and single-panel factorizations)
+    hipStream_t sq = nullptr, sq0 = nullptr;
+    hipEvent_t ev_q = nullptr;
     int panel_cus = 0;  // > 0: sp is restricted to this many CUs and su to the others (CU masks)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_next, ev_next2, ev_bdone;
@@ -108,9 +112,11 @@ namespace mnk {
 int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K,
                    const double* A, int64_t lda, const double* B, int64_t ldb,
                    double* C, int64_t ldc, const double* colscale, double* C2, int64_t ldc2,
-                   const int* info_flag);
+                   const int* info_flag, int* sig = nullptr, int sig_val = 0);
+// `sig` (optional): the workgroup of logical tile 0 stores sig_val there once its tile is complete in memory
 int launch_gemm_nt_lower_small(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
-                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag);
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag,
+                               int* sig = nullptr, int sig_val = 0);
 int gemm_nt_lower_tiles(int64_t M, int64_t N);
 int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double* C, int64_t ldc);

@@ -226,6 +226,35 @@ __device__ __forceinline__ void panel_phase4(double (&a)[T][16], double (*colbuf
 // ---------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// ---- device-side hand-offs between the diagonal-block kernels (companion stream) and the panel stream ----------
+// A flag holds the factorization's epoch once its producer is done.  Consumer: relaxed agent-scope polls by one
+// lane (or one uniform wave), ONE agent-scope acquire, then plain loads.  Every wait is bounded: a dependency that
+// never arrives (which would mean a scheduling assumption was violated) turns the factorization into a reported
+// failure (info = -7, every later kernel is a no-op) instead of a hang.
+constexpr long HANDOFF_SPIN_LIMIT = 1L << 23;
+__device__ __forceinline__ bool handoff_wait(const int* flag, int epoch, int* info) {
+    long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 1023) == 0) {
+            if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spins > HANDOFF_SPIN_LIMIT) {
+                atomicCAS(info, 0, -7);
+                return false;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+__device__ __forceinline__ void handoff_signal_wave(int* flag, int epoch) {
+    // one wave: its own stores -> agent-scope release -> drained flag store
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 template <bool LDL>
 __global__ __launch_bounds__(256) void potrf64_kernel(double* __restrict__ F, int64_t ld, int64_t j0,
                                                        double* __restrict__ Dout, double* __restrict__ inv16,
@@ -273,8 +302,15 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F
                                                            const double* __restrict__ Dblk,
                                                            const double* __restrict__ inv16,
                                                            const double* __restrict__ dinv, double* __restrict__ W,
-                                                           int64_t ldw, int64_t wcol, const int* __restrict__ info) {
+                                                           int64_t ldw, int64_t wcol, int* __restrict__ info,
+                                                           const int* __restrict__ wait_flag, int epoch) {
     if (*info != 0) return;
+    if (wait_flag != nullptr) {  // the diagonal block comes from the companion stream
+        __shared__ int ok;
+        if (threadIdx.x == 0) ok = handoff_wait(wait_flag, epoch, info) ? 1 : 0;
+        __syncthreads();
+        if (!ok) return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t r0 = j0 + 64 + ((int64_t)blockIdx.x * 4 + wave) * (16 * NS);
@@ -770,9 +806,14 @@ template <bool LDL>
 __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__ F, int64_t ld, int64_t j0,
                                                        double* __restrict__ Dout, double* __restrict__ inv16,
                                                        double* __restrict__ dvec, double* __restrict__ dinv,
-                                                       int* __restrict__ info, double pivot_tol) {
+                                                       int* __restrict__ info, double pivot_tol,
+                                                       const int* __restrict__ wait_flag, int* __restrict__ done_flag,
+                                                       int epoch) {
     if (*info != 0) return;
+    // wait_flag: "the diagonal tile is complete" from the update kernel still running on the panel stream
+    if (wait_flag != nullptr && !handoff_wait(wait_flag, epoch, info)) return;
     potrf64w_body<LDL>(F, ld, j0, Dout, inv16, dvec, dinv, info, pivot_tol, nullptr, nullptr);
+    if (done_flag != nullptr) handoff_signal_wave(done_flag, epoch);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1258,9 +1299,25 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
     bool waited = rest_ready == nullptr;
+    // Overlap (option "overlap"): from the second block of the panel on, potrf64 runs on a companion stream (same
+    // CUs) and starts as soon as the update kernel of the previous block has finished ITS tile 0 = the next
+    // diagonal block, instead of when that whole kernel has drained; the triangular solve then waits for the
+    // diagonal block through a flag.  flag_u[b] / flag_p[b]: block b's diagonal tile is updated / factored.
+    mnk_ctx* ctx = ls->ctx;
+    hipStream_t sq = s == ctx->sp ? ctx->sq : (s == ctx->stream ? ctx->sq0 : nullptr);
+    const bool overlap = ls->overlap && ls->panel_algo == 1 && sq != nullptr && kend - ko > NBI;
+    const int epoch = ls->epoch;
+    if (overlap) {
+        MNK_HIP(hipEventRecord(ctx->ev_q, s));  // the companion stream must not run ahead of this panel
+        MNK_HIP(hipStreamWaitEvent(sq, ctx->ev_q, 0));
+    }
     for (int64_t j = ko; j < kend; j += NBI) {
         double* dblk = ls->dblk.p + (j / NBI) * 4096;
         double* inv16 = ls->inv16.p + (j / NBI) * 1024;
+        const bool on_q = overlap && j > ko;
+        hipStream_t sd = on_q ? sq : s;
+        const int* wflag = on_q ? ls->flag_u.p + j / NBI : nullptr;
+        int* dflag = overlap ? ls->flag_p.p + j / NBI : nullptr;
         if (ls->panel_algo == 2) {  // 256-thread LDS/barrier diagonal-block kernel (A/B runs)
             if (ldl)
                 hipLaunchKernelGGL(potrf64_kernel<true>, dim3(1), dim3(256), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
@@ -1269,20 +1326,28 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
                 hipLaunchKernelGGL(potrf64_kernel<false>, dim3(1), dim3(256), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
                                    ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
         } else if (ldl) {
-            hipLaunchKernelGGL(potrf64w_kernel<true>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
-                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+            hipLaunchKernelGGL(potrf64w_kernel<true>, dim3(1), dim3(64), 0, sd, F, ld, j, dblk, inv16, ls->dvec.p,
+                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol, wflag, dflag, epoch);
         } else {
-            hipLaunchKernelGGL(potrf64w_kernel<false>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
-                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
+            hipLaunchKernelGGL(potrf64w_kernel<false>, dim3(1), dim3(64), 0, sd, F, ld, j, dblk, inv16, ls->dvec.p,
+                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol, wflag, dflag, epoch);
         }
         const int64_t M = Np - j - NBI;
-        if (M <= 0) break;
+        if (M <= 0) {
+            if (on_q) {  // nothing consumes the last diagonal block's flag: join the companion stream explicitly
+                MNK_HIP(hipEventRecord(ctx->ev_q, sq));
+                MNK_HIP(hipStreamWaitEvent(s, ctx->ev_q, 0));
+            }
+            break;
+        }
         // 16-row strips per wave: one while the panel is short (more workgroups, shortest chain), two beyond
         const bool two = M / 64 > 2 * (int64_t)ls->ctx->num_cu;
         const unsigned grid = (unsigned)((M / (two ? 32 : 16) + 3) / 4);
+        const int* tflag = overlap ? ls->flag_p.p + j / NBI : nullptr;
 #define MNK_TRSM(LD, NS)                                                                                          \
     hipLaunchKernelGGL((trsm64_mfma_kernel<LD, NS>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk, inv16,    \
-                       ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0, j - ko, ls->info_dev.p)
+                       ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0, j - ko, ls->info_dev.p, \
+                       tflag, epoch)
         if (ldl) { if (two) MNK_TRSM(true, 2); else MNK_TRSM(true, 1); }
         else { if (two) MNK_TRSM(false, 2); else MNK_TRSM(false, 1); }
 #undef MNK_TRSM
@@ -1297,13 +1362,14 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
             waited = true;
         }
         const double* Wp = ldl ? wbase + p1 + (p0 - ko) * ls->ldw : F + p1 + p0 * ld;
+        int* uflag = overlap ? ls->flag_u.p + p1 / NBI : nullptr;  // tile 0 of this update = diagonal tile of block p1
         int rc;
         if (gemm_nt_lower_tiles(Np - p1, ncols) < ls->small_tiles_mid)
             rc = launch_gemm_nt_lower_small(s, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
-                                            F + p1 + p1 * ld, ld, ls->info_dev.p);
+                                            F + p1 + p1 * ld, ld, ls->info_dev.p, uflag, epoch);
         else
             rc = launch_gemm_nt(s, 2, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
-                                F + p1 + p1 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
+                                F + p1 + p1 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p, uflag, epoch);
         if (rc) return rc;
     }
     MNK_HIP(hipGetLastError());
@@ -1328,6 +1394,12 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     double* F = ls->fact.p;
     const int64_t NBO = mnk_ls_effective_nbo(ls);
     MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));
+    if (ls->overlap && !ls->flag_u.p) {
+        if (ls->flag_u.alloc(Np / NBI + 1) || ls->flag_p.alloc(Np / NBI + 1)) return -2;
+        MNK_HIP(hipMemsetAsync(ls->flag_u.p, 0, (Np / NBI + 1) * sizeof(int), s));
+        MNK_HIP(hipMemsetAsync(ls->flag_p.p, 0, (Np / NBI + 1) * sizeof(int), s));
+    }
+    ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
     // chain, not by the update: narrower outer panels (tail_nbo) then drop the middle-level update and halve
     // the depth of the (a) piece the chain waits for (measured: 355 -> ~300 us per 512 columns of the tail).
@@ -1549,6 +1621,13 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     MNK_HIP(hipMemcpyAsync(h, ls->inertia_dev.p, sizeof(h), hipMemcpyDeviceToHost, s));
     MNK_HIP(hipMemcpyAsync(&hinfo, ls->info_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
     MNK_HIP(hipStreamSynchronize(s));
+    if (hinfo < 0) {
+        // a bounded device-side wait between the diagonal-block stream and the panel stream expired (see handoff_wait)
+        set_error("factorize!: a device-side hand-off timed out (info = %d); the factor is invalid -- retry with option "
+                  "overlap = 0", hinfo);
+        ls->overlap = 0;
+        return -4;
+    }
     ls->info = hinfo;
     if (ls->algo == MNK_LDL) {
         ls->npos = (int64_t)h[0];

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_ke
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
     const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
-    const int* __restrict__ info_flag, int tile_off) {
+    const int* __restrict__ info_flag, int tile_off, int* sig, int sig_val) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (info_flag != nullptr && *info_flag != 0) return;
 
@@ -249,6 +249,17 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_ke
     decode_tile<MODE>(logical, ntm, tm, tn);
     gemm_nt_tile<WM, WN, WT, MODE, LDL_EPI, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, colscale,
                                                                        C2, ldc2, smem_raw);
+    // Optional hand-off: the workgroup that owns logical tile 0 (the next diagonal block of the factorization)
+    // publishes "tile 0 is complete in memory" so that the next potrf64 can start while the other tiles are still
+    // being updated: stores -> barrier -> one lane's agent-scope release -> drained flag store.
+    if (sig != nullptr && logical == 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(sig, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <int WM, int WN, int WT, int MODE, int DBG>
@@ -300,7 +311,8 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_qu
 template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
 static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                     const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
-                    double* C2, int64_t ldc2, const int* info_flag, int tile_begin = 0, int tile_count = -1) {
+                    double* C2, int64_t ldc2, const int* info_flag, int tile_begin = 0, int tile_count = -1,
+                    int* sig = nullptr, int sig_val = 0) {
     constexpr int BM = 16 * WT * WM, BN = 16 * WT * WN;
     const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
     int ntiles = ntm * ntn;
@@ -322,14 +334,14 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
     if (tile_count >= 0) ntiles = std::min(ntiles - tile_begin, tile_count);
     if (ntiles <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, s, M, N, K, A, lda, B, ldb, C,
-                       ldc, colscale, C2, ldc2, ntm, info_flag, tile_begin);
+                       ldc, colscale, C2, ldc2, ntm, info_flag, tile_begin, sig, sig_val);
     MNK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
-                   double* C2, int64_t ldc2, const int* info_flag) {
+                   double* C2, int64_t ldc2, const int* info_flag, int* sig, int sig_val) {
     if (M <= 0 || N <= 0) return 0;
     MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
     if (mode == 1) {
@@ -352,7 +364,8 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, con
         return launch_t<2, 2, 4, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
     }
     if (mode == 2) {
-        return launch_t<2, 2, 4, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+        return launch_t<2, 2, 4, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag, 0, -1, sig,
+                                           sig_val);
     }
     if (mode == 4) {
         return launch_t<2, 2, 4, 4, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
@@ -365,10 +378,12 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, con
 // 128x128 tiling, for updates with too few tiles to fill the chip (latency-bound tail of the
 // factorization).
 int launch_gemm_nt_lower_small(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
-                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag) {
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag, int* sig,
+                               int sig_val) {
     if (M <= 0 || N <= 0) return 0;
     MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
-    return launch_t<2, 2, 2, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
+    return launch_t<2, 2, 2, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag, 0, -1, sig,
+                                       sig_val);
 }
 
 // a contiguous range of the lower tiles of the 128x128 tiling (mode 2), for chunked launches

@@ -53,6 +53,9 @@ struct mnk_ls {
     int small_tiles_mid = 1000;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, inv16, linv256, linv256t, dvec, dinv, xwork;
+    int overlap = 1;  // panel_algo 1: potrf64 on a companion stream, started by a flag from the update kernel's tile 0
+    int epoch = 0;    // value the hand-off flags of the current factorization carry
+    mnk::DevBuf<int> flag_u, flag_p;
     int panel0_whole = 1;  // look-ahead: the first outer panel is factored on the whole chip before the streams fork
     int small_tiles_256 = 160;  // panel_algo 3: inner K >= 256 updates with fewer 128x128 tiles than this use 64x64 tiles
     int panel_algo = 1;  // 3: potrf256 + trsm256 per 256 columns (measured slower, kept for A/B); 1: potrf64 + MFMA triangular solve + recursive inner updates; 0: fused elimination kernel (round 1)

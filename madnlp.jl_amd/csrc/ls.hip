@@ -76,6 +76,9 @@ static void ctx_free(mnk_ctx* c) {
     for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_next2) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
+    if (c->ev_q) (void)hipEventDestroy(c->ev_q);
+    if (c->sq) (void)hipStreamDestroy(c->sq);
+    if (c->sq0) (void)hipStreamDestroy(c->sq0);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -193,6 +196,17 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
         MNK_HIP(hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, prio_hi));
         MNK_HIP(hipStreamCreateWithPriority(&c->su, hipStreamNonBlocking, prio_lo));
     }
+    // companion streams of the diagonal-block kernels: same CU set as the panel stream / the whole chip
+    if (c->panel_cus > 0) {
+        if (!make_masked_stream(total, bits.data(), c->panel_cus, c->sq)) c->sq = nullptr;
+    }
+    if (!c->sq) {
+        int prio_lo = 0, prio_hi = 0;
+        MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MNK_HIP(hipStreamCreateWithPriority(&c->sq, hipStreamNonBlocking, prio_hi));
+    }
+    MNK_HIP(hipStreamCreateWithFlags(&c->sq0, hipStreamNonBlocking));
+    MNK_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
     *out = c;
@@ -248,6 +262,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
     if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
+    if (const char* e = getenv("MNK_OVERLAP")) ls->overlap = atoi(e);
     if (const char* e = getenv("MNK_SMALL_TILES_256")) ls->small_tiles_256 = atoi(e);
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
@@ -318,6 +333,8 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
+    // 1 (default): potrf64 overlaps the inner update of the previous block (companion stream + device flags)
+    if (!strcmp(key, "overlap")) { ls->overlap = (int)value; return 0; }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
     if (!strcmp(key, "ps_spin_limit")) {  // polls a persistent-solve wait may take before it gives up
         MNK_REQUIRE(value >= 1024.0, "ps_spin_limit must be at least 1024");
