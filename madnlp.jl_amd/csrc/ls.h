@@ -53,7 +53,9 @@ struct mnk_ls {
     int small_tiles_mid = 1000;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, inv16, linv256, linv256t, dvec, dinv, xwork;
-    int overlap = 1;  // panel_algo 1: potrf64 on a companion stream, started by a flag from the update kernel's tile 0
+    int overlap = 0;  // panel_algo 1: potrf64 on a companion stream, started by a flag from the update kernel's tile 0
+                      // (measured: no gain at N = 11192, 12.51 vs 12.61 ms, and 2x slower at N = 2048 -- cross-queue dispatch
+                      // latency eats the overlap; off by default)
     int epoch = 0;    // value the hand-off flags of the current factorization carry
     mnk::DevBuf<int> flag_u, flag_p;
     int panel0_whole = 1;  // look-ahead: the first outer panel is factored on the whole chip before the streams fork

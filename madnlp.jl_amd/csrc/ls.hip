@@ -333,7 +333,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
-    // 1 (default): potrf64 overlaps the inner update of the previous block (companion stream + device flags)
+    // 1: potrf64 overlaps the inner update of the previous block (companion stream + device flags); default 0 (no gain measured)
     if (!strcmp(key, "overlap")) { ls->overlap = (int)value; return 0; }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
     if (!strcmp(key, "ps_spin_limit")) {  // polls a persistent-solve wait may take before it gives up
