@@ -230,6 +230,34 @@ int mnk_dc_set_barrier_terms(mnk_dc* dc, const double* reg, const double* l_diag
 int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc);
 int mnk_dc_mul(mnk_dc* dc, double* w, const double* x, double alpha, double beta, int loc);
 
+/* ---- dense S stage of the Schur-complement KKT system ----------------------------------------------
+ * Reference: `SchurComplementKKTSystem` src/KKT/Schur/schur.jl -- `build_kkt!` :927-1001 (phase 1: factor every
+ * scenario block A_k and form A_k^-1 C_dk'; phase 2: S -= C_dk A_k^-1 C_dk'), `factorize_kkt!` :1003-1005, steps 3-5 of
+ * `solve_kkt!` :1040-1058.  Scenario blocks arrive DENSE here (the reference factors them with a sparse solver per
+ * scenario, which is outside this path); A_k (blk x blk, lower triangle read, symmetric indefinite), C_dk (nd x blk).
+ * Scenarios are sharded over the ranks of a multi-GPU job: a handle holds the ns_local scenarios of ONE rank.
+ *   mnk_schur_build_local  S_out = S0 - sum_{local k} C_dk A_k^-1 C_dk'   (S0 = H_dd + Sigma_dd + inequality terms on
+ *                          the rank that owns it, NULL elsewhere); S_out is caller-owned DEVICE memory, nd x nd; the
+ *                          caller sums the ranks' contributions with ONE all-reduce (RCCL), then
+ *   mnk_schur_factorize_s  every rank factors S with the dense solver; mnk_schur_inertia_s: reference
+ *                          `is_inertia_correct` :901-903 wants (nd, 0, 0)
+ *   mnk_schur_forward      r_k <- A_k^-1 r_k (rhs_k: ns_local x blk, device) and contrib_d = -sum_k C_dk r_k (nd, device):
+ *                          the caller adds r_d and all-reduces nd doubles
+ *   mnk_schur_solve_s      S x_d = r_d
+ *   mnk_schur_backward     x_k = r_k - (A_k^-1 C_dk') x_d */
+typedef struct mnk_schur mnk_schur;
+int mnk_schur_create(mnk_ctx* ctx, int64_t ns_local, int64_t blk, int64_t nd, int algo, mnk_schur** out);
+int mnk_schur_destroy(mnk_schur* h);
+int mnk_schur_set_block(mnk_schur* h, int64_t k, const double* A_kk, int64_t lda, const double* C_dk, int64_t ldc,
+                        int loc);
+int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_s0, double* S_out, int64_t lds_out);
+int mnk_schur_factorize_s(mnk_schur* h, const double* S, int64_t lds, int loc, int* info);
+int mnk_schur_inertia_s(mnk_schur* h, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg);
+int mnk_schur_scenario_inertia(mnk_schur* h, int64_t k, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg);
+int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d);
+int mnk_schur_solve_s(mnk_schur* h, double* rhs_d);
+int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d);
+
 /* Diagnostics: with option "solve_trace" = 1 the persistent solve kernel stamps the forward sweep's critical
  * path (8 x 100 MHz timer values per 64-row block); this copies them out (n = number of uint64 to copy). */
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);

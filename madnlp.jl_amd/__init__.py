@@ -16,3 +16,4 @@ from .kkt import (  # noqa: F401
 from .backsolve import RichardsonIterator  # noqa: F401
 
 __version__ = "0.1.0"
+from .schur import SchurDenseStage  # noqa: F401,E402

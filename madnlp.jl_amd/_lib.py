@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
-SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip"]
+SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip"]
 HEADERS = ["common.h", "ls.h", "kkt_vec.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
 
 MNK_HOST, MNK_DEVICE = 0, 1
@@ -102,6 +102,16 @@ SIGNATURES = {
     "mnk_dc_set_barrier_terms": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mnk_dc_solve_kkt": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mnk_dc_mul": (C.c_int, [_vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
+    "mnk_schur_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(_vp)]),
+    "mnk_schur_destroy": (C.c_int, [_vp]),
+    "mnk_schur_set_block": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int64, C.c_int]),
+    "mnk_schur_build_local": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, C.c_int64]),
+    "mnk_schur_factorize_s": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
+    "mnk_schur_inertia_s": (C.c_int, [_vp, _i64p, _i64p, _i64p]),
+    "mnk_schur_scenario_inertia": (C.c_int, [_vp, C.c_int64, _i64p, _i64p, _i64p]),
+    "mnk_schur_forward": (C.c_int, [_vp, _vp, _vp]),
+    "mnk_schur_solve_s": (C.c_int, [_vp, _vp]),
+    "mnk_schur_backward": (C.c_int, [_vp, _vp, _vp]),
     "mnk_ls_debug_solve_trace": (C.c_int, [_vp, _vp, C.c_int64]),
     "mnk_debug_update": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int,
                                    C.POINTER(C.c_double)]),

@@ -1,0 +1,223 @@
+// Dense `S` stage of the Schur-complement KKT system (reference src/KKT/Schur/schur.jl:927-1001 `build_kkt!`,
+// :1003-1005 `factorize_kkt!`, :1040-1065 steps 3-5 of `solve_kkt!`): SURVEY 8(f).3.
+//
+// Two-stage structure: ns scenario blocks A_k (blk x blk, symmetric indefinite) coupled to nd design variables by
+// dense C_dk (nd x blk); the Schur complement the dense linear solver sees is
+//       S = S0 - sum_k C_dk A_k^-1 C_dk',        S0 = H_dd + Sigma_dd + inequality terms,
+// and a solve is   r_k <- A_k^-1 r_k ;  r_d <- r_d - sum_k C_dk r_k ;  S x_d = r_d ;  x_k = r_k - (A_k^-1 C_dk') x_d.
+// The reference factors the A_k with a sparse solver per scenario (MUMPS; sparse direct solvers are out of this
+// path's scope); here the scenario blocks arrive dense and are factored by the same blocked fp64-MFMA factorization
+// as S itself (BUNCHKAUFMAN tiers: the blocks are indefinite), T_k = A_k^-1 C_dk' by its multi-right-hand-side solve,
+// and the accumulation S -= C_dk T_k on the MFMA tile kernel.
+//
+// Multi-GPU: scenarios are sharded over the ranks.  mnk_schur_build_local produces THIS rank's contribution
+// (S0 on the rank that owns it, minus its scenarios' terms) into a caller-owned device buffer; the caller sums the
+// contributions with ONE all-reduce of nd^2 doubles (RCCL over xGMI) and every rank factors S; a solve needs one more
+// all-reduce of nd doubles (mnk_schur_forward's contribution).  The library itself does no communication.
+#include <vector>
+
+#include "ls.h"
+
+struct mnk_schur {
+    mnk_ctx* ctx = nullptr;
+    int64_t ns = 0, blk = 0, nd = 0, ndp = 0, blkp = 0;
+    int algo = MNK_BUNCHKAUFMAN;
+    mnk::DevBuf<double> A;    // ns x (blk x blk)   scenario blocks (lower triangle read)
+    mnk::DevBuf<double> C;    // ns x (nd x blk)    coupling blocks
+    mnk::DevBuf<double> T;    // ns x (blk x nd)    A_k^-1 C_dk'
+    mnk::DevBuf<double> Cp;   // ndp x blkp  zero-padded copy of one C_dk   (MFMA operand)
+    mnk::DevBuf<double> Tt;   // ndp x blkp  zero-padded T_k'               (MFMA operand)
+    mnk::DevBuf<double> Sp;   // ndp x ndp   accumulator
+    std::vector<mnk_ls*> ls_k;
+    mnk_ls* ls_s = nullptr;
+    std::vector<int> info_k;
+    bool built = false;
+};
+
+namespace mnk {
+
+// dst (rows_d x cols_d, ld ldd; zero padding beyond the source) = src' or src
+__global__ void schur_copy_kernel(double* __restrict__ dst, int64_t ldd, int64_t rows_d, int64_t cols_d,
+                                  const double* __restrict__ src, int64_t lds, int64_t rows_s, int64_t cols_s, int trans) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= rows_d * cols_d) return;
+    const int64_t r = e % rows_d, c = e / rows_d;
+    double v = 0.0;
+    if (trans) { if (c < rows_s && r < cols_s) v = src[c + r * lds]; }   // dst[r][c] = src[c][r]
+    else { if (r < rows_s && c < cols_s) v = src[r + c * lds]; }
+    dst[r + c * ldd] = v;
+}
+
+// y[r] += alpha * sum_c A[r + c*lda] x[c]   (rows x cols, fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void schur_gemv_kernel(double* __restrict__ y, const double* __restrict__ A, int64_t lda,
+                                                         const double* __restrict__ x, int64_t rows, int64_t cols, double alpha) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t c = 0;
+    for (; c + 1 < cols; c += 2) {
+        s0 = fma(A[r + c * lda], x[c], s0);
+        s1 = fma(A[r + (c + 1) * lda], x[c + 1], s1);
+    }
+    if (c < cols) s0 = fma(A[r + c * lda], x[c], s0);
+    y[r] += alpha * (s0 + s1);
+}
+
+}  // namespace mnk
+
+using namespace mnk;
+
+extern "C" {
+
+int mnk_schur_create(mnk_ctx* ctx, int64_t ns_local, int64_t blk, int64_t nd, int algo, mnk_schur** out) {
+    MNK_REQUIRE(ctx && out, "mnk_schur_create: NULL argument");
+    MNK_REQUIRE(ns_local >= 0 && blk > 0 && nd > 0, "mnk_schur_create: bad dimensions");
+    MNK_HIP(hipSetDevice(ctx->device));
+    mnk_schur* h = new mnk_schur();
+    h->ctx = ctx;
+    h->ns = ns_local; h->blk = blk; h->nd = nd; h->algo = algo;
+    h->ndp = round_up(nd, 64);
+    h->blkp = round_up(blk, 16);
+    int rc = 0;
+    rc |= h->A.alloc((size_t)std::max<int64_t>(ns_local, 1) * blk * blk);
+    rc |= h->C.alloc((size_t)std::max<int64_t>(ns_local, 1) * nd * blk);
+    rc |= h->T.alloc((size_t)std::max<int64_t>(ns_local, 1) * blk * nd);
+    rc |= h->Cp.alloc((size_t)h->ndp * h->blkp + SLACK);
+    rc |= h->Tt.alloc((size_t)h->ndp * h->blkp + SLACK);
+    rc |= h->Sp.alloc((size_t)h->ndp * h->ndp + SLACK);
+    if (rc) { delete h; return -2; }
+    for (int64_t k = 0; k < ns_local && !rc; ++k) {
+        mnk_ls* ls = nullptr;
+        rc = mnk_ls_create(ctx, blk, algo, &ls);
+        if (!rc) h->ls_k.push_back(ls);
+    }
+    if (!rc) rc = mnk_ls_create(ctx, nd, algo, &h->ls_s);
+    if (rc) {
+        for (mnk_ls* l : h->ls_k) mnk_ls_destroy(l);
+        if (h->ls_s) mnk_ls_destroy(h->ls_s);
+        delete h;
+        return rc;
+    }
+    h->info_k.assign(ns_local, 0);
+    mnk_ctx_child_added(ctx);
+    *out = h;
+    return 0;
+}
+
+int mnk_schur_destroy(mnk_schur* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    for (mnk_ls* l : h->ls_k) mnk_ls_destroy(l);
+    if (h->ls_s) mnk_ls_destroy(h->ls_s);
+    mnk_ctx* ctx = h->ctx;
+    delete h;
+    mnk_ctx_child_gone(ctx);
+    return 0;
+}
+
+int mnk_schur_set_block(mnk_schur* h, int64_t k, const double* A_kk, int64_t lda, const double* C_dk, int64_t ldc, int loc) {
+    MNK_REQUIRE(h && A_kk && C_dk, "mnk_schur_set_block: NULL argument");
+    MNK_REQUIRE(k >= 0 && k < h->ns && lda >= h->blk && ldc >= h->nd, "mnk_schur_set_block: bad scenario index / leading dimension");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    MNK_HIP(hipMemcpy2DAsync(h->A.p + k * h->blk * h->blk, h->blk * sizeof(double), A_kk, lda * sizeof(double),
+                             h->blk * sizeof(double), h->blk, kind, s));
+    MNK_HIP(hipMemcpy2DAsync(h->C.p + k * h->nd * h->blk, h->nd * sizeof(double), C_dk, ldc * sizeof(double),
+                             h->nd * sizeof(double), h->blk, kind, s));
+    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    h->built = false;
+    return 0;
+}
+
+#define MNK_GRID1(cnt) dim3((unsigned)(((cnt) + 255) / 256)), dim3(256), 0, s
+
+int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_s0, double* S_out, int64_t lds_out) {
+    MNK_REQUIRE(h && S_out, "mnk_schur_build_local: NULL argument");
+    MNK_REQUIRE(lds_out >= h->nd && (S0 == nullptr || lds0 >= h->nd), "mnk_schur_build_local: bad leading dimension");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    const int64_t nd = h->nd, blk = h->blk, ndp = h->ndp, blkp = h->blkp;
+    // S <- S0 (or 0), zero padded
+    MNK_HIP(hipMemsetAsync(h->Sp.p, 0, (size_t)ndp * ndp * sizeof(double), s));
+    if (S0 != nullptr)
+        MNK_HIP(hipMemcpy2DAsync(h->Sp.p, ndp * sizeof(double), S0, lds0 * sizeof(double), nd * sizeof(double), nd,
+                                 loc_s0 == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    for (int64_t k = 0; k < h->ns; ++k) {
+        // Phase 1 (reference :955-990): factor A_k, T_k = A_k^-1 C_dk'
+        int info = 0;
+        int rc = mnk_ls_factorize_dense(h->ls_k[k], h->A.p + k * blk * blk, blk, MNK_DEVICE, &info);
+        if (rc) return rc;
+        h->info_k[k] = info;
+        double* Tk = h->T.p + k * blk * nd;
+        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(blk * nd), Tk, blk, blk, nd, h->C.p + k * nd * blk, nd, nd, blk, 1);
+        rc = mnk_ls_solve(h->ls_k[k], Tk, nd, blk, MNK_DEVICE);
+        if (rc) return rc;
+        // Phase 2 (reference :993-999): S -= C_dk T_k on the MFMA tile kernel (operands zero padded to tile multiples)
+        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Cp.p, ndp, ndp, blkp, h->C.p + k * nd * blk, nd, nd, blk, 0);
+        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Tt.p, ndp, ndp, blkp, Tk, blk, blk, nd, 1);
+        MNK_HIP(hipGetLastError());
+        rc = launch_gemm_nt(s, 0, ndp, ndp, blkp, h->Cp.p, ndp, h->Tt.p, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
+        if (rc) return rc;
+    }
+    MNK_HIP(hipMemcpy2DAsync(S_out, lds_out * sizeof(double), h->Sp.p, ndp * sizeof(double), nd * sizeof(double), nd,
+                             hipMemcpyDeviceToDevice, s));
+    h->built = true;
+    return 0;
+}
+
+int mnk_schur_factorize_s(mnk_schur* h, const double* S, int64_t lds, int loc, int* info) {
+    MNK_REQUIRE(h && S, "mnk_schur_factorize_s: NULL argument");
+    return mnk_ls_factorize_dense(h->ls_s, S, lds, loc, info);
+}
+
+int mnk_schur_inertia_s(mnk_schur* h, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg) {
+    MNK_REQUIRE(h, "mnk_schur_inertia_s: NULL argument");
+    return mnk_ls_inertia(h->ls_s, num_pos, num_zero, num_neg);
+}
+
+int mnk_schur_scenario_inertia(mnk_schur* h, int64_t k, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg) {
+    MNK_REQUIRE(h && k >= 0 && k < h->ns, "mnk_schur_scenario_inertia: bad argument");
+    return mnk_ls_inertia(h->ls_k[k], num_pos, num_zero, num_neg);
+}
+
+// Step 3 of solve_kkt! (reference :1040-1049): r_k <- A_k^-1 r_k for the local scenarios, and this rank's
+// contribution  -sum_k C_dk r_k  to the design right-hand side (the caller adds r_d and all-reduces).
+int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d) {
+    MNK_REQUIRE(h && contrib_d && (rhs_k || h->ns == 0), "mnk_schur_forward: NULL argument");
+    MNK_REQUIRE(h->built, "mnk_schur_forward: call mnk_schur_build_local first");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    MNK_HIP(hipMemsetAsync(contrib_d, 0, h->nd * sizeof(double), s));
+    for (int64_t k = 0; k < h->ns; ++k) {
+        int rc = mnk_ls_solve(h->ls_k[k], rhs_k + k * h->blk, 1, h->blk, MNK_DEVICE);
+        if (rc) return rc;
+        hipLaunchKernelGGL(schur_gemv_kernel, MNK_GRID1(h->nd), contrib_d, h->C.p + k * h->nd * h->blk, h->nd,
+                           rhs_k + k * h->blk, h->nd, h->blk, -1.0);
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// Step 4: S x_d = r_d (in place, device vector)
+int mnk_schur_solve_s(mnk_schur* h, double* rhs_d) {
+    MNK_REQUIRE(h && rhs_d, "mnk_schur_solve_s: NULL argument");
+    return mnk_ls_solve(h->ls_s, rhs_d, 1, h->nd, MNK_DEVICE);
+}
+
+// Step 5 (reference :1055-1058): x_k = r_k - T_k x_d
+int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
+    MNK_REQUIRE(h && x_d && (rhs_k || h->ns == 0), "mnk_schur_backward: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    for (int64_t k = 0; k < h->ns; ++k)
+        hipLaunchKernelGGL(schur_gemv_kernel, MNK_GRID1(h->blk), rhs_k + k * h->blk, h->T.p + k * h->blk * h->nd, h->blk,
+                           x_d, h->blk, h->nd, -1.0);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+#undef MNK_GRID1
+
+}  // extern "C"

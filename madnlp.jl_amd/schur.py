@@ -1,0 +1,107 @@
+"""Host-side mirror of the dense `S` stage of MadNLP's `SchurComplementKKTSystem` on the MI355X
+(reference `src/KKT/Schur/schur.jl:927-1058`; C ABI `mnk_schur_*`, `csrc/schur.hip`).
+
+One object per rank holds that rank's scenario blocks (scenario k of the global problem lives on rank
+`k % world`, the same instance-index partition as BASELINE config C5).  The only communication is one all-reduce
+of the nd x nd Schur complement per `build_kkt!` and one of the nd-vector per solve, both through
+`torch.distributed` (backend nccl = RCCL over xGMI on the GPU node, gloo in the CPU tests)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .linear_solver import BUNCHKAUFMAN, _ALGO, _LIVE_OBJECTS, FactorizationException, HipContext, SolveException
+
+
+def shard(ns: int, rank: int, world: int):
+    """Global scenario indices owned by `rank` (round-robin, as the C5 instance partition)."""
+    return list(range(rank, ns, world))
+
+
+class SchurDenseStage:
+    """`A`: this rank's (blk, blk) scenario blocks; `C`: its (nd, blk) coupling blocks; `S0`: (nd, nd) design block
+    on the rank that owns it (rank 0), else None.  `dist`: an initialized `torch.distributed` module or None."""
+
+    def __init__(self, A, C_dk, S0, nd, blk, ctx: HipContext | None = None, algorithm=BUNCHKAUFMAN, dist=None):
+        import torch
+        self.torch = torch
+        self.ctx = ctx or HipContext()
+        self.ns, self.nd, self.blk = len(A), int(nd), int(blk)
+        self.dist = dist
+        self._h = C.c_void_p()
+        L.check(L.lib().mnk_schur_create(self.ctx.handle, self.ns, self.blk, self.nd, _ALGO[algorithm], C.byref(self._h)),
+                "mnk_schur_create")
+        for k in range(self.ns):
+            a = np.asfortranarray(A[k], dtype=np.float64)
+            c = np.asfortranarray(C_dk[k], dtype=np.float64)
+            L.check(L.lib().mnk_schur_set_block(self._h, k, a.ctypes.data, self.blk, c.ctypes.data, self.nd, L.MNK_HOST),
+                    "mnk_schur_set_block")
+        self.S0 = None if S0 is None else np.asfortranarray(S0, dtype=np.float64)
+        dev = torch.device("cuda", self.ctx.device)
+        self.S = torch.zeros(self.nd * self.nd, dtype=torch.float64, device=dev)   # column-major nd x nd
+        self._contrib = torch.zeros(self.nd, dtype=torch.float64, device=dev)
+        _LIVE_OBJECTS.add(self)
+
+    def _allreduce(self, t):
+        if self.dist is not None:
+            self.ctx.synchronize()          # the library works on its own stream
+            self.dist.all_reduce(t)         # the ONE collective of this step (RCCL over xGMI)
+            self.torch.cuda.synchronize()
+
+    def build_kkt(self):
+        """`build_kkt!` (:927-1001): local phases 1-2, then the all-reduce of S; returns S (device, flat column-major)."""
+        s0 = None if self.S0 is None else self.S0.ctypes.data
+        L.check(L.lib().mnk_schur_build_local(self._h, s0, self.nd, L.MNK_HOST, self.S.data_ptr(), self.nd),
+                "mnk_schur_build_local")
+        self._allreduce(self.S)
+        return self.S
+
+    def factorize_kkt(self):
+        info = C.c_int(0)
+        rc = L.lib().mnk_schur_factorize_s(self._h, self.S.data_ptr(), self.nd, L.MNK_DEVICE, C.byref(info))
+        if rc:
+            raise FactorizationException(L.lib().mnk_last_error_string().decode())
+        return info.value
+
+    def inertia(self):
+        p, z, n = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().mnk_schur_inertia_s(self._h, C.byref(p), C.byref(z), C.byref(n)), "mnk_schur_inertia_s")
+        return (p.value, z.value, n.value)
+
+    def scenario_inertia(self, k):
+        p, z, n = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(L.lib().mnk_schur_scenario_inertia(self._h, k, C.byref(p), C.byref(z), C.byref(n)), "scenario inertia")
+        return (p.value, z.value, n.value)
+
+    def is_inertia_correct(self, num_pos, num_zero, num_neg):
+        """reference :901-903."""
+        return num_zero == 0 and num_pos == self.nd
+
+    def solve(self, rhs_k, rhs_d):
+        """Steps 3-5 of `solve_kkt!` (:1040-1058).  rhs_k: (ns_local, blk) device tensor (row = scenario), rhs_d: (nd)
+        device tensor, the SAME on every rank; both overwritten with the solution."""
+        rk = rhs_k.data_ptr() if self.ns else None
+        rc = L.lib().mnk_schur_forward(self._h, rk, self._contrib.data_ptr())
+        if rc:
+            raise SolveException(L.lib().mnk_last_error_string().decode())
+        self._allreduce(self._contrib)
+        self.ctx.synchronize()
+        rhs_d += self._contrib
+        self.torch.cuda.synchronize()
+        if L.lib().mnk_schur_solve_s(self._h, rhs_d.data_ptr()) or L.lib().mnk_schur_backward(self._h, rk, rhs_d.data_ptr()):
+            raise SolveException(L.lib().mnk_last_error_string().decode())
+        self.ctx.synchronize()
+        return rhs_k, rhs_d
+
+    def close(self):
+        if self._h:
+            L.lib().mnk_schur_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
