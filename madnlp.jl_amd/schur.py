@@ -56,6 +56,7 @@ class SchurDenseStage:
         L.check(L.lib().mnk_schur_build_local(self._h, s0, self.nd, L.MNK_HOST, self.S.data_ptr(), self.nd),
                 "mnk_schur_build_local")
         self._allreduce(self.S)
+        self.ctx.synchronize()   # S is handed to the caller (a torch tensor on the caller's stream)
         return self.S
 
     def factorize_kkt(self):

@@ -35,8 +35,12 @@ def two_stage_blocks(ns, nv, nc, nd, seed=0, delta=1e-8):
         Ak[nv:, nv:] = -delta * np.eye(nc)
         A.append(np.asfortranarray(Ak))
         Cs.append(np.asfortranarray(rng.standard_normal((nd, blk)) * 0.3))
+    # S0 chosen so that the Schur complement S = S0 - sum_k C_dk A_k^-1 C_dk' equals an SPD matrix G by construction
+    # (random couplings to the multiplier part of an indefinite A_k would otherwise make S indefinite)
     R = rng.standard_normal((nd, nd))
-    S0 = np.asfortranarray(R @ R.T / nd + np.diag(10.0 ** rng.uniform(0, 2, nd)) + ns * 2.0 * np.eye(nd))
+    G = R @ R.T / nd + np.diag(10.0 ** rng.uniform(0, 2, nd))
+    S0 = G + sum(Cs[k] @ np.linalg.solve(A[k], Cs[k].T) for k in range(ns))
+    S0 = np.asfortranarray((S0 + S0.T) / 2)
     return A, Cs, S0, blk
 
 
