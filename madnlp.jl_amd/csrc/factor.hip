@@ -1575,6 +1575,25 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     return 0;
 }
 
+int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows, double* Vrows, int64_t ldr, int64_t nrows) {
+    MNK_REQUIRE(ls->factorized && !ls->bk_active && nrows % 16 == 0 && j0 % NBI == 0 && j0 < ls->Np,
+                "mnk_ls_right_trsm_rows: needs a static-pivot factor, 16-row multiples and a block-aligned column");
+    // the kernel addresses rows j0 + 64 ... of ONE matrix: shift the row blocks so that its row r0 is their row 0
+    double* Fp = Xrows - (j0 + NBI);
+    double* Wp = Vrows ? Vrows - (j0 + NBI) : nullptr;
+    const unsigned grid = (unsigned)((nrows / 16 + 3) / 4);
+    const double* dblk = ls->dblk.p + (j0 / NBI) * 4096;
+    const double* inv16 = ls->inv16.p + (j0 / NBI) * 1024;
+    if (ls->algo == MNK_LDL)
+        hipLaunchKernelGGL((trsm64_mfma_kernel<true, 1>), dim3(grid), dim3(256), 0, s, Fp, ldr, j0, j0 + NBI + nrows, dblk,
+                           inv16, ls->dinv.p, Wp, ldr, (int64_t)j0, ls->info_dev.p, (const int*)nullptr, 0);
+    else
+        hipLaunchKernelGGL((trsm64_mfma_kernel<false, 1>), dim3(grid), dim3(256), 0, s, Fp, ldr, j0, j0 + NBI + nrows, dblk,
+                           inv16, ls->dinv.p, (double*)nullptr, (int64_t)0, (int64_t)0, ls->info_dev.p, (const int*)nullptr, 0);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 // Tier 2 of BUNCHKAUFMAN: fetch the matrix again, factor it with pivoting (bk.hip), rebuild the inverses the solves use.
 static int bk_fallback(mnk_ls* ls) {
     hipStream_t s = ls->ctx->stream;

@@ -87,6 +87,10 @@ int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s);
+// Right-side triangular solve of `nrows` free-standing rows (multiple of 16) against the factored diagonal block that
+// starts at column j0: V = B L_jj^-T, X = V D^-1 (LDL) / X = B L_jj^-T (Cholesky).  B is read from / X written to
+// Xrows(:, j0:j0+64), V written to Vrows(:, j0:j0+64) (LDL only); both row blocks have leading dimension ldr.
+int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows, double* Vrows, int64_t ldr, int64_t nrows);
 int mnk_ls_run_bunchkaufman(mnk_ls* ls);                                  // bk.hip
 int mnk_ls_bk_permute(mnk_ls* ls, double* x, double* tmp, bool forward);  // x <- P x (forward) / P^T x
 int mnk_ls_bk_dsolve(mnk_ls* ls, double* y);                              // y <- D^-1 y, 1x1 / 2x2 blocks

@@ -7,8 +7,10 @@
 // and a solve is   r_k <- A_k^-1 r_k ;  r_d <- r_d - sum_k C_dk r_k ;  S x_d = r_d ;  x_k = r_k - (A_k^-1 C_dk') x_d.
 // The reference factors the A_k with a sparse solver per scenario (MUMPS; sparse direct solvers are out of this
 // path's scope); here the scenario blocks arrive dense and are factored by the same blocked fp64-MFMA factorization
-// as S itself (BUNCHKAUFMAN tiers: the blocks are indefinite), T_k = A_k^-1 C_dk' by its multi-right-hand-side solve,
-// and the accumulation S -= C_dk T_k on the MFMA tile kernel.
+// as S itself (BUNCHKAUFMAN tiers: the blocks are indefinite).  With a static-pivot factor A_k = L D L' the term is
+// C A^-1 C' = (C L^-T) D^-1 (C L^-T)': ONE forward sweep over the nd rows of C_dk (right-side block triangular solve
+// on MFMA) and one MFMA rank-blk update of S; a block that needed the pivoted tier falls back to the reference's
+// column-by-column T_k = A_k^-1 C_dk' and S -= C_dk T_k.
 //
 // Multi-GPU: scenarios are sharded over the ranks.  mnk_schur_build_local produces THIS rank's contribution
 // (S0 on the rank that owns it, minus its scenarios' terms) into a caller-owned device buffer; the caller sums the
@@ -24,9 +26,11 @@ struct mnk_schur {
     int algo = MNK_BUNCHKAUFMAN;
     mnk::DevBuf<double> A;    // ns x (blk x blk)   scenario blocks (lower triangle read)
     mnk::DevBuf<double> C;    // ns x (nd x blk)    coupling blocks
-    mnk::DevBuf<double> T;    // ns x (blk x nd)    A_k^-1 C_dk'
-    mnk::DevBuf<double> Cp;   // ndp x blkp  zero-padded copy of one C_dk   (MFMA operand)
-    mnk::DevBuf<double> Tt;   // ndp x blkp  zero-padded T_k'               (MFMA operand)
+    mnk::DevBuf<double> T;    // blk x nd    A_k^-1 C_dk' of ONE scenario (pivoted-tier fallback only)
+    mnk::DevBuf<double> Cp;   // ndp x Npb   X = C_dk L^-T D^-1 (fast path) / zero-padded C_dk (fallback)   (MFMA operand)
+    mnk::DevBuf<double> Tt;   // ndp x Npb   V = C_dk L^-T (fast path) / zero-padded T_k' (fallback)         (MFMA operand)
+    mnk::DevBuf<double> tmpk; // Npb         C_dk' x_d of one scenario (back-substitution)
+    int64_t Npb = 0;          // padded order of a scenario factor (multiple of 128)
     mnk::DevBuf<double> Sp;   // ndp x ndp   accumulator
     std::vector<mnk_ls*> ls_k;
     mnk_ls* ls_s = nullptr;
@@ -63,6 +67,27 @@ __global__ __launch_bounds__(256) void schur_gemv_kernel(double* __restrict__ y,
     y[r] += alpha * (s0 + s1);
 }
 
+// y[c] = sum_r A[r + c*lda] x[r]   (A is rows x cols): one thread per column, fixed order
+__global__ __launch_bounds__(256) void schur_gemv_t_kernel(double* __restrict__ y, const double* __restrict__ A, int64_t lda,
+                                                           const double* __restrict__ x, int64_t rows, int64_t cols) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const double* a = A + c * lda;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t r = 0;
+    for (; r + 1 < rows; r += 2) {
+        s0 = fma(a[r], x[r], s0);
+        s1 = fma(a[r + 1], x[r + 1], s1);
+    }
+    if (r < rows) s0 = fma(a[r], x[r], s0);
+    y[c] = s0 + s1;
+}
+// y[i] -= x[i]
+__global__ void schur_sub_kernel(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) y[i] -= x[i];
+}
+
 }  // namespace mnk
 
 using namespace mnk;
@@ -78,12 +103,14 @@ int mnk_schur_create(mnk_ctx* ctx, int64_t ns_local, int64_t blk, int64_t nd, in
     h->ns = ns_local; h->blk = blk; h->nd = nd; h->algo = algo;
     h->ndp = round_up(nd, 64);
     h->blkp = round_up(blk, 16);
+    h->Npb = round_up(blk, PAD);
     int rc = 0;
     rc |= h->A.alloc((size_t)std::max<int64_t>(ns_local, 1) * blk * blk);
     rc |= h->C.alloc((size_t)std::max<int64_t>(ns_local, 1) * nd * blk);
-    rc |= h->T.alloc((size_t)std::max<int64_t>(ns_local, 1) * blk * nd);
-    rc |= h->Cp.alloc((size_t)h->ndp * h->blkp + SLACK);
-    rc |= h->Tt.alloc((size_t)h->ndp * h->blkp + SLACK);
+    rc |= h->T.alloc((size_t)blk * nd);
+    rc |= h->Cp.alloc((size_t)h->ndp * h->Npb + SLACK);
+    rc |= h->Tt.alloc((size_t)h->ndp * h->Npb + SLACK);
+    rc |= h->tmpk.alloc((size_t)h->Npb);
     rc |= h->Sp.alloc((size_t)h->ndp * h->ndp + SLACK);
     if (rc) { delete h; return -2; }
     for (int64_t k = 0; k < ns_local && !rc; ++k) {
@@ -149,17 +176,43 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         int info = 0;
         int rc = mnk_ls_factorize_dense(h->ls_k[k], h->A.p + k * blk * blk, blk, MNK_DEVICE, &info);
         if (rc) return rc;
-        h->info_k[k] = info;
-        double* Tk = h->T.p + k * blk * nd;
-        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(blk * nd), Tk, blk, blk, nd, h->C.p + k * nd * blk, nd, nd, blk, 1);
-        rc = mnk_ls_solve(h->ls_k[k], Tk, nd, blk, MNK_DEVICE);
-        if (rc) return rc;
-        // Phase 2 (reference :993-999): S -= C_dk T_k on the MFMA tile kernel (operands zero padded to tile multiples)
-        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Cp.p, ndp, ndp, blkp, h->C.p + k * nd * blk, nd, nd, blk, 0);
-        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Tt.p, ndp, ndp, blkp, Tk, blk, blk, nd, 1);
-        MNK_HIP(hipGetLastError());
-        rc = launch_gemm_nt(s, 0, ndp, ndp, blkp, h->Cp.p, ndp, h->Tt.p, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
-        if (rc) return rc;
+        h->info_k[k] = info;  // (the call fetched info/inertia, so the tier that produced the factor is known)
+        mnk_ls* ls = h->ls_k[k];
+        const double* Ck = h->C.p + k * nd * blk;
+        if (!ls->bk_active && h->info_k[k] == 0) {
+            // Fast path (static-pivot factor A_k = L D L' or L L'):  C A^-1 C' = (C L^-T) D^-1 (C L^-T)', so only the
+            // FORWARD sweep is needed, as a right-side triangular solve of the nd rows of C_dk -- left-looking over the
+            // 64-column blocks of L: an MFMA update with the finished blocks, then block substitution on MFMA
+            // (trsm64_mfma_kernel) against the diagonal block.  X = C L^-T D^-1 lands in Cp, V = C L^-T in Tt.
+            const int64_t Npb = h->Npb;
+            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * Npb), h->Cp.p, ndp, ndp, Npb, Ck, nd, nd, blk, 0);
+            const bool ldl = ls->algo == MNK_LDL;
+            double* X = h->Cp.p;
+            double* V = ldl ? h->Tt.p : h->Cp.p;
+            for (int64_t j0 = 0; j0 < Npb; j0 += NBI) {
+                if (j0 > 0) {
+                    rc = launch_gemm_nt(s, 0, ndp, NBI, j0, V, ndp, ls->fact.p + j0, ls->ld, X + j0 * ndp, ndp, nullptr,
+                                        nullptr, 0, nullptr);
+                    if (rc) return rc;
+                }
+                rc = mnk_ls_right_trsm_rows(ls, s, j0, X, ldl ? V : nullptr, ndp, ndp);
+                if (rc) return rc;
+            }
+            // Phase 2 (reference :993-999): S -= X V'
+            rc = launch_gemm_nt(s, 0, ndp, ndp, Npb, X, ndp, V, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
+            if (rc) return rc;
+        } else {
+            // Pivoted (Bunch-Kaufman tier) or failed factor: T_k = A_k^-1 C_dk' column by column, as the reference does
+            double* Tk = h->T.p;
+            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(blk * nd), Tk, blk, blk, nd, Ck, nd, nd, blk, 1);
+            rc = mnk_ls_solve(ls, Tk, nd, blk, MNK_DEVICE);
+            if (rc) return rc;
+            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Cp.p, ndp, ndp, blkp, Ck, nd, nd, blk, 0);
+            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Tt.p, ndp, ndp, blkp, Tk, blk, blk, nd, 1);
+            MNK_HIP(hipGetLastError());
+            rc = launch_gemm_nt(s, 0, ndp, ndp, blkp, h->Cp.p, ndp, h->Tt.p, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
+            if (rc) return rc;
+        }
     }
     MNK_HIP(hipMemcpy2DAsync(S_out, lds_out * sizeof(double), h->Sp.p, ndp * sizeof(double), nd * sizeof(double), nd,
                              hipMemcpyDeviceToDevice, s));
@@ -206,14 +259,19 @@ int mnk_schur_solve_s(mnk_schur* h, double* rhs_d) {
     return mnk_ls_solve(h->ls_s, rhs_d, 1, h->nd, MNK_DEVICE);
 }
 
-// Step 5 (reference :1055-1058): x_k = r_k - T_k x_d
+// Step 5 (reference :1055-1058): x_k = r_k - (A_k^-1 C_dk') x_d, applied as one more solve with A_k on C_dk' x_d
+// (the reference multiplies by the stored blk x nd matrix A_k^-1 C_dk'; the fast build path never forms it).
 int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
     MNK_REQUIRE(h && x_d && (rhs_k || h->ns == 0), "mnk_schur_backward: NULL argument");
     MNK_HIP(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
-    for (int64_t k = 0; k < h->ns; ++k)
-        hipLaunchKernelGGL(schur_gemv_kernel, MNK_GRID1(h->blk), rhs_k + k * h->blk, h->T.p + k * h->blk * h->nd, h->blk,
-                           x_d, h->blk, h->nd, -1.0);
+    for (int64_t k = 0; k < h->ns; ++k) {
+        hipLaunchKernelGGL(schur_gemv_t_kernel, MNK_GRID1(h->blk), h->tmpk.p, h->C.p + k * h->nd * h->blk, h->nd, x_d, h->nd,
+                           h->blk);
+        int rc = mnk_ls_solve(h->ls_k[k], h->tmpk.p, 1, h->blk, MNK_DEVICE);
+        if (rc) return rc;
+        hipLaunchKernelGGL(schur_sub_kernel, MNK_GRID1(h->blk), rhs_k + k * h->blk, h->tmpk.p, h->blk);
+    }
     MNK_HIP(hipGetLastError());
     return 0;
 }

@@ -36,6 +36,6 @@ ts = timeit(lambda: st.solve(rk, rd))
 flops_acc = 2.0 * ns * nd * nd * blk
 print(json.dumps({"config": f"Schur dense S stage: ns={ns} blk={blk} nd={nd} (one rank)", "ms_build_kkt": tb,
                   "ms_factorize_S": tf, "ms_solve": ts, "inertia_S": st.inertia(),
-                  "note": "build = ns x (blocked LDL^T of A_k + nd-column solve for A_k^-1 C_dk' + MFMA accumulation of S); "
-                          "the nd-column solve runs one right-hand side per launch and dominates",
+                  "note": "build = ns x (blocked LDL^T of A_k + right-side block triangular solve of the nd rows of C_dk on MFMA "
+                          "+ MFMA accumulation S -= (C L^-T D^-1)(C L^-T)'); solve = 2 single-RHS solves per scenario + one with S",
                   "S_accumulation_gflop": flops_acc / 1e9}))
