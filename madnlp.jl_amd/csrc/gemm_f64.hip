@@ -20,6 +20,7 @@
 //     buffered: the loads of k-tile t+1 are issued before the MFMAs of k-tile t.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -36,18 +37,39 @@ constexpr bool tile_big(int wm, int wn, int wt) { return wm == 2 && wn == 2 && w
 constexpr int tile_bk(int wm, int wn, int wt) { return tile_big(wm, wn, wt) ? 8 : BK; }
 constexpr int tile_occ(int wm, int wn, int wt) { return tile_big(wm, wn, wt) ? 3 : 2; }
 
-// Decode a logical tile index into (tm, tn).  Lower-only modes enumerate the tiles on/below the
-// diagonal column by column (tile column tn holds rows tn..ntm-1): first(tn) = tn*ntm - tn*(tn-1)/2.
+// Decode a logical tile index into (tm, tn).  Lower-only modes enumerate the tiles on/below the diagonal in
+// SUPER-COLUMNS of `sw` tile columns, row by row inside a super-column: a window of consecutive logical tiles
+// (what one XCD's workgroups hold at a time: ~72 tiles of the 128x128 kernel) then spans ~72/sw tile rows x sw tile
+// columns and shares ~72/sw + sw operand blocks through that XCD's L2, instead of 73 with a column-by-column order
+// (sw = 1, the round-1 order).  Tiles before tile column c: first(c) = c*ntm - c*(c-1)/2.
 template <int MODE>
-__device__ __forceinline__ void decode_tile(int logical, int ntm, int& tm, int& tn) {
+__device__ __forceinline__ void decode_tile(int logical, int ntm, int nc, int sw, int& tm, int& tn) {
     if (MODE == 2 || MODE == 4) {
         const double bq = 2.0 * ntm + 1.0;
         int c = (int)((bq - sqrt(bq * bq - 8.0 * (double)logical)) * 0.5);
         if (c < 0) c = 0;
         while (c > 0 && c * ntm - c * (c - 1) / 2 > logical) --c;
         while ((c + 1) * ntm - (c + 1) * c / 2 <= logical) ++c;
-        tn = c;
-        tm = tn + (logical - (c * ntm - c * (c - 1) / 2));
+        if (sw <= 1) {
+            tn = c;
+            tm = tn + (logical - (c * ntm - c * (c - 1) / 2));
+            return;
+        }
+        const int r0 = (c / sw) * sw;                       // first tile row/column of the super-column
+        const int W = nc - r0 < sw ? nc - r0 : sw;           // its width
+        int rem = logical - (r0 * ntm - r0 * (r0 - 1) / 2);  // index inside the super-column, row-major
+        const int tri = W * (W + 1) / 2;                     // its triangular top: row r0 + i holds i + 1 tiles
+        if (rem < tri) {
+            int i = (int)((sqrt(8.0 * (double)rem + 1.0) - 1.0) * 0.5);
+            while (i > 0 && i * (i + 1) / 2 > rem) --i;
+            while ((i + 1) * (i + 2) / 2 <= rem) ++i;
+            tm = r0 + i;
+            tn = r0 + (rem - i * (i + 1) / 2);
+        } else {
+            rem -= tri;
+            tm = r0 + W + rem / W;
+            tn = r0 + rem % W;
+        }
     } else {
         tm = logical % ntm;
         tn = logical / ntm;
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_ke
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
     const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
-    const int* __restrict__ info_flag, int tile_off, int* sig, int sig_val) {
+    const int* __restrict__ info_flag, int tile_off, int* sig, int sig_val, int nc, int sw) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (info_flag != nullptr && *info_flag != 0) return;
 
@@ -246,13 +268,13 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_ke
     int per = nblk >> 3;
     int logical = tile_off + ((per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid);
     int tm, tn;
-    decode_tile<MODE>(logical, ntm, tm, tn);
+    decode_tile<MODE>(logical, ntm, nc, sw, tm, tn);
     gemm_nt_tile<WM, WN, WT, MODE, LDL_EPI, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, colscale,
                                                                        C2, ldc2, smem_raw);
     // Optional hand-off: the workgroup that owns logical tile 0 (the next diagonal block of the factorization)
     // publishes "tile 0 is complete in memory" so that the next potrf64 can start while the other tiles are still
     // being updated: stores -> barrier -> one lane's agent-scope release -> drained flag store.
-    if (sig != nullptr && logical == 0) {
+    if (sig != nullptr && tm == 0 && tn == 0) {
         __syncthreads();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN, DBG == 6 ? 2 : tile_occ(WM, WN, WT)) 
     int nblk = gridDim.x, bid = blockIdx.x, per = nblk >> 3;
     int logical = (per > 0 && bid < per * 8) ? (bid & 7) * per + (bid >> 3) : bid;
     int tm, tn;
-    decode_tile<MODE>(logical, ntm, tm, tn);
+    decode_tile<MODE>(logical, ntm, ntm, 1, tm, tn);
     gemm_nt_tile<WM, WN, WT, MODE, false, DBG == 6 ? 0 : DBG, DBG == 6 ? 16 : tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, smem_raw);
 }
 
@@ -284,7 +306,7 @@ template <int WM, int WN, int WT, int MODE>
 __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_queue_kernel(
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc, int ntm, int ntiles,
-    int* __restrict__ counters /* [8] */, const int* __restrict__ info_flag) {
+    int* __restrict__ counters /* [8] */, const int* __restrict__ info_flag, int nc, int sw) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int s_tile;
     if (info_flag != nullptr && *info_flag != 0) return;
@@ -301,11 +323,17 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_qu
         __syncthreads();  // everyone has read s_tile before the next round overwrites it
         if (logical >= hi) { ++probe; continue; }
         int tm, tn;
-        decode_tile<MODE>(logical, ntm, tm, tn);
+        decode_tile<MODE>(logical, ntm, nc, sw, tm, tn);
         gemm_nt_tile<WM, WN, WT, MODE, false, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, nullptr,
                                                                           nullptr, 0, smem_raw);
         __syncthreads();  // LDS tiles are reused by the next round
     }
+}
+
+// width of the super-columns of the lower-tile enumeration (MNK_SUPER_W overrides; 1 = column-by-column)
+static int tile_super_width() {
+    static const int sw = getenv("MNK_SUPER_W") ? std::max(1, atoi(getenv("MNK_SUPER_W"))) : 8;
+    return sw;
 }
 
 template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
@@ -316,9 +344,9 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
     constexpr int BM = 16 * WT * WM, BN = 16 * WT * WN;
     const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
     int ntiles = ntm * ntn;
+    const int nc = ntn < ntm ? ntn : ntm;  // tile columns that contain a lower tile
     if (MODE == 2 || MODE == 4) {
         static_assert(MODE == 0 || MODE == 1 || WM == WN, "lower-only modes need square tiles");
-        const int nc = ntn < ntm ? ntn : ntm;  // tile columns that contain a lower tile
         ntiles = nc * ntm - nc * (nc - 1) / 2;
     }
     const size_t smem = 2 * tile_bk(WM, WN, WT) * ((BM + 16) + (BN + 16)) * sizeof(double);
@@ -334,7 +362,7 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
     if (tile_count >= 0) ntiles = std::min(ntiles - tile_begin, tile_count);
     if (ntiles <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, s, M, N, K, A, lda, B, ldb, C,
-                       ldc, colscale, C2, ldc2, ntm, info_flag, tile_begin, sig, sig_val);
+                       ldc, colscale, C2, ldc2, ntm, info_flag, tile_begin, sig, sig_val, nc, tile_super_width());
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -450,8 +478,9 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
         MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
     }
+    const int ntn_q = (int)((N + BM - 1) / BM);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm, ntiles, counter,
-                       info_flag);
+                       info_flag, ntn_q < ntm ? ntn_q : ntm, tile_super_width());
     MNK_HIP(hipGetLastError());
     return 0;
 }
