@@ -79,6 +79,8 @@ end
     share::Int = 1                  # 0 off / 1 adaptive / 2 always: panel-stream CUs join the trailing update
     persistent_solve::Bool = true   # both triangular sweeps in one launch
     single_rows::Int = 4608         # systems up to this order: one outer panel on the whole chip
+    bk_fallback::Bool = true        # BUNCHKAUFMAN: refactor with 1x1/2x2 Bunch-Kaufman pivoting when the static-pivot
+                                    # LDL^T breaks down (false: report the breakdown as num_zero, the IPM regularizes)
 end
 
 "aug_com of `HipSparseCondensedKKTSystem`: lower-triangular CSC whose VALUES live in HBM."
@@ -151,6 +153,7 @@ function HipLinearSolver(A::MT; opt = HipSolverOptions(), logger = MadNLPLogger(
     set_option!(h[], "share", opt.share)
     set_option!(h[], "persistent_solve", opt.persistent_solve)
     set_option!(h[], "single_rows", opt.single_rows)
+    set_option!(h[], "bk_fallback", opt.bk_fallback)
     M = HipLinearSolver{Float64, MT}(A, h[], ctx, n, Ref{Cint}(0), opt, logger)
     finalizer(M) do m
         m.handle == C_NULL || ccall((:mnk_ls_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), m.handle)
@@ -191,6 +194,27 @@ function MadNLP.solve_linear_system!(M::HipLinearSolver, x::Vector{Float64})
                M.handle, x, 1, length(x), MNK_HOST)
     check(rc, SolveException)
     return x
+end
+
+"""
+    check_solve(M)
+
+For callers that keep their vectors on the device: synchronize and throw `SolveException` if a one-launch solve gave up
+(the solver has then switched to the stepwise solve; repeat the solve).  Host-vector callers never need it.
+"""
+function check_solve(M::HipLinearSolver)
+    rc = ccall((:mnk_ls_check_solve, libmadnlp_hip), Cint, (Ptr{Cvoid},), M.handle)
+    check(rc, SolveException)
+    return nothing
+end
+
+"Which tier produced the current factor: (pivoted::Bool, count::Int) -- `mnk_ls_bk_info`."
+function bk_info(M::HipLinearSolver)
+    active = Ref{Cint}(0); count = Ref{Cint}(0)
+    rc = ccall((:mnk_ls_bk_info, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}, Ptr{Int32}, Ptr{Cdouble}),
+               M.handle, active, count, C_NULL, C_NULL)
+    check(rc, InertiaException)
+    return (active[] != 0, Int(count[]))
 end
 
 MadNLP.is_inertia(::HipLinearSolver) = true

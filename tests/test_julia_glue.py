@@ -116,6 +116,7 @@ def test_option_keys_and_defaults_match_the_library():
         "share": re.search(r"int share = (\d)", ls_h).group(1),
         "persistent_solve": re.search(r"int persistent_solve = (\d)", ls_h).group(1),
         "single_rows": re.search(r"single_rows = (\d+)", ls_h).group(1),
+        "bk_fallback": re.search(r"int bk_fallback = (\d)", ls_h).group(1),
     }
     norm = lambda v: {"true": "1", "false": "0"}.get(v, v)  # noqa: E731
     for k, v in lib.items():
