@@ -669,7 +669,9 @@ __device__ __forceinline__ void factor_piv4_vals(const double p00, const double 
 }
 
 // (one wave; `Lsh` / `Ish`: optional LDS copies of the factored block and of its four 16x16 inverses)
-template <bool LDL>
+// VAR != 0: timing-only ablations for mnk_debug_potrf64 (results are wrong): 1 no 16x16 inverses, 2 no dvec/dinv/info
+// stores, 3 only the critical update MFMA, 4 no per-lane selection of the 4x4 factor, 5 load + store only, 6 no Dout stores
+template <bool LDL, int VAR = 0>
 __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
                                               double* __restrict__ Dout, double* __restrict__ inv16,
                                               double* __restrict__ dvec, double* __restrict__ dinv,
@@ -689,7 +691,7 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
                 Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v;
             }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < (VAR == 5 ? 0 : 4); ++b) {
         double aopinv[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
@@ -706,8 +708,8 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
             double dg[4];
             int fail;
             factor_piv4_vals<LDL>(p00, p10, p11, p20, p21, p22, p30, p31, p32, p33, pivot_tol, P, dg, fail);
-            if (!LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
-            if (lane == 0) {
+            if (VAR != 2 && !LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
+            if (VAR != 2 && lane == 0) {
                 const double sc[4] = {P.s0, P.s1, P.s2, P.s3};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -734,7 +736,8 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
             const double yr1 = l4 == 0 ? y10 : (l4 == 1 ? y11 : 0.0);
             const double yr2 = l4 == 0 ? y20 : (l4 == 1 ? y21 : (l4 == 2 ? y22 : 0.0));
             const double yr3 = l4 == 0 ? y30 : (l4 == 1 ? y31 : (l4 == 2 ? y32 : y33));
-            const double aop = ii == 0 ? yr0 : (ii == 1 ? yr1 : (ii == 2 ? yr2 : (ii == 3 ? yr3 : 0.0)));
+            const double aop = VAR == 4 ? y00 + y10 + y20 + y30 + y21 + y31 + y32
+                                        : (ii == 0 ? yr0 : (ii == 1 ? yr1 : (ii == 2 ? yr2 : (ii == 3 ? yr3 : 0.0))));
             aopinv[tt] = aop;
             const double ssel = l4 == 0 ? P.s0 : (l4 == 1 ? P.s1 : (l4 == 2 ? P.s2 : P.s3));
             // exact entries of the pivot rows of the diagonal block (from the scalar factorization)
@@ -742,11 +745,11 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
             const double lr1 = l4 == 0 ? l10 : (l4 == 1 ? dg[1] : 0.0);
             const double lr2 = l4 == 0 ? l20 : (l4 == 1 ? l21 : (l4 == 2 ? dg[2] : 0.0));
             const double lr3 = l4 == 0 ? l30 : (l4 == 1 ? l31 : (l4 == 2 ? l32 : dg[3]));
-            const double lpiv = ii == 0 ? lr0 : (ii == 1 ? lr1 : (ii == 2 ? lr2 : lr3));
+            const double lpiv = VAR == 4 ? l10 + l20 + l30 + l21 + l31 + l32 : (ii == 0 ? lr0 : (ii == 1 ? lr1 : (ii == 2 ? lr2 : lr3)));
             const double vr1 = l4 == 0 ? P.c10 : (l4 == 1 ? dg[1] : 0.0);
             const double vr2 = l4 == 0 ? P.c20 : (l4 == 1 ? P.c21 : (l4 == 2 ? dg[2] : 0.0));
             const double vr3 = l4 == 0 ? P.c30 : (l4 == 1 ? P.c31 : (l4 == 2 ? P.c32 : dg[3]));
-            const double vpiv = ii == 0 ? lr0 : (ii == 1 ? vr1 : (ii == 2 ? vr2 : vr3));
+            const double vpiv = VAR == 4 ? P.c10 + P.c21 + P.c32 : (ii == 0 ? lr0 : (ii == 1 ? vr1 : (ii == 2 ? vr2 : vr3)));
             // ---- 2. X_t^T = inv(L44) A_t^T for every block of block column b
             double X[4], V[4];
 #pragma unroll
@@ -770,11 +773,12 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
                 const double na = (cb1 == b && l15 < 4 * tt + 4) ? 0.0 : -X[cb1];
 #pragma unroll
                 for (int cb2 = cb1; cb2 < 4; ++cb2)
-                    Lt[cb2][cb1] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, LDL ? V[cb2] : X[cb2], Lt[cb2][cb1], 0, 0, 0);
+                    if (VAR != 3 || (cb1 == b && cb2 == b))
+                        Lt[cb2][cb1] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, LDL ? V[cb2] : X[cb2], Lt[cb2][cb1], 0, 0, 0);
             }
         }
         // ---- inverse of the 16x16 diagonal block (unit diagonal for LDL): Y = inv(L16), block forward substitution
-        {
+        if (VAR != 1) {
             v4d T, Y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[r] = (l15 == l4 + 4 * r) ? 1.0 : 0.0;
@@ -796,9 +800,17 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Lt[cb][b][r];
-                Dout[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
+                if (VAR != 6) Dout[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
                 if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
             }
+    }
+    if (VAR == 5) {
+        double acc = 0.0;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int b = 0; b <= cb; ++b) acc += Lt[cb][b][0] + Lt[cb][b][1] + Lt[cb][b][2] + Lt[cb][b][3];
+        Dout[lane] = acc;
     }
 }
 
@@ -814,6 +826,13 @@ __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__
     if (wait_flag != nullptr && !handoff_wait(wait_flag, epoch, info)) return;
     potrf64w_body<LDL>(F, ld, j0, Dout, inv16, dvec, dinv, info, pivot_tol, nullptr, nullptr);
     if (done_flag != nullptr) handoff_signal_wave(done_flag, epoch);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(64) void potrf64w_dbg_kernel(const double* __restrict__ F, double* __restrict__ Dout,
+                                                           double* __restrict__ inv16, double* __restrict__ dvec,
+                                                           double* __restrict__ dinv, int* __restrict__ info) {
+    potrf64w_body<true, VAR>(F, 64, 0, Dout, inv16, dvec, dinv, info, 0.0, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1666,5 +1685,49 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         else { ls->npos = 0; ls->nzero = ls->N; ls->nneg = 0; }
     }
     ls->info_valid = true;
+    return 0;
+}
+
+// Diagnostics (tools/potrf_ablation.py): average duration of `reps` dependent launches of the one-wave potrf64 on a
+// 64x64 SPD block, full kernel (variant 0) or with one piece removed (see potrf64w_body; results of variants are wrong).
+extern "C" int mnk_debug_potrf64(mnk_ctx* ctx, int variant, int reps, double* ms) {
+    MNK_REQUIRE(ctx && ms && reps > 0, "mnk_debug_potrf64: bad argument");
+    MNK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBuf<double> A, D, I, dv, di;
+    DevBuf<int> info;
+    int rc = A.alloc(4096) | D.alloc(4096) | I.alloc(1024) | dv.alloc(64) | di.alloc(64) | info.alloc(1);
+    if (rc) return -2;
+    std::vector<double> h(4096, 0.0);
+    for (int c = 0; c < 64; ++c)
+        for (int r = c; r < 64; ++r) h[r + 64 * c] = r == c ? 70.0 + c : 1.0 / (1.0 + r - c);
+    MNK_HIP(hipMemcpyAsync(A.p, h.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, s));
+    MNK_HIP(hipMemsetAsync(info.p, 0, sizeof(int), s));
+    hipEvent_t e0, e1;
+    MNK_HIP(hipEventCreate(&e0));
+    MNK_HIP(hipEventCreate(&e1));
+#define MNK_PD(V) hipLaunchKernelGGL(potrf64w_dbg_kernel<V>, dim3(1), dim3(64), 0, s, A.p, D.p, I.p, dv.p, di.p, info.p)
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: warm-up
+        if (pass == 1) MNK_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; ++r) {
+            switch (variant) {
+            case 1: MNK_PD(1); break;
+            case 2: MNK_PD(2); break;
+            case 3: MNK_PD(3); break;
+            case 4: MNK_PD(4); break;
+            case 5: MNK_PD(5); break;
+            case 6: MNK_PD(6); break;
+            default: MNK_PD(0); break;
+            }
+        }
+    }
+#undef MNK_PD
+    MNK_HIP(hipEventRecord(e1, s));
+    MNK_HIP(hipStreamSynchronize(s));
+    float t = 0.f;
+    MNK_HIP(hipEventElapsedTime(&t, e0, e1));
+    *ms = (double)t / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
 }
