@@ -195,6 +195,13 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc);
  * doff (N entries: sub-diagonal of D, non-zero at the first index of a 2x2 block) may be NULL. */
 int mnk_ls_bk_info(mnk_ls* ls, int* active, int* count, int32_t* perm, double* doff);
 
+/* Diagnostics of the last factorization (tests, tuning): key "panel_algo" = the panel algorithm that produced the
+ * current factor (4: persistent panel kernel; 1: one launch per panel piece -- chosen automatically while more than
+ * one context of this process lives on the device, or for good after a persistent panel gave up on a dependency),
+ * "pp_fallbacks" = how many factorizations of this solver were redone for that reason.  Synchronizes when a
+ * factorization is pending (the fallback is decided when `info` is read). */
+int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value);
+
 /* ----------------------------------------------------------- utilities ------ */
 /* C (M x N) = / -= A (M x K) * B (N x K)^T on the fp64 MFMA tile kernel used by the
  * factorization's trailing update; exposed for unit tests and microbenchmarks.

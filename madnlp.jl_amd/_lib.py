@@ -94,6 +94,7 @@ SIGNATURES = {
     "mnk_ls_check_solve": (C.c_int, [_vp]),
     "mnk_ls_get_factor": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mnk_ls_bk_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp]),
+    "mnk_ls_get_stat": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "mnk_sc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
     "mnk_sc_set_barrier_terms": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mnk_sc_solve_kkt": (C.c_int, [_vp, _vp, _vp, C.c_int]),

@@ -101,6 +101,7 @@ struct mnk_ctx {
     int children = 0;
     bool released = false;
 };
+int mnk_live_contexts(int device);  // contexts alive on this device in this process
 void mnk_ctx_child_added(mnk_ctx* ctx);
 void mnk_ctx_child_gone(mnk_ctx* ctx);
 

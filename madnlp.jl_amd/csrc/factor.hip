@@ -21,6 +21,7 @@
 // A device-side `info` word makes every later kernel a no-op once a pivot fails
 // (LAPACK stops at the failing column; we cannot stop the host without a sync).
 #include <atomic>
+#include <type_traits>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -671,25 +672,16 @@ __device__ __forceinline__ void factor_piv4_vals(const double p00, const double 
 // (one wave; `Lsh` / `Ish`: optional LDS copies of the factored block and of its four 16x16 inverses)
 // VAR != 0: timing-only ablations for mnk_debug_potrf64 (results are wrong): 1 no 16x16 inverses, 2 no dvec/dinv/info
 // stores, 3 only the critical update MFMA, 4 no per-lane selection of the 4x4 factor, 5 load + store only, 6 no Dout stores
+// potrf64w_core: the block is already in registers (Lt[cb][b], b <= cb, strict upper triangle of the diagonal
+// 16x16 blocks zeroed); potrf64w_body loads it from the factor matrix first.
 template <bool LDL, int VAR = 0>
-__device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
-                                              double* __restrict__ Dout, double* __restrict__ inv16,
-                                              double* __restrict__ dvec, double* __restrict__ dinv,
-                                              int* __restrict__ info, double pivot_tol, double* Lsh, double* Ish) {
+__device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, double* __restrict__ Dout,
+                                              double* __restrict__ inv16, double* __restrict__ dvec,
+                                              double* __restrict__ dinv, int* __restrict__ info, double pivot_tol,
+                                              double* Lsh, double* Ish) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-    v4d Lt[4][4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int b = 0; b <= cb; ++b)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = F[(j0 + 16 * cb + l15) + (j0 + 16 * b + l4 + 4 * r) * ld];
-                // 'L' storage: the strict upper triangle of the block may hold anything (NaN included)
-                Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v;
-            }
 #pragma unroll
     for (int b = 0; b < (VAR == 5 ? 0 : 4); ++b) {
         double aopinv[4];
@@ -812,6 +804,27 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
             for (int b = 0; b <= cb; ++b) acc += Lt[cb][b][0] + Lt[cb][b][1] + Lt[cb][b][2] + Lt[cb][b][3];
         Dout[lane] = acc;
     }
+}
+
+template <bool LDL, int VAR = 0>
+__device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
+                                              double* __restrict__ Dout, double* __restrict__ inv16,
+                                              double* __restrict__ dvec, double* __restrict__ dinv,
+                                              int* __restrict__ info, double pivot_tol, double* Lsh, double* Ish) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4d Lt[4][4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int b = 0; b <= cb; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = F[(j0 + 16 * cb + l15) + (j0 + 16 * b + l4 + 4 * r) * ld];
+                // 'L' storage: the strict upper triangle of the block may hold anything (NaN included)
+                Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v;
+            }
+    potrf64w_core<LDL, VAR>(Lt, j0, Dout, inv16, dvec, dinv, info, pivot_tol, Lsh, Ish);
 }
 
 template <bool LDL>
@@ -1050,6 +1063,215 @@ __global__ __launch_bounds__(256) void trsm256_mfma_kernel(double* __restrict__ 
                 F[(r0 + l15) + (j0 + c) * ld] = X[cb][r];
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent panel kernel (panel_algo = 4): ONE launch factors nb <= NB 64-column blocks of a panel, every row of it.
+// Workgroup t owns the 64-row strip t of the panel (wave w: 16 rows, its nb x 4 column blocks of 16 stay in
+// registers, C^T layout as in trsm64_mfma_kernel).  The strips 0..nb-1 hold the diagonal blocks.  Right-looking, per
+// column block j:   strip j: wave 0 factors the diagonal block (potrf64w_core) and publishes it;
+//                   strip t > j: waits for it, X = T L_jj^-T, stores V / L, then T[t, c] -= V[t, j] L[c, j]^T for the
+//                   later column blocks c <= t, where L[c, j] is what strip c published in ITS step j.
+// prog[c] = 16 * epoch + (number of column blocks strip c has completed and published); release/acquire at agent scope
+// as in handoff_*.  Only the nb diagonal strips are ever waited for, and a diagonal strip only waits for lower-numbered
+// ones, so the kernel needs no co-residency beyond "lower block ids are dispatched no later than higher ones"; every
+// wait is bounded (info = -7 instead of a hang).  Strips that are dispatched late find every flag set.
+// The critical chain per 64 columns is potrf (one wave) -> flag hop -> strip j+1: triangular solve of 64 rows, K = 64
+// update of its diagonal block from LDS, exchange to wave 0 -> potrf: no kernel boundaries and no idle launches.
+// ---------------------------------------------------------------------------------------
+constexpr long PP_SPIN_LIMIT = 1L << 20;  // ~0.5 s
+constexpr int PP_LDS_BYTES = 3 * 4096 * 8;  // two staging tiles (the first doubles as the exchange buffer) + own tile
+
+__device__ __forceinline__ void pp_wait(const int* flag, int target, int& seen, int* info) {
+    if (seen >= target) return;
+    long spins = 0;
+    int v;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023) == 0) {
+            // a failed factorization (or a dependency that never arrives) must not hang: carry on with whatever is
+            // there -- info != 0 makes every result of this factorization void
+            if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (spins > PP_SPIN_LIMIT) {
+                atomicCAS(info, 0, -7);
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    seen = v;
+}
+
+template <bool LDL, int NB>
+__global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int64_t ld, int64_t p0, int nb, int64_t Np,
+                                                      double* __restrict__ dblk0, double* __restrict__ inv0,
+                                                      double* __restrict__ dvec, double* __restrict__ dinv,
+                                                      double* __restrict__ W, int64_t ldw, int64_t wcol0,
+                                                      int* __restrict__ info, double pivot_tol, int* __restrict__ prog,
+                                                      int epoch16, int dbg_missing) {
+    extern __shared__ __attribute__((aligned(16))) char pp_smem[];
+    v4d* stage = reinterpret_cast<v4d*>(pp_smem);          // [2][1024] v4d
+    v4d* own = reinterpret_cast<v4d*>(pp_smem) + 2 * 1024;  // [1024] v4d
+    __shared__ int s_go;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_go = (*info == 0) ? 1 : 0;
+    __syncthreads();
+    if (!s_go) return;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int t = blockIdx.x;
+    const int64_t R = p0 + 64 * (int64_t)t;
+    if (R >= Np || t == dbg_missing) return;
+    const int64_t r0 = R + 16 * w;
+    const int jmax = t < nb - 1 ? t : nb - 1;
+    const bool diag_strip = t < nb;
+    int seen[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) seen[c] = 0;
+
+    v4d X[4 * NB];
+#pragma unroll
+    for (int g = 0; g < 4 * NB; ++g)
+        if (g < 4 * (jmax + 1)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[g][r] = F[(r0 + l15) + (p0 + 16 * g + l4 + 4 * r) * ld];
+        }
+
+    // One step per column block.  `j` is a compile-time constant (generic lambda over integral_constant), so every
+    // index into X is static from the start and the strip stays in registers; returns true when the strip is done.
+    auto step = [&](auto Jc) __attribute__((always_inline)) -> bool {
+        constexpr int j = decltype(Jc)::value;
+        if (j > jmax) return true;
+        if (j > 0) __syncthreads();  // the LDS tiles of the previous step are free
+        if (j == t) {
+            // ---- diagonal step: hand the updated 64x64 block to wave 0 (same lane mapping), factor, publish
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (b <= w) stage[(w * (w + 1) / 2 + b) * 64 + lane] = X[4 * j + b];
+            __syncthreads();
+            if (w != 0) return true;
+            v4d Lt[4][4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int b = 0; b <= cb; ++b) {
+                    const v4d v = stage[(cb * (cb + 1) / 2 + b) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v[r];
+                }
+            const int64_t jb = (p0 >> 6) + j;
+            potrf64w_core<LDL>(Lt, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol, nullptr,
+                               nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(prog + j, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+        // ---- wait for the diagonal block j, X = T L_jj^-T
+        pp_wait(prog + j, epoch16 + j + 1, seen[j], info);
+        const int64_t jb = (p0 >> 6) + j;
+        const double* Dblk = dblk0 + jb * 4096;
+        const double* Iv16 = inv0 + jb * 1024;
+        {
+            double Ln[6][4], Iv[4][4];
+            int p = 0;
+#pragma unroll
+            for (int cb = 1; cb < 4; ++cb)
+#pragma unroll
+                for (int ib = 0; ib < cb; ++ib, ++p)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) Ln[p][s] = -Dblk[(16 * cb + l15) + 64 * (16 * ib + 4 * s + l4)];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) Iv[cb][s] = Iv16[cb * 256 + l15 + 16 * (4 * s + l4)];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                v4d tt = X[4 * j + cb];
+#pragma unroll
+                for (int ib = 0; ib < cb; ++ib) {
+                    const int q = cb * (cb - 1) / 2 + ib;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        tt = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[q][s], X[4 * j + ib][s], tt, 0, 0, 0);
+                }
+                v4d x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[cb][s], tt[s], x, 0, 0, 0);
+                X[4 * j + cb] = x;
+            }
+        }
+        // ---- store V (LDL: to the W panel) and L; a diagonal strip also keeps its L rows in LDS and publishes
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            v4d lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 64 * j + 16 * ib + l4 + 4 * r;
+                const int64_t row = r0 + l15;
+                const double v = X[4 * j + ib][r];
+                if (LDL) {
+                    lv[r] = v * dinv[p0 + c];
+                    W[row + (wcol0 + c) * ldw] = v;
+                } else {
+                    lv[r] = v;
+                }
+                F[row + (p0 + c) * ld] = lv[r];
+            }
+            if (diag_strip) own[(w * 4 + ib) * 64 + lane] = lv;
+        }
+        if (diag_strip) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(prog + t, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
+        v4d pre[4];
+        auto prefetch = [&](int c, int& seen_c) {
+            pp_wait(prog + c, epoch16 + j + 1, seen_c, info);
+            const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 + 64 * j + w) * ld;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pre[ib][s] = src[(16 * ib + 4 * s) * ld];
+        };
+        if (j + 1 <= jmax && j + 1 != t) prefetch(j + 1, seen[j + 1 < NB ? j + 1 : 0]);
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+            if (c > jmax) break;
+            v4d* tile = c == t ? own : stage + (c & 1) * 1024;
+            if (c != t) {
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) tile[((lane >> 4) * 4 + ib) * 64 + (lane & 15) + 16 * w] = pre[ib];
+            }
+            __syncthreads();
+            if (c + 1 < NB && c + 1 <= jmax && c + 1 != t) prefetch(c + 1, seen[c + 1 < NB ? c + 1 : 0]);
+#pragma unroll
+            for (int cb2 = 0; cb2 < 4; ++cb2) {
+                if (c == t && cb2 > w) break;  // own diagonal block: lower triangle only
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    const v4d a = tile[(cb2 * 4 + ib) * 64 + lane];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        X[4 * c + cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], X[4 * j + ib][s], X[4 * c + cb2], 0, 0, 0);
+                }
+            }
+        }
+        return false;
+    };
+    if (step(std::integral_constant<int, 0>{})) return;
+    if (NB > 1 && step(std::integral_constant<int, (NB > 1 ? 1 : 0)>{})) return;
+    if (NB > 2 && step(std::integral_constant<int, (NB > 2 ? 2 : 0)>{})) return;
+    if (NB > 3 && step(std::integral_constant<int, (NB > 3 ? 3 : 0)>{})) return;
+    if (NB > 4 && step(std::integral_constant<int, (NB > 4 ? 4 : 0)>{})) return;
+    if (NB > 5 && step(std::integral_constant<int, (NB > 5 ? 5 : 0)>{})) return;
+    if (NB > 6 && step(std::integral_constant<int, (NB > 6 ? 6 : 0)>{})) return;
+    if (NB > 7 && step(std::integral_constant<int, (NB > 7 ? 7 : 0)>{})) return;
 }
 
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
@@ -1310,10 +1532,71 @@ static int factor_outer_panel_256(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t
     return 0;
 }
 
+// panel_algo = 4: persistent panel launches (ppanel_kernel) of pp_nb blocks, recursive updates between them
+static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
+                                 hipEvent_t rest_ready, int64_t rest_from) {
+    const int64_t Np = ls->Np, ld = ls->ld;
+    const bool ldl = ls->algo == MNK_LDL;
+    double* F = ls->fact.p;
+    {   // 96 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        MNK_HIP(hipGetDevice(&dev));
+        if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
+    }
+    const int NBs = ls->pp_nb == 4 ? 4 : 8;
+    const int64_t ws = (int64_t)NBI * NBs;
+    const int epoch16 = ls->epoch * 16;
+    bool waited = rest_ready == nullptr;
+    for (int64_t p = ko; p < kend; p += ws) {
+        const int nbk = (int)std::min<int64_t>(NBs, (kend - p) / NBI);
+        if (!waited && p + NBI * nbk > ko + rest_from) {
+            MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
+            waited = true;
+        }
+        const unsigned grid = (unsigned)((Np - p) / NBI);
+#define MNK_PP(LD, NBT)                                                                                              \
+    hipLaunchKernelGGL((ppanel_kernel<LD, NBT>), dim3(grid), dim3(256), PP_LDS_BYTES, s, F, ld, p, nbk, Np, ls->dblk.p, \
+                       ls->inv16.p, ls->dvec.p, ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0,  \
+                       p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing)
+        if (ldl) { if (NBs == 8) MNK_PP(true, 8); else MNK_PP(true, 4); }
+        else { if (NBs == 8) MNK_PP(false, 8); else MNK_PP(false, 4); }
+#undef MNK_PP
+        const int64_t p1 = p + NBI * nbk;
+        if (p1 >= kend) break;
+        const int64_t jj = (p1 - ko) / ws;    // launches of this outer panel that are finished
+        const int64_t w = ws * (jj & -jj);     // columns whose contribution is applied now
+        const int64_t pb = p1 - w;
+        const int64_t ncols = std::min<int64_t>(w, kend - p1);
+        if (!waited && p1 + ncols > ko + rest_from) {
+            MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
+            waited = true;
+        }
+        const double* Wp = ldl ? wbase + p1 + (pb - ko) * ls->ldw : F + p1 + pb * ld;
+        int rc;
+        if (gemm_nt_lower_tiles(Np - p1, ncols) < ls->small_tiles_mid)
+            rc = launch_gemm_nt_lower_small(s, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + pb * ld, ld,
+                                            F + p1 + p1 * ld, ld, ls->info_dev.p);
+        else
+            rc = launch_gemm_nt(s, 2, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + pb * ld, ld, F + p1 + p1 * ld,
+                                ld, nullptr, nullptr, 0, ls->info_dev.p);
+        if (rc) return rc;
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
                               hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
-    if (ls->panel_algo == 0) return factor_outer_panel_fused(ls, s, ko, kend, wbase, rest_ready, rest_from);
-    if (ls->panel_algo == 3) return factor_outer_panel_256(ls, s, ko, kend, wbase, rest_ready, rest_from);
+    if (ls->algo_now == 4) return factor_outer_panel_pp(ls, s, ko, kend, wbase, rest_ready, rest_from);
+    if (ls->algo_now == 0) return factor_outer_panel_fused(ls, s, ko, kend, wbase, rest_ready, rest_from);
+    if (ls->algo_now == 3) return factor_outer_panel_256(ls, s, ko, kend, wbase, rest_ready, rest_from);
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
@@ -1324,7 +1607,7 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
     // diagonal block through a flag.  flag_u[b] / flag_p[b]: block b's diagonal tile is updated / factored.
     mnk_ctx* ctx = ls->ctx;
     hipStream_t sq = s == ctx->sp ? ctx->sq : (s == ctx->stream ? ctx->sq0 : nullptr);
-    const bool overlap = ls->overlap && ls->panel_algo == 1 && sq != nullptr && kend - ko > NBI;
+    const bool overlap = ls->overlap && ls->algo_now == 1 && sq != nullptr && kend - ko > NBI;
     const int epoch = ls->epoch;
     if (overlap) {
         MNK_HIP(hipEventRecord(ctx->ev_q, s));  // the companion stream must not run ahead of this panel
@@ -1337,7 +1620,7 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         hipStream_t sd = on_q ? sq : s;
         const int* wflag = on_q ? ls->flag_u.p + j / NBI : nullptr;
         int* dflag = overlap ? ls->flag_p.p + j / NBI : nullptr;
-        if (ls->panel_algo == 2) {  // 256-thread LDS/barrier diagonal-block kernel (A/B runs)
+        if (ls->algo_now == 2) {  // 256-thread LDS/barrier diagonal-block kernel (A/B runs)
             if (ldl)
                 hipLaunchKernelGGL(potrf64_kernel<true>, dim3(1), dim3(256), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
                                    ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
@@ -1413,12 +1696,17 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     double* F = ls->fact.p;
     const int64_t NBO = mnk_ls_effective_nbo(ls);
     MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));
-    if (ls->overlap && !ls->flag_u.p) {
+    if ((ls->overlap || ls->panel_algo == 4) && !ls->flag_u.p) {
         if (ls->flag_u.alloc(Np / NBI + 1) || ls->flag_p.alloc(Np / NBI + 1)) return -2;
         MNK_HIP(hipMemsetAsync(ls->flag_u.p, 0, (Np / NBI + 1) * sizeof(int), s));
         MNK_HIP(hipMemsetAsync(ls->flag_p.p, 0, (Np / NBI + 1) * sizeof(int), s));
     }
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
+    // The persistent panel kernel keeps waiting workgroups resident.  Two of them from different contexts on the same
+    // CUs can starve each other's diagonal strips (per-XCD dispatch order), so it is used only while this context is
+    // the only one on the device; a wait that expires anyway (another process) falls back for good (mnk_ls_fetch_info).
+    ls->algo_now = ls->panel_algo;
+    if (ls->algo_now == 4 && (ls->pp_blocked || mnk_live_contexts(ctx->device) > 1)) ls->algo_now = 1;
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
     // chain, not by the update: narrower outer panels (tail_nbo) then drop the middle-level update and halve
     // the depth of the (a) piece the chain waits for (measured: 355 -> ~300 us per 512 columns of the tail).
@@ -1517,7 +1805,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             // delivers the other columns while that block is being factored.  split_a == 1: first 256 columns
             // on the update stream, then the rest.
             // (the 256-column panel step needs the first 256 columns at once: they come from the update stream)
-            const bool own_first = ls->split_a == 2 && nnext > NBI && ls->panel_algo != 3;
+            const bool own_first = ls->split_a == 2 && nnext > NBI && ls->algo_now != 3;
             const int64_t n1 = own_first ? NBI : std::min<int64_t>(256, nnext);
             const bool split_a = ls->split_a && nnext > n1;
             if (own_first) {
@@ -1659,6 +1947,17 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     MNK_HIP(hipMemcpyAsync(h, ls->inertia_dev.p, sizeof(h), hipMemcpyDeviceToHost, s));
     MNK_HIP(hipMemcpyAsync(&hinfo, ls->info_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
     MNK_HIP(hipStreamSynchronize(s));
+    if (hinfo == -7 && ls->algo_now == 4 && ls->retransfer) {
+        // the persistent panel kernel gave up on a dependency (CUs shared with another process' persistent kernels):
+        // factor again with one launch per panel piece, and stay there
+        ls->pp_blocked = true;
+        ++ls->pp_fallbacks;
+        int rc = ls->retransfer();
+        if (rc) return rc;
+        rc = mnk_ls_run_factorization(ls);
+        if (rc) return rc;
+        return mnk_ls_fetch_info(ls);
+    }
     if (hinfo < 0) {
         // a bounded device-side wait between the diagonal-block stream and the panel stream expired (see handoff_wait)
         set_error("factorize!: a device-side hand-off timed out (info = %d); the factor is invalid -- retry with option "

@@ -60,10 +60,15 @@ struct mnk_ls {
     mnk::DevBuf<int> flag_u, flag_p;
     int panel0_whole = 1;  // look-ahead: the first outer panel is factored on the whole chip before the streams fork
     int small_tiles_256 = 160;  // panel_algo 3: inner K >= 256 updates with fewer 128x128 tiles than this use 64x64 tiles
-    int panel_algo = 1;  // 3: potrf256 + trsm256 per 256 columns (measured slower, kept for A/B); 1: potrf64 + MFMA triangular solve + recursive inner updates; 0: fused elimination kernel (round 1)
+    int algo_now = 1;    // the panel algorithm of the current factorization (panel_algo, or 1 where 4 is not safe)
+    bool pp_blocked = false;
+    int pp_fallbacks = 0;
+    int pp_nb = 4;       // panel_algo 4: 64-column blocks per persistent panel launch (4 or 8)
+    int panel_algo = 4;  // 3: potrf256 + trsm256 per 256 columns (measured slower, kept for A/B); 1: potrf64 + MFMA triangular solve + recursive inner updates; 0: fused elimination kernel (round 1)
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
     long ps_spin_limit = 6000000;  // polls (~0.5 us each) a persistent-solve wait may take before it gives up
+    int debug_pp_missing = -1;     // tests only: this diagonal strip of every persistent panel launch never publishes
     int debug_ps_missing = -1;     // tests only: this workgroup of the persistent solve leaves at once (a peer that never became resident)
     mnk::DevBuf<unsigned long long> solve_trace;  // diagnostics: 8 time stamps per 64-row block (option solve_trace)
     mnk::DevBuf<int> info_dev;

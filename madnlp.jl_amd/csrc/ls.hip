@@ -4,6 +4,7 @@
 // solve entry points.  See include/madnlp_hip.h for the per-function citations.
 #include <cstdarg>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 #include "ls.h"
@@ -67,9 +68,13 @@ __global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restri
 using namespace mnk;
 
 static std::mutex g_ctx_mutex;
+static std::atomic<int> g_live_ctx[64];
+
+int mnk_live_contexts(int device) { return g_live_ctx[device & 63].load(std::memory_order_relaxed); }
 
 static void ctx_free(mnk_ctx* c) {
     (void)hipSetDevice(c->device);
+    g_live_ctx[c->device & 63].fetch_sub(1, std::memory_order_relaxed);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
@@ -209,6 +214,7 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
     MNK_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+    g_live_ctx[device & 63].fetch_add(1, std::memory_order_relaxed);
     *out = c;
     return 0;
 }
@@ -261,6 +267,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
+    if (const char* e = getenv("MNK_PP_NB")) ls->pp_nb = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
     if (const char* e = getenv("MNK_OVERLAP")) ls->overlap = atoi(e);
     if (const char* e = getenv("MNK_SMALL_TILES_256")) ls->small_tiles_256 = atoi(e);
@@ -330,6 +337,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // 1 (default): one-wave potrf64 + trsm64 + recursive inner updates per 64 columns; 3: potrf256 + trsm256 per 256
     // columns (one launch per four pivot chains; measured 5 % slower at N = 11192, kept for A/B runs); 2: the same with the 256-thread LDS potrf64; 0: the fused elimination kernel of round 1
     if (!strcmp(key, "panel_algo")) { ls->panel_algo = (int)value; return 0; }
+    if (!strcmp(key, "pp_nb")) { ls->pp_nb = (int)value == 4 ? 4 : 8; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
@@ -343,6 +351,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     // tests only: workgroup `value` of every persistent solve leaves at once, as a peer that never became
     // resident would (< 0: off); the others must give up after ps_spin_limit polls instead of hanging
+    if (!strcmp(key, "debug_pp_missing")) { ls->debug_pp_missing = (int)value; return 0; }
     if (!strcmp(key, "debug_ps_missing")) { ls->debug_ps_missing = (int)value; return 0; }
     if (!strcmp(key, "solve_trace")) {  // diagnostics: time stamps of the forward sweep's critical path
         if (value != 0.0) {
@@ -599,6 +608,19 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
     if (D) MNK_HIP(hipMemcpyAsync(D, ls->dvec.p, ls->N * sizeof(double), kind, s));
     MNK_HIP(hipStreamSynchronize(s));
     return 0;
+}
+
+int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
+    MNK_REQUIRE(ls && key && value, "mnk_ls_get_stat: NULL argument");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    if (ls->factorized) {
+        int rc = mnk_ls_fetch_info(ls);
+        if (rc) return rc;
+    }
+    if (!strcmp(key, "panel_algo")) { *value = ls->algo_now; return 0; }
+    if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
+    set_error("mnk_ls_get_stat: unknown key '%s'", key);
+    return -1;
 }
 
 int mnk_ls_bk_info(mnk_ls* ls, int* active, int* count, int32_t* perm, double* doff) {

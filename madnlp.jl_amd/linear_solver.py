@@ -269,6 +269,12 @@ class HipLinearSolver:
                 "mnk_ls_bk_info")
         return True, cnt.value, perm, doff
 
+    def get_stat(self, key: str) -> float:
+        """`mnk_ls_get_stat`: "panel_algo" (algorithm that produced the current factor), "pp_fallbacks"."""
+        v = C.c_double(0.0)
+        L.check(L.lib().mnk_ls_get_stat(self._h, key.encode(), C.byref(v)), "mnk_ls_get_stat")
+        return v.value
+
     def set_option(self, key: str, value: float):
         L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(value)), "mnk_ls_set_option")
 

@@ -406,3 +406,55 @@ def test_ipm_lootsma_hip_reproduces_reference_answers(ctx, kind):
     cmp = lambda a, b: (np.abs(a - b).max() < tol) or (np.abs(a - b).max() / np.abs(b).max() < tol)  # noqa: E731
     assert cmp(sh.x[:3], nlp.LOOTSMA_X) and cmp(sh.y, nlp.LOOTSMA_Y), (sh.x[:3], sh.y)
     sh.kkt.close()
+
+
+# --------------------------------------------------------------------------- persistent panel kernel: safety net
+def test_persistent_panel_is_the_default_when_the_context_is_alone_and_gives_way_otherwise(ctx):
+    """panel_algo = 4 keeps waiting workgroups resident, which is only safe while no other context of the process
+    runs persistent kernels on the same CUs: with one live context the factor comes from it, with a second context
+    alive the solver takes the one-launch-per-piece path by itself; the factors agree to rounding."""
+    rng = np.random.default_rng(4)
+    N = 1500
+    A = _spd(rng, N)
+    b = rng.standard_normal(N)
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
+    M.factorize()
+    alone = M.get_stat("panel_algo")
+    x4 = M.solve_linear_system(b.copy())
+    other = mj.HipContext(0)
+    try:
+        M.factorize()
+        assert M.get_stat("panel_algo") == 1.0
+        x1 = M.solve_linear_system(b.copy())
+    finally:
+        other.close()
+    M.factorize()
+    assert M.get_stat("panel_algo") == alone
+    assert np.abs(A @ x4 - b).max() <= 1e-10 * N and np.abs(A @ x1 - b).max() <= 1e-10 * N
+    np.testing.assert_allclose(x1, x4, rtol=0, atol=1e-11 * np.abs(x4).max())
+    M.close()
+
+
+@pytest.mark.parametrize("alg", [mj.CHOLESKY, mj.LDL])
+def test_persistent_panel_that_gives_up_is_redone_without_it(ctx, alg):
+    """A diagonal strip that never publishes (simulated: option debug_pp_missing; in the field: another process'
+    persistent kernels starving it) must not hang: the waiters give up after a bounded number of polls (info = -7),
+    the factorization is redone with one launch per panel piece when `info` is read, and the solver stays there."""
+    rng = np.random.default_rng(5)
+    N = 1000
+    A = _spd(rng, N)
+    b = rng.standard_normal(N)
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
+    M.factorize()
+    assert M.get_stat("panel_algo") == 4.0, "the module's context should be the only live one here"
+    x_ok = M.solve_linear_system(b.copy())
+    M.set_option("debug_pp_missing", 1)
+    M.factorize()
+    assert M.inertia() == (N, 0, 0)
+    assert M.get_stat("pp_fallbacks") == 1.0 and M.get_stat("panel_algo") == 1.0
+    x = M.solve_linear_system(b.copy())
+    assert np.abs(A @ x - b).max() <= 1e-10 * N
+    np.testing.assert_allclose(x, x_ok, rtol=0, atol=1e-11 * np.abs(x_ok).max())
+    M.factorize()                      # stays on the safe path: no second time-out
+    assert M.get_stat("pp_fallbacks") == 1.0 and M.get_stat("panel_algo") == 1.0
+    M.close()
