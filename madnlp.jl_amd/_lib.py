@@ -29,20 +29,44 @@ def _stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+# Per-file backend flags.  `-amdgpu-mfma-vgpr-form` (MFMA accumulators in VGPRs, no AGPR copies) is worth +3 % on the
+# 168-VGPR tile kernels of gemm_f64.hip.  It must NOT be applied to factor.hip: the persistent panel kernel needs more
+# than 256 registers per lane, and with the flag the accumulators are pinned to the 256 architectural VGPRs and the rest
+# is shuffled through AGPRs -- hipcc 7.2 then miscompiles it (wrong pivots / memory faults that appear and disappear with
+# unrelated, never-executed code; bisected in round 2).
+FILE_FLAGS = {"gemm_f64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into madnlp.jl_amd/lib/libmadnlp_hip.so."""
+    """Compile every HIP source for gfx950 (one object per source, in parallel) and link
+    madnlp.jl_amd/lib/libmadnlp_hip.so."""
     if not force and not _stale():
         return LIBPATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-mllvm", "-amdgpu-mfma-vgpr-form",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIBPATH]
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = base + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIBPATH]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     return LIBPATH
 
 

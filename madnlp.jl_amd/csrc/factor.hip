@@ -1082,11 +1082,14 @@ __global__ __launch_bounds__(256) void trsm256_mfma_kernel(double* __restrict__ 
 constexpr long PP_SPIN_LIMIT = 1L << 20;  // ~0.5 s
 constexpr int PP_LDS_BYTES = 3 * 4096 * 8;  // two staging tiles (the first doubles as the exchange buffer) + own tile
 
-__device__ __forceinline__ void pp_wait(const int* flag, int target, int& seen, int* info) {
-    if (seen >= target) return;
+// Wave-uniform bounded wait for prog[c] >= target.  `seen` caches the last values read: one acquire covers everything
+// that was published before ANY flag value read ahead of it, so every successful wait refreshes all nb entries and
+// later waits that are already satisfied cost nothing (no further cache invalidation).
+template <int NB>
+__device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int target, int (&seen)[NB], int* info) {
+    if (seen[c] >= target) return;
     long spins = 0;
-    int v;
-    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+    while (__hip_atomic_load(prog + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023) == 0) {
             // a failed factorization (or a dependency that never arrives) must not hang: carry on with whatever is
@@ -1098,8 +1101,12 @@ __device__ __forceinline__ void pp_wait(const int* flag, int target, int& seen, 
             }
         }
     }
+    int v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v[i] = i < nb ? __hip_atomic_load(prog + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    seen = v;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) seen[i] = v[i];
 }
 
 template <bool LDL, int NB>
@@ -1108,8 +1115,9 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                                                       double* __restrict__ dvec, double* __restrict__ dinv,
                                                       double* __restrict__ W, int64_t ldw, int64_t wcol0,
                                                       int* __restrict__ info, double pivot_tol, int* __restrict__ prog,
-                                                      int epoch16, int dbg_missing) {
-    extern __shared__ __attribute__((aligned(16))) char pp_smem[];
+                                                      int epoch16, int dbg_missing, const double* __restrict__ Vp,
+                                                      int64_t ldv, int Kp) {
+    extern __shared__ __attribute__((aligned(128))) char pp_smem[];
     v4d* stage = reinterpret_cast<v4d*>(pp_smem);          // [2][1024] v4d
     v4d* own = reinterpret_cast<v4d*>(pp_smem) + 2 * 1024;  // [1024] v4d
     __shared__ int s_go;
@@ -1136,6 +1144,64 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) X[g][r] = F[(r0 + l15) + (p0 + 16 * g + l4 + 4 * r) * ld];
         }
+
+    // ---- optional left-looking prologue: apply the Kp columns just before this launch (the previous outer panel, or
+    // the previous launch of this panel) to the strip, instead of a separate update kernel in front of the launch:
+    // T[t, c] -= V[t, p0-Kp : p0] L[p0 + 64 c .., p0-Kp : p0]^T.  Used where the panel chain is the critical path (few
+    // rows left): the first diagonal block is ready after Kp/64 K = 64 products of one workgroup, with no kernel
+    // boundary and no cross-stream hand-over in front of the pivot chain.
+    if (Kp > 0) {
+        const int nch = Kp >> 6, ncb = jmax + 1;
+        v4d pre[4], Bv[4], Bn[4];
+        auto tile_load = [&](int kc, int c) {
+            const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 - Kp + 64 * (int64_t)kc + w) * ld;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) pre[ib][s] = src[(16 * ib + 4 * s) * ld];
+        };
+        auto b_load = [&](int kc, v4d (&B)[4]) {
+            const double* src = Vp + (r0 + l15) + (64 * (int64_t)kc + l4) * ldv;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) B[ib][s] = src[(16 * ib + 4 * s) * ldv];
+        };
+        int it = 0;
+        tile_load(0, 0);
+        b_load(0, Bn);
+        for (int kc = 0; kc < nch; ++kc) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) Bv[ib] = Bn[ib];
+            if (kc + 1 < nch) b_load(kc + 1, Bn);
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c >= ncb) break;
+                v4d* tile = stage + (it & 1) * 1024;
+                ++it;
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) tile[((lane >> 4) * 4 + ib) * 64 + (lane & 15) + 16 * w] = pre[ib];
+                __syncthreads();
+                {
+                    int c2 = c + 1, k2 = kc;
+                    if (c2 >= ncb) { c2 = 0; k2 = kc + 1; }
+                    if (k2 < nch) tile_load(k2, c2);
+                }
+#pragma unroll
+                for (int cb2 = 0; cb2 < 4; ++cb2) {
+                    if (c == t && cb2 > w) break;  // own diagonal block: lower triangle only
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) {
+                        const v4d a = tile[(cb2 * 4 + ib) * 64 + lane];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            X[4 * c + cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], Bv[ib][s], X[4 * c + cb2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // One step per column block.  `j` is a compile-time constant (generic lambda over integral_constant), so every
     // index into X is static from the start and the strip stays in registers; returns true when the strip is done.
@@ -1168,7 +1234,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
             return true;
         }
         // ---- wait for the diagonal block j, X = T L_jj^-T
-        pp_wait(prog + j, epoch16 + j + 1, seen[j], info);
+        pp_wait<NB>(prog, j, nb, epoch16 + j + 1, seen, info);
         const int64_t jb = (p0 >> 6) + j;
         const double* Dblk = dblk0 + jb * 4096;
         const double* Iv16 = inv0 + jb * 1024;
@@ -1231,15 +1297,15 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
         }
         // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
         v4d pre[4];
-        auto prefetch = [&](int c, int& seen_c) {
-            pp_wait(prog + c, epoch16 + j + 1, seen_c, info);
+        auto prefetch = [&](int c) {
+            pp_wait<NB>(prog, c, nb, epoch16 + j + 1, seen, info);
             const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 + 64 * j + w) * ld;
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) pre[ib][s] = src[(16 * ib + 4 * s) * ld];
         };
-        if (j + 1 <= jmax && j + 1 != t) prefetch(j + 1, seen[j + 1 < NB ? j + 1 : 0]);
+        if (j + 1 <= jmax && j + 1 != t) prefetch(j + 1 < NB ? j + 1 : 0);
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) {
             if (c > jmax) break;
@@ -1249,7 +1315,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                 for (int ib = 0; ib < 4; ++ib) tile[((lane >> 4) * 4 + ib) * 64 + (lane & 15) + 16 * w] = pre[ib];
             }
             __syncthreads();
-            if (c + 1 < NB && c + 1 <= jmax && c + 1 != t) prefetch(c + 1, seen[c + 1 < NB ? c + 1 : 0]);
+            if (c + 1 < NB && c + 1 <= jmax && c + 1 != t) prefetch(c + 1 < NB ? c + 1 : 0);
 #pragma unroll
             for (int cb2 = 0; cb2 < 4; ++cb2) {
                 if (c == t && cb2 > w) break;  // own diagonal block: lower triangle only
@@ -1534,7 +1600,8 @@ static int factor_outer_panel_256(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t
 
 // panel_algo = 4: persistent panel launches (ppanel_kernel) of pp_nb blocks, recursive updates between them
 static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
-                                 hipEvent_t rest_ready, int64_t rest_from) {
+                                 hipEvent_t rest_ready, int64_t rest_from, const double* Vfirst, int64_t ldvfirst,
+                                 int64_t Kfirst) {
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
@@ -1550,10 +1617,15 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
             attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
-    const int NBs = ls->pp_nb == 4 ? 4 : 8;
+    const int NBs = (ls->pp_nb == 4 && !(ls->pp_nb8_rows > 0 && Np - ko <= ls->pp_nb8_rows)) ? 4 : 8;
     const int64_t ws = (int64_t)NBI * NBs;
     const int epoch16 = ls->epoch * 16;
     bool waited = rest_ready == nullptr;
+    // columns in front of the next launch that it applies itself (ppanel_kernel's prologue)
+    const double* Vp = Vfirst;
+    int64_t ldv = ldvfirst;
+    int Kp = (int)Kfirst;
+    const bool fuse_mid = NBs == 4 && ls->pp_fuse_rows > 0 && Np - ko <= ls->pp_fuse_rows;
     for (int64_t p = ko; p < kend; p += ws) {
         const int nbk = (int)std::min<int64_t>(NBs, (kend - p) / NBI);
         if (!waited && p + NBI * nbk > ko + rest_from) {
@@ -1564,16 +1636,25 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
 #define MNK_PP(LD, NBT)                                                                                              \
     hipLaunchKernelGGL((ppanel_kernel<LD, NBT>), dim3(grid), dim3(256), PP_LDS_BYTES, s, F, ld, p, nbk, Np, ls->dblk.p, \
                        ls->inv16.p, ls->dvec.p, ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0,  \
-                       p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing)
+                       p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp,  \
+                       ldv, Kp)
         if (ldl) { if (NBs == 8) MNK_PP(true, 8); else MNK_PP(true, 4); }
         else { if (NBs == 8) MNK_PP(false, 8); else MNK_PP(false, 4); }
 #undef MNK_PP
+        Vp = nullptr;
+        Kp = 0;
         const int64_t p1 = p + NBI * nbk;
         if (p1 >= kend) break;
         const int64_t jj = (p1 - ko) / ws;    // launches of this outer panel that are finished
         const int64_t w = ws * (jj & -jj);     // columns whose contribution is applied now
         const int64_t pb = p1 - w;
         const int64_t ncols = std::min<int64_t>(w, kend - p1);
+        if (fuse_mid && w == ws && ncols <= ws) {  // exactly the next launch's columns: it applies them itself
+            Vp = ldl ? wbase + (pb - ko) * ls->ldw : F + pb * ld;
+            ldv = ldl ? ls->ldw : ld;
+            Kp = (int)w;
+            continue;
+        }
         if (!waited && p1 + ncols > ko + rest_from) {
             MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
             waited = true;
@@ -1592,9 +1673,13 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
     return 0;
 }
 
+// (Vfirst, ldvfirst, Kfirst: panel_algo 4 only -- the Kfirst columns in front of the panel are applied to its first
+// 256 columns by the first persistent launch itself; V[row, k] = Vfirst[row + k * ldvfirst])
 static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
-                              hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
-    if (ls->algo_now == 4) return factor_outer_panel_pp(ls, s, ko, kend, wbase, rest_ready, rest_from);
+                              hipEvent_t rest_ready = nullptr, int64_t rest_from = 256, const double* Vfirst = nullptr,
+                              int64_t ldvfirst = 0, int64_t Kfirst = 0) {
+    if (ls->algo_now == 4)
+        return factor_outer_panel_pp(ls, s, ko, kend, wbase, rest_ready, rest_from, Vfirst, ldvfirst, Kfirst);
     if (ls->algo_now == 0) return factor_outer_panel_fused(ls, s, ko, kend, wbase, rest_ready, rest_from);
     if (ls->algo_now == 3) return factor_outer_panel_256(ls, s, ko, kend, wbase, rest_ready, rest_from);
     const int64_t Np = ls->Np, ld = ls->ld;
@@ -1805,10 +1890,22 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             // delivers the other columns while that block is being factored.  split_a == 1: first 256 columns
             // on the update stream, then the rest.
             // (the 256-column panel step needs the first 256 columns at once: they come from the update stream)
-            const bool own_first = ls->split_a == 2 && nnext > NBI && ls->algo_now != 3;
-            const int64_t n1 = own_first ? NBI : std::min<int64_t>(256, nnext);
-            const bool split_a = ls->split_a && nnext > n1;
-            if (own_first) {
+            // Few rows left (the pivot chain is the critical path): the first persistent launch of the next panel applies
+            // panel k to its own 256 columns itself (ppanel_kernel's prologue) -- no (a) kernel and no cross-stream
+            // hand-over in front of the chain; the update stream delivers the other columns of the panel meanwhile.
+            const bool fuse_a = ls->algo_now == 4 && ls->pp_nb == 4 && ls->pp_fuse_rows > 0 && Mt <= ls->pp_fuse_rows &&
+                                Kw <= 512 && !(ls->pp_nb8_rows > 0 && Mt <= ls->pp_nb8_rows);
+            const bool own_first = !fuse_a && ls->split_a == 2 && nnext > NBI && ls->algo_now != 3;
+            const int64_t n1 = own_first ? std::min<int64_t>(ls->own_cols, nnext - NBI) : std::min<int64_t>(256, nnext);
+            const bool split_a = (ls->split_a || fuse_a) && nnext > n1;
+            if (fuse_a) {
+                if (k > 0) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_bdone[k - 1], 0));  // (b)_{k-1} touched these columns
+                if (split_a) {
+                    rc = update_a(su, n1, nnext);
+                    if (rc) return rc;
+                    MNK_HIP(hipEventRecord(ctx->ev_next2[k], su));
+                }
+            } else if (own_first) {
                 if (k > 0) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_bdone[k - 1], 0));  // (b)_{k-1} touched these columns
                 rc = update_a(sp, 0, n1);
                 if (rc) return rc;
@@ -1846,9 +1943,10 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             }
             MNK_HIP(hipEventRecord(ctx->ev_bdone[k], su));
             // panel k+1 on the panel stream, as soon as (a) is done
-            if (!own_first) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_next[k], 0));
+            if (!own_first && !fuse_a) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_next[k], 0));
             rc = factor_outer_panel(ls, sp, kend, kend + nnext, ls->wbuf[(k + 1) & 1].p,
-                                    split_a ? ctx->ev_next2[k] : nullptr, own_first ? NBI : 256);
+                                    split_a ? ctx->ev_next2[k] : nullptr, own_first ? n1 : 256,
+                                    fuse_a ? (ldl ? wk : F + ko * ld) : nullptr, ldws, fuse_a ? Kw : 0);
             if (rc) return rc;
             if (shared_b) {
                 rc = launch_gemm_nt_queue(sp, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,

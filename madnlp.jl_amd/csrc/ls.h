@@ -63,6 +63,9 @@ struct mnk_ls {
     int algo_now = 1;    // the panel algorithm of the current factorization (panel_algo, or 1 where 4 is not safe)
     bool pp_blocked = false;
     int pp_fallbacks = 0;
+    int64_t pp_nb8_rows = 0;  // > 0: persistent panel launches cover 8 blocks once this many rows (or fewer) remain
+    int64_t pp_fuse_rows = 4096; // > 0: once this many rows (or fewer) remain, persistent panel launches apply the columns in front of them themselves
+    int64_t own_cols = 128;   // split_a = 2: columns of the next panel that the panel stream updates itself
     int pp_nb = 4;       // panel_algo 4: 64-column blocks per persistent panel launch (4 or 8)
     int panel_algo = 4;  // 3: potrf256 + trsm256 per 256 columns (measured slower, kept for A/B); 1: potrf64 + MFMA triangular solve + recursive inner updates; 0: fused elimination kernel (round 1)
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
