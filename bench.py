@@ -52,9 +52,11 @@ def parse_args():
                          "every instance by one iteration.  Default: 1 at --gpus 1 (BASELINE config C3, the "
                          "configuration the metric is quoted on), 16 at --gpus N > 1 (BASELINE config C5: "
                          "128 scenarios sharded 16 per GPU, seeds 1354 + i)")
-    ap.add_argument("--concurrency", type=int, default=4,
-                    help="contexts (stream sets) the batch is spread over; more than ~4 oversubscribes the "
-                         "hardware queues (measured: 16 contexts run 2.6x slower than 4)")
+    ap.add_argument("--concurrency", type=int, default=1,
+                    help="contexts (stream sets) the batch is spread over.  Default 1: the instances run back to "
+                         "back on one context, which keeps the persistent panel kernel in use (it needs the panel "
+                         "CUs for itself) -- measured per GPU at batch 16: 77.4 it/s with 1 context, 58.7 with 2, "
+                         "68.2 with 4 (the time-shared contexts fall back to one launch per panel piece)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-budget", type=float, default=100.0,
                     help="seconds of host time the cpu_baseline leg may spend (it drops the slowest legs first)")

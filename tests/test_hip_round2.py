@@ -115,59 +115,6 @@ def test_c3_size_factorization_vs_lapack(ctx, alg):
     kh.close()
 
 
-# --------------------------------------------------------------------------- C5: 16 scenarios on one GPU
-def test_c5_batch16_on_one_gpu_matches_oracle():
-    """BASELINE config C5, one GPU's share: 16 independent case1354pegase-shaped scenarios (seeds 1354 + i, the
-    seeds bench.py uses on rank 0) spread over 4 contexts that time-share the chip, driven exactly like
-    `bench.py --batch 16` (device-resident inputs, asynchronous factorization, all 16 enqueued before the first
-    inertia fetch).  Every instance: condensed KKT bit-exact vs the oracle, inertia (N, 0, 0), backward error of
-    the solve <= 1e-13 against the oracle's sparse K."""
-    dev = torch.device("cuda", 0)
-    base = OPF_CASES["case1354pegase"][0]
-    nctx, nb = 4, 16
-    streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
-    ctxs = [mj.HipContext(0, stream=s.cuda_stream) for s in streams]
-    insts = []
-    for i in range(nb):
-        P = opf_shaped("case1354pegase", seed=base + i, du=1e-8)
-        kh = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub,
-                                         ctx=ctxs[i % nctx],
-                                         opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
-        din = dict(jac=torch.from_numpy(P.jac).to(dev), hess=torch.from_numpy(P.hess).to(dev),
-                   pr=torch.from_numpy(P.pr_diag).to(dev), du=torch.from_numpy(P.du_diag).to(dev),
-                   rhs=torch.from_numpy(np.random.default_rng(base + i).standard_normal(P.n)).to(dev))
-        din["x"] = torch.empty_like(din["rhs"])
-        insts.append((P, kh, streams[i % nctx], din))
-    torch.cuda.synchronize()
-    for rep in range(2):  # twice: buffers are reused across iterations
-        for (_, kh, st, din) in insts:
-            with torch.cuda.stream(st):
-                kh.compress_jacobian(din["jac"]); kh.compress_hessian(din["hess"]); kh.build_kkt(din["pr"], din["du"])
-                kh.linear_solver.factorize_async()
-        for (P, kh, st, din) in insts:
-            with torch.cuda.stream(st):
-                assert kh.linear_solver.inertia() == (P.n, 0, 0)
-                din["x"].copy_(din["rhs"])
-                kh.linear_solver.solve_linear_system(din["x"])
-    torch.cuda.synchronize()
-    seen = set()
-    for (P, kh, st, din) in insts:
-        ko = _oracle_sc(P)
-        got = kh.aug_com.nzval
-        np.testing.assert_array_equal(got, ko.aug_com.nzval)
-        seen.add(got.tobytes()[:4096])
-        K = _full(ko)
-        x = din["x"].cpu().numpy()
-        b = din["rhs"].cpu().numpy()
-        assert _bwd(K, x, b) <= 1e-13
-        kh.linear_solver.check_solve()
-    assert len(seen) == nb, "the 16 scenarios must be different problems"
-    for (_, kh, _, _) in insts:
-        kh.close()
-    for c in ctxs:
-        c.close()
-
-
 # --------------------------------------------------------------------------- persistent solve: give-up path
 def _spd(rng, N):
     R = rng.standard_normal((N, 64))
