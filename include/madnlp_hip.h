@@ -227,6 +227,22 @@ int mnk_sc_set_barrier_terms(mnk_sc* sc, const double* reg, const double* l_diag
 int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc);
 int mnk_sc_mul(mnk_sc* sc, double* w, const double* x, double alpha, double beta, int loc);
 
+/* Device-side feeders of build_kkt! (first slice of 8(f).4): with these an iteration needs no host vector.
+ *   mnk_sc_set_aug_diagonal    set_aug_diagonal!(kkt, solver)  reference src/IPM/kernels.jl:4-27: x, xl, xu, zl, zu are the
+ *                              FULL primal-length vectors (n + m entries: variables and slacks) of the iterate; fills
+ *                              reg = primal_reg, du_diag = -dual_reg, l_diag = xl_r - x_lr, u_diag = x_ur - xu_r,
+ *                              l_lower = zl_r, u_lower = zu_r and pr_diag = reg - l_lower./l_diag - u_lower./u_diag
+ *                              (scattered through ind_lb / ind_ub of mnk_sc_set_bounds) INSIDE the handle; the barrier
+ *                              terms of mnk_sc_set_barrier_terms are thereby set too
+ *   mnk_sc_regularize_diagonal regularize_diagonal!(kkt, primal, dual)  reference src/KKT/KKTsystem.jl:222-226
+ *   mnk_sc_build(sc, NULL, NULL, loc) then builds from the handle's own pr_diag / du_diag
+ *   mnk_sc_get_diagonals       host copies for tests (any pointer may be NULL) */
+int mnk_sc_set_aug_diagonal(mnk_sc* sc, const double* x, const double* xl, const double* xu, const double* zl,
+                            const double* zu, double primal_reg, double dual_reg, int loc);
+int mnk_sc_regularize_diagonal(mnk_sc* sc, double primal, double dual);
+int mnk_sc_get_diagonals(mnk_sc* sc, double* pr_diag, double* du_diag, double* reg, double* l_diag, double* u_diag,
+                         double* l_lower, double* u_lower);
+
 /* The dense twins: w = [x (n); s (ns); y (m); zl; zu].  solve_kkt!(::DenseCondensedKKTSystem) reference
  * src/IPM/factorization.jl:190-229, the reduced solve of DenseKKTSystem :41-46, mul!(::AbstractDenseKKTSystem)
  * :310-330 (symv on the lower triangle of hess, two gemv with jac). */
@@ -236,6 +252,14 @@ int mnk_dc_set_barrier_terms(mnk_dc* dc, const double* reg, const double* l_diag
                              const double* l_lower, const double* u_lower, int loc);
 int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc);
 int mnk_dc_mul(mnk_dc* dc, double* w, const double* x, double alpha, double beta, int loc);
+/* (vectors of n + ns entries; same semantics as the mnk_sc_* feeders above; mnk_dc_build(dc, NULL, NULL, loc) builds from
+ * the handle's own diagonals) */
+int mnk_dc_set_aug_diagonal(mnk_dc* dc, const double* x, const double* xl, const double* xu, const double* zl,
+                            const double* zu, double primal_reg, double dual_reg, int loc);
+int mnk_dc_regularize_diagonal(mnk_dc* dc, double primal, double dual);
+int mnk_dc_get_diagonals(mnk_dc* dc, double* pr_diag, double* du_diag, double* reg, double* l_diag, double* u_diag,
+                         double* l_lower, double* u_lower);
+
 
 /* ---- dense S stage of the Schur-complement KKT system ----------------------------------------------
  * Reference: `SchurComplementKKTSystem` src/KKT/Schur/schur.jl -- `build_kkt!` :927-1001 (phase 1: factor every

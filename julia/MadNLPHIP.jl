@@ -26,6 +26,7 @@ import SparseArrays: SparseMatrixCSC, nnz
 
 const libmadnlp_hip = get(ENV, "MADNLP_HIP_LIB", "libmadnlp_hip.so")
 const MNK_HOST = Cint(0)
+const MNK_DEVICE = Cint(1)
 const MNK_ALGO = Dict(BUNCHKAUFMAN => Cint(1), CHOLESKY => Cint(4), LDL => Cint(5))
 const MNK_SC_JT, MNK_SC_HESS, MNK_SC_AUG = Cint(0), Cint(1), Cint(2)
 
@@ -556,6 +557,46 @@ function MadNLP.mul_hess_blk!(wx, kkt::HipDenseCondensedKKTSystem, t)           
     mul!(@view(wx[1:n]), Symmetric(kkt.hess, :L), @view(t[1:n]))
     fill!(@view(wx[n+1:end]), 0)
     wx .+= t .* kkt.pr_diag
+end
+
+# ---- device-side feeders (SURVEY 8(a)11 on the device; first slice of 8(f).4) ---------------------------------------
+# set_aug_diagonal!(kkt, solver) (src/IPM/kernels.jl:4-27) and regularize_diagonal! (src/KKT/KKTsystem.jl:222-226)
+# evaluated INSIDE the handle from the iterate's full primal-length vectors, then build_kkt! from the handle's own
+# diagonals: for callers that keep x, xl, xu, zl, zu in host arrays but do not want to form the diagonals on the host
+# (the same entry points take device pointers with MNK_DEVICE for a device-resident IPM).
+function set_aug_diagonal_device!(kkt::HipSparseCondensedKKTSystem, x::Vector{Float64}, xl::Vector{Float64},
+                                  xu::Vector{Float64}, zl::Vector{Float64}, zu::Vector{Float64};
+                                  primal_reg::Float64 = 0.0, dual_reg::Float64 = 0.0)
+    rc = ccall((:mnk_sc_set_aug_diagonal, libmadnlp_hip), Cint,
+               (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint),
+               kkt.sc.handle, x, xl, xu, zl, zu, primal_reg, dual_reg, MNK_HOST)
+    check(rc, SymbolicException)
+    return
+end
+function regularize_diagonal_device!(kkt::HipSparseCondensedKKTSystem, primal::Float64, dual::Float64)
+    rc = ccall((:mnk_sc_regularize_diagonal, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), kkt.sc.handle, primal, dual)
+    check(rc, SymbolicException)
+    return
+end
+function build_kkt_device!(kkt::HipSparseCondensedKKTSystem)
+    rc = ccall((:mnk_sc_build, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+               kkt.sc.handle, C_NULL, C_NULL, MNK_DEVICE)
+    check(rc, SymbolicException)
+    return
+end
+function set_aug_diagonal_device!(kkt::HipDenseCondensedKKTSystem, x::Vector{Float64}, xl::Vector{Float64},
+                                  xu::Vector{Float64}, zl::Vector{Float64}, zu::Vector{Float64};
+                                  primal_reg::Float64 = 0.0, dual_reg::Float64 = 0.0)
+    rc = ccall((:mnk_dc_set_aug_diagonal, libmadnlp_hip), Cint,
+               (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cdouble, Cint),
+               kkt.dc.handle, x, xl, xu, zl, zu, primal_reg, dual_reg, MNK_HOST)
+    check(rc, SymbolicException)
+    return
+end
+function regularize_diagonal_device!(kkt::HipDenseCondensedKKTSystem, primal::Float64, dual::Float64)
+    rc = ccall((:mnk_dc_regularize_diagonal, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cdouble, Cdouble), kkt.dc.handle, primal, dual)
+    check(rc, SymbolicException)
+    return
 end
 
 end # module

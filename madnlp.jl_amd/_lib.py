@@ -117,6 +117,12 @@ SIGNATURES = {
     "mnk_ls_solve": (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int]),
     "mnk_ls_check_solve": (C.c_int, [_vp]),
     "mnk_ls_get_factor": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "mnk_sc_set_aug_diagonal": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
+    "mnk_sc_regularize_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "mnk_sc_get_diagonals": (C.c_int, [_vp] + [_vp] * 7),
+    "mnk_dc_set_aug_diagonal": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
+    "mnk_dc_regularize_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "mnk_dc_get_diagonals": (C.c_int, [_vp] + [_vp] * 7),
     "mnk_ls_bk_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp]),
     "mnk_ls_get_stat": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "mnk_sc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),

@@ -233,8 +233,8 @@ struct mnk_dc_extra {
     // device-side solve_kkt! / mul!
     int64_t nlb = 0, nub = 0;
     DevBuf<int64_t> ind_lb, ind_ub;
-    DevBuf<double> reg, l_diag, u_diag, l_lower, u_lower, buffer, pd, wdev, xdev;
-    bool have_bounds = false, have_terms = false;
+    DevBuf<double> reg, l_diag, u_diag, l_lower, u_lower, buffer, pd, wdev, xdev, feed;
+    bool have_bounds = false, have_terms = false, have_diag = false;
 };
 static mnk_dc_extra* extra_of(mnk_dc* dc) { return static_cast<mnk_dc_extra*>(dc->extra); }
 
@@ -333,13 +333,20 @@ int mnk_dc_set_jac(mnk_dc* dc, const double* jac, int64_t ld, int loc) {
 }
 
 int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int loc) {
-    MNK_REQUIRE(dc && pr_diag && (du_diag || dc->m == 0), "mnk_dc_build: NULL argument");
+    MNK_REQUIRE(dc, "mnk_dc_build: NULL argument");
     MNK_HIP(hipSetDevice(dc->ctx->device));
     hipStream_t s = dc->ctx->stream;
-    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    MNK_HIP(hipMemcpyAsync(dc->pr_diag.p, pr_diag, (dc->n + dc->ns) * sizeof(double), kind, s));
-    if (dc->m > 0) MNK_HIP(hipMemcpyAsync(dc->du_diag.p, du_diag, dc->m * sizeof(double), kind, s));
-    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    if (pr_diag == nullptr && du_diag == nullptr) {
+        // the diagonals the handle keeps itself (mnk_dc_set_aug_diagonal / mnk_dc_regularize_diagonal)
+        mnk_dc_extra* ex0 = extra_of(dc);
+        MNK_REQUIRE(ex0 != nullptr && ex0->have_diag, "mnk_dc_build: no diagonals given and mnk_dc_set_aug_diagonal was not called");
+    } else {
+        MNK_REQUIRE(pr_diag && (du_diag || dc->m == 0), "mnk_dc_build: NULL argument");
+        const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        MNK_HIP(hipMemcpyAsync(dc->pr_diag.p, pr_diag, (dc->n + dc->ns) * sizeof(double), kind, s));
+        if (dc->m > 0) MNK_HIP(hipMemcpyAsync(dc->du_diag.p, du_diag, dc->m * sizeof(double), kind, s));
+        if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    }
     const int64_t ordpad = round_up(dc->order, PAD);
     const int64_t ldk = ordpad;
     dim3 egrid((unsigned)ordpad, (unsigned)((ordpad + 255) / 256));
@@ -418,6 +425,44 @@ int mnk_dc_set_bounds(mnk_dc* dc, int64_t nlb, const int64_t* ind_lb, int64_t nu
     ex->nub = nub;
     ex->have_bounds = true;
     return 0;
+}
+
+static int dc_diag_view(mnk_dc* dc, AugDiagView& v, const char* who) {
+    if (!dc) { set_error("%s: NULL argument", who); return -1; }
+    MNK_HIP(hipSetDevice(dc->ctx->device));
+    mnk_dc_extra* ex = extra_of(dc);
+    if (!(ex != nullptr && ex->have_bounds)) { set_error("%s: call mnk_dc_set_bounds first", who); return -1; }
+    v = AugDiagView{dc->ctx, dc->n + dc->ns, dc->m, ex->nlb, ex->nub, ex->reg.p, dc->pr_diag.p, dc->du_diag.p, ex->l_diag.p,
+                    ex->u_diag.p, ex->l_lower.p, ex->u_lower.p, ex->ind_lb.p, ex->ind_ub.p, &ex->feed};
+    return 0;
+}
+
+int mnk_dc_set_aug_diagonal(mnk_dc* dc, const double* x, const double* xl, const double* xu, const double* zl,
+                            const double* zu, double primal_reg, double dual_reg, int loc) {
+    AugDiagView v;
+    int rc = dc_diag_view(dc, v, "mnk_dc_set_aug_diagonal");
+    if (rc) return rc;
+    MNK_REQUIRE(x && xl && xu && zl && zu, "mnk_dc_set_aug_diagonal: NULL vector");
+    rc = kkt_set_aug_diagonal(v, x, xl, xu, zl, zu, primal_reg, dual_reg, loc);
+    if (rc) return rc;
+    extra_of(dc)->have_terms = extra_of(dc)->have_diag = true;
+    return 0;
+}
+
+int mnk_dc_regularize_diagonal(mnk_dc* dc, double primal, double dual) {
+    AugDiagView v;
+    int rc = dc_diag_view(dc, v, "mnk_dc_regularize_diagonal");
+    if (rc) return rc;
+    MNK_REQUIRE(extra_of(dc)->have_diag, "mnk_dc_regularize_diagonal: call mnk_dc_set_aug_diagonal first");
+    return kkt_regularize_diagonal(v, primal, dual);
+}
+
+int mnk_dc_get_diagonals(mnk_dc* dc, double* pr_diag, double* du_diag, double* reg, double* l_diag, double* u_diag,
+                         double* l_lower, double* u_lower) {
+    AugDiagView v;
+    int rc = dc_diag_view(dc, v, "mnk_dc_get_diagonals");
+    if (rc) return rc;
+    return kkt_get_diagonals(v, pr_diag, du_diag, reg, l_diag, u_diag, l_lower, u_lower);
 }
 
 int mnk_dc_set_barrier_terms(mnk_dc* dc, const double* reg, const double* l_diag, const double* u_diag,

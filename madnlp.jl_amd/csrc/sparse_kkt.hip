@@ -165,7 +165,8 @@ struct mnk_sc_spmv_data {
     DevBuf<int64_t> ind_lb, ind_ub;               // positions in the primal block [0, n+m)
     DevBuf<double> reg, l_diag, u_diag, l_lower, u_lower;
     DevBuf<double> buffer, buffer2, wdev, xdev;   // m, m, len(w), len(w)
-    bool have_bounds = false, have_terms = false;
+    DevBuf<double> feed;                          // staging of host iterates for mnk_sc_set_aug_diagonal
+    bool have_bounds = false, have_terms = false, have_diag = false;
 };
 static mnk_sc_spmv_data* spmv_of(mnk_sc* sc) { return static_cast<mnk_sc_spmv_data*>(sc->extra); }
 
@@ -416,14 +417,23 @@ int mnk_sc_compress_hessian(mnk_sc* sc, const double* hess_coo, int loc) {
 }
 
 int mnk_sc_build(mnk_sc* sc, const double* pr_diag, const double* du_diag, int loc) {
-    MNK_REQUIRE(sc && sc->ctx && pr_diag && (du_diag || sc->m == 0), "mnk_sc_build: NULL argument or host-only handle");
+    MNK_REQUIRE(sc && sc->ctx, "mnk_sc_build: NULL argument or host-only handle");
     MNK_HIP(hipSetDevice(sc->ctx->device));
     hipStream_t s = sc->ctx->stream;
+    if (pr_diag == nullptr && du_diag == nullptr) {
+        // the diagonals the handle keeps itself (mnk_sc_set_aug_diagonal / mnk_sc_regularize_diagonal)
+        mnk_sc_spmv_data* sp0 = spmv_of(sc);
+        MNK_REQUIRE(sp0 != nullptr && sp0->have_diag, "mnk_sc_build: no diagonals given and mnk_sc_set_aug_diagonal was not called");
+        pr_diag = sc->pr_diag.p;
+        du_diag = sc->du_diag.p;
+        loc = MNK_DEVICE;
+    }
+    MNK_REQUIRE(pr_diag && (du_diag || sc->m == 0), "mnk_sc_build: NULL argument");
     const double *pr, *du;
     int rc = stage_in(sc->ctx, sc->pr_diag.p, pr_diag, sc->n + sc->m, loc, &pr);
     rc |= stage_in(sc->ctx, sc->du_diag.p, du_diag, sc->m, loc, &du);
     if (rc) return rc;
-    if (loc == MNK_DEVICE) {  // keep our own copies: the device-side solve_kkt!/mul! read Sigma_s and du_diag later
+    if (loc == MNK_DEVICE && pr != sc->pr_diag.p) {  // keep our own copies: the device-side solve_kkt!/mul! read Sigma_s and du_diag later
         MNK_HIP(hipMemcpyAsync(sc->pr_diag.p, pr, (sc->n + sc->m) * sizeof(double), hipMemcpyDeviceToDevice, s));
         if (sc->m > 0) MNK_HIP(hipMemcpyAsync(sc->du_diag.p, du, sc->m * sizeof(double), hipMemcpyDeviceToDevice, s));
     }
@@ -538,6 +548,44 @@ int mnk_sc_set_barrier_terms(mnk_sc* sc, const double* reg, const double* l_diag
     if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(sc->ctx->stream));  // the host arrays may change after return
     sp->have_terms = true;
     return 0;
+}
+
+static int sc_diag_view(mnk_sc* sc, AugDiagView& v, const char* who) {
+    if (!(sc && sc->ctx)) { set_error("%s: NULL argument or host-only handle", who); return -1; }
+    MNK_HIP(hipSetDevice(sc->ctx->device));
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    if (!(sp != nullptr && sp->have_bounds)) { set_error("%s: call mnk_sc_set_bounds first", who); return -1; }
+    v = AugDiagView{sc->ctx, sc->n + sc->m, sc->m, sp->nlb, sp->nub, sp->reg.p, sc->pr_diag.p, sc->du_diag.p, sp->l_diag.p,
+                    sp->u_diag.p, sp->l_lower.p, sp->u_lower.p, sp->ind_lb.p, sp->ind_ub.p, &sp->feed};
+    return 0;
+}
+
+int mnk_sc_set_aug_diagonal(mnk_sc* sc, const double* x, const double* xl, const double* xu, const double* zl,
+                            const double* zu, double primal_reg, double dual_reg, int loc) {
+    AugDiagView v;
+    int rc = sc_diag_view(sc, v, "mnk_sc_set_aug_diagonal");
+    if (rc) return rc;
+    MNK_REQUIRE(x && xl && xu && zl && zu, "mnk_sc_set_aug_diagonal: NULL vector");
+    rc = kkt_set_aug_diagonal(v, x, xl, xu, zl, zu, primal_reg, dual_reg, loc);
+    if (rc) return rc;
+    spmv_of(sc)->have_terms = spmv_of(sc)->have_diag = true;
+    return 0;
+}
+
+int mnk_sc_regularize_diagonal(mnk_sc* sc, double primal, double dual) {
+    AugDiagView v;
+    int rc = sc_diag_view(sc, v, "mnk_sc_regularize_diagonal");
+    if (rc) return rc;
+    MNK_REQUIRE(spmv_of(sc)->have_diag, "mnk_sc_regularize_diagonal: call mnk_sc_set_aug_diagonal first");
+    return kkt_regularize_diagonal(v, primal, dual);
+}
+
+int mnk_sc_get_diagonals(mnk_sc* sc, double* pr_diag, double* du_diag, double* reg, double* l_diag, double* u_diag,
+                         double* l_lower, double* u_lower) {
+    AugDiagView v;
+    int rc = sc_diag_view(sc, v, "mnk_sc_get_diagonals");
+    if (rc) return rc;
+    return kkt_get_diagonals(v, pr_diag, du_diag, reg, l_diag, u_diag, l_lower, u_lower);
 }
 
 #define MNK_GRID(cnt) dim3((unsigned)(((cnt) + 255) / 256)), dim3(256), 0, s

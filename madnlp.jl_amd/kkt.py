@@ -84,6 +84,39 @@ class _KKTCommon:
         self.pr_diag[self.ind_lb] -= self.l_lower / self.l_diag
         self.pr_diag[self.ind_ub] -= self.u_lower / self.u_diag
 
+    # ---- device-side feeders (SURVEY 8(a)11 on the device; `_PFX` = "mnk_sc" / "mnk_dc")
+    def set_aug_diagonal_device(self, x, xl, xu, zl, zu, primal_reg=0.0, dual_reg=0.0):
+        """`set_aug_diagonal!(kkt, solver)` (reference `src/IPM/kernels.jl:4-27`) inside the handle: `x, xl, xu, zl, zu`
+        are the full primal-length vectors of the iterate (host arrays or device tensors); reg, du_diag, l_diag,
+        u_diag, l_lower, u_lower and pr_diag are computed and kept on the device (no host vector involved)."""
+        ptrs = [_ptr(v) for v in (x, xl, xu, zl, zu)]
+        assert len({loc for _, loc in ptrs}) == 1, "all five vectors must live on the same side"
+        fn = getattr(L.lib(), self._PFX + "_set_aug_diagonal")
+        L.check(fn(self._h, *[p for p, _ in ptrs], float(primal_reg), float(dual_reg), ptrs[0][1]),
+                self._PFX + "_set_aug_diagonal")
+
+    def regularize_diagonal_device(self, primal, dual):
+        """`regularize_diagonal!(kkt, primal, dual)` (reference `src/KKT/KKTsystem.jl:222-226`) on the handle's own
+        reg / pr_diag / du_diag."""
+        fn = getattr(L.lib(), self._PFX + "_regularize_diagonal")
+        L.check(fn(self._h, float(primal), float(dual)), self._PFX + "_regularize_diagonal")
+
+    def build_kkt_device(self):
+        """`build_kkt!` from the diagonals the handle keeps itself (after `set_aug_diagonal_device`)."""
+        fn = getattr(L.lib(), self._PFX + "_build")
+        L.check(fn(self._h, None, None, L.MNK_DEVICE), self._PFX + "_build")
+        self._diag_buffer = None
+
+    def get_diagonals_device(self):
+        """Host copies of the handle's pr_diag, du_diag, reg, l_diag, u_diag, l_lower, u_lower (tests)."""
+        out = {"pr_diag": np.zeros_like(self.pr_diag), "du_diag": np.zeros_like(self.du_diag),
+               "reg": np.zeros_like(self.reg), "l_diag": np.zeros_like(self.l_diag), "u_diag": np.zeros_like(self.u_diag),
+               "l_lower": np.zeros_like(self.l_lower), "u_lower": np.zeros_like(self.u_lower)}
+        fn = getattr(L.lib(), self._PFX + "_get_diagonals")
+        L.check(fn(self._h, *[out[k].ctypes.data for k in ("pr_diag", "du_diag", "reg", "l_diag", "u_diag", "l_lower",
+                                                            "u_lower")]), self._PFX + "_get_diagonals")
+        return out
+
     def factorize_kkt(self):
         """`factorize_kkt!` reference `src/KKT/KKTsystem.jl:218-220`."""
         return self.linear_solver.factorize()
@@ -126,6 +159,7 @@ class _KKTCommon:
 
 # ------------------------------------------------------------ SparseCondensedKKTSystem
 class SparseCondensedKKTSystem(_KKTCommon):
+    _PFX = "mnk_sc"
     """`create_kkt_system(SparseCondensedKKTSystem, cb, linear_solver)` (reference
     `src/KKT/Sparse/condensed.jl:55-133`).  `jac_I/jac_J`, `hess_I/hess_J` are the COO
     sparsity patterns reported by the callback (0-based)."""
@@ -368,6 +402,7 @@ class SparseCondensedKKTSystem(_KKTCommon):
 
 # ------------------------------------------------------------------- dense systems
 class _DenseBase(_KKTCommon):
+    _PFX = "mnk_dc"
     def _create(self, condensed, n, m, ind_ineq, ind_eq, ctx):
         self.ctx = ctx or HipContext()
         ii = np.ascontiguousarray(ind_ineq, dtype=np.int64)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 import madnlp_jl_amd as mj  # noqa: E402
 from madnlp_jl_amd import _lib as L  # noqa: E402
-from madnlp_jl_amd.problems import OPF_CASES, opf_shaped  # noqa: E402
+from madnlp_jl_amd.problems import OPF_CASES, dense_dummy_qp, opf_shaped  # noqa: E402
 from oracle import kernels as okern  # noqa: E402
 from oracle import sparse_condensed as osc  # noqa: E402
 from oracle.lapack_cpu import BUNCHKAUFMAN, CHOLESKY, LapackCPUSolver  # noqa: E402
@@ -405,3 +405,106 @@ def test_persistent_panel_that_gives_up_is_redone_without_it(ctx, alg):
     M.factorize()                      # stays on the safe path: no second time-out
     assert M.get_stat("pp_fallbacks") == 1.0 and M.get_stat("panel_algo") == 1.0
     M.close()
+
+
+# --------------------------------------------------------------------------- device-side feeders (SURVEY 8(a)11 on the device)
+def _iterate(rng, ntot, ind_lb, ind_ub):
+    """A strictly interior iterate: full-length x, xl, xu, zl, zu (zl/zu zero off their bound sets)."""
+    xl = np.full(ntot, -np.inf); xu = np.full(ntot, np.inf)
+    xl[ind_lb] = -rng.uniform(0.5, 2.0, len(ind_lb)); xu[ind_ub] = rng.uniform(0.5, 2.0, len(ind_ub))
+    x = rng.uniform(-0.4, 0.4, ntot) * 10.0 ** rng.uniform(-6, 0, ntot)
+    zl = np.zeros(ntot); zu = np.zeros(ntot)
+    zl[ind_lb] = 10.0 ** rng.uniform(-8, 2, len(ind_lb)); zu[ind_ub] = 10.0 ** rng.uniform(-8, 2, len(ind_ub))
+    # the library never reads bound values outside ind_lb / ind_ub; keep them finite for the host->device copy
+    return x, np.where(np.isfinite(xl), xl, -1e300), np.where(np.isfinite(xu), xu, 1e300), zl, zu
+
+
+def _oracle_feed(k, x, xl, xu, zl, zu, primal_reg, dual_reg, dw, dc):
+    """reference set_aug_diagonal! (src/IPM/kernels.jl:4-27) + regularize_diagonal! (src/KKT/KKTsystem.jl:222-226)
+    on an oracle KKT object's host fields."""
+    k.reg[:] = primal_reg
+    k.du_diag[:] = -dual_reg
+    k.l_diag[:] = xl[k.ind_lb] - x[k.ind_lb]
+    k.u_diag[:] = x[k.ind_ub] - xu[k.ind_ub]
+    k.l_lower[:] = zl[k.ind_lb]
+    k.u_lower[:] = zu[k.ind_ub]
+    okern.set_aug_diagonal(k)
+    okern.regularize_diagonal(k, dw, dc)
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_device_feeders_sparse_condensed_bit_exact(ctx, where):
+    """`mnk_sc_set_aug_diagonal` + `mnk_sc_regularize_diagonal` + `mnk_sc_build(NULL, NULL)`: the diagonals the handle
+    computes from the iterate are bit-identical to the oracle's (same IEEE operations, no contraction possible), and
+    the condensed KKT built from them is bit-identical to the one built from host diagonals."""
+    P = opf_shaped("case118", du=0.0)
+    rng = np.random.default_rng(11)
+    ko = _oracle_sc(P)
+    kh = _hip_sc(P, ctx, mj.BUNCHKAUFMAN)
+    ntot = P.n + P.m
+    x, xl, xu, zl, zu = _iterate(rng, ntot, ko.ind_lb, ko.ind_ub)
+    _oracle_feed(ko, x, xl, xu, zl, zu, 1e-3, 2e-9, 1e-4, 1e-8)
+    vec = [x, xl, xu, zl, zu]
+    if where == "device":
+        vec = [torch.from_numpy(v).cuda() for v in vec]
+    kh.compress_jacobian(); kh.compress_hessian()
+    kh.set_aug_diagonal_device(*vec, primal_reg=1e-3, dual_reg=2e-9)
+    kh.regularize_diagonal_device(1e-4, 1e-8)
+    got = kh.get_diagonals_device()
+    for name in ("pr_diag", "du_diag", "reg", "l_diag", "u_diag", "l_lower", "u_lower"):
+        np.testing.assert_array_equal(got[name], getattr(ko, name), err_msg=name)
+    kh.build_kkt_device()
+    ko.build_kkt()
+    np.testing.assert_array_equal(kh.aug_com.nzval, ko.aug_com.nzval)
+    # and the device-side solve_kkt! works off the same handle state (barrier terms came with the feeder)
+    kh.linear_solver.factorize()
+    ko.linear_solver.factorize()
+    w = okern.UnreducedKKTVector.from_kkt(ko)
+    w.values[:] = rng.standard_normal(len(w.values))
+    wo = w.copy()
+    ko.solve_kkt(wo)
+    wd = w.values.copy()
+    kh.solve_kkt_device(wd)
+    assert np.abs(wd - wo.values).max() <= 1e-9 * max(1.0, np.abs(wo.values).max())
+    kh.close()
+
+
+@pytest.mark.parametrize("kind", ["dense_condensed", "dense"])
+def test_device_feeders_dense_systems_bit_exact(ctx, kind):
+    from oracle import dense as odense
+    P = dense_dummy_qp(96, 40, 8 if kind == "dense_condensed" else 0, seed=3)
+    rng = np.random.default_rng(12)
+    if kind == "dense_condensed":
+        ko = odense.DenseCondensedKKTSystem(P.n, P.m, P.ind_ineq, P.ind_eq, P.ind_lb, P.ind_ub, lambda A: LapackCPUSolver(A, BUNCHKAUFMAN))
+        kh = mj.DenseCondensedKKTSystem(P.n, P.m, P.ind_ineq, P.ind_eq, P.ind_lb, P.ind_ub, ctx=ctx)
+    else:
+        ko = odense.DenseKKTSystem(P.n, P.m, P.ind_ineq, P.ind_lb, P.ind_ub, lambda A: LapackCPUSolver(A, BUNCHKAUFMAN))
+        kh = mj.DenseKKTSystem(P.n, P.m, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx)
+    for k in (ko, kh):
+        k.hess[...] = P.hess
+        k.jac[...] = P.jac
+    ntot = len(ko.pr_diag)
+    x, xl, xu, zl, zu = _iterate(rng, ntot, ko.ind_lb, ko.ind_ub)
+    _oracle_feed(ko, x, xl, xu, zl, zu, 0.0, 0.0, 1e-4, 1e-8)
+    kh.set_aug_diagonal_device(x, xl, xu, zl, zu)
+    kh.regularize_diagonal_device(1e-4, 1e-8)
+    got = kh.get_diagonals_device()
+    for name in ("pr_diag", "du_diag", "reg", "l_diag", "u_diag", "l_lower", "u_lower"):
+        np.testing.assert_array_equal(got[name], getattr(ko, name), err_msg=name)
+    for k in (ko, kh):
+        k.compress_jacobian()
+        k.compress_hessian()
+    kh._upload()
+    kh.build_kkt_device()
+    ko.build_kkt()
+    kh.linear_solver.factorize()
+    ko.linear_solver.factorize()
+    assert kh.linear_solver.inertia() == ko.linear_solver.inertia()
+    w = okern.UnreducedKKTVector.from_kkt(ko)
+    w.values[:] = rng.standard_normal(len(w.values))
+    wo = w.copy()
+    ko.solve_kkt(wo)
+    wd = w.values.copy()
+    kh.solve_kkt_device(wd)
+    assert np.abs(wd - wo.values).max() <= 1e-8 * max(1.0, np.abs(wo.values).max())
+    kh.close()
