@@ -261,6 +261,39 @@ int mnk_dc_get_diagonals(mnk_dc* dc, double* pr_diag, double* du_diag, double* r
                          double* l_lower, double* u_lower);
 
 
+/* ---- IPM scalar reductions over DEVICE-resident iterates (second slice) ----------------------------------
+ * The regular-phase functions of reference src/IPM/kernels.jl:263-388,675-695 (GPU twins: mapreduce calls in
+ * lib/MadNLPGPU/src/IPM/kernels.jl:4-116).  Every vector argument is a DEVICE pointer; x, xl, xu, zl, zu, f, jacl, dx are
+ * the FULL primal-length vectors (ntot = variables + slacks), the *_r views of the reference are taken through the
+ * ind_lb / ind_ub given at creation; dzl / dzu (mnk_ipm_get_alpha_z) are the bound-length blocks dual_lb(d) / dual_ub(d)
+ * of a KKT vector.  Each call enqueues one or two one-pass reductions on the context's stream, synchronizes and returns
+ * the scalar(s) in *out (host).  max/min-type results are bit-identical to the reference's loops, sum-type results agree to
+ * summation-order rounding. */
+typedef struct mnk_ipm mnk_ipm;
+int mnk_ipm_create(mnk_ctx* ctx, int64_t ntot, int64_t nlb, const int64_t* ind_lb, int64_t nub, const int64_t* ind_ub,
+                   int index_base, mnk_ipm** out);
+int mnk_ipm_destroy(mnk_ipm* ipm);
+int mnk_ipm_get_varphi(mnk_ipm* ipm, double obj_val, const double* x, const double* xl, const double* xu, double mu,
+                       double* out);                                                    /* kernels.jl:263-283 */
+int mnk_ipm_get_inf_du(mnk_ipm* ipm, const double* f, const double* zl, const double* zu, const double* jacl, double sd,
+                       double* out);                                                    /* :285-291 */
+int mnk_ipm_get_inf_compl(mnk_ipm* ipm, const double* x, const double* xl, const double* xu, const double* zl,
+                          const double* zu, double mu, double sc, double* out);         /* :293-303 */
+int mnk_ipm_get_min_complementarity(mnk_ipm* ipm, const double* x, const double* xl, const double* xu, const double* zl,
+                                    const double* zu, double* out);                     /* :322-332 */
+int mnk_ipm_get_average_complementarity(mnk_ipm* ipm, const double* x, const double* xl, const double* xu,
+                                        const double* zl, const double* zu, double* out); /* :305-313 */
+int mnk_ipm_get_varphi_d(mnk_ipm* ipm, const double* f, const double* x, const double* xl, const double* xu,
+                         const double* dx, double mu, double* out);                     /* :341-354 */
+int mnk_ipm_get_alpha_max(mnk_ipm* ipm, const double* x, const double* xl, const double* xu, const double* dx, double tau,
+                          double* out);                                                 /* :356-371 */
+int mnk_ipm_get_alpha_z(mnk_ipm* ipm, const double* zl, const double* zu, const double* dzl, const double* dzu, double tau,
+                        double* out);                                                   /* :373-388 */
+int mnk_ipm_get_rel_search_norm(mnk_ipm* ipm, const double* x, const double* dx, double* out);   /* :675-682 */
+int mnk_ipm_get_sd_sc(mnk_ipm* ipm, const double* l, int64_t m, const double* zl, const double* zu, double s_max,
+                      double* out /* [sd, sc] */);                                      /* :684-695 */
+int mnk_ipm_get_norms(mnk_ipm* ipm, const double* c, int64_t m, double* out /* [norm(c, Inf), norm(c, 1)] */);
+
 /* ---- dense S stage of the Schur-complement KKT system ----------------------------------------------
  * Reference: `SchurComplementKKTSystem` src/KKT/Schur/schur.jl -- `build_kkt!` :927-1001 (phase 1: factor every
  * scenario block A_k and form A_k^-1 C_dk'; phase 2: S -= C_dk A_k^-1 C_dk'), `factorize_kkt!` :1003-1005, steps 3-5 of

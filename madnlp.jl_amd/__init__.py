@@ -17,3 +17,4 @@ from .backsolve import RichardsonIterator  # noqa: F401
 
 __version__ = "0.1.0"
 from .schur import SchurDenseStage  # noqa: F401,E402
+from .ipm_device import IPMDeviceKernels  # noqa: F401,E402

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
-SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip"]
+SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip", "ipm_vec.hip"]
 HEADERS = ["common.h", "ls.h", "kkt_vec.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
 
 MNK_HOST, MNK_DEVICE = 0, 1
@@ -123,6 +123,19 @@ SIGNATURES = {
     "mnk_dc_set_aug_diagonal": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
     "mnk_dc_regularize_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),
     "mnk_dc_get_diagonals": (C.c_int, [_vp] + [_vp] * 7),
+    "mnk_ipm_create": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.POINTER(_vp)]),
+    "mnk_ipm_destroy": (C.c_int, [_vp]),
+    "mnk_ipm_get_varphi": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_inf_du": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_inf_compl": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_min_complementarity": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_average_complementarity": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_varphi_d": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_alpha_max": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_alpha_z": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_rel_search_norm": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_sd_sc": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_norms": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_double)]),
     "mnk_ls_bk_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp]),
     "mnk_ls_get_stat": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "mnk_sc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),

@@ -1,0 +1,340 @@
+// Device-side IPM scalar reductions over device-resident iterates (second slice): the regular-phase
+// functions of reference src/IPM/kernels.jl:263-388,675-695 (GPU twins: lib/MadNLPGPU/src/IPM/kernels.jl:4-116, which
+// are mapreduce calls over the same expressions).  HBM-bound one-pass reductions: algorithmic bytes = 8 x (vectors read)
+// per element; two launches (grid-stride partials in a fixed order -> one block) + one 8/16-byte D2H per call, so results
+// are deterministic run to run.  Expressions are evaluated exactly as the reference writes them (no FMA contraction):
+// max/min-type results are bit-identical to the host restatement, sum-type results agree to summation-order rounding.
+#pragma clang fp contract(off)
+#include <cfloat>
+#include <cmath>
+
+#include "common.h"
+
+using namespace mnk;
+
+struct mnk_ipm {
+    mnk_ctx* ctx = nullptr;
+    int64_t ntot = 0, nlb = 0, nub = 0;
+    DevBuf<int64_t> ind_lb, ind_ub;
+    DevBuf<double> part;   // 2 x IPM_BLOCKS partials
+    DevBuf<double> res;    // 2 results
+};
+
+namespace {
+
+constexpr int IPM_BLOCKS = 256;
+constexpr int IPM_THREADS = 256;
+enum { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
+
+template <int RED>
+__device__ __forceinline__ double red_id() { return RED == R_SUM ? 0.0 : (RED == R_MAX ? -INFINITY : INFINITY); }
+template <int RED>
+__device__ __forceinline__ double red_op(double a, double b) {
+    return RED == R_SUM ? a + b : (RED == R_MAX ? fmax(a, b) : fmin(a, b));
+}
+// NaN must propagate like the reference's max(a, b) / min(a, b) (Julia: NaN if either is NaN)
+template <int RED>
+__device__ __forceinline__ double red_op_nan(double a, double b) {
+    if (RED != R_SUM && (a != a || b != b)) return NAN;
+    return red_op<RED>(a, b);
+}
+
+template <int RED>
+__device__ __forceinline__ void block_reduce_store(double v, double* __restrict__ out) {
+    __shared__ double sh[IPM_THREADS];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = IPM_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = red_op_nan<RED>(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+template <int RED>
+__global__ __launch_bounds__(IPM_THREADS) void final_reduce_kernel(const double* __restrict__ part, int nparts,
+                                                                     double* __restrict__ res) {
+    double v = red_id<RED>();
+    for (int i = threadIdx.x; i < nparts; i += IPM_THREADS) v = red_op_nan<RED>(v, part[i]);
+    __shared__ double sh[IPM_THREADS];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = IPM_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = red_op_nan<RED>(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) res[0] = sh[0];
+}
+
+// ---- element functors.  side 0: lower-bounded entries (index set ind_lb), side 1: upper-bounded (ind_ub) ----------
+// get_varphi (kernels.jl:263-283): -mu log(x_lr - xl_r) resp. -mu log(xu_r - x_ur), Inf when the slack is negative
+struct FVarphi {
+    const double *x, *xb; const int64_t* ind; double mu; int upper;
+    __device__ double operator()(int64_t i) const {
+        const int64_t p = ind[i];
+        const double d = upper ? xb[p] - x[p] : x[p] - xb[p];
+        return d < 0 ? INFINITY : -mu * log(d);
+    }
+};
+// get_inf_du (:285-291): |f - zl + zu + jacl|
+struct FInfDu {
+    const double *f, *zl, *zu, *jacl;
+    __device__ double operator()(int64_t i) const { return fabs(f[i] - zl[i] + zu[i] + jacl[i]); }
+};
+// get_inf_compl (:293-303): |(x_lr - xl_r) zl_r - mu| resp. |(xu_r - x_ur) zu_r - mu|
+struct FCompl {
+    const double *x, *xb, *z; const int64_t* ind; double mu; int upper; int absolute;
+    __device__ double operator()(int64_t i) const {
+        const int64_t p = ind[i];
+        const double d = upper ? xb[p] - x[p] : x[p] - xb[p];
+        const double c = d * z[p];
+        return absolute ? fabs(c - mu) : c;   // absolute = 0: the complementarity product itself (min / average)
+    }
+};
+// get_varphi_d (:341-354): (f - mu/(x - xl) + mu/(xu - x)) dx
+struct FVarphiD {
+    const double *f, *x, *xl, *xu, *dx; double mu;
+    __device__ double operator()(int64_t i) const { return (f[i] - mu / (x[i] - xl[i]) + mu / (xu[i] - x[i])) * dx[i]; }
+};
+// get_alpha_max (:356-371)
+struct FAlphaMax {
+    const double *x, *xl, *xu, *dx; double tau;
+    __device__ double operator()(int64_t i) const {
+        const double a = dx[i] < 0 ? (-x[i] + xl[i]) * tau / dx[i] : INFINITY;
+        const double b = dx[i] > 0 ? (-x[i] + xu[i]) * tau / dx[i] : INFINITY;
+        return fmin(a, b);
+    }
+};
+// get_alpha_z (:373-388): dz is the bound-length step, z the full-length multiplier
+struct FAlphaZ {
+    const double *z, *dz; const int64_t* ind; double tau;
+    __device__ double operator()(int64_t i) const { return dz[i] < 0 ? (-z[ind[i]]) * tau / dz[i] : INFINITY; }
+};
+// get_rel_search_norm (:675-682)
+struct FRelNorm {
+    const double *x, *dx;
+    __device__ double operator()(int64_t i) const { return fabs(dx[i]) / (1.0 + fabs(x[i])); }
+};
+// norm(v, 1) / norm(v, Inf) pieces, optionally gathered
+struct FAbs {
+    const double* v; const int64_t* ind;
+    __device__ double operator()(int64_t i) const { return fabs(ind ? v[ind[i]] : v[i]); }
+};
+
+template <int RED, class F>
+__global__ __launch_bounds__(IPM_THREADS) void map_reduce_kernel(F f, int64_t n, double* __restrict__ part) {
+    double v = red_id<RED>();
+    for (int64_t i = blockIdx.x * (int64_t)IPM_THREADS + threadIdx.x; i < n; i += (int64_t)IPM_BLOCKS * IPM_THREADS)
+        v = red_op_nan<RED>(v, f(i));
+    block_reduce_store<RED>(v, part);
+}
+
+// enqueue "res[slot] = reduce_{i < n} f(i)" (identity when n == 0)
+template <int RED, class F>
+int enqueue(mnk_ipm* h, F f, int64_t n, int slot) {
+    hipStream_t s = h->ctx->stream;
+    double* part = h->part.p + slot * IPM_BLOCKS;
+    hipLaunchKernelGGL((map_reduce_kernel<RED, F>), dim3(IPM_BLOCKS), dim3(IPM_THREADS), 0, s, f, n, part);
+    hipLaunchKernelGGL((final_reduce_kernel<RED>), dim3(1), dim3(IPM_THREADS), 0, s, part, IPM_BLOCKS, h->res.p + slot);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+inline double max0(double r) { return r != r ? r : fmax(0.0, r); }  // reference: max(zero, ...), NaN propagates
+
+int fetch(mnk_ipm* h, int count, double* out) {
+    MNK_HIP(hipMemcpyAsync(out, h->res.p, count * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
+    MNK_HIP(hipStreamSynchronize(h->ctx->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mnk_ipm_create(mnk_ctx* ctx, int64_t ntot, int64_t nlb, const int64_t* ind_lb, int64_t nub, const int64_t* ind_ub,
+                   int index_base, mnk_ipm** out) {
+    MNK_REQUIRE(ctx && out && ntot > 0 && nlb >= 0 && nub >= 0, "mnk_ipm_create: bad argument");
+    MNK_REQUIRE((nlb == 0 || ind_lb) && (nub == 0 || ind_ub) && (index_base == 0 || index_base == 1),
+                "mnk_ipm_create: bad index sets");
+    MNK_HIP(hipSetDevice(ctx->device));
+    std::vector<int64_t> lb(nlb), ub(nub);
+    for (int64_t i = 0; i < nlb; ++i) {
+        lb[i] = ind_lb[i] - index_base;
+        MNK_REQUIRE(lb[i] >= 0 && lb[i] < ntot, "mnk_ipm_create: ind_lb out of range");
+    }
+    for (int64_t i = 0; i < nub; ++i) {
+        ub[i] = ind_ub[i] - index_base;
+        MNK_REQUIRE(ub[i] >= 0 && ub[i] < ntot, "mnk_ipm_create: ind_ub out of range");
+    }
+    mnk_ipm* h = new mnk_ipm();
+    h->ctx = ctx;
+    h->ntot = ntot; h->nlb = nlb; h->nub = nub;
+    int rc = h->ind_lb.upload(lb, ctx->stream) | h->ind_ub.upload(ub, ctx->stream) | h->part.alloc(2 * IPM_BLOCKS) |
+             h->res.alloc(2);
+    if (rc) { delete h; return rc; }
+    mnk_ctx_child_added(ctx);
+    *out = h;
+    return 0;
+}
+
+int mnk_ipm_destroy(mnk_ipm* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    mnk_ctx* ctx = h->ctx;
+    delete h;
+    mnk_ctx_child_gone(ctx);
+    return 0;
+}
+
+#define IPM_ENTER(h, who)                                              \
+    MNK_REQUIRE((h) != nullptr && out != nullptr, who ": NULL argument"); \
+    MNK_HIP(hipSetDevice((h)->ctx->device))
+
+int mnk_ipm_get_varphi(mnk_ipm* h, double obj_val, const double* x, const double* xl, const double* xu, double mu,
+                       double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_varphi");
+    int rc = enqueue<R_SUM>(h, FVarphi{x, xl, h->ind_lb.p, mu, 0}, h->nlb, 0) |
+             enqueue<R_SUM>(h, FVarphi{x, xu, h->ind_ub.p, mu, 1}, h->nub, 1);
+    if (rc) return rc;
+    double r[2];
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    *out = obj_val + r[0] + r[1];
+    return 0;
+}
+
+int mnk_ipm_get_inf_du(mnk_ipm* h, const double* f, const double* zl, const double* zu, const double* jacl, double sd,
+                       double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_inf_du");
+    int rc = enqueue<R_MAX>(h, FInfDu{f, zl, zu, jacl}, h->ntot, 0);
+    if (rc) return rc;
+    double r;
+    rc = fetch(h, 1, &r);
+    if (rc) return rc;
+    *out = max0(r) / sd;
+    return 0;
+}
+
+int mnk_ipm_get_inf_compl(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
+                          const double* zu, double mu, double sc, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_inf_compl");
+    int rc = enqueue<R_MAX>(h, FCompl{x, xl, zl, h->ind_lb.p, mu, 0, 1}, h->nlb, 0) |
+             enqueue<R_MAX>(h, FCompl{x, xu, zu, h->ind_ub.p, mu, 1, 1}, h->nub, 1);
+    if (rc) return rc;
+    double r[2];
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    *out = ((r[0] != r[0] || r[1] != r[1]) ? NAN : max0(fmax(r[0], r[1]))) / sc;
+    return 0;
+}
+
+int mnk_ipm_get_min_complementarity(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
+                                    const double* zu, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_min_complementarity");
+    int rc = enqueue<R_MIN>(h, FCompl{x, xl, zl, h->ind_lb.p, 0.0, 0, 0}, h->nlb, 0) |
+             enqueue<R_MIN>(h, FCompl{x, xu, zu, h->ind_ub.p, 0.0, 1, 0}, h->nub, 1);
+    if (rc) return rc;
+    double r[2];
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    *out = (r[0] != r[0] || r[1] != r[1]) ? NAN : fmin(r[0], r[1]);
+    return 0;
+}
+
+int mnk_ipm_get_average_complementarity(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
+                                        const double* zu, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_average_complementarity");
+    if (h->nlb + h->nub == 0) { *out = 0.0; return 0; }
+    int rc = enqueue<R_SUM>(h, FCompl{x, xl, zl, h->ind_lb.p, 0.0, 0, 0}, h->nlb, 0) |
+             enqueue<R_SUM>(h, FCompl{x, xu, zu, h->ind_ub.p, 0.0, 1, 0}, h->nub, 1);
+    if (rc) return rc;
+    double r[2];
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    *out = (r[0] + r[1]) / (double)(h->nlb + h->nub);
+    return 0;
+}
+
+int mnk_ipm_get_varphi_d(mnk_ipm* h, const double* f, const double* x, const double* xl, const double* xu,
+                         const double* dx, double mu, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_varphi_d");
+    int rc = enqueue<R_SUM>(h, FVarphiD{f, x, xl, xu, dx, mu}, h->ntot, 0);
+    if (rc) return rc;
+    return fetch(h, 1, out);
+}
+
+int mnk_ipm_get_alpha_max(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* dx, double tau,
+                          double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_alpha_max");
+    int rc = enqueue<R_MIN>(h, FAlphaMax{x, xl, xu, dx, tau}, h->ntot, 0);
+    if (rc) return rc;
+    double r;
+    rc = fetch(h, 1, &r);
+    if (rc) return rc;
+    *out = r != r ? r : fmin(1.0, r);
+    return 0;
+}
+
+int mnk_ipm_get_alpha_z(mnk_ipm* h, const double* zl, const double* zu, const double* dzl, const double* dzu, double tau,
+                        double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_alpha_z");
+    int rc = enqueue<R_MIN>(h, FAlphaZ{zl, dzl, h->ind_lb.p, tau}, h->nlb, 0) |
+             enqueue<R_MIN>(h, FAlphaZ{zu, dzu, h->ind_ub.p, tau}, h->nub, 1);
+    if (rc) return rc;
+    double r[2];
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    const double m = fmin(r[0], r[1]);
+    *out = (r[0] != r[0] || r[1] != r[1]) ? NAN : fmin(1.0, m);
+    return 0;
+}
+
+int mnk_ipm_get_rel_search_norm(mnk_ipm* h, const double* x, const double* dx, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_rel_search_norm");
+    int rc = enqueue<R_MAX>(h, FRelNorm{x, dx}, h->ntot, 0);
+    if (rc) return rc;
+    double r;
+    rc = fetch(h, 1, &r);
+    if (rc) return rc;
+    *out = max0(r);
+    return 0;
+}
+
+// get_sd / get_sc (kernels.jl:684-695): l = the constraint multipliers (m entries), zl / zu full-length
+int mnk_ipm_get_sd_sc(mnk_ipm* h, const double* l, int64_t m, const double* zl, const double* zu, double s_max,
+                      double* out /* [sd, sc] */) {
+    IPM_ENTER(h, "mnk_ipm_get_sd_sc");
+    MNK_REQUIRE(m >= 0, "mnk_ipm_get_sd_sc: bad size");
+    double r[2], nl = 0.0;
+    int rc = enqueue<R_SUM>(h, FAbs{zl, h->ind_lb.p}, h->nlb, 0) | enqueue<R_SUM>(h, FAbs{zu, h->ind_ub.p}, h->nub, 1);
+    if (rc) return rc;
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    rc = enqueue<R_SUM>(h, FAbs{l, nullptr}, m, 0);
+    if (rc) return rc;
+    rc = fetch(h, 1, &nl);
+    if (rc) return rc;
+    const double nz = r[0] + r[1];
+    const double cnt_d = (double)std::max<int64_t>(1, m + h->nlb + h->nub), cnt_c = (double)std::max<int64_t>(1, h->nlb + h->nub);
+    out[0] = fmax(s_max, (nl + r[0] + r[1]) / cnt_d) / s_max;
+    out[1] = fmax(s_max, nz / cnt_c) / s_max;
+    return 0;
+}
+
+// get_inf_pr = norm(c, Inf) (kernels.jl:284) and theta = norm(c, 1) (solver.jl get_theta)
+int mnk_ipm_get_norms(mnk_ipm* h, const double* c, int64_t m, double* out /* [inf, one] */) {
+    IPM_ENTER(h, "mnk_ipm_get_norms");
+    MNK_REQUIRE(m >= 0, "mnk_ipm_get_norms: bad size");
+    int rc = enqueue<R_MAX>(h, FAbs{c, nullptr}, m, 0) | enqueue<R_SUM>(h, FAbs{c, nullptr}, m, 1);
+    if (rc) return rc;
+    double r[2];
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    out[0] = max0(r[0]);
+    out[1] = r[1];
+    return 0;
+}
+
+}  // extern "C"

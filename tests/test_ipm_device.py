@@ -1,0 +1,128 @@
+"""Device IPM reductions (`mnk_ipm_*`, SURVEY 8(f).4 second slice) against the oracle restatement of reference
+`src/IPM/kernels.jl:263-388,675-695`.  The CPU half pins the oracle on hand-computed values; the GPU half compares the
+HIP reductions with it: max/min-type results bit-exact, sum-type results to summation-order rounding."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import ipm_kernels as ok
+
+
+# --------------------------------------------------------------------------- oracle pins (CPU)
+def test_oracle_reductions_on_hand_computed_values():
+    x = np.array([1.0, 2.0, 3.0]); xl = np.array([0.0, 1.0, -1e300]); xu = np.array([2.0, 1e300, 5.0])
+    lb, ub = np.array([0, 1]), np.array([0, 2])
+    mu = 0.1
+    # varphi = obj - mu (log 1 + log 1) - mu (log 1 + log 2)
+    assert ok.get_varphi(7.0, x[lb], xl[lb], xu[ub], x[ub], mu) == pytest.approx(7.0 - mu * math.log(2.0), rel=1e-15)
+    assert ok.get_varphi(7.0, np.array([0.5]), np.array([1.0]), xu[ub], x[ub], mu) == float("inf")  # negative slack
+    f = np.array([1.0, -2.0, 0.5]); zl = np.array([0.5, 0.25, 0.0]); zu = np.array([0.125, 0.0, 2.0]); jl = np.array([0.0, 1.0, -4.0])
+    assert ok.get_inf_du(f, zl, zu, jl, 2.0) == max(abs(1 - .5 + .125), abs(-2 - .25 + 1), abs(.5 + 2 - 4)) / 2.0
+    assert ok.get_inf_compl(x[lb], xl[lb], zl[lb], xu[ub], x[ub], zu[ub], mu, 4.0) == \
+        max(abs(1 * .5 - mu), abs(1 * .25 - mu), abs(1 * .125 - mu), abs(2 * 2.0 - mu)) / 4.0
+    assert ok.get_min_complementarity(x[lb], xl[lb], zl[lb], x[ub], xu[ub], zu[ub]) == 0.125
+    assert ok.get_average_complementarity(x[lb], xl[lb], zl[lb], x[ub], xu[ub], zu[ub]) == pytest.approx((.5 + .25 + .125 + 4.0) / 4)
+    dx = np.array([-4.0, 0.0, 8.0])
+    assert ok.get_alpha_max(x, xl, xu, dx, 0.99) == min(1.0, (-1.0 + 0.0) * 0.99 / -4.0, (-3.0 + 5.0) * 0.99 / 8.0)
+    assert ok.get_alpha_max(x, xl, xu, np.zeros(3), 0.99) == 1.0
+    assert ok.get_alpha_z(zl[lb], zu[ub], np.array([-1.0, 1.0]), np.array([0.0, -16.0]), 0.5) == min((-0.5) * 0.5 / -1.0, (-2.0) * 0.5 / -16.0)
+    assert ok.get_rel_search_norm(x, dx) == 8.0 / 4.0
+    assert ok.get_sd(np.array([3.0, -5.0]), zl[lb], zu[ub], 1.0) == (8.0 + .75 + 2.125) / 6
+    assert ok.get_sc(zl[lb], zu[ub], 100.0) == 1.0
+    assert ok.get_varphi_d(f, x, np.array([0.0, 1.0, -np.inf]), np.array([2.0, np.inf, 5.0]), dx, mu) == \
+        pytest.approx((1 - mu / 1 + mu / 1) * -4.0 + (0.5 - 0.0 + mu / 2.0) * 8.0, rel=1e-15)
+
+
+# --------------------------------------------------------------------------- HIP vs oracle (GPU)
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import madnlp_jl_amd as mj
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    c = mj.HipContext(0)
+    yield c
+    c.close()
+
+
+def _data(rng, ntot, nlb, nub, m):
+    lb = np.sort(rng.choice(ntot, nlb, replace=False)); ub = np.sort(rng.choice(ntot, nub, replace=False))
+    xl = np.full(ntot, -1e300); xu = np.full(ntot, 1e300)
+    xl[lb] = -rng.uniform(0.5, 2.0, nlb); xu[ub] = rng.uniform(0.5, 2.0, nub)
+    x = rng.uniform(-0.45, 0.45, ntot)
+    near = rng.random(ntot) < 0.05   # some entries close to a bound (tiny slacks: the interesting end of the barrier)
+    x[near] = np.where(rng.random(near.sum()) < 0.5, xl[near] + 1e-9, xu[near] - 1e-9)
+    x = np.clip(x, np.where(xl > -1e299, xl + 1e-12, -1.0), np.where(xu < 1e299, xu - 1e-12, 1.0))
+    zl = np.zeros(ntot); zu = np.zeros(ntot)
+    zl[lb] = 10.0 ** rng.uniform(-9, 3, nlb); zu[ub] = 10.0 ** rng.uniform(-9, 3, nub)
+    f = rng.standard_normal(ntot) * 10.0 ** rng.uniform(-3, 3, ntot)
+    jacl = rng.standard_normal(ntot)
+    dx = rng.standard_normal(ntot) * 10.0 ** rng.uniform(-4, 1, ntot)
+    dx[rng.random(ntot) < 0.1] = 0.0
+    dzl = rng.standard_normal(nlb); dzu = rng.standard_normal(nub)
+    y = rng.standard_normal(m) * 10.0
+    c = rng.standard_normal(m) * 10.0 ** rng.uniform(-8, 0, m)
+    return dict(lb=lb, ub=ub, x=x, xl=xl, xu=xu, zl=zl, zu=zu, f=f, jacl=jacl, dx=dx, dzl=dzl, dzu=dzu, y=y, c=c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntot,nlb,nub,m", [(1, 1, 1, 1), (7, 3, 0, 2), (1000, 400, 377, 300), (27838, 16646 + 4000, 16646 + 3000, 16646),
+                                             (300001, 150000, 120000, 100000), (50, 0, 0, 0)])
+def test_device_reductions_match_the_oracle(ctx, ntot, nlb, nub, m):
+    import madnlp_jl_amd as mj
+    rng = np.random.default_rng(ntot)
+    nlb, nub = min(nlb, ntot), min(nub, ntot)
+    d = _data(rng, ntot, nlb, nub, m)
+    lb, ub = d["lb"], d["ub"]
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items() if k not in ("lb", "ub")}
+    K = mj.IPMDeviceKernels(ntot, lb, ub, ctx=ctx)
+    x, xl, xu, zl, zu = d["x"], d["xl"], d["xu"], d["zl"], d["zu"]
+    mu, tau, sd, sc = 0.01, 0.99, 1.7, 2.3
+    # max / min type: bit-exact
+    assert K.get_inf_du(dev["f"], dev["zl"], dev["zu"], dev["jacl"], sd) == ok.get_inf_du(d["f"], zl, zu, d["jacl"], sd)
+    assert K.get_inf_compl(dev["x"], dev["xl"], dev["xu"], dev["zl"], dev["zu"], mu, sc) == \
+        ok.get_inf_compl(x[lb], xl[lb], zl[lb], xu[ub], x[ub], zu[ub], mu, sc)
+    assert K.get_min_complementarity(dev["x"], dev["xl"], dev["xu"], dev["zl"], dev["zu"]) == \
+        ok.get_min_complementarity(x[lb], xl[lb], zl[lb], x[ub], xu[ub], zu[ub])
+    assert K.get_alpha_max(dev["x"], dev["xl"], dev["xu"], dev["dx"], tau) == ok.get_alpha_max(x, xl, xu, d["dx"], tau)
+    assert K.get_alpha_z(dev["zl"], dev["zu"], dev["dzl"], dev["dzu"], tau) == ok.get_alpha_z(zl[lb], zu[ub], d["dzl"], d["dzu"], tau)
+    assert K.get_rel_search_norm(dev["x"], dev["dx"]) == ok.get_rel_search_norm(x, d["dx"])
+    ninf, none = K.get_norms(dev["c"])
+    assert ninf == np.abs(d["c"]).max(initial=0.0)
+    # sum type: summation-order rounding (relative to the sum of magnitudes)
+    assert none == pytest.approx(np.abs(d["c"]).sum(), rel=1e-13, abs=0.0 if m else 1e-300)
+    vo = ok.get_varphi(3.5, x[lb], xl[lb], xu[ub], x[ub], mu)
+    mag = abs(3.5) + mu * (np.abs(np.log(x[lb] - xl[lb])).sum() + np.abs(np.log(xu[ub] - x[ub])).sum())
+    assert abs(K.get_varphi(3.5, dev["x"], dev["xl"], dev["xu"], mu) - vo) <= 1e-13 * max(mag, 1.0)
+    terms = (d["f"] - mu / (x - xl) + mu / (xu - x)) * d["dx"]
+    assert abs(K.get_varphi_d(dev["f"], dev["x"], dev["xl"], dev["xu"], dev["dx"], mu) -
+               ok.get_varphi_d(d["f"], x, xl, xu, d["dx"], mu)) <= 1e-13 * max(np.abs(terms).sum(), 1e-300)
+    avg = ok.get_average_complementarity(x[lb], xl[lb], zl[lb], x[ub], xu[ub], zu[ub])
+    cmag = (np.abs((x[lb] - xl[lb]) * zl[lb]).sum() + np.abs((xu[ub] - x[ub]) * zu[ub]).sum()) / max(1, nlb + nub)
+    # (the reference forms dot(x, z) - dot(xl, z); the device sums (x - xl) z: same value up to cancellation in the former)
+    assert abs(K.get_average_complementarity(dev["x"], dev["xl"], dev["xu"], dev["zl"], dev["zu"]) - avg) <= \
+        1e-10 * max(cmag + (np.abs(x[lb] * zl[lb]).sum() + np.abs(xu[ub] * zu[ub]).sum()) / max(1, nlb + nub) * 1e-3, 1e-300) + 1e-12 * abs(avg)
+    sd_d, sc_d = K.get_sd_sc(dev["y"], dev["zl"], dev["zu"], 100.0)
+    assert sd_d == pytest.approx(ok.get_sd(d["y"], zl[lb], zu[ub], 100.0), rel=1e-13)
+    assert sc_d == pytest.approx(ok.get_sc(zl[lb], zu[ub], 100.0), rel=1e-13)
+    K.close()
+
+
+@pytest.mark.gpu
+def test_device_reductions_edge_cases(ctx):
+    """A negative slack makes the barrier objective +Inf (reference `_get_varphi`), a zero step gives alpha = 1, NaN
+    propagates through max/min like the reference's `max` / `min`."""
+    import madnlp_jl_amd as mj
+    ntot = 5
+    lb, ub = np.array([0, 2]), np.array([1, 2])
+    K = mj.IPMDeviceKernels(ntot, lb, ub, ctx=ctx)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device="cuda")  # noqa: E731
+    x = t([0.0, 1.0, 0.5, 0.0, 0.0]); xl = t([0.1, -9.0, 0.0, -9.0, -9.0]); xu = t([9.0, 2.0, 1.0, 9.0, 9.0])
+    assert K.get_varphi(1.0, x, xl, xu, 0.1) == float("inf")                 # x[0] < xl[0]
+    assert K.get_alpha_max(x, xl, xu, t([0.0] * 5), 0.99) == 1.0
+    assert K.get_alpha_z(t([1.0] * 5), t([1.0] * 5), t([0.0, 1.0]), t([2.0, 0.0]), 0.99) == 1.0
+    assert math.isnan(K.get_inf_du(t([float("nan"), 0, 0, 0, 0]), x, x, x, 1.0))
+    assert math.isnan(K.get_rel_search_norm(x, t([0, 0, float("nan"), 0, 0])))
+    K.close()
