@@ -116,11 +116,18 @@ def timed_region(step_fn, steps, warmup, sync_fn, dist, device_tensor_fn):
     if dist is not None:
         dist.barrier()
     sync_fn()
+    trace = os.environ.get("MNK_BENCH_STEP_TIMES")  # diagnostics: host time stamps per step (steps end with a sync)
+    stamps = []
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+        if trace:
+            stamps.append(time.perf_counter())
     sync_fn()
     elapsed = time.perf_counter() - t0
+    if trace:
+        prev = [t0] + stamps[:-1]
+        print("step times (ms):", " ".join("%.2f" % (1e3 * (b - a)) for a, b in zip(prev, stamps)), file=sys.stderr)
     if dist is not None:
         dist.barrier()
         t = device_tensor_fn([elapsed])
