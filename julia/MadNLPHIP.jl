@@ -80,6 +80,8 @@ end
     share::Int = 1                  # 0 off / 1 adaptive / 2 always: panel-stream CUs join the trailing update
     persistent_solve::Bool = true   # both triangular sweeps in one launch
     single_rows::Int = 4608         # systems up to this order: one outer panel on the whole chip
+    panel_algo::Int = 4             # 4: persistent panel kernel (one launch per 256 columns; needs the panel CUs for
+                                    # itself -- set 1 when several PROCESSES share the GPU); 1: one launch per piece
     bk_fallback::Bool = true        # BUNCHKAUFMAN: refactor with 1x1/2x2 Bunch-Kaufman pivoting when the static-pivot
                                     # LDL^T breaks down (false: report the breakdown as num_zero, the IPM regularizes)
 end
@@ -154,6 +156,7 @@ function HipLinearSolver(A::MT; opt = HipSolverOptions(), logger = MadNLPLogger(
     set_option!(h[], "share", opt.share)
     set_option!(h[], "persistent_solve", opt.persistent_solve)
     set_option!(h[], "single_rows", opt.single_rows)
+    set_option!(h[], "panel_algo", opt.panel_algo)
     set_option!(h[], "bk_fallback", opt.bk_fallback)
     M = HipLinearSolver{Float64, MT}(A, h[], ctx, n, Ref{Cint}(0), opt, logger)
     finalizer(M) do m

@@ -118,6 +118,8 @@ class HipSolverOptions:
     small_tiles: int = 400  # (a)-updates with fewer 128x128 tiles use 64x64 workgroup tiles
     persistent_solve: bool = True  # both triangular sweeps in one launch (False: one launch per 256-column step)
     single_rows: int = 4608  # systems up to this order are factored as one outer panel on the whole chip (0: never)
+    panel_algo: int = 4      # 4: persistent panel kernel (needs the panel CUs for itself: set 1 when several PROCESSES
+                             # share the GPU); 1: one launch per piece of a 64-column block
 
 
 class HipLinearSolver:
@@ -152,6 +154,8 @@ class HipLinearSolver:
             settings.append(("persistent_solve", float(self.opt.persistent_solve)))
         if "MNK_SINGLE_ROWS" not in os.environ:
             settings.append(("single_rows", float(self.opt.single_rows)))
+        if "MNK_PANEL_ALGO" not in os.environ:
+            settings.append(("panel_algo", float(self.opt.panel_algo)))
         for key, val in settings:
             L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(val)), "mnk_ls_set_option")
         self.info = 0

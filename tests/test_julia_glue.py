@@ -117,6 +117,7 @@ def test_option_keys_and_defaults_match_the_library():
         "persistent_solve": re.search(r"int persistent_solve = (\d)", ls_h).group(1),
         "single_rows": re.search(r"single_rows = (\d+)", ls_h).group(1),
         "bk_fallback": re.search(r"int bk_fallback = (\d)", ls_h).group(1),
+        "panel_algo": re.search(r"int panel_algo = (\d)", ls_h).group(1),
     }
     norm = lambda v: {"true": "1", "false": "0"}.get(v, v)  # noqa: E731
     for k, v in lib.items():
@@ -126,6 +127,6 @@ def test_option_keys_and_defaults_match_the_library():
     sys.path.insert(0, ROOT)
     from madnlp_jl_amd.linear_solver import HipSolverOptions
     o = HipSolverOptions()
-    assert (o.outer_block, int(o.lookahead), o.share, int(o.persistent_solve), o.single_rows, o.pivot_tol) == (
+    assert (o.outer_block, int(o.lookahead), o.share, int(o.persistent_solve), o.single_rows, o.pivot_tol, o.panel_algo) == (
         int(lib["outer_block"]), int(lib["lookahead"]), int(lib["share"]), int(lib["persistent_solve"]),
-        int(lib["single_rows"]), float(lib["pivot_tol"]))
+        int(lib["single_rows"]), float(lib["pivot_tol"]), int(lib["panel_algo"]))
