@@ -55,10 +55,11 @@ def get_alpha_max(x, xl, xu, dx, tau):
     """`kernels.jl:356-371`."""
     a = 1.0
     neg, pos = dx < 0, dx > 0
-    if neg.any():
-        a = min(a, ((-x[neg] + xl[neg]) * tau / dx[neg]).min())
-    if pos.any():
-        a = min(a, ((-x[pos] + xu[pos]) * tau / dx[pos]).min())
+    with np.errstate(over="ignore"):  # unbounded sides: (-x + xu) * tau / dx overflows to +Inf, as in the reference
+        if neg.any():
+            a = min(a, ((-x[neg] + xl[neg]) * tau / dx[neg]).min())
+        if pos.any():
+            a = min(a, ((-x[pos] + xu[pos]) * tau / dx[pos]).min())
     return a
 
 

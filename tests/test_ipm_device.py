@@ -126,3 +126,77 @@ def test_device_reductions_edge_cases(ctx):
     assert math.isnan(K.get_inf_du(t([float("nan"), 0, 0, 0, 0]), x, x, x, 1.0))
     assert math.isnan(K.get_rel_search_norm(x, t([0, 0, float("nan"), 0, 0])))
     K.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dense_condensed", "sparse_condensed"])
+def test_device_kernels_on_the_iterates_of_a_real_ipm_run(ctx, kind):
+    """The IPM mirror solves `lootsma` on the HIP back-end; at EVERY call of set_aug_diagonal!, get_inf_compl,
+    get_varphi and get_alpha_max the device-side twin is evaluated on the same iterate: the feeder's diagonals and the
+    max/min reductions must be bit-identical to the host values, the barrier objective equal to summation rounding."""
+    import madnlp_jl_amd as mj
+    from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver
+    from madnlp_jl_amd.problems import LootsmaModel
+    nlp = LootsmaModel()
+    sparse = kind == "sparse_condensed"
+    counts = {"diag": 0, "compl": 0, "varphi": 0, "alpha": 0}
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()  # noqa: E731
+    fin = lambda a: np.clip(a, -1e300, 1e300)  # noqa: E731  (the library never reads bounds outside ind_lb / ind_ub)
+
+    class Checked(MadNLPSolver):
+        _K = None
+
+        def _kern(self):
+            if self._K is None:
+                self._K = mj.IPMDeviceKernels(len(self.x), self.ind_lb, self.ind_ub, ctx=ctx)
+            return self._K
+
+        def set_aug_diagonal(self):
+            super().set_aug_diagonal()
+            k, o = self.kkt, self.opt
+            k.set_aug_diagonal_device(self.x, fin(self.xl), fin(self.xu), self.zl, self.zu,
+                                      o.default_primal_regularization, o.default_dual_regularization)
+            got = k.get_diagonals_device()
+            for name in ("pr_diag", "du_diag", "reg", "l_diag", "u_diag", "l_lower", "u_lower"):
+                np.testing.assert_array_equal(got[name], getattr(k, name), err_msg=name)
+            counts["diag"] += 1
+
+        def inf_compl(self, mu, sc):
+            v = super().inf_compl(mu, sc)
+            assert self._kern().get_inf_compl(dev(self.x), dev(fin(self.xl)), dev(fin(self.xu)), dev(self.zl), dev(self.zu), mu, sc) == v
+            counts["compl"] += 1
+            return v
+
+        def varphi(self, obj, x):
+            v = super().varphi(obj, x)
+            d = self._kern().get_varphi(obj, dev(x), dev(fin(self.xl)), dev(fin(self.xu)), self.mu)
+            assert (d == v) if not np.isfinite(v) else abs(d - v) <= 1e-12 * max(1.0, abs(v))
+            counts["varphi"] += 1
+            return v
+
+        def alpha_max(self, dx):
+            v = super().alpha_max(dx)
+            assert self._kern().get_alpha_max(dev(self.x), dev(self.xl), dev(self.xu), dev(dx), self.tau) == v
+            counts["alpha"] += 1
+            return v
+
+    def factory(info):
+        opt = mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN)
+        if sparse:
+            return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J,
+                                               info["ind_ineq"], info["ind_lb"], info["ind_ub"], ctx=ctx, opt_linear_solver=opt)
+        return mj.DenseCondensedKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_eq"], info["ind_lb"],
+                                          info["ind_ub"], ctx=ctx, opt_linear_solver=opt)
+
+    opt = IPMOptions(tol=1e-6 if sparse else 1e-8)
+    if sparse:
+        opt.relax_equality, opt.dual_initialization = True, "zero"
+    s = Checked(nlp, factory, opt, sparse=sparse)
+    s.solve()
+    assert s.status == "SOLVE_SUCCEEDED"
+    assert min(counts.values()) >= 5, counts
+    tol = np.sqrt(s.opt.tol)
+    assert np.abs(s.x[:3] - nlp.LOOTSMA_X).max() < tol
+    if s._K is not None:
+        s._K.close()
+    s.kkt.close()
