@@ -293,6 +293,23 @@ int mnk_ipm_get_rel_search_norm(mnk_ipm* ipm, const double* x, const double* dx,
 int mnk_ipm_get_sd_sc(mnk_ipm* ipm, const double* l, int64_t m, const double* zl, const double* zu, double s_max,
                       double* out /* [sd, sc] */);                                      /* :684-695 */
 int mnk_ipm_get_norms(mnk_ipm* ipm, const double* c, int64_t m, double* out /* [norm(c, Inf), norm(c, 1)] */);
+/* Elementwise pieces of the regular phase on device-resident vectors (asynchronous on the context's stream):
+ *   mnk_ipm_set_aug_rhs            set_aug_rhs!  kernels.jl:113-131: px = -f + zl - zu - jacl, py = -c,
+ *                                  pzl = (xl_r - x_lr) zl_r + mu, pzu = (xu_r - x_ur) zu_r - mu  (px ntot, py m, pzl nlb, pzu nub)
+ *   mnk_ipm_set_perturbation_sets  ind_llb / ind_uub (entries bounded on one side only), once
+ *   mnk_ipm_dual_inf_perturbation  dual_inf_perturbation!  :818-823
+ *   mnk_ipm_adjust_boundary        adjust_boundary!  :656-673 (xl, xu full-length, in place)
+ *   mnk_ipm_reset_bound_dual       the two reset_bound_dual! calls of an accepted step, :775-801 / solver.jl:280-291
+ *                                  (full-length vectors; unbounded entries carry -Inf / +Inf bounds) */
+int mnk_ipm_set_perturbation_sets(mnk_ipm* ipm, int64_t nllb, const int64_t* ind_llb, int64_t nuub, const int64_t* ind_uub,
+                                  int index_base);
+int mnk_ipm_set_aug_rhs(mnk_ipm* ipm, const double* f, const double* zl, const double* zu, const double* jacl,
+                        const double* c, int64_t m, const double* x, const double* xl, const double* xu, double mu,
+                        double* px, double* py, double* pzl, double* pzu);
+int mnk_ipm_dual_inf_perturbation(mnk_ipm* ipm, double* px, double mu, double kappa_d);
+int mnk_ipm_adjust_boundary(mnk_ipm* ipm, const double* x, double* xl, double* xu, double mu);
+int mnk_ipm_reset_bound_dual(mnk_ipm* ipm, double* zl, double* zu, const double* x, const double* xl, const double* xu,
+                             double mu, double kappa_sigma);
 
 /* ---- dense S stage of the Schur-complement KKT system ----------------------------------------------
  * Reference: `SchurComplementKKTSystem` src/KKT/Schur/schur.jl -- `build_kkt!` :927-1001 (phase 1: factor every

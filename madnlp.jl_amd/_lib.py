@@ -136,6 +136,11 @@ SIGNATURES = {
     "mnk_ipm_get_rel_search_norm": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_double)]),
     "mnk_ipm_get_sd_sc": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
     "mnk_ipm_get_norms": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_double)]),
+    "mnk_ipm_set_perturbation_sets": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),
+    "mnk_ipm_set_aug_rhs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "mnk_ipm_dual_inf_perturbation": (C.c_int, [_vp, _vp, C.c_double, C.c_double]),
+    "mnk_ipm_adjust_boundary": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double]),
+    "mnk_ipm_reset_bound_dual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double]),
     "mnk_ls_bk_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp]),
     "mnk_ls_get_stat": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "mnk_sc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),

@@ -15,7 +15,8 @@ using namespace mnk;
 struct mnk_ipm {
     mnk_ctx* ctx = nullptr;
     int64_t ntot = 0, nlb = 0, nub = 0;
-    DevBuf<int64_t> ind_lb, ind_ub;
+    int64_t nllb = 0, nuub = 0;
+    DevBuf<int64_t> ind_lb, ind_ub, ind_llb, ind_uub;
     DevBuf<double> part;   // 2 x IPM_BLOCKS partials
     DevBuf<double> res;    // 2 results
 };
@@ -334,6 +335,126 @@ int mnk_ipm_get_norms(mnk_ipm* h, const double* c, int64_t m, double* out /* [in
     if (rc) return rc;
     out[0] = max0(r[0]);
     out[1] = r[1];
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- elementwise pieces of the regular phase (reference src/IPM/kernels.jl:113-131, 656-673, 775-801, 818-823) ------
+namespace {
+__device__ __forceinline__ double jl_min(double a, double b) { return (a != a || b != b) ? NAN : fmin(a, b); }
+__device__ __forceinline__ double jl_max(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+
+__global__ void aug_rhs_primal_kernel(double* __restrict__ px, const double* __restrict__ f, const double* __restrict__ zl,
+                                      const double* __restrict__ zu, const double* __restrict__ jacl, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) px[i] = -f[i] + zl[i] - zu[i] - jacl[i];
+}
+__global__ void negate_kernel(double* __restrict__ py, const double* __restrict__ c, int64_t m) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < m) py[i] = -c[i];
+}
+// pzl = (xl_r - x_lr) zl_r + mu (upper = 0) ; pzu = (xu_r - x_ur) zu_r - mu (upper = 1)
+__global__ void aug_rhs_bound_kernel(double* __restrict__ pz, const double* __restrict__ x, const double* __restrict__ xb,
+                                     const double* __restrict__ z, const int64_t* __restrict__ ind, double mu, int64_t nb,
+                                     int upper) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int64_t p = ind[i];
+    const double t = (xb[p] - x[p]) * z[p];
+    pz[i] = upper ? t - mu : t + mu;
+}
+__global__ void shift_gather_kernel(double* __restrict__ v, const int64_t* __restrict__ ind, double delta, int64_t nb) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < nb) v[ind[i]] += delta;
+}
+// adjust_boundary!: xl_r = (x_lr - xl_r < c1) ? xl_r - c2 max(1, |x_lr|) : xl_r ; xu_r = (xu_r - x_ur < c1) ? xu_r + c2 max(1, |x_ur|) : xu_r
+__global__ void adjust_boundary_kernel(double* __restrict__ xb, const double* __restrict__ x, const int64_t* __restrict__ ind,
+                                       double c1, double c2, int64_t nb, int upper) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int64_t p = ind[i];
+    const double xv = x[p], b = xb[p];
+    const double slack = upper ? b - xv : xv - b;
+    if (slack < c1) xb[p] = upper ? b + c2 * fmax(1.0, fabs(xv)) : b - c2 * fmax(1.0, fabs(xv));
+}
+// reset_bound_dual!(z, x1, x2, mu, kappa_sigma) on full-length vectors: z = max(min(z, (ks mu)/(x1-x2)), (mu/ks)/(x1-x2))
+__global__ void reset_bound_dual_kernel(double* __restrict__ z, const double* __restrict__ x1, const double* __restrict__ x2,
+                                        double ksmu, double muks, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = x1[i] - x2[i];
+    z[i] = jl_max(jl_min(z[i], ksmu / d), muks / d);
+}
+}  // namespace
+
+extern "C" {
+
+#define IPM_G(cnt) dim3((unsigned)(((cnt) + 255) / 256)), dim3(256), 0, h->ctx->stream
+
+int mnk_ipm_set_perturbation_sets(mnk_ipm* h, int64_t nllb, const int64_t* ind_llb, int64_t nuub, const int64_t* ind_uub,
+                                  int index_base) {
+    MNK_REQUIRE(h && nllb >= 0 && nuub >= 0 && (nllb == 0 || ind_llb) && (nuub == 0 || ind_uub) &&
+                    (index_base == 0 || index_base == 1), "mnk_ipm_set_perturbation_sets: bad argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    std::vector<int64_t> a(nllb), b(nuub);
+    for (int64_t i = 0; i < nllb; ++i) {
+        a[i] = ind_llb[i] - index_base;
+        MNK_REQUIRE(a[i] >= 0 && a[i] < h->ntot, "mnk_ipm_set_perturbation_sets: ind_llb out of range");
+    }
+    for (int64_t i = 0; i < nuub; ++i) {
+        b[i] = ind_uub[i] - index_base;
+        MNK_REQUIRE(b[i] >= 0 && b[i] < h->ntot, "mnk_ipm_set_perturbation_sets: ind_uub out of range");
+    }
+    h->nllb = nllb; h->nuub = nuub;
+    return h->ind_llb.upload(a, h->ctx->stream) | h->ind_uub.upload(b, h->ctx->stream);
+}
+
+// set_aug_rhs!(solver, kkt, c, mu) (kernels.jl:113-131): the four blocks of the right-hand side p
+int mnk_ipm_set_aug_rhs(mnk_ipm* h, const double* f, const double* zl, const double* zu, const double* jacl,
+                        const double* c, int64_t m, const double* x, const double* xl, const double* xu, double mu,
+                        double* px, double* py, double* pzl, double* pzu) {
+    MNK_REQUIRE(h && f && zl && zu && jacl && x && xl && xu && px && (m == 0 || (c && py)) && (h->nlb == 0 || pzl) &&
+                    (h->nub == 0 || pzu), "mnk_ipm_set_aug_rhs: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipLaunchKernelGGL(aug_rhs_primal_kernel, IPM_G(h->ntot), px, f, zl, zu, jacl, h->ntot);
+    if (m > 0) hipLaunchKernelGGL(negate_kernel, IPM_G(m), py, c, m);
+    if (h->nlb > 0) hipLaunchKernelGGL(aug_rhs_bound_kernel, IPM_G(h->nlb), pzl, x, xl, zl, h->ind_lb.p, mu, h->nlb, 0);
+    if (h->nub > 0) hipLaunchKernelGGL(aug_rhs_bound_kernel, IPM_G(h->nub), pzu, x, xu, zu, h->ind_ub.p, mu, h->nub, 1);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// dual_inf_perturbation!(px, ind_llb, ind_uub, mu, kappa_d) (kernels.jl:818-823)
+int mnk_ipm_dual_inf_perturbation(mnk_ipm* h, double* px, double mu, double kappa_d) {
+    MNK_REQUIRE(h && px, "mnk_ipm_dual_inf_perturbation: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    if (h->nllb > 0) hipLaunchKernelGGL(shift_gather_kernel, IPM_G(h->nllb), px, h->ind_llb.p, -(mu * kappa_d), h->nllb);
+    if (h->nuub > 0) hipLaunchKernelGGL(shift_gather_kernel, IPM_G(h->nuub), px, h->ind_uub.p, mu * kappa_d, h->nuub);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// adjust_boundary!(x_lr, xl_r, x_ur, xu_r, mu) (kernels.jl:656-673), xl / xu full-length, updated in place
+int mnk_ipm_adjust_boundary(mnk_ipm* h, const double* x, double* xl, double* xu, double mu) {
+    MNK_REQUIRE(h && x && xl && xu, "mnk_ipm_adjust_boundary: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    const double c1 = DBL_EPSILON * mu, c2 = pow(DBL_EPSILON, 0.75);
+    if (h->nlb > 0) hipLaunchKernelGGL(adjust_boundary_kernel, IPM_G(h->nlb), xl, x, h->ind_lb.p, c1, c2, h->nlb, 0);
+    if (h->nub > 0) hipLaunchKernelGGL(adjust_boundary_kernel, IPM_G(h->nub), xu, x, h->ind_ub.p, c1, c2, h->nub, 1);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// the two reset_bound_dual! calls of the accepted step (solver.jl:280-291), full primal-length vectors (unbounded
+// entries carry -Inf / +Inf bounds and come out as exactly 0, as in the reference)
+int mnk_ipm_reset_bound_dual(mnk_ipm* h, double* zl, double* zu, const double* x, const double* xl, const double* xu,
+                             double mu, double kappa_sigma) {
+    MNK_REQUIRE(h && zl && zu && x && xl && xu, "mnk_ipm_reset_bound_dual: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipLaunchKernelGGL(reset_bound_dual_kernel, IPM_G(h->ntot), zl, x, xl, kappa_sigma * mu, mu / kappa_sigma, h->ntot);
+    hipLaunchKernelGGL(reset_bound_dual_kernel, IPM_G(h->ntot), zu, xu, x, kappa_sigma * mu, mu / kappa_sigma, h->ntot);
+    MNK_HIP(hipGetLastError());
     return 0;
 }
 

@@ -66,6 +66,29 @@ class IPMDeviceKernels:
         """(norm(c, Inf), norm(c, 1)): `get_inf_pr` and `get_theta`."""
         return self._call("mnk_ipm_get_norms", _dev(c), int(c.numel()), n=2)
 
+    # ---- elementwise pieces (asynchronous on the context's stream; outputs are device tensors of the caller)
+    def set_perturbation_sets(self, ind_llb, ind_uub):
+        a = np.ascontiguousarray(ind_llb, dtype=np.int64)
+        b = np.ascontiguousarray(ind_uub, dtype=np.int64)
+        L.check(L.lib().mnk_ipm_set_perturbation_sets(self._h, len(a), a.ctypes.data, len(b), b.ctypes.data, 0),
+                "mnk_ipm_set_perturbation_sets")
+
+    def set_aug_rhs(self, f, zl, zu, jacl, c, x, xl, xu, mu, px, py, pzl, pzu):
+        L.check(L.lib().mnk_ipm_set_aug_rhs(self._h, _dev(f), _dev(zl), _dev(zu), _dev(jacl), _dev(c), int(c.numel()),
+                                            _dev(x), _dev(xl), _dev(xu), float(mu), _dev(px), _dev(py), _dev(pzl),
+                                            _dev(pzu)), "mnk_ipm_set_aug_rhs")
+
+    def dual_inf_perturbation(self, px, mu, kappa_d):
+        L.check(L.lib().mnk_ipm_dual_inf_perturbation(self._h, _dev(px), float(mu), float(kappa_d)),
+                "mnk_ipm_dual_inf_perturbation")
+
+    def adjust_boundary(self, x, xl, xu, mu):
+        L.check(L.lib().mnk_ipm_adjust_boundary(self._h, _dev(x), _dev(xl), _dev(xu), float(mu)), "mnk_ipm_adjust_boundary")
+
+    def reset_bound_dual(self, zl, zu, x, xl, xu, mu, kappa_sigma):
+        L.check(L.lib().mnk_ipm_reset_bound_dual(self._h, _dev(zl), _dev(zu), _dev(x), _dev(xl), _dev(xu), float(mu),
+                                                 float(kappa_sigma)), "mnk_ipm_reset_bound_dual")
+
     def close(self):
         if self._h:
             L.lib().mnk_ipm_destroy(self._h)

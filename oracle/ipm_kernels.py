@@ -87,3 +87,32 @@ def get_sd(l, zl_r, zu_r, s_max):
 def get_sc(zl_r, zu_r, s_max):
     """`kernels.jl:690-695`."""
     return max(s_max, (np.abs(zl_r).sum() + np.abs(zu_r).sum()) / max(1, len(zl_r) + len(zu_r))) / s_max
+
+
+# ---- elementwise pieces of the regular phase ------------------------------------------------------------------------
+def set_aug_rhs(f, zl, zu, jacl, c, x_lr, xl_r, zl_r, xu_r, x_ur, zu_r, mu):
+    """`set_aug_rhs!` `kernels.jl:113-131`: returns (px, py, pzl, pzu)."""
+    return -f + zl - zu - jacl, -c, (xl_r - x_lr) * zl_r + mu, (xu_r - x_ur) * zu_r - mu
+
+
+def dual_inf_perturbation(px, ind_llb, ind_uub, mu, kappa_d):
+    """`kernels.jl:818-823` (in place)."""
+    px[ind_llb] -= mu * kappa_d
+    px[ind_uub] += mu * kappa_d
+
+
+def adjust_boundary(x, xl, xu, ind_lb, ind_ub, mu):
+    """`adjust_boundary!` `kernels.jl:656-673` on full-length xl / xu (in place)."""
+    eps = np.finfo(np.float64).eps
+    c1, c2 = eps * mu, eps ** 0.75
+    x_lr, xl_r = x[ind_lb], xl[ind_lb]
+    xl[ind_lb] = np.where(x_lr - xl_r < c1, xl_r - c2 * np.maximum(1.0, np.abs(x_lr)), xl_r)
+    x_ur, xu_r = x[ind_ub], xu[ind_ub]
+    xu[ind_ub] = np.where(xu_r - x_ur < c1, xu_r + c2 * np.maximum(1.0, np.abs(x_ur)), xu_r)
+
+
+def reset_bound_dual(z, x1, x2, mu, kappa_sigma):
+    """`reset_bound_dual!(z, x1, x2, mu, kappa_sigma)` `kernels.jl:788-801` (in place, full-length)."""
+    with np.errstate(divide="ignore"):
+        d = x1 - x2
+        z[:] = np.maximum(np.minimum(z, (kappa_sigma * mu) / d), (mu / kappa_sigma) / d)

@@ -200,3 +200,63 @@ def test_device_kernels_on_the_iterates_of_a_real_ipm_run(ctx, kind):
     if s._K is not None:
         s._K.close()
     s.kkt.close()
+
+
+def test_oracle_elementwise_pieces_on_hand_computed_values():
+    x = np.array([1.0, 2.0, 3.0]); xl = np.array([0.0, 2.0 - 1e-18, -np.inf]); xu = np.array([1.0 + 1e-17, np.inf, 5.0])
+    lb, ub = np.array([0, 1]), np.array([0, 2])
+    zl = np.array([0.5, 0.25, 0.0]); zu = np.array([0.125, 0.0, 2.0])
+    px, py, pzl, pzu = ok.set_aug_rhs(np.array([1.0, 2.0, 3.0]), zl, zu, np.array([0.5, 0.5, 0.5]), np.array([7.0]),
+                                      x[lb], xl[lb], zl[lb], xu[ub], x[ub], zu[ub], 0.1)
+    np.testing.assert_array_equal(px, [-1 + .5 - .125 - .5, -2 + .25 - 0 - .5, -3 + 0 - 2 - .5])
+    np.testing.assert_array_equal(py, [-7.0])
+    np.testing.assert_array_equal(pzl, [(0.0 - 1.0) * .5 + .1, (xl[1] - 2.0) * .25 + .1])
+    np.testing.assert_array_equal(pzu, [(xu[0] - 1.0) * .125 - .1, (5.0 - 3.0) * 2.0 - .1])
+    p = px.copy(); ok.dual_inf_perturbation(p, np.array([1]), np.array([2]), 0.1, 1e-5)
+    np.testing.assert_array_equal(p, [px[0], px[1] - 1e-6, px[2] + 1e-6])
+    eps = np.finfo(float).eps
+    xl2, xu2 = xl.copy(), xu.copy()
+    ok.adjust_boundary(x, xl2, xu2, lb, ub, 0.1)   # x[1] - xl[1] = 0 < eps mu: pushed out; x[0] at its upper bound likewise
+    assert xl2[0] == 0.0 and xl2[1] == xl[1] - eps ** 0.75 * 2.0 and xu2[0] == xu[0] + eps ** 0.75 * 1.0 and xu2[2] == 5.0
+    z = np.array([0.5, 1e12, 0.0, 1e-30]); xx = np.array([1.0, 2.0, 3.0, 4.0]); xb = np.array([0.0, 1.5, -np.inf, 3.0])
+    ok.reset_bound_dual(z, xx, xb, 0.1, 1e10)   # kept / clipped from above / unbounded stays 0 / lifted from below
+    np.testing.assert_array_equal(z, [0.5, (1e10 * 0.1) / 0.5, 0.0, (0.1 / 1e10) / 1.0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ntot,nlb,nub,m", [(7, 3, 2, 2), (1000, 400, 377, 300), (27838, 20646, 19646, 16646)])
+def test_device_elementwise_pieces_bit_exact(ctx, ntot, nlb, nub, m):
+    """set_aug_rhs!, dual_inf_perturbation!, adjust_boundary!, reset_bound_dual! on device vectors: bit-identical to the
+    oracle (elementwise IEEE operations, no contraction)."""
+    import madnlp_jl_amd as mj
+    rng = np.random.default_rng(ntot + 1)
+    d = _data(rng, ntot, nlb, nub, m)
+    lb, ub = d["lb"], d["ub"]
+    xl = np.where(d["xl"] < -1e299, -np.inf, d["xl"]); xu = np.where(d["xu"] > 1e299, np.inf, d["xu"])
+    x, zl, zu, mu = d["x"], d["zl"], d["zu"], 3e-3
+    near = rng.choice(nlb, max(1, nlb // 20), replace=False)
+    x[lb[near]] = xl[lb[near]] + 1e-20          # entries sitting on their lower bound: adjust_boundary! must fire
+    llb = np.setdiff1d(lb, ub); uub = np.setdiff1d(ub, lb)
+    K = mj.IPMDeviceKernels(ntot, lb, ub, ctx=ctx)
+    K.set_perturbation_sets(llb, uub)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    px, py, pzl, pzu = (torch.empty(n, dtype=torch.float64, device="cuda") for n in (ntot, m, nlb, nub))
+    K.set_aug_rhs(t(d["f"]), t(zl), t(zu), t(d["jacl"]), t(d["c"]), t(x), t(xl), t(xu), mu, px, py, pzl, pzu)
+    K.dual_inf_perturbation(px, mu, 1e-5)
+    opx, opy, opzl, opzu = ok.set_aug_rhs(d["f"], zl, zu, d["jacl"], d["c"], x[lb], xl[lb], zl[lb], xu[ub], x[ub], zu[ub], mu)
+    ok.dual_inf_perturbation(opx, llb, uub, mu, 1e-5)
+    for got, want in ((px, opx), (py, opy), (pzl, opzl), (pzu, opzu)):
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    dxl, dxu = t(xl), t(xu)
+    K.adjust_boundary(t(x), dxl, dxu, mu)
+    oxl, oxu = xl.copy(), xu.copy()
+    ok.adjust_boundary(x, oxl, oxu, lb, ub, mu)
+    assert (oxl != xl).sum() >= len(near)
+    np.testing.assert_array_equal(dxl.cpu().numpy(), oxl); np.testing.assert_array_equal(dxu.cpu().numpy(), oxu)
+    dzl, dzu = t(zl), t(zu)
+    K.reset_bound_dual(dzl, dzu, t(x), t(oxl), t(oxu), mu, 1e10)
+    ozl, ozu = zl.copy(), zu.copy()
+    ok.reset_bound_dual(ozl, x, oxl, mu, 1e10); ok.reset_bound_dual(ozu, oxu, x, mu, 1e10)
+    np.testing.assert_array_equal(dzl.cpu().numpy(), ozl); np.testing.assert_array_equal(dzu.cpu().numpy(), ozu)
+    assert (ozl[np.isinf(xl)] == 0).all() and (ozu[np.isinf(xu)] == 0).all()
+    K.close()
