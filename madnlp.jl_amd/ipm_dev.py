@@ -1,0 +1,361 @@
+"""Device-resident regular phase of the IPM mirror: the iterate, the multipliers, the KKT vectors and the
+right-hand sides live in HBM; per iteration only scalars cross PCIe.  Same algorithm, same order of operations as
+`madnlp_jl_amd.ipm.MadNLPSolver` (which documents the reference lines); the vector work goes through
+
+  * the KKT handle:   `set_aug_diagonal!`, `regularize_diagonal!`, `build_kkt!`, `factorize!`, `solve_kkt!`, `mul!`, SpMV
+  * `mnk_ipm_*`:      the reductions and elementwise pieces of reference `src/IPM/kernels.jl`
+  * torch:            axpy-type updates and copies on the device tensors (plumbing)
+
+Scope: `SparseCondensedKKTSystem` (all constraints relaxed to inequalities, as the reference's preset does) and models
+whose callbacks can be evaluated on the device -- here a QP, through the KKT handle's own SpMV on the compressed
+Jacobian / Hessian.  Initialization runs once on the host (the base class) and is uploaded."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .ipm import EPS, INF, IPMOptions, IterRecord, MadNLPSolver
+from .ipm_device import IPMDeviceKernels
+
+
+class DeviceQPCallbacks:
+    """f = 0.5 x'Hx + q'x, c = Jx with H = Symmetric(hess_com, :L) and J = jt_csc' held by the KKT handle."""
+
+    def __init__(self, nlp, kkt, dev):
+        self.kkt, self.n, self.m = kkt, nlp.n, nlp.m
+        self.q = torch.from_numpy(np.asarray(nlp.q, dtype=np.float64)).to(dev)
+        self.jv = torch.from_numpy(np.ascontiguousarray(nlp.jac_coord(None), dtype=np.float64)).to(dev)
+        self.hv = torch.from_numpy(np.ascontiguousarray(nlp.hess_coord(None, None, 1.0), dtype=np.float64)).to(dev)
+        self._hx = torch.empty(self.n, dtype=torch.float64, device=dev)
+
+    def _hmul(self, x):
+        self.kkt.spmv_device(L.MNK_SC_HESS, 0, 1.0, x, 0.0, self._hx)
+        return self._hx
+
+    def obj(self, x):
+        hx = self._hmul(x)
+        return float(0.5 * torch.dot(x, hx) + torch.dot(self.q, x))
+
+    def grad(self, g, x):
+        g.copy_(self._hmul(x))
+        g.add_(self.q)
+
+    def cons(self, c, x):
+        self.kkt.spmv_device(L.MNK_SC_JT, 1, 1.0, x, 0.0, c)
+
+
+class DeviceMadNLPSolver(MadNLPSolver):
+    def __init__(self, nlp, kkt_factory, opt: IPMOptions | None = None, device="cuda"):
+        super().__init__(nlp, kkt_factory, opt, sparse=True)
+        assert self.ns == self.m, "device driver: all-inequality (RelaxEquality) sparse condensed systems"
+        self.dev = torch.device(device)
+        self._on_device = False
+
+    # ------------------------------------------------------------------ host initialization, then upload
+    def _upload(self):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.dev)  # noqa: E731
+        for name in ("x", "xl", "xu", "zl", "zu", "f", "y", "c", "rhs", "jacl", "x_trial", "c_trial"):
+            setattr(self, name, t(getattr(self, name)))
+        nt, m, nlb, nub = self.n + self.ns, self.m, len(self.ind_lb), len(self.ind_ub)
+        self.nt = nt
+        self._lw = nt + m + nlb + nub
+        V = lambda: torch.zeros(self._lw, dtype=torch.float64, device=self.dev)  # noqa: E731
+        self.dv, self.pv, self.w1v, self.w4v = V(), V(), V(), V()
+        self.K = IPMDeviceKernels(nt, self.ind_lb, self.ind_ub, ctx=self.kkt.linear_solver.ctx)
+        self.K.set_perturbation_sets(self.ind_llb, self.ind_uub)
+        self.cb = DeviceQPCallbacks(self.nlp, self.kkt, self.dev)
+        self.ind_lb_t = torch.from_numpy(np.asarray(self.ind_lb, dtype=np.int64)).to(self.dev)
+        self.ind_ub_t = torch.from_numpy(np.asarray(self.ind_ub, dtype=np.int64)).to(self.dev)
+        self.kkt.device_kkt_ops = True
+        self._on_device = True
+        self._sync = self.kkt.linear_solver.ctx.synchronize if hasattr(self.kkt.linear_solver.ctx, "synchronize") else None
+
+    # slices of a KKT vector (reference src/KKT/rhs.jl:90-150)
+    def _primal(self, v): return v[:self.nt]
+    def _dual(self, v): return v[self.nt:self.nt + self.m]
+    def _dual_lb(self, v): return v[self.nt + self.m:self.nt + self.m + len(self.ind_lb)]
+    def _dual_ub(self, v): return v[self.nt + self.m + len(self.ind_lb):]
+
+    # ------------------------------------------------------------------ callbacks
+    def eval_f(self, x):
+        if not self._on_device:
+            return super().eval_f(x)
+        return self.cb.obj(x[:self.n])
+
+    def eval_grad(self, x):
+        if not self._on_device:
+            return super().eval_grad(x)
+        self.cb.grad(self.f[:self.n], x[:self.n])
+        self.f[self.n:] = 0.0
+
+    def eval_cons(self, c, x):
+        if not self._on_device:
+            return super().eval_cons(c, x)
+        self.cb.cons(c, x[:self.n])
+        c.sub_(x[self.n:])          # ind_ineq = all constraints, in order
+        c.sub_(self.rhs)
+
+    def eval_jac(self, x):
+        if not self._on_device:
+            return super().eval_jac(x)
+        self.kkt.compress_jacobian(self.cb.jv)
+
+    def eval_lag_hess(self, x, y):
+        if not self._on_device:
+            return super().eval_lag_hess(x, y)
+        self.kkt.compress_hessian(self.cb.hv)
+
+    def jtprod(self, out, y):
+        """`jtprod!` reference src/KKT/Sparse/condensed.jl:150-156."""
+        self.kkt.spmv_device(L.MNK_SC_JT, 0, 1.0, y, 0.0, out[:self.n])
+        torch.neg(y, out=out[self.n:])
+
+    # ------------------------------------------------------------------ factorization glue
+    def factorize_wrapper(self):
+        if not self._on_device:
+            return super().factorize_wrapper()
+        self.kkt.build_kkt_device()
+        self.kkt.linear_solver.factorize_async()
+        self.cnt.factorization_cnt += 1
+
+    def solve_refine(self, x, b, w):
+        """Richardson refinement (reference src/LinearSolvers/backsolve.jl:27-76) on device vectors."""
+        it = self.iterator
+        norm_b = self.K.get_norms(b)[0]
+        residual_ratio = 0.0
+        x.zero_()
+        it.ir = 0
+        if norm_b != 0:
+            w.copy_(b)
+            while True:
+                self.kkt.solve_kkt_device(w)
+                x.add_(w)
+                w.copy_(b)
+                self.kkt.mul_device(w, x, -1.0, 1.0)
+                norm_w = self.K.get_norms(w)[0]
+                norm_x = self.K.get_norms(x)[0]
+                residual_ratio = norm_w / (min(norm_x, 1e6 * norm_b) + norm_b)
+                it.ir += 1
+                if it.ir >= it.richardson_max_iter or residual_ratio < it.richardson_tol:
+                    break
+        it.residual_ratio = residual_ratio
+        return residual_ratio < it.richardson_acceptable_tol
+
+    def solve_refine_wrapper(self, d, p, w):
+        if not self._on_device:
+            return super().solve_refine_wrapper(d, p, w)
+        ok = self.solve_refine(d, p, w)
+        self.cnt.backsolve_cnt += self.iterator.ir
+        return ok
+
+    # ------------------------------------------------------------------ kernels
+    def set_aug_diagonal(self):
+        o = self.opt
+        self.kkt.set_aug_diagonal_device(self.x, self.xl, self.xu, self.zl, self.zu, o.default_primal_regularization,
+                                         o.default_dual_regularization)
+
+    def set_aug_rhs(self, c):
+        p = self.pv
+        self.K.set_aug_rhs(self.f, self.zl, self.zu, self.jacl, c, self.x, self.xl, self.xu, self.mu, self._primal(p),
+                           self._dual(p), self._dual_lb(p), self._dual_ub(p))
+        self.K.dual_inf_perturbation(self._primal(p), self.mu, self.opt.kappa_d)
+
+    def inf_compl(self, mu, sc):
+        return self.K.get_inf_compl(self.x, self.xl, self.xu, self.zl, self.zu, mu, sc)
+
+    def varphi(self, obj, x):
+        return self.K.get_varphi(obj, x, self.xl, self.xu, self.mu)
+
+    def alpha_max(self, dx):
+        return self.K.get_alpha_max(self.x, self.xl, self.xu, dx, self.tau)
+
+    def inertia_correction(self):
+        o, k = self.opt, self.kkt
+        n_trial = 0
+        dw_prev = dc_prev = 0.0
+        self.del_w = self.del_c = 0.0
+        self.factorize_wrapper()
+        inertia = k.linear_solver.inertia()
+        ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if k.is_inertia_correct(*inertia) else False
+        while not ok:
+            if n_trial == 0:
+                self.del_w = (o.first_hessian_perturbation if self.del_w_last == 0 else
+                              max(o.min_hessian_perturbation, o.perturb_dec_fact * self.del_w_last))
+            else:
+                self.del_w *= o.perturb_inc_fact_first if self.del_w_last == 0 else o.perturb_inc_fact
+                if self.del_w > o.max_hessian_perturbation:
+                    self.cnt.k += 1
+                    return False
+            self.del_c = (o.jacobian_regularization_value * self.mu ** o.jacobian_regularization_exponent
+                          if k.should_regularize_dual(*inertia) else 0.0)
+            k.regularize_diagonal_device(self.del_w - dw_prev, self.del_c - dc_prev)
+            dw_prev, dc_prev = self.del_w, self.del_c
+            self.factorize_wrapper()
+            inertia = k.linear_solver.inertia()
+            ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if k.is_inertia_correct(*inertia) else False
+            n_trial += 1
+        if self.del_w != 0:
+            self.del_w_last = self.del_w
+        return True
+
+    # ------------------------------------------------------------------ filter line search
+    def filter_line_search(self):
+        o, K = self.opt, self.K
+        dx = self._primal(self.dv)
+        theta = K.get_norms(self.c)[1]
+        varphi = self.varphi(self.obj_val, self.x)
+        varphi_d = K.get_varphi_d(self.f, self.x, self.xl, self.xu, dx, self.mu)
+        alpha_max = self.alpha_max(dx)
+        self.alpha_z = K.get_alpha_z(self.zl, self.zu, self._dual_lb(self.dv), self._dual_ub(self.dv), self.tau)
+        if varphi_d < 0:
+            if theta <= self.theta_min:
+                alpha_min = o.alpha_min_frac * min(o.gamma_theta, o.gamma_phi * theta / (-varphi_d),
+                                                   o.delta * theta ** o.s_theta / (-varphi_d) ** o.s_phi)
+            else:
+                alpha_min = o.alpha_min_frac * min(o.gamma_theta, -o.gamma_phi * theta / varphi_d)
+        else:
+            alpha_min = o.alpha_min_frac * o.gamma_theta
+        self.cnt.l = 1
+        self.alpha = alpha_max
+        small = K.get_rel_search_norm(self.x, dx) < 10 * EPS
+        switching = varphi_d < 0 and self.alpha * (-varphi_d) ** o.s_phi > o.delta * 2.0 ** o.s_theta
+        armijo = False
+        unsuccessful = False
+        theta_trial = varphi_trial = 0.0
+        norm_dx = None
+        while True:
+            torch.add(self.x, dx, alpha=self.alpha, out=self.x_trial)
+            self.obj_val_trial = self.eval_f(self.x_trial)
+            self.eval_cons(self.c_trial, self.x_trial)
+            theta_trial = K.get_norms(self.c_trial)[1]
+            varphi_trial = self.varphi(self.obj_val_trial, self.x_trial)
+            armijo = varphi_trial <= varphi + o.eta_phi * self.alpha * varphi_d
+            if small:
+                break
+            ftype = self._ftype(theta, theta_trial, varphi, varphi_trial, switching, armijo)
+            if ftype in ("f", "h"):
+                break
+            if self.cnt.l == 1 and theta_trial >= theta:
+                if self._second_order_correction(alpha_max, theta, varphi, theta_trial, varphi_d, switching):
+                    theta_trial = K.get_norms(self.c_trial)[1]
+                    varphi_trial = self.varphi(self.obj_val_trial, self.x_trial)
+                    break
+            unsuccessful = True
+            self.alpha /= 2
+            self.cnt.l += 1
+            if self.alpha < alpha_min:
+                self.cnt.k += 1
+                return "RESTORE"
+            if norm_dx is None:
+                norm_dx = float(torch.linalg.vector_norm(dx))
+            if self.alpha * norm_dx < EPS * 10:
+                return "SEARCH_DIRECTION_BECOMES_TOO_SMALL"
+        if unsuccessful:
+            self.cnt.unsuccessful_iterate += 1
+            if self.cnt.unsuccessful_iterate >= 4:
+                if self.theta_max / 10 > theta_trial:
+                    self.theta_max /= 10
+                    self.filter = [(self.theta_max, -INF)]
+                self.cnt.unsuccessful_iterate = 0
+        else:
+            self.cnt.unsuccessful_iterate = 0
+        if not switching or not armijo:
+            self.filter.append(((1 - o.gamma_theta) * theta_trial, varphi_trial - o.gamma_theta * theta_trial))
+        return "LINESEARCH_SUCCEEDED"
+
+    def _second_order_correction(self, alpha_max, theta, varphi, theta_trial, varphi_d, switching):
+        o, K = self.opt, self.K
+        w1 = self.w1v
+        wy = self._dual(w1)
+        torch.add(self.c_trial, self.c, alpha=alpha_max, out=wy)
+        theta_soc_old = theta_trial
+        for _ in range(o.max_soc):
+            self.set_aug_rhs(wy)
+            self.solve_refine_wrapper(w1, self.pv, self.w4v)
+            wx = self._primal(w1)
+            alpha_soc = self.alpha_max(wx)
+            torch.add(self.x, wx, alpha=alpha_soc, out=self.x_trial)
+            self.eval_cons(self.c_trial, self.x_trial)
+            self.obj_val_trial = self.eval_f(self.x_trial)
+            theta_soc = K.get_norms(self.c_trial)[1]
+            varphi_soc = self.varphi(self.obj_val_trial, self.x_trial)
+            if not self._filter_ok(theta_soc, varphi_soc):
+                break
+            if theta <= self.theta_min and switching:
+                if varphi_soc <= varphi + o.eta_phi * self.alpha * varphi_d:
+                    self.alpha = alpha_soc
+                    return True
+            else:
+                suff = (self.m > 0 and theta_soc <= (1 - o.gamma_theta) * theta + 10 * EPS * abs(theta)) or \
+                       (varphi_soc <= varphi - o.gamma_phi * theta + 10 * EPS * abs(varphi))
+                if suff:
+                    self.alpha = alpha_soc
+                    return True
+            if theta_soc > o.kappa_soc * theta_soc_old:
+                break
+            theta_soc_old = theta_soc
+        return False
+
+    # ------------------------------------------------------------------ regular!
+    def solve(self):
+        if self.status == "INITIAL":
+            self.initialize()          # host (numpy), once
+            self._upload()
+        o, K = self.opt, self.K
+        while True:
+            if self.cnt.k != 0:
+                self.eval_jac(self.x)
+            self.jtprod(self.jacl, self.y)
+            sd, sc = K.get_sd_sc(self.y, self.zl, self.zu, o.s_max)
+            self.inf_pr = K.get_norms(self.c)[0]
+            self.inf_du = K.get_inf_du(self.f, self.zl, self.zu, self.jacl, sd)
+            self.inf_compl_v = self.inf_compl(0.0, sc)
+            self.history.append(IterRecord(self.cnt.k, self.obj_val, self.inf_pr, self.inf_du, self.inf_compl_v,
+                                           self.mu, self.del_w, self.alpha, self.cnt.l))
+            inf_total = max(self.inf_pr, self.inf_du, self.inf_compl_v)
+            if inf_total <= o.tol:
+                self.status = "SOLVE_SUCCEEDED"
+                return self.status
+            if inf_total <= o.acceptable_tol:
+                if self.cnt.acceptable_cnt < o.acceptable_iter:
+                    self.cnt.acceptable_cnt += 1
+                else:
+                    self.status = "SOLVED_TO_ACCEPTABLE_LEVEL"
+                    return self.status
+            else:
+                self.cnt.acceptable_cnt = 0
+            if inf_total >= o.diverging_iterates_tol:
+                self.status = "DIVERGING_ITERATES"
+                return self.status
+            if self.cnt.k >= o.max_iter:
+                self.status = "MAXIMUM_ITERATIONS_EXCEEDED"
+                return self.status
+            if self.cnt.k != 0:
+                self.eval_lag_hess(self.x, self.y)
+            self.update_barrier(sc)
+            self.set_aug_diagonal()
+            self.set_aug_rhs(self.c)
+            if not self.inertia_correction():
+                self.status = "ROBUST (restoration not implemented)"
+                return self.status
+            st = self.filter_line_search()
+            if st != "LINESEARCH_SUCCEEDED":
+                self.status = st + " (restoration not implemented)" if st == "RESTORE" else st
+                return self.status
+            self.x.copy_(self.x_trial)
+            self.c.copy_(self.c_trial)
+            self.obj_val = self.obj_val_trial
+            K.adjust_boundary(self.x, self.xl, self.xu, self.mu)
+            self.y.add_(self._dual(self.dv), alpha=self.alpha)
+            self.zl[self.ind_lb_t] += self.alpha_z * self._dual_lb(self.dv)
+            self.zu[self.ind_ub_t] += self.alpha_z * self._dual_ub(self.dv)
+            K.reset_bound_dual(self.zl, self.zu, self.x, self.xl, self.xu, self.mu, o.kappa_sigma)
+            self.eval_grad(self.x)
+            self.cnt.k += 1
+
+    def host_state(self):
+        """x, y, zl, zu on the host (tests, reporting)."""
+        return tuple(v.cpu().numpy() for v in (self.x, self.y, self.zl, self.zu))

@@ -327,6 +327,14 @@ class SparseCondensedKKTSystem(_KKTCommon):
         L.check(L.lib().mnk_sc_mul(self._h, pw, px, float(alpha), float(beta), loc), "mnk_sc_mul")
         return w
 
+    def spmv_device(self, which, trans, alpha, x, beta, y):
+        """y = alpha op(A) x + beta y on device vectors with A = jt_csc (`MNK_SC_JT`; trans 0: n <- m, 1: m <- n) or
+        Symmetric(hess_com, :L) (`MNK_SC_HESS`), the compressed values the handle holds (`mnk_sc_spmv`)."""
+        px, lx = _ptr(x)
+        py, ly = _ptr(y)
+        assert lx == ly == L.MNK_DEVICE
+        L.check(L.lib().mnk_sc_spmv(self._h, int(which), int(trans), float(alpha), px, float(beta), py), "mnk_sc_spmv")
+
     def is_inertia_correct(self, num_pos, num_zero, num_neg):
         """reference `src/KKT/Sparse/condensed.jl:138-140`."""
         return num_zero == 0 and num_pos == self.n

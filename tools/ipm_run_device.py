@@ -1,0 +1,51 @@
+"""End-to-end IPM run with DEVICE-RESIDENT vectors (madnlp_jl_amd.ipm_dev) next to the host mirror on the same
+OPF-shaped convex QP (default case1354pegase shape, N = 11192 condensed KKT): iterations, counts, wall clock."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import madnlp_jl_amd as mj  # noqa: E402
+from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver  # noqa: E402
+from madnlp_jl_amd.ipm_dev import DeviceMadNLPSolver  # noqa: E402
+from madnlp_jl_amd.problems import SparseQPModel  # noqa: E402
+
+case = sys.argv[1] if len(sys.argv) > 1 else "case1354pegase"
+nlp = SparseQPModel(case)
+st = torch.cuda.Stream()
+torch.cuda.set_stream(st)
+ctx = mj.HipContext(0, stream=st.cuda_stream)
+
+
+def factory(info):
+    return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J, info["ind_ineq"],
+                                       info["ind_lb"], info["ind_ub"], ctx=ctx,
+                                       opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN),
+                                       device_kkt_ops=True)
+
+
+def options():
+    o = IPMOptions(tol=1e-6)
+    o.relax_equality, o.dual_initialization = True, "zero"
+    return o
+
+
+for label, cls in (("host mirror (numpy vectors, device KKT ops)", MadNLPSolver), ("device-resident vectors", DeviceMadNLPSolver)):
+    for rep in range(2):  # second run: warm
+        s = cls(nlp, factory, options()) if cls is DeviceMadNLPSolver else cls(nlp, factory, options(), sparse=True)
+        s.initialize()
+        if cls is DeviceMadNLPSolver:
+            s._upload()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.solve()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        rec = {"case": case, "driver": label, "run": rep, "n": nlp.n, "m": nlp.m, "status": s.status, "iterations": s.cnt.k,
+               "factorizations": s.cnt.factorization_cnt, "backsolves": s.cnt.backsolve_cnt, "wall_s_regular_phase": wall,
+               "ms_per_iteration_wall": 1e3 * wall / max(1, s.cnt.k), "it_per_s": s.cnt.k / wall, "obj": float(s.obj_val)}
+        print(json.dumps(rec), flush=True)
+        s.kkt.close()
