@@ -28,7 +28,27 @@ import os
 import sys
 import time
 
-import numpy as np
+
+def _cpu_quota():
+    """CPUs this process may actually use: min(visible cpus, cgroup v2 cpu.max quota).  The GPU boxes of the pool show
+    256 logical cpus but carry `cpu.max = 1600000 100000` (16 CPUs): BLAS / OpenMP pools sized after the visible count
+    spin on 100+ threads, the cgroup gets throttled and EVERY thread of the process -- the one driving the GPU included --
+    freezes for 40-80 ms at a time (measured: GPU events 11.9 ms, host wait up to 88 ms; cpu.stat nr_throttled rising)."""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+CPU_CAP = _cpu_quota()
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(CPU_CAP))  # must be set before numpy / torch create their pools
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -253,12 +273,13 @@ def cpu_baseline(P, algorithm, nsolve, budget_s=100.0):
                 "blas_threads": int(threads), "ms_per_factorize": 1e3 * tf, "ms_per_solve": 1e3 * ts,
                 "it_per_s": 1.0 / total, "gflops_factorize": P.n ** 3 / 3.0 / tf / 1e9}
 
-    # Most informative legs first.  Measured on the MI355X host (2 x 64 cores): OpenBLAS dsytrf does not scale
-    # with threads (its panel factorization dlasyf is level-2 bound: ~37 GFLOP/s at 64 or 128 threads, 12.5 s at
-    # N = 11192) while dpotrf does (385 GFLOP/s, 1.2 s), so a small thread count is tried as well.
-    few = max(2, min(16, phys // 2))
-    plan = [(main_alg, 1), (main_alg, few), (main_alg, phys), (other_alg, phys), (other_alg, 1),
-            (main_alg, max(1, phys // 2)), (other_alg, max(1, phys // 2)), (other_alg, few)]
+    # Most informative legs first.  Thread counts never exceed what the process may use (CPU_CAP = min(cores, cgroup
+    # quota): on the pool's boxes 16 of the 256 visible cpus -- round 2's first protocol ran 64 / 128 BLAS threads there
+    # and measured the cgroup throttle, not OpenBLAS: 12.6 s for dsytrf).
+    cap = max(1, min(phys, CPU_CAP))
+    few = max(1, min(16, cap))
+    plan = [(main_alg, 1), (main_alg, few), (main_alg, cap), (other_alg, cap), (other_alg, 1),
+            (main_alg, max(1, cap // 2)), (other_alg, max(1, cap // 2)), (other_alg, few)]
     runs, skipped, seen = [], [], set()
     for alg, thr in plan:
         if (alg, thr) in seen:
@@ -279,9 +300,9 @@ def cpu_baseline(P, algorithm, nsolve, budget_s=100.0):
         "sample": f"ONE iteration of the same hot path per setting ({P.name}-shaped, N={P.n}; numpy assembly + "
                   f"CSC->dense copy + scipy/OpenBLAS {best['lapack']}), each after a warm-up factorization at "
                   f"N=2048; value = fastest BLAS-thread setting of {main_alg}; host has {phys} physical cores / "
-                  f"{logical} logical cpus",
+                  f"{logical} logical cpus, of which the process may use {CPU_CAP} (cgroup cpu.max)",
         "ms_per_factorize": best["ms_per_factorize"], "ms_per_solve": best["ms_per_solve"], "ms_build": ms_build,
-        "host_physical_cores": phys, "host_logical_cpus": logical,
+        "host_physical_cores": phys, "host_logical_cpus": logical, "host_cpu_quota": CPU_CAP,
         "reference_default": ref_default,   # blas_num_threads = 1 (reference src/IPM/options.jl:127)
         "runs": runs, "skipped": skipped,
         "seconds_spent": time.perf_counter() - t_start,
@@ -318,6 +339,13 @@ def main():
     torch.cuda.set_device(local)
     import madnlp_jl_amd as mj
     from madnlp_jl_amd.problems import OPF_CASES, opf_shaped
+    # GPU phase: no host thread pool may spin beside the thread that drives the GPU (see _cpu_quota)
+    torch.set_num_threads(1)
+    try:
+        from threadpoolctl import threadpool_limits
+        host_pool_limit = threadpool_limits(limits=1)
+    except Exception:
+        host_pool_limit = None
 
     dev = torch.device("cuda", local)
     # a non-default stream: its handle is non-NULL, the library enqueues on it and torch's
@@ -451,6 +479,8 @@ def main():
             except Exception as e:  # never let the supplement break the bench line
                 out["end_to_end_ipm"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
+            if host_pool_limit is not None:
+                host_pool_limit.restore_original_limits()  # the CPU leg sets its own BLAS thread counts
             cb = cpu_baseline(P, args.algorithm, args.nsolve, args.cpu_baseline_budget)
             out["cpu_baseline"] = cb
             # GPU it/s over the CPU port's it/s (NOT `vs_baseline`: BASELINE.md holds no published number)

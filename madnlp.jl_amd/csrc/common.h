@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -39,6 +40,24 @@ constexpr int PAD = 128;
 // wave tile past the last row (values are discarded, memory must be mapped).
 constexpr int SLACK = 256;
 
+// Host-side wait for a stream: hipStreamSynchronize (short spin, then an interrupt-driven sleep) by default; with
+// MNK_SPIN_WAIT=1 the stream is polled instead (one host core busy for the duration of every wait).  Round 2 chased
+// 40-80 ms stalls of the inertia fetch down to the HOST being frozen by its cgroup CPU quota (BLAS / OpenMP pools sized
+// after 256 visible cpus on a 16-CPU quota), not to this wait: both forms measure the same once the pools are bounded
+// (bench.py: _cpu_quota).
+inline hipError_t stream_wait(hipStream_t s) {
+    static const bool spin = []() {
+        const char* e = getenv("MNK_SPIN_WAIT");
+        return e != nullptr && atoi(e) != 0;
+    }();
+    if (!spin) return hipStreamSynchronize(s);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        __builtin_ia32_pause();
+    }
+}
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 template <class T>
@@ -63,7 +82,7 @@ struct DevBuf {
         if (!h.empty()) {
             hipError_t e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
             if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); return -2; }
-            e = hipStreamSynchronize(s);
+            e = stream_wait(s);
             if (e != hipSuccess) { set_error("upload sync failed: %s", hipGetErrorString(e)); return -2; }
         }
         return 0;

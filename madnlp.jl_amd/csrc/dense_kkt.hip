@@ -300,7 +300,7 @@ int mnk_dc_create(mnk_ctx* ctx, int condensed, int64_t n, int64_t m, int64_t ns,
 int mnk_dc_destroy(mnk_dc* dc) {
     if (!dc) return 0;
     (void)hipSetDevice(dc->ctx->device);
-    (void)hipStreamSynchronize(dc->ctx->stream);
+    (void)mnk::stream_wait(dc->ctx->stream);
     delete extra_of(dc);
     dc->extra = nullptr;
     mnk_ctx* ctx = dc->ctx;
@@ -316,7 +316,7 @@ static int copy_in_2d(mnk_ctx* ctx, double* dst, int64_t rows, int64_t cols, con
     MNK_REQUIRE(ld >= rows, "leading dimension smaller than the number of rows");
     MNK_HIP(hipMemcpy2DAsync(dst, rows * sizeof(double), src, ld * sizeof(double), rows * sizeof(double), cols,
                              loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(ctx->stream));
+    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(ctx->stream));
     return 0;
 }
 
@@ -345,7 +345,7 @@ int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int l
         const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         MNK_HIP(hipMemcpyAsync(dc->pr_diag.p, pr_diag, (dc->n + dc->ns) * sizeof(double), kind, s));
         if (dc->m > 0) MNK_HIP(hipMemcpyAsync(dc->du_diag.p, du_diag, dc->m * sizeof(double), kind, s));
-        if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+        if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(s));
     }
     const int64_t ordpad = round_up(dc->order, PAD);
     const int64_t ldk = ordpad;
@@ -386,7 +386,7 @@ int mnk_dc_get_aug(mnk_dc* dc, double* out, int loc) {
     MNK_HIP(hipMemcpy2DAsync(out, dc->order * sizeof(double), dc->aug.p, ldk * sizeof(double),
                              dc->order * sizeof(double), dc->order,
                              loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, dc->ctx->stream));
-    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(dc->ctx->stream));
+    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(dc->ctx->stream));
     return 0;
 }
 
@@ -485,7 +485,7 @@ int mnk_dc_set_barrier_terms(mnk_dc* dc, const double* reg, const double* l_diag
     rc |= put(ex->l_lower.p, l_lower, ex->nlb);
     rc |= put(ex->u_lower.p, u_lower, ex->nub);
     if (rc) return rc;
-    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(s));
     ex->have_terms = true;
     return 0;
 }
@@ -542,10 +542,10 @@ int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc) {
         if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, ex->ind_ub.p, ex->u_lower.p, ex->u_diag.p, nub, 1);
         MNK_HIP(hipGetLastError());
         if (loc == MNK_DEVICE) break;
-        MNK_HIP(hipStreamSynchronize(s));
+        MNK_HIP(mnk::stream_wait(s));
         if (attempt == 0 && mnk_ls_take_solve_abort(ls)) continue;
         MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(hipStreamSynchronize(s));
+        MNK_HIP(mnk::stream_wait(s));
         break;
     }
     return 0;
@@ -587,7 +587,7 @@ int mnk_dc_mul(mnk_dc* dc, double* w, const double* x, double alpha, double beta
     MNK_HIP(hipGetLastError());
     if (loc != MNK_DEVICE) {
         MNK_HIP(hipMemcpyAsync(w, dw, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(hipStreamSynchronize(s));
+        MNK_HIP(mnk::stream_wait(s));
     }
     return 0;
 }

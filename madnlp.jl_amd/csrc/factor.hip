@@ -1598,6 +1598,16 @@ static int factor_outer_panel_256(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t
     return 0;
 }
 
+// The host reads the inertia counters and the info word from pinned, device-mapped memory that this one-thread kernel
+// fills with system-scope stores: no copy engine and no staging copy between the last kernel and the host.
+__global__ void publish_info_kernel(const unsigned long long* __restrict__ inertia, const int* __restrict__ info,
+                                    unsigned long long* __restrict__ host_words) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 3; ++i) __hip_atomic_store(host_words + i, inertia[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 3, (unsigned long long)(long long)*info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // panel_algo = 4: persistent panel launches (ppanel_kernel) of pp_nb blocks, recursive updates between them
 static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
                                  hipEvent_t rest_ready, int64_t rest_from, const double* Vfirst, int64_t ldvfirst,
@@ -2024,11 +2034,12 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         // numneg from the 1x1 / 2x2 blocks of D (-1 if a block is exactly singular), numpos the rest
         int rc = mnk_ls_bk_inertia(ls, ls->inertia_dev.p);
         if (rc) return rc;
-        unsigned long long h[3];
-        int hinfo = 0;
-        MNK_HIP(hipMemcpyAsync(h, ls->inertia_dev.p, sizeof(h), hipMemcpyDeviceToHost, s));
-        MNK_HIP(hipMemcpyAsync(&hinfo, ls->info_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        MNK_HIP(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(publish_info_kernel, dim3(1), dim3(64), 0, s, ls->inertia_dev.p, ls->info_dev.p, ls->pin_dev);
+        MNK_HIP(hipGetLastError());
+        MNK_HIP(mnk::stream_wait(s));
+        volatile unsigned long long* pw = ls->pin;
+        unsigned long long h[3] = {pw[0], pw[1], pw[2]};
+        int hinfo = (int)(long long)pw[3];
         ls->info = hinfo;
         ls->nneg = h[1] > 0 ? -1 : (int64_t)h[0];
         ls->nzero = hinfo > 0 ? 1 : 0;
@@ -2040,11 +2051,12 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         const int blocks = (int)std::min<int64_t>(256, (ls->N + 255) / 256);
         hipLaunchKernelGGL(inertia_kernel, dim3(blocks), dim3(256), 0, s, ls->dvec.p, ls->N, ls->inertia_dev.p);
     }
-    unsigned long long h[3];
-    int hinfo = 0;
-    MNK_HIP(hipMemcpyAsync(h, ls->inertia_dev.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    MNK_HIP(hipMemcpyAsync(&hinfo, ls->info_dev.p, sizeof(int), hipMemcpyDeviceToHost, s));
-    MNK_HIP(hipStreamSynchronize(s));
+    hipLaunchKernelGGL(publish_info_kernel, dim3(1), dim3(64), 0, s, ls->inertia_dev.p, ls->info_dev.p, ls->pin_dev);
+    MNK_HIP(hipGetLastError());
+    MNK_HIP(mnk::stream_wait(s));
+    volatile unsigned long long* pw = ls->pin;
+    unsigned long long h[3] = {pw[0], pw[1], pw[2]};
+    int hinfo = (int)(long long)pw[3];
     if (hinfo == -7 && ls->algo_now == 4 && ls->retransfer) {
         // the persistent panel kernel gave up on a dependency (CUs shared with another process' persistent kernels):
         // factor again with one launch per panel piece, and stay there
@@ -2120,7 +2132,7 @@ extern "C" int mnk_debug_potrf64(mnk_ctx* ctx, int variant, int reps, double* ms
     }
 #undef MNK_PD
     MNK_HIP(hipEventRecord(e1, s));
-    MNK_HIP(hipStreamSynchronize(s));
+    MNK_HIP(mnk::stream_wait(s));
     float t = 0.f;
     MNK_HIP(hipEventElapsedTime(&t, e0, e1));
     *ms = (double)t / reps;

@@ -19,6 +19,8 @@ struct mnk_ipm {
     DevBuf<int64_t> ind_lb, ind_ub, ind_llb, ind_uub;
     DevBuf<double> part;   // 2 x IPM_BLOCKS partials
     DevBuf<double> res;    // 2 results
+    double* pin = nullptr;     // 2 pinned, device-mapped host words: the final reduction stores its result here
+    double* pin_dev = nullptr;
 };
 
 namespace {
@@ -64,7 +66,9 @@ __global__ __launch_bounds__(IPM_THREADS) void final_reduce_kernel(const double*
         if ((int)threadIdx.x < s) sh[threadIdx.x] = red_op_nan<RED>(sh[threadIdx.x], sh[threadIdx.x + s]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) res[0] = sh[0];
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(res), (unsigned long long)__double_as_longlong(sh[0]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- element functors.  side 0: lower-bounded entries (index set ind_lb), side 1: upper-bounded (ind_ub) ----------
@@ -136,7 +140,7 @@ int enqueue(mnk_ipm* h, F f, int64_t n, int slot) {
     hipStream_t s = h->ctx->stream;
     double* part = h->part.p + slot * IPM_BLOCKS;
     hipLaunchKernelGGL((map_reduce_kernel<RED, F>), dim3(IPM_BLOCKS), dim3(IPM_THREADS), 0, s, f, n, part);
-    hipLaunchKernelGGL((final_reduce_kernel<RED>), dim3(1), dim3(IPM_THREADS), 0, s, part, IPM_BLOCKS, h->res.p + slot);
+    hipLaunchKernelGGL((final_reduce_kernel<RED>), dim3(1), dim3(IPM_THREADS), 0, s, part, IPM_BLOCKS, h->pin_dev + slot);
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -144,8 +148,10 @@ int enqueue(mnk_ipm* h, F f, int64_t n, int slot) {
 inline double max0(double r) { return r != r ? r : fmax(0.0, r); }  // reference: max(zero, ...), NaN propagates
 
 int fetch(mnk_ipm* h, int count, double* out) {
-    MNK_HIP(hipMemcpyAsync(out, h->res.p, count * sizeof(double), hipMemcpyDeviceToHost, h->ctx->stream));
-    MNK_HIP(hipStreamSynchronize(h->ctx->stream));
+    // the final reductions stored their results straight into pinned, device-mapped host memory: poll the stream, read
+    MNK_HIP(mnk::stream_wait(h->ctx->stream));
+    volatile double* pw = h->pin;
+    for (int i = 0; i < count; ++i) out[i] = pw[i];
     return 0;
 }
 
@@ -173,6 +179,11 @@ int mnk_ipm_create(mnk_ctx* ctx, int64_t ntot, int64_t nlb, const int64_t* ind_l
     h->ntot = ntot; h->nlb = nlb; h->nub = nub;
     int rc = h->ind_lb.upload(lb, ctx->stream) | h->ind_ub.upload(ub, ctx->stream) | h->part.alloc(2 * IPM_BLOCKS) |
              h->res.alloc(2);
+    if (!rc && (hipHostMalloc((void**)&h->pin, 2 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&h->pin_dev, h->pin, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        rc = -2;
+    }
     if (rc) { delete h; return rc; }
     mnk_ctx_child_added(ctx);
     *out = h;
@@ -182,8 +193,9 @@ int mnk_ipm_create(mnk_ctx* ctx, int64_t ntot, int64_t nlb, const int64_t* ind_l
 int mnk_ipm_destroy(mnk_ipm* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->ctx->device);
-    (void)hipStreamSynchronize(h->ctx->stream);
+    (void)mnk::stream_wait(h->ctx->stream);
     mnk_ctx* ctx = h->ctx;
+    if (h->pin) (void)hipHostFree(h->pin);
     delete h;
     mnk_ctx_child_gone(ctx);
     return 0;

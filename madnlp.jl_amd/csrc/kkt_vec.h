@@ -85,7 +85,7 @@ static inline int kkt_set_aug_diagonal(const AugDiagView& v, const double* x, co
             MNK_HIP(hipMemcpyAsync(v.feed->p + k * v.npr, in[k], v.npr * sizeof(double), hipMemcpyHostToDevice, s));
             in[k] = v.feed->p + k * v.npr;
         }
-        MNK_HIP(hipStreamSynchronize(s));  // the caller's arrays are only valid for the duration of the call
+        MNK_HIP(mnk::stream_wait(s));  // the caller's arrays are only valid for the duration of the call
     }
 #define MNK_G1(cnt) dim3((unsigned)(((cnt) + 255) / 256)), dim3(256), 0, s
     hipLaunchKernelGGL(vec_fill2_kernel, MNK_G1(v.npr), v.reg, v.pr_diag, primal_reg, v.npr);
@@ -121,7 +121,7 @@ static inline int kkt_get_diagonals(const AugDiagView& v, double* pr_diag, doubl
              get(l_diag, v.l_diag, v.nlb) | get(u_diag, v.u_diag, v.nub) | get(l_lower, v.l_lower, v.nlb) |
              get(u_lower, v.u_lower, v.nub);
     if (rc) return rc;
-    MNK_HIP(hipStreamSynchronize(s));
+    MNK_HIP(mnk::stream_wait(s));
     return 0;
 }
 #undef MNK_G1

@@ -76,6 +76,8 @@ struct mnk_ls {
     mnk::DevBuf<unsigned long long> solve_trace;  // diagnostics: 8 time stamps per 64-row block (option solve_trace)
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
+    unsigned long long* pin = nullptr;  // 4 pinned, device-mapped host words: inertia counters + info are stored here by a kernel
+    unsigned long long* pin_dev = nullptr;  // the same words as the device sees them
     // Bunch-Kaufman tier (bk.hip): taken when BUNCHKAUFMAN was requested and the static-pivot factorization broke down
     bool bk_requested = false;   // mnk_ls_create was called with MNK_BUNCHKAUFMAN (MNK_LDL: static pivoting only)
     int bk_fallback = 1;         // option: 0 = never take the pivoted tier (a breakdown is reported as num_zero)

@@ -237,7 +237,7 @@ int mnk_ctx_destroy(mnk_ctx* c) {
 
 int mnk_ctx_synchronize(mnk_ctx* c) {
     MNK_REQUIRE(c != nullptr, "ctx is NULL");
-    MNK_HIP(hipStreamSynchronize(c->stream));
+    MNK_HIP(mnk::stream_wait(c->stream));
     return 0;
 }
 
@@ -294,6 +294,11 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     } else {
         *ls->solve_abort = 0;
     }
+    if (hipHostMalloc((void**)&ls->pin, 4 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&ls->pin_dev, ls->pin, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        rc |= -2;
+    }
     rc |= ls->info_dev.alloc(1);
     rc |= ls->inertia_dev.alloc(3);
     if (rc) { delete ls; return -2; }
@@ -306,8 +311,9 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
 int mnk_ls_destroy(mnk_ls* ls) {
     if (!ls) return 0;
     (void)hipSetDevice(ls->ctx->device);
-    (void)hipStreamSynchronize(ls->ctx->stream);
+    (void)mnk::stream_wait(ls->ctx->stream);
     if (ls->solve_abort) (void)hipHostFree(ls->solve_abort);
+    if (ls->pin) (void)hipHostFree(ls->pin);
     mnk_ctx* ctx = ls->ctx;
     delete ls;
     mnk_ctx_child_gone(ctx);
@@ -467,7 +473,7 @@ int mnk_ls_factorize_dense(mnk_ls* ls, const double* A, int64_t lda, int loc, in
         MNK_HIP(hipMemcpy2DAsync(tmp.p, ls->N * sizeof(double), A, lda * sizeof(double), ls->N * sizeof(double),
                                  ls->N, hipMemcpyHostToDevice, ls->ctx->stream));
         rc = factorize_dense_dev(ls, tmp.p, ls->N);
-        MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+        MNK_HIP(mnk::stream_wait(ls->ctx->stream));
         if (!rc) rc = finish_info(ls, info);  // (a breakdown is handled while the staging buffer is alive)
         ls->retransfer = nullptr;
         return rc;
@@ -513,7 +519,7 @@ int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowva
     ls->retransfer = transfer;
     rc = mnk_ls_run_factorization(ls);
     if (!rc) {
-        MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+        MNK_HIP(mnk::stream_wait(ls->ctx->stream));
         rc = finish_info(ls, info);
     }
     ls->retransfer = nullptr;  // the staging buffers die with this call
@@ -535,7 +541,7 @@ int mnk_ls_inertia(mnk_ls* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num
 int mnk_ls_check_solve(mnk_ls* ls) {
     MNK_REQUIRE(ls, "mnk_ls_check_solve: NULL argument");
     MNK_HIP(hipSetDevice(ls->ctx->device));
-    MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+    MNK_HIP(mnk::stream_wait(ls->ctx->stream));
     if (mnk_ls_take_solve_abort(ls)) {
         set_error("mnk_ls_check_solve: a persistent solve on device-resident data gave up waiting for a peer workgroup "
                   "(device oversubscribed by another process?); its result is invalid -- solve again "
@@ -577,7 +583,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
             // The one-launch solve gives up (instead of hanging the device) if its workgroups cannot all become
             // resident, e.g. another process saturates the GPU with its own persistent kernels.  The host still
             // owns the right-hand side here: redo this and all later solves with one launch per step.
-            MNK_HIP(hipStreamSynchronize(s));
+            MNK_HIP(mnk::stream_wait(s));
             if (mnk_ls_take_solve_abort(ls)) {
                 MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
                 MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
@@ -587,7 +593,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
         }
         MNK_HIP(hipMemcpyAsync(xk, w, N * sizeof(double),
                                loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-        if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+        if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(s));
     }
     return 0;
 }
@@ -595,7 +601,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n) {
     MNK_REQUIRE(ls && out && ls->solve_trace.p, "mnk_ls_debug_solve_trace: tracing is off (option solve_trace)");
     MNK_HIP(hipSetDevice(ls->ctx->device));
-    MNK_HIP(hipStreamSynchronize(ls->ctx->stream));
+    MNK_HIP(mnk::stream_wait(ls->ctx->stream));
     const int64_t cnt = std::min<int64_t>(n, (ls->Np / 64) * 8);
     MNK_HIP(hipMemcpy(out, ls->solve_trace.p, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
@@ -610,7 +616,7 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
     MNK_HIP(hipMemcpy2DAsync(L, ls->N * sizeof(double), ls->fact.p, ls->ld * sizeof(double),
                              ls->N * sizeof(double), ls->N, kind, s));
     if (D) MNK_HIP(hipMemcpyAsync(D, ls->dvec.p, ls->N * sizeof(double), kind, s));
-    MNK_HIP(hipStreamSynchronize(s));
+    MNK_HIP(mnk::stream_wait(s));
     return 0;
 }
 
@@ -640,7 +646,7 @@ int mnk_ls_bk_info(mnk_ls* ls, int* active, int* count, int32_t* perm, double* d
         hipStream_t s = ls->ctx->stream;
         if (perm) MNK_HIP(hipMemcpyAsync(perm, ls->bk_perm.p, ls->N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         if (doff) MNK_HIP(hipMemcpyAsync(doff, ls->bk_doff.p, ls->N * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(hipStreamSynchronize(s));
+        MNK_HIP(mnk::stream_wait(s));
     }
     return 0;
 }
@@ -734,7 +740,7 @@ int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const doub
     MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
     MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
     MNK_HIP(hipEventRecord(e1, s));
-    MNK_HIP(hipStreamSynchronize(s));
+    MNK_HIP(mnk::stream_wait(s));
     float t = 0.f;
     MNK_HIP(hipEventElapsedTime(&t, e0, e1));
     *ms = (double)t;

@@ -134,7 +134,7 @@ int mnk_schur_create(mnk_ctx* ctx, int64_t ns_local, int64_t blk, int64_t nd, in
 int mnk_schur_destroy(mnk_schur* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->ctx->device);
-    (void)hipStreamSynchronize(h->ctx->stream);
+    (void)mnk::stream_wait(h->ctx->stream);
     for (mnk_ls* l : h->ls_k) mnk_ls_destroy(l);
     if (h->ls_s) mnk_ls_destroy(h->ls_s);
     mnk_ctx* ctx = h->ctx;
@@ -153,7 +153,7 @@ int mnk_schur_set_block(mnk_schur* h, int64_t k, const double* A_kk, int64_t lda
                              h->blk * sizeof(double), h->blk, kind, s));
     MNK_HIP(hipMemcpy2DAsync(h->C.p + k * h->nd * h->blk, h->nd * sizeof(double), C_dk, ldc * sizeof(double),
                              h->nd * sizeof(double), h->blk, kind, s));
-    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(s));
+    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(s));
     h->built = false;
     return 0;
 }

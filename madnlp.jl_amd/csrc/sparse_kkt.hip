@@ -332,7 +332,7 @@ int mnk_sc_destroy(mnk_sc* sc) {
     if (!sc) return 0;
     if (sc->ctx) {
         (void)hipSetDevice(sc->ctx->device);
-        (void)hipStreamSynchronize(sc->ctx->stream);
+        (void)mnk::stream_wait(sc->ctx->stream);
     }
     delete spmv_of(sc);
     sc->extra = nullptr;
@@ -384,7 +384,7 @@ static int stage_in(mnk_ctx* ctx, double* dev, const double* src, int64_t n, int
     if (loc == MNK_DEVICE) { *use = src; return 0; }
     if (n > 0) {
         MNK_HIP(hipMemcpyAsync(dev, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        MNK_HIP(hipStreamSynchronize(ctx->stream));  // caller's buffer is only valid for the duration of the call
+        MNK_HIP(mnk::stream_wait(ctx->stream));  // caller's buffer is only valid for the duration of the call
     }
     *use = dev;
     return 0;
@@ -459,7 +459,7 @@ int mnk_sc_get_values(mnk_sc* sc, int which, double* out, int loc) {
     if (cnt > 0)
         MNK_HIP(hipMemcpyAsync(out, src, cnt * sizeof(double),
                                loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, sc->ctx->stream));
-    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(sc->ctx->stream));
+    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(sc->ctx->stream));
     return 0;
 }
 
@@ -545,7 +545,7 @@ int mnk_sc_set_barrier_terms(mnk_sc* sc, const double* reg, const double* l_diag
     rc |= copy_in(sc->ctx, sp->l_lower.p, l_lower, sp->nlb, loc);
     rc |= copy_in(sc->ctx, sp->u_lower.p, u_lower, sp->nub, loc);
     if (rc) return rc;
-    if (loc != MNK_DEVICE) MNK_HIP(hipStreamSynchronize(sc->ctx->stream));  // the host arrays may change after return
+    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(sc->ctx->stream));  // the host arrays may change after return
     sp->have_terms = true;
     return 0;
 }
@@ -628,10 +628,10 @@ int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc) {
         if (nub > 0) hipLaunchKernelGGL(finish_aug_kernel, MNK_GRID(nub), wu, d, sp->ind_ub.p, sp->u_lower.p, sp->u_diag.p, nub, 1);
         MNK_HIP(hipGetLastError());
         if (loc == MNK_DEVICE) break;  // device-resident caller: mnk_ls_check_solve() reports an abort
-        MNK_HIP(hipStreamSynchronize(s));
+        MNK_HIP(mnk::stream_wait(s));
         if (attempt == 0 && mnk_ls_take_solve_abort(ls)) continue;  // redo with the stepwise solve
         MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(hipStreamSynchronize(s));
+        MNK_HIP(mnk::stream_wait(s));
         break;
     }
     return 0;
@@ -672,7 +672,7 @@ int mnk_sc_mul(mnk_sc* sc, double* w, const double* x, double alpha, double beta
     MNK_HIP(hipGetLastError());
     if (loc != MNK_DEVICE) {
         MNK_HIP(hipMemcpyAsync(w, dw, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(hipStreamSynchronize(s));
+        MNK_HIP(mnk::stream_wait(s));
     }
     return 0;
 }

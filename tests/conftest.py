@@ -1,3 +1,8 @@
+import os as _os
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    # the GPU boxes show 256 cpus behind a 16-CPU cgroup quota: BLAS pools sized after the visible count spin, the cgroup
+    # is throttled and the whole process (GPU-driving thread included) freezes for tens of ms at a time
+    _os.environ.setdefault(_v, "8")
 import os
 import sys
 

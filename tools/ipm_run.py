@@ -3,6 +3,8 @@ N = 11192 condensed KKT) through the host mirror of MadNLP's regular phase.  Rep
 factorizations and back-solves per iteration (the n_f, n_s of SURVEY 8(d)) and the wall-clock split."""
 import json
 import os
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
 import sys
 import time
 
