@@ -4,6 +4,8 @@ LapackCPUSolver calls) are timed at N = 11 192 and N = 22 384 on this host and e
 rate of the LARGEST measured size (labelled as an extrapolation).  usage: python tools/cpu_c4_table.py out.json"""
 import json
 import os
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
 import sys
 import time
 

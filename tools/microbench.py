@@ -2,6 +2,8 @@
 kernel rate, per-phase factorization time.  Run on the GPU box:
     python tools/microbench.py [N ...]"""
 import os
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
 import sys
 import time
 

@@ -1,6 +1,8 @@
 """Time the (b)-shaped trailing update under the schedules of the factorization (diagnostics)."""
 import ctypes as C
 import os
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
 import sys
 
 import torch

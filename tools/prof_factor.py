@@ -1,5 +1,7 @@
 """Run a few factorizations + solves of an N x N SPD matrix (for rocprofv3 --kernel-trace --stats)."""
 import os
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
 import sys
 
 import torch

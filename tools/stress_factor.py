@@ -2,6 +2,8 @@
 compiler problem made the persistent panel kernel return wrong pivots for ONE matrix in the whole suite).
 usage: python tools/stress_factor.py [count] [--fuse ROWS]"""
 import os
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
 import sys
 
 import numpy as np
