@@ -5,7 +5,7 @@ rate of the LARGEST measured size (labelled as an extrapolation).  us
 import json
 import os
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_v, "8")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
+    os.environ.setdefault(_v, "16")  # the pool's boxes cap the process at 16 CPUs: idle BLAS pools must not spin on 256
 import sys
 import time
 
