@@ -79,7 +79,7 @@ end
     lookahead::Bool = true
     share::Int = 1                  # 0 off / 1 adaptive / 2 always: panel-stream CUs join the trailing update
     persistent_solve::Bool = true   # both triangular sweeps in one launch
-    single_rows::Int = 4608         # systems up to this order: one outer panel on the whole chip
+    single_rows::Int = 2560         # systems up to this order: one outer panel on the whole chip
     panel_algo::Int = 4             # 4: persistent panel kernel (one launch per 256 columns; needs the panel CUs for
                                     # itself -- set 1 when several PROCESSES share the GPU); 1: one launch per piece
     bk_fallback::Bool = true        # BUNCHKAUFMAN: refactor with 1x1/2x2 Bunch-Kaufman pivoting when the static-pivot

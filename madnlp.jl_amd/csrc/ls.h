@@ -47,7 +47,7 @@ struct mnk_ls {
     int share = 1;         // look-ahead only: the panel stream's CUs join the trailing update through a tile queue
     int small_tiles = 400;  // (a)-updates with fewer 128x128 tiles than this use 64x64 workgroup tiles
     int split_a = 2;          // 1: next panel delivered in two pieces by the update stream; 2: its first 64 columns by the panel stream itself
-    int64_t single_rows = 4608;  // systems up to this (padded) order are factored as ONE outer panel on the whole chip
+    int64_t single_rows = 2560;  // systems up to this (padded) order are factored as ONE outer panel on the whole chip (with the fused tail panels the look-ahead schedule wins from N = 3072 on: 2.12 vs 2.34 ms at 4096)
     int64_t tail_rows = 4096; // outer panels are tail_nbo wide once this many rows (or fewer) remain: one persistent launch per panel with the fused prologue, no inner update (C3: 11.80 -> 11.71 ms; 0 disables)
     int64_t tail_nbo = 256;
     int small_tiles_mid = 1000;  // same for the middle-level update inside an outer panel

@@ -117,7 +117,7 @@ class HipSolverOptions:
     share: int = 1          # 0 off, 1 adaptive, 2 always: panel-stream CUs join the trailing update
     small_tiles: int = 400  # (a)-updates with fewer 128x128 tiles use 64x64 workgroup tiles
     persistent_solve: bool = True  # both triangular sweeps in one launch (False: one launch per 256-column step)
-    single_rows: int = 4608  # systems up to this order are factored as one outer panel on the whole chip (0: never)
+    single_rows: int = 2560  # systems up to this order are factored as one outer panel on the whole chip (0: never)
     panel_algo: int = 4      # 4: persistent panel kernel (needs the panel CUs for itself: set 1 when several PROCESSES
                              # share the GPU); 1: one launch per piece of a 64-column block
 

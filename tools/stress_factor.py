@@ -37,7 +37,7 @@ def main():
             A[n1:, n1:] *= -1.0
         ob = int(rng.choice([256, 512]))
         M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, outer_block=ob))
-        if N > 4608 or it % 3 == 0:
+        if N > 2560 or it % 3 == 0:
             M.set_option("single_rows", 0)  # exercise the look-ahead schedule on small systems too
         if fuse is not None:
             M.set_option("pp_fuse_rows", fuse)
