@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT/gpurun_out/prof_r02
 [ -z "$SKIP_BENCH" ] && rm -rf $R; mkdir -p $R
 cd /tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-ipm-loop"
 timeout 300 rocprofv3 --kernel-trace -d $R/bench -o p -- $B --steps 10 --warmup 2 > $R/bench_under_rocprof.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o p -- $B --steps 2 --warmup 1 > $R/fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o p -- $B --steps 2 --warmup 1 > $R/write.log 2>&1
