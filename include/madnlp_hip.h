@@ -311,6 +311,79 @@ int mnk_ipm_adjust_boundary(mnk_ipm* ipm, const double* x, double* xl, double* x
 int mnk_ipm_reset_bound_dual(mnk_ipm* ipm, double* zl, double* zu, const double* x, const double* xl, const double* xu,
                              double mu, double kappa_sigma);
 
+/* ---- restoration phase (robust restorer) on device-resident vectors (third slice) -------------------------
+ * Reference src/IPM/kernels.jl:390-636 (GPU twins lib/MadNLPGPU/src/IPM/kernels.jl:117-462).  pp / nn / zp / zn / dpp / dnn /
+ * dzp / dzn, c, l (= y) and dl are m-vectors (the RobustRestorer of src/IPM/restoration.jl:1-37 and the constraint block),
+ * f_R / D_R / x_ref and x, xl, xu, zl, zu, jacl, dx full primal length; dzl / dzu bound-length blocks of a KKT vector.
+ * Same conventions as the regular-phase reductions above (one synchronizing call per reference function). */
+int mnk_ipm_get_obj_val_R(mnk_ipm* ipm, const double* p, const double* n, int64_t m, const double* D_R, const double* x,
+                          const double* x_ref, double rho, double zeta, double* out);   /* kernels.jl:390-407 */
+int mnk_ipm_get_theta_R(mnk_ipm* ipm, const double* c, const double* p, const double* n, int64_t m, double* out); /* :411-421 */
+int mnk_ipm_get_inf_pr_R(mnk_ipm* ipm, const double* c, const double* p, const double* n, int64_t m, double* out); /* :423-433 */
+int mnk_ipm_get_inf_du_R(mnk_ipm* ipm, const double* f_R, const double* l, const double* zl, const double* zu,
+                         const double* jacl, const double* zp, const double* zn, int64_t m, double rho, double sd,
+                         double* out);                                                  /* :435-454 */
+int mnk_ipm_get_inf_compl_R(mnk_ipm* ipm, const double* x, const double* xl, const double* xu, const double* zl,
+                            const double* zu, const double* pp, const double* zp, const double* nn, const double* zn,
+                            int64_t m, double mu_R, double sc, double* out);            /* :456-484 */
+int mnk_ipm_get_alpha_max_R(mnk_ipm* ipm, const double* x, const double* xl, const double* xu, const double* dx,
+                            const double* pp, const double* dpp, const double* nn, const double* dnn, int64_t m,
+                            double tau_R, double* out);                                 /* :486-515 */
+int mnk_ipm_get_alpha_z_R(mnk_ipm* ipm, const double* zl, const double* zu, const double* dzl, const double* dzu,
+                          const double* zp, const double* dzp, const double* zn, const double* dzn, int64_t m,
+                          double tau_R, double* out);                                   /* :517-542 */
+int mnk_ipm_get_varphi_R(mnk_ipm* ipm, double obj_val, const double* x, const double* xl, const double* xu, const double* pp,
+                         const double* nn, int64_t m, double mu_R, double* out);        /* :544-570 */
+/* get_F (soft restoration, :572-610).  The upper-bound term is the reference's own expression |(xu_r - xu_r) zu_r - mu|
+ * (:606, the same in the GPU twin :407-410), restated as written */
+int mnk_ipm_get_F(mnk_ipm* ipm, const double* c, int64_t m, const double* f, const double* zl, const double* zu,
+                  const double* jacl, const double* x, const double* xl, const double* xu, double mu, double* out);
+int mnk_ipm_get_varphi_d_R(mnk_ipm* ipm, const double* f_R, const double* x, const double* xl, const double* xu,
+                           const double* dx, const double* pp, const double* nn, const double* dpp, const double* dnn,
+                           int64_t m, double mu_R, double rho, double* out);            /* :612-636 */
+/* Elementwise pieces (asynchronous on the context's stream):
+ *   mnk_ipm_populate_RR_nn              populate_RR_nn!  :825-829
+ *   mnk_ipm_initialize_robust_restorer  vector part of initialize_robust_restorer!  src/IPM/restoration.jl:46-70:
+ *                                       x_ref = x, D_R = min(1, 1/|x_ref|), nn, pp = c + nn, zp = mu_R/pp, zn = mu_R/nn,
+ *                                       zl_r / zu_r = min(rho, .) in place in the full-length zl / zu
+ *   mnk_ipm_set_f_RR                    set_f_RR!  :106-110
+ *   mnk_ipm_set_aug_rhs_RR              set_aug_rhs_RR!  :133-158
+ *   mnk_ipm_finish_aug_solve_RR         finish_aug_solve_RR!  :251-257
+ *   mnk_ipm_reset_bound_dual_1          reset_bound_dual!(z, x, mu, kappa_sigma)  :775-786
+ *   mnk_ipm_set_initial_bounds          set_initial_bounds!  :206-218
+ *   mnk_ipm_set_initial_rhs             set_initial_rhs!  :220-230
+ *   mnk_ipm_set_aug_rhs_ifr             set_aug_rhs_ifr!  :233-240
+ *   mnk_ipm_set_g_ifr                   set_g_ifr!  :242-248
+ *   mnk_ipm_initialize_variables        initialize_variables!  :638-654 (in place)
+ *   mnk_sc_set_aug_RR / mnk_dc_set_aug_RR   set_aug_RR!  :72-87 + _set_aug_diagonal!  :22-27 inside the KKT handle */
+int mnk_ipm_populate_RR_nn(mnk_ipm* ipm, double* nn, const double* c, int64_t m, double mu, double rho);
+int mnk_ipm_initialize_robust_restorer(mnk_ipm* ipm, const double* x, const double* c, int64_t m, double mu_R, double rho,
+                                       double* x_ref, double* D_R, double* nn, double* pp, double* zp, double* zn,
+                                       double* zl, double* zu);
+int mnk_ipm_set_f_RR(mnk_ipm* ipm, double* f_R, const double* D_R, const double* x, const double* x_ref, double zeta);
+int mnk_ipm_set_aug_rhs_RR(mnk_ipm* ipm, const double* f_R, const double* zl, const double* zu, const double* jacl,
+                           const double* c, const double* y, const double* pp, const double* nn, const double* zp,
+                           const double* zn, int64_t m, const double* x, const double* xl, const double* xu, double mu_R,
+                           double rho, double* px, double* py, double* pzl, double* pzu);
+int mnk_ipm_finish_aug_solve_RR(mnk_ipm* ipm, double* dpp, double* dnn, double* dzp, double* dzn, const double* l,
+                                const double* dl, const double* pp, const double* nn, const double* zp, const double* zn,
+                                int64_t m, double mu_R, double rho);
+int mnk_ipm_reset_bound_dual_1(mnk_ipm* ipm, double* z, const double* x, int64_t n, double mu, double kappa_sigma);
+int mnk_ipm_set_initial_bounds(mnk_ipm* ipm, double* xl, double* xu, int64_t n, double tol);
+int mnk_ipm_set_initial_rhs(mnk_ipm* ipm, const double* f, const double* zl, const double* zu, double* px, double* py,
+                            int64_t m, double* pzl, double* pzu);
+int mnk_ipm_set_aug_rhs_ifr(mnk_ipm* ipm, const double* c, int64_t m, double* px, double* py, double* pzl, double* pzu);
+int mnk_ipm_set_g_ifr(mnk_ipm* ipm, double* g, const double* f, const double* x, const double* xl, const double* xu,
+                      const double* jacl, double mu);
+int mnk_ipm_initialize_variables(mnk_ipm* ipm, double* x, const double* xl, const double* xu, int64_t n, double bound_push,
+                                 double bound_fac);
+int mnk_sc_set_aug_RR(mnk_sc* sc, const double* x, const double* xl, const double* xu, const double* zl, const double* zu,
+                      const double* D_R, const double* pp, const double* zp, const double* nn, const double* zn, double zeta,
+                      double primal_reg, double dual_reg);
+int mnk_dc_set_aug_RR(mnk_dc* dc, const double* x, const double* xl, const double* xu, const double* zl, const double* zu,
+                      const double* D_R, const double* pp, const double* zp, const double* nn, const double* zn, double zeta,
+                      double primal_reg, double dual_reg);
+
 /* ---- dense S stage of the Schur-complement KKT system ----------------------------------------------
  * Reference: `SchurComplementKKTSystem` src/KKT/Schur/schur.jl -- `build_kkt!` :927-1001 (phase 1: factor every
  * scenario block A_k and form A_k^-1 C_dk'; phase 2: S -= C_dk A_k^-1 C_dk'), `factorize_kkt!` :1003-1005, steps 3-5 of

@@ -141,6 +141,29 @@ SIGNATURES = {
     "mnk_ipm_dual_inf_perturbation": (C.c_int, [_vp, _vp, C.c_double, C.c_double]),
     "mnk_ipm_adjust_boundary": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double]),
     "mnk_ipm_reset_bound_dual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double]),
+    "mnk_ipm_get_obj_val_R": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_theta_R": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_inf_pr_R": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_inf_du_R": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_inf_compl_R": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_alpha_max_R": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_alpha_z_R": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_varphi_R": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_F": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_varphi_d_R": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+    "mnk_ipm_populate_RR_nn": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double]),
+    "mnk_ipm_initialize_robust_restorer": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mnk_ipm_set_f_RR": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double]),
+    "mnk_ipm_set_aug_rhs_RR": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
+    "mnk_ipm_finish_aug_solve_RR": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.c_double]),
+    "mnk_ipm_reset_bound_dual_1": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double, C.c_double]),
+    "mnk_ipm_set_initial_bounds": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_double]),
+    "mnk_ipm_set_initial_rhs": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "mnk_ipm_set_aug_rhs_ifr": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
+    "mnk_ipm_set_g_ifr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double]),
+    "mnk_ipm_initialize_variables": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.c_double]),
+    "mnk_sc_set_aug_RR": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double]),
+    "mnk_dc_set_aug_RR": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double]),
     "mnk_ls_bk_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp]),
     "mnk_ls_get_stat": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "mnk_sc_set_bounds": (C.c_int, [_vp, C.c_int64, _vp, C.c_int64, _vp, C.c_int]),

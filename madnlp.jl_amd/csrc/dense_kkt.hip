@@ -449,6 +449,20 @@ int mnk_dc_set_aug_diagonal(mnk_dc* dc, const double* x, const double* xl, const
     return 0;
 }
 
+// set_aug_RR!(kkt, solver, RR) (reference src/IPM/kernels.jl:72-87): device-resident vectors only
+int mnk_dc_set_aug_RR(mnk_dc* dc, const double* x, const double* xl, const double* xu, const double* zl, const double* zu,
+                      const double* D_R, const double* pp, const double* zp, const double* nn, const double* zn, double zeta,
+                      double primal_reg, double dual_reg) {
+    AugDiagView v;
+    int rc = dc_diag_view(dc, v, "mnk_dc_set_aug_RR");
+    if (rc) return rc;
+    MNK_REQUIRE(x && xl && xu && zl && zu && D_R && (v.ndu == 0 || (pp && zp && nn && zn)), "mnk_dc_set_aug_RR: NULL vector");
+    rc = kkt_set_aug_RR(v, x, xl, xu, zl, zu, D_R, pp, zp, nn, zn, zeta, primal_reg, dual_reg);
+    if (rc) return rc;
+    extra_of(dc)->have_terms = extra_of(dc)->have_diag = true;
+    return 0;
+}
+
 int mnk_dc_regularize_diagonal(mnk_dc* dc, double primal, double dual) {
     AugDiagView v;
     int rc = dc_diag_view(dc, v, "mnk_dc_regularize_diagonal");

@@ -17,15 +17,15 @@ struct mnk_ipm {
     int64_t ntot = 0, nlb = 0, nub = 0;
     int64_t nllb = 0, nuub = 0;
     DevBuf<int64_t> ind_lb, ind_ub, ind_llb, ind_uub;
-    DevBuf<double> part;   // 2 x IPM_BLOCKS partials
-    DevBuf<double> res;    // 2 results
-    double* pin = nullptr;     // 2 pinned, device-mapped host words: the final reduction stores its result here
+    DevBuf<double> part;   // IPM_SLOTS x IPM_BLOCKS partials
+    double* pin = nullptr;     // IPM_SLOTS pinned, device-mapped host words: the final reduction stores its result here
     double* pin_dev = nullptr;
 };
 
 namespace {
 
 constexpr int IPM_BLOCKS = 256;
+constexpr int IPM_SLOTS = 4;   // reductions in flight per call (the restoration-phase functions have up to four terms)
 constexpr int IPM_THREADS = 256;
 enum { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
 
@@ -177,9 +177,8 @@ int mnk_ipm_create(mnk_ctx* ctx, int64_t ntot, int64_t nlb, const int64_t* ind_l
     mnk_ipm* h = new mnk_ipm();
     h->ctx = ctx;
     h->ntot = ntot; h->nlb = nlb; h->nub = nub;
-    int rc = h->ind_lb.upload(lb, ctx->stream) | h->ind_ub.upload(ub, ctx->stream) | h->part.alloc(2 * IPM_BLOCKS) |
-             h->res.alloc(2);
-    if (!rc && (hipHostMalloc((void**)&h->pin, 2 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+    int rc = h->ind_lb.upload(lb, ctx->stream) | h->ind_ub.upload(ub, ctx->stream) | h->part.alloc(IPM_SLOTS * IPM_BLOCKS);
+    if (!rc && (hipHostMalloc((void**)&h->pin, IPM_SLOTS * sizeof(double), hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer((void**)&h->pin_dev, h->pin, 0) != hipSuccess)) {
         (void)hipGetLastError();
         rc = -2;
@@ -468,6 +467,436 @@ int mnk_ipm_reset_bound_dual(mnk_ipm* h, double* zl, double* zu, const double* x
     hipLaunchKernelGGL(reset_bound_dual_kernel, IPM_G(h->ntot), zu, xu, x, kappa_sigma * mu, mu / kappa_sigma, h->ntot);
     MNK_HIP(hipGetLastError());
     return 0;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Restoration phase (robust restorer), SURVEY 8(f).4 third slice: reference src/IPM/kernels.jl:390-636 (GPU twins
+// lib/MadNLPGPU/src/IPM/kernels.jl:117-462), the elementwise pieces :72-110,133-158,206-257,638-654,775-786,825-829 and the
+// vector part of initialize_robust_restorer! (src/IPM/restoration.jl:39-76).  pp / nn / zp / zn / dpp / ... are the
+// m-vectors of the RobustRestorer, everything else is full primal length (ntot) unless noted.
+// =====================================================================================================================
+namespace {
+
+struct FObjPN {  // rho (p + n)
+    const double *p, *n; double rho;
+    __device__ double operator()(int64_t i) const { return rho * (p[i] + n[i]); }
+};
+struct FObjProx {  // zeta/2 D_R^2 (x - x_ref)^2
+    const double *D, *x, *xr; double zeta;
+    __device__ double operator()(int64_t i) const {
+        const double d = x[i] - xr[i];
+        return zeta / 2 * (D[i] * D[i]) * (d * d);
+    }
+};
+struct FCPN {  // |c - p + n|
+    const double *c, *p, *n;
+    __device__ double operator()(int64_t i) const { return fabs(c[i] - p[i] + n[i]); }
+};
+struct FRhoL {  // |rho - l - zp| (plus = 0) / |rho + l - zn| (plus = 1)
+    const double *l, *z; double rho; int plus;
+    __device__ double operator()(int64_t i) const { return plus ? fabs(rho + l[i] - z[i]) : fabs(rho - l[i] - z[i]); }
+};
+struct FProdMu {  // |a z - mu|
+    const double *a, *z; double mu;
+    __device__ double operator()(int64_t i) const { return fabs(a[i] * z[i] - mu); }
+};
+struct FStepRatio {  // dv < 0 ? -v tau / dv : Inf
+    const double *v, *dv; double tau;
+    __device__ double operator()(int64_t i) const { return dv[i] < 0 ? (-v[i]) * tau / dv[i] : INFINITY; }
+};
+struct FLogBar {  // d = x_lr - xl_r (upper = 0) / xu_r - x_ur (upper = 1): d < 0 ? Inf : mu log(d)
+    const double *x, *xb; const int64_t* ind; double mu; int upper;
+    __device__ double operator()(int64_t i) const {
+        const int64_t p = ind[i];
+        const double d = upper ? xb[p] - x[p] : x[p] - xb[p];
+        return d < 0 ? INFINITY : mu * log(d);
+    }
+};
+struct FLog1 {  // v < 0 ? Inf : mu log(v)
+    const double* v; double mu;
+    __device__ double operator()(int64_t i) const { return v[i] < 0 ? INFINITY : mu * log(v[i]); }
+};
+struct FSumDu {  // |f - zl + zu + jacl| (summed by get_F)
+    const double *f, *zl, *zu, *jacl;
+    __device__ double operator()(int64_t i) const { return fabs(f[i] - zl[i] + zu[i] + jacl[i]); }
+};
+// get_F (:572-610): lower side (x_lr >= xl_r && zl_r >= 0) ? |(x_lr - xl_r) zl_r - mu| : Inf; the upper side is restated
+// as the reference computes it, |(xu_r - xu_r) zu_r - mu| under the guard (xu_r >= x_ur && zu_r >= 0) (:606)
+struct FFBound {
+    const double *x, *xb, *z; const int64_t* ind; double mu; int upper;
+    __device__ double operator()(int64_t i) const {
+        const int64_t p = ind[i];
+        if (upper) return (xb[p] >= x[p] && z[p] >= 0) ? fabs((xb[p] - xb[p]) * z[p] - mu) : INFINITY;
+        return (x[p] >= xb[p] && z[p] >= 0) ? fabs((x[p] - xb[p]) * z[p] - mu) : INFINITY;
+    }
+};
+struct FRhoMu {  // (rho - mu / v) dv
+    const double *v, *dv; double mu, rho;
+    __device__ double operator()(int64_t i) const { return (rho - mu / v[i]) * dv[i]; }
+};
+
+inline double nanmax(double a, double b) { return (a != a || b != b) ? NAN : fmax(a, b); }
+inline double nanmin(double a, double b) { return (a != a || b != b) ? NAN : fmin(a, b); }
+
+}  // namespace
+
+extern "C" {
+
+#define IPM_M(who) MNK_REQUIRE(m >= 0, who ": bad size")
+
+int mnk_ipm_get_obj_val_R(mnk_ipm* h, const double* p, const double* n, int64_t m, const double* D_R, const double* x,
+                          const double* x_ref, double rho, double zeta, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_obj_val_R");
+    IPM_M("mnk_ipm_get_obj_val_R");
+    int rc = enqueue<R_SUM>(h, FObjPN{p, n, rho}, m, 0) | enqueue<R_SUM>(h, FObjProx{D_R, x, x_ref, zeta}, h->ntot, 1);
+    if (rc) return rc;
+    double r[2];
+    rc = fetch(h, 2, r);
+    if (rc) return rc;
+    *out = r[0] + r[1];
+    return 0;
+}
+
+int mnk_ipm_get_theta_R(mnk_ipm* h, const double* c, const double* p, const double* n, int64_t m, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_theta_R");
+    IPM_M("mnk_ipm_get_theta_R");
+    int rc = enqueue<R_SUM>(h, FCPN{c, p, n}, m, 0);
+    if (rc) return rc;
+    return fetch(h, 1, out);
+}
+
+int mnk_ipm_get_inf_pr_R(mnk_ipm* h, const double* c, const double* p, const double* n, int64_t m, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_inf_pr_R");
+    IPM_M("mnk_ipm_get_inf_pr_R");
+    int rc = enqueue<R_MAX>(h, FCPN{c, p, n}, m, 0);
+    if (rc) return rc;
+    double r;
+    rc = fetch(h, 1, &r);
+    if (rc) return rc;
+    *out = max0(r);
+    return 0;
+}
+
+int mnk_ipm_get_inf_du_R(mnk_ipm* h, const double* f_R, const double* l, const double* zl, const double* zu,
+                         const double* jacl, const double* zp, const double* zn, int64_t m, double rho, double sd,
+                         double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_inf_du_R");
+    IPM_M("mnk_ipm_get_inf_du_R");
+    int rc = enqueue<R_MAX>(h, FInfDu{f_R, zl, zu, jacl}, h->ntot, 0) | enqueue<R_MAX>(h, FRhoL{l, zp, rho, 0}, m, 1) |
+             enqueue<R_MAX>(h, FRhoL{l, zn, rho, 1}, m, 2);
+    if (rc) return rc;
+    double r[3];
+    rc = fetch(h, 3, r);
+    if (rc) return rc;
+    *out = nanmax(0.0, nanmax(r[0], nanmax(r[1], r[2]))) / sd;
+    return 0;
+}
+
+int mnk_ipm_get_inf_compl_R(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
+                            const double* zu, const double* pp, const double* zp, const double* nn, const double* zn,
+                            int64_t m, double mu_R, double sc, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_inf_compl_R");
+    IPM_M("mnk_ipm_get_inf_compl_R");
+    int rc = enqueue<R_MAX>(h, FCompl{x, xl, zl, h->ind_lb.p, mu_R, 0, 1}, h->nlb, 0) |
+             enqueue<R_MAX>(h, FCompl{x, xu, zu, h->ind_ub.p, mu_R, 1, 1}, h->nub, 1) |
+             enqueue<R_MAX>(h, FProdMu{pp, zp, mu_R}, m, 2) | enqueue<R_MAX>(h, FProdMu{nn, zn, mu_R}, m, 3);
+    if (rc) return rc;
+    double r[4];
+    rc = fetch(h, 4, r);
+    if (rc) return rc;
+    *out = nanmax(0.0, nanmax(nanmax(r[0], r[1]), nanmax(r[2], r[3]))) / sc;
+    return 0;
+}
+
+int mnk_ipm_get_alpha_max_R(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* dx,
+                            const double* pp, const double* dpp, const double* nn, const double* dnn, int64_t m,
+                            double tau_R, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_alpha_max_R");
+    IPM_M("mnk_ipm_get_alpha_max_R");
+    int rc = enqueue<R_MIN>(h, FAlphaMax{x, xl, xu, dx, tau_R}, h->ntot, 0) |
+             enqueue<R_MIN>(h, FStepRatio{pp, dpp, tau_R}, m, 1) | enqueue<R_MIN>(h, FStepRatio{nn, dnn, tau_R}, m, 2);
+    if (rc) return rc;
+    double r[3];
+    rc = fetch(h, 3, r);
+    if (rc) return rc;
+    *out = nanmin(1.0, nanmin(r[0], nanmin(r[1], r[2])));
+    return 0;
+}
+
+int mnk_ipm_get_alpha_z_R(mnk_ipm* h, const double* zl, const double* zu, const double* dzl, const double* dzu,
+                          const double* zp, const double* dzp, const double* zn, const double* dzn, int64_t m,
+                          double tau_R, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_alpha_z_R");
+    IPM_M("mnk_ipm_get_alpha_z_R");
+    int rc = enqueue<R_MIN>(h, FAlphaZ{zl, dzl, h->ind_lb.p, tau_R}, h->nlb, 0) |
+             enqueue<R_MIN>(h, FAlphaZ{zu, dzu, h->ind_ub.p, tau_R}, h->nub, 1) |
+             enqueue<R_MIN>(h, FStepRatio{zp, dzp, tau_R}, m, 2) | enqueue<R_MIN>(h, FStepRatio{zn, dzn, tau_R}, m, 3);
+    if (rc) return rc;
+    double r[4];
+    rc = fetch(h, 4, r);
+    if (rc) return rc;
+    *out = nanmin(1.0, nanmin(nanmin(r[0], r[1]), nanmin(r[2], r[3])));
+    return 0;
+}
+
+int mnk_ipm_get_varphi_R(mnk_ipm* h, double obj_val, const double* x, const double* xl, const double* xu, const double* pp,
+                         const double* nn, int64_t m, double mu_R, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_varphi_R");
+    IPM_M("mnk_ipm_get_varphi_R");
+    int rc = enqueue<R_SUM>(h, FLogBar{x, xl, h->ind_lb.p, mu_R, 0}, h->nlb, 0) |
+             enqueue<R_SUM>(h, FLogBar{x, xu, h->ind_ub.p, mu_R, 1}, h->nub, 1) | enqueue<R_SUM>(h, FLog1{pp, mu_R}, m, 2) |
+             enqueue<R_SUM>(h, FLog1{nn, mu_R}, m, 3);
+    if (rc) return rc;
+    double r[4];
+    rc = fetch(h, 4, r);
+    if (rc) return rc;
+    *out = obj_val - (r[0] + r[1] + r[2] + r[3]);
+    return 0;
+}
+
+int mnk_ipm_get_F(mnk_ipm* h, const double* c, int64_t m, const double* f, const double* zl, const double* zu,
+                  const double* jacl, const double* x, const double* xl, const double* xu, double mu, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_F");
+    IPM_M("mnk_ipm_get_F");
+    int rc = enqueue<R_SUM>(h, FAbs{c, nullptr}, m, 0) | enqueue<R_SUM>(h, FSumDu{f, zl, zu, jacl}, h->ntot, 1) |
+             enqueue<R_SUM>(h, FFBound{x, xl, zl, h->ind_lb.p, mu, 0}, h->nlb, 2) |
+             enqueue<R_SUM>(h, FFBound{x, xu, zu, h->ind_ub.p, mu, 1}, h->nub, 3);
+    if (rc) return rc;
+    double r[4];
+    rc = fetch(h, 4, r);
+    if (rc) return rc;
+    *out = r[0] + r[1] + r[2] + r[3];
+    return 0;
+}
+
+int mnk_ipm_get_varphi_d_R(mnk_ipm* h, const double* f_R, const double* x, const double* xl, const double* xu,
+                           const double* dx, const double* pp, const double* nn, const double* dpp, const double* dnn,
+                           int64_t m, double mu_R, double rho, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_varphi_d_R");
+    IPM_M("mnk_ipm_get_varphi_d_R");
+    int rc = enqueue<R_SUM>(h, FVarphiD{f_R, x, xl, xu, dx, mu_R}, h->ntot, 0) |
+             enqueue<R_SUM>(h, FRhoMu{pp, dpp, mu_R, rho}, m, 1) | enqueue<R_SUM>(h, FRhoMu{nn, dnn, mu_R, rho}, m, 2);
+    if (rc) return rc;
+    double r[3];
+    rc = fetch(h, 3, r);
+    if (rc) return rc;
+    *out = r[0] + r[1] + r[2];
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- elementwise pieces of the restoration phase ----------------------------------------------------------------------
+namespace {
+#define IPM_IDX(cnt) const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; if (i >= (cnt)) return
+
+// populate_RR_nn! (:825-829): nn = t + sqrt(t^2 + mu c / (2 rho)), t = (mu - rho c) / (2 rho)
+__global__ void populate_nn_kernel(double* __restrict__ nn, const double* __restrict__ c, double mu, double rho, int64_t m) {
+    IPM_IDX(m);
+    const double t = (mu - rho * c[i]) / (2 * rho);
+    nn[i] = t + sqrt(t * t + mu * c[i] / (2 * rho));
+}
+// initialize_robust_restorer! (restoration.jl:46-53): x_ref = x, D_R = min(1, 1 / |x_ref|)
+__global__ void rr_ref_kernel(double* __restrict__ x_ref, double* __restrict__ D_R, const double* __restrict__ x, int64_t n) {
+    IPM_IDX(n);
+    const double v = x[i];
+    x_ref[i] = v;
+    D_R[i] = jl_min(1.0, 1.0 / fabs(v));
+}
+// (:59-62): populate_RR_nn!, pp = c + nn, zp = mu_R / pp, zn = mu_R / nn
+__global__ void rr_slack_kernel(double* __restrict__ nn, double* __restrict__ pp, double* __restrict__ zp,
+                                double* __restrict__ zn, const double* __restrict__ c, double mu, double rho, int64_t m) {
+    IPM_IDX(m);
+    const double t = (mu - rho * c[i]) / (2 * rho);
+    const double nv = t + sqrt(t * t + mu * c[i] / (2 * rho));
+    const double pv = c[i] + nv;
+    nn[i] = nv;
+    pp[i] = pv;
+    zp[i] = mu / pv;
+    zn[i] = mu / nv;
+}
+// (:69-70): z_r = min(rho, z_r) through the index set
+__global__ void cap_gather_kernel(double* __restrict__ z, const int64_t* __restrict__ ind, double rho, int64_t nb) {
+    IPM_IDX(nb);
+    const int64_t p = ind[i];
+    z[p] = jl_min(rho, z[p]);
+}
+// set_f_RR! (:106-110): f_R = zeta D_R^2 (x - x_ref)
+__global__ void f_rr_kernel(double* __restrict__ f_R, const double* __restrict__ D, const double* __restrict__ x,
+                            const double* __restrict__ xr, double zeta, int64_t n) {
+    IPM_IDX(n);
+    f_R[i] = zeta * (D[i] * D[i]) * (x[i] - xr[i]);
+}
+// set_aug_rhs_RR! (:133-158), py = -c + pp - nn + (mu - (rho - y) pp) / zp - (mu - (rho + y) nn) / zn
+__global__ void aug_rhs_rr_dual_kernel(double* __restrict__ py, const double* __restrict__ c, const double* __restrict__ y,
+                                       const double* __restrict__ pp, const double* __restrict__ nn,
+                                       const double* __restrict__ zp, const double* __restrict__ zn, double mu, double rho,
+                                       int64_t m) {
+    IPM_IDX(m);
+    py[i] = -c[i] + pp[i] - nn[i] + (mu - (rho - y[i]) * pp[i]) / zp[i] - (mu - (rho + y[i]) * nn[i]) / zn[i];
+}
+// finish_aug_solve_RR! (:251-257)
+__global__ void finish_rr_kernel(double* __restrict__ dpp, double* __restrict__ dnn, double* __restrict__ dzp,
+                                 double* __restrict__ dzn, const double* __restrict__ l, const double* __restrict__ dl,
+                                 const double* __restrict__ pp, const double* __restrict__ nn, const double* __restrict__ zp,
+                                 const double* __restrict__ zn, double mu, double rho, int64_t m) {
+    IPM_IDX(m);
+    const double a = rho - l[i] - dl[i] - zp[i];
+    const double b = rho + l[i] + dl[i] - zn[i];
+    dzp[i] = a;
+    dzn[i] = b;
+    dpp[i] = -pp[i] + mu / zp[i] - (pp[i] / zp[i]) * a;
+    dnn[i] = -nn[i] + mu / zn[i] - (nn[i] / zn[i]) * b;
+}
+// reset_bound_dual!(z, x, mu, kappa_sigma) (:775-786)
+__global__ void reset_bound_dual1_kernel(double* __restrict__ z, const double* __restrict__ x, double ksmu, double muks,
+                                         int64_t n) {
+    IPM_IDX(n);
+    z[i] = jl_max(jl_min(z[i], ksmu / x[i]), muks / x[i]);
+}
+// set_initial_bounds! (:206-218)
+__global__ void initial_bounds_kernel(double* __restrict__ xl, double* __restrict__ xu, double tol, int64_t n) {
+    IPM_IDX(n);
+    const double l = xl[i], u = xu[i];
+    xl[i] = l - jl_max(1.0, fabs(l)) * tol;
+    xu[i] = u + jl_max(1.0, fabs(u)) * tol;
+}
+// set_initial_rhs! (:220-230): px = -f + zl - zu
+__global__ void initial_rhs_kernel(double* __restrict__ px, const double* __restrict__ f, const double* __restrict__ zl,
+                                   const double* __restrict__ zu, int64_t n) {
+    IPM_IDX(n);
+    px[i] = -f[i] + zl[i] - zu[i];
+}
+__global__ void zero_kernel(double* __restrict__ v, int64_t n) {
+    IPM_IDX(n);
+    v[i] = 0.0;
+}
+// set_g_ifr! (:242-248): g = f - mu / (x - xl) + mu / (xu - x) + jacl
+__global__ void g_ifr_kernel(double* __restrict__ g, const double* __restrict__ f, const double* __restrict__ x,
+                             const double* __restrict__ xl, const double* __restrict__ xu, const double* __restrict__ jacl,
+                             double mu, int64_t n) {
+    IPM_IDX(n);
+    g[i] = f[i] - mu / (x[i] - xl[i]) + mu / (xu[i] - x[i]) + jacl[i];
+}
+// _initialize_variables! (:638-650)
+__global__ void initialize_variables_kernel(double* __restrict__ x, const double* __restrict__ xl,
+                                            const double* __restrict__ xu, double bound_push, double bound_fac, int64_t n) {
+    IPM_IDX(n);
+    const double l = xl[i], u = xu[i], v = x[i];
+    const bool hl = l != -INFINITY, hu = u != INFINITY;
+    if (hl && hu)
+        x[i] = jl_min(u - jl_min(bound_push * jl_max(1.0, fabs(u)), bound_fac * (u - l)),
+                      jl_max(l + jl_min(bound_push * jl_max(1.0, fabs(l)), bound_fac * (u - l)), v));
+    else if (hl && !hu)
+        x[i] = jl_max(l + bound_push * jl_max(1.0, fabs(l)), v);
+    else if (!hl && hu)
+        x[i] = jl_min(u - bound_push * jl_max(1.0, fabs(u)), v);
+}
+}  // namespace
+
+extern "C" {
+
+#define IPM_VOID_ENTER(cond, who)                   \
+    MNK_REQUIRE(h != nullptr && (cond), who ": bad argument"); \
+    MNK_HIP(hipSetDevice(h->ctx->device))
+#define IPM_DONE() MNK_HIP(hipGetLastError()); return 0
+
+int mnk_ipm_populate_RR_nn(mnk_ipm* h, double* nn, const double* c, int64_t m, double mu, double rho) {
+    IPM_VOID_ENTER(m >= 0 && (m == 0 || (nn && c)), "mnk_ipm_populate_RR_nn");
+    if (m > 0) hipLaunchKernelGGL(populate_nn_kernel, IPM_G(m), nn, c, mu, rho, m);
+    IPM_DONE();
+}
+
+/* vector part of initialize_robust_restorer!: x_ref, D_R from x; nn, pp, zp, zn from c (mu_R, rho given by the caller,
+ * mu_R = max(mu, norm(c, Inf)) through mnk_ipm_get_norms); zl_r / zu_r capped at rho in the full-length zl / zu */
+int mnk_ipm_initialize_robust_restorer(mnk_ipm* h, const double* x, const double* c, int64_t m, double mu_R, double rho,
+                                       double* x_ref, double* D_R, double* nn, double* pp, double* zp, double* zn,
+                                       double* zl, double* zu) {
+    IPM_VOID_ENTER(m >= 0 && x && x_ref && D_R && zl && zu && (m == 0 || (c && nn && pp && zp && zn)),
+                   "mnk_ipm_initialize_robust_restorer");
+    hipLaunchKernelGGL(rr_ref_kernel, IPM_G(h->ntot), x_ref, D_R, x, h->ntot);
+    if (m > 0) hipLaunchKernelGGL(rr_slack_kernel, IPM_G(m), nn, pp, zp, zn, c, mu_R, rho, m);
+    if (h->nlb > 0) hipLaunchKernelGGL(cap_gather_kernel, IPM_G(h->nlb), zl, h->ind_lb.p, rho, h->nlb);
+    if (h->nub > 0) hipLaunchKernelGGL(cap_gather_kernel, IPM_G(h->nub), zu, h->ind_ub.p, rho, h->nub);
+    IPM_DONE();
+}
+
+int mnk_ipm_set_f_RR(mnk_ipm* h, double* f_R, const double* D_R, const double* x, const double* x_ref, double zeta) {
+    IPM_VOID_ENTER(f_R && D_R && x && x_ref, "mnk_ipm_set_f_RR");
+    hipLaunchKernelGGL(f_rr_kernel, IPM_G(h->ntot), f_R, D_R, x, x_ref, zeta, h->ntot);
+    IPM_DONE();
+}
+
+int mnk_ipm_set_aug_rhs_RR(mnk_ipm* h, const double* f_R, const double* zl, const double* zu, const double* jacl,
+                           const double* c, const double* y, const double* pp, const double* nn, const double* zp,
+                           const double* zn, int64_t m, const double* x, const double* xl, const double* xu, double mu_R,
+                           double rho, double* px, double* py, double* pzl, double* pzu) {
+    IPM_VOID_ENTER(m >= 0 && f_R && zl && zu && jacl && x && xl && xu && px &&
+                       (m == 0 || (c && y && pp && nn && zp && zn && py)) && (h->nlb == 0 || pzl) && (h->nub == 0 || pzu),
+                   "mnk_ipm_set_aug_rhs_RR");
+    hipLaunchKernelGGL(aug_rhs_primal_kernel, IPM_G(h->ntot), px, f_R, zl, zu, jacl, h->ntot);
+    if (m > 0) hipLaunchKernelGGL(aug_rhs_rr_dual_kernel, IPM_G(m), py, c, y, pp, nn, zp, zn, mu_R, rho, m);
+    if (h->nlb > 0) hipLaunchKernelGGL(aug_rhs_bound_kernel, IPM_G(h->nlb), pzl, x, xl, zl, h->ind_lb.p, mu_R, h->nlb, 0);
+    if (h->nub > 0) hipLaunchKernelGGL(aug_rhs_bound_kernel, IPM_G(h->nub), pzu, x, xu, zu, h->ind_ub.p, mu_R, h->nub, 1);
+    IPM_DONE();
+}
+
+int mnk_ipm_finish_aug_solve_RR(mnk_ipm* h, double* dpp, double* dnn, double* dzp, double* dzn, const double* l,
+                                const double* dl, const double* pp, const double* nn, const double* zp, const double* zn,
+                                int64_t m, double mu_R, double rho) {
+    IPM_VOID_ENTER(m >= 0 && (m == 0 || (dpp && dnn && dzp && dzn && l && dl && pp && nn && zp && zn)),
+                   "mnk_ipm_finish_aug_solve_RR");
+    if (m > 0) hipLaunchKernelGGL(finish_rr_kernel, IPM_G(m), dpp, dnn, dzp, dzn, l, dl, pp, nn, zp, zn, mu_R, rho, m);
+    IPM_DONE();
+}
+
+int mnk_ipm_reset_bound_dual_1(mnk_ipm* h, double* z, const double* x, int64_t n, double mu, double kappa_sigma) {
+    IPM_VOID_ENTER(n >= 0 && (n == 0 || (z && x)), "mnk_ipm_reset_bound_dual_1");
+    if (n > 0) hipLaunchKernelGGL(reset_bound_dual1_kernel, IPM_G(n), z, x, kappa_sigma * mu, mu / kappa_sigma, n);
+    IPM_DONE();
+}
+
+int mnk_ipm_set_initial_bounds(mnk_ipm* h, double* xl, double* xu, int64_t n, double tol) {
+    IPM_VOID_ENTER(n >= 0 && (n == 0 || (xl && xu)), "mnk_ipm_set_initial_bounds");
+    if (n > 0 && tol > 0) hipLaunchKernelGGL(initial_bounds_kernel, IPM_G(n), xl, xu, tol, n);
+    IPM_DONE();
+}
+
+int mnk_ipm_set_initial_rhs(mnk_ipm* h, const double* f, const double* zl, const double* zu, double* px, double* py,
+                            int64_t m, double* pzl, double* pzu) {
+    IPM_VOID_ENTER(m >= 0 && f && zl && zu && px && (m == 0 || py) && (h->nlb == 0 || pzl) && (h->nub == 0 || pzu),
+                   "mnk_ipm_set_initial_rhs");
+    hipLaunchKernelGGL(initial_rhs_kernel, IPM_G(h->ntot), px, f, zl, zu, h->ntot);
+    if (m > 0) hipLaunchKernelGGL(zero_kernel, IPM_G(m), py, m);
+    if (h->nlb > 0) hipLaunchKernelGGL(zero_kernel, IPM_G(h->nlb), pzl, h->nlb);
+    if (h->nub > 0) hipLaunchKernelGGL(zero_kernel, IPM_G(h->nub), pzu, h->nub);
+    IPM_DONE();
+}
+
+int mnk_ipm_set_aug_rhs_ifr(mnk_ipm* h, const double* c, int64_t m, double* px, double* py, double* pzl, double* pzu) {
+    IPM_VOID_ENTER(m >= 0 && px && (m == 0 || (c && py)) && (h->nlb == 0 || pzl) && (h->nub == 0 || pzu),
+                   "mnk_ipm_set_aug_rhs_ifr");
+    hipLaunchKernelGGL(zero_kernel, IPM_G(h->ntot), px, h->ntot);
+    if (m > 0) hipLaunchKernelGGL(negate_kernel, IPM_G(m), py, c, m);
+    if (h->nlb > 0) hipLaunchKernelGGL(zero_kernel, IPM_G(h->nlb), pzl, h->nlb);
+    if (h->nub > 0) hipLaunchKernelGGL(zero_kernel, IPM_G(h->nub), pzu, h->nub);
+    IPM_DONE();
+}
+
+int mnk_ipm_set_g_ifr(mnk_ipm* h, double* g, const double* f, const double* x, const double* xl, const double* xu,
+                      const double* jacl, double mu) {
+    IPM_VOID_ENTER(g && f && x && xl && xu && jacl, "mnk_ipm_set_g_ifr");
+    hipLaunchKernelGGL(g_ifr_kernel, IPM_G(h->ntot), g, f, x, xl, xu, jacl, mu, h->ntot);
+    IPM_DONE();
+}
+
+int mnk_ipm_initialize_variables(mnk_ipm* h, double* x, const double* xl, const double* xu, int64_t n, double bound_push,
+                                 double bound_fac) {
+    IPM_VOID_ENTER(n >= 0 && (n == 0 || (x && xl && xu)), "mnk_ipm_initialize_variables");
+    if (n > 0) hipLaunchKernelGGL(initialize_variables_kernel, IPM_G(n), x, xl, xu, bound_push, bound_fac, n);
+    IPM_DONE();
 }
 
 }  // extern "C"

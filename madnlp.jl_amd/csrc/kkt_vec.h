@@ -102,6 +102,39 @@ static inline int kkt_set_aug_diagonal(const AugDiagView& v, const double* x, co
     return 0;
 }
 
+// set_aug_RR! (reference src/IPM/kernels.jl:72-87) + _set_aug_diagonal! (:22-27): the robust restorer's diagonals from
+// DEVICE-resident vectors: reg = primal_reg + zeta D_R^2, du_diag = -dual_reg - pp/zp - nn/zn, bound terms as above.
+static __global__ void rr_reg_kernel(double* __restrict__ reg, double* __restrict__ pr_diag, const double* __restrict__ D,
+                                     double primal_reg, double zeta, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = primal_reg + zeta * (D[i] * D[i]);
+    reg[i] = v;
+    pr_diag[i] = v;
+}
+static __global__ void rr_du_kernel(double* __restrict__ du_diag, const double* __restrict__ pp, const double* __restrict__ zp,
+                                    const double* __restrict__ nn, const double* __restrict__ zn, double dual_reg, int64_t m) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < m) du_diag[i] = -dual_reg - pp[i] / zp[i] - nn[i] / zn[i];
+}
+static inline int kkt_set_aug_RR(const AugDiagView& v, const double* x, const double* xl, const double* xu, const double* zl,
+                                 const double* zu, const double* D_R, const double* pp, const double* zp, const double* nn,
+                                 const double* zn, double zeta, double primal_reg, double dual_reg) {
+    hipStream_t s = v.ctx->stream;
+    hipLaunchKernelGGL(rr_reg_kernel, MNK_G1(v.npr), v.reg, v.pr_diag, D_R, primal_reg, zeta, v.npr);
+    if (v.ndu > 0) hipLaunchKernelGGL(rr_du_kernel, MNK_G1(v.ndu), v.du_diag, pp, zp, nn, zn, dual_reg, v.ndu);
+    if (v.nlb > 0) {
+        hipLaunchKernelGGL(aug_terms_kernel, MNK_G1(v.nlb), v.l_diag, v.l_lower, x, xl, zl, v.ind_lb, v.nlb, 0);
+        hipLaunchKernelGGL(aug_diag_sub_kernel, MNK_G1(v.nlb), v.pr_diag, v.l_lower, v.l_diag, v.ind_lb, v.nlb);
+    }
+    if (v.nub > 0) {
+        hipLaunchKernelGGL(aug_terms_kernel, MNK_G1(v.nub), v.u_diag, v.u_lower, x, xu, zu, v.ind_ub, v.nub, 1);
+        hipLaunchKernelGGL(aug_diag_sub_kernel, MNK_G1(v.nub), v.pr_diag, v.u_lower, v.u_diag, v.ind_ub, v.nub);
+    }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 static inline int kkt_regularize_diagonal(const AugDiagView& v, double primal, double dual) {
     hipStream_t s = v.ctx->stream;
     hipLaunchKernelGGL(vec_shift2_kernel, MNK_G1(v.npr), v.reg, v.pr_diag, primal, v.npr);

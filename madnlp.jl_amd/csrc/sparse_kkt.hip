@@ -572,6 +572,20 @@ int mnk_sc_set_aug_diagonal(mnk_sc* sc, const double* x, const double* xl, const
     return 0;
 }
 
+// set_aug_RR!(kkt, solver, RR) (reference src/IPM/kernels.jl:72-87): device-resident vectors only
+int mnk_sc_set_aug_RR(mnk_sc* sc, const double* x, const double* xl, const double* xu, const double* zl, const double* zu,
+                      const double* D_R, const double* pp, const double* zp, const double* nn, const double* zn, double zeta,
+                      double primal_reg, double dual_reg) {
+    AugDiagView v;
+    int rc = sc_diag_view(sc, v, "mnk_sc_set_aug_RR");
+    if (rc) return rc;
+    MNK_REQUIRE(x && xl && xu && zl && zu && D_R && (v.ndu == 0 || (pp && zp && nn && zn)), "mnk_sc_set_aug_RR: NULL vector");
+    rc = kkt_set_aug_RR(v, x, xl, xu, zl, zu, D_R, pp, zp, nn, zn, zeta, primal_reg, dual_reg);
+    if (rc) return rc;
+    spmv_of(sc)->have_terms = spmv_of(sc)->have_diag = true;
+    return 0;
+}
+
 int mnk_sc_regularize_diagonal(mnk_sc* sc, double primal, double dual) {
     AugDiagView v;
     int rc = sc_diag_view(sc, v, "mnk_sc_regularize_diagonal");

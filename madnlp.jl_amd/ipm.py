@@ -13,8 +13,11 @@ reference closely enough that iteration counts and residual histories are meanin
   inertia_correction!    src/IPM/solver.jl:611-670 (InertiaBased)
   solve_refine_wrapper!  src/IPM/factorization.jl:1-19 + backsolve.jl
   filter_line_search!    src/IPM/line_search.jl:6-123 (+ second-order correction solver.jl:547-608)
+  restore!               src/IPM/solver.jl:300-411 (soft restoration, get_F kernels.jl:572-610)
+  robust!                src/IPM/solver.jl:413-545, src/IPM/restoration.jl:39-76, filter_line_search_RR!
+                         src/IPM/line_search.jl:128-222, _update_monotone_RR! src/IPM/barrier.jl:39-84
 
-Not implemented (reported as the exit status): restoration phases (RESTORE / ROBUST), NLP
+Not implemented: NLP
 scaling (problems used here have gradients below nlp_scaling_max_gradient, so the reference's
 scaling factors are 1), inertia-free regularization, quasi-Newton.
 
@@ -33,6 +36,14 @@ from .kkt import UnreducedKKTVector
 
 INF = float("inf")
 EPS = np.finfo(np.float64).eps
+
+
+def _pow(a, b):
+    """a^b with IEEE overflow to Inf (Python's float power raises OverflowError instead)."""
+    try:
+        return a ** b
+    except OverflowError:
+        return INF
 
 
 @dataclass
@@ -77,6 +88,9 @@ class IPMOptions:
     mu_init: float = 1e-1
     mu_linear_decrease_factor: float = 0.2
     mu_superlinear_decrease_power: float = 1.5
+    rho: float = 1000.0                                  # options.jl:195
+    soft_resto_pderror_reduction_factor: float = 0.9999  # options.jl:178
+    required_infeasibility_reduction: float = 0.9        # options.jl:179
 
     @property
     def mu_min(self):
@@ -92,6 +106,23 @@ class Counters:
     acceptable_cnt: int = 0
     unsuccessful_iterate: int = 0
     restoration_fail_count: int = 0
+    t: int = 0
+
+
+@dataclass
+class RobustRestorer:
+    """`RobustRestorer` reference src/IPM/types.jl / src/IPM/restoration.jl:1-37 (vectors are created by the solver: numpy
+    arrays here, device tensors in the device-resident driver)."""
+    obj_val_R: float = 0.0
+    theta_ref: float = 0.0
+    obj_val_R_trial: float = 0.0
+    inf_pr_R: float = 0.0
+    inf_du_R: float = 0.0
+    inf_compl_R: float = 0.0
+    mu_R: float = 0.0
+    tau_R: float = 0.0
+    zeta: float = 0.0
+    filter: list = field(default_factory=list)
 
 
 @dataclass
@@ -105,6 +136,7 @@ class IterRecord:
     del_w: float
     alpha: float
     ls: int
+    phase: str = ""   # "" regular, "r" soft restoration (restore!), "R" robust restoration (robust!)
 
 
 def parse_indexes(lvar, uvar, lcon, ucon, enforce_equality):
@@ -197,11 +229,13 @@ class MadNLPSolver:
             self.kkt.get_jacobian()[...] = self.nlp.jac_dense(x[:self.n])
         self.kkt.compress_jacobian()
 
-    def eval_lag_hess(self, x, y):
+    def eval_lag_hess(self, x, y, is_resto=False):
+        """`eval_lag_hess_wrapper!` callbacks.jl:77-95: objective weight 0 in the robust restoration phase."""
+        w = 0.0 if is_resto else 1.0
         if self.sparse:
-            self.kkt.get_hessian()[:] = self.nlp.hess_coord(x[:self.n], y, 1.0)
+            self.kkt.get_hessian()[:] = self.nlp.hess_coord(x[:self.n], y, w)
         else:
-            self.kkt.get_hessian()[...] = self.nlp.hess_dense(x[:self.n], y, 1.0)
+            self.kkt.get_hessian()[...] = self.nlp.hess_dense(x[:self.n], y, w)
         self.kkt.compress_hessian()
 
     # ------------------------------------------------------------------ views
@@ -234,7 +268,7 @@ class MadNLPSolver:
         con = nlp.cons(x0)
         self.xl[n:] = lcon[self.ind_ineq]
         self.xu[n:] = ucon[self.ind_ineq]
-        self.rhs[:] = (lcon == ucon) * lcon
+        self.rhs[:] = np.where(lcon == ucon, lcon, 0.0)   # Julia: false * -Inf == -0.0 (`false` is a strong zero)
         self.x[n:] = con[self.ind_ineq]
         sl, su = self.xl[n:], self.xu[n:]
         _set_initial_bounds(sl, su, o.bound_relax_factor)
@@ -414,7 +448,7 @@ class MadNLPSolver:
         if varphi_d < 0:
             if theta <= self.theta_min:
                 alpha_min = o.alpha_min_frac * min(o.gamma_theta, o.gamma_phi * theta / (-varphi_d),
-                                                   o.delta * theta ** o.s_theta / (-varphi_d) ** o.s_phi)
+                                                   o.delta * _pow(theta, o.s_theta) / _pow(-varphi_d, o.s_phi))
             else:
                 alpha_min = o.alpha_min_frac * min(o.gamma_theta, -o.gamma_phi * theta / varphi_d)
         else:
@@ -422,7 +456,7 @@ class MadNLPSolver:
         self.cnt.l = 1
         self.alpha = alpha_max
         small = (np.abs(dx) / (1 + np.abs(self.x))).max(initial=0.0) < 10 * EPS
-        switching = varphi_d < 0 and self.alpha * (-varphi_d) ** o.s_phi > o.delta * 2.0 ** o.s_theta
+        switching = varphi_d < 0 and self.alpha * _pow(-varphi_d, o.s_phi) > o.delta * 2.0 ** o.s_theta
         armijo = False
         unsuccessful = False
         theta_trial = varphi_trial = 0.0
@@ -500,74 +534,462 @@ class MadNLPSolver:
             theta_soc_old = theta_soc
         return False
 
-    # ------------------------------------------------------------------ regular! (solver.jl:216-298)
+    # ------------------------------------------------------------------ vector primitives shared with the device driver
+    # (the restoration phases below are written once against these; `ipm_dev.DeviceMadNLPSolver` overrides them with the
+    # `mnk_ipm_*` kernels on device tensors)
+    def _dx(self): return self.d.primal()
+    def _dy(self): return self.d.dual()
+    def _dzl(self): return self.d.dual_lb()
+    def _dzu(self): return self.d.dual_ub()
+
+    def _new_vec(self, n): return np.zeros(n)
+
+    def _clone(self, v): return v.copy()
+
+    def _theta(self, c): return float(np.abs(c).sum())
+
+    def _norm_inf(self, v): return float(np.abs(v).max(initial=0.0))
+
+    def _sd_sc(self):
+        o, nl, nu = self.opt, len(self.ind_lb), len(self.ind_ub)
+        nz = np.abs(self.zl_r).sum() + np.abs(self.zu_r).sum()
+        sd = max(o.s_max, (np.abs(self.y).sum() + nz) / max(1, self.m + nl + nu)) / o.s_max
+        return sd, max(o.s_max, nz / max(1, nl + nu)) / o.s_max
+
+    def _inf_du(self, sd): return float(np.abs(self.f - self.zl + self.zu + self.jacl).max(initial=0.0) / sd)
+
+    def _jtprod(self): self.kkt.jtprod(self.jacl, self.y)
+
+    def _alpha_z(self, tau):
+        """`get_alpha_z` kernels.jl:373-388."""
+        az = 1.0
+        for z, dz in ((self.zl_r, self._dzl()), (self.zu_r, self._dzu())):
+            neg = dz < 0
+            if neg.any():
+                az = min(az, (-z[neg] * tau / dz[neg]).min())
+        return float(az)
+
+    def _bound_dual_axpy(self, a):
+        self.zl[self.ind_lb] += a * self._dzl()
+        self.zu[self.ind_ub] += a * self._dzu()
+
+    def _bound_dual_fill(self, v):
+        self.zl[self.ind_lb] = v
+        self.zu[self.ind_ub] = v
+
+    def _adjust_boundary(self):
+        """`adjust_boundary!` kernels.jl:656-673."""
+        c1, c2 = EPS * self.mu, EPS ** 0.75
+        xl_r, x_lr = self.xl_r, self.x_lr
+        adj = x_lr - xl_r < c1
+        self.xl[self.ind_lb[adj]] = xl_r[adj] - c2 * np.maximum(1, np.abs(x_lr[adj]))
+        xu_r, x_ur = self.xu_r, self.x_ur
+        adj = xu_r - x_ur < c1
+        self.xu[self.ind_ub[adj]] = xu_r[adj] + c2 * np.maximum(1, np.abs(x_ur[adj]))
+
+    def _reset_bound_dual(self, mu):
+        """the two `reset_bound_dual!` calls on the full primal-sized vectors (kernels.jl:788-800)."""
+        ks = self.opt.kappa_sigma
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dl = self.x - self.xl
+            self.zl[:] = np.where(np.isfinite(dl), np.maximum(np.minimum(self.zl, ks * mu / dl), mu / ks / dl), self.zl)
+            du = self.xu - self.x
+            self.zu[:] = np.where(np.isfinite(du), np.maximum(np.minimum(self.zu, ks * mu / du), mu / ks / du), self.zu)
+
+    def _get_F(self):
+        """`get_F` kernels.jl:572-610; the upper-bound term as the reference writes it, `(xu_r - xu_r) * zu_r - mu`."""
+        mu = self.mu
+        x_lr, xl_r, zl_r, xu_r, x_ur, zu_r = self.x_lr, self.xl_r, self.zl_r, self.xu_r, self.x_ur, self.zu_r
+        F3 = np.where((x_lr >= xl_r) & (zl_r >= 0), np.abs((x_lr - xl_r) * zl_r - mu), INF).sum()
+        with np.errstate(invalid="ignore"):
+            F4 = np.where((xu_r >= x_ur) & (zu_r >= 0), np.abs((xu_r - xu_r) * zu_r - mu), INF).sum()
+        return float(np.abs(self.c).sum() + np.abs(self.f - self.zl + self.zu + self.jacl).sum() + F3 + F4)
+
+    def _set_initial_rhs(self):
+        """`set_initial_rhs!` kernels.jl:220-230."""
+        self.p.values[:] = 0.0
+        self.p.primal()[:] = -self.f + self.zl - self.zu
+
+    def _kkt_initialize(self): self.kkt.initialize()
+
+    def _record(self, phase=""):
+        self.history.append(IterRecord(self.cnt.k, self.obj_val, self.inf_pr, self.inf_du, self.inf_compl_v, self.mu,
+                                       self.del_w, self.alpha, self.cnt.l, phase))
+
+    # robust restorer pieces
+    def _rr_init_vectors(self, RR, mu_R, rho):
+        """vector part of `initialize_robust_restorer!` restoration.jl:46-70."""
+        RR.x_ref[:] = self.x
+        with np.errstate(divide="ignore"):
+            RR.D_R[:] = np.minimum(1.0, 1.0 / np.abs(RR.x_ref))
+        t = (mu_R - rho * self.c) / (2 * rho)
+        RR.nn[:] = t + np.sqrt(t * t + mu_R * self.c / (2 * rho))      # populate_RR_nn! kernels.jl:825-829
+        RR.pp[:] = self.c + RR.nn
+        RR.zp[:] = mu_R / RR.pp
+        RR.zn[:] = mu_R / RR.nn
+        RR.f_R[:] = 0.0
+        self.y[:] = 0.0
+        self.zl[self.ind_lb] = np.minimum(rho, self.zl_r)
+        self.zu[self.ind_ub] = np.minimum(rho, self.zu_r)
+
+    def _rr_obj_val(self, pp, nn, x):
+        RR, o = self.RR, self.opt
+        return float((o.rho * (pp + nn)).sum() + (RR.zeta / 2 * RR.D_R ** 2 * (x - RR.x_ref) ** 2).sum())
+
+    def _rr_theta(self, c, pp, nn): return float(np.abs(c - pp + nn).sum())
+
+    def _rr_inf_pr(self): return float(np.abs(self.c - self.RR.pp + self.RR.nn).max(initial=0.0))
+
+    def _rr_inf_du(self, sd):
+        RR, rho = self.RR, self.opt.rho
+        return float(max(np.abs(RR.f_R - self.zl + self.zu + self.jacl).max(initial=0.0),
+                         np.abs(rho - self.y - RR.zp).max(initial=0.0), np.abs(rho + self.y - RR.zn).max(initial=0.0)) / sd)
+
+    def _rr_inf_compl(self, mu, sc):
+        RR = self.RR
+        return float(max(np.abs((self.x_lr - self.xl_r) * self.zl_r - mu).max(initial=0.0),
+                         np.abs((self.xu_r - self.x_ur) * self.zu_r - mu).max(initial=0.0),
+                         np.abs(RR.pp * RR.zp - mu).max(initial=0.0), np.abs(RR.nn * RR.zn - mu).max(initial=0.0)) / sc)
+
+    def _rr_varphi(self, obj, x, pp, nn):
+        mu = self.RR.mu_R
+        dl, du = x[self.ind_lb] - self.xl_r, self.xu_r - x[self.ind_ub]
+        if (dl < 0).any() or (du < 0).any() or (pp < 0).any() or (nn < 0).any():
+            return -INF
+        with np.errstate(divide="ignore"):
+            return float(obj - mu * (np.log(dl).sum() + np.log(du).sum() + np.log(pp).sum() + np.log(nn).sum()))
+
+    def _rr_varphi_d(self):
+        RR, mu, rho, dx = self.RR, self.RR.mu_R, self.opt.rho, self._dx()
+        with np.errstate(divide="ignore"):
+            return float(((RR.f_R - mu / (self.x - self.xl) + mu / (self.xu - self.x)) * dx).sum()
+                         + ((rho - mu / RR.pp) * RR.dpp).sum() + ((rho - mu / RR.nn) * RR.dnn).sum())
+
+    def _rr_alpha_max(self):
+        RR, tau = self.RR, self.RR.tau_R
+        keep, self.tau = self.tau, tau
+        a = self.alpha_max(self._dx())
+        self.tau = keep
+        for v, dv in ((RR.pp, RR.dpp), (RR.nn, RR.dnn)):
+            neg = dv < 0
+            if neg.any():
+                a = min(a, (-v[neg] * tau / dv[neg]).min())
+        return float(a)
+
+    def _rr_alpha_z(self):
+        RR, tau = self.RR, self.RR.tau_R
+        a = self._alpha_z(tau)
+        for z, dz in ((RR.zp, RR.dzp), (RR.zn, RR.dzn)):
+            neg = dz < 0
+            if neg.any():
+                a = min(a, (-z[neg] * tau / dz[neg]).min())
+        return float(a)
+
+    def _rr_set_aug(self):
+        """`set_aug_RR!` kernels.jl:72-87."""
+        k, o, RR = self.kkt, self.opt, self.RR
+        k.reg[:] = o.default_primal_regularization + RR.zeta * RR.D_R ** 2
+        k.du_diag[:] = -o.default_dual_regularization - RR.pp / RR.zp - RR.nn / RR.zn
+        k.l_lower[:] = self.zl_r
+        k.u_lower[:] = self.zu_r
+        k.l_diag[:] = self.xl_r - self.x_lr
+        k.u_diag[:] = self.x_ur - self.xu_r
+        k.pr_diag[:] = k.reg
+        k.pr_diag[self.ind_lb] -= k.l_lower / k.l_diag
+        k.pr_diag[self.ind_ub] -= k.u_lower / k.u_diag
+
+    def _rr_set_rhs(self):
+        """`set_aug_rhs_RR!` kernels.jl:133-158."""
+        p, RR, mu, rho, y = self.p, self.RR, self.RR.mu_R, self.opt.rho, self.y
+        p.primal()[:] = -RR.f_R + self.zl - self.zu - self.jacl
+        p.dual()[:] = -self.c + RR.pp - RR.nn + (mu - (rho - y) * RR.pp) / RR.zp - (mu - (rho + y) * RR.nn) / RR.zn
+        p.dual_lb()[:] = (self.xl_r - self.x_lr) * self.zl_r + mu
+        p.dual_ub()[:] = (self.xu_r - self.x_ur) * self.zu_r - mu
+
+    def _rr_finish(self):
+        """`finish_aug_solve_RR!` kernels.jl:251-257."""
+        RR, mu, rho, l, dl = self.RR, self.RR.mu_R, self.opt.rho, self.y, self._dy()
+        RR.dzp[:] = rho - l - dl - RR.zp
+        RR.dzn[:] = rho + l + dl - RR.zn
+        RR.dpp[:] = -RR.pp + mu / RR.zp - (RR.pp / RR.zp) * RR.dzp
+        RR.dnn[:] = -RR.nn + mu / RR.zn - (RR.nn / RR.zn) * RR.dzn
+
+    def _rr_set_f(self):
+        RR = self.RR
+        RR.f_R[:] = RR.zeta * RR.D_R ** 2 * (self.x - RR.x_ref)      # set_f_RR! kernels.jl:106-110
+
+    def _rr_reset_slack_duals(self):
+        RR, mu, ks = self.RR, self.RR.mu_R, self.opt.kappa_sigma
+        for z, v in ((RR.zp, RR.pp), (RR.zn, RR.nn)):                  # reset_bound_dual!(z, x, mu, ks) kernels.jl:775-786
+            with np.errstate(divide="ignore"):
+                z[:] = np.maximum(np.minimum(z, (ks * mu) / v), (mu / ks) / v)
+
+    def _rel_search_norm(self): return float((np.abs(self._dx()) / (1 + np.abs(self.x))).max(initial=0.0))
+
+    # ------------------------------------------------------------------ restore! (solver.jl:300-411)
+    def restore(self):
+        o = self.opt
+        self.del_w = 0.0
+        w1x, w1y, w2c = self._clone(self.x), self._clone(self.y), self._clone(self.c)   # the backups in _w1 / _w2
+        F = self._get_F()
+        self.alpha_z = 0.0
+        while True:
+            alpha_max = self.alpha_max(self._dx())
+            self.alpha = min(alpha_max, self._alpha_z(self.tau))
+            self.x += self.alpha * self._dx()
+            self.y += self.alpha * self._dy()
+            self._bound_dual_axpy(self.alpha)
+            self.eval_cons(self.c, self.x)
+            self.eval_grad(self.x)
+            self.obj_val = self.eval_f(self.x)
+            self.eval_jac(self.x)
+            self._jtprod()
+            F_trial = self._get_F()
+            if F_trial > o.soft_resto_pderror_reduction_factor * F:
+                self.x[:] = w1x
+                self.y[:] = w1y
+                self.c[:] = w2c
+                return "ROBUST"
+            self._adjust_boundary()
+            F = F_trial
+            theta = self._theta(self.c)
+            varphi = self.varphi(self.obj_val, self.x)
+            self.cnt.k += 1
+            if self._filter_ok(theta, varphi):
+                return "REGULAR"
+            self.cnt.t += 1
+            if self.cnt.k >= o.max_iter:
+                return "MAXIMUM_ITERATIONS_EXCEEDED"
+            sd, sc = self._sd_sc()
+            self.inf_pr = self._norm_inf(self.c)
+            self.inf_du = self._inf_du(sd)
+            self.inf_compl_v = self.inf_compl(0.0, sc)
+            self._record("r")
+            self.eval_lag_hess(self.x, self.y)
+            self.set_aug_diagonal()
+            self.set_aug_rhs(self.c)
+            self.factorize_wrapper()
+            self._solve_newton()
+
+    def _solve_newton(self):
+        return self.solve_refine_wrapper(self.d, self.p, self._w4)
+
+    # ------------------------------------------------------------------ robust! (solver.jl:413-545)
+    def _initialize_robust_restorer(self):
+        """`initialize_robust_restorer!` restoration.jl:39-76."""
+        o = self.opt
+        if getattr(self, "RR", None) is None:
+            RR = RobustRestorer()
+            nt, m = len(self.x), self.m
+            for name, n in (("f_R", nt), ("x_ref", nt), ("D_R", nt)) + tuple((v, m) for v in (
+                    "pp", "nn", "zp", "zn", "dpp", "dnn", "dzp", "dzn", "pp_trial", "nn_trial")):
+                setattr(RR, name, self._new_vec(n))
+            self.RR = RR
+        RR = self.RR
+        RR.theta_ref = self._theta(self.c)
+        RR.mu_R = max(self.mu, self._norm_inf(self.c))
+        RR.tau_R = max(o.tau_min, 1 - RR.mu_R)
+        RR.zeta = math.sqrt(RR.mu_R)
+        self._rr_init_vectors(RR, RR.mu_R, o.rho)
+        RR.obj_val_R = self._rr_obj_val(RR.pp, RR.nn, self.x)
+        RR.filter = [(self.theta_max, -INF)]
+        self.cnt.t = 0
+        self.del_w = 0.0
+
+    def _update_monotone_RR(self, sc):
+        """`_update_monotone_RR!` barrier.jl:39-84."""
+        o, RR = self.opt, self.RR
+        inf_compl_mu_R = self._rr_inf_compl(RR.mu_R, sc)
+        while RR.mu_R >= o.mu_min and max(RR.inf_pr_R, RR.inf_du_R, inf_compl_mu_R) <= o.barrier_tol_factor * RR.mu_R:
+            a = min(99.0 * o.mu_min / o.tol, 0.01)
+            RR.mu_R = max(o.mu_min, a * o.tol, min(o.mu_linear_decrease_factor * RR.mu_R,
+                                                   RR.mu_R ** o.mu_superlinear_decrease_power))
+            inf_compl_mu_R = self._rr_inf_compl(RR.mu_R, sc)
+            RR.tau_R = max(o.tau_min, 1 - RR.mu_R)
+            RR.zeta = math.sqrt(RR.mu_R)
+            RR.filter = [(self.theta_max, -INF)]
+
+    def robust(self):
+        o = self.opt
+        self._initialize_robust_restorer()
+        RR = self.RR
+        while True:
+            self.eval_jac(self.x)
+            self._jtprod()
+            sd, sc = self._sd_sc()
+            self.inf_pr = self._norm_inf(self.c)
+            self.inf_du = self._inf_du(sd)
+            self.inf_compl_v = self.inf_compl(0.0, sc)
+            RR.inf_pr_R = self._rr_inf_pr()
+            RR.inf_du_R = self._rr_inf_du(sd)
+            RR.inf_compl_R = self._rr_inf_compl(0.0, sc)
+            self._record("R")
+            if max(RR.inf_pr_R, RR.inf_du_R, RR.inf_compl_R) <= o.tol:
+                return "INFEASIBLE_PROBLEM_DETECTED"
+            if self.cnt.k >= o.max_iter:
+                return "MAXIMUM_ITERATIONS_EXCEEDED"
+            self._update_monotone_RR(sc)
+            self.eval_lag_hess(self.x, self.y, is_resto=True)
+            self._rr_set_aug()
+            self._rr_set_rhs()
+            if not self.inertia_correction():
+                return "RESTORATION_FAILED"
+            self._rr_finish()
+            st = self.filter_line_search_RR()
+            if st != "LINESEARCH_SUCCEEDED":
+                return st
+            self.x[:] = self.x_trial
+            self.c[:] = self.c_trial
+            RR.pp[:] = RR.pp_trial
+            RR.nn[:] = RR.nn_trial
+            RR.obj_val_R = RR.obj_val_R_trial
+            self._rr_set_f()
+            self.y += self.alpha * self._dy()
+            RR.zp += self.alpha_z * RR.dzp
+            RR.zn += self.alpha_z * RR.dzn
+            self._bound_dual_axpy(self.alpha_z)
+            self._reset_bound_dual(RR.mu_R)
+            self._rr_reset_slack_duals()
+            self._adjust_boundary()
+            self.obj_val = self.eval_f(self.x)
+            self.eval_grad(self.x)
+            theta = self._theta(self.c)
+            varphi = self.varphi(self.obj_val, self.x)
+            if self._filter_ok(theta, varphi) and theta <= o.required_infeasibility_reduction * RR.theta_ref:
+                self._set_initial_rhs()
+                self._kkt_initialize()
+                self.factorize_wrapper()
+                self._solve_newton()
+                if self._norm_inf(self._dy()) > o.constr_mult_init_max:
+                    self.y[:] = 0.0
+                else:
+                    self.y[:] = self._dy()
+                self.cnt.k += 1
+                self.cnt.t += 1
+                return "REGULAR"
+            if self.cnt.k >= o.max_iter:
+                return "MAXIMUM_ITERATIONS_EXCEEDED"
+            self.cnt.k += 1
+            self.cnt.t += 1
+
+    def _ftype_RR(self, theta, theta_trial, varphi, varphi_trial, switching, armijo):
+        keep, self.filter = self.filter, self.RR.filter
+        try:
+            return self._ftype(theta, theta_trial, varphi, varphi_trial, switching, armijo)
+        finally:
+            self.filter = keep
+
+    def filter_line_search_RR(self):
+        """`filter_line_search_RR!` line_search.jl:128-222."""
+        o, RR = self.opt, self.RR
+        theta_R = self._rr_theta(self.c, RR.pp, RR.nn)
+        varphi_R = self._rr_varphi(RR.obj_val_R, self.x, RR.pp, RR.nn)
+        varphi_d_R = self._rr_varphi_d()
+        alpha_max = self._rr_alpha_max()
+        self.alpha_z = self._rr_alpha_z()
+        if varphi_d_R < 0:
+            if theta_R <= self.theta_min:
+                alpha_min = o.alpha_min_frac * min(o.gamma_theta, o.gamma_phi * theta_R / (-varphi_d_R),
+                                                   o.delta * _pow(theta_R, o.s_theta) / _pow(-varphi_d_R, o.s_phi))
+            else:
+                alpha_min = o.alpha_min_frac * min(o.gamma_theta, -o.gamma_phi * theta_R / varphi_d_R)
+        else:
+            alpha_min = o.alpha_min_frac * o.gamma_theta
+        self.alpha = alpha_max
+        self.cnt.l = 1
+        small = self._rel_search_norm() < 10 * EPS
+        switching = varphi_d_R < 0 and self.alpha * _pow(-varphi_d_R, o.s_phi) > o.delta * _pow(theta_R, o.s_theta)
+        armijo = False
+        while True:
+            self.x_trial[:] = self.x
+            self.x_trial += self.alpha * self._dx()
+            RR.pp_trial[:] = RR.pp
+            RR.pp_trial += self.alpha * RR.dpp
+            RR.nn_trial[:] = RR.nn
+            RR.nn_trial += self.alpha * RR.dnn
+            RR.obj_val_R_trial = self._rr_obj_val(RR.pp_trial, RR.nn_trial, self.x_trial)
+            self.eval_cons(self.c_trial, self.x_trial)
+            theta_R_trial = self._rr_theta(self.c_trial, RR.pp_trial, RR.nn_trial)
+            varphi_R_trial = self._rr_varphi(RR.obj_val_R_trial, self.x_trial, RR.pp_trial, RR.nn_trial)
+            armijo = varphi_R_trial <= varphi_R + o.eta_phi * self.alpha * varphi_d_R
+            if small:
+                break
+            if self._ftype_RR(theta_R, theta_R_trial, varphi_R, varphi_R_trial, switching, armijo) in ("f", "h"):
+                break
+            self.alpha /= 2
+            self.cnt.l += 1
+            if self.alpha < alpha_min:
+                self.cnt.restoration_fail_count += 1
+                if self.cnt.restoration_fail_count >= 4:
+                    return "RESTORATION_FAILED"
+                # the reference's "second chance": back to the regular phase from the current iterate
+                self.y[:] = 0.0
+                self._bound_dual_fill(1.0)
+                self.filter = [(self.theta_max, -INF)]
+                self.cnt.k += 1
+                self.cnt.t += 1
+                return "REGULAR"
+            if self.alpha < EPS * 10:
+                return "SOLVED_TO_ACCEPTABLE_LEVEL" if self.cnt.acceptable_cnt > 0 else "SEARCH_DIRECTION_BECOMES_TOO_SMALL"
+        if not switching or not armijo:
+            RR.filter.append(((1 - o.gamma_theta) * theta_R_trial, varphi_R_trial - o.gamma_theta * theta_R_trial))
+        return "LINESEARCH_SUCCEEDED"
+
+    # ------------------------------------------------------------------ solve! (solver.jl:119-166)
     def solve(self):
         if self.status == "INITIAL":
             self.initialize()
+        while self.status in ("REGULAR", "RESTORE", "ROBUST"):
+            if self.status == "REGULAR":
+                self.status = self.regular()
+            if self.status == "RESTORE":
+                self.status = self.restore()
+            if self.status == "ROBUST":
+                self.status = self.robust()
+        return self.status
+
+    # ------------------------------------------------------------------ regular! (solver.jl:216-298)
+    def regular(self):
         o = self.opt
         while True:
             if self.cnt.k != 0:
                 self.eval_jac(self.x)
-            self.kkt.jtprod(self.jacl, self.y)
-            nl, nu = len(self.ind_lb), len(self.ind_ub)
-            sd = max(o.s_max, (np.abs(self.y).sum() + np.abs(self.zl_r).sum() + np.abs(self.zu_r).sum())
-                     / max(1, self.m + nl + nu)) / o.s_max
-            sc = max(o.s_max, (np.abs(self.zl_r).sum() + np.abs(self.zu_r).sum()) / max(1, nl + nu)) / o.s_max
-            self.inf_pr = np.abs(self.c).max(initial=0.0)
-            self.inf_du = np.abs(self.f - self.zl + self.zu + self.jacl).max(initial=0.0) / sd
+            self._jtprod()
+            sd, sc = self._sd_sc()
+            self.inf_pr = self._norm_inf(self.c)
+            self.inf_du = self._inf_du(sd)
             self.inf_compl_v = self.inf_compl(0.0, sc)
-            self.history.append(IterRecord(self.cnt.k, self.obj_val, self.inf_pr, self.inf_du, self.inf_compl_v,
-                                           self.mu, self.del_w, self.alpha, self.cnt.l))
+            self._record()
             inf_total = max(self.inf_pr, self.inf_du, self.inf_compl_v)
             if inf_total <= o.tol:
-                self.status = "SOLVE_SUCCEEDED"
-                return self.status
+                return "SOLVE_SUCCEEDED"
             if inf_total <= o.acceptable_tol:
                 if self.cnt.acceptable_cnt < o.acceptable_iter:
                     self.cnt.acceptable_cnt += 1
                 else:
-                    self.status = "SOLVED_TO_ACCEPTABLE_LEVEL"
-                    return self.status
+                    return "SOLVED_TO_ACCEPTABLE_LEVEL"
             else:
                 self.cnt.acceptable_cnt = 0
             if inf_total >= o.diverging_iterates_tol:
-                self.status = "DIVERGING_ITERATES"
-                return self.status
+                return "DIVERGING_ITERATES"
             if self.cnt.k >= o.max_iter:
-                self.status = "MAXIMUM_ITERATIONS_EXCEEDED"
-                return self.status
+                return "MAXIMUM_ITERATIONS_EXCEEDED"
             if self.cnt.k != 0:
                 self.eval_lag_hess(self.x, self.y)
             self.update_barrier(sc)
             self.set_aug_diagonal()
             self.set_aug_rhs(self.c)
             if not self.inertia_correction():
-                self.status = "ROBUST (restoration not implemented)"
-                return self.status
+                return "ROBUST"
             st = self.filter_line_search()
             if st != "LINESEARCH_SUCCEEDED":
-                self.status = st + " (restoration not implemented)" if st == "RESTORE" else st
-                return self.status
+                return st
             self.x[:] = self.x_trial
             self.c[:] = self.c_trial
             self.obj_val = self.obj_val_trial
-            # adjust_boundary! (kernels.jl:656-673)
-            c1, c2 = EPS * self.mu, EPS ** 0.75
-            xl_r, x_lr = self.xl_r, self.x_lr
-            adj = x_lr - xl_r < c1
-            self.xl[self.ind_lb[adj]] = xl_r[adj] - c2 * np.maximum(1, np.abs(x_lr[adj]))
-            xu_r, x_ur = self.xu_r, self.x_ur
-            adj = xu_r - x_ur < c1
-            self.xu[self.ind_ub[adj]] = xu_r[adj] + c2 * np.maximum(1, np.abs(x_ur[adj]))
-            self.y += self.alpha * self.d.dual()
-            self.zl[self.ind_lb] += self.alpha_z * self.d.dual_lb()
-            self.zu[self.ind_ub] += self.alpha_z * self.d.dual_ub()
-            # reset_bound_dual! (kernels.jl:775-800) on the full primal-sized vectors
-            ks, mu = o.kappa_sigma, self.mu
-            with np.errstate(divide="ignore", invalid="ignore"):
-                dl = self.x - self.xl
-                self.zl[:] = np.where(np.isfinite(dl), np.maximum(np.minimum(self.zl, ks * mu / dl), mu / ks / dl), self.zl)
-                du = self.xu - self.x
-                self.zu[:] = np.where(np.isfinite(du), np.maximum(np.minimum(self.zu, ks * mu / du), mu / ks / du), self.zu)
+            self._adjust_boundary()
+            self.y += self.alpha * self._dy()
+            self._bound_dual_axpy(self.alpha_z)
+            self._reset_bound_dual(self.mu)
             self.eval_grad(self.x)
             self.cnt.k += 1

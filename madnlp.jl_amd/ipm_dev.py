@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .ipm import EPS, INF, IPMOptions, IterRecord, MadNLPSolver
+from .ipm import EPS, INF, IPMOptions, MadNLPSolver, _pow
 from .ipm_device import IPMDeviceKernels
 
 
@@ -29,6 +29,7 @@ class DeviceQPCallbacks:
         self.q = torch.from_numpy(np.asarray(nlp.q, dtype=np.float64)).to(dev)
         self.jv = torch.from_numpy(np.ascontiguousarray(nlp.jac_coord(None), dtype=np.float64)).to(dev)
         self.hv = torch.from_numpy(np.ascontiguousarray(nlp.hess_coord(None, None, 1.0), dtype=np.float64)).to(dev)
+        self.hv0 = torch.zeros_like(self.hv)
         self._hx = torch.empty(self.n, dtype=torch.float64, device=dev)
 
     def _hmul(self, x):
@@ -103,10 +104,10 @@ class DeviceMadNLPSolver(MadNLPSolver):
             return super().eval_jac(x)
         self.kkt.compress_jacobian(self.cb.jv)
 
-    def eval_lag_hess(self, x, y):
+    def eval_lag_hess(self, x, y, is_resto=False):
         if not self._on_device:
-            return super().eval_lag_hess(x, y)
-        self.kkt.compress_hessian(self.cb.hv)
+            return super().eval_lag_hess(x, y, is_resto)
+        self.kkt.compress_hessian(self.cb.hv0 if is_resto else self.cb.hv)   # objective weight 0 in robust!
 
     def jtprod(self, out, y):
         """`jtprod!` reference src/KKT/Sparse/condensed.jl:150-156."""
@@ -213,7 +214,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         if varphi_d < 0:
             if theta <= self.theta_min:
                 alpha_min = o.alpha_min_frac * min(o.gamma_theta, o.gamma_phi * theta / (-varphi_d),
-                                                   o.delta * theta ** o.s_theta / (-varphi_d) ** o.s_phi)
+                                                   o.delta * _pow(theta, o.s_theta) / _pow(-varphi_d, o.s_phi))
             else:
                 alpha_min = o.alpha_min_frac * min(o.gamma_theta, -o.gamma_phi * theta / varphi_d)
         else:
@@ -221,7 +222,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         self.cnt.l = 1
         self.alpha = alpha_max
         small = K.get_rel_search_norm(self.x, dx) < 10 * EPS
-        switching = varphi_d < 0 and self.alpha * (-varphi_d) ** o.s_phi > o.delta * 2.0 ** o.s_theta
+        switching = varphi_d < 0 and self.alpha * _pow(-varphi_d, o.s_phi) > o.delta * 2.0 ** o.s_theta
         armijo = False
         unsuccessful = False
         theta_trial = varphi_trial = 0.0
@@ -299,62 +300,132 @@ class DeviceMadNLPSolver(MadNLPSolver):
             theta_soc_old = theta_soc
         return False
 
-    # ------------------------------------------------------------------ regular!
+    # ------------------------------------------------------------------ vector primitives (see `ipm.MadNLPSolver`): the regular
+    # phase, restore! and robust! of the base class run unchanged on device tensors through these
+    def _dx(self): return self._primal(self.dv)
+    def _dy(self): return self._dual(self.dv)
+    def _dzl(self): return self._dual_lb(self.dv)
+    def _dzu(self): return self._dual_ub(self.dv)
+
+    def _new_vec(self, n): return torch.zeros(n, dtype=torch.float64, device=self.dev)
+
+    def _clone(self, v): return v.clone()
+
+    def _theta(self, c): return self.K.get_norms(c)[1]
+
+    def _norm_inf(self, v): return self.K.get_norms(v)[0]
+
+    def _sd_sc(self): return self.K.get_sd_sc(self.y, self.zl, self.zu, self.opt.s_max)
+
+    def _inf_du(self, sd): return self.K.get_inf_du(self.f, self.zl, self.zu, self.jacl, sd)
+
+    def _jtprod(self): self.jtprod(self.jacl, self.y)
+
+    def _alpha_z(self, tau): return self.K.get_alpha_z(self.zl, self.zu, self._dzl(), self._dzu(), tau)
+
+    def _bound_dual_axpy(self, a):
+        self.zl[self.ind_lb_t] += a * self._dzl()
+        self.zu[self.ind_ub_t] += a * self._dzu()
+
+    def _bound_dual_fill(self, v):
+        self.zl[self.ind_lb_t] = v
+        self.zu[self.ind_ub_t] = v
+
+    def _adjust_boundary(self): self.K.adjust_boundary(self.x, self.xl, self.xu, self.mu)
+
+    def _reset_bound_dual(self, mu):
+        self.K.reset_bound_dual(self.zl, self.zu, self.x, self.xl, self.xu, mu, self.opt.kappa_sigma)
+
+    def _get_F(self):
+        return self.K.get_F(self.c, self.f, self.zl, self.zu, self.jacl, self.x, self.xl, self.xu, self.mu)
+
+    def _set_initial_rhs(self):
+        p = self.pv
+        self.K.set_initial_rhs(self.f, self.zl, self.zu, self._primal(p), self._dual(p), self._dual_lb(p), self._dual_ub(p))
+
+    def _kkt_initialize(self):
+        """`initialize!(kkt)` (reference src/KKT/Sparse/utils.jl:52-62) on the handle's device state: zero Hessian, and
+        reg = pr_diag = 1, du_diag = 0, l_diag = u_diag = 1, l_lower = u_lower = 0 through the feeder (x = 0, xl = 1,
+        xu = -1, zl = zu = 0, primal_reg = 1)."""
+        self.kkt.initialize()
+        nt = self.nt
+        z = np.zeros(nt)
+        self.kkt.set_aug_diagonal_device(z, np.ones(nt), -np.ones(nt), z, z, 1.0, 0.0)
+
+    def _solve_newton(self):
+        return self.solve_refine_wrapper(self.dv, self.pv, self.w4v)
+
+    def _rel_search_norm(self): return self.K.get_rel_search_norm(self.x, self._dx())
+
+    # robust restorer (`mnk_ipm_*_R`)
+    def _rr_init_vectors(self, RR, mu_R, rho):
+        self.K.initialize_robust_restorer(self.x, self.c, mu_R, rho, RR.x_ref, RR.D_R, RR.nn, RR.pp, RR.zp, RR.zn, self.zl, self.zu)
+        RR.f_R.zero_()
+        self.y.zero_()
+
+    def _rr_obj_val(self, pp, nn, x):
+        RR = self.RR
+        return self.K.get_obj_val_R(pp, nn, RR.D_R, x, RR.x_ref, self.opt.rho, RR.zeta)
+
+    def _rr_theta(self, c, pp, nn): return self.K.get_theta_R(c, pp, nn)
+
+    def _rr_inf_pr(self): return self.K.get_inf_pr_R(self.c, self.RR.pp, self.RR.nn)
+
+    def _rr_inf_du(self, sd):
+        RR = self.RR
+        return self.K.get_inf_du_R(RR.f_R, self.y, self.zl, self.zu, self.jacl, RR.zp, RR.zn, self.opt.rho, sd)
+
+    def _rr_inf_compl(self, mu, sc):
+        RR = self.RR
+        return self.K.get_inf_compl_R(self.x, self.xl, self.xu, self.zl, self.zu, RR.pp, RR.zp, RR.nn, RR.zn, mu, sc)
+
+    def _rr_varphi(self, obj, x, pp, nn):
+        return self.K.get_varphi_R(obj, x, self.xl, self.xu, pp, nn, self.RR.mu_R)
+
+    def _rr_varphi_d(self):
+        RR = self.RR
+        return self.K.get_varphi_d_R(RR.f_R, self.x, self.xl, self.xu, self._dx(), RR.pp, RR.nn, RR.dpp, RR.dnn, RR.mu_R,
+                                     self.opt.rho)
+
+    def _rr_alpha_max(self):
+        RR = self.RR
+        return self.K.get_alpha_max_R(self.x, self.xl, self.xu, self._dx(), RR.pp, RR.dpp, RR.nn, RR.dnn, RR.tau_R)
+
+    def _rr_alpha_z(self):
+        RR = self.RR
+        return self.K.get_alpha_z_R(self.zl, self.zu, self._dzl(), self._dzu(), RR.zp, RR.dzp, RR.zn, RR.dzn, RR.tau_R)
+
+    def _rr_set_aug(self):
+        o, RR = self.opt, self.RR
+        self.kkt.set_aug_RR_device(self.x, self.xl, self.xu, self.zl, self.zu, RR.D_R, RR.pp, RR.zp, RR.nn, RR.zn, RR.zeta,
+                                   o.default_primal_regularization, o.default_dual_regularization)
+
+    def _rr_set_rhs(self):
+        p, RR = self.pv, self.RR
+        self.K.set_aug_rhs_RR(RR.f_R, self.zl, self.zu, self.jacl, self.c, self.y, RR.pp, RR.nn, RR.zp, RR.zn, self.x, self.xl,
+                              self.xu, RR.mu_R, self.opt.rho, self._primal(p), self._dual(p), self._dual_lb(p), self._dual_ub(p))
+
+    def _rr_finish(self):
+        RR = self.RR
+        self.K.finish_aug_solve_RR(RR.dpp, RR.dnn, RR.dzp, RR.dzn, self.y, self._dy(), RR.pp, RR.nn, RR.zp, RR.zn, RR.mu_R,
+                                   self.opt.rho)
+
+    def _rr_set_f(self):
+        RR = self.RR
+        self.K.set_f_RR(RR.f_R, RR.D_R, self.x, RR.x_ref, RR.zeta)
+
+    def _rr_reset_slack_duals(self):
+        RR, ks = self.RR, self.opt.kappa_sigma
+        self.K.reset_bound_dual_1(RR.zp, RR.pp, RR.mu_R, ks)
+        self.K.reset_bound_dual_1(RR.zn, RR.nn, RR.mu_R, ks)
+
+    # ------------------------------------------------------------------ solve!: host initialization, upload, then the base
+    # class's phases (regular! / restore! / robust!) on the device tensors
     def solve(self):
         if self.status == "INITIAL":
             self.initialize()          # host (numpy), once
             self._upload()
-        o, K = self.opt, self.K
-        while True:
-            if self.cnt.k != 0:
-                self.eval_jac(self.x)
-            self.jtprod(self.jacl, self.y)
-            sd, sc = K.get_sd_sc(self.y, self.zl, self.zu, o.s_max)
-            self.inf_pr = K.get_norms(self.c)[0]
-            self.inf_du = K.get_inf_du(self.f, self.zl, self.zu, self.jacl, sd)
-            self.inf_compl_v = self.inf_compl(0.0, sc)
-            self.history.append(IterRecord(self.cnt.k, self.obj_val, self.inf_pr, self.inf_du, self.inf_compl_v,
-                                           self.mu, self.del_w, self.alpha, self.cnt.l))
-            inf_total = max(self.inf_pr, self.inf_du, self.inf_compl_v)
-            if inf_total <= o.tol:
-                self.status = "SOLVE_SUCCEEDED"
-                return self.status
-            if inf_total <= o.acceptable_tol:
-                if self.cnt.acceptable_cnt < o.acceptable_iter:
-                    self.cnt.acceptable_cnt += 1
-                else:
-                    self.status = "SOLVED_TO_ACCEPTABLE_LEVEL"
-                    return self.status
-            else:
-                self.cnt.acceptable_cnt = 0
-            if inf_total >= o.diverging_iterates_tol:
-                self.status = "DIVERGING_ITERATES"
-                return self.status
-            if self.cnt.k >= o.max_iter:
-                self.status = "MAXIMUM_ITERATIONS_EXCEEDED"
-                return self.status
-            if self.cnt.k != 0:
-                self.eval_lag_hess(self.x, self.y)
-            self.update_barrier(sc)
-            self.set_aug_diagonal()
-            self.set_aug_rhs(self.c)
-            if not self.inertia_correction():
-                self.status = "ROBUST (restoration not implemented)"
-                return self.status
-            st = self.filter_line_search()
-            if st != "LINESEARCH_SUCCEEDED":
-                self.status = st + " (restoration not implemented)" if st == "RESTORE" else st
-                return self.status
-            self.x.copy_(self.x_trial)
-            self.c.copy_(self.c_trial)
-            self.obj_val = self.obj_val_trial
-            K.adjust_boundary(self.x, self.xl, self.xu, self.mu)
-            self.y.add_(self._dual(self.dv), alpha=self.alpha)
-            self.zl[self.ind_lb_t] += self.alpha_z * self._dual_lb(self.dv)
-            self.zu[self.ind_ub_t] += self.alpha_z * self._dual_ub(self.dv)
-            K.reset_bound_dual(self.zl, self.zu, self.x, self.xl, self.xu, self.mu, o.kappa_sigma)
-            self.eval_grad(self.x)
-            self.cnt.k += 1
+        return super().solve()
 
     def host_state(self):
         """x, y, zl, zu on the host (tests, reporting)."""

@@ -89,6 +89,87 @@ class IPMDeviceKernels:
         L.check(L.lib().mnk_ipm_reset_bound_dual(self._h, _dev(zl), _dev(zu), _dev(x), _dev(xl), _dev(xu), float(mu),
                                                  float(kappa_sigma)), "mnk_ipm_reset_bound_dual")
 
+    # ---- restoration phase (robust restorer): reference src/IPM/kernels.jl:390-636 and the elementwise pieces
+    def get_obj_val_R(self, p, n, D_R, x, x_ref, rho, zeta):
+        return self._call("mnk_ipm_get_obj_val_R", _dev(p), _dev(n), int(p.numel()), _dev(D_R), _dev(x), _dev(x_ref),
+                          float(rho), float(zeta))
+
+    def get_theta_R(self, c, p, n):
+        return self._call("mnk_ipm_get_theta_R", _dev(c), _dev(p), _dev(n), int(c.numel()))
+
+    def get_inf_pr_R(self, c, p, n):
+        return self._call("mnk_ipm_get_inf_pr_R", _dev(c), _dev(p), _dev(n), int(c.numel()))
+
+    def get_inf_du_R(self, f_R, l, zl, zu, jacl, zp, zn, rho, sd):
+        return self._call("mnk_ipm_get_inf_du_R", _dev(f_R), _dev(l), _dev(zl), _dev(zu), _dev(jacl), _dev(zp), _dev(zn),
+                          int(l.numel()), float(rho), float(sd))
+
+    def get_inf_compl_R(self, x, xl, xu, zl, zu, pp, zp, nn, zn, mu_R, sc):
+        return self._call("mnk_ipm_get_inf_compl_R", _dev(x), _dev(xl), _dev(xu), _dev(zl), _dev(zu), _dev(pp), _dev(zp),
+                          _dev(nn), _dev(zn), int(pp.numel()), float(mu_R), float(sc))
+
+    def get_alpha_max_R(self, x, xl, xu, dx, pp, dpp, nn, dnn, tau_R):
+        return self._call("mnk_ipm_get_alpha_max_R", _dev(x), _dev(xl), _dev(xu), _dev(dx), _dev(pp), _dev(dpp), _dev(nn),
+                          _dev(dnn), int(pp.numel()), float(tau_R))
+
+    def get_alpha_z_R(self, zl, zu, dzl, dzu, zp, dzp, zn, dzn, tau_R):
+        return self._call("mnk_ipm_get_alpha_z_R", _dev(zl), _dev(zu), _dev(dzl), _dev(dzu), _dev(zp), _dev(dzp), _dev(zn),
+                          _dev(dzn), int(zp.numel()), float(tau_R))
+
+    def get_varphi_R(self, obj_val, x, xl, xu, pp, nn, mu_R):
+        return self._call("mnk_ipm_get_varphi_R", float(obj_val), _dev(x), _dev(xl), _dev(xu), _dev(pp), _dev(nn),
+                          int(pp.numel()), float(mu_R))
+
+    def get_F(self, c, f, zl, zu, jacl, x, xl, xu, mu):
+        return self._call("mnk_ipm_get_F", _dev(c), int(c.numel()), _dev(f), _dev(zl), _dev(zu), _dev(jacl), _dev(x),
+                          _dev(xl), _dev(xu), float(mu))
+
+    def get_varphi_d_R(self, f_R, x, xl, xu, dx, pp, nn, dpp, dnn, mu_R, rho):
+        return self._call("mnk_ipm_get_varphi_d_R", _dev(f_R), _dev(x), _dev(xl), _dev(xu), _dev(dx), _dev(pp), _dev(nn),
+                          _dev(dpp), _dev(dnn), int(pp.numel()), float(mu_R), float(rho))
+
+    def _void(self, name, *args):
+        L.check(getattr(L.lib(), name)(self._h, *args), name)
+
+    def populate_RR_nn(self, nn, c, mu, rho):
+        self._void("mnk_ipm_populate_RR_nn", _dev(nn), _dev(c), int(c.numel()), float(mu), float(rho))
+
+    def initialize_robust_restorer(self, x, c, mu_R, rho, x_ref, D_R, nn, pp, zp, zn, zl, zu):
+        self._void("mnk_ipm_initialize_robust_restorer", _dev(x), _dev(c), int(c.numel()), float(mu_R), float(rho),
+                   _dev(x_ref), _dev(D_R), _dev(nn), _dev(pp), _dev(zp), _dev(zn), _dev(zl), _dev(zu))
+
+    def set_f_RR(self, f_R, D_R, x, x_ref, zeta):
+        self._void("mnk_ipm_set_f_RR", _dev(f_R), _dev(D_R), _dev(x), _dev(x_ref), float(zeta))
+
+    def set_aug_rhs_RR(self, f_R, zl, zu, jacl, c, y, pp, nn, zp, zn, x, xl, xu, mu_R, rho, px, py, pzl, pzu):
+        self._void("mnk_ipm_set_aug_rhs_RR", _dev(f_R), _dev(zl), _dev(zu), _dev(jacl), _dev(c), _dev(y), _dev(pp), _dev(nn),
+                   _dev(zp), _dev(zn), int(c.numel()), _dev(x), _dev(xl), _dev(xu), float(mu_R), float(rho), _dev(px),
+                   _dev(py), _dev(pzl), _dev(pzu))
+
+    def finish_aug_solve_RR(self, dpp, dnn, dzp, dzn, l, dl, pp, nn, zp, zn, mu_R, rho):
+        self._void("mnk_ipm_finish_aug_solve_RR", _dev(dpp), _dev(dnn), _dev(dzp), _dev(dzn), _dev(l), _dev(dl), _dev(pp),
+                   _dev(nn), _dev(zp), _dev(zn), int(pp.numel()), float(mu_R), float(rho))
+
+    def reset_bound_dual_1(self, z, x, mu, kappa_sigma):
+        self._void("mnk_ipm_reset_bound_dual_1", _dev(z), _dev(x), int(z.numel()), float(mu), float(kappa_sigma))
+
+    def set_initial_bounds(self, xl, xu, tol):
+        self._void("mnk_ipm_set_initial_bounds", _dev(xl), _dev(xu), int(xl.numel()), float(tol))
+
+    def set_initial_rhs(self, f, zl, zu, px, py, pzl, pzu):
+        self._void("mnk_ipm_set_initial_rhs", _dev(f), _dev(zl), _dev(zu), _dev(px), _dev(py), int(py.numel()), _dev(pzl),
+                   _dev(pzu))
+
+    def set_aug_rhs_ifr(self, c, px, py, pzl, pzu):
+        self._void("mnk_ipm_set_aug_rhs_ifr", _dev(c), int(c.numel()), _dev(px), _dev(py), _dev(pzl), _dev(pzu))
+
+    def set_g_ifr(self, g, f, x, xl, xu, jacl, mu):
+        self._void("mnk_ipm_set_g_ifr", _dev(g), _dev(f), _dev(x), _dev(xl), _dev(xu), _dev(jacl), float(mu))
+
+    def initialize_variables(self, x, xl, xu, bound_push, bound_fac):
+        self._void("mnk_ipm_initialize_variables", _dev(x), _dev(xl), _dev(xu), int(x.numel()), float(bound_push),
+                   float(bound_fac))
+
     def close(self):
         if self._h:
             L.lib().mnk_ipm_destroy(self._h)

@@ -95,6 +95,15 @@ class _KKTCommon:
         L.check(fn(self._h, *[p for p, _ in ptrs], float(primal_reg), float(dual_reg), ptrs[0][1]),
                 self._PFX + "_set_aug_diagonal")
 
+    def set_aug_RR_device(self, x, xl, xu, zl, zu, D_R, pp, zp, nn, zn, zeta, primal_reg, dual_reg):
+        """`set_aug_RR!(kkt, solver, RR)` (reference `src/IPM/kernels.jl:72-87`) inside the handle, from device tensors:
+        reg = primal_reg + zeta D_R^2, du_diag = -dual_reg - pp/zp - nn/zn, bound terms and pr_diag as
+        `set_aug_diagonal!`."""
+        ptrs = [_ptr(v) for v in (x, xl, xu, zl, zu, D_R, pp, zp, nn, zn)]
+        assert all(loc == L.MNK_DEVICE for _, loc in ptrs), "set_aug_RR_device takes device tensors"
+        fn = getattr(L.lib(), self._PFX + "_set_aug_RR")
+        L.check(fn(self._h, *[p for p, _ in ptrs], float(zeta), float(primal_reg), float(dual_reg)), self._PFX + "_set_aug_RR")
+
     def regularize_diagonal_device(self, primal, dual):
         """`regularize_diagonal!(kkt, primal, dual)` (reference `src/KKT/KKTsystem.jl:222-226`) on the handle's own
         reg / pr_diag / du_diag."""

@@ -276,6 +276,92 @@ class HS15Model:
         return np.array([[h[0], h[1]], [h[1], h[2]]], order="F")
 
 
+class InfeasibleModel:
+    """The reference's `infeasible` test problem (lib/MadNLPTests/src/MadNLPTests.jl:120-136): min x^2 s.t. x == 0, x >= 1.
+    The reference's own suite requires the exit status INFEASIBLE_PROBLEM_DETECTED (reached through restore! / robust!)."""
+    n, m = 1, 1
+    x0 = np.zeros(1)
+    y0 = np.zeros(1)
+    lvar = np.array([1.0])
+    uvar = np.array([np.inf])
+    lcon = np.array([0.0])
+    ucon = np.array([0.0])
+    jac_I = np.array([0])
+    jac_J = np.array([0])
+    hess_I = np.array([0])
+    hess_J = np.array([0])
+    q = np.zeros(1)          # as a QP 0.5 x'Hx + q'x for the device-resident driver (H = [2], J = [1])
+
+    def obj(self, x):
+        return x[0] ** 2
+
+    def grad(self, x):
+        return np.array([2.0 * x[0]])
+
+    def cons(self, x):
+        return np.array([x[0]])
+
+    def jac_coord(self, x):
+        return np.array([1.0])
+
+    def jac_dense(self, x):
+        return np.array([[1.0]], order="F")
+
+    def hess_coord(self, x, y, w=1.0):
+        return np.array([2.0 * w])
+
+    def hess_dense(self, x, y, w=1.0):
+        return np.array([[2.0 * w]], order="F")
+
+
+class CubicDiskModel:
+    """min -x1  s.t.  x2 - x1^3 = 0,  x1^2 + x2^2 <= r.  Small nonconvex NLP whose runs from poor starting points leave the
+    regular phase (line-search failure -> restore! / robust!) and come back: used to exercise the restoration state machine.
+    Optimum: x1 = the positive root of t^2 + t^6 = r, x2 = x1^3 (`solution()`)."""
+    n, m = 2, 2
+    lvar = np.array([-np.inf, -np.inf])
+    uvar = np.array([np.inf, np.inf])
+    jac_I = np.array([0, 0, 1, 1])
+    jac_J = np.array([0, 1, 0, 1])
+    hess_I = np.array([0, 1, 1])
+    hess_J = np.array([0, 0, 1])
+
+    def __init__(self, r, x0):
+        self.r = float(r)
+        self.x0, self.y0 = np.array(x0, dtype=float), np.zeros(2)
+        self.lcon = np.array([0.0, -np.inf])
+        self.ucon = np.array([0.0, self.r])
+
+    def solution(self):
+        lo, hi = 0.0, max(1.0, self.r)
+        for _ in range(200):
+            t = 0.5 * (lo + hi)
+            lo, hi = (t, hi) if t ** 2 + t ** 6 < self.r else (lo, t)
+        return np.array([lo, lo ** 3])
+
+    def obj(self, x):
+        return -x[0]
+
+    def grad(self, x):
+        return np.array([-1.0, 0.0])
+
+    def cons(self, x):
+        return np.array([x[1] - x[0] ** 3, x[0] ** 2 + x[1] ** 2])
+
+    def jac_coord(self, x):
+        return np.array([-3.0 * x[0] ** 2, 1.0, 2.0 * x[0], 2.0 * x[1]])
+
+    def jac_dense(self, x):
+        return np.array([[-3.0 * x[0] ** 2, 1.0], [2.0 * x[0], 2.0 * x[1]]], order="F")
+
+    def hess_coord(self, x, y, w=1.0):
+        return np.array([-6.0 * x[0] * y[0] + 2.0 * y[1], 0.0, 2.0 * y[1]])
+
+    def hess_dense(self, x, y, w=1.0):
+        h = self.hess_coord(x, y, w)
+        return np.array([[h[0], h[1]], [h[1], h[2]]], order="F")
+
+
 class LootsmaModel:
     """The reference's `lootsma` test problem (lib/MadNLPTests/src/MadNLPTests.jl:153-194), the fixed
     variable par = 6 substituted:  min x1^3 + 11 x1 - 6 sqrt(x1) + x3  s.t.  -sqrt(x1) - sqrt(x2) + sqrt(x3) >= 0,

@@ -22,12 +22,36 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.mnk_version() == 100
     header = open(os.path.join(ROOT, "include", "madnlp_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(mnk_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mnk_[A-Za-z0-9_]+)\s*\(", header))
     assert len(declared) >= 35
     raw = C.CDLL(L.LIBPATH)
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} declared in the header but not exported"
     assert declared == set(L.SIGNATURES), "ctypes signature table out of sync with the header"
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/madnlp_hip.h against the ctypes table the Python mirror calls through: same number of
+    arguments, pointers where the header has pointers, double / int64_t / int where it has those."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "madnlp_hip.h")).read(), flags=re.S)
+    protos = re.findall(r"\b(?:int|const char\s*\*|void)\s+(mnk_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    assert len(protos) >= 100
+    for name, args in protos:
+        want = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        have = L.SIGNATURES[name][1]
+        assert len(want) == len(have), f"{name}: header has {len(want)} arguments, ctypes table {len(have)}"
+        for a, t in zip(want, have):
+            if "*" in a:
+                ok_ = t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents")
+            elif a.startswith("double"):
+                ok_ = t is C.c_double
+            elif a.startswith("int64_t"):
+                ok_ = t is C.c_int64
+            elif a.startswith("int "):
+                ok_ = t is C.c_int
+            else:
+                ok_ = True
+            assert ok_, f"{name}: header argument '{a}' bound as {t}"
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -38,7 +38,7 @@ def c_class(decl: str) -> str:
 def header_prototypes():
     text = re.sub(r"/\*.*?\*/", "", HDR, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(?:^|\n)\s*(const char\*|void\*|int64_t|int)\s+(mnk_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"(?:^|\n)\s*(const char\*|void\*|int64_t|int)\s+(mnk_[A-Za-z_0-9]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argl = [] if args in ("", "void") else [c_class(a) for a in args.split(",")]
         protos[name] = ({"int": "int", "int64_t": "int64", "const char*": "cstr", "void*": "handle"}[ret], argl)
@@ -47,7 +47,7 @@ def header_prototypes():
 
 def julia_ccalls():
     calls = []
-    for m in re.finditer(r"ccall\(\(:(mnk_[a-z_0-9]+),\s*libmadnlp_hip\),\s*([A-Za-z0-9{}]+),\s*\(([^)]*)\)", JL):
+    for m in re.finditer(r"ccall\(\(:(mnk_[A-Za-z_0-9]+),\s*libmadnlp_hip\),\s*([A-Za-z0-9{}]+),\s*\(([^)]*)\)", JL):
         name, ret, args = m.group(1), m.group(2), m.group(3)
         argl = [a.strip() for a in re.findall(r"Ptr\{Ptr\{Cvoid\}\}|Ptr\{[A-Za-z0-9]+\}|[A-Za-z0-9]+", args)]
         calls.append((name, ret, argl))
