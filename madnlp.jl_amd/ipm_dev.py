@@ -11,7 +11,6 @@ whose callbacks can be evaluated on the device -- here a QP, through the KKT han
 Jacobian / Hessian.  Initialization runs once on the host (the base class) and is uploaded."""
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch
@@ -30,10 +29,17 @@ class DeviceQPCallbacks:
         self.jv = torch.from_numpy(np.ascontiguousarray(nlp.jac_coord(None), dtype=np.float64)).to(dev)
         self.hv = torch.from_numpy(np.ascontiguousarray(nlp.hess_coord(None, None, 1.0), dtype=np.float64)).to(dev)
         self.hv0 = torch.zeros_like(self.hv)
+        self.handle_has_H = True
         self._hx = torch.empty(self.n, dtype=torch.float64, device=dev)
 
     def _hmul(self, x):
+        # the SpMV runs on the handle's compressed Lagrangian Hessian: while that holds something else (zero after
+        # initialize!(kkt), objective weight 0 in robust!) H is put back for the product
+        if not self.handle_has_H:
+            self.kkt.compress_hessian(self.hv)
         self.kkt.spmv_device(L.MNK_SC_HESS, 0, 1.0, x, 0.0, self._hx)
+        if not self.handle_has_H:
+            self.kkt.compress_hessian(self.hv0)
         return self._hx
 
     def obj(self, x):
@@ -108,6 +114,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         if not self._on_device:
             return super().eval_lag_hess(x, y, is_resto)
         self.kkt.compress_hessian(self.cb.hv0 if is_resto else self.cb.hv)   # objective weight 0 in robust!
+        self.cb.handle_has_H = not is_resto
 
     def jtprod(self, out, y):
         """`jtprod!` reference src/KKT/Sparse/condensed.jl:150-156."""
@@ -348,6 +355,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         reg = pr_diag = 1, du_diag = 0, l_diag = u_diag = 1, l_lower = u_lower = 0 through the feeder (x = 0, xl = 1,
         xu = -1, zl = zu = 0, primal_reg = 1)."""
         self.kkt.initialize()
+        self.cb.handle_has_H = False
         nt = self.nt
         z = np.zeros(nt)
         self.kkt.set_aug_diagonal_device(z, np.ones(nt), -np.ones(nt), z, z, 1.0, 0.0)

@@ -210,13 +210,14 @@ def test_device_restoration_elementwise_pieces(ctx, ntot, nlb, nub, m):
     eq(nn, ok.populate_RR_nn(c, mu_R, rho))
     x_ref, D_R, nn, pp, zp, zn = e(ntot), e(ntot), e(m), e(m), e(m), e(m)
     gzl, gzu = t(zl), t(zu)
-    K.initialize_robust_restorer(t(x), t(c), mu_R, rho, x_ref, D_R, nn, pp, zp, zn, gzl, gzu)
-    o = ok.initialize_robust_restorer(x, c, zl[lb], zu[ub], 0.1, rho)
+    rho_s = 5.0                               # small enough that the cap z_r = min(rho, z_r) fires
+    K.initialize_robust_restorer(t(x), t(c), mu_R, rho_s, x_ref, D_R, nn, pp, zp, zn, gzl, gzu)
+    o = ok.initialize_robust_restorer(x, c, zl[lb], zu[ub], 0.1, rho_s)
     assert o[2] == mu_R
     ozl, ozu = zl.copy(), zu.copy(); ozl[lb] = o[7]; ozu[ub] = o[8]
     for got, want in ((x_ref, o[0]), (D_R, o[1]), (nn, o[3]), (pp, o[4]), (zp, o[5]), (zn, o[6]), (gzl, ozl), (gzu, ozu)):
         eq(got, want)
-    assert (ozl != zl).any() or nlb < 10     # the cap at rho fired somewhere (multipliers range up to 1e3)
+    assert (ozl != zl).any() or nlb < 10     # the cap at rho_s fired somewhere (multipliers range up to 1e3)
     f_R = e(ntot); K.set_f_RR(f_R, t(d["D_R"]), t(x), t(d["x_ref"]), zeta)
     eq(f_R, ok.set_f_RR(d["D_R"], x, d["x_ref"], zeta))
     px, py, pzl, pzu = e(ntot), e(m), e(nlb), e(nub)
