@@ -1861,6 +1861,25 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             }
             MNK_HIP(hipMemsetAsync(ls->tile_ctr.p, 0, 8 * ((size_t)npanel + 1) * sizeof(int), s));
         }
+        // Deferred tail region (defer_rows > 0).  The early outer steps are throughput-bound and the last ones bound by
+        // the pivot chain with three quarters of the chip idle.  Panels 0 .. kd-1 therefore leave the region
+        // rows, columns >= c1 alone ((b) shrinks to the columns in front of c1); the missing K = Kd update of every later
+        // panel j is applied as ONE merged left-looking product D_j on the update stream, two panels ahead of its use,
+        // i.e. under the pivot chain of the tail.
+        int64_t kd = -1, c1 = Np, Kd = 0, ldwd = 0;
+        if (ls->defer_rows > 0 && npanel >= 4) {
+            for (int64_t i = 2; i < npanel; ++i)
+                if (Np - bnd[i] <= ls->defer_rows) { kd = i - 1; break; }
+            if (kd >= 1) {
+                c1 = bnd[kd + 1];
+                Kd = bnd[kd];
+                ldwd = Np - c1;
+                if (ldl && ls->wdefer.n < (size_t)(ldwd * Kd + SLACK)) {
+                    int rc0 = ls->wdefer.alloc((size_t)(ldwd * Kd + SLACK));
+                    if (rc0) return rc0;
+                }
+            } else kd = -1;
+        }
         // Panel 0 has nothing to overlap with: it runs on the caller's stream, i.e. on the whole chip (its
         // triangular solves and inner updates are throughput-bound at this height), before the fork.
         int rc = 0;
@@ -1883,6 +1902,10 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             const int64_t Kw = kend - ko;
             // ev_panel[k] is recorded after panel k and after the panel stream's share of (b)_{k-1}
             MNK_HIP(hipStreamWaitEvent(su, ctx->ev_panel[k], 0));
+            const bool early = kd >= 0 && k < kd;  // this panel does not touch the deferred region
+            if (early && ldl)  // keep L*D of the rows behind c1 for the merged updates
+                MNK_HIP(hipMemcpy2DAsync(ls->wdefer.p + ko * ldwd, ldwd * sizeof(double), wk + c1, ls->ldw * sizeof(double),
+                                         ldwd * sizeof(double), Kw, hipMemcpyDeviceToDevice, su));
             // (a) columns of the next outer panel, delivered in two pieces: its first 256-column middle
             // panel (the panel stream starts on it at once), then the remaining columns (needed only when
             // that middle panel is finished)
@@ -1932,21 +1955,36 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                     MNK_HIP(hipEventRecord(ctx->ev_next2[k], su));
                 }
             }
-            // (b) the rest of the trailing matrix
+            // D_{k+2}: the deferred K = Kd update of the panel after next (all its sources are final by now)
+            if (kd >= 0 && k >= kd - 1 && k + 2 < npanel) {
+                const int64_t j0 = bnd[k + 2], Nj = bnd[k + 3] - j0, Mj = Np - j0;
+                const double* Ad = ldl ? ls->wdefer.p + (j0 - c1) : F + j0;
+                const int64_t ldad = ldl ? ldwd : ld;
+                static const int defer_small = getenv("MNK_DEFER_SMALL") ? atoi(getenv("MNK_DEFER_SMALL")) : 1;
+                if (defer_small && gemm_nt_lower_tiles(Mj, Nj) < ls->small_tiles)
+                    rc = launch_gemm_nt_lower_small(su, Mj, Nj, Kd, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, ls->info_dev.p);
+                else
+                    rc = launch_gemm_nt(su, 2, Mj, Nj, Kd, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, nullptr, nullptr, 0,
+                                        ls->info_dev.p);
+                if (rc) return rc;
+            }
+            // (b) the rest of the trailing matrix: Mb rows, Nb columns of lower tiles (early panels: only the columns in
+            // front of c1, i.e. a trapezoid -- the rows behind c1 still get these columns)
             const int64_t Mb = Mt - nnext;
+            const int64_t Nb = early ? c1 - (kend + nnext) : Mb;
             bool shared_b = false;
-            if (Mb > 0) {
-                const int ntiles = gemm_nt_lower_tiles(Mb, Mb);
+            if (Mb > 0 && Nb > 0) {
+                const int ntiles = gemm_nt_lower_tiles(Mb, Nb);
                 // CU-us per 128x128xKw tile at ~80 % of the MFMA rate; ~55 us of panel stream per 64 columns
                 const double t_upd = ntiles * (68.0 * (double)Kw / 512.0) / ucus;
                 const double t_pan = 55.0 * (double)nnext / 64.0 * (pcus > 0 ? 64.0 / pcus : 1.0);
                 shared_b = share && pcus > 0 && (t_upd > t_pan || ls->share == 2);
                 if (shared_b)
-                    rc = launch_gemm_nt_queue(su, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
+                    rc = launch_gemm_nt_queue(su, Mb, Nb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
                                               F + (kend + nnext) + (kend + nnext) * ld, ld, ls->tile_ctr.p + 8 * k,
                                               ucus, ls->info_dev.p);
                 else
-                    rc = launch_gemm_nt(su, 2, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
+                    rc = launch_gemm_nt(su, 2, Mb, Nb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
                                         F + (kend + nnext) + (kend + nnext) * ld, ld, nullptr, nullptr, 0,
                                         ls->info_dev.p);
                 if (rc) return rc;
@@ -1959,7 +1997,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                                     fuse_a ? (ldl ? wk : F + ko * ld) : nullptr, ldws, fuse_a ? Kw : 0);
             if (rc) return rc;
             if (shared_b) {
-                rc = launch_gemm_nt_queue(sp, Mb, Mb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
+                rc = launch_gemm_nt_queue(sp, Mb, Nb, Kw, Wsrc + nnext, ldws, F + kend + nnext + ko * ld, ld,
                                           F + (kend + nnext) + (kend + nnext) * ld, ld, ls->tile_ctr.p + 8 * k,
                                           pcus, ls->info_dev.p);
                 if (rc) return rc;
