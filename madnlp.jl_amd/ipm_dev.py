@@ -6,9 +6,10 @@ right-hand sides live in HBM; per iteration only scalars cross PCIe.  Same algor
   * `mnk_ipm_*`:      the reductions and elementwise pieces of reference `src/IPM/kernels.jl`
   * torch:            axpy-type updates and copies on the device tensors (plumbing)
 
-Scope: `SparseCondensedKKTSystem` (all constraints relaxed to inequalities, as the reference's preset does) and models
-whose callbacks can be evaluated on the device -- here a QP, through the KKT handle's own SpMV on the compressed
-Jacobian / Hessian.  Initialization runs once on the host (the base class) and is uploaded."""
+Scope: `SparseCondensedKKTSystem` (all constraints relaxed to inequalities, as the reference's preset does) and
+`DenseCondensedKKTSystem` (equalities allowed), with models whose callbacks can be evaluated on the device -- here QPs: the
+sparse one through the KKT handle's own SpMV on the compressed Jacobian / Hessian, the dense one through torch matrix-vector
+products on device copies of P and A.  Initialization runs once on the host (the base class) and is uploaded."""
 from __future__ import annotations
 
 
@@ -53,11 +54,58 @@ class DeviceQPCallbacks:
     def cons(self, c, x):
         self.kkt.spmv_device(L.MNK_SC_JT, 1, 1.0, x, 0.0, c)
 
+    def jtprod_x(self, out_x, y):
+        self.kkt.spmv_device(L.MNK_SC_JT, 0, 1.0, y, 0.0, out_x)
+
+    def load_jac(self):
+        self.kkt.compress_jacobian(self.jv)
+
+    def load_hess(self, zero=False):
+        self.kkt.compress_hessian(self.hv0 if zero else self.hv)
+        self.handle_has_H = not zero
+
+
+class DeviceDenseQPCallbacks:
+    """f = 0.5 x'Px + q'x, c = Ax with dense P, A on the device (`DenseQPModel`); Hessian / Jacobian of the KKT handle are
+    loaded from these device copies (`mnk_dc_set_hess` / `mnk_dc_set_jac` with device pointers)."""
+
+    def __init__(self, nlp, kkt, dev):
+        self.kkt, self.n, self.m = kkt, nlp.n, nlp.m
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+        self.P, self.A, self.q = t(nlp.P), t(nlp.A), t(nlp.q)
+        # column-major device images for the handle (torch is row-major: the transpose's buffer IS the column-major matrix)
+        self.P_cm = self.P.t().contiguous()
+        self.A_cm = self.A.t().contiguous()          # (n, m) row-major == (m, n) column-major
+        self.P0_cm = torch.zeros_like(self.P_cm)
+        self.handle_has_H = True
+
+    def obj(self, x):
+        return float(0.5 * torch.dot(x, torch.mv(self.P, x)) + torch.dot(self.q, x))
+
+    def grad(self, g, x):
+        torch.mv(self.P, x, out=g)
+        g.add_(self.q)
+
+    def cons(self, c, x):
+        torch.mv(self.A, x, out=c)
+
+    def jtprod_x(self, out_x, y):
+        torch.mv(self.A.t(), y, out=out_x)
+
+    def load_jac(self):
+        if self.m > 0:
+            L.check(L.lib().mnk_dc_set_jac(self.kkt._h, self.A_cm.data_ptr(), self.m, L.MNK_DEVICE), "mnk_dc_set_jac")
+
+    def load_hess(self, zero=False):
+        src = self.P0_cm if zero else self.P_cm
+        L.check(L.lib().mnk_dc_set_hess(self.kkt._h, src.data_ptr(), self.n, L.MNK_DEVICE), "mnk_dc_set_hess")
+        self.handle_has_H = not zero
+
 
 class DeviceMadNLPSolver(MadNLPSolver):
-    def __init__(self, nlp, kkt_factory, opt: IPMOptions | None = None, device="cuda"):
-        super().__init__(nlp, kkt_factory, opt, sparse=True)
-        assert self.ns == self.m, "device driver: all-inequality (RelaxEquality) sparse condensed systems"
+    def __init__(self, nlp, kkt_factory, opt: IPMOptions | None = None, device="cuda", sparse=True):
+        super().__init__(nlp, kkt_factory, opt, sparse=sparse)
+        assert not sparse or self.ns == self.m, "device driver: all-inequality (RelaxEquality) sparse condensed systems"
         self.dev = torch.device(device)
         self._on_device = False
 
@@ -73,10 +121,14 @@ class DeviceMadNLPSolver(MadNLPSolver):
         self.dv, self.pv, self.w1v, self.w4v = V(), V(), V(), V()
         self.K = IPMDeviceKernels(nt, self.ind_lb, self.ind_ub, ctx=self.kkt.linear_solver.ctx)
         self.K.set_perturbation_sets(self.ind_llb, self.ind_uub)
-        self.cb = DeviceQPCallbacks(self.nlp, self.kkt, self.dev)
+        self.cb = (DeviceQPCallbacks if self.sparse else DeviceDenseQPCallbacks)(self.nlp, self.kkt, self.dev)
         self.ind_lb_t = torch.from_numpy(np.asarray(self.ind_lb, dtype=np.int64)).to(self.dev)
         self.ind_ub_t = torch.from_numpy(np.asarray(self.ind_ub, dtype=np.int64)).to(self.dev)
+        self.ind_ineq_t = torch.from_numpy(np.asarray(self.ind_ineq, dtype=np.int64)).to(self.dev)
         self.kkt.device_kkt_ops = True
+        if not self.sparse:          # the dense handle reads Hessian / Jacobian from its own device copies
+            self.cb.load_jac()
+            self.cb.load_hess()
         self._on_device = True
         self._sync = self.kkt.linear_solver.ctx.synchronize if hasattr(self.kkt.linear_solver.ctx, "synchronize") else None
 
@@ -102,24 +154,29 @@ class DeviceMadNLPSolver(MadNLPSolver):
         if not self._on_device:
             return super().eval_cons(c, x)
         self.cb.cons(c, x[:self.n])
-        c.sub_(x[self.n:])          # ind_ineq = all constraints, in order
+        if self.ns == self.m:
+            c.sub_(x[self.n:])      # ind_ineq = all constraints, in order
+        else:
+            c[self.ind_ineq_t] -= x[self.n:]
         c.sub_(self.rhs)
 
     def eval_jac(self, x):
         if not self._on_device:
             return super().eval_jac(x)
-        self.kkt.compress_jacobian(self.cb.jv)
+        self.cb.load_jac()
 
     def eval_lag_hess(self, x, y, is_resto=False):
         if not self._on_device:
             return super().eval_lag_hess(x, y, is_resto)
-        self.kkt.compress_hessian(self.cb.hv0 if is_resto else self.cb.hv)   # objective weight 0 in robust!
-        self.cb.handle_has_H = not is_resto
+        self.cb.load_hess(zero=is_resto)   # objective weight 0 in robust!
 
     def jtprod(self, out, y):
         """`jtprod!` reference src/KKT/Sparse/condensed.jl:150-156."""
-        self.kkt.spmv_device(L.MNK_SC_JT, 0, 1.0, y, 0.0, out[:self.n])
-        torch.neg(y, out=out[self.n:])
+        self.cb.jtprod_x(out[:self.n], y)
+        if self.ns == self.m:
+            torch.neg(y, out=out[self.n:])
+        else:
+            torch.neg(y[self.ind_ineq_t], out=out[self.n:])
 
     # ------------------------------------------------------------------ factorization glue
     def factorize_wrapper(self):
@@ -355,7 +412,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         reg = pr_diag = 1, du_diag = 0, l_diag = u_diag = 1, l_lower = u_lower = 0 through the feeder (x = 0, xl = 1,
         xu = -1, zl = zu = 0, primal_reg = 1)."""
         self.kkt.initialize()
-        self.cb.handle_has_H = False
+        self.cb.load_hess(zero=True)
         nt = self.nt
         z = np.zeros(nt)
         self.kkt.set_aug_diagonal_device(z, np.ones(nt), -np.ones(nt), z, z, 1.0, 0.0)

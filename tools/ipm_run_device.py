@@ -1,5 +1,6 @@
-"""End-to-end IPM run with DEVICE-RESIDENT vectors (madnlp_jl_amd.ipm_dev) next to the host mirror on the same
-OPF-shaped convex QP (default case1354pegase shape, N = 11192 condensed KKT): iterations, counts, wall clock."""
+"""End-to-end IPM run with DEVICE-RESIDENT vectors (madnlp_jl_amd.ipm_dev) next to the host mirror on the same convex QP:
+iterations, counts, wall clock.  usage: ipm_run_device.py [case]            OPF-shaped sparse condensed (default case1354pegase)
+                                                ipm_run_device.py dense n m [n_eq]   DenseDummyQP, DenseCondensedKKTSystem (C2: 2048 512)"""
 import json
 import os
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -13,16 +14,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import madnlp_jl_amd as mj  # noqa: E402
 from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver  # noqa: E402
 from madnlp_jl_amd.ipm_dev import DeviceMadNLPSolver  # noqa: E402
-from madnlp_jl_amd.problems import SparseQPModel  # noqa: E402
+from madnlp_jl_amd.problems import DenseQPModel, SparseQPModel  # noqa: E402
 
 case = sys.argv[1] if len(sys.argv) > 1 else "case1354pegase"
-nlp = SparseQPModel(case)
+dense = case == "dense"
+if dense:
+    dn, dm = int(sys.argv[2]), int(sys.argv[3])
+    dne = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    nlp = DenseQPModel(dn, dm, dne)
+    case = f"dense n={dn} m={dm} n_eq={dne}"
+else:
+    nlp = SparseQPModel(case)
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 ctx = mj.HipContext(0, stream=st.cuda_stream)
 
 
 def factory(info):
+    if dense:
+        return mj.DenseCondensedKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_eq"], info["ind_lb"], info["ind_ub"],
+                                          ctx=ctx, opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN),
+                                          device_kkt_ops=True)
     return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J, info["ind_ineq"],
                                        info["ind_lb"], info["ind_ub"], ctx=ctx,
                                        opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN),
@@ -30,6 +42,8 @@ def factory(info):
 
 
 def options():
+    if dense:
+        return IPMOptions(tol=1e-8)
     o = IPMOptions(tol=1e-6)
     o.relax_equality, o.dual_initialization = True, "zero"
     return o
@@ -37,7 +51,7 @@ def options():
 
 for label, cls in (("host mirror (numpy vectors, device KKT ops)", MadNLPSolver), ("device-resident vectors", DeviceMadNLPSolver)):
     for rep in range(2):  # second run: warm
-        s = cls(nlp, factory, options()) if cls is DeviceMadNLPSolver else cls(nlp, factory, options(), sparse=True)
+        s = cls(nlp, factory, options(), sparse=not dense)
         s.initialize()
         if cls is DeviceMadNLPSolver:
             s._upload()
