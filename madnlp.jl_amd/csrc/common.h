@@ -143,6 +143,9 @@ int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64
 int launch_gemm_nt_lower_range(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                                const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag,
                                int tile_begin, int tile_count);
+int launch_gemm_nt_splitk(hipStream_t s, int64_t M, int64_t N, int64_t K, int nsplit, const double* A, int64_t lda,
+                          const double* B, int64_t ldb, double* C, int64_t ldc, double* S, int64_t lds, int64_t sstride,
+                          const int* info_flag);
 int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                          const double* B, int64_t ldb, double* C, int64_t ldc, int* counter, int cus,
                          const int* info_flag);

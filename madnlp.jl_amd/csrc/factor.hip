@@ -1961,7 +1961,20 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                 const double* Ad = ldl ? ls->wdefer.p + (j0 - c1) : F + j0;
                 const int64_t ldad = ldl ? ldwd : ld;
                 static const int defer_small = getenv("MNK_DEFER_SMALL") ? atoi(getenv("MNK_DEFER_SMALL")) : 1;
-                if (defer_small && gemm_nt_lower_tiles(Mj, Nj) < ls->small_tiles)
+                static const int defer_split = getenv("MNK_DEFER_SPLIT") ? atoi(getenv("MNK_DEFER_SPLIT")) : 0;
+                int nsplit = defer_split;
+                while (nsplit > 1 && (Kd % nsplit != 0 || (Kd / nsplit) % 16 != 0)) --nsplit;
+                if (nsplit > 1) {
+                    // split-K: nsplit * tiles workgroups of the big-tile kernel, partial sums in scratch, fixed-order reduce
+                    const int64_t ldsx = Np - c1, sstride = ldsx * NBO;
+                    if (ls->sdefer.n < (size_t)(nsplit * sstride + SLACK)) {
+                        int rc0 = ls->sdefer.alloc((size_t)(nsplit * sstride + SLACK));
+                        if (rc0) return rc0;
+                        MNK_HIP(hipMemsetAsync(ls->sdefer.p, 0, ls->sdefer.n * sizeof(double), su));
+                    }
+                    rc = launch_gemm_nt_splitk(su, Mj, Nj, Kd, nsplit, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, ls->sdefer.p,
+                                               ldsx, sstride, ls->info_dev.p);
+                } else if (defer_small && gemm_nt_lower_tiles(Mj, Nj) < ls->small_tiles)
                     rc = launch_gemm_nt_lower_small(su, Mj, Nj, Kd, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, ls->info_dev.p);
                 else
                     rc = launch_gemm_nt(su, 2, Mj, Nj, Kd, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, nullptr, nullptr, 0,

@@ -51,6 +51,7 @@ struct mnk_ls {
     int64_t tail_rows = 4096; // outer panels are tail_nbo wide once this many rows (or fewer) remain: one persistent launch per panel with the fused prologue, no inner update (C3: 11.80 -> 11.71 ms; 0 disables)
     int64_t tail_nbo = 256;
     int64_t defer_rows = 0;   // > 0: the early outer panels do not update the last defer_rows rows/columns; merged left-looking updates under the tail's pivot chain do (factor.hip)
+    mnk::DevBuf<double> sdefer;  // split-K partial sums of the merged updates (zero between uses)
     mnk::DevBuf<double> wdefer;  // L*D of the rows behind the deferred region's first column (LDL^T only)
     int small_tiles_mid = 1000;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
