@@ -1961,8 +1961,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                 const double* Ad = ldl ? ls->wdefer.p + (j0 - c1) : F + j0;
                 const int64_t ldad = ldl ? ldwd : ld;
                 static const int defer_small = getenv("MNK_DEFER_SMALL") ? atoi(getenv("MNK_DEFER_SMALL")) : 1;
-                static const int defer_split = getenv("MNK_DEFER_SPLIT") ? atoi(getenv("MNK_DEFER_SPLIT")) : 0;
-                int nsplit = defer_split;
+                int nsplit = ls->defer_split;
                 while (nsplit > 1 && (Kd % nsplit != 0 || (Kd / nsplit) % 16 != 0)) --nsplit;
                 if (nsplit > 1) {
                     // split-K: nsplit * tiles workgroups of the big-tile kernel, partial sums in scratch, fixed-order reduce

@@ -50,6 +50,7 @@ struct mnk_ls {
     int64_t single_rows = 2560;  // systems up to this (padded) order are factored as ONE outer panel on the whole chip (with the fused tail panels the look-ahead schedule wins from N = 3072 on: 2.12 vs 2.34 ms at 4096)
     int64_t tail_rows = 4096; // outer panels are tail_nbo wide once this many rows (or fewer) remain: one persistent launch per panel with the fused prologue, no inner update (C3: 11.80 -> 11.71 ms; 0 disables)
     int64_t tail_nbo = 256;
+    int defer_split = 0;      // > 1: the merged updates of the deferred schedule run as split-K launches with this many chunks
     int64_t defer_rows = 0;   // > 0: the early outer panels do not update the last defer_rows rows/columns; merged left-looking updates under the tail's pivot chain do (factor.hip)
     mnk::DevBuf<double> sdefer;  // split-K partial sums of the merged updates (zero between uses)
     mnk::DevBuf<double> wdefer;  // L*D of the rows behind the deferred region's first column (LDL^T only)

@@ -271,6 +271,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_PP_NB8_ROWS")) ls->pp_nb8_rows = atol(e);
     if (const char* e = getenv("MNK_PP_FUSE_ROWS")) ls->pp_fuse_rows = atol(e);
     if (const char* e = getenv("MNK_DEFER_ROWS")) ls->defer_rows = atol(e);
+    if (const char* e = getenv("MNK_DEFER_SPLIT")) ls->defer_split = atoi(e);
     if (const char* e = getenv("MNK_OWN_COLS")) ls->own_cols = std::max<long>(64, atol(e) / 64 * 64);
     if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
     if (const char* e = getenv("MNK_OVERLAP")) ls->overlap = atoi(e);
@@ -349,6 +350,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "panel_algo")) { ls->panel_algo = (int)value; return 0; }
     if (!strcmp(key, "pp_fuse_rows")) { ls->pp_fuse_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "defer_rows")) { ls->defer_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "defer_split")) { ls->defer_split = (int)value; return 0; }
     if (!strcmp(key, "pp_nb")) { ls->pp_nb = (int)value == 4 ? 4 : 8; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
