@@ -293,6 +293,12 @@ int mnk_ipm_get_rel_search_norm(mnk_ipm* ipm, const double* x, const double* dx,
 int mnk_ipm_get_sd_sc(mnk_ipm* ipm, const double* l, int64_t m, const double* zl, const double* zu, double s_max,
                       double* out /* [sd, sc] */);                                      /* :684-695 */
 int mnk_ipm_get_norms(mnk_ipm* ipm, const double* c, int64_t m, double* out /* [norm(c, Inf), norm(c, 1)] */);
+/* Batch mode: between mnk_ipm_batch_begin and mnk_ipm_batch_end the mnk_ipm_get_* calls (regular and restoration phase) only
+ * enqueue their reductions and return at once; batch_end synchronizes ONCE and then stores every result into the `out` pointer
+ * its call was given (the pointers must stay valid until then; a scalar that divides a result -- sd, sc -- can be passed as 1
+ * and applied by the caller).  At most 32 reductions per batch (each call uses one to four). */
+int mnk_ipm_batch_begin(mnk_ipm* ipm);
+int mnk_ipm_batch_end(mnk_ipm* ipm);
 /* Elementwise pieces of the regular phase on device-resident vectors (asynchronous on the context's stream):
  *   mnk_ipm_set_aug_rhs            set_aug_rhs!  kernels.jl:113-131: px = -f + zl - zu - jacl, py = -c,
  *                                  pzl = (xl_r - x_lr) zl_r + mu, pzu = (xu_r - x_ur) zu_r - mu  (px ntot, py m, pzl nlb, pzu nub)

@@ -125,6 +125,8 @@ SIGNATURES = {
     "mnk_dc_get_diagonals": (C.c_int, [_vp] + [_vp] * 7),
     "mnk_ipm_create": (C.c_int, [_vp, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.POINTER(_vp)]),
     "mnk_ipm_destroy": (C.c_int, [_vp]),
+    "mnk_ipm_batch_begin": (C.c_int, [_vp]),
+    "mnk_ipm_batch_end": (C.c_int, [_vp]),
     "mnk_ipm_get_varphi": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
     "mnk_ipm_get_inf_du": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, C.POINTER(C.c_double)]),
     "mnk_ipm_get_inf_compl": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.POINTER(C.c_double)]),

@@ -7,6 +7,8 @@
 #pragma clang fp contract(off)
 #include <cfloat>
 #include <cmath>
+#include <functional>
+#include <utility>
 
 #include "common.h"
 
@@ -20,12 +22,17 @@ struct mnk_ipm {
     DevBuf<double> part;   // IPM_SLOTS x IPM_BLOCKS partials
     double* pin = nullptr;     // IPM_SLOTS pinned, device-mapped host words: the final reduction stores its result here
     double* pin_dev = nullptr;
+    // batch mode (mnk_ipm_batch_begin / _end): the get_* calls only enqueue their reductions into successive slots and
+    // leave a finalizer behind; ONE synchronization at batch_end, then every deferred `out` receives its value
+    bool batching = false;
+    int next_slot = 0;
+    std::vector<std::pair<int, std::function<void(const double*)>>> pending;  // (first slot, finalizer)
 };
 
 namespace {
 
 constexpr int IPM_BLOCKS = 256;
-constexpr int IPM_SLOTS = 4;   // reductions in flight per call (the restoration-phase functions have up to four terms)
+constexpr int IPM_SLOTS = 32;  // reductions in flight: up to four per call, several calls per batch
 constexpr int IPM_THREADS = 256;
 enum { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
 
@@ -147,11 +154,32 @@ int enqueue(mnk_ipm* h, F f, int64_t n, int slot) {
 
 inline double max0(double r) { return r != r ? r : fmax(0.0, r); }  // reference: max(zero, ...), NaN propagates
 
-int fetch(mnk_ipm* h, int count, double* out) {
-    // the final reductions stored their results straight into pinned, device-mapped host memory: poll the stream, read
+// first slot of a call that needs `count` reductions (-1: the batch is full)
+int slot_base(mnk_ipm* h, int count) {
+    if (!h->batching) return 0;
+    if (h->next_slot + count > IPM_SLOTS) {
+        set_error("mnk_ipm: more than %d reductions in one batch", IPM_SLOTS);
+        return -1;
+    }
+    const int b = h->next_slot;
+    h->next_slot += count;
+    return b;
+}
+
+// Outside a batch: wait for the stream, read the `count` results that start at slot `base` and run the finalizer (which
+// writes the caller's `out`).  Inside a batch: keep the finalizer for mnk_ipm_batch_end.
+template <class Fin>
+int finish(mnk_ipm* h, int base, int count, Fin fin) {
+    if (h->batching) {
+        h->pending.emplace_back(base, std::function<void(const double*)>(fin));
+        return 0;
+    }
+    // the final reductions stored their results straight into pinned, device-mapped host memory
     MNK_HIP(mnk::stream_wait(h->ctx->stream));
-    volatile double* pw = h->pin;
-    for (int i = 0; i < count; ++i) out[i] = pw[i];
+    volatile double* pw = h->pin + base;
+    double r[4];
+    for (int i = 0; i < count; ++i) r[i] = pw[i];
+    fin(r);
     return 0;
 }
 
@@ -204,114 +232,120 @@ int mnk_ipm_destroy(mnk_ipm* h) {
     MNK_REQUIRE((h) != nullptr && out != nullptr, who ": NULL argument"); \
     MNK_HIP(hipSetDevice((h)->ctx->device))
 
+int mnk_ipm_batch_begin(mnk_ipm* h) {
+    MNK_REQUIRE(h != nullptr && !h->batching, "mnk_ipm_batch_begin: NULL handle or a batch is already open");
+    h->batching = true;
+    h->next_slot = 0;
+    h->pending.clear();
+    return 0;
+}
+
+int mnk_ipm_batch_end(mnk_ipm* h) {
+    MNK_REQUIRE(h != nullptr && h->batching, "mnk_ipm_batch_end: no open batch");
+    h->batching = false;
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    MNK_HIP(mnk::stream_wait(h->ctx->stream));
+    double r[IPM_SLOTS];
+    volatile double* pw = h->pin;
+    for (int i = 0; i < h->next_slot; ++i) r[i] = pw[i];
+    for (auto& pf : h->pending) pf.second(r + pf.first);
+    h->pending.clear();
+    h->next_slot = 0;
+    return 0;
+}
+
+#define IPM_BASE(cnt)                 \
+    const int b = slot_base(h, cnt);  \
+    if (b < 0) return -1
+
 int mnk_ipm_get_varphi(mnk_ipm* h, double obj_val, const double* x, const double* xl, const double* xu, double mu,
                        double* out) {
     IPM_ENTER(h, "mnk_ipm_get_varphi");
-    int rc = enqueue<R_SUM>(h, FVarphi{x, xl, h->ind_lb.p, mu, 0}, h->nlb, 0) |
-             enqueue<R_SUM>(h, FVarphi{x, xu, h->ind_ub.p, mu, 1}, h->nub, 1);
+    IPM_BASE(2);
+    int rc = enqueue<R_SUM>(h, FVarphi{x, xl, h->ind_lb.p, mu, 0}, h->nlb, b) |
+             enqueue<R_SUM>(h, FVarphi{x, xu, h->ind_ub.p, mu, 1}, h->nub, b + 1);
     if (rc) return rc;
-    double r[2];
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    *out = obj_val + r[0] + r[1];
-    return 0;
+    return finish(h, b, 2, [=](const double* r) { *out = obj_val + r[0] + r[1]; });
 }
 
 int mnk_ipm_get_inf_du(mnk_ipm* h, const double* f, const double* zl, const double* zu, const double* jacl, double sd,
                        double* out) {
     IPM_ENTER(h, "mnk_ipm_get_inf_du");
-    int rc = enqueue<R_MAX>(h, FInfDu{f, zl, zu, jacl}, h->ntot, 0);
+    IPM_BASE(1);
+    int rc = enqueue<R_MAX>(h, FInfDu{f, zl, zu, jacl}, h->ntot, b);
     if (rc) return rc;
-    double r;
-    rc = fetch(h, 1, &r);
-    if (rc) return rc;
-    *out = max0(r) / sd;
-    return 0;
+    return finish(h, b, 1, [=](const double* r) { *out = max0(r[0]) / sd; });
 }
 
 int mnk_ipm_get_inf_compl(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
                           const double* zu, double mu, double sc, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_inf_compl");
-    int rc = enqueue<R_MAX>(h, FCompl{x, xl, zl, h->ind_lb.p, mu, 0, 1}, h->nlb, 0) |
-             enqueue<R_MAX>(h, FCompl{x, xu, zu, h->ind_ub.p, mu, 1, 1}, h->nub, 1);
+    IPM_BASE(2);
+    int rc = enqueue<R_MAX>(h, FCompl{x, xl, zl, h->ind_lb.p, mu, 0, 1}, h->nlb, b) |
+             enqueue<R_MAX>(h, FCompl{x, xu, zu, h->ind_ub.p, mu, 1, 1}, h->nub, b + 1);
     if (rc) return rc;
-    double r[2];
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    *out = ((r[0] != r[0] || r[1] != r[1]) ? NAN : max0(fmax(r[0], r[1]))) / sc;
-    return 0;
+    return finish(h, b, 2, [=](const double* r) { *out = ((r[0] != r[0] || r[1] != r[1]) ? NAN : max0(fmax(r[0], r[1]))) / sc; });
 }
 
 int mnk_ipm_get_min_complementarity(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
                                     const double* zu, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_min_complementarity");
-    int rc = enqueue<R_MIN>(h, FCompl{x, xl, zl, h->ind_lb.p, 0.0, 0, 0}, h->nlb, 0) |
-             enqueue<R_MIN>(h, FCompl{x, xu, zu, h->ind_ub.p, 0.0, 1, 0}, h->nub, 1);
+    IPM_BASE(2);
+    int rc = enqueue<R_MIN>(h, FCompl{x, xl, zl, h->ind_lb.p, 0.0, 0, 0}, h->nlb, b) |
+             enqueue<R_MIN>(h, FCompl{x, xu, zu, h->ind_ub.p, 0.0, 1, 0}, h->nub, b + 1);
     if (rc) return rc;
-    double r[2];
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    *out = (r[0] != r[0] || r[1] != r[1]) ? NAN : fmin(r[0], r[1]);
-    return 0;
+    return finish(h, b, 2, [=](const double* r) { *out = (r[0] != r[0] || r[1] != r[1]) ? NAN : fmin(r[0], r[1]); });
 }
 
 int mnk_ipm_get_average_complementarity(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
                                         const double* zu, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_average_complementarity");
     if (h->nlb + h->nub == 0) { *out = 0.0; return 0; }
-    int rc = enqueue<R_SUM>(h, FCompl{x, xl, zl, h->ind_lb.p, 0.0, 0, 0}, h->nlb, 0) |
-             enqueue<R_SUM>(h, FCompl{x, xu, zu, h->ind_ub.p, 0.0, 1, 0}, h->nub, 1);
+    IPM_BASE(2);
+    int rc = enqueue<R_SUM>(h, FCompl{x, xl, zl, h->ind_lb.p, 0.0, 0, 0}, h->nlb, b) |
+             enqueue<R_SUM>(h, FCompl{x, xu, zu, h->ind_ub.p, 0.0, 1, 0}, h->nub, b + 1);
     if (rc) return rc;
-    double r[2];
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    *out = (r[0] + r[1]) / (double)(h->nlb + h->nub);
-    return 0;
+    const double cnt = (double)(h->nlb + h->nub);
+    return finish(h, b, 2, [=](const double* r) { *out = (r[0] + r[1]) / cnt; });
 }
 
 int mnk_ipm_get_varphi_d(mnk_ipm* h, const double* f, const double* x, const double* xl, const double* xu,
                          const double* dx, double mu, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_varphi_d");
-    int rc = enqueue<R_SUM>(h, FVarphiD{f, x, xl, xu, dx, mu}, h->ntot, 0);
+    IPM_BASE(1);
+    int rc = enqueue<R_SUM>(h, FVarphiD{f, x, xl, xu, dx, mu}, h->ntot, b);
     if (rc) return rc;
-    return fetch(h, 1, out);
+    return finish(h, b, 1, [=](const double* r) { *out = r[0]; });
 }
 
 int mnk_ipm_get_alpha_max(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* dx, double tau,
                           double* out) {
     IPM_ENTER(h, "mnk_ipm_get_alpha_max");
-    int rc = enqueue<R_MIN>(h, FAlphaMax{x, xl, xu, dx, tau}, h->ntot, 0);
+    IPM_BASE(1);
+    int rc = enqueue<R_MIN>(h, FAlphaMax{x, xl, xu, dx, tau}, h->ntot, b);
     if (rc) return rc;
-    double r;
-    rc = fetch(h, 1, &r);
-    if (rc) return rc;
-    *out = r != r ? r : fmin(1.0, r);
-    return 0;
+    return finish(h, b, 1, [=](const double* r) { *out = r[0] != r[0] ? r[0] : fmin(1.0, r[0]); });
 }
 
 int mnk_ipm_get_alpha_z(mnk_ipm* h, const double* zl, const double* zu, const double* dzl, const double* dzu, double tau,
                         double* out) {
     IPM_ENTER(h, "mnk_ipm_get_alpha_z");
-    int rc = enqueue<R_MIN>(h, FAlphaZ{zl, dzl, h->ind_lb.p, tau}, h->nlb, 0) |
-             enqueue<R_MIN>(h, FAlphaZ{zu, dzu, h->ind_ub.p, tau}, h->nub, 1);
+    IPM_BASE(2);
+    int rc = enqueue<R_MIN>(h, FAlphaZ{zl, dzl, h->ind_lb.p, tau}, h->nlb, b) |
+             enqueue<R_MIN>(h, FAlphaZ{zu, dzu, h->ind_ub.p, tau}, h->nub, b + 1);
     if (rc) return rc;
-    double r[2];
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    const double m = fmin(r[0], r[1]);
-    *out = (r[0] != r[0] || r[1] != r[1]) ? NAN : fmin(1.0, m);
-    return 0;
+    return finish(h, b, 2, [=](const double* r) {
+        const double m = fmin(r[0], r[1]);
+        *out = (r[0] != r[0] || r[1] != r[1]) ? NAN : fmin(1.0, m);
+    });
 }
 
 int mnk_ipm_get_rel_search_norm(mnk_ipm* h, const double* x, const double* dx, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_rel_search_norm");
-    int rc = enqueue<R_MAX>(h, FRelNorm{x, dx}, h->ntot, 0);
+    IPM_BASE(1);
+    int rc = enqueue<R_MAX>(h, FRelNorm{x, dx}, h->ntot, b);
     if (rc) return rc;
-    double r;
-    rc = fetch(h, 1, &r);
-    if (rc) return rc;
-    *out = max0(r);
-    return 0;
+    return finish(h, b, 1, [=](const double* r) { *out = max0(r[0]); });
 }
 
 // get_sd / get_sc (kernels.jl:684-695): l = the constraint multipliers (m entries), zl / zu full-length
@@ -319,34 +353,29 @@ int mnk_ipm_get_sd_sc(mnk_ipm* h, const double* l, int64_t m, const double* zl, 
                       double* out /* [sd, sc] */) {
     IPM_ENTER(h, "mnk_ipm_get_sd_sc");
     MNK_REQUIRE(m >= 0, "mnk_ipm_get_sd_sc: bad size");
-    double r[2], nl = 0.0;
-    int rc = enqueue<R_SUM>(h, FAbs{zl, h->ind_lb.p}, h->nlb, 0) | enqueue<R_SUM>(h, FAbs{zu, h->ind_ub.p}, h->nub, 1);
+    IPM_BASE(3);
+    int rc = enqueue<R_SUM>(h, FAbs{zl, h->ind_lb.p}, h->nlb, b) | enqueue<R_SUM>(h, FAbs{zu, h->ind_ub.p}, h->nub, b + 1) |
+             enqueue<R_SUM>(h, FAbs{l, nullptr}, m, b + 2);
     if (rc) return rc;
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    rc = enqueue<R_SUM>(h, FAbs{l, nullptr}, m, 0);
-    if (rc) return rc;
-    rc = fetch(h, 1, &nl);
-    if (rc) return rc;
-    const double nz = r[0] + r[1];
     const double cnt_d = (double)std::max<int64_t>(1, m + h->nlb + h->nub), cnt_c = (double)std::max<int64_t>(1, h->nlb + h->nub);
-    out[0] = fmax(s_max, (nl + r[0] + r[1]) / cnt_d) / s_max;
-    out[1] = fmax(s_max, nz / cnt_c) / s_max;
-    return 0;
+    return finish(h, b, 3, [=](const double* r) {
+        const double nz = r[0] + r[1];
+        out[0] = fmax(s_max, (r[2] + r[0] + r[1]) / cnt_d) / s_max;
+        out[1] = fmax(s_max, nz / cnt_c) / s_max;
+    });
 }
 
 // get_inf_pr = norm(c, Inf) (kernels.jl:284) and theta = norm(c, 1) (solver.jl get_theta)
 int mnk_ipm_get_norms(mnk_ipm* h, const double* c, int64_t m, double* out /* [inf, one] */) {
     IPM_ENTER(h, "mnk_ipm_get_norms");
     MNK_REQUIRE(m >= 0, "mnk_ipm_get_norms: bad size");
-    int rc = enqueue<R_MAX>(h, FAbs{c, nullptr}, m, 0) | enqueue<R_SUM>(h, FAbs{c, nullptr}, m, 1);
+    IPM_BASE(2);
+    int rc = enqueue<R_MAX>(h, FAbs{c, nullptr}, m, b) | enqueue<R_SUM>(h, FAbs{c, nullptr}, m, b + 1);
     if (rc) return rc;
-    double r[2];
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    out[0] = max0(r[0]);
-    out[1] = r[1];
-    return 0;
+    return finish(h, b, 2, [=](const double* r) {
+        out[0] = max0(r[0]);
+        out[1] = r[1];
+    });
 }
 
 }  // extern "C"
@@ -550,33 +579,28 @@ int mnk_ipm_get_obj_val_R(mnk_ipm* h, const double* p, const double* n, int64_t 
                           const double* x_ref, double rho, double zeta, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_obj_val_R");
     IPM_M("mnk_ipm_get_obj_val_R");
-    int rc = enqueue<R_SUM>(h, FObjPN{p, n, rho}, m, 0) | enqueue<R_SUM>(h, FObjProx{D_R, x, x_ref, zeta}, h->ntot, 1);
+    IPM_BASE(2);
+    int rc = enqueue<R_SUM>(h, FObjPN{p, n, rho}, m, b) | enqueue<R_SUM>(h, FObjProx{D_R, x, x_ref, zeta}, h->ntot, b + 1);
     if (rc) return rc;
-    double r[2];
-    rc = fetch(h, 2, r);
-    if (rc) return rc;
-    *out = r[0] + r[1];
-    return 0;
+    return finish(h, b, 2, [=](const double* r) { *out = r[0] + r[1]; });
 }
 
 int mnk_ipm_get_theta_R(mnk_ipm* h, const double* c, const double* p, const double* n, int64_t m, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_theta_R");
     IPM_M("mnk_ipm_get_theta_R");
-    int rc = enqueue<R_SUM>(h, FCPN{c, p, n}, m, 0);
+    IPM_BASE(1);
+    int rc = enqueue<R_SUM>(h, FCPN{c, p, n}, m, b);
     if (rc) return rc;
-    return fetch(h, 1, out);
+    return finish(h, b, 1, [=](const double* r) { *out = r[0]; });
 }
 
 int mnk_ipm_get_inf_pr_R(mnk_ipm* h, const double* c, const double* p, const double* n, int64_t m, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_inf_pr_R");
     IPM_M("mnk_ipm_get_inf_pr_R");
-    int rc = enqueue<R_MAX>(h, FCPN{c, p, n}, m, 0);
+    IPM_BASE(1);
+    int rc = enqueue<R_MAX>(h, FCPN{c, p, n}, m, b);
     if (rc) return rc;
-    double r;
-    rc = fetch(h, 1, &r);
-    if (rc) return rc;
-    *out = max0(r);
-    return 0;
+    return finish(h, b, 1, [=](const double* r) { *out = max0(r[0]); });
 }
 
 int mnk_ipm_get_inf_du_R(mnk_ipm* h, const double* f_R, const double* l, const double* zl, const double* zu,
@@ -584,14 +608,11 @@ int mnk_ipm_get_inf_du_R(mnk_ipm* h, const double* f_R, const double* l, const d
                          double* out) {
     IPM_ENTER(h, "mnk_ipm_get_inf_du_R");
     IPM_M("mnk_ipm_get_inf_du_R");
-    int rc = enqueue<R_MAX>(h, FInfDu{f_R, zl, zu, jacl}, h->ntot, 0) | enqueue<R_MAX>(h, FRhoL{l, zp, rho, 0}, m, 1) |
-             enqueue<R_MAX>(h, FRhoL{l, zn, rho, 1}, m, 2);
+    IPM_BASE(3);
+    int rc = enqueue<R_MAX>(h, FInfDu{f_R, zl, zu, jacl}, h->ntot, b) | enqueue<R_MAX>(h, FRhoL{l, zp, rho, 0}, m, b + 1) |
+             enqueue<R_MAX>(h, FRhoL{l, zn, rho, 1}, m, b + 2);
     if (rc) return rc;
-    double r[3];
-    rc = fetch(h, 3, r);
-    if (rc) return rc;
-    *out = nanmax(0.0, nanmax(r[0], nanmax(r[1], r[2]))) / sd;
-    return 0;
+    return finish(h, b, 3, [=](const double* r) { *out = nanmax(0.0, nanmax(r[0], nanmax(r[1], r[2]))) / sd; });
 }
 
 int mnk_ipm_get_inf_compl_R(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* zl,
@@ -599,15 +620,14 @@ int mnk_ipm_get_inf_compl_R(mnk_ipm* h, const double* x, const double* xl, const
                             int64_t m, double mu_R, double sc, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_inf_compl_R");
     IPM_M("mnk_ipm_get_inf_compl_R");
-    int rc = enqueue<R_MAX>(h, FCompl{x, xl, zl, h->ind_lb.p, mu_R, 0, 1}, h->nlb, 0) |
-             enqueue<R_MAX>(h, FCompl{x, xu, zu, h->ind_ub.p, mu_R, 1, 1}, h->nub, 1) |
-             enqueue<R_MAX>(h, FProdMu{pp, zp, mu_R}, m, 2) | enqueue<R_MAX>(h, FProdMu{nn, zn, mu_R}, m, 3);
+    IPM_BASE(4);
+    int rc = enqueue<R_MAX>(h, FCompl{x, xl, zl, h->ind_lb.p, mu_R, 0, 1}, h->nlb, b) |
+             enqueue<R_MAX>(h, FCompl{x, xu, zu, h->ind_ub.p, mu_R, 1, 1}, h->nub, b + 1) |
+             enqueue<R_MAX>(h, FProdMu{pp, zp, mu_R}, m, b + 2) | enqueue<R_MAX>(h, FProdMu{nn, zn, mu_R}, m, b + 3);
     if (rc) return rc;
-    double r[4];
-    rc = fetch(h, 4, r);
-    if (rc) return rc;
-    *out = nanmax(0.0, nanmax(nanmax(r[0], r[1]), nanmax(r[2], r[3]))) / sc;
-    return 0;
+    return finish(h, b, 4, [=](const double* r) {
+        *out = nanmax(0.0, nanmax(nanmax(r[0], r[1]), nanmax(r[2], r[3]))) / sc;
+    });
 }
 
 int mnk_ipm_get_alpha_max_R(mnk_ipm* h, const double* x, const double* xl, const double* xu, const double* dx,
@@ -615,14 +635,11 @@ int mnk_ipm_get_alpha_max_R(mnk_ipm* h, const double* x, const double* xl, const
                             double tau_R, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_alpha_max_R");
     IPM_M("mnk_ipm_get_alpha_max_R");
-    int rc = enqueue<R_MIN>(h, FAlphaMax{x, xl, xu, dx, tau_R}, h->ntot, 0) |
-             enqueue<R_MIN>(h, FStepRatio{pp, dpp, tau_R}, m, 1) | enqueue<R_MIN>(h, FStepRatio{nn, dnn, tau_R}, m, 2);
+    IPM_BASE(3);
+    int rc = enqueue<R_MIN>(h, FAlphaMax{x, xl, xu, dx, tau_R}, h->ntot, b) |
+             enqueue<R_MIN>(h, FStepRatio{pp, dpp, tau_R}, m, b + 1) | enqueue<R_MIN>(h, FStepRatio{nn, dnn, tau_R}, m, b + 2);
     if (rc) return rc;
-    double r[3];
-    rc = fetch(h, 3, r);
-    if (rc) return rc;
-    *out = nanmin(1.0, nanmin(r[0], nanmin(r[1], r[2])));
-    return 0;
+    return finish(h, b, 3, [=](const double* r) { *out = nanmin(1.0, nanmin(r[0], nanmin(r[1], r[2]))); });
 }
 
 int mnk_ipm_get_alpha_z_R(mnk_ipm* h, const double* zl, const double* zu, const double* dzl, const double* dzu,
@@ -630,45 +647,38 @@ int mnk_ipm_get_alpha_z_R(mnk_ipm* h, const double* zl, const double* zu, const 
                           double tau_R, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_alpha_z_R");
     IPM_M("mnk_ipm_get_alpha_z_R");
-    int rc = enqueue<R_MIN>(h, FAlphaZ{zl, dzl, h->ind_lb.p, tau_R}, h->nlb, 0) |
-             enqueue<R_MIN>(h, FAlphaZ{zu, dzu, h->ind_ub.p, tau_R}, h->nub, 1) |
-             enqueue<R_MIN>(h, FStepRatio{zp, dzp, tau_R}, m, 2) | enqueue<R_MIN>(h, FStepRatio{zn, dzn, tau_R}, m, 3);
+    IPM_BASE(4);
+    int rc = enqueue<R_MIN>(h, FAlphaZ{zl, dzl, h->ind_lb.p, tau_R}, h->nlb, b) |
+             enqueue<R_MIN>(h, FAlphaZ{zu, dzu, h->ind_ub.p, tau_R}, h->nub, b + 1) |
+             enqueue<R_MIN>(h, FStepRatio{zp, dzp, tau_R}, m, b + 2) | enqueue<R_MIN>(h, FStepRatio{zn, dzn, tau_R}, m, b + 3);
     if (rc) return rc;
-    double r[4];
-    rc = fetch(h, 4, r);
-    if (rc) return rc;
-    *out = nanmin(1.0, nanmin(nanmin(r[0], r[1]), nanmin(r[2], r[3])));
-    return 0;
+    return finish(h, b, 4, [=](const double* r) {
+        *out = nanmin(1.0, nanmin(nanmin(r[0], r[1]), nanmin(r[2], r[3])));
+    });
 }
 
 int mnk_ipm_get_varphi_R(mnk_ipm* h, double obj_val, const double* x, const double* xl, const double* xu, const double* pp,
                          const double* nn, int64_t m, double mu_R, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_varphi_R");
     IPM_M("mnk_ipm_get_varphi_R");
-    int rc = enqueue<R_SUM>(h, FLogBar{x, xl, h->ind_lb.p, mu_R, 0}, h->nlb, 0) |
-             enqueue<R_SUM>(h, FLogBar{x, xu, h->ind_ub.p, mu_R, 1}, h->nub, 1) | enqueue<R_SUM>(h, FLog1{pp, mu_R}, m, 2) |
-             enqueue<R_SUM>(h, FLog1{nn, mu_R}, m, 3);
+    IPM_BASE(4);
+    int rc = enqueue<R_SUM>(h, FLogBar{x, xl, h->ind_lb.p, mu_R, 0}, h->nlb, b) |
+             enqueue<R_SUM>(h, FLogBar{x, xu, h->ind_ub.p, mu_R, 1}, h->nub, b + 1) |
+             enqueue<R_SUM>(h, FLog1{pp, mu_R}, m, b + 2) | enqueue<R_SUM>(h, FLog1{nn, mu_R}, m, b + 3);
     if (rc) return rc;
-    double r[4];
-    rc = fetch(h, 4, r);
-    if (rc) return rc;
-    *out = obj_val - (r[0] + r[1] + r[2] + r[3]);
-    return 0;
+    return finish(h, b, 4, [=](const double* r) { *out = obj_val - (r[0] + r[1] + r[2] + r[3]); });
 }
 
 int mnk_ipm_get_F(mnk_ipm* h, const double* c, int64_t m, const double* f, const double* zl, const double* zu,
                   const double* jacl, const double* x, const double* xl, const double* xu, double mu, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_F");
     IPM_M("mnk_ipm_get_F");
-    int rc = enqueue<R_SUM>(h, FAbs{c, nullptr}, m, 0) | enqueue<R_SUM>(h, FSumDu{f, zl, zu, jacl}, h->ntot, 1) |
-             enqueue<R_SUM>(h, FFBound{x, xl, zl, h->ind_lb.p, mu, 0}, h->nlb, 2) |
-             enqueue<R_SUM>(h, FFBound{x, xu, zu, h->ind_ub.p, mu, 1}, h->nub, 3);
+    IPM_BASE(4);
+    int rc = enqueue<R_SUM>(h, FAbs{c, nullptr}, m, b) | enqueue<R_SUM>(h, FSumDu{f, zl, zu, jacl}, h->ntot, b + 1) |
+             enqueue<R_SUM>(h, FFBound{x, xl, zl, h->ind_lb.p, mu, 0}, h->nlb, b + 2) |
+             enqueue<R_SUM>(h, FFBound{x, xu, zu, h->ind_ub.p, mu, 1}, h->nub, b + 3);
     if (rc) return rc;
-    double r[4];
-    rc = fetch(h, 4, r);
-    if (rc) return rc;
-    *out = r[0] + r[1] + r[2] + r[3];
-    return 0;
+    return finish(h, b, 4, [=](const double* r) { *out = r[0] + r[1] + r[2] + r[3]; });
 }
 
 int mnk_ipm_get_varphi_d_R(mnk_ipm* h, const double* f_R, const double* x, const double* xl, const double* xu,
@@ -676,14 +686,11 @@ int mnk_ipm_get_varphi_d_R(mnk_ipm* h, const double* f_R, const double* x, const
                            int64_t m, double mu_R, double rho, double* out) {
     IPM_ENTER(h, "mnk_ipm_get_varphi_d_R");
     IPM_M("mnk_ipm_get_varphi_d_R");
-    int rc = enqueue<R_SUM>(h, FVarphiD{f_R, x, xl, xu, dx, mu_R}, h->ntot, 0) |
-             enqueue<R_SUM>(h, FRhoMu{pp, dpp, mu_R, rho}, m, 1) | enqueue<R_SUM>(h, FRhoMu{nn, dnn, mu_R, rho}, m, 2);
+    IPM_BASE(3);
+    int rc = enqueue<R_SUM>(h, FVarphiD{f_R, x, xl, xu, dx, mu_R}, h->ntot, b) |
+             enqueue<R_SUM>(h, FRhoMu{pp, dpp, mu_R, rho}, m, b + 1) | enqueue<R_SUM>(h, FRhoMu{nn, dnn, mu_R, rho}, m, b + 2);
     if (rc) return rc;
-    double r[3];
-    rc = fetch(h, 3, r);
-    if (rc) return rc;
-    *out = r[0] + r[1] + r[2];
-    return 0;
+    return finish(h, b, 3, [=](const double* r) { *out = r[0] + r[1] + r[2]; });
 }
 
 }  // extern "C"

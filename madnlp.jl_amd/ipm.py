@@ -558,6 +558,11 @@ class MadNLPSolver:
 
     def _inf_du(self, sd): return float(np.abs(self.f - self.zl + self.zu + self.jacl).max(initial=0.0) / sd)
 
+    def _iteration_scalars(self):
+        """sd, sc, inf_pr, inf_du, inf_compl(mu = 0) at the top of an iteration (solver.jl:224-234)."""
+        sd, sc = self._sd_sc()
+        return sd, sc, self._norm_inf(self.c), self._inf_du(sd), self.inf_compl(0.0, sc)
+
     def _jtprod(self): self.kkt.jtprod(self.jacl, self.y)
 
     def _alpha_z(self, tau):
@@ -760,10 +765,7 @@ class MadNLPSolver:
             self.cnt.t += 1
             if self.cnt.k >= o.max_iter:
                 return "MAXIMUM_ITERATIONS_EXCEEDED"
-            sd, sc = self._sd_sc()
-            self.inf_pr = self._norm_inf(self.c)
-            self.inf_du = self._inf_du(sd)
-            self.inf_compl_v = self.inf_compl(0.0, sc)
+            sd, sc, self.inf_pr, self.inf_du, self.inf_compl_v = self._iteration_scalars()
             self._record("r")
             self.eval_lag_hess(self.x, self.y)
             self.set_aug_diagonal()
@@ -816,10 +818,7 @@ class MadNLPSolver:
         while True:
             self.eval_jac(self.x)
             self._jtprod()
-            sd, sc = self._sd_sc()
-            self.inf_pr = self._norm_inf(self.c)
-            self.inf_du = self._inf_du(sd)
-            self.inf_compl_v = self.inf_compl(0.0, sc)
+            sd, sc, self.inf_pr, self.inf_du, self.inf_compl_v = self._iteration_scalars()
             RR.inf_pr_R = self._rr_inf_pr()
             RR.inf_du_R = self._rr_inf_du(sd)
             RR.inf_compl_R = self._rr_inf_compl(0.0, sc)
@@ -955,10 +954,7 @@ class MadNLPSolver:
             if self.cnt.k != 0:
                 self.eval_jac(self.x)
             self._jtprod()
-            sd, sc = self._sd_sc()
-            self.inf_pr = self._norm_inf(self.c)
-            self.inf_du = self._inf_du(sd)
-            self.inf_compl_v = self.inf_compl(0.0, sc)
+            sd, sc, self.inf_pr, self.inf_du, self.inf_compl_v = self._iteration_scalars()
             self._record()
             inf_total = max(self.inf_pr, self.inf_du, self.inf_compl_v)
             if inf_total <= o.tol:

@@ -200,8 +200,10 @@ class DeviceMadNLPSolver(MadNLPSolver):
                 x.add_(w)
                 w.copy_(b)
                 self.kkt.mul_device(w, x, -1.0, 1.0)
-                norm_w = self.K.get_norms(w)[0]
-                norm_x = self.K.get_norms(x)[0]
+                with self.K.batch():
+                    b_w = self.K.get_norms(w)
+                    b_x = self.K.get_norms(x)
+                norm_w, norm_x = b_w[0], b_x[0]
                 residual_ratio = norm_w / (min(norm_x, 1e6 * norm_b) + norm_b)
                 it.ir += 1
                 if it.ir >= it.richardson_max_iter or residual_ratio < it.richardson_tol:
@@ -270,11 +272,14 @@ class DeviceMadNLPSolver(MadNLPSolver):
     def filter_line_search(self):
         o, K = self.opt, self.K
         dx = self._primal(self.dv)
-        theta = K.get_norms(self.c)[1]
-        varphi = self.varphi(self.obj_val, self.x)
-        varphi_d = K.get_varphi_d(self.f, self.x, self.xl, self.xu, dx, self.mu)
-        alpha_max = self.alpha_max(dx)
-        self.alpha_z = K.get_alpha_z(self.zl, self.zu, self._dual_lb(self.dv), self._dual_ub(self.dv), self.tau)
+        with K.batch():     # six reductions, one synchronization
+            b_n = K.get_norms(self.c)
+            b_v = K.get_varphi(self.obj_val, self.x, self.xl, self.xu, self.mu)
+            b_d = K.get_varphi_d(self.f, self.x, self.xl, self.xu, dx, self.mu)
+            b_a = K.get_alpha_max(self.x, self.xl, self.xu, dx, self.tau)
+            b_z = K.get_alpha_z(self.zl, self.zu, self._dual_lb(self.dv), self._dual_ub(self.dv), self.tau)
+            b_r = K.get_rel_search_norm(self.x, dx)
+        theta, varphi, varphi_d, alpha_max, self.alpha_z, rel_norm = b_n[1], b_v[0], b_d[0], b_a[0], b_z[0], b_r[0]
         if varphi_d < 0:
             if theta <= self.theta_min:
                 alpha_min = o.alpha_min_frac * min(o.gamma_theta, o.gamma_phi * theta / (-varphi_d),
@@ -285,7 +290,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
             alpha_min = o.alpha_min_frac * o.gamma_theta
         self.cnt.l = 1
         self.alpha = alpha_max
-        small = K.get_rel_search_norm(self.x, dx) < 10 * EPS
+        small = rel_norm < 10 * EPS
         switching = varphi_d < 0 and self.alpha * _pow(-varphi_d, o.s_phi) > o.delta * 2.0 ** o.s_theta
         armijo = False
         unsuccessful = False
@@ -295,8 +300,10 @@ class DeviceMadNLPSolver(MadNLPSolver):
             torch.add(self.x, dx, alpha=self.alpha, out=self.x_trial)
             self.obj_val_trial = self.eval_f(self.x_trial)
             self.eval_cons(self.c_trial, self.x_trial)
-            theta_trial = K.get_norms(self.c_trial)[1]
-            varphi_trial = self.varphi(self.obj_val_trial, self.x_trial)
+            with K.batch():
+                b_n = K.get_norms(self.c_trial)
+                b_v = K.get_varphi(self.obj_val_trial, self.x_trial, self.xl, self.xu, self.mu)
+            theta_trial, varphi_trial = b_n[1], b_v[0]
             armijo = varphi_trial <= varphi + o.eta_phi * self.alpha * varphi_d
             if small:
                 break
@@ -382,6 +389,17 @@ class DeviceMadNLPSolver(MadNLPSolver):
     def _sd_sc(self): return self.K.get_sd_sc(self.y, self.zl, self.zu, self.opt.s_max)
 
     def _inf_du(self, sd): return self.K.get_inf_du(self.f, self.zl, self.zu, self.jacl, sd)
+
+    def _iteration_scalars(self):
+        """the five reductions of the iteration header in ONE synchronization (`mnk_ipm_batch_*`)."""
+        K = self.K
+        with K.batch():
+            b_s = K.get_sd_sc(self.y, self.zl, self.zu, self.opt.s_max)
+            b_n = K.get_norms(self.c)
+            b_d = K.get_inf_du(self.f, self.zl, self.zu, self.jacl, 1.0)
+            b_c = K.get_inf_compl(self.x, self.xl, self.xu, self.zl, self.zu, 0.0, 1.0)
+        sd, sc = b_s[0], b_s[1]
+        return sd, sc, b_n[0], b_d[0] / sd, b_c[0] / sc
 
     def _jtprod(self): self.jtprod(self.jacl, self.y)
 

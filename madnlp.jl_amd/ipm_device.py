@@ -4,6 +4,7 @@ Python float.  Same names as the reference; the `_r` views are taken inside the 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -17,6 +18,27 @@ def _dev(v):
     return p
 
 
+class _Batch:
+    """MNK_IPM_NO_BATCH=1 (A/B): the calls of the block synchronize one by one, as outside a batch."""
+    _off = os.environ.get("MNK_IPM_NO_BATCH", "0") not in ("", "0")
+
+    def __init__(self, K):
+        self.K = K
+
+    def __enter__(self):
+        if not self._off:
+            L.check(L.lib().mnk_ipm_batch_begin(self.K._h), "mnk_ipm_batch_begin")
+        self.K._batching, self.K._keep = True, []
+        return self.K
+
+    def __exit__(self, *exc):
+        self.K._batching = False
+        if not self._off:
+            L.check(L.lib().mnk_ipm_batch_end(self.K._h), "mnk_ipm_batch_end")
+        self.K._keep = []
+        return False
+
+
 class IPMDeviceKernels:
     def __init__(self, ntot, ind_lb, ind_ub, ctx: HipContext | None = None):
         self.ctx = ctx or HipContext()
@@ -27,10 +49,20 @@ class IPMDeviceKernels:
         L.check(L.lib().mnk_ipm_create(self.ctx.handle, self.ntot, len(lb), lb.ctypes.data, len(ub), ub.ctypes.data, 0,
                                        C.byref(self._h)), "mnk_ipm_create")
 
+    _batching = False
+
     def _call(self, name, *args, n=1):
         out = (C.c_double * n)()
         L.check(getattr(L.lib(), name)(self._h, *args, out), name)
+        if self._batching:          # filled by batch_end: the caller reads out[i] after the `with` block
+            self._keep.append(out)
+            return out
         return out[0] if n == 1 else tuple(out)
+
+    def batch(self):
+        """`with K.batch(): a = K.get_...(); b = K.get_...()` -- the calls only enqueue their reductions and return their
+        result buffers; ONE synchronization when the block ends, after which `a[0]`, `b[0]`, ... hold the values."""
+        return _Batch(self)
 
     def get_varphi(self, obj_val, x, xl, xu, mu):
         return self._call("mnk_ipm_get_varphi", float(obj_val), _dev(x), _dev(xl), _dev(xu), float(mu))

@@ -260,3 +260,39 @@ def test_device_elementwise_pieces_bit_exact(ctx, ntot, nlb, nub, m):
     np.testing.assert_array_equal(dzl.cpu().numpy(), ozl); np.testing.assert_array_equal(dzu.cpu().numpy(), ozu)
     assert (ozl[np.isinf(xl)] == 0).all() and (ozu[np.isinf(xu)] == 0).all()
     K.close()
+
+
+@pytest.mark.gpu
+def test_batched_reductions_equal_the_unbatched_ones(ctx):
+    """`mnk_ipm_batch_begin/_end`: the calls of a batch only enqueue; one synchronization; the deferred results are bit-identical
+    to the same calls issued one by one (regular and restoration phase); an over-full or nested batch is an error."""
+    import madnlp_jl_amd as mj
+    rng = np.random.default_rng(99)
+    ntot, nlb, nub, m = 5000, 2100, 1900, 1500
+    d = _data(rng, ntot, nlb, nub, m)
+    g = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items() if k not in ("lb", "ub")}
+    pp, zp = torch.rand(m, dtype=torch.float64, device="cuda") + 0.1, torch.rand(m, dtype=torch.float64, device="cuda") + 0.1
+    K = mj.IPMDeviceKernels(ntot, d["lb"], d["ub"], ctx=ctx)
+    calls = [lambda: K.get_sd_sc(g["y"], g["zl"], g["zu"], 100.0), lambda: K.get_norms(g["c"]),
+             lambda: K.get_inf_du(g["f"], g["zl"], g["zu"], g["jacl"], 1.7),
+             lambda: K.get_inf_compl(g["x"], g["xl"], g["xu"], g["zl"], g["zu"], 0.01, 2.3),
+             lambda: K.get_varphi(3.5, g["x"], g["xl"], g["xu"], 0.01),
+             lambda: K.get_varphi_d(g["f"], g["x"], g["xl"], g["xu"], g["dx"], 0.01),
+             lambda: K.get_alpha_max(g["x"], g["xl"], g["xu"], g["dx"], 0.99),
+             lambda: K.get_alpha_z(g["zl"], g["zu"], g["dzl"], g["dzu"], 0.99),
+             lambda: K.get_rel_search_norm(g["x"], g["dx"]),
+             lambda: K.get_inf_compl_R(g["x"], g["xl"], g["xu"], g["zl"], g["zu"], pp, zp, pp, zp, 0.01, 2.3),
+             lambda: K.get_theta_R(g["c"], pp, zp)]
+    one_by_one = [f() for f in calls]
+    with K.batch():
+        bufs = [f() for f in calls]
+    for a, b in zip(one_by_one, bufs):
+        a = a if isinstance(a, tuple) else (a,)
+        assert tuple(b) == a
+    assert K.get_norms(g["c"]) == one_by_one[1]          # plain calls work again after the batch
+    with pytest.raises(mj.HipError):
+        with K.batch():
+            for _ in range(20):
+                K.get_norms(g["c"])                      # 2 slots each: the 17th call does not fit
+    assert K.get_norms(g["c"]) == one_by_one[1]          # ... and the handle is usable afterwards
+    K.close()
