@@ -724,24 +724,28 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             const double y32 = -(l32 * y22) * rd3;
             // A operand of step 2: lane (i, k) holds inv(L44)[i - 4tt][k] on the rows of the pivot group, else 0
             const int ii = l15 - 4 * tt;
-            const double yr0 = l4 == 0 ? y00 : 0.0;
-            const double yr1 = l4 == 0 ? y10 : (l4 == 1 ? y11 : 0.0);
-            const double yr2 = l4 == 0 ? y20 : (l4 == 1 ? y21 : (l4 == 2 ? y22 : 0.0));
-            const double yr3 = l4 == 0 ? y30 : (l4 == 1 ? y31 : (l4 == 2 ? y32 : y33));
+            // entry (ii, l4) of a lower-triangular 4x4 matrix of uniform values for lane (ii, l4): the strictly lower part
+            // by column then row (5 selections), the diagonal by column (3), zero elsewhere (2) -- instead of four row
+            // vectors and a 4-way choice between them (13-14)
+            const bool r1 = ii == 1, r2 = ii == 2, on_diag = ii == l4, below = (l4 < ii) & (ii < 4);  // (& not &&: no branch)
+            auto sel44 = [&](double d0, double d1, double d2, double d3, double e10, double e20, double e30, double e21,
+                             double e31, double e32, bool unit) {
+                const double c0v = r1 ? e10 : (r2 ? e20 : e30), c1v = r2 ? e21 : e31;
+                const double off = l4 == 0 ? c0v : (l4 == 1 ? c1v : e32);
+                const double dia = unit ? 1.0 : (l4 == 0 ? d0 : (l4 == 1 ? d1 : (l4 == 2 ? d2 : d3)));
+                const double lo = below ? off : 0.0;
+                return on_diag ? dia : lo;
+            };
             const double aop = VAR == 4 ? y00 + y10 + y20 + y30 + y21 + y31 + y32
-                                        : (ii == 0 ? yr0 : (ii == 1 ? yr1 : (ii == 2 ? yr2 : (ii == 3 ? yr3 : 0.0))));
+                                        : sel44(y00, y11, y22, y33, y10, y20, y30, y21, y31, y32, LDL);
             aopinv[tt] = aop;
             const double ssel = l4 == 0 ? P.s0 : (l4 == 1 ? P.s1 : (l4 == 2 ? P.s2 : P.s3));
             // exact entries of the pivot rows of the diagonal block (from the scalar factorization)
-            const double lr0 = l4 == 0 ? dg[0] : 0.0;
-            const double lr1 = l4 == 0 ? l10 : (l4 == 1 ? dg[1] : 0.0);
-            const double lr2 = l4 == 0 ? l20 : (l4 == 1 ? l21 : (l4 == 2 ? dg[2] : 0.0));
-            const double lr3 = l4 == 0 ? l30 : (l4 == 1 ? l31 : (l4 == 2 ? l32 : dg[3]));
-            const double lpiv = VAR == 4 ? l10 + l20 + l30 + l21 + l31 + l32 : (ii == 0 ? lr0 : (ii == 1 ? lr1 : (ii == 2 ? lr2 : lr3)));
-            const double vr1 = l4 == 0 ? P.c10 : (l4 == 1 ? dg[1] : 0.0);
-            const double vr2 = l4 == 0 ? P.c20 : (l4 == 1 ? P.c21 : (l4 == 2 ? dg[2] : 0.0));
-            const double vr3 = l4 == 0 ? P.c30 : (l4 == 1 ? P.c31 : (l4 == 2 ? P.c32 : dg[3]));
-            const double vpiv = VAR == 4 ? P.c10 + P.c21 + P.c32 : (ii == 0 ? lr0 : (ii == 1 ? vr1 : (ii == 2 ? vr2 : vr3)));
+            // (Cholesky: c IS l, one selection tree.  LDL^T: v = c by selection; l_ik = c_ik * s_k is the very product the
+            // scalar factorization forms, so l comes from v with one multiplication -- bit-identical, 11 selections fewer)
+            const double vpiv = VAR == 4 ? P.c10 + P.c21 + P.c32
+                                         : sel44(dg[0], dg[1], dg[2], dg[3], P.c10, P.c20, P.c30, P.c21, P.c31, P.c32, false);
+            const double lpiv = LDL ? (VAR == 4 ? l10 + l20 + l30 + l21 + l31 + l32 : (l4 < ii ? vpiv * ssel : vpiv)) : vpiv;
             // ---- 2. X_t^T = inv(L44) A_t^T for every block of block column b
             double X[4], V[4];
 #pragma unroll
@@ -751,8 +755,9 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
                 double x = LDL ? v * ssel : v;
                 if (cb == b) {
                     // rows above the pivot group: not part of the lower triangle; the pivot rows: exact values
-                    x = ii < 0 ? 0.0 : (ii < 4 ? lpiv : x);
-                    v = ii < 0 ? 0.0 : (ii < 4 ? (LDL ? vpiv : lpiv) : v);
+                    // (lpiv / vpiv are already zero on the rows above the group: one selection each)
+                    x = ii < 4 ? lpiv : x;
+                    v = ii < 4 ? (LDL ? vpiv : lpiv) : v;
                 }
                 X[cb] = x;
                 V[cb] = v;
