@@ -701,14 +701,6 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             int fail;
             factor_piv4_vals<LDL>(p00, p10, p11, p20, p21, p22, p30, p31, p32, p33, pivot_tol, P, dg, fail);
             if (VAR != 2 && !LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
-            if (VAR != 2 && lane == 0) {
-                const double sc[4] = {P.s0, P.s1, P.s2, P.s3};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    dvec[j0 + 4 * t + k] = dg[k];
-                    dinv[j0 + 4 * t + k] = LDL ? sc[k] : 1.0;
-                }
-            }
             // entries of the 4x4 factor: l = L (unit lower for LDL), cv = d_k L (LDL) / L (Cholesky)
             const double l10 = LDL ? P.c10 * P.s0 : P.c10, l20 = LDL ? P.c20 * P.s0 : P.c20,
                          l30 = LDL ? P.c30 * P.s0 : P.c30, l21 = LDL ? P.c21 * P.s1 : P.c21,
@@ -789,6 +781,18 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             for (int r = 0; r < 4; ++r) {
                 inv16[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
                 if (Ish != nullptr) Ish[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
+            }
+        }
+        // ---- D and D^-1 of the 16 pivots of this block column, once per block column instead of once per pivot group by
+        // lane 0: the pivots sit on the diagonal of the factored block -- entry (i, i) in register i >> 2 of lane
+        // (l15 = i, l4 = i & 3) -- and D^-1 is the same fast_rcp of the same recorded pivot (0 recorded -> harmless pivot 1)
+        if (VAR != 2) {
+            const int rsel = l15 >> 2;
+            const v4d dd = Lt[b][b];
+            const double dsel = rsel == 0 ? dd[0] : (rsel == 1 ? dd[1] : (rsel == 2 ? dd[2] : dd[3]));
+            if ((l15 & 3) == l4) {
+                dvec[j0 + 16 * b + l15] = dsel;
+                dinv[j0 + 16 * b + l15] = LDL ? fast_rcp(dsel == 0.0 ? 1.0 : dsel) : 1.0;
             }
         }
         // ---- store block column b of the factored block (column-major 64x64, lower part)
