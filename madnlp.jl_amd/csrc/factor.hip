@@ -1247,6 +1247,15 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
         const int64_t jb = (p0 >> 6) + j;
         const double* Dblk = dblk0 + jb * 4096;
         const double* Iv16 = inv0 + jb * 1024;
+        // D^-1 of the block's 64 pivots for X = V D^-1 below: requested here, together with the block itself, so that the
+        // latency is covered by the triangular solve instead of sitting between it and the stores
+        double dsc[4][4];
+        if (LDL) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsc[ib][r] = dinv[p0 + 64 * j + 16 * ib + l4 + 4 * r];
+        }
         {
             double Ln[6][4], Iv[4][4];
             int p = 0;
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                 const int64_t row = r0 + l15;
                 const double v = X[4 * j + ib][r];
                 if (LDL) {
-                    lv[r] = v * dinv[p0 + c];
+                    lv[r] = v * dsc[ib][r];
                     W[row + (wcol0 + c) * ldw] = v;
                 } else {
                     lv[r] = v;
