@@ -362,6 +362,47 @@ class CubicDiskModel:
         return np.array([[h[0], h[1]], [h[1], h[2]]], order="F")
 
 
+class WachterBieglerModel:
+    """Waechter & Biegler's example (Math. Program. 88, 2000):  min x1  s.t.  x1^2 - x2 - 1 = 0,  x1 - x3 - 1/2 = 0,
+    x2, x3 >= 0, started from (-2, 3, 1) -- the point from which pure line-search interior-point steps cannot reach the
+    feasible region.  Drives the regular phase into restoration and back (state-machine regression; no reference-held
+    answer for this instance)."""
+    n, m = 3, 2
+    x0 = np.array([-2.0, 3.0, 1.0])
+    y0 = np.zeros(2)
+    lvar = np.array([-np.inf, 0.0, 0.0])
+    uvar = np.array([np.inf, np.inf, np.inf])
+    lcon = np.zeros(2)
+    ucon = np.zeros(2)
+    jac_I = np.array([0, 0, 1, 1])
+    jac_J = np.array([0, 1, 0, 2])
+    hess_I = np.array([0])
+    hess_J = np.array([0])
+
+    def obj(self, x):
+        return x[0]
+
+    def grad(self, x):
+        return np.array([1.0, 0.0, 0.0])
+
+    def cons(self, x):
+        return np.array([x[0] ** 2 - x[1] - 1.0, x[0] - x[2] - 0.5])
+
+    def jac_coord(self, x):
+        return np.array([2.0 * x[0], -1.0, 1.0, -1.0])
+
+    def jac_dense(self, x):
+        return np.array([[2.0 * x[0], -1.0, 0.0], [1.0, 0.0, -1.0]], order="F")
+
+    def hess_coord(self, x, y, w=1.0):
+        return np.array([2.0 * y[0]])
+
+    def hess_dense(self, x, y, w=1.0):
+        h = np.zeros((3, 3), order="F")
+        h[0, 0] = 2.0 * y[0]
+        return h
+
+
 class LootsmaModel:
     """The reference's `lootsma` test problem (lib/MadNLPTests/src/MadNLPTests.jl:153-194), the fixed
     variable par = 6 substituted:  min x1^3 + 11 x1 - 6 sqrt(x1) + x3  s.t.  -sqrt(x1) - sqrt(x2) + sqrt(x3) >= 0,

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver
-from madnlp_jl_amd.problems import CubicDiskModel, InfeasibleModel
+from madnlp_jl_amd.problems import CubicDiskModel, InfeasibleModel, WachterBieglerModel
 
 from test_ipm_oracle import run
 
@@ -48,6 +48,21 @@ def test_runs_that_leave_the_regular_phase_come_back_and_converge(kind, r, x0, e
     # iteration counter keeps counting through the phases
     ks = [h.k for h in s.history]
     assert ks == sorted(ks) and len(set(ks)) == len(ks)
+
+
+@pytest.mark.parametrize("kind", ["dense", "dense_condensed"])
+def test_waechter_biegler_start_walks_robust_regular_robust(kind):
+    """State-machine regression (this mirror's own behaviour, not a reference-held answer): from (-2, 3, 1) the regular phase
+    gives up, robust! brings the iterate back into the filter, the regular phase fails again, and the second robust! run ends
+    at (-1, 0, 0) -- a stationary point of the l1 infeasibility under the bounds (c = (0, -3/2): moving x1 up trades
+    |c2| for twice as much |c1|) -- with INFEASIBLE_PROBLEM_DETECTED."""
+    s = run(kind, WachterBieglerModel(), tol=1e-8, max_iter=300)
+    ph = phases(s)
+    assert s.status == "INFEASIBLE_PROBLEM_DETECTED", (s.status, ph)
+    first, last = ph.index("R"), ph.rindex(".")
+    assert first < last < len(ph) - 1 and ph.endswith("R"), ph        # R ... . ... R
+    np.testing.assert_allclose(s.x[:3], [-1.0, 0.0, 0.0], atol=1e-6)
+    np.testing.assert_allclose(s.c, [0.0, -1.5], atol=1e-6)
 
 
 def test_one_sided_constraint_with_infinite_lower_bound_has_a_finite_rhs():
