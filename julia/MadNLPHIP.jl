@@ -7,10 +7,12 @@
 # GPU through the ctypes mirror in madnlp.jl_amd/ (tests/test_hip_parity.py).
 #
 # It adds three types that plug into MadNLP's own option seam
-#     madnlp(nlp; kkt_system = MadNLPHIP.HipSparseCondensedKKTSystem, linear_solver = MadNLPHIP.HipLinearSolver)
+#     MadNLPHIP.madnlp_hip(nlp)      # = madnlp(nlp; MadNLPHIP.hip_sparse_condensed_options()...)
 #     madnlp(nlp; kkt_system = MadNLPHIP.HipDenseCondensedKKTSystem,  linear_solver = MadNLPHIP.HipLinearSolver)
 # (reference src/IPM/options.jl:121-122, consumed at src/IPM/IPM.jl:157-165); nothing else in the IPM
-# loop changes.  Pattern: ccall + finalizer as in src/LinearSolvers/mumps.jl:148-165,211 and
+# loop changes.  The reference keys four option presets on `kkt_system <: MadNLP.SparseCondensedKKTSystem`
+# (src/IPM/options.jl:146-147,160,226); HipSparseCondensedKKTSystem is a sibling type, not a subtype, so
+# `hip_sparse_condensed_options` passes the same four values explicitly (see "option presets" below).  Pattern: ccall + finalizer as in src/LinearSolvers/mumps.jl:148-165,211 and
 # src/LinearSolvers/lapack.jl:50-139; KKT-system contract as in docs/src/tutorials/diag_kkt.jl:6-215.
 module MadNLPHIP
 
@@ -285,6 +287,37 @@ function fetch_map(sc::HipSC, which::Cint, len::Int)
     return Vector{Int}(map .+ 1)
 end
 
+# ------------------------------------------------------------------ option presets
+# The reference selects the sparse-condensed presets by type, `kkt_system <: MadNLP.SparseCondensedKKTSystem`
+# (src/IPM/options.jl:146-147: fixed_variable_treatment = RelaxBound, equality_treatment = RelaxEquality;
+# :160: dual_initialization_method = DualInitializeSetZero; :215,226: tol = get_tolerance(T, kkt_system) = 1e-4 for
+# Float64).  HipSparseCondensedKKTSystem cannot be a subtype of that concrete struct, so without these four values the
+# options would default to EnforceEquality / MakeParameter / DualInitializeLeastSquares / tol = 1e-8 and
+# create_kkt_system below would (rightly) refuse any NLP with equality constraints -- AC-OPF included.
+# `tol` needs no keyword: MadNLPOptions{T}(nlp; kkt_system, ...) calls get_tolerance(T, kkt_system) (options.jl:215).
+MadNLP.get_tolerance(::Type{T}, ::Type{HipSparseCondensedKKTSystem}) where T =
+    MadNLP.get_tolerance(T, MadNLP.SparseCondensedKKTSystem)
+
+"""
+    hip_sparse_condensed_options(T = Float64)
+
+Keyword arguments that make `madnlp` / `MadNLPSolver` take the device path with exactly the presets the reference
+applies to `MadNLP.SparseCondensedKKTSystem` (src/IPM/options.jl:146-147,160,226).  Later keywords override them:
+`madnlp(nlp; hip_sparse_condensed_options()..., tol = 1e-6)`.
+"""
+hip_sparse_condensed_options(::Type{T} = Float64) where T = (
+    kkt_system = HipSparseCondensedKKTSystem,
+    linear_solver = HipLinearSolver,
+    fixed_variable_treatment = MadNLP.RelaxBound,
+    equality_treatment = MadNLP.RelaxEquality,
+    dual_initialization_method = MadNLP.DualInitializeSetZero,
+    tol = MadNLP.get_tolerance(T, HipSparseCondensedKKTSystem),
+)
+
+"`madnlp(nlp; ...)` on the device path: the presets above first, the caller's keywords after (they win)."
+madnlp_hip(nlp::MadNLP.AbstractNLPModel{T}; kwargs...) where T =
+    MadNLP.madnlp(nlp; hip_sparse_condensed_options(T)..., kwargs...)
+
 # create_kkt_system: reference src/KKT/Sparse/condensed.jl:55-133.  coo_to_csc (x2) and
 # build_condensed_aug_symbolic are replaced by ONE call, mnk_sc_create (host C++), whose results come back
 # through mnk_sc_sizes / mnk_sc_get_structure / mnk_sc_get_map.
@@ -301,7 +334,9 @@ function MadNLP.create_kkt_system(
     ind_ineq = cb.ind_ineq
     n = cb.nvar
     m = cb.ncon
-    length(ind_ineq) == m || error("HipSparseCondensedKKTSystem does not support equality constrained NLPs.")
+    length(ind_ineq) == m || error("HipSparseCondensedKKTSystem does not support equality constrained NLPs: pass " *
+        "equality_treatment = MadNLP.RelaxEquality (MadNLPHIP.hip_sparse_condensed_options() does), as the reference's " *
+        "own preset for SparseCondensedKKTSystem does (src/IPM/options.jl:147).")
 
     jac_sparsity_I = create_array(cb, Int32, cb.nnzj)
     jac_sparsity_J = create_array(cb, Int32, cb.nnzj)

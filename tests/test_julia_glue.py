@@ -130,3 +130,73 @@ def test_option_keys_and_defaults_match_the_library():
     assert (o.outer_block, int(o.lookahead), o.share, int(o.persistent_solve), o.single_rows, o.pivot_tol, o.panel_algo) == (
         int(lib["outer_block"]), int(lib["lookahead"]), int(lib["share"]), int(lib["persistent_solve"]),
         int(lib["single_rows"]), float(lib["pivot_tol"]), int(lib["panel_algo"]))
+
+
+REF = "/root/reference/src"
+
+
+def _first_julia_block(md: str) -> str:
+    m = re.search(r"```julia\n(.*?)```", md, flags=re.S)
+    assert m, "INTEGRATION.md has no julia snippet"
+    return m.group(1)
+
+
+PRESETS = {  # the values the reference applies when kkt_system <: SparseCondensedKKTSystem (src/IPM/options.jl:146-147,160,226)
+    "fixed_variable_treatment": "MadNLP.RelaxBound",
+    "equality_treatment": "MadNLP.RelaxEquality",
+    "dual_initialization_method": "MadNLP.DualInitializeSetZero",
+    "tol": "MadNLP.get_tolerance",
+}
+
+
+def test_documented_entry_point_selects_the_path():
+    """The snippet INTEGRATION.md opens with must carry the four presets the reference keys on
+    `kkt_system <: SparseCondensedKKTSystem` -- without them the options default to EnforceEquality and the Hip
+    KKT type refuses every NLP with equality constraints (AC-OPF: configs 3-5)."""
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    snip = _first_julia_block(integ)
+    assert "MadNLPHIP.HipSparseCondensedKKTSystem" in snip and "MadNLPHIP.HipLinearSolver" in snip
+    for key, val in PRESETS.items():
+        assert re.search(rf"\b{key}\s*=\s*{re.escape(val)}", snip), f"INTEGRATION.md snippet lacks {key} = {val}"
+    # the helper returns the same keywords, and madnlp_hip splats it in front of the caller's
+    helper = JL.split("hip_sparse_condensed_options(::Type{T} = Float64) where T = (")[1].split("\n)")[0]
+    for key, val in PRESETS.items():
+        assert re.search(rf"\b{key}\s*=\s*{re.escape(val)}", helper), (key, val)
+    assert "kkt_system = HipSparseCondensedKKTSystem" in helper and "linear_solver = HipLinearSolver" in helper
+    assert re.search(r"madnlp_hip\(nlp::MadNLP\.AbstractNLPModel\{T\}; kwargs\.\.\.\) where T =\s*\n?\s*"
+                     r"MadNLP\.madnlp\(nlp; hip_sparse_condensed_options\(T\)\.\.\., kwargs\.\.\.\)", JL)
+    # tol follows from kkt_system alone through the reference's own hook (options.jl:215)
+    assert re.search(r"MadNLP\.get_tolerance\(::Type\{T\}, ::Type\{HipSparseCondensedKKTSystem\}\) where T =\s*\n?\s*"
+                     r"MadNLP\.get_tolerance\(T, MadNLP\.SparseCondensedKKTSystem\)", JL)
+    # the refusal message tells the caller what to pass
+    assert "RelaxEquality" in JL.split("length(ind_ineq) == m ||")[1][:400]
+
+
+def _reference_defines(name: str) -> bool:
+    """grep-level: `name` is defined (function / struct / abstract type / const / macro-generated enum member) or
+    imported somewhere under /root/reference/src."""
+    bare = name.rstrip("!")
+    n, b, end = re.escape(name), re.escape(bare), r"(?![A-Za-z_0-9!])"
+    pat = re.compile(
+        rf"(function\s+(MadNLP\.)?{n}{end}|^\s*{n}\(.*\)\s*(where.*)?=|struct\s+{b}{end}|abstract type\s+{b}{end}|"
+        rf"const\s+{b}{end}|@enum.*\b{b}{end}|^\s*{b}\s*(=|::)|\b{b}\s*=\s*\d+|import\s+\w+:.*\b{n}{end})", re.M)
+    for dp, _, fs in os.walk(REF):
+        for f in fs:
+            if f.endswith(".jl") and pat.search(open(os.path.join(dp, f)).read()):
+                return True
+    return False
+
+
+def test_every_madnlp_name_the_glue_uses_exists_in_the_reference():
+    """Build box only (the reference tree is not shipped to the GPU box): every name the glue imports from MadNLP,
+    extends as `MadNLP.f(...)`, or reads as `MadNLP.X` must exist in /root/reference/src."""
+    import pytest
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present")
+    imported = re.search(r"import MadNLP: (.*?)\nimport LinearAlgebra", JL, flags=re.S).group(1)
+    names = {n.strip() for n in imported.replace("\n", " ").split(",") if n.strip()}
+    names |= set(re.findall(r"\bMadNLP\.([A-Za-z_][A-Za-z_0-9]*!?)", JL))
+    names -= {"jl"}
+    assert len(names) > 40
+    missing = sorted(n for n in names if not _reference_defines(n))
+    assert not missing, f"not found in {REF}: {missing}"
