@@ -427,10 +427,6 @@ int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);
 int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const double* A, int64_t lda,
                      double* C, double* C2, int64_t ldc, int reps, double* ms);
 
-/* Diagnostics (tools/potrf_ablation.py): average ms of `reps` dependent launches of the one-wave potrf64 kernel on a
- * 64x64 block; variant 0 = the kernel, 1..6 = one piece removed (timing only). */
-int mnk_debug_potrf64(mnk_ctx* ctx, int variant, int reps, double* ms);
-
 #ifdef __cplusplus
 }
 #endif

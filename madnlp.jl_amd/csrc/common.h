@@ -103,10 +103,6 @@ struct mnk_ctx {
     bool own_stream = false;
     // look-ahead of the factorization: panel stream (high priority), update stream, fork/join events
     hipStream_t sp = nullptr, su = nullptr;
-    // companion streams for the diagonal-block kernels (potrf64), which overlap the inner updates: sq runs on the
-    // panel stream's CUs, sq0 on the whole chip (panel 0 and single-panel factorizations)
-    hipStream_t sq = nullptr, sq0 = nullptr;
-    hipEvent_t ev_q = nullptr;
     int panel_cus = 0;  // > 0: sp is restricted to this many CUs and su to the others (CU masks)
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_next, ev_next2, ev_bdone;
@@ -132,20 +128,15 @@ namespace mnk {
 int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K,
                    const double* A, int64_t lda, const double* B, int64_t ldb,
                    double* C, int64_t ldc, const double* colscale, double* C2, int64_t ldc2,
-                   const int* info_flag, int* sig = nullptr, int sig_val = 0);
-// `sig` (optional): the workgroup of logical tile 0 stores sig_val there once its tile is complete in memory
+                   const int* info_flag);
 int launch_gemm_nt_lower_small(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
-                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag,
-                               int* sig = nullptr, int sig_val = 0);
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag);
 int gemm_nt_lower_tiles(int64_t M, int64_t N);
 int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double* C, int64_t ldc);
 int launch_gemm_nt_lower_range(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                                const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag,
                                int tile_begin, int tile_count);
-int launch_gemm_nt_splitk(hipStream_t s, int64_t M, int64_t N, int64_t K, int nsplit, const double* A, int64_t lda,
-                          const double* B, int64_t ldb, double* C, int64_t ldc, double* S, int64_t lds, int64_t sstride,
-                          const int* info_flag);
 int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                          const double* B, int64_t ldb, double* C, int64_t ldc, int* counter, int cus,
                          const int* info_flag);

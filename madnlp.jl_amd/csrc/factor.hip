@@ -47,172 +47,9 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
-// ---------------------------------------------------------------------------------------
-// Fused diagonal-block factorization + panel solve.
-// Thread (row i = tid & 63, wave w = tid >> 6) owns row i of the columns c = 4*cl + w of
-// T row tiles: tile 0 is the 64x64 diagonal block (every workgroup holds a private copy),
-// tiles 1..T-1 are 64-row tiles of the panel below it.  The factored diagonal block is written
-// to a separate 64x64 buffer (Dout), never in place: other workgroups of the same launch may
-// still be loading the unfactored block.  One barrier per pivot: the pivot
-// column of every tile is published through a double-buffered LDS vector (stored permuted so
-// that the 16 entries a wave needs are contiguous) and every thread applies the rank-one
-// update a_ic -= (w_i / piv) * w_c to its own rows and columns.
-//
-// Columns are processed in 16 groups of 4 (one column per wave); the register array is
-// rotated after every group so that the live column group always sits at index 0 (static
-// register indices with a rolled loop).  NL = live slots per wave during a phase of 4 groups.
-// ---------------------------------------------------------------------------------------
-constexpr int CB_LD = 72;  // 64 + slack: a wave reads up to 3 dead slots past its 16
-
-// ---------------------------------------------------------------------------------------
-// Rank-4 variant of the fused panel kernel (the one used): ONE barrier per group of 4 pivots.
-// The four waves publish their raw current columns together; every thread then factors the
-// 4x4 pivot block redundantly in registers (4 dependent rsqrt/rcp chains, no LDS round trip
-// between them), forward-substitutes its own row (per tile) and its own live columns, and
-// applies the rank-4 update.  Compared with the rank-1 kernel above this removes 3 of every 4
-// LDS-publish/barrier/read round trips from the pivot chain.
-//   Cf[r][k] : coefficient of the substitution = L[r][k] (Cholesky) or d_k L[r][k] (LDL)
-//   s[k]     : 1/L[k][k] (Cholesky) or 1/d_k (LDL)
-//   x_k = (w_k - sum_{m<k} x_m Cf[k][m]) * s_k ,  v_k = the same before scaling
-// ---------------------------------------------------------------------------------------
 struct Piv4 {
     double c10, c20, c30, c21, c31, c32, s0, s1, s2, s3;
 };
-
-template <bool LDL>
-__device__ __forceinline__ void sub4(const Piv4& P, double w0, double w1, double w2, double w3, double (&x)[4],
-                                     double (&v)[4]) {
-    v[0] = w0;
-    x[0] = v[0] * P.s0;
-    v[1] = fma(-x[0], P.c10, w1);
-    x[1] = v[1] * P.s1;
-    v[2] = fma(-x[1], P.c21, fma(-x[0], P.c20, w2));
-    x[2] = v[2] * P.s2;
-    v[3] = fma(-x[2], P.c32, fma(-x[1], P.c31, fma(-x[0], P.c30, w3)));
-    x[3] = v[3] * P.s3;
-}
-
-template <bool LDL, int T, int NL>
-__device__ __forceinline__ void panel_phase4(double (&a)[T][16], double (*colbuf)[4][CB_LD], const int g0,
-                                             const int i, const int w, const bool lead, const bool (&valid)[T],
-                                             const int64_t (&trow)[T], double* __restrict__ F, const int64_t ld,
-                                             const int64_t j0, double* __restrict__ Dout,
-                                             double* __restrict__ W, const int64_t ldw, const int64_t wcol,
-                                             double* __restrict__ dvec, double* __restrict__ dinv,
-                                             int* __restrict__ info, const double pivot_tol,
-                                             double* Lsh = nullptr /* optional LDS copy of the factored block */) {
-    const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row index i
-#pragma unroll 1
-    for (int g = g0; g < g0 + 4; ++g) {
-        double (*cb)[4][CB_LD] = colbuf + (g & 1) * T;  // [q][k][slot]
-#pragma unroll
-        for (int q = 0; q < T; ++q) cb[q][w][pos_i] = a[q][0];
-        __syncthreads();
-        // ---- 4x4 pivot block: rows/cols 4g..4g+3 of the diagonal tile; slot(4g+r) = r*16 + g
-        const double p00 = cb[0][0][0 * 16 + g];
-        const double p10 = cb[0][0][1 * 16 + g], p11 = cb[0][1][1 * 16 + g];
-        const double p20 = cb[0][0][2 * 16 + g], p21 = cb[0][1][2 * 16 + g], p22 = cb[0][2][2 * 16 + g];
-        const double p30 = cb[0][0][3 * 16 + g], p31 = cb[0][1][3 * 16 + g], p32 = cb[0][2][3 * 16 + g];
-        const double p33 = cb[0][3][3 * 16 + g];
-        Piv4 P;
-        double dg[4];  // recorded diagonal: L[k][k] (Cholesky) or d_k (LDL, 0 for a zero pivot)
-        int fail = 0;
-        if (LDL) {
-            auto piv = [&](double d, double& sc, double& rec) {
-                const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
-                sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
-                rec = zero ? 0.0 : d;
-            };
-            piv(p00, P.s0, dg[0]);
-            P.c10 = p10; P.c20 = p20; P.c30 = p30;
-            const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
-            piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
-            P.c21 = fma(-x20, P.c10, p21);
-            P.c31 = fma(-x30, P.c10, p31);
-            const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
-            piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
-            P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
-            const double x32 = P.c32 * P.s2;
-            piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
-        } else {
-            auto piv = [&](double t, double& sc, double& rec, int k) {
-                // not positive definite (also catches NaN/Inf): remember the first failing pivot
-                const bool bad = !(t > 0.0) || !(t <= DBL_MAX);
-                fail = (bad && fail == 0) ? k + 1 : fail;
-                sc = fast_rsqrt(bad ? 1.0 : t);
-                rec = bad ? 1.0 : t * sc;
-            };
-            piv(p00, P.s0, dg[0], 0);
-            P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
-            piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
-            P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
-            P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
-            piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
-            P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
-            piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
-            // flag the failure; remaining work runs on harmless values, later kernels are no-ops
-            if (fail != 0 && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + 4 * g + fail));
-        }
-        // ---- second factors for the live columns of this wave: rows c = 4*(g+cl)+w, slot w*16+g+cl
-        double y[NL][4];
-#pragma unroll
-        for (int cl = 1; cl < NL; ++cl) {
-            const int sl = w * 16 + g + cl;
-            double x[4], v[4];
-            sub4<LDL>(P, cb[0][0][sl], cb[0][1][sl], cb[0][2][sl], cb[0][3][sl], x, v);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) y[cl][k] = LDL ? v[k] : x[k];
-        }
-        // ---- own rows
-        const int c0 = 4 * g + w;  // the column this wave finishes in this group
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            double x[4], v[4];
-            sub4<LDL>(P, cb[q][0][pos_i], cb[q][1][pos_i], cb[q][2][pos_i], cb[q][3][pos_i], x, v);
-            if (q == 0) {
-                // rows above the pivot block of the diagonal tile hold upper-triangle values: no part
-                const bool above = i < 4 * g;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = above ? 0.0 : x[k];
-            }
-#pragma unroll
-            for (int cl = 1; cl < NL; ++cl) {
-                double acc = a[q][cl];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc = fma(-x[k], y[cl][k], acc);
-                a[q][cl] = acc;
-            }
-            const double xw = w == 0 ? x[0] : (w == 1 ? x[1] : (w == 2 ? x[2] : x[3]));  // L[row][c0]
-            if (q == 0) {
-                if (lead) {
-                    if (i > c0) {
-                        Dout[i + 64 * c0] = xw;
-                        if (Lsh != nullptr) Lsh[i + 64 * c0] = xw;
-                    }
-                    if (i == c0) {
-                        const double d = w == 0 ? dg[0] : (w == 1 ? dg[1] : (w == 2 ? dg[2] : dg[3]));
-                        const double sc = w == 0 ? P.s0 : (w == 1 ? P.s1 : (w == 2 ? P.s2 : P.s3));
-                        Dout[i + 64 * c0] = d;  // L[c][c], or d_c for LDL (as LAPACK stores it)
-                        if (Lsh != nullptr) Lsh[i + 64 * c0] = d;
-                        dvec[j0 + c0] = d;
-                        dinv[j0 + c0] = LDL ? sc : 1.0;
-                    }
-                }
-            } else if (valid[q]) {
-                F[trow[q] + i + (j0 + c0) * ld] = xw;
-                if (LDL) {
-                    const double vw = w == 0 ? v[0] : (w == 1 ? v[1] : (w == 2 ? v[2] : v[3]));
-                    W[trow[q] + i + (wcol + c0) * ldw] = vw;
-                }
-            }
-        }
-        // rotate: the next column group moves to slot 0
-#pragma unroll
-        for (int q = 0; q < T; ++q)
-#pragma unroll
-            for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // Split panel step (the default): potrf64_kernel + trsm64_mfma_kernel replace the fused elimination
@@ -227,73 +64,6 @@ __device__ __forceinline__ void panel_phase4(double (&a)[T][16], double (*colbuf
 // ---------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// ---- device-side hand-offs between the diagonal-block kernels (companion stream) and the panel stream ----------
-// A flag holds the factorization's epoch once its producer is done.  Consumer: relaxed agent-scope polls by one
-// lane (or one uniform wave), ONE agent-scope acquire, then plain loads.  Every wait is bounded: a dependency that
-// never arrives (which would mean a scheduling assumption was violated) turns the factorization into a reported
-// failure (info = -7, every later kernel is a no-op) instead of a hang.
-constexpr long HANDOFF_SPIN_LIMIT = 1L << 23;
-__device__ __forceinline__ bool handoff_wait(const int* flag, int epoch, int* info) {
-    long spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        __builtin_amdgcn_s_sleep(2);
-        if ((++spins & 1023) == 0) {
-            if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            if (spins > HANDOFF_SPIN_LIMIT) {
-                atomicCAS(info, 0, -7);
-                return false;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return true;
-}
-__device__ __forceinline__ void handoff_signal_wave(int* flag, int epoch) {
-    // one wave: its own stores -> agent-scope release -> drained flag store
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-
-template <bool LDL>
-__global__ __launch_bounds__(256) void potrf64_kernel(double* __restrict__ F, int64_t ld, int64_t j0,
-                                                       double* __restrict__ Dout, double* __restrict__ inv16,
-                                                       double* __restrict__ dvec, double* __restrict__ dinv,
-                                                       int* __restrict__ info, double pivot_tol) {
-    __shared__ double colbuf[2][4][CB_LD];
-    __shared__ double Ls[64 * 64];  // factored block, column-major (lower part + diagonal are written)
-    if (*info != 0) return;
-    const int tid = threadIdx.x;
-    const int i = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int64_t trow[1] = {j0};
-    bool valid[1] = {true};
-    double a[1][16];
-#pragma unroll
-    for (int cl = 0; cl < 16; ++cl) a[0][cl] = F[j0 + i + (j0 + 4 * cl + w) * ld];
-    panel_phase4<LDL, 1, 16>(a, colbuf, 0, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
-    panel_phase4<LDL, 1, 12>(a, colbuf, 4, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
-    panel_phase4<LDL, 1, 8>(a, colbuf, 8, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
-    panel_phase4<LDL, 1, 4>(a, colbuf, 12, i, w, true, valid, trow, F, ld, j0, Dout, nullptr, 0, 0, dvec, dinv, info, pivot_tol, Ls);
-    __syncthreads();
-    // inverse of the 16x16 diagonal sub-block b = wave (unit diagonal for LDL): lane c < 16 solves L x = e_c
-    if (i < 16) {
-        const int c = i, b16 = 16 * w;
-        double x[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int k = 0; k < r; ++k) sacc = fma(Ls[(b16 + r) + 64 * (b16 + k)], x[k], sacc);  // x[k] = 0 for k < c
-            const double rd = LDL ? 1.0 : 1.0 / Ls[(b16 + r) + 64 * (b16 + r)];
-            x[r] = r > c ? -sacc * rd : (r == c ? rd : 0.0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) inv16[w * 256 + r + 16 * c] = x[r];
-    }
-}
-
 // X = B L_jj^-T (Cholesky) / V = B L_jj^-T, X = V D^-1 (LDL) for every row below the diagonal block.
 // Wave = NS strips of 16 rows; lane (l15, l4): accumulator register r of column block cb holds
 // X[row0 + l15][16 cb + l4 + 4 r] (the C^T layout of gemm_f64.hip, so register r of X^T[ib] IS the
@@ -303,15 +73,8 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F
                                                            const double* __restrict__ Dblk,
                                                            const double* __restrict__ inv16,
                                                            const double* __restrict__ dinv, double* __restrict__ W,
-                                                           int64_t ldw, int64_t wcol, int* __restrict__ info,
-                                                           const int* __restrict__ wait_flag, int epoch) {
+                                                           int64_t ldw, int64_t wcol, int* __restrict__ info) {
     if (*info != 0) return;
-    if (wait_flag != nullptr) {  // the diagonal block comes from the companion stream
-        __shared__ int ok;
-        if (threadIdx.x == 0) ok = handoff_wait(wait_flag, epoch, info) ? 1 : 0;
-        __syncthreads();
-        if (!ok) return;
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int64_t r0 = j0 + 64 + ((int64_t)blockIdx.x * 4 + wave) * (16 * NS);
@@ -373,241 +136,10 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F
             }
 }
 
-template <bool LDL, int T>
-__global__ __launch_bounds__(256) void panel64r4_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
-                                                         double* __restrict__ Dout, double* __restrict__ W,
-                                                         int64_t ldw, int64_t wcol, double* __restrict__ dvec,
-                                                         double* __restrict__ dinv, int* __restrict__ info,
-                                                         double pivot_tol) {
-    __shared__ double colbuf[2 * T][4][CB_LD];
-    if (*info != 0) return;
-    const int tid = threadIdx.x;
-    const int i = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool lead = blockIdx.x == 0;
-    int64_t trow[T];
-    bool valid[T];
-    trow[0] = j0;
-    valid[0] = true;
-#pragma unroll
-    for (int q = 1; q < T; ++q) {
-        const int64_t r = j0 + 64 * ((int64_t)blockIdx.x * (T - 1) + q);
-        valid[q] = r < Np;
-        trow[q] = valid[q] ? r : j0;  // a tile past the end aliases the diagonal tile (never stored)
-    }
-    double a[T][16];
-#pragma unroll
-    for (int q = 0; q < T; ++q)
-#pragma unroll
-        for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
-
-    panel_phase4<LDL, T, 16>(a, colbuf, 0, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase4<LDL, T, 12>(a, colbuf, 4, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase4<LDL, T, 8>(a, colbuf, 8, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-    panel_phase4<LDL, T, 4>(a, colbuf, 12, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, dinv, info, pivot_tol);
-}
-
-// ---------------------------------------------------------------------------------------
-// Software-pipelined rank-4 panel kernel (the one launched).  Same arithmetic as
-// panel64r4_kernel, different schedule: after the own-row substitution of group g every wave
-// first updates only the column it contributes to the NEXT pivot block, publishes it and reads
-// the next raw 4x4 block; the dependent rsqrt/rcp chain of group g+1 then sits in the same
-// basic block as the bulk rank-4 update of group g, so the compiler interleaves the two
-// independent instruction streams and the chain latency hides behind the FMAs.  The second
-// factors y_k(c) are the substituted rows of the diagonal tile, which every wave already holds
-// lane-wise: they are fetched with v_readlane (uniform operands) instead of being recomputed.
-// ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
-}
-
-template <bool LDL>
-__device__ __forceinline__ void factor_piv4(const double (*cb0)[CB_LD], const int g, const double pivot_tol, Piv4& P,
-                                            double (&dg)[4], int& fail) {
-    // 4x4 pivot block: rows/cols 4g..4g+3 of the diagonal tile; slot(4g+r) = r*16 + g
-    const double p00 = cb0[0][0 * 16 + g];
-    const double p10 = cb0[0][1 * 16 + g], p11 = cb0[1][1 * 16 + g];
-    const double p20 = cb0[0][2 * 16 + g], p21 = cb0[1][2 * 16 + g], p22 = cb0[2][2 * 16 + g];
-    const double p30 = cb0[0][3 * 16 + g], p31 = cb0[1][3 * 16 + g], p32 = cb0[2][3 * 16 + g];
-    const double p33 = cb0[3][3 * 16 + g];
-    fail = 0;
-    if (LDL) {
-        auto piv = [&](double d, double& sc, double& rec) {
-            const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
-            sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
-            rec = zero ? 0.0 : d;
-        };
-        piv(p00, P.s0, dg[0]);
-        P.c10 = p10; P.c20 = p20; P.c30 = p30;
-        const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
-        piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
-        P.c21 = fma(-x20, P.c10, p21);
-        P.c31 = fma(-x30, P.c10, p31);
-        const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
-        piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
-        P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
-        const double x32 = P.c32 * P.s2;
-        piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
-    } else {
-        auto piv = [&](double t, double& sc, double& rec, int k) {
-            const bool bad = !(t > 0.0) || !(t <= DBL_MAX);  // not positive definite / NaN / Inf
-            fail = (bad && fail == 0) ? k + 1 : fail;
-            sc = fast_rsqrt(bad ? 1.0 : t);
-            rec = bad ? 1.0 : t * sc;
-        };
-        piv(p00, P.s0, dg[0], 0);
-        P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
-        piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
-        P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
-        P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
-        piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
-        P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
-        piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
-    }
-}
-
-template <bool LDL, int T, int NL>
-__device__ __forceinline__ void panel_phase_p(double (&a)[T][16], double (*raw)[4][CB_LD], const int g0, Piv4& P,
-                                              double (&dg)[4], const int i, const int w, const bool lead,
-                                              const bool (&valid)[T], const int64_t (&trow)[T],
-                                              double* __restrict__ F, const int64_t ld, const int64_t j0,
-                                              double* __restrict__ Dout, double* __restrict__ W, const int64_t ldw,
-                                              const int64_t wcol, double* __restrict__ dvec,
-                                              double* __restrict__ dinv, int* __restrict__ info,
-                                              const double pivot_tol) {
-    const int pos_i = (i & 3) * 16 + (i >> 2);  // permuted slot of row index i
-#pragma unroll 1
-    for (int g = g0; g < g0 + 4; ++g) {
-        double (*cb)[4][CB_LD] = raw + (g & 1) * T;  // raw columns of group g: [tile][k][slot]
-        // ---- own rows: forward substitution against the factored pivot block of group g
-        double x[T][4], v[T][4];
-#pragma unroll
-        for (int q = 0; q < T; ++q)
-            sub4<LDL>(P, cb[q][0][pos_i], cb[q][1][pos_i], cb[q][2][pos_i], cb[q][3][pos_i], x[q], v[q]);
-        {
-            // rows above the pivot block of the diagonal tile hold upper-triangle values: no part
-            const bool above = i < 4 * g;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x[0][k] = above ? 0.0 : x[0][k];
-        }
-        // second factors y_k(c) = substituted row c of the diagonal tile (lane c of x[0] / v[0])
-        auto second = [&](int c, double (&y)[4]) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) y[k] = readlane_f64(LDL ? v[0][k] : x[0][k], c);
-        };
-        Piv4 Pn = P;
-        double dgn[4] = {dg[0], dg[1], dg[2], dg[3]};
-        const bool has_next = g < 15;
-        if (has_next) {
-            // early: the column this wave contributes to the next pivot block (slot 1), then publish it
-            double y[4];
-            second((4 * (g + 1) + w) & 63, y);
-#pragma unroll
-            for (int q = 0; q < T; ++q)
-                a[q][1] = fma(-x[q][3], y[3], fma(-x[q][2], y[2], fma(-x[q][1], y[1], fma(-x[q][0], y[0], a[q][1]))));
-            double (*nb)[4][CB_LD] = raw + ((g + 1) & 1) * T;
-#pragma unroll
-            for (int q = 0; q < T; ++q) nb[q][w][pos_i] = a[q][1];
-            __syncthreads();
-            // ---- dependent chain of group g+1 (independent of the bulk update below)
-            int fail;
-            factor_piv4<LDL>(nb[0], g + 1, pivot_tol, Pn, dgn, fail);
-            if (!LDL && fail != 0 && lead && threadIdx.x == 0) atomicCAS(info, 0, (int)(j0 + 4 * (g + 1) + fail));
-        }
-        // ---- bulk rank-4 update of the remaining live columns of this wave (slots 2..NL-1)
-#pragma unroll
-        for (int cl = 2; cl < NL; ++cl) {
-            double y[4];
-            second((4 * (g + cl) + w) & 63, y);
-#pragma unroll
-            for (int q = 0; q < T; ++q)
-                a[q][cl] = fma(-x[q][3], y[3], fma(-x[q][2], y[2], fma(-x[q][1], y[1], fma(-x[q][0], y[0], a[q][cl]))));
-        }
-        // ---- the column this wave finishes in this group (slot 0)
-        const int c0 = 4 * g + w;
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-            const double xw = w == 0 ? x[q][0] : (w == 1 ? x[q][1] : (w == 2 ? x[q][2] : x[q][3]));  // L[row][c0]
-            if (q == 0) {
-                if (lead) {
-                    if (i > c0) Dout[i + 64 * c0] = xw;
-                    if (i == c0) {
-                        const double d = w == 0 ? dg[0] : (w == 1 ? dg[1] : (w == 2 ? dg[2] : dg[3]));
-                        const double sc = w == 0 ? P.s0 : (w == 1 ? P.s1 : (w == 2 ? P.s2 : P.s3));
-                        Dout[i + 64 * c0] = d;  // L[c][c], or d_c for LDL (as LAPACK stores it)
-                        dvec[j0 + c0] = d;
-                        dinv[j0 + c0] = LDL ? sc : 1.0;
-                    }
-                }
-            } else if (valid[q]) {
-                F[trow[q] + i + (j0 + c0) * ld] = xw;
-                if (LDL) {
-                    const double vw = w == 0 ? v[q][0] : (w == 1 ? v[q][1] : (w == 2 ? v[q][2] : v[q][3]));
-                    W[trow[q] + i + (wcol + c0) * ldw] = vw;
-                }
-            }
-        }
-        // rotate: the next column group moves to slot 0
-#pragma unroll
-        for (int q = 0; q < T; ++q)
-#pragma unroll
-            for (int cl = 0; cl < NL - 1; ++cl) a[q][cl] = a[q][cl + 1];
-        P = Pn;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dg[k] = dgn[k];
-    }
-}
-
-template <bool LDL, int T>
-__global__ __launch_bounds__(256) void panel64p_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
-                                                        double* __restrict__ Dout, double* __restrict__ W,
-                                                        int64_t ldw, int64_t wcol, double* __restrict__ dvec,
-                                                        double* __restrict__ dinv, int* __restrict__ info,
-                                                        double pivot_tol) {
-    __shared__ double raw[2 * T][4][CB_LD];
-    if (*info != 0) return;
-    const int tid = threadIdx.x;
-    const int i = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool lead = blockIdx.x == 0;
-    int64_t trow[T];
-    bool valid[T];
-    trow[0] = j0;
-    valid[0] = true;
-#pragma unroll
-    for (int q = 1; q < T; ++q) {
-        const int64_t r = j0 + 64 * ((int64_t)blockIdx.x * (T - 1) + q);
-        valid[q] = r < Np;
-        trow[q] = valid[q] ? r : j0;  // a tile past the end aliases the diagonal tile (never stored)
-    }
-    double a[T][16];
-#pragma unroll
-    for (int q = 0; q < T; ++q)
-#pragma unroll
-        for (int cl = 0; cl < 16; ++cl) a[q][cl] = F[trow[q] + i + (j0 + 4 * cl + w) * ld];
-
-    // prologue: raw columns of group 0, first pivot block
-    const int pos_i = (i & 3) * 16 + (i >> 2);
-#pragma unroll
-    for (int q = 0; q < T; ++q) raw[q][w][pos_i] = a[q][0];
-    __syncthreads();
-    Piv4 P;
-    double dg[4];
-    {
-        int fail;
-        factor_piv4<LDL>(raw[0], 0, pivot_tol, P, dg, fail);
-        if (!LDL && fail != 0 && lead && tid == 0) atomicCAS(info, 0, (int)(j0 + fail));
-    }
-#define MNK_PHASE(NLV, G0)                                                                                      \
-    panel_phase_p<LDL, T, NLV>(a, raw, G0, P, dg, i, w, lead, valid, trow, F, ld, j0, Dout, W, ldw, wcol, dvec, \
-                               dinv, info, pivot_tol)
-    MNK_PHASE(16, 0);
-    MNK_PHASE(12, 4);
-    MNK_PHASE(8, 8);
-    MNK_PHASE(4, 12);
-#undef MNK_PHASE
 }
 
 // ---------------------------------------------------------------------------------------
@@ -670,11 +202,9 @@ __device__ __forceinline__ void factor_piv4_vals(const double p00, const double 
 }
 
 // (one wave; `Lsh` / `Ish`: optional LDS copies of the factored block and of its four 16x16 inverses)
-// VAR != 0: timing-only ablations for mnk_debug_potrf64 (results are wrong): 1 no 16x16 inverses, 2 no dvec/dinv/info
-// stores, 3 only the critical update MFMA, 4 no per-lane selection of the 4x4 factor, 5 load + store only, 6 no Dout stores
 // potrf64w_core: the block is already in registers (Lt[cb][b], b <= cb, strict upper triangle of the diagonal
 // 16x16 blocks zeroed); potrf64w_body loads it from the factor matrix first.
-template <bool LDL, int VAR = 0>
+template <bool LDL>
 __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, double* __restrict__ Dout,
                                               double* __restrict__ inv16, double* __restrict__ dvec,
                                               double* __restrict__ dinv, int* __restrict__ info, double pivot_tol,
@@ -683,7 +213,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
     const int l15 = lane & 15, l4 = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int b = 0; b < (VAR == 5 ? 0 : 4); ++b) {
+    for (int b = 0; b < 4; ++b) {
         double aopinv[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
@@ -700,7 +230,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             double dg[4];
             int fail;
             factor_piv4_vals<LDL>(p00, p10, p11, p20, p21, p22, p30, p31, p32, p33, pivot_tol, P, dg, fail);
-            if (VAR != 2 && !LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
+            if (!LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
             // entries of the 4x4 factor: l = L (unit lower for LDL), cv = d_k L (LDL) / L (Cholesky)
             const double l10 = LDL ? P.c10 * P.s0 : P.c10, l20 = LDL ? P.c20 * P.s0 : P.c20,
                          l30 = LDL ? P.c30 * P.s0 : P.c30, l21 = LDL ? P.c21 * P.s1 : P.c21,
@@ -728,16 +258,14 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
                 const double lo = below ? off : 0.0;
                 return on_diag ? dia : lo;
             };
-            const double aop = VAR == 4 ? y00 + y10 + y20 + y30 + y21 + y31 + y32
-                                        : sel44(y00, y11, y22, y33, y10, y20, y30, y21, y31, y32, LDL);
+            const double aop = sel44(y00, y11, y22, y33, y10, y20, y30, y21, y31, y32, LDL);
             aopinv[tt] = aop;
             const double ssel = l4 == 0 ? P.s0 : (l4 == 1 ? P.s1 : (l4 == 2 ? P.s2 : P.s3));
             // exact entries of the pivot rows of the diagonal block (from the scalar factorization)
             // (Cholesky: c IS l, one selection tree.  LDL^T: v = c by selection; l_ik = c_ik * s_k is the very product the
             // scalar factorization forms, so l comes from v with one multiplication -- bit-identical, 11 selections fewer)
-            const double vpiv = VAR == 4 ? P.c10 + P.c21 + P.c32
-                                         : sel44(dg[0], dg[1], dg[2], dg[3], P.c10, P.c20, P.c30, P.c21, P.c31, P.c32, false);
-            const double lpiv = LDL ? (VAR == 4 ? l10 + l20 + l30 + l21 + l31 + l32 : (l4 < ii ? vpiv * ssel : vpiv)) : vpiv;
+            const double vpiv = sel44(dg[0], dg[1], dg[2], dg[3], P.c10, P.c20, P.c30, P.c21, P.c31, P.c32, false);
+            const double lpiv = LDL ? (l4 < ii ? vpiv * ssel : vpiv) : vpiv;
             // ---- 2. X_t^T = inv(L44) A_t^T for every block of block column b
             double X[4], V[4];
 #pragma unroll
@@ -762,12 +290,11 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
                 const double na = (cb1 == b && l15 < 4 * tt + 4) ? 0.0 : -X[cb1];
 #pragma unroll
                 for (int cb2 = cb1; cb2 < 4; ++cb2)
-                    if (VAR != 3 || (cb1 == b && cb2 == b))
-                        Lt[cb2][cb1] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, LDL ? V[cb2] : X[cb2], Lt[cb2][cb1], 0, 0, 0);
+                    Lt[cb2][cb1] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, LDL ? V[cb2] : X[cb2], Lt[cb2][cb1], 0, 0, 0);
             }
         }
         // ---- inverse of the 16x16 diagonal block (unit diagonal for LDL): Y = inv(L16), block forward substitution
-        if (VAR != 1) {
+        {
             v4d T, Y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) T[r] = (l15 == l4 + 4 * r) ? 1.0 : 0.0;
@@ -786,7 +313,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
         // ---- D and D^-1 of the 16 pivots of this block column, once per block column instead of once per pivot group by
         // lane 0: the pivots sit on the diagonal of the factored block -- entry (i, i) in register i >> 2 of lane
         // (l15 = i, l4 = i & 3) -- and D^-1 is the same fast_rcp of the same recorded pivot (0 recorded -> harmless pivot 1)
-        if (VAR != 2) {
+        {
             const int rsel = l15 >> 2;
             const v4d dd = Lt[b][b];
             const double dsel = rsel == 0 ? dd[0] : (rsel == 1 ? dd[1] : (rsel == 2 ? dd[2] : dd[3]));
@@ -801,21 +328,13 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Lt[cb][b][r];
-                if (VAR != 6) Dout[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
+                Dout[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
                 if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
             }
     }
-    if (VAR == 5) {
-        double acc = 0.0;
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-            for (int b = 0; b <= cb; ++b) acc += Lt[cb][b][0] + Lt[cb][b][1] + Lt[cb][b][2] + Lt[cb][b][3];
-        Dout[lane] = acc;
-    }
 }
 
-template <bool LDL, int VAR = 0>
+template <bool LDL>
 __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
                                               double* __restrict__ Dout, double* __restrict__ inv16,
                                               double* __restrict__ dvec, double* __restrict__ dinv,
@@ -833,245 +352,16 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
                 // 'L' storage: the strict upper triangle of the block may hold anything (NaN included)
                 Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v;
             }
-    potrf64w_core<LDL, VAR>(Lt, j0, Dout, inv16, dvec, dinv, info, pivot_tol, Lsh, Ish);
+    potrf64w_core<LDL>(Lt, j0, Dout, inv16, dvec, dinv, info, pivot_tol, Lsh, Ish);
 }
 
 template <bool LDL>
 __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__ F, int64_t ld, int64_t j0,
                                                        double* __restrict__ Dout, double* __restrict__ inv16,
                                                        double* __restrict__ dvec, double* __restrict__ dinv,
-                                                       int* __restrict__ info, double pivot_tol,
-                                                       const int* __restrict__ wait_flag, int* __restrict__ done_flag,
-                                                       int epoch) {
+                                                       int* __restrict__ info, double pivot_tol) {
     if (*info != 0) return;
-    // wait_flag: "the diagonal tile is complete" from the update kernel still running on the panel stream
-    if (wait_flag != nullptr && !handoff_wait(wait_flag, epoch, info)) return;
     potrf64w_body<LDL>(F, ld, j0, Dout, inv16, dvec, dinv, info, pivot_tol, nullptr, nullptr);
-    if (done_flag != nullptr) handoff_signal_wave(done_flag, epoch);
-}
-
-template <int VAR>
-__global__ __launch_bounds__(64) void potrf64w_dbg_kernel(const double* __restrict__ F, double* __restrict__ Dout,
-                                                           double* __restrict__ inv16, double* __restrict__ dvec,
-                                                           double* __restrict__ dinv, int* __restrict__ info) {
-    potrf64w_body<true, VAR>(F, 64, 0, Dout, inv16, dvec, dinv, info, 0.0, nullptr, nullptr);
-}
-
-// ---------------------------------------------------------------------------------------
-// 256-column panel step (panel_algo = 3; NOT the default -- measured: potrf256 102 us vs 4 x 16.4 us for the separate
-// potrf64 launches, trsm256 35-118 us; C3 13.2 ms against 12.5 ms for panel_algo = 1): potrf256_kernel + trsm256_mfma_kernel.
-// One workgroup factors a whole 256x256 diagonal block: wave 0 runs the one-wave potrf64 above on each of its
-// four 64x64 diagonal tiles; between them all four waves do the triangular solves of the tiles below it
-// (block substitution on MFMA, operands from LDS) and the rank-64 updates of the block's trailing tiles
-// (acc -= X V^T on MFMA, the just-solved tiles kept in LDS).  That is four pivot chains and their in-block
-// updates in ONE launch instead of four rounds of {potrf64, trsm64, inner update} launches.
-// The rows below the block are then solved against the whole 256x256 factor in one launch
-// (trsm256_mfma_kernel): per 16-row strip, left-looking block substitution over sixteen 16-column blocks --
-// the K = 64 / 128 inner updates of the 64-column scheme happen inside the strip's registers.
-// ---------------------------------------------------------------------------------------
-constexpr int P256_VP = 80;  // pitch of a V tile in LDS: 16 mod 32 doubles, so the lanes of an operand read hit disjoint banks
-constexpr int P256_LDS_BYTES = (4096 + 1024 + 3 * 64 * P256_VP) * 8;  // factored tile, its 16x16 inverses, V tiles (= 160 KiB)
-constexpr int P256_NT = 256;  // 4 waves (512 VGPRs each: the pivot-chain body must not spill): wave 0 owns the pivot chains,
-                              // the other three hide the in-block updates behind them
-
-// one strip task of the in-block update: C(rows rr..rr+15, cols cc..cc+63) -= X(t1) V(t2)^T, operands from LDS
-template <bool LDL>
-__device__ __forceinline__ void p256_update_strip(double* __restrict__ F, int64_t ld, int64_t rr, int64_t cc,
-                                                  const double* V1, const double* V2, int sub,
-                                                  const double* __restrict__ dinvj, int l15, int l4) {
-    v4d C[4];
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) C[cb][r] = F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld];
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-        const double bop = V2[(16 * sub + l15) + P256_VP * (4 * s + l4)];
-        const double sc = LDL ? -dinvj[4 * s + l4] : -1.0;
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            const double aop = V1[(16 * cb + l15) + P256_VP * (4 * s + l4)] * sc;
-            C[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, C[cb], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) F[(rr + l15) + (cc + 16 * cb + l4 + 4 * r) * ld] = C[cb][r];
-}
-
-template <bool LDL>
-__global__ __launch_bounds__(P256_NT) void potrf256_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int nblk,
-                                                            double* __restrict__ Dblk, double* __restrict__ Inv16,
-                                                            double* __restrict__ W, int64_t ldw, int64_t wcol,
-                                                            double* __restrict__ dvec, double* __restrict__ dinv,
-                                                            int* __restrict__ info, double pivot_tol) {
-    extern __shared__ __attribute__((aligned(16))) char p256_smem[];
-    double* Ls = reinterpret_cast<double*>(p256_smem);   // [64 x 64] factored diagonal tile (L; d on the diagonal for LDL)
-    double* Is = Ls + 4096;                              // [4][16 x 16] inverses of its diagonal 16-blocks
-    double* Vs = Is + 1024;                              // [3][64 x P256_VP] V = L D (LDL) / L (Cholesky) of the tiles below
-    if (*info != 0) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int NW = P256_NT / 64, PRE = NW - 4;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-    // Pending non-critical update tasks of the previous block column are finished by waves 1..7 while wave 0 runs the
-    // next pivot chain: (first task, tile count below) of the block column whose updates are still running.
-    int pend_jb = -1;
-    for (int jb = 0; jb < nblk; ++jb) {
-        const int64_t jc = j0 + 64 * jb;  // first column of this 64-column block
-        if (wave == 0) {
-            potrf64w_body<LDL>(F, ld, jc, Dblk + (int64_t)jb * 4096, Inv16 + (int64_t)jb * 1024, dvec, dinv, info,
-                               pivot_tol, Ls, Is);
-        } else if (pend_jb >= 0) {
-            // the rest of the previous block column's updates: every tile except its first (done before the barrier)
-            const int pj = pend_jb, nb = nblk - 1 - pj;
-            const int64_t pc = j0 + 64 * pj;
-            int task = 0;
-            for (int t1 = 0; t1 < nb; ++t1)
-                for (int t2 = t1; t2 < nb; ++t2) {
-                    if (t1 == 0 && t2 == 0) continue;
-                    for (int sub = 0; sub < 4; ++sub, ++task) {
-                        // the first PRE tasks of this list were taken by waves 4.. before the barrier (none with 4 waves)
-                        if (task < PRE || (task - PRE) % (NW - 1) != wave - 1) continue;
-                        p256_update_strip<LDL>(F, ld, pc + 64 * (t2 + 1) + 16 * sub, pc + 64 * (t1 + 1),
-                                               Vs + t1 * 64 * P256_VP, Vs + t2 * 64 * P256_VP, sub, dinv + pc, l15, l4);
-                    }
-                }
-        }
-        __syncthreads();  // factored tile jb in LDS; every update of the previous block column is in memory
-        pend_jb = -1;
-        const int nbel = nblk - 1 - jb;  // tiles below the diagonal tile inside the 256-block
-        if (nbel == 0) break;
-        // ---- triangular solve of the tiles below: strip = 16 rows; 4 * nbel strips over the eight waves
-        if (wave < 4 * nbel) {
-            double Ln[6][4], Iv[4][4];
-            int p = 0;
-#pragma unroll
-            for (int cb = 1; cb < 4; ++cb)
-#pragma unroll
-                for (int ib = 0; ib < cb; ++ib, ++p)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) Ln[p][s] = -Ls[(16 * cb + l15) + 64 * (16 * ib + 4 * s + l4)];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) Iv[cb][s] = Is[cb * 256 + l15 + 16 * (4 * s + l4)];
-            for (int st = wave; st < 4 * nbel; st += NW) {
-                const int tile = st >> 2, sub = st & 3;  // tile below (0-based), 16-row strip inside it
-                const int64_t r0 = jc + 64 * (tile + 1) + 16 * sub;
-                v4d X[4];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) X[cb][r] = F[(r0 + l15) + (jc + 16 * cb + l4 + 4 * r) * ld];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    v4d t = X[cb];
-#pragma unroll
-                    for (int ib = 0; ib < cb; ++ib) {
-                        const int q = cb * (cb - 1) / 2 + ib;
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[q][s], X[ib][s], t, 0, 0, 0);
-                    }
-                    v4d x = zero4;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[cb][s], t[s], x, 0, 0, 0);
-                    X[cb] = x;
-                }
-                double* Vt = Vs + tile * 64 * P256_VP;
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = 16 * cb + l4 + 4 * r;
-                        const double v = X[cb][r];
-                        Vt[(16 * sub + l15) + P256_VP * c] = v;
-                        if (LDL) {
-                            W[(r0 + l15) + (wcol + 64 * jb + c) * ldw] = v;
-                            F[(r0 + l15) + (jc + c) * ld] = v * dinv[jc + c];
-                        } else {
-                            F[(r0 + l15) + (jc + c) * ld] = v;
-                        }
-                    }
-            }
-        }
-        __syncthreads();
-        // ---- rank-64 updates of the block's trailing tiles, C(t2, t1) -= X(t1) V(t2)^T.  The next diagonal tile
-        // (t1 = t2 = 0) is on the critical path: waves 0..3 update its four strips now; waves 4..7 take the first
-        // four other strip tasks meanwhile; everything else overlaps the next pivot chain (top of the loop).
-        if (wave < 4) {
-            p256_update_strip<LDL>(F, ld, jc + 64 + 16 * wave, jc + 64, Vs, Vs, wave, dinv + jc, l15, l4);
-        } else {
-            int task = 0;
-            for (int t1 = 0; t1 < nbel && task < PRE; ++t1)
-                for (int t2 = t1; t2 < nbel && task < PRE; ++t2) {
-                    if (t1 == 0 && t2 == 0) continue;
-                    for (int sub = 0; sub < 4 && task < PRE; ++sub, ++task)
-                        if (task == wave - 4)
-                            p256_update_strip<LDL>(F, ld, jc + 64 * (t2 + 1) + 16 * sub, jc + 64 * (t1 + 1),
-                                                   Vs + t1 * 64 * P256_VP, Vs + t2 * 64 * P256_VP, sub, dinv + jc, l15, l4);
-                }
-        }
-        pend_jb = jb;
-        __syncthreads();  // the next diagonal tile is complete in memory
-    }
-}
-
-// Rows below a factored 256-column block: X = B L^-T by left-looking block substitution over NB16 = 4 nblk blocks
-// of 16 columns, one 16-row strip per wave, everything in the strip's registers.  L's 16x16 blocks come from the
-// factored diagonal tiles (Dblk, same 64-tile) or from the factor itself (F, tiles below the diagonal).
-template <bool LDL, int NBK /* 64-column blocks: 1..4 */>
-__global__ __launch_bounds__(256) void trsm256_mfma_kernel(double* __restrict__ F, int64_t ld, int64_t j0,
-                                                            int64_t Np, const double* __restrict__ Dblk,
-                                                            const double* __restrict__ Inv16,
-                                                            const double* __restrict__ dinv, double* __restrict__ W,
-                                                            int64_t ldw, int64_t wcol, const int* __restrict__ info) {
-    if (*info != 0) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t r0 = j0 + 64 * (int64_t)NBK + ((int64_t)blockIdx.x * 4 + wave) * 16;
-    if (r0 >= Np) return;
-    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-    constexpr int NB16 = 4 * NBK;
-    v4d X[NB16];
-#pragma unroll
-    for (int cb = 0; cb < NB16; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) X[cb][r] = F[(r0 + l15) + (j0 + 16 * cb + l4 + 4 * r) * ld];
-#pragma unroll
-    for (int cb = 0; cb < NB16; ++cb) {
-        v4d t = X[cb];
-        const int tb = cb >> 2;  // 64-tile of this column block
-#pragma unroll
-        for (int ib = 0; ib < cb; ++ib) {
-            const int ti = ib >> 2;
-            // L[16 cb + i][16 ib + k]: inside the factored diagonal tile, or in a tile below the diagonal
-            const double* src = (ti == tb) ? Dblk + (int64_t)tb * 4096 + (16 * (cb & 3) + l15) + 64 * (16 * (ib & 3) + l4)
-                                           : F + (j0 + 16 * cb + l15) + (j0 + 16 * ib + l4) * ld;
-            const int64_t pitch = (ti == tb) ? 64 : ld;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                t = __builtin_amdgcn_mfma_f64_16x16x4f64(-src[(int64_t)(4 * s) * pitch], X[ib][s], t, 0, 0, 0);
-        }
-        const double* iv = Inv16 + (int64_t)tb * 1024 + (cb & 3) * 256 + l15 + 16 * l4;
-        v4d x = zero4;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[64 * s], t[s], x, 0, 0, 0);
-        X[cb] = x;
-    }
-#pragma unroll
-    for (int cb = 0; cb < NB16; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 16 * cb + l4 + 4 * r;
-            if (LDL) {
-                W[(r0 + l15) + (wcol + c) * ldw] = X[cb][r];
-                F[(r0 + l15) + (j0 + c) * ld] = X[cb][r] * dinv[j0 + c];
-            } else {
-                F[(r0 + l15) + (j0 + c) * ld] = X[cb][r];
-            }
-        }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1082,7 +372,7 @@ __global__ __launch_bounds__(256) void trsm256_mfma_kernel(double* __restrict__ 
 //                   strip t > j: waits for it, X = T L_jj^-T, stores V / L, then T[t, c] -= V[t, j] L[c, j]^T for the
 //                   later column blocks c <= t, where L[c, j] is what strip c published in ITS step j.
 // prog[c] = 16 * epoch + (number of column blocks strip c has completed and published); release/acquire at agent scope
-// as in handoff_*.  Only the nb diagonal strips are ever waited for, and a diagonal strip only waits for lower-numbered
+// (producer: stores -> release fence -> drained flag store; consumer: relaxed polls, one acquire).  Only the nb diagonal strips are ever waited for, and a diagonal strip only waits for lower-numbered
 // ones, so the kernel needs no co-residency beyond "lower block ids are dispatched no later than higher ones"; every
 // wait is bounded (info = -7 instead of a hang).  Strips that are dispatched late find every flag set.
 // The critical chain per 64 columns is potrf (one wave) -> flag hop -> strip j+1: triangular solve of 64 rows, K = 64
@@ -1438,184 +728,6 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 
 using namespace mnk;
 
-// factor the outer panel [ko, kend) completely (inner right-looking steps) on stream s
-// `rest_ready` (optional): event to wait for before the first kernel that touches the columns from
-// `rest_from` on (offset inside the panel, 64 or 256): the look-ahead delivers the outer panel's columns in
-// two pieces.
-static int factor_outer_panel_fused(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
-                                    hipEvent_t rest_ready = nullptr, int64_t rest_from = 256) {
-    const int64_t Np = ls->Np, ld = ls->ld;
-    const bool ldl = ls->algo == MNK_LDL;
-    double* F = ls->fact.p;
-    // Middle level: right-looking between NBM-column middle panels, left-looking inside one.  64 (= the inner
-    // block: purely right-looking inside the outer panel, no skinny left-looking products) measured best for
-    // N <= 6k (N = 1024 -27 %, 2048 -19 %, 4096 -8 % vs 256) and equal at N >= 11k; MNK_NBM overrides.
-    static const int64_t NBM = getenv("MNK_NBM") ? std::max<int64_t>(64, atol(getenv("MNK_NBM")) / 64 * 64) : 64;
-    for (int64_t j = ko; j < kend; j += NBI) {
-        // the first kernel that touches columns the caller delivers late: the first middle-level update (it spans
-        // all remaining columns of the panel) or the left-looking update of block column `rest_from`
-        if (rest_ready != nullptr && j == ko + std::min<int64_t>(rest_from, NBM)) MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
-        const int64_t mo = ko + ((j - ko) / NBM) * NBM;  // start of the middle panel of block j
-        // middle level, right-looking: when a 256-column middle panel is complete, apply it to the
-        // remaining columns of the outer panel with one K = 256 product (MFMA tiles, lower part)
-        if (j == mo && j > ko) {
-            const int64_t pm = mo - NBM;  // the middle panel just finished: columns [pm, mo)
-            const double* Wp = ldl ? wbase + mo + (pm - ko) * ls->ldw : F + mo + pm * ld;
-            int rc;
-            if (gemm_nt_lower_tiles(Np - mo, kend - mo) < ls->small_tiles_mid)
-                rc = launch_gemm_nt_lower_small(s, Np - mo, kend - mo, NBM, Wp, ldl ? ls->ldw : ld, F + mo + pm * ld,
-                                                ld, F + mo + mo * ld, ld, ls->info_dev.p);
-            else
-                rc = launch_gemm_nt(s, 2, Np - mo, kend - mo, NBM, Wp, ldl ? ls->ldw : ld, F + mo + pm * ld, ld,
-                                    F + mo + mo * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
-            if (rc) return rc;
-        }
-        // inner level, left-looking inside the middle panel: bring block column j up to date with the
-        // blocks [mo, j) already factored (one K = j-mo product on 64 columns)
-        if (j > mo) {
-            const double* Wp = ldl ? wbase + j + (mo - ko) * ls->ldw : F + j + mo * ld;
-            int rc = launch_gemm_nt(s, 0, Np - j, NBI, j - mo, Wp, ldl ? ls->ldw : ld, F + j + mo * ld, ld,
-                                    F + j + j * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
-            if (rc) return rc;
-        }
-        const int64_t r0 = j + NBI;
-        const int64_t Mr = Np - r0;
-        const int64_t ntile = Mr / 64;
-        // Tiles per workgroup: few (little redundant diagonal work, short steps) when the whole chip
-        // is available, many when the panel stream owns only `panel_cus` CUs (look-ahead): one
-        // workgroup per CU, the extra rank-one work hides behind the next pivot's latency chain.
-        const int64_t wgs = (ls->lookahead && ls->ctx->panel_cus > 0 && s == ls->ctx->sp) ? ls->ctx->panel_cus : 512;
-        // tiles per workgroup (incl. the diagonal tile)
-        int T = 2;
-        while (T < 7 && (ntile + T - 2) / (T - 1) > wgs) T = (T == 2) ? 3 : (T == 3 ? 5 : 7);
-        // MNK_PANEL_PIPE=1 selects the software-pipelined variant: measured 15-20 % SLOWER than the plain
-        // rank-4 kernel on gfx950 (v_readlane traffic outweighs the hidden chain), kept for A/B runs.
-        static const bool use_r4 = getenv("MNK_PANEL_PIPE") == nullptr;
-#define MNK_LAUNCH_R4(TT)                                                                                     \
-    do {                                                                                                      \
-        const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));                              \
-        if (ldl)                                                                                              \
-            hipLaunchKernelGGL((panel64r4_kernel<true, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,       \
-                               ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, j - ko, ls->dvec.p,             \
-                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                                    \
-        else                                                                                                  \
-            hipLaunchKernelGGL((panel64r4_kernel<false, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,      \
-                               ls->dblk.p + (j / NBI) * 4096, (double*)nullptr, (int64_t)0, (int64_t)0,       \
-                               ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                        \
-    } while (0)
-#define MNK_LAUNCH_P(TT)                                                                                      \
-    do {                                                                                                      \
-        const int grid = (int)std::max<int64_t>(1, (ntile + TT - 2) / (TT - 1));                              \
-        if (ldl)                                                                                              \
-            hipLaunchKernelGGL((panel64p_kernel<true, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,        \
-                               ls->dblk.p + (j / NBI) * 4096, wbase, ls->ldw, j - ko, ls->dvec.p,             \
-                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                                    \
-        else                                                                                                  \
-            hipLaunchKernelGGL((panel64p_kernel<false, TT>), dim3(grid), dim3(256), 0, s, F, ld, j, Np,       \
-                               ls->dblk.p + (j / NBI) * 4096, (double*)nullptr, (int64_t)0, (int64_t)0,       \
-                               ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);                        \
-    } while (0)
-        if (use_r4) {
-            if (T == 2) MNK_LAUNCH_R4(2);
-            else if (T == 3) MNK_LAUNCH_R4(3);
-            else if (T == 5) MNK_LAUNCH_R4(5);
-            else MNK_LAUNCH_R4(7);
-        } else {
-            if (T == 2) MNK_LAUNCH_P(2);
-            else if (T == 3) MNK_LAUNCH_P(3);
-            else if (T == 5) MNK_LAUNCH_P(5);
-            else MNK_LAUNCH_P(7);
-        }
-#undef MNK_LAUNCH_P
-#undef MNK_LAUNCH_R4
-#undef MNK_LAUNCH_PANEL
-    }
-    MNK_HIP(hipGetLastError());
-    return 0;
-}
-
-// Split panel step (panel_algo = 1, the default), per 64-column block j of the outer panel [ko, kend):
-//   potrf64_kernel      one workgroup: the diagonal block (the pivot chain) + its 16x16 inverses
-//   trsm64_mfma_kernel  every row below it, block substitution on the matrix cores
-//   gemm_nt (lower)     recursive right-looking update inside the outer panel: after jj blocks are done, the next
-//                       w = 64 * lowbit(jj) columns receive the last w columns' contribution in ONE K = w product
-//                       (K = 64, 128, 64, 256, ...: the same flops as updating all remaining columns after every
-//                       block, in fewer, deeper products -- 2.3x less read-modify-write traffic on the panel).
-// 256-column panel step (panel_algo = 3): potrf256_kernel + trsm256_mfma_kernel per 256 columns, recursive
-// right-looking updates between 256-blocks (K = 256, 512, 256, 1024, ...).
-static int factor_outer_panel_256(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
-                                  hipEvent_t rest_ready, int64_t rest_from) {
-    const int64_t Np = ls->Np, ld = ls->ld;
-    const bool ldl = ls->algo == MNK_LDL;
-    double* F = ls->fact.p;
-    {   // 136 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
-        static std::atomic<uint64_t> attr_devs{0};
-        int dev = 0;
-        MNK_HIP(hipGetDevice(&dev));
-        if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
-            MNK_HIP(hipFuncSetAttribute((const void*)potrf256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, P256_LDS_BYTES));
-            MNK_HIP(hipFuncSetAttribute((const void*)potrf256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, P256_LDS_BYTES));
-            attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
-        }
-    }
-    bool waited = rest_ready == nullptr;
-    for (int64_t j = ko; j < kend;) {
-        const int nblk = (int)std::min<int64_t>(4, (kend - j) / NBI);
-        if (!waited && j + NBI * nblk > ko + rest_from) {
-            MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
-            waited = true;
-        }
-        double* dblk = ls->dblk.p + (j / NBI) * 4096;
-        double* inv16 = ls->inv16.p + (j / NBI) * 1024;
-        if (ldl)
-            hipLaunchKernelGGL(potrf256_kernel<true>, dim3(1), dim3(P256_NT), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
-                               wbase, ls->ldw, j - ko, ls->dvec.p, ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
-        else
-            hipLaunchKernelGGL(potrf256_kernel<false>, dim3(1), dim3(P256_NT), P256_LDS_BYTES, s, F, ld, j, nblk, dblk, inv16,
-                               (double*)nullptr, (int64_t)0, (int64_t)0, ls->dvec.p, ls->dinv.p, ls->info_dev.p,
-                               ls->pivot_tol);
-        const int64_t p1 = j + NBI * nblk;
-        const int64_t M = Np - p1;
-        if (M <= 0) break;
-        const unsigned grid = (unsigned)((M / 16 + 3) / 4);
-#define MNK_TRSM256(NB)                                                                                             \
-    do {                                                                                                            \
-        if (ldl)                                                                                                    \
-            hipLaunchKernelGGL((trsm256_mfma_kernel<true, NB>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk,   \
-                               inv16, ls->dinv.p, wbase, ls->ldw, j - ko, ls->info_dev.p);                          \
-        else                                                                                                        \
-            hipLaunchKernelGGL((trsm256_mfma_kernel<false, NB>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk,  \
-                               inv16, ls->dinv.p, (double*)nullptr, (int64_t)0, (int64_t)0, ls->info_dev.p);        \
-    } while (0)
-        if (nblk == 4) MNK_TRSM256(4);
-        else if (nblk == 3) MNK_TRSM256(3);
-        else if (nblk == 2) MNK_TRSM256(2);
-        else MNK_TRSM256(1);
-#undef MNK_TRSM256
-        if (p1 >= kend) break;
-        const int64_t q = (p1 - ko) / 256;               // finished 256-blocks (only the last one can be short)
-        const int64_t w = 256 * (q & -q);
-        const int64_t p0 = p1 - w;
-        const int64_t ncols = std::min<int64_t>(w, kend - p1);
-        if (!waited && p1 + ncols > ko + rest_from) {
-            MNK_HIP(hipStreamWaitEvent(s, rest_ready, 0));
-            waited = true;
-        }
-        const double* Wp = ldl ? wbase + p1 + (p0 - ko) * ls->ldw : F + p1 + p0 * ld;
-        int rc;
-        if (gemm_nt_lower_tiles(Np - p1, ncols) < ls->small_tiles_256)
-            rc = launch_gemm_nt_lower_small(s, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
-                                            F + p1 + p1 * ld, ld, ls->info_dev.p);
-        else
-            rc = launch_gemm_nt(s, 2, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
-                                F + p1 + p1 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
-        if (rc) return rc;
-        j = p1;
-    }
-    MNK_HIP(hipGetLastError());
-    return 0;
-}
-
 // The host reads the inertia counters and the info word from pinned, device-mapped memory that this one-thread kernel
 // fills with system-scope stores: no copy engine and no staging copy between the last kernel and the host.
 __global__ void publish_info_kernel(const unsigned long long* __restrict__ inertia, const int* __restrict__ info,
@@ -1626,7 +738,7 @@ __global__ void publish_info_kernel(const unsigned long long* __restrict__ inert
     }
 }
 
-// panel_algo = 4: persistent panel launches (ppanel_kernel) of pp_nb blocks, recursive updates between them
+// panel_algo = 4: persistent panel launches (ppanel_kernel) of 4 blocks, recursive updates between them
 static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t kend, double* wbase,
                                  hipEvent_t rest_ready, int64_t rest_from, const double* Vfirst, int64_t ldvfirst,
                                  int64_t Kfirst) {
@@ -1638,14 +750,12 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
         int dev = 0;
         MNK_HIP(hipGetDevice(&dev));
         if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
-            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
             MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
             MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
             attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
-    const int NBs = (ls->pp_nb == 4 && !(ls->pp_nb8_rows > 0 && Np - ko <= ls->pp_nb8_rows)) ? 4 : 8;
+    constexpr int NBs = 4;  // 64-column blocks per persistent launch (8 was built and measured slower: 197 + 256 registers)
     const int64_t ws = (int64_t)NBI * NBs;
     const int epoch16 = ls->epoch * 16;
     bool waited = rest_ready == nullptr;
@@ -1653,7 +763,7 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
     const double* Vp = Vfirst;
     int64_t ldv = ldvfirst;
     int Kp = (int)Kfirst;
-    const bool fuse_mid = NBs == 4 && ls->pp_fuse_rows > 0 && Np - ko <= ls->pp_fuse_rows;
+    const bool fuse_mid = ls->pp_fuse_rows > 0 && Np - ko <= ls->pp_fuse_rows;
     for (int64_t p = ko; p < kend; p += ws) {
         const int nbk = (int)std::min<int64_t>(NBs, (kend - p) / NBI);
         if (!waited && p + NBI * nbk > ko + rest_from) {
@@ -1666,8 +776,8 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
                        ls->inv16.p, ls->dvec.p, ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0,  \
                        p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp,  \
                        ldv, Kp)
-        if (ldl) { if (NBs == 8) MNK_PP(true, 8); else MNK_PP(true, 4); }
-        else { if (NBs == 8) MNK_PP(false, 8); else MNK_PP(false, 4); }
+        if (ldl) MNK_PP(true, 4);
+        else MNK_PP(false, 4);
 #undef MNK_PP
         Vp = nullptr;
         Kp = 0;
@@ -1708,61 +818,27 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
                               int64_t ldvfirst = 0, int64_t Kfirst = 0) {
     if (ls->algo_now == 4)
         return factor_outer_panel_pp(ls, s, ko, kend, wbase, rest_ready, rest_from, Vfirst, ldvfirst, Kfirst);
-    if (ls->algo_now == 0) return factor_outer_panel_fused(ls, s, ko, kend, wbase, rest_ready, rest_from);
-    if (ls->algo_now == 3) return factor_outer_panel_256(ls, s, ko, kend, wbase, rest_ready, rest_from);
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
     bool waited = rest_ready == nullptr;
-    // Overlap (option "overlap"): from the second block of the panel on, potrf64 runs on a companion stream (same
-    // CUs) and starts as soon as the update kernel of the previous block has finished ITS tile 0 = the next
-    // diagonal block, instead of when that whole kernel has drained; the triangular solve then waits for the
-    // diagonal block through a flag.  flag_u[b] / flag_p[b]: block b's diagonal tile is updated / factored.
-    mnk_ctx* ctx = ls->ctx;
-    hipStream_t sq = s == ctx->sp ? ctx->sq : (s == ctx->stream ? ctx->sq0 : nullptr);
-    const bool overlap = ls->overlap && ls->algo_now == 1 && sq != nullptr && kend - ko > NBI;
-    const int epoch = ls->epoch;
-    if (overlap) {
-        MNK_HIP(hipEventRecord(ctx->ev_q, s));  // the companion stream must not run ahead of this panel
-        MNK_HIP(hipStreamWaitEvent(sq, ctx->ev_q, 0));
-    }
     for (int64_t j = ko; j < kend; j += NBI) {
         double* dblk = ls->dblk.p + (j / NBI) * 4096;
         double* inv16 = ls->inv16.p + (j / NBI) * 1024;
-        const bool on_q = overlap && j > ko;
-        hipStream_t sd = on_q ? sq : s;
-        const int* wflag = on_q ? ls->flag_u.p + j / NBI : nullptr;
-        int* dflag = overlap ? ls->flag_p.p + j / NBI : nullptr;
-        if (ls->algo_now == 2) {  // 256-thread LDS/barrier diagonal-block kernel (A/B runs)
-            if (ldl)
-                hipLaunchKernelGGL(potrf64_kernel<true>, dim3(1), dim3(256), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
-                                   ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
-            else
-                hipLaunchKernelGGL(potrf64_kernel<false>, dim3(1), dim3(256), 0, s, F, ld, j, dblk, inv16, ls->dvec.p,
-                                   ls->dinv.p, ls->info_dev.p, ls->pivot_tol);
-        } else if (ldl) {
-            hipLaunchKernelGGL(potrf64w_kernel<true>, dim3(1), dim3(64), 0, sd, F, ld, j, dblk, inv16, ls->dvec.p,
-                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol, wflag, dflag, epoch);
-        } else {
-            hipLaunchKernelGGL(potrf64w_kernel<false>, dim3(1), dim3(64), 0, sd, F, ld, j, dblk, inv16, ls->dvec.p,
-                               ls->dinv.p, ls->info_dev.p, ls->pivot_tol, wflag, dflag, epoch);
-        }
+        if (ldl)
+            hipLaunchKernelGGL(potrf64w_kernel<true>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p, ls->dinv.p,
+                               ls->info_dev.p, ls->pivot_tol);
+        else
+            hipLaunchKernelGGL(potrf64w_kernel<false>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p, ls->dinv.p,
+                               ls->info_dev.p, ls->pivot_tol);
         const int64_t M = Np - j - NBI;
-        if (M <= 0) {
-            if (on_q) {  // nothing consumes the last diagonal block's flag: join the companion stream explicitly
-                MNK_HIP(hipEventRecord(ctx->ev_q, sq));
-                MNK_HIP(hipStreamWaitEvent(s, ctx->ev_q, 0));
-            }
-            break;
-        }
+        if (M <= 0) break;
         // 16-row strips per wave: one while the panel is short (more workgroups, shortest chain), two beyond
         const bool two = M / 64 > 2 * (int64_t)ls->ctx->num_cu;
         const unsigned grid = (unsigned)((M / (two ? 32 : 16) + 3) / 4);
-        const int* tflag = overlap ? ls->flag_p.p + j / NBI : nullptr;
 #define MNK_TRSM(LD, NS)                                                                                          \
     hipLaunchKernelGGL((trsm64_mfma_kernel<LD, NS>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk, inv16,    \
-                       ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0, j - ko, ls->info_dev.p, \
-                       tflag, epoch)
+                       ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0, j - ko, ls->info_dev.p)
         if (ldl) { if (two) MNK_TRSM(true, 2); else MNK_TRSM(true, 1); }
         else { if (two) MNK_TRSM(false, 2); else MNK_TRSM(false, 1); }
 #undef MNK_TRSM
@@ -1777,14 +853,13 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
             waited = true;
         }
         const double* Wp = ldl ? wbase + p1 + (p0 - ko) * ls->ldw : F + p1 + p0 * ld;
-        int* uflag = overlap ? ls->flag_u.p + p1 / NBI : nullptr;  // tile 0 of this update = diagonal tile of block p1
         int rc;
         if (gemm_nt_lower_tiles(Np - p1, ncols) < ls->small_tiles_mid)
             rc = launch_gemm_nt_lower_small(s, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
-                                            F + p1 + p1 * ld, ld, ls->info_dev.p, uflag, epoch);
+                                            F + p1 + p1 * ld, ld, ls->info_dev.p);
         else
             rc = launch_gemm_nt(s, 2, Np - p1, ncols, w, Wp, ldl ? ls->ldw : ld, F + p1 + p0 * ld, ld,
-                                F + p1 + p1 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p, uflag, epoch);
+                                F + p1 + p1 * ld, ld, nullptr, nullptr, 0, ls->info_dev.p);
         if (rc) return rc;
     }
     MNK_HIP(hipGetLastError());
@@ -1809,9 +884,8 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     double* F = ls->fact.p;
     const int64_t NBO = mnk_ls_effective_nbo(ls);
     MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));
-    if ((ls->overlap || ls->panel_algo == 4) && !ls->flag_u.p) {
-        if (ls->flag_u.alloc(Np / NBI + 1) || ls->flag_p.alloc(Np / NBI + 1)) return -2;
-        MNK_HIP(hipMemsetAsync(ls->flag_u.p, 0, (Np / NBI + 1) * sizeof(int), s));
+    if (ls->panel_algo == 4 && !ls->flag_p.p) {
+        if (ls->flag_p.alloc(Np / NBI + 1)) return -2;
         MNK_HIP(hipMemsetAsync(ls->flag_p.p, 0, (Np / NBI + 1) * sizeof(int), s));
     }
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
@@ -1879,25 +953,6 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             }
             MNK_HIP(hipMemsetAsync(ls->tile_ctr.p, 0, 8 * ((size_t)npanel + 1) * sizeof(int), s));
         }
-        // Deferred tail region (defer_rows > 0).  The early outer steps are throughput-bound and the last ones bound by
-        // the pivot chain with three quarters of the chip idle.  Panels 0 .. kd-1 therefore leave the region
-        // rows, columns >= c1 alone ((b) shrinks to the columns in front of c1); the missing K = Kd update of every later
-        // panel j is applied as ONE merged left-looking product D_j on the update stream, two panels ahead of its use,
-        // i.e. under the pivot chain of the tail.
-        int64_t kd = -1, c1 = Np, Kd = 0, ldwd = 0;
-        if (ls->defer_rows > 0 && npanel >= 4) {
-            for (int64_t i = 2; i < npanel; ++i)
-                if (Np - bnd[i] <= ls->defer_rows) { kd = i - 1; break; }
-            if (kd >= 1) {
-                c1 = bnd[kd + 1];
-                Kd = bnd[kd];
-                ldwd = Np - c1;
-                if (ldl && ls->wdefer.n < (size_t)(ldwd * Kd + SLACK)) {
-                    int rc0 = ls->wdefer.alloc((size_t)(ldwd * Kd + SLACK));
-                    if (rc0) return rc0;
-                }
-            } else kd = -1;
-        }
         // Panel 0 has nothing to overlap with: it runs on the caller's stream, i.e. on the whole chip (its
         // triangular solves and inner updates are throughput-bound at this height), before the fork.
         int rc = 0;
@@ -1920,10 +975,6 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             const int64_t Kw = kend - ko;
             // ev_panel[k] is recorded after panel k and after the panel stream's share of (b)_{k-1}
             MNK_HIP(hipStreamWaitEvent(su, ctx->ev_panel[k], 0));
-            const bool early = kd >= 0 && k < kd;  // this panel does not touch the deferred region
-            if (early && ldl)  // keep L*D of the rows behind c1 for the merged updates
-                MNK_HIP(hipMemcpy2DAsync(ls->wdefer.p + ko * ldwd, ldwd * sizeof(double), wk + c1, ls->ldw * sizeof(double),
-                                         ldwd * sizeof(double), Kw, hipMemcpyDeviceToDevice, su));
             // (a) columns of the next outer panel, delivered in two pieces: its first 256-column middle
             // panel (the panel stream starts on it at once), then the remaining columns (needed only when
             // that middle panel is finished)
@@ -1944,9 +995,8 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
             // Few rows left (the pivot chain is the critical path): the first persistent launch of the next panel applies
             // panel k to its own 256 columns itself (ppanel_kernel's prologue) -- no (a) kernel and no cross-stream
             // hand-over in front of the chain; the update stream delivers the other columns of the panel meanwhile.
-            const bool fuse_a = ls->algo_now == 4 && ls->pp_nb == 4 && ls->pp_fuse_rows > 0 && Mt <= ls->pp_fuse_rows &&
-                                Kw <= 512 && !(ls->pp_nb8_rows > 0 && Mt <= ls->pp_nb8_rows);
-            const bool own_first = !fuse_a && ls->split_a == 2 && nnext > NBI && ls->algo_now != 3;
+            const bool fuse_a = ls->algo_now == 4 && ls->pp_fuse_rows > 0 && Mt <= ls->pp_fuse_rows && Kw <= 512;
+            const bool own_first = !fuse_a && ls->split_a == 2 && nnext > NBI;
             const int64_t n1 = own_first ? std::min<int64_t>(ls->own_cols, nnext - NBI) : std::min<int64_t>(256, nnext);
             const bool split_a = (ls->split_a || fuse_a) && nnext > n1;
             if (fuse_a) {
@@ -1973,35 +1023,9 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
                     MNK_HIP(hipEventRecord(ctx->ev_next2[k], su));
                 }
             }
-            // D_{k+2}: the deferred K = Kd update of the panel after next (all its sources are final by now)
-            if (kd >= 0 && k >= kd - 1 && k + 2 < npanel) {
-                const int64_t j0 = bnd[k + 2], Nj = bnd[k + 3] - j0, Mj = Np - j0;
-                const double* Ad = ldl ? ls->wdefer.p + (j0 - c1) : F + j0;
-                const int64_t ldad = ldl ? ldwd : ld;
-                static const int defer_small = getenv("MNK_DEFER_SMALL") ? atoi(getenv("MNK_DEFER_SMALL")) : 1;
-                int nsplit = ls->defer_split;
-                while (nsplit > 1 && (Kd % nsplit != 0 || (Kd / nsplit) % 16 != 0)) --nsplit;
-                if (nsplit > 1) {
-                    // split-K: nsplit * tiles workgroups of the big-tile kernel, partial sums in scratch, fixed-order reduce
-                    const int64_t ldsx = Np - c1, sstride = ldsx * NBO;
-                    if (ls->sdefer.n < (size_t)(nsplit * sstride + SLACK)) {
-                        int rc0 = ls->sdefer.alloc((size_t)(nsplit * sstride + SLACK));
-                        if (rc0) return rc0;
-                        MNK_HIP(hipMemsetAsync(ls->sdefer.p, 0, ls->sdefer.n * sizeof(double), su));
-                    }
-                    rc = launch_gemm_nt_splitk(su, Mj, Nj, Kd, nsplit, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, ls->sdefer.p,
-                                               ldsx, sstride, ls->info_dev.p);
-                } else if (defer_small && gemm_nt_lower_tiles(Mj, Nj) < ls->small_tiles)
-                    rc = launch_gemm_nt_lower_small(su, Mj, Nj, Kd, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, ls->info_dev.p);
-                else
-                    rc = launch_gemm_nt(su, 2, Mj, Nj, Kd, Ad, ldad, F + j0, ld, F + j0 + j0 * ld, ld, nullptr, nullptr, 0,
-                                        ls->info_dev.p);
-                if (rc) return rc;
-            }
-            // (b) the rest of the trailing matrix: Mb rows, Nb columns of lower tiles (early panels: only the columns in
-            // front of c1, i.e. a trapezoid -- the rows behind c1 still get these columns)
+            // (b) the rest of the trailing matrix
             const int64_t Mb = Mt - nnext;
-            const int64_t Nb = early ? c1 - (kend + nnext) : Mb;
+            const int64_t Nb = Mb;
             bool shared_b = false;
             if (Mb > 0 && Nb > 0) {
                 const int ntiles = gemm_nt_lower_tiles(Mb, Nb);
@@ -2069,10 +1093,10 @@ int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows,
     const double* inv16 = ls->inv16.p + (j0 / NBI) * 1024;
     if (ls->algo == MNK_LDL)
         hipLaunchKernelGGL((trsm64_mfma_kernel<true, 1>), dim3(grid), dim3(256), 0, s, Fp, ldr, j0, j0 + NBI + nrows, dblk,
-                           inv16, ls->dinv.p, Wp, ldr, (int64_t)j0, ls->info_dev.p, (const int*)nullptr, 0);
+                           inv16, ls->dinv.p, Wp, ldr, (int64_t)j0, ls->info_dev.p);
     else
         hipLaunchKernelGGL((trsm64_mfma_kernel<false, 1>), dim3(grid), dim3(256), 0, s, Fp, ldr, j0, j0 + NBI + nrows, dblk,
-                           inv16, ls->dinv.p, (double*)nullptr, (int64_t)0, (int64_t)0, ls->info_dev.p, (const int*)nullptr, 0);
+                           inv16, ls->dinv.p, (double*)nullptr, (int64_t)0, (int64_t)0, ls->info_dev.p);
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -2137,10 +1161,9 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         return mnk_ls_fetch_info(ls);
     }
     if (hinfo < 0) {
-        // a bounded device-side wait between the diagonal-block stream and the panel stream expired (see handoff_wait)
-        set_error("factorize!: a device-side hand-off timed out (info = %d); the factor is invalid -- retry with option "
-                  "overlap = 0", hinfo);
-        ls->overlap = 0;
+        // a bounded device-side wait expired and there is no way to redo the factorization (no source to transfer again)
+        set_error("factorize!: a device-side hand-off timed out (info = %d) and the matrix cannot be transferred again; the "
+                  "factor is invalid -- set panel_algo = 1", hinfo);
         return -4;
     }
     ls->info = hinfo;
@@ -2165,46 +1188,3 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     return 0;
 }
 
-// Diagnostics (tools/potrf_ablation.py): average duration of `reps` dependent launches of the one-wave potrf64 on a
-// 64x64 SPD block, full kernel (variant 0) or with one piece removed (see potrf64w_body; results of variants are wrong).
-extern "C" int mnk_debug_potrf64(mnk_ctx* ctx, int variant, int reps, double* ms) {
-    MNK_REQUIRE(ctx && ms && reps > 0, "mnk_debug_potrf64: bad argument");
-    MNK_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    DevBuf<double> A, D, I, dv, di;
-    DevBuf<int> info;
-    int rc = A.alloc(4096) | D.alloc(4096) | I.alloc(1024) | dv.alloc(64) | di.alloc(64) | info.alloc(1);
-    if (rc) return -2;
-    std::vector<double> h(4096, 0.0);
-    for (int c = 0; c < 64; ++c)
-        for (int r = c; r < 64; ++r) h[r + 64 * c] = r == c ? 70.0 + c : 1.0 / (1.0 + r - c);
-    MNK_HIP(hipMemcpyAsync(A.p, h.data(), 4096 * sizeof(double), hipMemcpyHostToDevice, s));
-    MNK_HIP(hipMemsetAsync(info.p, 0, sizeof(int), s));
-    hipEvent_t e0, e1;
-    MNK_HIP(hipEventCreate(&e0));
-    MNK_HIP(hipEventCreate(&e1));
-#define MNK_PD(V) hipLaunchKernelGGL(potrf64w_dbg_kernel<V>, dim3(1), dim3(64), 0, s, A.p, D.p, I.p, dv.p, di.p, info.p)
-    for (int pass = 0; pass < 2; ++pass) {  // pass 0: warm-up
-        if (pass == 1) MNK_HIP(hipEventRecord(e0, s));
-        for (int r = 0; r < reps; ++r) {
-            switch (variant) {
-            case 1: MNK_PD(1); break;
-            case 2: MNK_PD(2); break;
-            case 3: MNK_PD(3); break;
-            case 4: MNK_PD(4); break;
-            case 5: MNK_PD(5); break;
-            case 6: MNK_PD(6); break;
-            default: MNK_PD(0); break;
-            }
-        }
-    }
-#undef MNK_PD
-    MNK_HIP(hipEventRecord(e1, s));
-    MNK_HIP(mnk::stream_wait(s));
-    float t = 0.f;
-    MNK_HIP(hipEventElapsedTime(&t, e0, e1));
-    *ms = (double)t / reps;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return 0;
-}

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_ke
     int64_t M, int64_t N, int64_t K, const double* __restrict__ A, int64_t lda,
     const double* __restrict__ B, int64_t ldb, double* C, int64_t ldc,
     const double* __restrict__ colscale, double* C2, int64_t ldc2, int ntm,
-    const int* __restrict__ info_flag, int tile_off, int* sig, int sig_val, int nc, int sw) {
+    const int* __restrict__ info_flag, int tile_off, int nc, int sw) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (info_flag != nullptr && *info_flag != 0) return;
 
@@ -271,17 +271,6 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_ke
     decode_tile<MODE>(logical, ntm, nc, sw, tm, tn);
     gemm_nt_tile<WM, WN, WT, MODE, LDL_EPI, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, K, A, lda, B, ldb, C, ldc, colscale,
                                                                        C2, ldc2, smem_raw);
-    // Optional hand-off: the workgroup that owns logical tile 0 (the next diagonal block of the factorization)
-    // publishes "tile 0 is complete in memory" so that the next potrf64 can start while the other tiles are still
-    // being updated: stores -> barrier -> one lane's agent-scope release -> drained flag store.
-    if (sig != nullptr && tm == 0 && tn == 0) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(sig, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 
 template <int WM, int WN, int WT, int MODE, int DBG>
@@ -330,40 +319,6 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_qu
     }
 }
 
-// Split-K variant for merged left-looking updates (long K, few tiles): workgroup (c, logical) computes the lower tile
-// `logical` over the K-chunk c into its own scratch image S_c (pre-zeroed: S_c = -A_c B_c^T on the lower tiles), so the
-// chunks run side by side and the sum is formed afterwards in a fixed order (splitk_reduce_kernel) -- deterministic, no
-// atomics.
-template <int WM, int WN, int WT>
-__global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_splitk_kernel(
-    int64_t M, int64_t N, int64_t Kc, const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
-    double* S, int64_t lds, int64_t sstride, int ntm, int ntiles, const int* __restrict__ info_flag, int nc, int sw) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if (info_flag != nullptr && *info_flag != 0) return;
-    const int c = (int)blockIdx.x / ntiles, logical = (int)blockIdx.x % ntiles;
-    int tm, tn;
-    decode_tile<2>(logical, ntm, nc, sw, tm, tn);
-    gemm_nt_tile<WM, WN, WT, 2, false, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, Kc, A + (int64_t)c * Kc * lda, lda,
-                                                                B + (int64_t)c * Kc * ldb, ldb, S + (int64_t)c * sstride, lds,
-                                                                nullptr, nullptr, 0, smem_raw);
-}
-
-// C(lower trapezoid, M x N) += S_0 + S_1 + ... (fixed order); the scratch images are zeroed again for their next use
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(double* __restrict__ C, int64_t ldc, double* __restrict__ S,
-                                                            int64_t lds, int64_t sstride, int nsplit, int64_t M, int64_t N,
-                                                            const int* __restrict__ info_flag) {
-    if (info_flag != nullptr && *info_flag != 0) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
-    if (i >= M || j >= N) return;
-    double acc = 0.0;
-    for (int c = 0; c < nsplit; ++c) {
-        double* p = S + (int64_t)c * sstride + i + j * lds;
-        acc += *p;
-        *p = 0.0;   // (also above the diagonal, where the diagonal tiles may have left something)
-    }
-    if (i >= j) C[i + j * ldc] += acc;
-}
-
 // width of the super-columns of the lower-tile enumeration (MNK_SUPER_W overrides; 1 = column-by-column)
 static int tile_super_width() {
     static const int sw = getenv("MNK_SUPER_W") ? std::max(1, atoi(getenv("MNK_SUPER_W"))) : 8;
@@ -373,8 +328,7 @@ static int tile_super_width() {
 template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
 static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                     const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
-                    double* C2, int64_t ldc2, const int* info_flag, int tile_begin = 0, int tile_count = -1,
-                    int* sig = nullptr, int sig_val = 0) {
+                    double* C2, int64_t ldc2, const int* info_flag, int tile_begin = 0, int tile_count = -1) {
     constexpr int BM = 16 * WT * WM, BN = 16 * WT * WN;
     const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
     int ntiles = ntm * ntn;
@@ -396,14 +350,14 @@ static int launch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const double
     if (tile_count >= 0) ntiles = std::min(ntiles - tile_begin, tile_count);
     if (ntiles <= 0) return 0;
     hipLaunchKernelGGL(kern, dim3(ntiles), dim3(64 * WM * WN), smem, s, M, N, K, A, lda, B, ldb, C,
-                       ldc, colscale, C2, ldc2, ntm, info_flag, tile_begin, sig, sig_val, nc, tile_super_width());
+                       ldc, colscale, C2, ldc2, ntm, info_flag, tile_begin, nc, tile_super_width());
     MNK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                    const double* B, int64_t ldb, double* C, int64_t ldc, const double* colscale,
-                   double* C2, int64_t ldc2, const int* info_flag, int* sig, int sig_val) {
+                   double* C2, int64_t ldc2, const int* info_flag) {
     if (M <= 0 || N <= 0) return 0;
     MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
     if (mode == 1) {
@@ -426,8 +380,7 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, con
         return launch_t<2, 2, 4, 0, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
     }
     if (mode == 2) {
-        return launch_t<2, 2, 4, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag, 0, -1, sig,
-                                           sig_val);
+        return launch_t<2, 2, 4, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
     }
     if (mode == 4) {
         return launch_t<2, 2, 4, 4, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
@@ -440,12 +393,10 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K, con
 // 128x128 tiling, for updates with too few tiles to fill the chip (latency-bound tail of the
 // factorization).
 int launch_gemm_nt_lower_small(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
-                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag, int* sig,
-                               int sig_val) {
+                               const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag) {
     if (M <= 0 || N <= 0) return 0;
     MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt: M,N must be multiples of 64, K of 16");
-    return launch_t<2, 2, 2, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag, 0, -1, sig,
-                                       sig_val);
+    return launch_t<2, 2, 2, 2, false>(s, M, N, K, A, lda, B, ldb, C, ldc, nullptr, nullptr, 0, info_flag);
 }
 
 // a contiguous range of the lower tiles of the 128x128 tiling (mode 2), for chunked launches
@@ -458,7 +409,6 @@ int launch_gemm_nt_lower_range(hipStream_t s, int64_t M, int64_t N, int64_t K, c
                                        tile_count);
 }
 
-int gemm_nt_lower_tiles(int64_t M, int64_t N);
 int gemm_nt_lower_tiles(int64_t M, int64_t N);
 int launch_gemm_nt_dbg(hipStream_t s, int shared_ab, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                        const double* B, int64_t ldb, double* C, int64_t ldc) {
@@ -515,35 +465,6 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
     const int ntn_q = (int)((N + BM - 1) / BM);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, s, M, N, K, A, lda, B, ldb, C, ldc, ntm, ntiles, counter,
                        info_flag, ntn_q < ntm ? ntn_q : ntm, tile_super_width());
-    MNK_HIP(hipGetLastError());
-    return 0;
-}
-
-// Merged left-looking update C(lower M x N) -= A B^T with K split into `nsplit` chunks (K % nsplit == 0, chunk % 16 == 0):
-// 128x128 tiles, nsplit * tiles workgroups, scratch of nsplit images of lds * N doubles (zero on entry, zero on exit).
-int launch_gemm_nt_splitk(hipStream_t s, int64_t M, int64_t N, int64_t K, int nsplit, const double* A, int64_t lda,
-                          const double* B, int64_t ldb, double* C, int64_t ldc, double* S, int64_t lds, int64_t sstride,
-                          const int* info_flag) {
-    if (M <= 0 || N <= 0) return 0;
-    MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && nsplit > 0 && K % nsplit == 0 && (K / nsplit) % BK == 0 && K > 0 && lds >= M &&
-                    sstride >= lds * N, "gemm_nt_splitk: bad shape");
-    constexpr int BM = 128;
-    const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BM - 1) / BM);
-    const int nc = ntn < ntm ? ntn : ntm;
-    const int ntiles = nc * ntm - nc * (nc - 1) / 2;
-    const size_t smem = 2 * tile_bk(2, 2, 4) * ((BM + 16) + (BM + 16)) * sizeof(double);
-    auto kern = gemm_nt_splitk_kernel<2, 2, 4>;
-    static std::atomic<uint64_t> attr_devs{0};
-    int dev = 0;
-    MNK_HIP(hipGetDevice(&dev));
-    if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
-        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nsplit * ntiles)), dim3(256), smem, s, M, N, K / nsplit, A, lda, B, ldb, S, lds,
-                       sstride, ntm, ntiles, info_flag, nc, tile_super_width());
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)N), dim3(256), 0, s, C, ldc, S, lds,
-                       sstride, nsplit, M, N, info_flag);
     MNK_HIP(hipGetLastError());
     return 0;
 }

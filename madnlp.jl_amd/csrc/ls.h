@@ -50,28 +50,18 @@ struct mnk_ls {
     int64_t single_rows = 2560;  // systems up to this (padded) order are factored as ONE outer panel on the whole chip (with the fused tail panels the look-ahead schedule wins from N = 3072 on: 2.12 vs 2.34 ms at 4096)
     int64_t tail_rows = 4096; // outer panels are tail_nbo wide once this many rows (or fewer) remain: one persistent launch per panel with the fused prologue, no inner update (C3: 11.80 -> 11.71 ms; 0 disables)
     int64_t tail_nbo = 256;
-    int defer_split = 0;      // > 1: the merged updates of the deferred schedule run as split-K launches with this many chunks
-    int64_t defer_rows = 0;   // > 0: the early outer panels do not update the last defer_rows rows/columns; merged left-looking updates under the tail's pivot chain do (factor.hip)
-    mnk::DevBuf<double> sdefer;  // split-K partial sums of the merged updates (zero between uses)
-    mnk::DevBuf<double> wdefer;  // L*D of the rows behind the deferred region's first column (LDL^T only)
     int small_tiles_mid = 1000;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, inv16, linv256, linv256t, dvec, dinv, xwork;
-    int overlap = 0;  // panel_algo 1: potrf64 on a companion stream, started by a flag from the update kernel's tile 0
-                      // (measured: no gain at N = 11192, 12.51 vs 12.61 ms, and 2x slower at N = 2048 -- cross-queue dispatch
-                      // latency eats the overlap; off by default)
     int epoch = 0;    // value the hand-off flags of the current factorization carry
-    mnk::DevBuf<int> flag_u, flag_p;
+    mnk::DevBuf<int> flag_p;
     int panel0_whole = 1;  // look-ahead: the first outer panel is factored on the whole chip before the streams fork
-    int small_tiles_256 = 160;  // panel_algo 3: inner K >= 256 updates with fewer 128x128 tiles than this use 64x64 tiles
     int algo_now = 1;    // the panel algorithm of the current factorization (panel_algo, or 1 where 4 is not safe)
     bool pp_blocked = false;
     int pp_fallbacks = 0;
-    int64_t pp_nb8_rows = 0;  // > 0: persistent panel launches cover 8 blocks once this many rows (or fewer) remain
     int64_t pp_fuse_rows = 4096; // > 0: once this many rows (or fewer) remain, persistent panel launches apply the columns in front of them themselves
     int64_t own_cols = 128;   // split_a = 2: columns of the next panel that the panel stream updates itself
-    int pp_nb = 4;       // panel_algo 4: 64-column blocks per persistent panel launch (4 or 8)
-    int panel_algo = 4;  // 3: potrf256 + trsm256 per 256 columns (measured slower, kept for A/B); 1: potrf64 + MFMA triangular solve + recursive inner updates; 0: fused elimination kernel (round 1)
+    int panel_algo = 4;  // 4: persistent panel kernel (one flag-synchronized launch per 256 columns); 1: one launch per piece (potrf64w + MFMA triangular solve + recursive inner updates), also the fallback of 4
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
     long ps_spin_limit = 6000000;  // polls (~0.5 us each) a persistent-solve wait may take before it gives up

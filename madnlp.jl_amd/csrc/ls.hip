@@ -81,9 +81,6 @@ static void ctx_free(mnk_ctx* c) {
     for (hipEvent_t e : c->ev_next) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_next2) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
-    if (c->ev_q) (void)hipEventDestroy(c->ev_q);
-    if (c->sq) (void)hipStreamDestroy(c->sq);
-    if (c->sq0) (void)hipStreamDestroy(c->sq0);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -201,17 +198,6 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
         MNK_HIP(hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, prio_hi));
         MNK_HIP(hipStreamCreateWithPriority(&c->su, hipStreamNonBlocking, prio_lo));
     }
-    // companion streams of the diagonal-block kernels: same CU set as the panel stream / the whole chip
-    if (c->panel_cus > 0) {
-        if (!make_masked_stream(total, bits.data(), c->panel_cus, c->sq)) c->sq = nullptr;
-    }
-    if (!c->sq) {
-        int prio_lo = 0, prio_hi = 0;
-        MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        MNK_HIP(hipStreamCreateWithPriority(&c->sq, hipStreamNonBlocking, prio_hi));
-    }
-    MNK_HIP(hipStreamCreateWithFlags(&c->sq0, hipStreamNonBlocking));
-    MNK_HIP(hipEventCreateWithFlags(&c->ev_q, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
     g_live_ctx[device & 63].fetch_add(1, std::memory_order_relaxed);
@@ -267,15 +253,9 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
-    if (const char* e = getenv("MNK_PP_NB")) ls->pp_nb = atoi(e) == 4 ? 4 : 8;
-    if (const char* e = getenv("MNK_PP_NB8_ROWS")) ls->pp_nb8_rows = atol(e);
     if (const char* e = getenv("MNK_PP_FUSE_ROWS")) ls->pp_fuse_rows = atol(e);
-    if (const char* e = getenv("MNK_DEFER_ROWS")) ls->defer_rows = atol(e);
-    if (const char* e = getenv("MNK_DEFER_SPLIT")) ls->defer_split = atoi(e);
     if (const char* e = getenv("MNK_OWN_COLS")) ls->own_cols = std::max<long>(64, atol(e) / 64 * 64);
     if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
-    if (const char* e = getenv("MNK_OVERLAP")) ls->overlap = atoi(e);
-    if (const char* e = getenv("MNK_SMALL_TILES_256")) ls->small_tiles_256 = atoi(e);
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
     ls->ldw = ls->Np;
@@ -345,18 +325,16 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
     if (!strcmp(key, "small_tiles_mid")) { ls->small_tiles_mid = (int)value; return 0; }
-    // 1 (default): one-wave potrf64 + trsm64 + recursive inner updates per 64 columns; 3: potrf256 + trsm256 per 256
-    // columns (one launch per four pivot chains; measured 5 % slower at N = 11192, kept for A/B runs); 2: the same with the 256-thread LDS potrf64; 0: the fused elimination kernel of round 1
-    if (!strcmp(key, "panel_algo")) { ls->panel_algo = (int)value; return 0; }
+    // 4 (default): persistent panel kernel; 1: one launch per piece (also the fallback of 4)
+    if (!strcmp(key, "panel_algo")) {
+        MNK_REQUIRE((int)value == 1 || (int)value == 4, "panel_algo must be 1 or 4");
+        ls->panel_algo = (int)value;
+        return 0;
+    }
     if (!strcmp(key, "pp_fuse_rows")) { ls->pp_fuse_rows = (int64_t)value; return 0; }
-    if (!strcmp(key, "defer_rows")) { ls->defer_rows = (int64_t)value; return 0; }
-    if (!strcmp(key, "defer_split")) { ls->defer_split = (int)value; return 0; }
-    if (!strcmp(key, "pp_nb")) { ls->pp_nb = (int)value == 4 ? 4 : 8; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
-    // 1: potrf64 overlaps the inner update of the previous block (companion stream + device flags); default 0 (no gain measured)
-    if (!strcmp(key, "overlap")) { ls->overlap = (int)value; return 0; }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
     if (!strcmp(key, "ps_spin_limit")) {  // polls a persistent-solve wait may take before it gives up
         MNK_REQUIRE(value >= 1024.0, "ps_spin_limit must be at least 1024");

@@ -508,29 +508,3 @@ def test_device_feeders_dense_systems_bit_exact(ctx, kind):
     kh.solve_kkt_device(wd)
     assert np.abs(wd - wo.values).max() <= 1e-8 * max(1.0, np.abs(wo.values).max())
     kh.close()
-
-
-def test_deferred_tail_region_schedule_is_correct(ctx):
-    """`defer_rows` (measured slower, kept for A/B -- DESIGN 5a): the early outer panels skip the last rows/columns and
-    merged left-looking updates deliver them under the tail's pivot chain; same factor as the default schedule."""
-    rng = np.random.default_rng(5)
-    n = 3200
-    G = rng.standard_normal((n, 64))
-    A = G @ G.T + np.diag(rng.uniform(1.0, 2.0, n))
-    A[n // 2:, n // 2:] -= np.diag(rng.uniform(3.0, 5.0, n - n // 2)) + 2 * (G[n // 2:] @ G[n // 2:].T)   # indefinite: LDL^T
-    b = rng.standard_normal(n)
-    sols, inertias = [], []
-    for defer, split in ((0, 0), (1536, 0), (1536, 4)):
-        M = mj.HipLinearSolver(np.asfortranarray(np.tril(A)), ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL, outer_block=512, single_rows=0))
-        M.set_option("defer_rows", defer)
-        M.set_option("defer_split", split)      # split-K merged updates (gemm_nt_splitk_kernel + fixed-order reduce)
-        M.factorize()
-        inertias.append(M.inertia())
-        x = b.copy()
-        M.solve_linear_system(x)
-        sols.append(x)
-        assert np.abs(A @ x - b).max() <= 1e-8 * max(1.0, np.abs(A).max() * np.abs(x).max())
-        M.close()
-    assert inertias[0] == inertias[1] == inertias[2]
-    for x in sols[1:]:
-        np.testing.assert_allclose(x, sols[0], rtol=0, atol=1e-9 * np.abs(sols[0]).max())
