@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
-SOURCES = ["gemm_f64.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip", "ipm_vec.hip"]
-HEADERS = ["common.h", "ls.h", "kkt_vec.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
+SOURCES = ["gemm_f64.hip", "dag.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip", "ipm_vec.hip"]
+HEADERS = ["common.h", "ls.h", "kkt_vec.h", "gemm_tile.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
 
 MNK_HOST, MNK_DEVICE = 0, 1
 MNK_BUNCHKAUFMAN, MNK_LU, MNK_QR, MNK_CHOLESKY, MNK_LDL, MNK_EVD = 1, 2, 3, 4, 5, 6
@@ -34,7 +34,7 @@ def _stale() -> bool:
 # than 256 registers per lane, and with the flag the accumulators are pinned to the 256 architectural VGPRs and the rest
 # is shuffled through AGPRs -- hipcc 7.2 then miscompiles it (wrong pivots / memory faults that appear and disappear with
 # unrelated, never-executed code; bisected in round 2).
-FILE_FLAGS = {"gemm_f64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FILE_FLAGS = {"gemm_f64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dag.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

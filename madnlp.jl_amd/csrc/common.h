@@ -104,6 +104,9 @@ struct mnk_ctx {
     // look-ahead of the factorization: panel stream (high priority), update stream, fork/join events
     hipStream_t sp = nullptr, su = nullptr;
     int panel_cus = 0;  // > 0: sp is restricted to this many CUs and su to the others (CU masks)
+    // task-DAG schedule (dag.hip): the pivot chain needs only a few CUs, the persistent bulk kernel gets all the others
+    hipStream_t sp_dag = nullptr, su_dag = nullptr;
+    int dag_cus = 0;    // > 0: sp_dag is restricted to this many CUs and su_dag to the others
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_next, ev_next2, ev_bdone;
     int num_cu = 256;   // CUs this context may use (the whole device, or its partition)
@@ -140,5 +143,14 @@ int launch_gemm_nt_lower_range(hipStream_t s, int64_t M, int64_t N, int64_t K, c
 int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                          const double* B, int64_t ldb, double* C, int64_t ldc, int* counter, int cus,
                          const int* info_flag);
+
+// ---- task-DAG schedule (dag.hip): persistent left-looking tile kernel beside the pivot chain -------------------------
+// index of the "band tile (I, Jt) accumulated" flag: a tile row is in the band of two strip-columns (as follower of one,
+// as diagonal rows of the next), each with two tile columns
+__host__ __device__ inline int dag_af_index(int I, int Jt) { return (I * 2 + ((Jt >> 1) & 1)) * 2 + (Jt & 1); }
+void dag_build_tasks(int ntile, std::vector<int>& out);  // 4 ints per task: type, I, J, kend
+int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
+                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* qctr, int* info,
+                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace);
 
 }  // namespace mnk

@@ -1,0 +1,367 @@
+// Task-DAG schedule of the blocked factorization (panel_algo = 5): the bulk of `factorize!` (reference
+// src/LinearSolvers/lapack_common.jl:54-66 -> dsytrf / dpotrf, src/LinearSolvers/lapack.jl:145-148,164-167) as ONE
+// persistent, LEFT-LOOKING tile kernel that runs beside the pivot chain instead of one trailing-update launch per outer
+// panel.
+//
+// Units: block = 64 columns, tile = 128 x 128, strip-column = 256 columns (one persistent panel launch of factor.hip).
+//   * chain (factor.hip, ppanel_kernel, panel stream, a few CUs): for every strip-column Js the eight 64-row strips of the
+//     BAND -- its four diagonal strips and the four below them, which are the diagonal strips of Js + 1.  A strip applies
+//     the previous strip-column itself (left-looking prologue, K = 256) and then runs the right-looking pivot chain.
+//   * bulk (this file, update stream, all other CUs): every 128 x 128 tile (I, J) below the band is ONE task: it
+//     accumulates  C(I, J) -= sum_{k < 128 J} L(I, k) d_k L(J, k)^T  in registers over the whole depth (the k-loop of the
+//     MFMA tile kernel, waiting on per-row progress counters where the factor is not final yet), writes the tile ONCE,
+//     and finalizes it in place: X = C L_JJ^-T (D^-1) against the two diagonal blocks of tile column J.  The band's own
+//     tiles are accumulated the same way up to the columns the chain's prologue covers (BANDACC tasks).
+//   * order: tasks are drawn from one queue in a topological order (column-major, band tiles first); a workgroup that
+//     holds a task only ever waits for tasks drawn before it, so any number of resident workgroups makes progress.
+//   * progress: front[t] = number of leading 128-column tile columns for which the 64-row strip t of L is final
+//     (monotone; zeroed per factorization); af[] = "band tile accumulated".  Producer: stores -> barrier -> one lane's
+//     agent-scope release -> drained relaxed store; consumer: relaxed polls by one wave, one agent-scope acquire, barrier.
+//     Every wait is bounded (info = -7 -> the host redoes the factorization with the launch-per-piece schedule).
+// Nothing is updated right-looking any more: every element of the factor is written once by the bulk kernel (plus once by
+// its finalization), the trailing matrix is not re-read and re-written per outer panel, and the look-ahead is as deep as
+// the number of resident workgroups -- the pivot chain never waits for a bulk update of an older panel.
+// LDL^T: V = L D is kept in a second N x N array (written once per element, next to L): scaling the B operand's k-columns
+// by d_k inside the k-loop instead was built first and cost 16 % of the loop (fp64 VALU work between the fp64 MFMAs).
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <vector>
+
+#include "gemm_tile.h"
+#include "ls.h"
+
+namespace mnk {
+
+struct DagArgs {
+    double* F;
+    int64_t ld;
+    double* V;            // LDL^T: V = L D, same layout as F (the B operand of the updates); Cholesky: nullptr (V = L)
+    const double* dinv;   // 1 / d_k
+    const double* dblk;   // factored 64x64 diagonal blocks
+    const double* inv16;  // inverses of their 16x16 diagonal sub-blocks
+    const int4* tasks;    // (type, I, J, kend)
+    int ntasks;
+    int* front;
+    int* af;
+    int* qctr;
+    int* info;
+    const int* prog;      // the pivot chain's per-block progress words (epoch16 + steps completed), see ppanel_kernel
+    int epoch16;
+    long spin_limit;
+    unsigned long long* trace;  // diagnostics (option dag_trace): 8 time stamps per task
+};
+
+constexpr int DAG_BULK = 0, DAG_BANDACC = 1;
+
+// Wave 0 waits until min(front[s0..s3]) > c and returns that minimum (clamped to kend): tile columns [c, ret) are final
+// for all four strips.  -1: the factorization failed elsewhere or the wait expired.  Ends with an acquire + barrier.
+__device__ __forceinline__ int dag_wait_front(const DagArgs& a, int s0, int s1, int s2, int s3, int c, int kend, int* s_val) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const int idx = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? s2 : s3));
+        long spins = 0;
+        int r;
+        for (;;) {
+            int f = lane < 4 ? __hip_atomic_load(a.front + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT_MAX;
+            f = min(f, __shfl_xor(f, 1));
+            f = min(f, __shfl_xor(f, 2));
+            r = __builtin_amdgcn_readfirstlane(f);
+            if (r > c) break;
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 255) == 0) {
+                if (__hip_atomic_load(a.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { r = -1; break; }
+                if (spins > a.spin_limit) {
+                    if (lane == 0) atomicCAS(a.info, 0, -7);
+                    r = -1;
+                    break;
+                }
+            }
+        }
+        if (r > kend) r = kend;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) *s_val = r;
+    }
+    __syncthreads();
+    const int r = *s_val;
+    __syncthreads();
+    return r;
+}
+
+// Wave 0 waits until *w0 >= t0 and *w1 >= t1 (progress words of the pivot chain); false: failed / expired.  Acquire + barrier.
+__device__ __forceinline__ bool dag_wait_words(const DagArgs& a, const int* w0, int t0, const int* w1, int t1, int* s_val) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        long spins = 0;
+        int ok = 1;
+        for (;;) {
+            const int v = lane < 2 ? __hip_atomic_load(lane == 0 ? w0 : w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT_MAX;
+            if (__all(v >= (lane == 0 ? t0 : (lane == 1 ? t1 : INT_MIN)))) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255) == 0) {
+                if (__hip_atomic_load(a.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (spins > a.spin_limit) {
+                    if (lane == 0) atomicCAS(a.info, 0, -7);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) *s_val = ok;
+    }
+    __syncthreads();
+    const int ok = *s_val;
+    __syncthreads();
+    return ok != 0;
+}
+
+// In-place finalization of a bulk tile against the two factored diagonal blocks (ja, jb = ja + 1) of its tile column:
+// the block substitution of trsm64_mfma_kernel (factor.hip) for the 64 columns of block ja, the K = 64 update of the
+// columns of block jb with L(jb, ja), the substitution for block jb.  Wave w owns the 16-row strips 2w, 2w + 1 of the
+// tile (C^T layout: register r of column block cb at lane (l15, l4) is C[row + l15][16 cb + l4 + 4 r]) and runs their two
+// independent MFMA chains interleaved.  The operands every wave needs -- the strictly lower 16x16 blocks and the 16x16
+// inverses of a diagonal block, then L(jb, ja) -- are staged ONCE per workgroup through the k-loop's LDS tiles in MFMA
+// A-operand order (one v4 per lane and block: M[l15][l4 + 4 s], s = 0..3): fed straight from global memory the chains
+// waited for one L2 round trip per MFMA (90 us per tile measured, on the critical path of every row of tiles; ~30 us
+// staged).  (Starting the block-ja part before D_jb is published, with all operands prefetched into registers, was built
+// and measured slower: the 168-register budget of the k-loop forces the strips to run one after the other.)
+template <bool LDL>
+__device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0, int64_t col0, int ja, char* smem_raw, int tid) {
+    v4f64* S = reinterpret_cast<v4f64*>(smem_raw);  // up to 16 blocks x 64 lanes (32 KB of the 36 KB)
+    double* F = a.F;
+    const int64_t ld = a.ld;
+    const int lane = tid & 63, w = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double* Fs = F + (row0 + 32 * w + l15) + (col0 + l4) * ld;  // this lane's element (row of strip 0, column l4)
+    double* Vs = LDL ? a.V + (row0 + 32 * w + l15) + (col0 + l4) * ld : nullptr;
+
+    // blocks 0..5: -L_kk[cb, ib] for (cb, ib) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2); blocks 6..9: inv(L_kk[cb, cb])
+    auto fill_diag = [&](int jk) {
+        const double* __restrict__ Dk = a.dblk + (int64_t)jk * 4096;
+        const double* __restrict__ Iv = a.inv16 + (int64_t)jk * 1024;
+        for (int slot = tid; slot < 640; slot += 256) {
+            const int q = slot >> 6, i = slot & 15, k4 = (slot >> 4) & 3;
+            v4f64 v;
+            if (q < 6) {
+                const int cb = q == 0 ? 1 : (q < 3 ? 2 : 3), ib = q == 0 ? 0 : (q < 3 ? q - 1 : q - 3);
+                const double* src = Dk + (16 * cb + i) + 64 * (16 * ib + k4);
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) v[sx] = -src[64 * 4 * sx];
+            } else {
+                const double* src = Iv + (q - 6) * 256 + i + 16 * k4;
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) v[sx] = src[16 * 4 * sx];
+            }
+            S[slot] = v;
+        }
+    };
+    // X <- X L_kk^-T for both strips; stores L (LDL^T: V D^-1, and V next to it), keeps V in X
+    auto trsm = [&](v4f64 (&X)[2][4], int coff) {
+        double di[4][4];  // (fetched before the first store: a load behind a possibly aliasing store waits for it)
+        if (LDL) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) di[cb][r] = a.dinv[col0 + l4 + coff + 16 * cb + 4 * r];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            v4f64 t0 = X[0][cb], t1 = X[1][cb];
+#pragma unroll
+            for (int ib = 0; ib < cb; ++ib) {
+                const v4f64 aop = S[(cb * (cb - 1) / 2 + ib) * 64 + lane];
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) {
+                    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[0][ib][sx], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[1][ib][sx], t1, 0, 0, 0);
+                }
+            }
+            const v4f64 iv = S[(6 + cb) * 64 + lane];
+            v4f64 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[sx], t0[sx], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[sx], t1[sx], x1, 0, 0, 0);
+            }
+            X[0][cb] = x0;
+            X[1][cb] = x1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t cc = (int64_t)(coff + 16 * cb + 4 * r) * ld;
+                Fs[cc] = LDL ? x0[r] * di[cb][r] : x0[r];
+                Fs[cc + 16] = LDL ? x1[r] * di[cb][r] : x1[r];
+                if (LDL) {
+                    Vs[cc] = x0[r];
+                    Vs[cc + 16] = x1[r];
+                }
+            }
+        }
+    };
+    auto load_strips = [&](v4f64 (&X)[2][4], int coff) {
+#pragma unroll
+        for (int ns = 0; ns < 2; ++ns)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[ns][cb][r] = Fs[16 * ns + (int64_t)(coff + 16 * cb + 4 * r) * ld];
+    };
+
+    v4f64 Xa[2][4], Xb[2][4];
+    load_strips(Xa, 0);
+    fill_diag(ja);
+    __syncthreads();
+    trsm(Xa, 0);
+    __syncthreads();
+    load_strips(Xb, 64);
+    {   // blocks (cb2, ib): -L(jb, ja)[16 cb2 + i][16 ib + k]
+        const double* __restrict__ Lba = F + (int64_t)64 * (ja + 1) + (int64_t)64 * ja * ld;
+        for (int slot = tid; slot < 1024; slot += 256) {
+            const int q = slot >> 6, i = slot & 15, k4 = (slot >> 4) & 3;
+            const double* src = Lba + (16 * (q >> 2) + i) + (int64_t)(16 * (q & 3) + k4) * ld;
+            v4f64 v;
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) v[sx] = -src[(int64_t)(4 * sx) * ld];
+            S[slot] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb2 = 0; cb2 < 4; ++cb2)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const v4f64 aop = S[(cb2 * 4 + ib) * 64 + lane];
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) {
+                Xb[0][cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], Xa[0][ib][sx], Xb[0][cb2], 0, 0, 0);
+                Xb[1][cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], Xa[1][ib][sx], Xb[1][cb2], 0, 0, 0);
+            }
+        }
+    __syncthreads();
+    fill_diag(ja + 1);
+    __syncthreads();
+    trsm(Xb, 64);
+}
+
+template <bool LDL>
+__global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int s_val;
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // (keeps the thread-id arithmetic out of the task loop's live ranges, as in gemm_nt_tile)
+        if (tid == 0)
+            s_val = __hip_atomic_load(a.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? INT_MAX : atomicAdd(a.qctr, 1);
+        __syncthreads();
+        const int t = s_val;
+        __syncthreads();
+        if (t >= a.ntasks) return;
+        const int4 tk = a.tasks[t];
+        const int type = __builtin_amdgcn_readfirstlane(tk.x), I = __builtin_amdgcn_readfirstlane(tk.y),
+                  J = __builtin_amdgcn_readfirstlane(tk.z), kend = __builtin_amdgcn_readfirstlane(tk.w);
+        const int64_t row0 = (int64_t)128 * I, col0 = (int64_t)128 * J;
+        unsigned long long* tr = a.trace != nullptr && tid == 0 ? a.trace + (int64_t)t * 8 : nullptr;
+        if (tr) { tr[0] = wall_clock64(); tr[6] = 0; tr[7] = 0; }
+
+        v4f64 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+        // k-tiles [0, limit) have final operands; the gate blocks at the first k-tile of a tile column that is not final yet
+        int limit = 0;
+        auto gate = [&](int kt) -> bool {
+            if (kt < limit) return true;
+            const unsigned long long w0 = tr ? wall_clock64() : 0;
+            const int r = dag_wait_front(a, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kt >> 4, kend, &s_val);
+            if (tr) { const unsigned long long w1 = wall_clock64(); tr[1] = w0; tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; }
+            if (r < 0) return false;
+            limit = __builtin_amdgcn_readfirstlane(r) * 16;
+            // A task that has caught up with the pivot chain (the wait released only a tile column or two) is on the critical
+            // path of the next band; one that still has a deep backlog is throughput work.  Both kinds share the CU's
+            // matrix cores: the former issue first.
+            if (limit - kt <= 32) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+            return true;
+        };
+        if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, a.F + row0, a.ld, (LDL ? a.V : a.F) + col0, a.ld, kend * 16, smem_raw, tid, gate))
+            return;
+        // C(I, J) -= acc (a diagonal tile: lower wave tiles only), written once
+        if (kend > 0)
+            gemm_nt_epilogue<2, 2, 4, 2, false>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, a.F, a.ld, nullptr, nullptr, 0, tid);
+        __builtin_amdgcn_s_setprio(3);
+        if (tr) tr[3] = wall_clock64();
+        if (type == DAG_BULK) {
+            // the diagonal blocks of tile column J and L(2J + 1, 2J)
+            if (dag_wait_front(a, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return;
+            if (tr) tr[4] = wall_clock64();
+            dag_finalize_tile<LDL>(a, row0, col0, 2 * J, smem_raw, tid);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (type == DAG_BULK) {
+                __hip_atomic_store(a.front + 2 * I, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.front + 2 * I + 1, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(a.af + dag_af_index(I, J), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tr) tr[5] = wall_clock64();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();  // (s_val and the LDS tiles are reused by the next task)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+// Task list for a matrix of `ntile` 128-row tiles (depends on the order only; cached by the caller).
+void dag_build_tasks(int ntile, std::vector<int>& out) {
+    out.clear();
+    auto emit = [&](int type, int I, int J, int kend) {
+        out.push_back(type); out.push_back(I); out.push_back(J); out.push_back(kend);
+    };
+    // Band tiles of strip-column Js (tile rows 2Js .. 2Js+3, tile columns 2Js, 2Js+1, lower part) are accumulated over the
+    // tile columns k < 2Js - 2 (the chain's prologue applies strip-column Js - 1 itself); their last sources are the bulk
+    // tiles (r, 2Js - 3), so they are queued right behind those -- at the head of tile column 2Js - 3.
+    for (int Jt = 0; Jt < ntile; ++Jt) {
+        const int Js = Jt / 2;
+        for (int I = 2 * Js + 4; I < ntile; ++I) {
+            emit(DAG_BULK, I, Jt, Jt);
+            if ((Jt & 1) && I < 2 * Js + 8) {   // I = 2(Js+2) .. 2(Js+2)+3: band rows of strip-column Js + 2
+                const int Jb = Js + 2, kend = 2 * Jb - 2;  // = Jt + 1 - ... tile columns [0, 2Jb - 2) = [0, Jt + 1)
+                for (int cc = 2 * Jb; cc <= 2 * Jb + 1 && cc < ntile; ++cc)
+                    if (I >= cc) emit(DAG_BANDACC, I, cc, kend);
+            }
+        }
+    }
+}
+
+template <bool LDL>
+static int launch_bulk_t(hipStream_t s, const DagArgs& a, int nwg) {
+    const size_t smem = 2 * 8 * ((128 + 16) + (128 + 16)) * sizeof(double);
+    auto kern = dag_bulk_kernel<LDL>;
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    MNK_HIP(hipGetDevice(&dev));
+    if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, s, a);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
+                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* qctr, int* info,
+                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace) {
+    if (ntasks <= 0) return 0;
+    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, qctr, info, prog, epoch16, spin_limit, trace};
+    return ldl ? launch_bulk_t<true>(s, a, nwg) : launch_bulk_t<false>(s, a, nwg);
+}
+
+}  // namespace mnk

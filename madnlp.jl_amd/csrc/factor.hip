@@ -408,6 +408,17 @@ __device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int targ
     for (int i = 0; i < NB; ++i) seen[i] = v[i];
 }
 
+// Task-DAG schedule (dag.hip): the launch covers only the band of its strip-column and synchronizes with the persistent
+// bulk kernel through progress counters instead of stream events.  front == nullptr: off.
+struct PpDag {
+    int* front;          // front[t]: leading 128-column tile columns for which the 64-row strip t of L is final
+    const int* af;       // "band tile accumulated" flags written by the bulk kernel (dag_af_index)
+    int need_front;      // > 0: strips t >= 4 (rows the bulk kernel finalizes) wait for front[t] >= need_front
+    int af_tilecol;      // >= 0: first tile column of this launch; its band tiles were pre-accumulated by the bulk kernel
+    long spin_limit;
+    unsigned long long* trace;  // diagnostics: 4 time stamps per strip of this launch
+};
+
 template <bool LDL, int NB>
 __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int64_t ld, int64_t p0, int nb, int64_t Np,
                                                       double* __restrict__ dblk0, double* __restrict__ inv0,
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                                                       double* __restrict__ W, int64_t ldw, int64_t wcol0,
                                                       int* __restrict__ info, double pivot_tol, int* __restrict__ prog,
                                                       int epoch16, int dbg_missing, const double* __restrict__ Vp,
-                                                      int64_t ldv, int Kp) {
+                                                      int64_t ldv, int Kp, PpDag dag) {
     extern __shared__ __attribute__((aligned(128))) char pp_smem[];
     v4d* stage = reinterpret_cast<v4d*>(pp_smem);          // [2][1024] v4d
     v4d* own = reinterpret_cast<v4d*>(pp_smem) + 2 * 1024;  // [1024] v4d
@@ -435,6 +446,36 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
     int seen[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) seen[c] = 0;
+    const int tabs = (int)(p0 >> 6) + t;  // this strip's 64-row block
+    unsigned long long* ptr_tr = dag.trace != nullptr && tid == 0 ? dag.trace + 4 * t : nullptr;
+    if (ptr_tr) ptr_tr[0] = wall_clock64();
+    if (dag.front != nullptr && (dag.af_tilecol >= 0 || (dag.need_front > 0 && t >= 4))) {
+        // the strip's tiles as the bulk kernel leaves them (accumulated over the older columns), and -- rows below the
+        // previous launch's band -- its rows of the previous strip-column, finalized by the bulk kernel
+        if (tid == 0) {
+            auto wait_ge = [&](const int* word, int target) {
+                long spins = 0;
+                while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++spins & 255) == 0) {
+                        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        if (spins > dag.spin_limit) {
+                            atomicCAS(info, 0, -7);
+                            break;
+                        }
+                    }
+                }
+            };
+            if (dag.need_front > 0 && t >= 4) wait_ge(dag.front + tabs, dag.need_front);
+            if (dag.af_tilecol >= 0) {
+                wait_ge(dag.af + dag_af_index(tabs >> 1, dag.af_tilecol), 1);
+                if (t >= 2 && nb > 2) wait_ge(dag.af + dag_af_index(tabs >> 1, dag.af_tilecol + 1), 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    if (ptr_tr) ptr_tr[1] = wall_clock64();
 
     v4d X[4 * NB];
 #pragma unroll
@@ -529,7 +570,13 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                                nullptr);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(prog + j, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                __hip_atomic_store(prog + j, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (its last step: the strip's rows are final through the tile column of block j)
+                if (dag.front != nullptr)
+                    __hip_atomic_store(dag.front + tabs, (int)(p0 >> 7) + (j >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dag.trace != nullptr) dag.trace[4 * t + 2] = wall_clock64();
+            }
             return true;
         }
         // ---- wait for the diagonal block j, X = T L_jj^-T
@@ -586,7 +633,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                 const double v = X[4 * j + ib][r];
                 if (LDL) {
                     lv[r] = v * dsc[ib][r];
-                    W[row + (wcol0 + c) * ldw] = v;
+                    if (W != nullptr) W[row + (wcol0 + c) * ldw] = v;
                 } else {
                     lv[r] = v;
                 }
@@ -594,13 +641,18 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
             }
             if (diag_strip) own[(w * 4 + ib) * 64 + lane] = lv;
         }
-        if (diag_strip) {
+        // task-DAG schedule: the strip's rows are final through a whole tile column after every second block
+        const bool pub_front = dag.front != nullptr && ((j & 1) != 0 || j == jmax);
+        if (diag_strip || pub_front) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(prog + t, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (diag_strip) __hip_atomic_store(prog + t, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pub_front)
+                    __hip_atomic_store(dag.front + tabs, (int)(p0 >> 7) + (j >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pub_front && dag.trace != nullptr) dag.trace[4 * t + (j == jmax ? 2 : 3)] = wall_clock64();
             }
         }
         // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
@@ -775,7 +827,7 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
     hipLaunchKernelGGL((ppanel_kernel<LD, NBT>), dim3(grid), dim3(256), PP_LDS_BYTES, s, F, ld, p, nbk, Np, ls->dblk.p, \
                        ls->inv16.p, ls->dvec.p, ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0,  \
                        p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp,  \
-                       ldv, Kp)
+                       ldv, Kp, PpDag{nullptr, nullptr, 0, -1, 0, nullptr})
         if (ldl) MNK_PP(true, 4);
         else MNK_PP(false, 4);
 #undef MNK_PP
@@ -876,6 +928,84 @@ int64_t mnk_ls_effective_nbo(const mnk_ls* ls) {
     return (ls->single_rows > 0 && ls->Np <= ls->single_rows) ? ls->Np : ls->nbo;
 }
 
+// panel_algo = 5: task-DAG schedule (dag.hip).  The panel stream runs one persistent panel launch per strip-column of 256
+// columns over the BAND only (eight 64-row strips: the four diagonal strips and the four below them), each applying the
+// previous strip-column to its own rows first; ONE persistent kernel on all the other CUs computes every tile below the
+// band left-looking.  The two sides meet through progress counters in device memory; no event is recorded or awaited
+// between the fork and the join.
+static int run_factorization_dag(mnk_ls* ls) {
+    mnk_ctx* ctx = ls->ctx;
+    hipStream_t s = ctx->stream, sp = ctx->sp_dag, su = ctx->su_dag;
+    const int64_t Np = ls->Np, ld = ls->ld;
+    const bool ldl = ls->algo == MNK_LDL;
+    double* F = ls->fact.p;
+    const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI);
+    if (!ls->dag_tasks.p) {
+        std::vector<int> h;
+        mnk::dag_build_tasks(ntile, h);
+        ls->dag_ntasks = (int)(h.size() / 4);
+        if (ls->dag_tasks.alloc(h.size() + 4)) return -2;
+        if (!h.empty()) MNK_HIP(hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        MNK_HIP(mnk::stream_wait(s));  // (h goes out of scope)
+        if (ls->dag_flags.alloc((size_t)1 + nblk + 4 * (size_t)ntile)) return -2;
+    }
+    if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) return -2;  // V = L D of every column (LDL^T)
+    double* V = ldl ? ls->vfull.p : nullptr;
+    MNK_HIP(hipMemsetAsync(ls->dag_flags.p, 0, ((size_t)1 + nblk + 4 * (size_t)ntile) * sizeof(int), s));
+    int* qctr = ls->dag_flags.p;
+    int* front = qctr + 1;
+    int* af = front + nblk;
+    {   // 96 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        MNK_HIP(hipGetDevice(&dev));
+        if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
+    }
+    const long spin_limit = 1L << 24;
+    unsigned long long* trace = nullptr;
+    if (ls->dag_trace_on) {
+        const size_t ntr = (size_t)ls->dag_ntasks * 8 + (size_t)(Np / 256 + 1) * 8 * 4;
+        if (!ls->dag_trace.p && ls->dag_trace.alloc(ntr)) return -2;
+        MNK_HIP(hipMemsetAsync(ls->dag_trace.p, 0, ntr * sizeof(unsigned long long), s));
+        trace = ls->dag_trace.p;
+    }
+    MNK_HIP(hipEventRecord(ctx->ev_a, s));
+    MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
+    MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
+    // bulk: three workgroups per CU of the update stream's partition, for the whole factorization
+    int rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p,
+                                  ls->dag_ntasks, front, af, qctr, ls->info_dev.p, ls->flag_p.p, ls->epoch * 16, spin_limit,
+                                  std::min(ls->dag_ntasks, 3 * (ctx->num_cu - ctx->dag_cus)), trace);
+    if (rc) return rc;
+    // chain: one launch per strip-column
+    const int epoch16 = ls->epoch * 16;
+    for (int64_t p = 0, Js = 0; p < Np; p += 256, ++Js) {
+        const int nbk = (int)std::min<int64_t>(4, (Np - p) / NBI);
+        const unsigned grid = (unsigned)std::min<int64_t>(8, (Np - p) / NBI);
+        const int Kp = Js > 0 ? 256 : 0;
+        const double* Vp = Js > 0 ? (ldl ? V : F) + (p - 256) * ld : nullptr;
+        PpDag dag{front, af, Js > 0 ? (int)(2 * Js) : 0, 2 * Js - 2 > 0 ? (int)(2 * Js) : -1, spin_limit,
+                  trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)Js * 32 : nullptr};
+#define MNK_PPD(LD)                                                                                                  \
+    hipLaunchKernelGGL((ppanel_kernel<LD, 4>), dim3(grid), dim3(256), PP_LDS_BYTES, sp, F, ld, p, nbk, Np, ls->dblk.p,  \
+                       ls->inv16.p, ls->dvec.p, ls->dinv.p, V, LD ? ld : (int64_t)0, (int64_t)p, ls->info_dev.p,          \
+                       ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp, ld, Kp, dag)
+        if (ldl) MNK_PPD(true);
+        else MNK_PPD(false);
+#undef MNK_PPD
+    }
+    MNK_HIP(hipGetLastError());
+    MNK_HIP(hipEventRecord(ctx->ev_a, sp));
+    MNK_HIP(hipEventRecord(ctx->ev_b, su));
+    MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
+    MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
+    return 0;
+}
+
 int mnk_ls_run_factorization(mnk_ls* ls) {
     mnk_ctx* ctx = ls->ctx;
     hipStream_t s = ctx->stream;
@@ -884,7 +1014,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     double* F = ls->fact.p;
     const int64_t NBO = mnk_ls_effective_nbo(ls);
     MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));
-    if (ls->panel_algo == 4 && !ls->flag_p.p) {
+    if (ls->panel_algo >= 4 && !ls->flag_p.p) {
         if (ls->flag_p.alloc(Np / NBI + 1)) return -2;
         MNK_HIP(hipMemsetAsync(ls->flag_p.p, 0, (Np / NBI + 1) * sizeof(int), s));
     }
@@ -893,7 +1023,8 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     // CUs can starve each other's diagonal strips (per-XCD dispatch order), so it is used only while this context is
     // the only one on the device; a wait that expires anyway (another process) falls back for good (mnk_ls_fetch_info).
     ls->algo_now = ls->panel_algo;
-    if (ls->algo_now == 4 && (ls->pp_blocked || mnk_live_contexts(ctx->device) > 1)) ls->algo_now = 1;
+    if (ls->algo_now == 5 && (ctx->dag_cus <= 0 || !ls->lookahead || Np < ls->dag_min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
+    if (ls->algo_now >= 4 && (ls->pp_blocked || mnk_live_contexts(ctx->device) > 1)) ls->algo_now = 1;
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
     // chain, not by the update: narrower outer panels (tail_nbo) then drop the middle-level update and halve
     // the depth of the (a) piece the chain waits for (measured: 355 -> ~300 us per 512 columns of the tail).
@@ -906,7 +1037,10 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     const int64_t npanel = (int64_t)bnd.size() - 1;
     const bool la = ls->lookahead && npanel > 1;
 
-    if (!la) {
+    if (ls->algo_now == 5) {
+        int rc = run_factorization_dag(ls);
+        if (rc) return rc;
+    } else if (!la) {
         for (int64_t ko = 0; ko < Np; ko += NBO) {
             const int64_t kend = std::min<int64_t>(ko + NBO, Np);
             int rc = factor_outer_panel(ls, s, ko, kend, ls->wbuf[0].p);
@@ -1149,7 +1283,7 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     volatile unsigned long long* pw = ls->pin;
     unsigned long long h[3] = {pw[0], pw[1], pw[2]};
     int hinfo = (int)(long long)pw[3];
-    if (hinfo == -7 && ls->algo_now == 4 && ls->retransfer) {
+    if (hinfo == -7 && ls->algo_now >= 4 && ls->retransfer) {
         // the persistent panel kernel gave up on a dependency (CUs shared with another process' persistent kernels):
         // factor again with one launch per panel piece, and stay there
         ls->pp_blocked = true;

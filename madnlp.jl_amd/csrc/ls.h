@@ -61,6 +61,15 @@ struct mnk_ls {
     int pp_fallbacks = 0;
     int64_t pp_fuse_rows = 4096; // > 0: once this many rows (or fewer) remain, persistent panel launches apply the columns in front of them themselves
     int64_t own_cols = 128;   // split_a = 2: columns of the next panel that the panel stream updates itself
+    // task-DAG schedule (panel_algo = 5, dag.hip)
+    mnk::DevBuf<int> dag_tasks;   // 4 ints per task, built once per order
+    int dag_ntasks = 0;
+    mnk::DevBuf<int> dag_flags;   // [queue counter | front: Np/64 | af: 4 * Np/128], zeroed per factorization
+    mnk::DevBuf<double> vfull;    // LDL^T: V = L D of every column, same layout as `fact` (B operand of the left-looking updates)
+    mnk::DevBuf<unsigned long long> dag_trace;  // diagnostics (option dag_trace): time stamps per bulk task / chain strip
+    bool dag_trace_on = false;
+    int64_t dag_min_rows = 3072;  // smaller systems keep the launch-per-panel schedules
+    int64_t dag_max_rows = 40000; // larger ones too: their trailing updates already run at the update kernel's rate
     int panel_algo = 4;  // 4: persistent panel kernel (one flag-synchronized launch per 256 columns); 1: one launch per piece (potrf64w + MFMA triangular solve + recursive inner updates), also the fallback of 4
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)

@@ -83,6 +83,8 @@ static void ctx_free(mnk_ctx* c) {
     for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
+    if (c->sp_dag) (void)hipStreamDestroy(c->sp_dag);
+    if (c->su_dag) (void)hipStreamDestroy(c->su_dag);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -192,6 +194,11 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
         const int q4 = std::max(4, c->num_cu / 4);
         if (make_pair(q4, c->sp, c->su)) c->panel_cus = q4;
     }
+    // second pair for the task-DAG schedule: a handful of CUs for the pivot chain (two per XCD), the rest for the bulk kernel
+    if (c->num_cu >= 64) {
+        const int want = getenv("MNK_DAG_CUS") ? atoi(getenv("MNK_DAG_CUS")) : 16;
+        if (make_pair(want, c->sp_dag, c->su_dag)) c->dag_cus = want;
+    }
     if (!c->sp) {
         int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
         MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
@@ -253,6 +260,8 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
+    if (const char* e = getenv("MNK_DAG_MIN_ROWS")) ls->dag_min_rows = atol(e);
+    if (const char* e = getenv("MNK_DAG_MAX_ROWS")) ls->dag_max_rows = atol(e);
     if (const char* e = getenv("MNK_PP_FUSE_ROWS")) ls->pp_fuse_rows = atol(e);
     if (const char* e = getenv("MNK_OWN_COLS")) ls->own_cols = std::max<long>(64, atol(e) / 64 * 64);
     if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
@@ -325,13 +334,17 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "share")) { ls->share = (int)value; return 0; }
     if (!strcmp(key, "small_tiles")) { ls->small_tiles = (int)value; return 0; }
     if (!strcmp(key, "small_tiles_mid")) { ls->small_tiles_mid = (int)value; return 0; }
-    // 4 (default): persistent panel kernel; 1: one launch per piece (also the fallback of 4)
+    // 5: task-DAG schedule (persistent left-looking bulk kernel beside the pivot chain, dag.hip); 4: persistent panel
+    // kernel per 256 columns + one trailing update per outer panel; 1: one launch per piece (the fallback of 4 and 5)
     if (!strcmp(key, "panel_algo")) {
-        MNK_REQUIRE((int)value == 1 || (int)value == 4, "panel_algo must be 1 or 4");
+        MNK_REQUIRE((int)value == 1 || (int)value == 4 || (int)value == 5, "panel_algo must be 1, 4 or 5");
         ls->panel_algo = (int)value;
         return 0;
     }
     if (!strcmp(key, "pp_fuse_rows")) { ls->pp_fuse_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "dag_min_rows")) { ls->dag_min_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "dag_trace")) { ls->dag_trace_on = value != 0.0; return 0; }  // diagnostics: tools/dag_timeline.py
+    if (!strcmp(key, "dag_max_rows")) { ls->dag_max_rows = (int64_t)value; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
@@ -581,6 +594,13 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
 }
 
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n) {
+    if (ls && out && ls->dag_trace.p) {  // the task-DAG schedule's trace (option dag_trace) shares this read-out
+        MNK_HIP(hipSetDevice(ls->ctx->device));
+        MNK_HIP(mnk::stream_wait(ls->ctx->stream));
+        const int64_t cnt = std::min<int64_t>(n, (int64_t)ls->dag_trace.n);
+        MNK_HIP(hipMemcpy(out, ls->dag_trace.p, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        return 0;
+    }
     MNK_REQUIRE(ls && out && ls->solve_trace.p, "mnk_ls_debug_solve_trace: tracing is off (option solve_trace)");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     MNK_HIP(mnk::stream_wait(ls->ctx->stream));
