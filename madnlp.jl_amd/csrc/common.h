@@ -145,12 +145,13 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
                          const int* info_flag);
 
 // ---- task-DAG schedule (dag.hip): persistent left-looking tile kernel beside the pivot chain -------------------------
-// index of the "band tile (I, Jt) accumulated" flag: a tile row is in the band of two strip-columns (as follower of one,
-// as diagonal rows of the next), each with two tile columns
-__host__ __device__ inline int dag_af_index(int I, int Jt) { return (I * 2 + ((Jt >> 1) & 1)) * 2 + (Jt & 1); }
-void dag_build_tasks(int ntile, std::vector<int>& out);  // 4 ints per task: type, I, J, kend
+// index of the "band tile (I, Jt) accumulated" flag: a tile row is in the band of up to four consecutive strip-columns
+// (band depth <= 16 strips), each with two tile columns
+__host__ __device__ inline int dag_af_index(int I, int Jt) { return (I * 4 + ((Jt >> 1) & 3)) * 2 + (Jt & 1); }
+void dag_build_tasks(int ntile, int chunk, int band_tiles, std::vector<int>& out);  // 4 ints per task (see dag.hip)
 int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
-                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* qctr, int* info,
+                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
+                    int* info,
                     const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace);
 
 }  // namespace mnk

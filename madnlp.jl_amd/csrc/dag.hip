@@ -7,20 +7,25 @@
 //   * chain (factor.hip, ppanel_kernel, panel stream, a few CUs): for every strip-column Js the eight 64-row strips of the
 //     BAND -- its four diagonal strips and the four below them, which are the diagonal strips of Js + 1.  A strip applies
 //     the previous strip-column itself (left-looking prologue, K = 256) and then runs the right-looking pivot chain.
-//   * bulk (this file, update stream, all other CUs): every 128 x 128 tile (I, J) below the band is ONE task: it
-//     accumulates  C(I, J) -= sum_{k < 128 J} L(I, k) d_k L(J, k)^T  in registers over the whole depth (the k-loop of the
-//     MFMA tile kernel, waiting on per-row progress counters where the factor is not final yet), writes the tile ONCE,
-//     and finalizes it in place: X = C L_JJ^-T (D^-1) against the two diagonal blocks of tile column J.  The band's own
-//     tiles are accumulated the same way up to the columns the chain's prologue covers (BANDACC tasks).
-//   * order: tasks are drawn from one queue in a topological order (column-major, band tiles first); a workgroup that
-//     holds a task only ever waits for tasks drawn before it, so any number of resident workgroups makes progress.
+//   * bulk (this file, update stream, all other CUs): every 128 x 128 tile (I, J) below the band receives
+//     C(I, J) -= sum_{k < 128 J} L(I, k) d_k L(J, k)^T  left-looking, in CHUNKS of tile columns of k: one task = one chunk
+//     accumulated in registers (the k-loop of the MFMA tile kernel) and applied to the tile in memory; the task of the
+//     last tile column also finalizes the tile in place, X = C L_JJ^-T (D^-1) against the two diagonal blocks of tile
+//     column J, and publishes the rows.  The band's own tiles are accumulated the same way up to the columns the chain's
+//     prologue covers (BANDACC tasks).  (One task per tile over the whole depth -- the tile written once -- was built
+//     first: a task that has caught up with the pivot chain then holds its workgroup slot while it advances one tile
+//     column per chain step, and the slots doing catch-up work were too few: 63 % of the slot-time computing.)
+//   * order: tasks are drawn from ONE queue sorted by the chain position at which they become ready (the last tile
+//     column they read), band tiles and rows next to the band first: a drawn task can start at once or nearly so, and a
+//     workgroup that holds a task only ever waits for tasks drawn before it, so any number of resident workgroups makes
+//     progress.
 //   * progress: front[t] = number of leading 128-column tile columns for which the 64-row strip t of L is final
-//     (monotone; zeroed per factorization); af[] = "band tile accumulated".  Producer: stores -> barrier -> one lane's
+//     (monotone; zeroed per factorization); af[] = "band tile accumulated"; tprog[I, J] = chunks applied to tile (I, J).
+//     Producer: stores -> barrier -> one lane's
 //     agent-scope release -> drained relaxed store; consumer: relaxed polls by one wave, one agent-scope acquire, barrier.
 //     Every wait is bounded (info = -7 -> the host redoes the factorization with the launch-per-piece schedule).
-// Nothing is updated right-looking any more: every element of the factor is written once by the bulk kernel (plus once by
-// its finalization), the trailing matrix is not re-read and re-written per outer panel, and the look-ahead is as deep as
-// the number of resident workgroups -- the pivot chain never waits for a bulk update of an older panel.
+// There is no trailing-update launch per outer panel any more and no barrier between the updates of different panels: the
+// look-ahead is as deep as the queue -- the pivot chain never waits for a bulk update of an older panel.
 // LDL^T: V = L D is kept in a second N x N array (written once per element, next to L): scaling the B operand's k-columns
 // by d_k inside the k-loop instead was built first and cost 16 % of the loop (fp64 VALU work between the fp64 MFMAs).
 #include <algorithm>
@@ -40,19 +45,22 @@ struct DagArgs {
     const double* dinv;   // 1 / d_k
     const double* dblk;   // factored 64x64 diagonal blocks
     const double* inv16;  // inverses of their 16x16 diagonal sub-blocks
-    const int4* tasks;    // (type, I, J, kend)
+    const int4* tasks;    // (flags | chunk index << 8, I, J, kbeg | kend << 16)
     int ntasks;
     int* front;
     int* af;
+    int* tprog;           // [I * ntile + J]: chunks of tile (I, J) that are in memory
+    int ntile;
     int* qctr;
     int* info;
     const int* prog;      // the pivot chain's per-block progress words (epoch16 + steps completed), see ppanel_kernel
     int epoch16;
     long spin_limit;
     unsigned long long* trace;  // diagnostics (option dag_trace): 8 time stamps per task
+    unsigned long long* wgstat; // diagnostics: per workgroup {first grab, exit, ticks waited, tasks, ticks in finalize}
 };
 
-constexpr int DAG_BULK = 0, DAG_BANDACC = 1;
+constexpr int DAG_BANDACC = 1, DAG_FINAL = 2, DAG_FIRST = 4;  // task flags
 
 // Wave 0 waits until min(front[s0..s3]) > c and returns that minimum (clamped to kend): tile columns [c, ret) are final
 // for all four strips.  -1: the factorization failed elsewhere or the wait expired.  Ends with an acquire + barrier.
@@ -247,6 +255,7 @@ template <bool LDL>
 __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int s_val;
+    unsigned long long st_first = 0, st_wait = 0, st_tasks = 0, st_fin = 0;
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (keeps the thread-id arithmetic out of the task loop's live ranges, as in gemm_nt_tile)
@@ -255,10 +264,18 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
         __syncthreads();
         const int t = s_val;
         __syncthreads();
-        if (t >= a.ntasks) return;
+        if (t >= a.ntasks) {
+            if (a.wgstat != nullptr && tid == 0) {
+                unsigned long long* w = a.wgstat + (int64_t)blockIdx.x * 8;
+                w[0] = st_first; w[1] = wall_clock64(); w[2] = st_wait; w[3] = st_tasks; w[4] = st_fin;
+            }
+            return;
+        }
+        if (a.wgstat != nullptr && tid == 0) { if (st_first == 0) st_first = wall_clock64(); ++st_tasks; }
         const int4 tk = a.tasks[t];
-        const int type = __builtin_amdgcn_readfirstlane(tk.x), I = __builtin_amdgcn_readfirstlane(tk.y),
-                  J = __builtin_amdgcn_readfirstlane(tk.z), kend = __builtin_amdgcn_readfirstlane(tk.w);
+        const int flags = __builtin_amdgcn_readfirstlane(tk.x) & 255, q = __builtin_amdgcn_readfirstlane(tk.x) >> 8;
+        const int I = __builtin_amdgcn_readfirstlane(tk.y), J = __builtin_amdgcn_readfirstlane(tk.z);
+        const int kbeg = __builtin_amdgcn_readfirstlane(tk.w) & 0xffff, kend = __builtin_amdgcn_readfirstlane(tk.w) >> 16;
         const int64_t row0 = (int64_t)128 * I, col0 = (int64_t)128 * J;
         unsigned long long* tr = a.trace != nullptr && tid == 0 ? a.trace + (int64_t)t * 8 : nullptr;
         if (tr) { tr[0] = wall_clock64(); tr[6] = 0; tr[7] = 0; }
@@ -268,41 +285,50 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
-        // k-tiles [0, limit) have final operands; the gate blocks at the first k-tile of a tile column that is not final yet
+        // k-tiles [0, limit) of this chunk have final operands; the gate blocks at the first k-tile of a tile column that is
+        // not final yet (a rare event: the queue is sorted by readiness)
         int limit = 0;
         auto gate = [&](int kt) -> bool {
             if (kt < limit) return true;
             const unsigned long long w0 = tr ? wall_clock64() : 0;
-            const int r = dag_wait_front(a, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kt >> 4, kend, &s_val);
-            if (tr) { const unsigned long long w1 = wall_clock64(); tr[1] = w0; tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; }
+            const int r = dag_wait_front(a, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kbeg + (kt >> 4), kend, &s_val);
+            if (tr) { const unsigned long long w1 = wall_clock64(); tr[1] = w0; tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; st_wait += w1 - w0; }
             if (r < 0) return false;
-            limit = __builtin_amdgcn_readfirstlane(r) * 16;
-            // A task that has caught up with the pivot chain (the wait released only a tile column or two) is on the critical
-            // path of the next band; one that still has a deep backlog is throughput work.  Both kinds share the CU's
-            // matrix cores: the former issue first.
-            if (limit - kt <= 32) __builtin_amdgcn_s_setprio(3);
-            else __builtin_amdgcn_s_setprio(0);
+            limit = (__builtin_amdgcn_readfirstlane(r) - kbeg) * 16;
             return true;
         };
-        if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, a.F + row0, a.ld, (LDL ? a.V : a.F) + col0, a.ld, kend * 16, smem_raw, tid, gate))
+        // the last chunk of a tile is on the critical path of its row (and through it of the next band): it issues first
+        if (flags & DAG_FINAL) __builtin_amdgcn_s_setprio(3);
+        if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, a.F + row0 + (int64_t)128 * kbeg * a.ld, a.ld,
+                                             (LDL ? a.V : a.F) + col0 + (int64_t)128 * kbeg * a.ld, a.ld, (kend - kbeg) * 16,
+                                             smem_raw, tid, gate))
             return;
-        // C(I, J) -= acc (a diagonal tile: lower wave tiles only), written once
-        if (kend > 0)
+        // the chunks of one tile are applied in order
+        if (!(flags & DAG_FIRST)) {
+            const int* word = a.tprog + (int64_t)I * a.ntile + J;
+            const unsigned long long w0 = tr ? wall_clock64() : 0;
+            if (!dag_wait_words(a, word, q, word, q, &s_val)) return;
+            if (tr) st_wait += wall_clock64() - w0;
+        }
+        // C(I, J) -= acc (a diagonal tile: lower wave tiles only)
+        if (kend > kbeg)
             gemm_nt_epilogue<2, 2, 4, 2, false>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, a.F, a.ld, nullptr, nullptr, 0, tid);
-        __builtin_amdgcn_s_setprio(3);
         if (tr) tr[3] = wall_clock64();
-        if (type == DAG_BULK) {
+        if ((flags & DAG_FINAL) && !(flags & DAG_BANDACC)) {
             // the diagonal blocks of tile column J and L(2J + 1, 2J)
             if (dag_wait_front(a, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return;
-            if (tr) tr[4] = wall_clock64();
+            if (tr) { tr[4] = wall_clock64(); st_wait += tr[4] - tr[3]; }
             dag_finalize_tile<LDL>(a, row0, col0, 2 * J, smem_raw, tid);
+            if (tr) st_fin += wall_clock64() - tr[4];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (type == DAG_BULK) {
+            if (!(flags & DAG_FINAL)) {
+                __hip_atomic_store(a.tprog + (int64_t)I * a.ntile + J, q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (!(flags & DAG_BANDACC)) {
                 __hip_atomic_store(a.front + 2 * I, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.front + 2 * I + 1, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
@@ -318,25 +344,59 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-// Task list for a matrix of `ntile` 128-row tiles (depends on the order only; cached by the caller).
-void dag_build_tasks(int ntile, std::vector<int>& out) {
-    out.clear();
-    auto emit = [&](int type, int I, int J, int kend) {
-        out.push_back(type); out.push_back(I); out.push_back(J); out.push_back(kend);
+// Task list for a matrix of `ntile` 128-row tiles, chunks of at most `chunk` tile columns and a band of `band_tiles` tile
+// rows (depends on these three only; cached by the caller).  4 ints per task: flags | chunk index << 8, I, J, kbeg | kend << 16.
+void dag_build_tasks(int ntile, int chunk, int band_tiles, std::vector<int>& out) {
+    struct T { int ready, cls, J, I, flags, q, kbeg, kend; };
+    std::vector<T> ts;
+    // Tile (I, J), tile columns [0, K) to accumulate.  A bulk tile's last tile column is a task of its own (paced by the pivot
+    // chain: K = 128 step, then the finalization); the columns in front of it -- all columns of a band tile -- go in chunks:
+    //   * STAGGERED from tile to tile (first chunk 1 .. chunk tile columns long, by a hash of the tile's coordinates): at
+    //     every chain position about 1 / chunk of the tiles have a chunk that just became ready, so ready work arrives
+    //     evenly.  (With boundaries at multiples of `chunk` the queue alternated between a big batch of ready chunks and a
+    //     stretch of tile-closing tasks that are serialized along every row of tiles: 23 % of the slot-time waiting.)
+    //   * TAPERED towards K (..., chunk, 4, 2, 1): a chunk [b, e) cannot start before the chain has passed tile column
+    //     e - 1 and the tile is due when the chain reaches K, so a full-length chunk that becomes ready one chain step
+    //     before the tile is due was 100-300 us late for the band, every time (measured).
+    auto add_tile = [&](int I, int J, int K, bool band) {
+        const int body = band ? K : std::max(0, K - 1);
+        std::vector<int> cuts{body};  // chunk boundaries, back to front
+        int e = body;
+        for (int len = 1; len < chunk && e > 0; len *= 2) { e = std::max(0, e - len); cuts.push_back(e); }
+        const int first = 1 + (I * 5 + J * 3) % chunk;
+        while (e > first) { e = std::max(first, e - chunk); cuts.push_back(e); }
+        if (e > 0) cuts.push_back(0);
+        int q = 0;
+        for (int c = (int)cuts.size() - 1; c > 0; --c, ++q) {
+            const int kb = cuts[c], ke = cuts[c - 1];
+            const bool last = band && ke == K;
+            ts.push_back({ke, band ? 0 : 2, J, I, (band ? DAG_BANDACC : 0) | (last ? DAG_FINAL : 0) | (q == 0 ? DAG_FIRST : 0), q, kb, ke});
+        }
+        if (!band) ts.push_back({K, 1, J, I, DAG_FINAL | (q == 0 ? DAG_FIRST : 0), q, body, K});
     };
-    // Band tiles of strip-column Js (tile rows 2Js .. 2Js+3, tile columns 2Js, 2Js+1, lower part) are accumulated over the
-    // tile columns k < 2Js - 2 (the chain's prologue applies strip-column Js - 1 itself); their last sources are the bulk
-    // tiles (r, 2Js - 3), so they are queued right behind those -- at the head of tile column 2Js - 3.
     for (int Jt = 0; Jt < ntile; ++Jt) {
         const int Js = Jt / 2;
-        for (int I = 2 * Js + 4; I < ntile; ++I) {
-            emit(DAG_BULK, I, Jt, Jt);
-            if ((Jt & 1) && I < 2 * Js + 8) {   // I = 2(Js+2) .. 2(Js+2)+3: band rows of strip-column Js + 2
-                const int Jb = Js + 2, kend = 2 * Jb - 2;  // = Jt + 1 - ... tile columns [0, 2Jb - 2) = [0, Jt + 1)
-                for (int cc = 2 * Jb; cc <= 2 * Jb + 1 && cc < ntile; ++cc)
-                    if (I >= cc) emit(DAG_BANDACC, I, cc, kend);
-            }
-        }
+        for (int I = 2 * Js + band_tiles; I < ntile; ++I) add_tile(I, Jt, Jt, false);
+        // band tiles of strip-column Js (tile rows 2Js .. 2Js + band_tiles - 1, lower part): accumulated over the tile columns
+        // k < 2Js - 2 (the chain's prologue applies strip-column Js - 1 itself)
+        if (2 * Js - 2 > 0)
+            for (int I = std::max(2 * Js, Jt); I < 2 * Js + band_tiles && I < ntile; ++I) add_tile(I, Jt, 2 * Js - 2, true);
+    }
+    // by the chain position that makes a task ready (the last tile column it reads), then band tiles, then the tile-closing
+    // tasks, then by column and row (rows next to the band first)
+    std::stable_sort(ts.begin(), ts.end(), [](const T& x, const T& y) {
+        if (x.ready != y.ready) return x.ready < y.ready;
+        if (x.cls != y.cls) return x.cls < y.cls;
+        if (x.J != y.J) return x.J < y.J;
+        return x.I < y.I;
+    });
+    out.clear();
+    out.reserve(ts.size() * 4);
+    for (const T& t : ts) {
+        out.push_back(t.flags | (t.q << 8));
+        out.push_back(t.I);
+        out.push_back(t.J);
+        out.push_back(t.kbeg | (t.kend << 16));
     }
 }
 
@@ -357,10 +417,12 @@ static int launch_bulk_t(hipStream_t s, const DagArgs& a, int nwg) {
 }
 
 int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
-                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* qctr, int* info,
+                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
+                    int* info,
                     const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace) {
     if (ntasks <= 0) return 0;
-    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, qctr, info, prog, epoch16, spin_limit, trace};
+    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace,
+              trace ? trace + (size_t)ntasks * 8 + 4096 * 8 : nullptr};
     return ldl ? launch_bulk_t<true>(s, a, nwg) : launch_bulk_t<false>(s, a, nwg);
 }
 

@@ -413,31 +413,30 @@ __device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int targ
 struct PpDag {
     int* front;          // front[t]: leading 128-column tile columns for which the 64-row strip t of L is final
     const int* af;       // "band tile accumulated" flags written by the bulk kernel (dag_af_index)
-    int need_front;      // > 0: strips t >= 4 (rows the bulk kernel finalizes) wait for front[t] >= need_front
+    int need_front;      // > 0: strips t >= front_from wait for front[t] >= need_front (their rows of the older columns)
+    int front_from;      // 4: one launch per strip-column (stream order covers the strips above); 0: persistent chain
     int af_tilecol;      // >= 0: first tile column of this launch; its band tiles were pre-accumulated by the bulk kernel
     long spin_limit;
     unsigned long long* trace;  // diagnostics: 4 time stamps per strip of this launch
 };
 
+// One strip t of one persistent panel step (the body of ppanel_kernel / pchain_kernel): every thread of the workgroup calls
+// it with the same arguments; waves may return at different times (callers that go on synchronize first).
 template <bool LDL, int NB>
-__global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int64_t ld, int64_t p0, int nb, int64_t Np,
-                                                      double* __restrict__ dblk0, double* __restrict__ inv0,
-                                                      double* __restrict__ dvec, double* __restrict__ dinv,
-                                                      double* __restrict__ W, int64_t ldw, int64_t wcol0,
-                                                      int* __restrict__ info, double pivot_tol, int* __restrict__ prog,
-                                                      int epoch16, int dbg_missing, const double* __restrict__ Vp,
-                                                      int64_t ldv, int Kp, PpDag dag) {
-    extern __shared__ __attribute__((aligned(128))) char pp_smem[];
+__device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, int64_t ld, int64_t p0, int nb, int64_t Np,
+                                         double* __restrict__ dblk0, double* __restrict__ inv0, double* __restrict__ dvec,
+                                         double* __restrict__ dinv, double* __restrict__ W, int64_t ldw, int64_t wcol0,
+                                         int* __restrict__ info, double pivot_tol, int* __restrict__ prog, int epoch16,
+                                         int dbg_missing, const double* __restrict__ Vp, int64_t ldv, int Kp, PpDag dag,
+                                         char* pp_smem, int* s_go) {
     v4d* stage = reinterpret_cast<v4d*>(pp_smem);          // [2][1024] v4d
     v4d* own = reinterpret_cast<v4d*>(pp_smem) + 2 * 1024;  // [1024] v4d
-    __shared__ int s_go;
     const int tid = threadIdx.x;
-    if (tid == 0) s_go = (*info == 0) ? 1 : 0;
+    if (tid == 0) *s_go = (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 0;
     __syncthreads();
-    if (!s_go) return;
+    if (!*s_go) return;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int t = blockIdx.x;
     const int64_t R = p0 + 64 * (int64_t)t;
     if (R >= Np || t == dbg_missing) return;
     const int64_t r0 = R + 16 * w;
@@ -447,9 +446,9 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
 #pragma unroll
     for (int c = 0; c < NB; ++c) seen[c] = 0;
     const int tabs = (int)(p0 >> 6) + t;  // this strip's 64-row block
-    unsigned long long* ptr_tr = dag.trace != nullptr && tid == 0 ? dag.trace + 4 * t : nullptr;
+    unsigned long long* ptr_tr = dag.trace != nullptr && tid == 0 ? dag.trace + 8 * t : nullptr;
     if (ptr_tr) ptr_tr[0] = wall_clock64();
-    if (dag.front != nullptr && (dag.af_tilecol >= 0 || (dag.need_front > 0 && t >= 4))) {
+    if (dag.front != nullptr && (dag.af_tilecol >= 0 || (dag.need_front > 0 && t >= dag.front_from))) {
         // the strip's tiles as the bulk kernel leaves them (accumulated over the older columns), and -- rows below the
         // previous launch's band -- its rows of the previous strip-column, finalized by the bulk kernel
         if (tid == 0) {
@@ -466,7 +465,12 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                     }
                 }
             };
-            if (dag.need_front > 0 && t >= 4) wait_ge(dag.front + tabs, dag.need_front);
+            if (dag.need_front > 0 && t >= dag.front_from) wait_ge(dag.front + tabs, dag.need_front);
+            // persistent chain: the prologue also reads the rows of this strip-column's diagonal strips in the previous
+            // strip-column (strips 4..7 there; nothing but these counters orders the strip-columns)
+            if (dag.need_front > 0 && dag.front_from == 0)
+                for (int c = 0; c < nb && c <= t; ++c) wait_ge(dag.front + (int)(p0 >> 6) + c, dag.need_front);
+            if (dag.trace != nullptr) dag.trace[8 * t + 5] = wall_clock64();
             if (dag.af_tilecol >= 0) {
                 wait_ge(dag.af + dag_af_index(tabs >> 1, dag.af_tilecol), 1);
                 if (t >= 2 && nb > 2) wait_ge(dag.af + dag_af_index(tabs >> 1, dag.af_tilecol + 1), 1);
@@ -542,6 +546,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
         }
         __syncthreads();
     }
+    if (ptr_tr) ptr_tr[4] = wall_clock64();
 
     // One step per column block.  `j` is a compile-time constant (generic lambda over integral_constant), so every
     // index into X is static from the start and the strip stays in registers; returns true when the strip is done.
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                 // (its last step: the strip's rows are final through the tile column of block j)
                 if (dag.front != nullptr)
                     __hip_atomic_store(dag.front + tabs, (int)(p0 >> 7) + (j >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (dag.trace != nullptr) dag.trace[4 * t + 2] = wall_clock64();
+                if (dag.trace != nullptr) dag.trace[8 * t + 2] = wall_clock64();
             }
             return true;
         }
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
                 if (diag_strip) __hip_atomic_store(prog + t, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pub_front)
                     __hip_atomic_store(dag.front + tabs, (int)(p0 >> 7) + (j >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (pub_front && dag.trace != nullptr) dag.trace[4 * t + (j == jmax ? 2 : 3)] = wall_clock64();
+                if (pub_front && dag.trace != nullptr) dag.trace[8 * t + (j == jmax ? 2 : 3)] = wall_clock64();
             }
         }
         // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
@@ -698,6 +703,52 @@ __global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int
     if (NB > 5 && step(std::integral_constant<int, (NB > 5 ? 5 : 0)>{})) return;
     if (NB > 6 && step(std::integral_constant<int, (NB > 6 ? 6 : 0)>{})) return;
     if (NB > 7 && step(std::integral_constant<int, (NB > 7 ? 7 : 0)>{})) return;
+}
+
+template <bool LDL, int NB>
+__global__ __launch_bounds__(256) void ppanel_kernel(double* __restrict__ F, int64_t ld, int64_t p0, int nb, int64_t Np,
+                                                      double* __restrict__ dblk0, double* __restrict__ inv0,
+                                                      double* __restrict__ dvec, double* __restrict__ dinv,
+                                                      double* __restrict__ W, int64_t ldw, int64_t wcol0,
+                                                      int* __restrict__ info, double pivot_tol, int* __restrict__ prog,
+                                                      int epoch16, int dbg_missing, const double* __restrict__ Vp,
+                                                      int64_t ldv, int Kp, PpDag dag) {
+    extern __shared__ __attribute__((aligned(128))) char pp_smem[];
+    __shared__ int s_go;
+    pp_strip<LDL, NB>((int)blockIdx.x, F, ld, p0, nb, Np, dblk0, inv0, dvec, dinv, W, ldw, wcol0, info, pivot_tol, prog, epoch16,
+                      dbg_missing, Vp, ldv, Kp, dag, pp_smem, &s_go);
+}
+
+// Persistent pivot chain of the task-DAG schedule (dag.hip): ONE launch for the whole factorization.  Workgroup t owns strip
+// t of the band of EVERY strip-column Js = 0, 1, ... (the band: `gridDim.x` strips of 64 rows from the strip-column's first
+// row; strips 0..3 are its diagonal strips, strip t + 4 of one strip-column is strip t of the next).  A strip waits for its
+// rows of the older columns (front[]: published by strip t + 4 of the previous strip-column, or by the bulk kernel for the
+// rows that enter the band), for its band tiles (af[]) and for the diagonal blocks (prog[]); nothing else orders the
+// strip-columns, so the diagonal strips of Js + 1 start the moment strips 4..7 of Js are done, however long the strips
+// further down wait for the bulk kernel.  All workgroups must be resident (one per CU of the chain's partition); every
+// workgroup walks its strips in order and every wait is on a strip of an earlier strip-column or of the same one with a
+// smaller index, so residency implies progress.
+template <bool LDL>
+__global__ __launch_bounds__(256) void pchain_kernel(double* __restrict__ F, int64_t ld, int64_t Np, double* __restrict__ dblk0,
+                                                      double* __restrict__ inv0, double* __restrict__ dvec,
+                                                      double* __restrict__ dinv, double* __restrict__ V, int* __restrict__ info,
+                                                      double pivot_tol, int* __restrict__ flag_p, int epoch16, int dbg_missing,
+                                                      PpDag dag) {
+    extern __shared__ __attribute__((aligned(128))) char pp_smem[];
+    __shared__ int s_go;
+    const int t = blockIdx.x;
+    for (int64_t p0 = 0, Js = 0; p0 + 64 * (int64_t)t < Np; p0 += 256, ++Js) {
+        const int nb = (int)((Np - p0) / 64 < 4 ? (Np - p0) / 64 : 4);
+        PpDag d = dag;
+        d.need_front = Js > 0 ? (int)(2 * Js) : 0;
+        d.front_from = 0;
+        d.af_tilecol = 2 * Js - 2 > 0 ? (int)(2 * Js) : -1;
+        if (dag.trace != nullptr) d.trace = dag.trace + Js * 8 * (int64_t)gridDim.x;
+        const double* Vp = Js > 0 ? (LDL ? V : F) + (p0 - 256) * ld : nullptr;
+        pp_strip<LDL, 4>(t, F, ld, p0, nb, Np, dblk0, inv0, dvec, dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, info, pivot_tol,
+                         flag_p + p0 / 64, epoch16, dbg_missing, Vp, ld, Js > 0 ? 256 : 0, d, pp_smem, &s_go);
+        __syncthreads();  // (waves leave a strip at different times; its LDS tiles and s_go are reused)
+    }
 }
 
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
@@ -827,7 +878,7 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
     hipLaunchKernelGGL((ppanel_kernel<LD, NBT>), dim3(grid), dim3(256), PP_LDS_BYTES, s, F, ld, p, nbk, Np, ls->dblk.p, \
                        ls->inv16.p, ls->dvec.p, ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0,  \
                        p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp,  \
-                       ldv, Kp, PpDag{nullptr, nullptr, 0, -1, 0, nullptr})
+                       ldv, Kp, PpDag{nullptr, nullptr, 0, 4, -1, 0, nullptr})
         if (ldl) MNK_PP(true, 4);
         else MNK_PP(false, 4);
 #undef MNK_PP
@@ -942,19 +993,20 @@ static int run_factorization_dag(mnk_ls* ls) {
     const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI);
     if (!ls->dag_tasks.p) {
         std::vector<int> h;
-        mnk::dag_build_tasks(ntile, h);
+        mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, h);
         ls->dag_ntasks = (int)(h.size() / 4);
         if (ls->dag_tasks.alloc(h.size() + 4)) return -2;
         if (!h.empty()) MNK_HIP(hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
         MNK_HIP(mnk::stream_wait(s));  // (h goes out of scope)
-        if (ls->dag_flags.alloc((size_t)1 + nblk + 4 * (size_t)ntile)) return -2;
+        if (ls->dag_flags.alloc((size_t)1 + nblk + 8 * (size_t)ntile + (size_t)ntile * ntile)) return -2;
     }
     if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) return -2;  // V = L D of every column (LDL^T)
     double* V = ldl ? ls->vfull.p : nullptr;
-    MNK_HIP(hipMemsetAsync(ls->dag_flags.p, 0, ((size_t)1 + nblk + 4 * (size_t)ntile) * sizeof(int), s));
+    MNK_HIP(hipMemsetAsync(ls->dag_flags.p, 0, ((size_t)1 + nblk + 8 * (size_t)ntile + (size_t)ntile * ntile) * sizeof(int), s));
     int* qctr = ls->dag_flags.p;
     int* front = qctr + 1;
     int* af = front + nblk;
+    int* tprog = af + 8 * (size_t)ntile;
     {   // 96 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
         static std::atomic<uint64_t> attr_devs{0};
         int dev = 0;
@@ -968,7 +1020,7 @@ static int run_factorization_dag(mnk_ls* ls) {
     const long spin_limit = 1L << 24;
     unsigned long long* trace = nullptr;
     if (ls->dag_trace_on) {
-        const size_t ntr = (size_t)ls->dag_ntasks * 8 + (size_t)(Np / 256 + 1) * 8 * 4;
+        const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;  // tasks | chain strips (<= 512 launches) | per-workgroup statistics
         if (!ls->dag_trace.p && ls->dag_trace.alloc(ntr)) return -2;
         MNK_HIP(hipMemsetAsync(ls->dag_trace.p, 0, ntr * sizeof(unsigned long long), s));
         trace = ls->dag_trace.p;
@@ -978,26 +1030,29 @@ static int run_factorization_dag(mnk_ls* ls) {
     MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
     // bulk: three workgroups per CU of the update stream's partition, for the whole factorization
     int rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p,
-                                  ls->dag_ntasks, front, af, qctr, ls->info_dev.p, ls->flag_p.p, ls->epoch * 16, spin_limit,
+                                  ls->dag_ntasks, front, af, tprog, ntile, qctr, ls->info_dev.p, ls->flag_p.p, ls->epoch * 16, spin_limit,
                                   std::min(ls->dag_ntasks, 3 * (ctx->num_cu - ctx->dag_cus)), trace);
     if (rc) return rc;
-    // chain: one launch per strip-column
+    // chain: ONE persistent launch, workgroup t = strip t of every band
     const int epoch16 = ls->epoch * 16;
-    for (int64_t p = 0, Js = 0; p < Np; p += 256, ++Js) {
-        const int nbk = (int)std::min<int64_t>(4, (Np - p) / NBI);
-        const unsigned grid = (unsigned)std::min<int64_t>(8, (Np - p) / NBI);
-        const int Kp = Js > 0 ? 256 : 0;
-        const double* Vp = Js > 0 ? (ldl ? V : F) + (p - 256) * ld : nullptr;
-        PpDag dag{front, af, Js > 0 ? (int)(2 * Js) : 0, 2 * Js - 2 > 0 ? (int)(2 * Js) : -1, spin_limit,
-                  trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)Js * 32 : nullptr};
-#define MNK_PPD(LD)                                                                                                  \
-    hipLaunchKernelGGL((ppanel_kernel<LD, 4>), dim3(grid), dim3(256), PP_LDS_BYTES, sp, F, ld, p, nbk, Np, ls->dblk.p,  \
-                       ls->inv16.p, ls->dvec.p, ls->dinv.p, V, LD ? ld : (int64_t)0, (int64_t)p, ls->info_dev.p,          \
-                       ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp, ld, Kp, dag)
-        if (ldl) MNK_PPD(true);
-        else MNK_PPD(false);
-#undef MNK_PPD
+    {
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        MNK_HIP(hipGetDevice(&dev));
+        if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
     }
+    const unsigned bstrips = (unsigned)std::min<int64_t>(ls->dag_band, Np / NBI);
+    PpDag dag{front, af, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 : nullptr};
+    if (ldl)
+        hipLaunchKernelGGL(pchain_kernel<true>, dim3(bstrips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
+                           ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing, dag);
+    else
+        hipLaunchKernelGGL(pchain_kernel<false>, dim3(bstrips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
+                           ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing, dag);
     MNK_HIP(hipGetLastError());
     MNK_HIP(hipEventRecord(ctx->ev_a, sp));
     MNK_HIP(hipEventRecord(ctx->ev_b, su));
@@ -1023,7 +1078,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     // CUs can starve each other's diagonal strips (per-XCD dispatch order), so it is used only while this context is
     // the only one on the device; a wait that expires anyway (another process) falls back for good (mnk_ls_fetch_info).
     ls->algo_now = ls->panel_algo;
-    if (ls->algo_now == 5 && (ctx->dag_cus <= 0 || !ls->lookahead || Np < ls->dag_min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
+    if (ls->algo_now == 5 && (ctx->dag_cus < ls->dag_band || !ls->lookahead || Np < ls->dag_min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
     if (ls->algo_now >= 4 && (ls->pp_blocked || mnk_live_contexts(ctx->device) > 1)) ls->algo_now = 1;
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
     // chain, not by the update: narrower outer panels (tail_nbo) then drop the middle-level update and halve

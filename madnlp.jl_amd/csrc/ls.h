@@ -68,6 +68,8 @@ struct mnk_ls {
     mnk::DevBuf<double> vfull;    // LDL^T: V = L D of every column, same layout as `fact` (B operand of the left-looking updates)
     mnk::DevBuf<unsigned long long> dag_trace;  // diagnostics (option dag_trace): time stamps per bulk task / chain strip
     bool dag_trace_on = false;
+    int dag_band = 16;            // 64-row strips per band of the persistent pivot chain (8, 12 or 16; <= the chain's CUs)
+    int dag_chunk = 8;            // tile columns (of 128) per bulk task
     int64_t dag_min_rows = 3072;  // smaller systems keep the launch-per-panel schedules
     int64_t dag_max_rows = 40000; // larger ones too: their trailing updates already run at the update kernel's rate
     int panel_algo = 4;  // 4: persistent panel kernel (one flag-synchronized launch per 256 columns); 1: one launch per piece (potrf64w + MFMA triangular solve + recursive inner updates), also the fallback of 4

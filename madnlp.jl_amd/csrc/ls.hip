@@ -261,6 +261,8 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
     if (const char* e = getenv("MNK_DAG_MIN_ROWS")) ls->dag_min_rows = atol(e);
+    if (const char* e = getenv("MNK_DAG_CHUNK")) ls->dag_chunk = std::max(1, atoi(e));
+    if (const char* e = getenv("MNK_DAG_BAND")) ls->dag_band = std::min(16, std::max(8, atoi(e) / 4 * 4));
     if (const char* e = getenv("MNK_DAG_MAX_ROWS")) ls->dag_max_rows = atol(e);
     if (const char* e = getenv("MNK_PP_FUSE_ROWS")) ls->pp_fuse_rows = atol(e);
     if (const char* e = getenv("MNK_OWN_COLS")) ls->own_cols = std::max<long>(64, atol(e) / 64 * 64);

@@ -1,5 +1,6 @@
-"""Per-task timeline of ONE factorization under the task-DAG schedule (option dag_trace): what every chain launch waited
-for and when the bulk tasks it depends on were finished.  usage: python tools/dag_timeline.py [N] [LDL|CHOLESKY]"""
+"""Per-strip timeline of the persistent pivot chain of ONE factorization under the task-DAG schedule (option dag_trace):
+when every strip of every band started, what it waited for, when it was done, and when the bulk kernel delivered the rows
+that enter the band.  usage: python tools/dag_timeline.py [N] [LDL|CHOLESKY]   (env MNK_DAG_CHUNK / MNK_DAG_BAND as the run)"""
 import os
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "8")
@@ -9,11 +10,15 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import madnlp_jl_amd as mj  # noqa: E402
 from madnlp_jl_amd import _lib as L  # noqa: E402
+from dag_tasks import dag_tasks  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 11192
 alg = sys.argv[2] if len(sys.argv) > 2 else "CHOLESKY"
+chunk = int(os.environ.get("MNK_DAG_CHUNK", "8"))
+band = int(os.environ.get("MNK_DAG_BAND", "16"))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
     ctx = mj.HipContext(0, stream=s.cuda_stream)
@@ -29,50 +34,32 @@ with torch.cuda.stream(s):
     s.synchronize()
 Np = (N + 127) // 128 * 128
 ntile = Np // 128
-# the task list, rebuilt as dag_build_tasks does
-tasks = []
-for Jt in range(ntile):
-    Js = Jt // 2
-    for I in range(2 * Js + 4, ntile):
-        tasks.append((0, I, Jt, Jt))
-        if (Jt & 1) and I < 2 * Js + 8:
-            Jb = Js + 2
-            for cc in (2 * Jb, 2 * Jb + 1):
-                if cc < ntile and I >= cc:
-                    tasks.append((1, I, cc, 2 * Jb - 2))
-nt = len(tasks)
-nsc = Np // 256 + 1
-tr = np.zeros(nt * 8 + nsc * 32, dtype=np.uint64)
+ts = dag_tasks(ntile, chunk, band // 2)
+nt = len(ts)
+nsc = (Np + 255) // 256
+tr = np.zeros(nt * 8 + 4096 * 8, dtype=np.uint64)
 L.check(L.lib().mnk_ls_debug_solve_trace(ls._h, tr.ctypes.data, tr.size), "trace")
 bulk = tr[: nt * 8].reshape(nt, 8).astype(np.float64)
-chain = tr[nt * 8:].reshape(nsc, 8, 4).astype(np.float64)
+chain = tr[nt * 8: nt * 8 + nsc * band * 8].reshape(nsc, band, 8).astype(np.float64)
 t0 = min(bulk[:, 0][bulk[:, 0] > 0].min(), chain[:, :, 0][chain[:, :, 0] > 0].min())
 us = lambda x: (x - t0) / 100.0  # wall_clock64: 100 MHz  # noqa: E731
-print(f"N={N} {alg}: {nt} bulk tasks, span {us(max(bulk[:, 5].max(), chain[:, :, 2].max())):.0f} us")
-fin = {}   # (I, J) -> (type, grab, acc_done, diag_ready, end, nwait, wait_us)
-for k, (ty, I, J, kend) in enumerate(tasks):
-    b = bulk[k]
-    fin[(ty, I, J)] = (us(b[0]), us(b[3]), us(b[4]) if ty == 0 else float("nan"), us(b[5]), int(b[6]), b[7] / 100.0, us(b[1]), us(b[2]))
-print("launch: start | per strip: wait-end(+), end(+) relative to the launch start | band tiles: acc end; rows below: finalize end")
-for Js in range(min(nsc, Np // 256)):
+print(f"N={N} {alg}: {nt} bulk tasks, chunk {chunk}, band {band}; span {us(max(bulk[:, 5].max(), chain[:, :, 2].max())):.0f} us")
+closing = {}
+for k, t in enumerate(ts):
+    if t[1] == 1:
+        closing[(t[3], t[2])] = (us(bulk[k, 0]), us(bulk[k, 3]), us(bulk[k, 4]), us(bulk[k, 5]))   # grab, acc, diag, end
+print("Js: D3 ready (end of strip 3) | strip t: start+wait -> end, all relative to the previous strip-column's D3 | rows entering: closing-task end")
+prev = 0.0
+for Js in range(nsc):
     c = chain[Js]
     if c[0, 0] == 0:
         continue
-    st = us(c[:, 0][c[:, 0] > 0].min())
-    en = us(c[:, 2].max())
-    strips = " ".join(f"{t}:{us(c[t,1])-st:.0f}/{us(c[t,2])-st:.0f}" for t in range(8) if c[t, 0] > 0)
-    line = f"Js={Js:2d} start {st:7.0f} dur {en-st:5.0f} | {strips}"
-    # band tiles accumulated (BANDACC) for this launch and the bulk tiles whose rows enter the band (strips 4..7)
-    ba = [fin.get((1, r, cc)) for r in range(2 * Js, 2 * Js + 4) for cc in (2 * Js, 2 * Js + 1)]
-    ba = [x for x in ba if x]
-    if ba:
-        line += f" | bandacc grab {min(x[0] for x in ba)-st:.0f}..{max(x[0] for x in ba)-st:.0f} lastwait {max(x[7] for x in ba)-st:.0f} end {max(x[3] for x in ba)-st:.0f}"
-    rows = [fin.get((0, r, cc)) for r in (2 * Js + 2, 2 * Js + 3) for cc in (2 * Js - 2, 2 * Js - 1)]
+    nst = int((c[:, 0] > 0).sum())
+    d3 = us(c[min(3, nst - 1), 2])
+    # strip t: start, +front wait, +af wait, +prologue, > end
+    strips = " ".join(f"{t}:{us(c[t,0])-prev:.0f}+{us(c[t,5])-us(c[t,0]):.0f}f+{us(c[t,1])-us(c[t,5]):.0f}a+{us(c[t,4])-us(c[t,1]):.0f}p>{us(c[t,2])-prev:.0f}" for t in (0, 3, 4, 8, 12, 15) if t < nst and c[t, 0] > 0)
+    rows = [closing.get((r, cc)) for r in range(2 * Js + band // 2 - 2, 2 * Js + band // 2) for cc in (2 * Js - 2, 2 * Js - 1)]
     rows = [x for x in rows if x]
-    if rows:
-        line += f" | rows-in: acc {max(x[1] for x in rows)-st:.0f} diag {max(x[2] for x in rows)-st:.0f} end {max(x[3] for x in rows)-st:.0f}"
-    print(line)
-# bulk summary: time in waits vs compute
-dur = bulk[:, 5] - bulk[:, 0]
-print(f"bulk tasks: mean duration {dur.mean()/100:.0f} us, mean wait {bulk[:,7].mean()/100:.0f} us, mean finalize {np.nanmean([f[3]-f[2] for f in fin.values() if f[2]==f[2]]):.1f} us, "
-      f"mean diag wait {np.nanmean([f[2]-f[1] for f in fin.values() if f[2]==f[2]]):.1f} us")
+    rin = f" | rows-in: acc {max(x[1] for x in rows)-prev:.0f} diag {max(x[2] for x in rows)-prev:.0f} end {max(x[3] for x in rows)-prev:.0f}" if rows else ""
+    print(f"Js={Js:2d} D3 {d3:7.0f} (+{d3-prev:4.0f}) | {strips}{rin}")
+    prev = d3
