@@ -82,8 +82,9 @@ end
     share::Int = 1                  # 0 off / 1 adaptive / 2 always: panel-stream CUs join the trailing update
     persistent_solve::Bool = true   # both triangular sweeps in one launch
     single_rows::Int = 2560         # systems up to this order: one outer panel on the whole chip
-    panel_algo::Int = 4             # 4: persistent panel kernel (one launch per 256 columns; needs the panel CUs for
-                                    # itself -- set 1 when several PROCESSES share the GPU); 1: one launch per piece
+    panel_algo::Int = 5             # 5: task-DAG schedule (persistent pivot chain + persistent bulk kernel); 4: persistent panel
+                                    # kernel per 256 columns + one trailing update per outer panel; 1: one launch per piece (set 1
+                                    # when several processes share the GPU: 4 and 5 keep waiting workgroups resident)
     bk_fallback::Bool = true        # BUNCHKAUFMAN: refactor with 1x1/2x2 Bunch-Kaufman pivoting when the static-pivot
                                     # LDL^T breaks down (false: report the breakdown as num_zero, the IPM regularizes)
 end

@@ -107,6 +107,9 @@ struct mnk_ctx {
     // task-DAG schedule (dag.hip): the pivot chain needs only a few CUs, the persistent bulk kernel gets all the others
     hipStream_t sp_dag = nullptr, su_dag = nullptr;
     int dag_cus = 0;    // > 0: sp_dag is restricted to this many CUs and su_dag to the others
+    // ... and a third pair for its second phase, where every remaining row is in the chain's band (one CU per 64 rows)
+    hipStream_t sp_dag2 = nullptr, su_dag2 = nullptr;
+    int dag_cus2 = 0;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_next, ev_next2, ev_bdone;
     int num_cu = 256;   // CUs this context may use (the whole device, or its partition)
@@ -145,13 +148,12 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
                          const int* info_flag);
 
 // ---- task-DAG schedule (dag.hip): persistent left-looking tile kernel beside the pivot chain -------------------------
-// index of the "band tile (I, Jt) accumulated" flag: a tile row is in the band of up to four consecutive strip-columns
-// (band depth <= 16 strips), each with two tile columns
-__host__ __device__ inline int dag_af_index(int I, int Jt) { return (I * 4 + ((Jt >> 1) & 3)) * 2 + (Jt & 1); }
-void dag_build_tasks(int ntile, int chunk, int band_tiles, std::vector<int>& out);  // 4 ints per task (see dag.hip)
+// Task list (4 ints per task, see dag.hip).  Strip-columns Js < js2 have a band of `band_tiles` tile rows, the others a band
+// that covers every remaining row; returns the number of tasks of the first phase (ready before the chain enters js2).
+int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out);
 int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
                     const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
                     int* info,
-                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace);
+                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace, unsigned long long* wgstat);
 
 }  // namespace mnk

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
                 __hip_atomic_store(a.front + 2 * I, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(a.front + 2 * I + 1, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                __hip_atomic_store(a.af + dag_af_index(I, J), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.af + (int64_t)I * a.ntile + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tr) tr[5] = wall_clock64();
         }
@@ -345,8 +345,10 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 // Task list for a matrix of `ntile` 128-row tiles, chunks of at most `chunk` tile columns and a band of `band_tiles` tile
-// rows (depends on these three only; cached by the caller).  4 ints per task: flags | chunk index << 8, I, J, kbeg | kend << 16.
-void dag_build_tasks(int ntile, int chunk, int band_tiles, std::vector<int>& out) {
+// rows for the strip-columns Js < js2, every remaining row from js2 on (depends on these four only; cached by the caller).
+// 4 ints per task: flags | chunk index << 8, I, J, kbeg | kend << 16.  Returns the number of first-phase tasks: the ones
+// that are ready before the chain enters strip-column js2 (they come first in the list).
+int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out) {
     struct T { int ready, cls, J, I, flags, q, kbeg, kend; };
     std::vector<T> ts;
     // Tile (I, J), tile columns [0, K) to accumulate.  A bulk tile's last tile column is a task of its own (paced by the pivot
@@ -376,11 +378,12 @@ void dag_build_tasks(int ntile, int chunk, int band_tiles, std::vector<int>& out
     };
     for (int Jt = 0; Jt < ntile; ++Jt) {
         const int Js = Jt / 2;
-        for (int I = 2 * Js + band_tiles; I < ntile; ++I) add_tile(I, Jt, Jt, false);
-        // band tiles of strip-column Js (tile rows 2Js .. 2Js + band_tiles - 1, lower part): accumulated over the tile columns
+        const int bt = Js >= js2 ? ntile : band_tiles;
+        for (int I = 2 * Js + bt; I < ntile; ++I) add_tile(I, Jt, Jt, false);
+        // band tiles of strip-column Js (tile rows 2Js .. 2Js + bt - 1, lower part): accumulated over the tile columns
         // k < 2Js - 2 (the chain's prologue applies strip-column Js - 1 itself)
         if (2 * Js - 2 > 0)
-            for (int I = std::max(2 * Js, Jt); I < 2 * Js + band_tiles && I < ntile; ++I) add_tile(I, Jt, 2 * Js - 2, true);
+            for (int I = std::max(2 * Js, Jt); I < 2 * Js + bt && I < ntile; ++I) add_tile(I, Jt, 2 * Js - 2, true);
     }
     // by the chain position that makes a task ready (the last tile column it reads), then band tiles, then the tile-closing
     // tasks, then by column and row (rows next to the band first)
@@ -392,12 +395,15 @@ void dag_build_tasks(int ntile, int chunk, int band_tiles, std::vector<int>& out
     });
     out.clear();
     out.reserve(ts.size() * 4);
+    int n1 = 0;
     for (const T& t : ts) {
+        if (t.ready <= 2 * js2) ++n1;  // needs only tile columns the first phase's chain has passed (sorted by `ready`)
         out.push_back(t.flags | (t.q << 8));
         out.push_back(t.I);
         out.push_back(t.J);
         out.push_back(t.kbeg | (t.kend << 16));
     }
+    return n1;
 }
 
 template <bool LDL>
@@ -419,10 +425,9 @@ static int launch_bulk_t(hipStream_t s, const DagArgs& a, int nwg) {
 int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
                     const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
                     int* info,
-                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace) {
+                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace, unsigned long long* wgstat) {
     if (ntasks <= 0) return 0;
-    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace,
-              trace ? trace + (size_t)ntasks * 8 + 4096 * 8 : nullptr};
+    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace, wgstat};
     return ldl ? launch_bulk_t<true>(s, a, nwg) : launch_bulk_t<false>(s, a, nwg);
 }
 

@@ -64,6 +64,16 @@ struct Piv4 {
 // ---------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Store of a result another CU will read after a flag.  WT (the persistent chain of the task-DAG schedule): write-through
+// (sc1), so that the publishing workgroup needs no agent-scope release fence -- that fence (buffer_wbl2) writes back EVERY
+// dirty line of the XCD's L2, and with a dozen strips per XCD storing their rows it grew the pivot chain's step from 24 to
+// 38 us per block (measured: the step time followed the number of resident strips).
+template <bool WT>
+__device__ __forceinline__ void put(double* p, double v) {
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // X = B L_jj^-T (Cholesky) / V = B L_jj^-T, X = V D^-1 (LDL) for every row below the diagonal block.
 // Wave = NS strips of 16 rows; lane (l15, l4): accumulator register r of column block cb holds
 // X[row0 + l15][16 cb + l4 + 4 r] (the C^T layout of gemm_f64.hip, so register r of X^T[ib] IS the
@@ -204,7 +214,7 @@ __device__ __forceinline__ void factor_piv4_vals(const double p00, const double 
 // (one wave; `Lsh` / `Ish`: optional LDS copies of the factored block and of its four 16x16 inverses)
 // potrf64w_core: the block is already in registers (Lt[cb][b], b <= cb, strict upper triangle of the diagonal
 // 16x16 blocks zeroed); potrf64w_body loads it from the factor matrix first.
-template <bool LDL>
+template <bool LDL, bool WT = false>
 __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, double* __restrict__ Dout,
                                               double* __restrict__ inv16, double* __restrict__ dvec,
                                               double* __restrict__ dinv, int* __restrict__ info, double pivot_tol,
@@ -306,7 +316,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                inv16[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
+                put<WT>(inv16 + b * 256 + (l4 + 4 * r) + 16 * l15, Y[r]);
                 if (Ish != nullptr) Ish[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
             }
         }
@@ -318,8 +328,8 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             const v4d dd = Lt[b][b];
             const double dsel = rsel == 0 ? dd[0] : (rsel == 1 ? dd[1] : (rsel == 2 ? dd[2] : dd[3]));
             if ((l15 & 3) == l4) {
-                dvec[j0 + 16 * b + l15] = dsel;
-                dinv[j0 + 16 * b + l15] = LDL ? fast_rcp(dsel == 0.0 ? 1.0 : dsel) : 1.0;
+                put<WT>(dvec + j0 + 16 * b + l15, dsel);
+                put<WT>(dinv + j0 + 16 * b + l15, LDL ? fast_rcp(dsel == 0.0 ? 1.0 : dsel) : 1.0);
             }
         }
         // ---- store block column b of the factored block (column-major 64x64, lower part)
@@ -328,7 +338,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Lt[cb][b][r];
-                Dout[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
+                put<WT>(Dout + (16 * cb + l15) + 64 * (16 * b + l4 + 4 * r), v);
                 if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
             }
     }
@@ -412,7 +422,8 @@ __device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int targ
 // bulk kernel through progress counters instead of stream events.  front == nullptr: off.
 struct PpDag {
     int* front;          // front[t]: leading 128-column tile columns for which the 64-row strip t of L is final
-    const int* af;       // "band tile accumulated" flags written by the bulk kernel (dag_af_index)
+    const int* af;       // "band tile (I, Jt) accumulated" flags written by the bulk kernel, [I * ntile + Jt]
+    int ntile;
     int need_front;      // > 0: strips t >= front_from wait for front[t] >= need_front (their rows of the older columns)
     int front_from;      // 4: one launch per strip-column (stream order covers the strips above); 0: persistent chain
     int af_tilecol;      // >= 0: first tile column of this launch; its band tiles were pre-accumulated by the bulk kernel
@@ -422,7 +433,7 @@ struct PpDag {
 
 // One strip t of one persistent panel step (the body of ppanel_kernel / pchain_kernel): every thread of the workgroup calls
 // it with the same arguments; waves may return at different times (callers that go on synchronize first).
-template <bool LDL, int NB>
+template <bool LDL, int NB, bool WT = false>
 __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, int64_t ld, int64_t p0, int nb, int64_t Np,
                                          double* __restrict__ dblk0, double* __restrict__ inv0, double* __restrict__ dvec,
                                          double* __restrict__ dinv, double* __restrict__ W, int64_t ldw, int64_t wcol0,
@@ -472,8 +483,8 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 for (int c = 0; c < nb && c <= t; ++c) wait_ge(dag.front + (int)(p0 >> 6) + c, dag.need_front);
             if (dag.trace != nullptr) dag.trace[8 * t + 5] = wall_clock64();
             if (dag.af_tilecol >= 0) {
-                wait_ge(dag.af + dag_af_index(tabs >> 1, dag.af_tilecol), 1);
-                if (t >= 2 && nb > 2) wait_ge(dag.af + dag_af_index(tabs >> 1, dag.af_tilecol + 1), 1);
+                wait_ge(dag.af + (int64_t)(tabs >> 1) * dag.ntile + dag.af_tilecol, 1);
+                if (t >= 2 && nb > 2) wait_ge(dag.af + (int64_t)(tabs >> 1) * dag.ntile + dag.af_tilecol + 1, 1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -571,9 +582,9 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                     for (int r = 0; r < 4; ++r) Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v[r];
                 }
             const int64_t jb = (p0 >> 6) + j;
-            potrf64w_core<LDL>(Lt, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol, nullptr,
-                               nullptr);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            potrf64w_core<LDL, WT>(Lt, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol, nullptr,
+                                   nullptr);
+            if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
                 __hip_atomic_store(prog + j, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -638,11 +649,11 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 const double v = X[4 * j + ib][r];
                 if (LDL) {
                     lv[r] = v * dsc[ib][r];
-                    if (W != nullptr) W[row + (wcol0 + c) * ldw] = v;
+                    if (W != nullptr) put<WT>(W + row + (wcol0 + c) * ldw, v);
                 } else {
                     lv[r] = v;
                 }
-                F[row + (p0 + c) * ld] = lv[r];
+                put<WT>(F + row + (p0 + c) * ld, lv[r]);
             }
             if (diag_strip) own[(w * 4 + ib) * 64 + lane] = lv;
         }
@@ -652,7 +663,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (diag_strip) __hip_atomic_store(prog + t, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pub_front)
@@ -733,19 +744,19 @@ __global__ __launch_bounds__(256) void pchain_kernel(double* __restrict__ F, int
                                                       double* __restrict__ inv0, double* __restrict__ dvec,
                                                       double* __restrict__ dinv, double* __restrict__ V, int* __restrict__ info,
                                                       double pivot_tol, int* __restrict__ flag_p, int epoch16, int dbg_missing,
-                                                      PpDag dag) {
+                                                      PpDag dag, int js_begin, int js_end) {
     extern __shared__ __attribute__((aligned(128))) char pp_smem[];
     __shared__ int s_go;
     const int t = blockIdx.x;
-    for (int64_t p0 = 0, Js = 0; p0 + 64 * (int64_t)t < Np; p0 += 256, ++Js) {
+    for (int64_t Js = js_begin, p0 = 256 * (int64_t)js_begin; Js < js_end && p0 + 64 * (int64_t)t < Np; p0 += 256, ++Js) {
         const int nb = (int)((Np - p0) / 64 < 4 ? (Np - p0) / 64 : 4);
         PpDag d = dag;
         d.need_front = Js > 0 ? (int)(2 * Js) : 0;
         d.front_from = 0;
         d.af_tilecol = 2 * Js - 2 > 0 ? (int)(2 * Js) : -1;
-        if (dag.trace != nullptr) d.trace = dag.trace + Js * 8 * (int64_t)gridDim.x;
+        if (dag.trace != nullptr) d.trace = dag.trace + (Js - js_begin) * 8 * (int64_t)gridDim.x;
         const double* Vp = Js > 0 ? (LDL ? V : F) + (p0 - 256) * ld : nullptr;
-        pp_strip<LDL, 4>(t, F, ld, p0, nb, Np, dblk0, inv0, dvec, dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, info, pivot_tol,
+        pp_strip<LDL, 4, true>(t, F, ld, p0, nb, Np, dblk0, inv0, dvec, dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, info, pivot_tol,
                          flag_p + p0 / 64, epoch16, dbg_missing, Vp, ld, Js > 0 ? 256 : 0, d, pp_smem, &s_go);
         __syncthreads();  // (waves leave a strip at different times; its LDS tiles and s_go are reused)
     }
@@ -878,7 +889,7 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
     hipLaunchKernelGGL((ppanel_kernel<LD, NBT>), dim3(grid), dim3(256), PP_LDS_BYTES, s, F, ld, p, nbk, Np, ls->dblk.p, \
                        ls->inv16.p, ls->dvec.p, ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0,  \
                        p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp,  \
-                       ldv, Kp, PpDag{nullptr, nullptr, 0, 4, -1, 0, nullptr})
+                       ldv, Kp, PpDag{nullptr, nullptr, 0, 0, 4, -1, 0, nullptr})
         if (ldl) MNK_PP(true, 4);
         else MNK_PP(false, 4);
 #undef MNK_PP
@@ -986,56 +997,40 @@ int64_t mnk_ls_effective_nbo(const mnk_ls* ls) {
 // between the fork and the join.
 static int run_factorization_dag(mnk_ls* ls) {
     mnk_ctx* ctx = ls->ctx;
-    hipStream_t s = ctx->stream, sp = ctx->sp_dag, su = ctx->su_dag;
+    hipStream_t s = ctx->stream;
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
-    const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI);
+    const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI), nsc = (int)((Np + 255) / 256);
+    const size_t nflags = (size_t)2 + nblk + 2 * (size_t)ntile * ntile;  // two queue counters | front | af | tprog
     if (!ls->dag_tasks.p) {
+        // Two band shapes.  Large systems (more than dag_cus2 strips of 64 rows): a shallow band on a handful of CUs, the
+        // rows below it closed by the bulk kernel's own tasks -- the factorization is bound by the bulk work for most of its
+        // columns.  Small systems: EVERY row is a strip of the chain's band (one CU each, on a larger partition) and the
+        // bulk kernel only accumulates: they are bound by the pivot chain from the first column on, and a row of tiles that
+        // the bulk kernel closes advances one tile column per {K = 128 step + finalization} ~ 80 us against the chain's
+        // ~50 us.  (Switching from the first shape to the second in mid-factorization, once dag_cus2 strips remain, is
+        // supported by the task list -- dag_js2 -- and was measured: the deep band needs one CU per strip, the remaining bulk
+        // work of a C3-size system then no longer fits the smaller bulk partition, 10.7 vs 10.3 ms.)
+        const int64_t deep_rows = (int64_t)ctx->dag_cus2 * NBI;
+        ls->dag_js2 = (ctx->dag_cus2 > 0 && Np <= deep_rows) ? 0 : nsc;
+        if (const char* e = getenv("MNK_DAG_JS2")) ls->dag_js2 = std::min(nsc, std::max(0, atoi(e)));
         std::vector<int> h;
-        mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, h);
+        ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h);
         ls->dag_ntasks = (int)(h.size() / 4);
         if (ls->dag_tasks.alloc(h.size() + 4)) return -2;
         if (!h.empty()) MNK_HIP(hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
         MNK_HIP(mnk::stream_wait(s));  // (h goes out of scope)
-        if (ls->dag_flags.alloc((size_t)1 + nblk + 8 * (size_t)ntile + (size_t)ntile * ntile)) return -2;
+        if (ls->dag_flags.alloc(nflags)) return -2;
     }
     if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) return -2;  // V = L D of every column (LDL^T)
     double* V = ldl ? ls->vfull.p : nullptr;
-    MNK_HIP(hipMemsetAsync(ls->dag_flags.p, 0, ((size_t)1 + nblk + 8 * (size_t)ntile + (size_t)ntile * ntile) * sizeof(int), s));
+    MNK_HIP(hipMemsetAsync(ls->dag_flags.p, 0, nflags * sizeof(int), s));
     int* qctr = ls->dag_flags.p;
-    int* front = qctr + 1;
+    int* front = qctr + 2;
     int* af = front + nblk;
-    int* tprog = af + 8 * (size_t)ntile;
+    int* tprog = af + (size_t)ntile * ntile;
     {   // 96 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
-        static std::atomic<uint64_t> attr_devs{0};
-        int dev = 0;
-        MNK_HIP(hipGetDevice(&dev));
-        if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
-            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-            MNK_HIP(hipFuncSetAttribute((const void*)ppanel_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-            attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
-        }
-    }
-    const long spin_limit = 1L << 24;
-    unsigned long long* trace = nullptr;
-    if (ls->dag_trace_on) {
-        const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;  // tasks | chain strips (<= 512 launches) | per-workgroup statistics
-        if (!ls->dag_trace.p && ls->dag_trace.alloc(ntr)) return -2;
-        MNK_HIP(hipMemsetAsync(ls->dag_trace.p, 0, ntr * sizeof(unsigned long long), s));
-        trace = ls->dag_trace.p;
-    }
-    MNK_HIP(hipEventRecord(ctx->ev_a, s));
-    MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
-    MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
-    // bulk: three workgroups per CU of the update stream's partition, for the whole factorization
-    int rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p,
-                                  ls->dag_ntasks, front, af, tprog, ntile, qctr, ls->info_dev.p, ls->flag_p.p, ls->epoch * 16, spin_limit,
-                                  std::min(ls->dag_ntasks, 3 * (ctx->num_cu - ctx->dag_cus)), trace);
-    if (rc) return rc;
-    // chain: ONE persistent launch, workgroup t = strip t of every band
-    const int epoch16 = ls->epoch * 16;
-    {
         static std::atomic<uint64_t> attr_devs{0};
         int dev = 0;
         MNK_HIP(hipGetDevice(&dev));
@@ -1045,19 +1040,54 @@ static int run_factorization_dag(mnk_ls* ls) {
             attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
-    const unsigned bstrips = (unsigned)std::min<int64_t>(ls->dag_band, Np / NBI);
-    PpDag dag{front, af, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 : nullptr};
-    if (ldl)
-        hipLaunchKernelGGL(pchain_kernel<true>, dim3(bstrips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
-                           ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing, dag);
-    else
-        hipLaunchKernelGGL(pchain_kernel<false>, dim3(bstrips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
-                           ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing, dag);
-    MNK_HIP(hipGetLastError());
-    MNK_HIP(hipEventRecord(ctx->ev_a, sp));
-    MNK_HIP(hipEventRecord(ctx->ev_b, su));
-    MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
-    MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
+    const long spin_limit = ls->dag_spin_limit;
+    unsigned long long* trace = nullptr;
+    if (ls->dag_trace_on) {
+        const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;  // tasks | chain strips | per-workgroup statistics (2 x 512)
+        if (!ls->dag_trace.p && ls->dag_trace.alloc(ntr)) return -2;
+        MNK_HIP(hipMemsetAsync(ls->dag_trace.p, 0, ntr * sizeof(unsigned long long), s));
+        trace = ls->dag_trace.p;
+    }
+    const int epoch16 = ls->epoch * 16;
+    const int js2 = ls->dag_js2;
+    // one phase = one persistent bulk launch (update stream) beside one persistent chain launch (panel stream)
+    auto phase = [&](hipStream_t sp, hipStream_t su, int bulk_cus, int task0, int ntask, int* counter, int js_begin, int js_end,
+                     unsigned strips) -> int {
+        MNK_HIP(hipEventRecord(ctx->ev_a, s));
+        MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
+        MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
+        int rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p + 4 * (size_t)task0, ntask,
+                                      front, af, tprog, ntile, counter, ls->info_dev.p, ls->flag_p.p, epoch16, spin_limit,
+                                      std::min(ntask, 3 * bulk_cus), trace ? trace + 8 * (size_t)task0 : nullptr,
+                                      trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
+        if (rc) return rc;
+        PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr};
+        if (ldl)
+            hipLaunchKernelGGL(pchain_kernel<true>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
+                               ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing,
+                               dag, js_begin, js_end);
+        else
+            hipLaunchKernelGGL(pchain_kernel<false>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
+                               ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing,
+                               dag, js_begin, js_end);
+        MNK_HIP(hipGetLastError());
+        MNK_HIP(hipEventRecord(ctx->ev_a, sp));
+        MNK_HIP(hipEventRecord(ctx->ev_b, su));
+        MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
+        MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
+        return 0;
+    };
+    if (js2 > 0) {
+        int rc = phase(ctx->sp_dag, ctx->su_dag, ctx->num_cu - ctx->dag_cus, 0, ls->dag_ntasks1, qctr, 0, std::min(js2, nsc),
+                       (unsigned)std::min<int64_t>(ls->dag_band, Np / NBI));
+        if (rc) return rc;
+    }
+    if (js2 < nsc) {
+        const int64_t rows2 = Np - 256 * (int64_t)js2;
+        int rc = phase(ctx->sp_dag2, ctx->su_dag2, ctx->num_cu - ctx->dag_cus2, ls->dag_ntasks1, ls->dag_ntasks - ls->dag_ntasks1,
+                       qctr + 1, js2, nsc, (unsigned)(rows2 / NBI));
+        if (rc) return rc;
+    }
     return 0;
 }
 

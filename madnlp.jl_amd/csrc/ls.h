@@ -63,16 +63,17 @@ struct mnk_ls {
     int64_t own_cols = 128;   // split_a = 2: columns of the next panel that the panel stream updates itself
     // task-DAG schedule (panel_algo = 5, dag.hip)
     mnk::DevBuf<int> dag_tasks;   // 4 ints per task, built once per order
-    int dag_ntasks = 0;
+    int dag_ntasks = 0, dag_ntasks1 = 0, dag_js2 = 0;  // all tasks / tasks of the first phase / first strip-column of the second
     mnk::DevBuf<int> dag_flags;   // [queue counter | front: Np/64 | af: 4 * Np/128], zeroed per factorization
     mnk::DevBuf<double> vfull;    // LDL^T: V = L D of every column, same layout as `fact` (B operand of the left-looking updates)
     mnk::DevBuf<unsigned long long> dag_trace;  // diagnostics (option dag_trace): time stamps per bulk task / chain strip
     bool dag_trace_on = false;
     int dag_band = 16;            // 64-row strips per band of the persistent pivot chain (8, 12 or 16; <= the chain's CUs)
+    long dag_spin_limit = 1L << 24;  // polls (~0.5 us each) a device-side wait of the schedule may take before it gives up (info = -7)
     int dag_chunk = 8;            // tile columns (of 128) per bulk task
-    int64_t dag_min_rows = 3072;  // smaller systems keep the launch-per-panel schedules
+    int64_t dag_min_rows = 1536;  // smaller systems keep the launch-per-panel schedules (measured break-even: N ~ 1500)
     int64_t dag_max_rows = 40000; // larger ones too: their trailing updates already run at the update kernel's rate
-    int panel_algo = 4;  // 4: persistent panel kernel (one flag-synchronized launch per 256 columns); 1: one launch per piece (potrf64w + MFMA triangular solve + recursive inner updates), also the fallback of 4
+    int panel_algo = 5;  // 5: task-DAG schedule (dag.hip: persistent pivot chain + persistent left-looking bulk kernel); 4: persistent panel kernel per 256 columns + one trailing update per outer panel (also what 5 uses outside [dag_min_rows, dag_max_rows]); 1: one launch per piece, the fallback of 4 and 5
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
     long ps_spin_limit = 6000000;  // polls (~0.5 us each) a persistent-solve wait may take before it gives up

@@ -85,6 +85,8 @@ static void ctx_free(mnk_ctx* c) {
     if (c->su) (void)hipStreamDestroy(c->su);
     if (c->sp_dag) (void)hipStreamDestroy(c->sp_dag);
     if (c->su_dag) (void)hipStreamDestroy(c->su_dag);
+    if (c->sp_dag2) (void)hipStreamDestroy(c->sp_dag2);
+    if (c->su_dag2) (void)hipStreamDestroy(c->su_dag2);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -198,6 +200,8 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
     if (c->num_cu >= 64) {
         const int want = getenv("MNK_DAG_CUS") ? atoi(getenv("MNK_DAG_CUS")) : 16;
         if (make_pair(want, c->sp_dag, c->su_dag)) c->dag_cus = want;
+        const int want2 = getenv("MNK_DAG_CUS2") ? atoi(getenv("MNK_DAG_CUS2")) : 96;
+        if (c->dag_cus > 0 && make_pair(want2, c->sp_dag2, c->su_dag2)) c->dag_cus2 = want2;
     }
     if (!c->sp) {
         int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
@@ -345,6 +349,11 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     if (!strcmp(key, "pp_fuse_rows")) { ls->pp_fuse_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "dag_min_rows")) { ls->dag_min_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "dag_spin_limit")) {  // polls a wait of the task-DAG schedule's kernels may take before it gives up
+        MNK_REQUIRE(value >= 1024.0, "dag_spin_limit must be at least 1024");
+        ls->dag_spin_limit = (long)value;
+        return 0;
+    }
     if (!strcmp(key, "dag_trace")) { ls->dag_trace_on = value != 0.0; return 0; }  // diagnostics: tools/dag_timeline.py
     if (!strcmp(key, "dag_max_rows")) { ls->dag_max_rows = (int64_t)value; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
@@ -633,6 +642,9 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     }
     if (!strcmp(key, "panel_algo")) { *value = ls->algo_now; return 0; }
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
+    if (!strcmp(key, "dag_ntasks")) { *value = ls->dag_ntasks; return 0; }    // task-DAG schedule: bulk tasks, ...
+    if (!strcmp(key, "dag_ntasks1")) { *value = ls->dag_ntasks1; return 0; }  // ... of them in the first phase, ...
+    if (!strcmp(key, "dag_js2")) { *value = ls->dag_js2; return 0; }          // ... first strip-column of the second phase
     set_error("mnk_ls_get_stat: unknown key '%s'", key);
     return -1;
 }

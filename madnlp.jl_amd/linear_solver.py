@@ -118,8 +118,9 @@ class HipSolverOptions:
     small_tiles: int = 400  # (a)-updates with fewer 128x128 tiles use 64x64 workgroup tiles
     persistent_solve: bool = True  # both triangular sweeps in one launch (False: one launch per 256-column step)
     single_rows: int = 2560  # systems up to this order are factored as one outer panel on the whole chip (0: never)
-    panel_algo: int = 4      # 4: persistent panel kernel (needs the panel CUs for itself: set 1 when several PROCESSES
-                             # share the GPU); 1: one launch per piece of a 64-column block
+    panel_algo: int = 5      # 5: task-DAG schedule (persistent pivot chain + persistent bulk kernel); 4: persistent panel
+                             # kernel per 256 columns + one trailing update per outer panel; 1: one launch per piece.
+                             # 4 and 5 keep waiting workgroups resident: set 1 when several PROCESSES share the GPU
 
 
 class HipLinearSolver:

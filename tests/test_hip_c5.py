@@ -99,7 +99,7 @@ def test_c5_batch_on_one_gpu_matches_oracle(nctx, nb):
         b = din["rhs"].cpu().numpy()
         assert _bwd(K, x, b) <= 1e-13
         kh.linear_solver.check_solve()
-        assert kh.linear_solver.get_stat("panel_algo") == (4.0 if nctx == 1 else 1.0)
+        assert kh.linear_solver.get_stat("panel_algo") == (5.0 if nctx == 1 else 1.0)   # task-DAG schedule while the context is alone
     assert len(seen) == nb, "the scenarios must be different problems"
     for (_, kh, _, _) in insts:
         kh.close()

@@ -356,17 +356,19 @@ def test_ipm_lootsma_hip_reproduces_reference_answers(ctx, kind):
 
 
 # --------------------------------------------------------------------------- persistent panel kernel: safety net
-def test_persistent_panel_is_the_default_when_the_context_is_alone_and_gives_way_otherwise(ctx):
-    """panel_algo = 4 keeps waiting workgroups resident, which is only safe while no other context of the process
-    runs persistent kernels on the same CUs: with one live context the factor comes from it, with a second context
-    alive the solver takes the one-launch-per-piece path by itself; the factors agree to rounding."""
+@pytest.mark.parametrize("N,expect", [(1200, 4.0), (2300, 5.0)])
+def test_persistent_panel_is_the_default_when_the_context_is_alone_and_gives_way_otherwise(ctx, N, expect):
+    """panel_algo = 4 / 5 keep waiting workgroups resident, which is only safe while no other context of the process
+    runs persistent kernels on the same CUs: with one live context the factor comes from them (small systems: the
+    persistent panel kernel; from dag_min_rows on: the task-DAG schedule), with a second context alive the solver takes
+    the one-launch-per-piece path by itself; the factors agree to rounding."""
     rng = np.random.default_rng(4)
-    N = 1500
     A = _spd(rng, N)
     b = rng.standard_normal(N)
     M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
     M.factorize()
     alone = M.get_stat("panel_algo")
+    assert alone == expect
     x4 = M.solve_linear_system(b.copy())
     other = mj.HipContext(0)
     try:
@@ -383,17 +385,19 @@ def test_persistent_panel_is_the_default_when_the_context_is_alone_and_gives_way
 
 
 @pytest.mark.parametrize("alg", [mj.CHOLESKY, mj.LDL])
-def test_persistent_panel_that_gives_up_is_redone_without_it(ctx, alg):
+@pytest.mark.parametrize("N,expect", [(1000, 4.0), (2100, 5.0)])
+def test_persistent_panel_that_gives_up_is_redone_without_it(ctx, alg, N, expect):
     """A diagonal strip that never publishes (simulated: option debug_pp_missing; in the field: another process'
     persistent kernels starving it) must not hang: the waiters give up after a bounded number of polls (info = -7),
-    the factorization is redone with one launch per panel piece when `info` is read, and the solver stays there."""
+    the factorization is redone with one launch per panel piece when `info` is read, and the solver stays there.
+    Both persistent schedules: the panel kernel (N = 1000) and the task-DAG schedule's chain + bulk kernels (N = 2100)."""
     rng = np.random.default_rng(5)
-    N = 1000
     A = _spd(rng, N)
     b = rng.standard_normal(N)
     M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
+    M.set_option("dag_spin_limit", 1 << 17)   # (the default bound is sized for factorizations that take seconds)
     M.factorize()
-    assert M.get_stat("panel_algo") == 4.0, "the module's context should be the only live one here"
+    assert M.get_stat("panel_algo") == expect, "the module's context should be the only live one here"
     x_ok = M.solve_linear_system(b.copy())
     M.set_option("debug_pp_missing", 1)
     M.factorize()

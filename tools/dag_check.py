@@ -30,7 +30,7 @@ with torch.cuda.stream(s):
             b = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
             ref = None
             for pa in algos:
-                ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, panel_algo=pa, single_rows=0))
+                ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, panel_algo=pa, single_rows=int(os.environ.get("DAG_SINGLE", "0")) if pa == 5 else int(os.environ.get("DAG_SINGLE4", "0"))))
                 ls.set_option("dag_min_rows", 0)
                 ts = []
                 facs = []

@@ -91,3 +91,11 @@ for a, b in zip(edges[:-1], edges[1:]):
     if m.sum() == 0:
         continue
     print(f"{a:8.0f} | {m.sum():5d} | {dur[m].mean():7.1f} | {100*gatew[m].sum()/dur[m].sum():5.1f} | {100*diagw[m].sum()/dur[m].sum():5.1f} | {ready[m].min()}..{ready[m].max()}")
+
+# ---- anatomy of the tile-closing tasks late in the factorization (the chain-bound part)
+m = (cls == 1) & (ready >= ntile // 2) & (bulk[:, 2] > 0)
+if m.sum():
+    b = bulk[m]
+    print(f"tile-closing tasks with chain position >= {ntile//2}: {m.sum()}; mean us: grab->front ready {(b[:,2]-b[:,0]).mean()/100:.1f}, "
+          f"front ready->tile applied (k-step + chunk order + epilogue) {(b[:,3]-b[:,2]).mean()/100:.1f}, diagonal wait {(b[:,4]-b[:,3]).mean()/100:.1f}, "
+          f"finalize + publish {(b[:,5]-b[:,4]).mean()/100:.1f}")
