@@ -78,6 +78,7 @@ def parse_args():
                          "CUs for itself) -- measured per GPU at batch 16: 77.4 it/s with 1 context, 58.7 with 2, "
                          "68.2 with 4 (the time-shared contexts fall back to one launch per panel piece)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the supplementary config-C4 record (case9241pegase shape, ~15 s)")
     ap.add_argument("--no-ipm-loop", action="store_true",
                     help="skip the supplementary end-to-end IPM run (device-resident vectors) reported as `end_to_end_ipm`")
     ap.add_argument("--cpu-baseline-budget", type=float, default=100.0,
@@ -309,18 +310,82 @@ def cpu_baseline(P, algorithm, nsolve, budget_s=100.0):
     }
 
 
-def pmc_traffic(N, args):
+def pmc_traffic(N, args, schedule):
     """HBM bytes per factorize! call from the committed rocprofv3 PMC passes of this same command
     (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, two separate --pmc passes: counters cannot be
-    collected inside the timed run).  Returns (bytes or None, the profile the number came from)."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    collected inside the timed run).  Returns (bytes or None, the profile the number came from).
+    A profile only describes the schedule it was collected on (its "panel_algo"; the round-2 files: 4)."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if N == 11192 and args.batch == 1 and os.path.exists(path):
             try:
-                return json.load(open(path))["traffic_bytes"], "profiles/" + name
+                rec = json.load(open(path))
+                if int(rec.get("panel_algo", 4)) == int(schedule):
+                    return rec["traffic_bytes"], "profiles/" + name
             except Exception:
                 pass
     return None, None
+
+
+def config_c4(ctx, torch, mj):
+    """Supplementary record, OUTSIDE the timed region: BASELINE config C4 (case9241pegase-shaped sparse-condensed KKT,
+    N = 85 568, 58.7 GB factor) -- the configuration north_star's >= 5x and >= 70 % targets name.  One warm and one timed
+    `factorize!`, two timed `solve!`, HIP events on the launch stream; the CPU side is the labelled N^3 extrapolation of
+    profiles/r02_config_C4_cpu_extrapolation.json (a 58.7 GB dsytrf does not finish inside a bench run)."""
+    from madnlp_jl_amd.problems import opf_shaped
+    free, _ = torch.cuda.mem_get_info()
+    if free < 75e9:
+        return {"skipped": f"free HBM {free/1e9:.0f} GB < 75 GB"}
+    t0 = time.perf_counter()
+    P = opf_shaped("case9241pegase", du=1e-8)
+    k = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                    opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+    setup_s = time.perf_counter() - t0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dj, dh = torch.from_numpy(P.jac).to(dev), torch.from_numpy(P.hess).to(dev)
+    dp, dd = torch.from_numpy(P.pr_diag).to(dev), torch.from_numpy(P.du_diag).to(dev)
+
+    def ev_ms(fn):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b)
+
+    def assemble():
+        k.compress_jacobian(dj)
+        k.compress_hessian(dh)
+        k.build_kkt(dp, dd)
+    assemble()
+    k.linear_solver.factorize_async()          # warm (first-touch of the 58.7 GB factor)
+    ms_a = ev_ms(assemble)
+    ms_f = ev_ms(k.linear_solver.factorize_async)
+    inertia = k.linear_solver.inertia()
+    x = torch.randn(P.n, dtype=torch.float64, device=dev)
+    ms_s = float(np.mean([ev_ms(lambda: k.linear_solver.solve_linear_system(x)) for _ in range(2)]))
+    N = P.n
+    rec = {"workload": f"BASELINE config C4: case9241pegase-shaped sparse-condensed KKT, N={N}, nnz(K)={k.nnz_aug}; one warm + one "
+                       f"timed factorize!, two timed solve!",
+           "ms_assemble": ms_a, "ms_per_factorize": ms_f, "ms_per_solve": ms_s, "inertia_ok": bool(k.is_inertia_correct(*inertia)),
+           "it_per_s_nf1_ns2": 1e3 / (ms_a + ms_f + 2 * ms_s),
+           "roofline": {"bound": "mfma", "achieved": N ** 3 / 3.0 / (ms_f * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                        "frac": N ** 3 / 3.0 / (ms_f * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, "traffic": None},
+           "schedule_panel_algo": k.linear_solver.get_stat("panel_algo"), "setup_s": setup_s}
+    try:
+        ext = json.load(open(os.path.join(ROOT, "profiles", "r02_config_C4_cpu_extrapolation.json")))
+        best = min((r for r in ext["rows"] if r["routine"] == "dsytrf" and r["N"] == max(q["N"] for q in ext["rows"])),
+                   key=lambda r: r["seconds"])
+        cpu_s = best["seconds"] * (N / best["N"]) ** 3
+        rec["cpu_baseline_extrapolated"] = {
+            "kind": "port", "labelled": f"N^3 extrapolation of scipy/OpenBLAS dsytrf at N={best['N']}, {best['threads']} threads "
+                                        f"({best['seconds']:.2f} s measured, profiles/r02_config_C4_cpu_extrapolation.json)",
+            "s_per_factorize": cpu_s, "gpu_over_cpu_factorize": cpu_s / (ms_f * 1e-3)}
+    except Exception:
+        pass
+    k.close()
+    return rec
 
 
 # ---------------------------------------------------------------------------- main
@@ -443,6 +508,8 @@ def main():
         flops = N ** 3 / 3.0
         fact_ms = float(np.mean([a[1] for a in allms]))
         ach = flops / (fact_ms * 1e-3) / 1e12
+        schedule = ls.get_stat("panel_algo")
+        traffic, traffic_src = pmc_traffic(N, args, schedule)
         out = {
             "metric": METRIC, "value": world * args.batch * args.steps / elapsed, "unit": "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -465,10 +532,11 @@ def main():
             "ms_assemble": float(np.mean([a[0] for a in allms])),
             "per_rank_ms": allms,
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP64_TFLOPS, "traffic": pmc_traffic(N, args)[0],
-                         "traffic_source": pmc_traffic(N, args)[1],
+                         "frac": ach / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "factorize! (densify + blocked LDL^T/Cholesky; N^3/3 flop per call, "
-                                   "HIP-event timed on the launch stream)"},
+                                   "HIP-event timed on the launch stream)",
+                         "schedule_panel_algo": schedule},
         }
         if not args.no_ipm_loop and world == 1 and args.batch == 1:
             # Supplementary, OUTSIDE the timed region: a complete IPM regular phase with device-resident vectors on a
@@ -478,6 +546,13 @@ def main():
                 out["end_to_end_ipm"] = ipm_loop(args, ctx)
             except Exception as e:  # never let the supplement break the bench line
                 out["end_to_end_ipm"] = {"error": repr(e)[:300]}
+        if not args.no_c4 and world == 1 and args.batch == 1:
+            try:
+                for (_, kb, _, _) in insts:   # the C3 instances' 1 GB factors are not needed any more
+                    kb.close()
+                out["config_C4"] = config_c4(ctx, torch, mj)
+            except Exception as e:  # never let the supplement break the bench line
+                out["config_C4"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             if host_pool_limit is not None:
                 host_pool_limit.restore_original_limits()  # the CPU leg sets its own BLAS thread counts
