@@ -154,6 +154,7 @@ int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<i
 int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
                     const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
                     int* info,
-                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace, unsigned long long* wgstat);
+                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* vmax, unsigned long long* trace,
+                    unsigned long long* wgstat);
 
 }  // namespace mnk

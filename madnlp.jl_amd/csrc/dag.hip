@@ -30,6 +30,7 @@
 // by d_k inside the k-loop instead was built first and cost 16 % of the loop (fp64 VALU work between the fp64 MFMAs).
 #include <algorithm>
 #include <atomic>
+#include <cfloat>
 #include <climits>
 #include <vector>
 
@@ -58,6 +59,7 @@ struct DagArgs {
     long spin_limit;
     unsigned long long* trace;  // diagnostics (option dag_trace): 8 time stamps per task
     unsigned long long* wgstat; // diagnostics: per workgroup {first grab, exit, ticks waited, tasks, ticks in finalize}
+    unsigned long long* vmax;   // growth monitor of the static-pivot LDL^T (factor.hip growth_fold): receives max|V|, or NULL
 };
 
 constexpr int DAG_BANDACC = 1, DAG_FINAL = 2, DAG_FIRST = 4;  // task flags
@@ -143,6 +145,7 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
     const int l15 = lane & 15, l4 = lane >> 4;
     double* Fs = F + (row0 + 32 * w + l15) + (col0 + l4) * ld;  // this lane's element (row of strip 0, column l4)
     double* Vs = LDL ? a.V + (row0 + 32 * w + l15) + (col0 + l4) * ld : nullptr;
+    double vm = 0.0;  // max|V| of this wave's strips (growth monitor)
 
     // blocks 0..5: -L_kk[cb, ib] for (cb, ib) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2); blocks 6..9: inv(L_kk[cb, cb])
     auto fill_diag = [&](int jk) {
@@ -196,6 +199,7 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
             X[1][cb] = x1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (LDL) vm = fmax(vm, fmax(fabs(x0[r]), fabs(x1[r])));
                 const int64_t cc = (int64_t)(coff + 16 * cb + 4 * r) * ld;
                 Fs[cc] = LDL ? x0[r] * di[cb][r] : x0[r];
                 Fs[cc + 16] = LDL ? x1[r] * di[cb][r] : x1[r];
@@ -249,6 +253,11 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
     fill_diag(ja + 1);
     __syncthreads();
     trsm(Xb, 64);
+    if (LDL && a.vmax != nullptr) {
+        if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
+        for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
+        if (lane == 0 && vm > 0.0) atomicMax(a.vmax, (unsigned long long)__double_as_longlong(vm));
+    }
 }
 
 template <bool LDL>
@@ -425,9 +434,10 @@ static int launch_bulk_t(hipStream_t s, const DagArgs& a, int nwg) {
 int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
                     const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
                     int* info,
-                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* trace, unsigned long long* wgstat) {
+                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* vmax, unsigned long long* trace,
+                    unsigned long long* wgstat) {
     if (ntasks <= 0) return 0;
-    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace, wgstat};
+    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace, wgstat, vmax};
     return ldl ? launch_bulk_t<true>(s, a, nwg) : launch_bulk_t<false>(s, a, nwg);
 }
 

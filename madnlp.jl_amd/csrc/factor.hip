@@ -74,6 +74,17 @@ __device__ __forceinline__ void put(double* p, double v) {
     else *p = v;
 }
 
+// Growth monitor of the static-pivot LDL^T (the guard of BUNCHKAUFMAN's first tier, ls.h): the entries of V = L D are the
+// entries of the successive Schur complements at the moment their column is eliminated, so max|v_ik| / max|a_ij| is the
+// element growth of the elimination as far as it can be seen without extra passes.  Every kernel that produces V folds
+// |v| into one word: max over the wave, one atomicMax on the bit pattern (NaN / Inf -> +Inf).
+__device__ __forceinline__ void growth_fold(unsigned long long* word, double vm) {
+    if (word == nullptr) return;
+    if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
+    for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
+    if ((threadIdx.x & 63) == 0 && vm > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(vm));
+}
+
 // X = B L_jj^-T (Cholesky) / V = B L_jj^-T, X = V D^-1 (LDL) for every row below the diagonal block.
 // Wave = NS strips of 16 rows; lane (l15, l4): accumulator register r of column block cb holds
 // X[row0 + l15][16 cb + l4 + 4 r] (the C^T layout of gemm_f64.hip, so register r of X^T[ib] IS the
@@ -83,7 +94,8 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F
                                                            const double* __restrict__ Dblk,
                                                            const double* __restrict__ inv16,
                                                            const double* __restrict__ dinv, double* __restrict__ W,
-                                                           int64_t ldw, int64_t wcol, int* __restrict__ info) {
+                                                           int64_t ldw, int64_t wcol, int* __restrict__ info,
+                                                           unsigned long long* __restrict__ vmax = nullptr) {
     if (*info != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F
             X[ns][cb] = x;
         }
     }
+    double vm = 0.0;
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
@@ -140,10 +153,12 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F
                 if (LDL) {
                     W[row + (wcol + c) * ldw] = X[ns][cb][r];
                     F[row + (j0 + c) * ld] = X[ns][cb][r] * dinv[j0 + c];
+                    vm = fmax(vm, fabs(X[ns][cb][r]));
                 } else {
                     F[row + (j0 + c) * ld] = X[ns][cb][r];
                 }
             }
+    if (LDL) growth_fold(vmax, vm);
 }
 
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
@@ -218,10 +233,11 @@ template <bool LDL, bool WT = false>
 __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, double* __restrict__ Dout,
                                               double* __restrict__ inv16, double* __restrict__ dvec,
                                               double* __restrict__ dinv, int* __restrict__ info, double pivot_tol,
-                                              double* Lsh, double* Ish) {
+                                              double* Lsh, double* Ish, unsigned long long* __restrict__ vmax = nullptr) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    double vm = 0.0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         double aopinv[4];
@@ -291,6 +307,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
                 }
                 X[cb] = x;
                 V[cb] = v;
+                if (LDL) vm = fmax(vm, fabs(v));
                 Lt[cb][b][tt] = x;
             }
             // ---- 3. rank-4 update of the trailing blocks: acc(cb2, cb1) -= X[cb1] (V|X)[cb2]^T
@@ -342,13 +359,15 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
                 if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
             }
     }
+    if (LDL) growth_fold(vmax, vm);
 }
 
 template <bool LDL>
 __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
                                               double* __restrict__ Dout, double* __restrict__ inv16,
                                               double* __restrict__ dvec, double* __restrict__ dinv,
-                                              int* __restrict__ info, double pivot_tol, double* Lsh, double* Ish) {
+                                              int* __restrict__ info, double pivot_tol, double* Lsh, double* Ish,
+                                              unsigned long long* __restrict__ vmax = nullptr) {
     const int lane = threadIdx.x & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     v4d Lt[4][4];
@@ -362,16 +381,17 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
                 // 'L' storage: the strict upper triangle of the block may hold anything (NaN included)
                 Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v;
             }
-    potrf64w_core<LDL>(Lt, j0, Dout, inv16, dvec, dinv, info, pivot_tol, Lsh, Ish);
+    potrf64w_core<LDL>(Lt, j0, Dout, inv16, dvec, dinv, info, pivot_tol, Lsh, Ish, vmax);
 }
 
 template <bool LDL>
 __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__ F, int64_t ld, int64_t j0,
                                                        double* __restrict__ Dout, double* __restrict__ inv16,
                                                        double* __restrict__ dvec, double* __restrict__ dinv,
-                                                       int* __restrict__ info, double pivot_tol) {
+                                                       int* __restrict__ info, double pivot_tol,
+                                                       unsigned long long* __restrict__ vmax) {
     if (*info != 0) return;
-    potrf64w_body<LDL>(F, ld, j0, Dout, inv16, dvec, dinv, info, pivot_tol, nullptr, nullptr);
+    potrf64w_body<LDL>(F, ld, j0, Dout, inv16, dvec, dinv, info, pivot_tol, nullptr, nullptr, vmax);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -428,7 +448,8 @@ struct PpDag {
     int front_from;      // 4: one launch per strip-column (stream order covers the strips above); 0: persistent chain
     int af_tilecol;      // >= 0: first tile column of this launch; its band tiles were pre-accumulated by the bulk kernel
     long spin_limit;
-    unsigned long long* trace;  // diagnostics: 4 time stamps per strip of this launch
+    unsigned long long* trace;  // diagnostics: 8 time stamps per strip of this launch
+    unsigned long long* vmax;   // growth monitor (LDL^T with the BUNCHKAUFMAN guard on): receives max|V|, see growth_fold
 };
 
 // One strip t of one persistent panel step (the body of ppanel_kernel / pchain_kernel): every thread of the workgroup calls
@@ -583,7 +604,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 }
             const int64_t jb = (p0 >> 6) + j;
             potrf64w_core<LDL, WT>(Lt, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol, nullptr,
-                                   nullptr);
+                                   nullptr, dag.vmax);
             if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
@@ -639,6 +660,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             }
         }
         // ---- store V (LDL: to the W panel) and L; a diagonal strip also keeps its L rows in LDS and publishes
+        double vm = 0.0;
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib) {
             v4d lv;
@@ -649,6 +671,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 const double v = X[4 * j + ib][r];
                 if (LDL) {
                     lv[r] = v * dsc[ib][r];
+                    vm = fmax(vm, fabs(v));
                     if (W != nullptr) put<WT>(W + row + (wcol0 + c) * ldw, v);
                 } else {
                     lv[r] = v;
@@ -657,6 +680,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             }
             if (diag_strip) own[(w * 4 + ib) * 64 + lane] = lv;
         }
+        if (LDL) growth_fold(dag.vmax, vm);
         // task-DAG schedule: the strip's rows are final through a whole tile column after every second block
         const bool pub_front = dag.front != nullptr && ((j & 1) != 0 || j == jmax);
         if (diag_strip || pub_front) {
@@ -818,13 +842,24 @@ __global__ __launch_bounds__(256) void linv64_kernel(double* __restrict__ F, int
 }
 
 // Count signs of D over the first N pivots: out[0]=pos, out[1]=zero, out[2]=neg.
-__global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsigned long long* out) {
+// (`dmax`: optional, max|d_k| as a bit pattern -- the growth guard of BUNCHKAUFMAN's static-pivot tier)
+__global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsigned long long* out,
+                               unsigned long long* __restrict__ dmax) {
     unsigned long long pos = 0, zer = 0, neg = 0;
+    double amx = 0.0;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < N; k += (int64_t)gridDim.x * blockDim.x) {
         const double d = dvec[k];
         if (d > 0.0) ++pos;
         else if (d < 0.0) ++neg;
         else ++zer;
+        const double a = fabs(d) <= DBL_MAX ? fabs(d) : __longlong_as_double(0x7ff0000000000000LL);  // NaN / Inf pivot -> Inf
+        amx = fmax(amx, a);
+        // sign changes along the pivot sequence (word dmax[1]): <= 1 means "positive pivots, then negative ones"
+        if (dmax != nullptr && k + 1 < N && ((d > 0.0) != (dvec[k + 1] > 0.0))) atomicAdd(dmax + 1, 1ull);
+    }
+    if (dmax != nullptr) {
+        for (int off = 32; off > 0; off >>= 1) amx = fmax(amx, __shfl_xor(amx, off));
+        if ((threadIdx.x & 63) == 0 && amx > 0.0) atomicMax(dmax, (unsigned long long)__double_as_longlong(amx));
     }
     for (int off = 32; off > 0; off >>= 1) {
         pos += __shfl_down(pos, off);
@@ -842,12 +877,19 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 
 using namespace mnk;
 
+// the word the kernels fold max|V| into (zeroed with max|a_ij| when the matrix was transferred), or NULL: guard off
+static unsigned long long* mnk_ls_growth_word(mnk_ls* ls) {
+    return (ls->algo == MNK_LDL && ls->bk_requested && ls->bk_fallback && ls->amax_dev.p) ? ls->amax_dev.p + 1 : nullptr;
+}
+
 // The host reads the inertia counters and the info word from pinned, device-mapped memory that this one-thread kernel
 // fills with system-scope stores: no copy engine and no staging copy between the last kernel and the host.
 __global__ void publish_info_kernel(const unsigned long long* __restrict__ inertia, const int* __restrict__ info,
-                                    unsigned long long* __restrict__ host_words) {
+                                    unsigned long long* __restrict__ host_words, const unsigned long long* __restrict__ amax = nullptr) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int i = 0; i < 3; ++i) __hip_atomic_store(host_words + i, inertia[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = 0; i < 3; ++i)  // max|a_ij|, max(|d_k|, |v_ik|), sign changes of the pivot sequence (words 4, 5, 6)
+            __hip_atomic_store(host_words + 4 + i, amax != nullptr ? amax[i] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_words + 3, (unsigned long long)(long long)*info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -885,11 +927,12 @@ static int factor_outer_panel_pp(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t 
             waited = true;
         }
         const unsigned grid = (unsigned)((Np - p) / NBI);
+    unsigned long long* vmaxw = mnk_ls_growth_word(ls);
 #define MNK_PP(LD, NBT)                                                                                              \
     hipLaunchKernelGGL((ppanel_kernel<LD, NBT>), dim3(grid), dim3(256), PP_LDS_BYTES, s, F, ld, p, nbk, Np, ls->dblk.p, \
                        ls->inv16.p, ls->dvec.p, ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0,  \
                        p - ko, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p + p / NBI, epoch16, ls->debug_pp_missing, Vp,  \
-                       ldv, Kp, PpDag{nullptr, nullptr, 0, 0, 4, -1, 0, nullptr})
+                       ldv, Kp, PpDag{nullptr, nullptr, 0, 0, 4, -1, 0, nullptr, vmaxw})
         if (ldl) MNK_PP(true, 4);
         else MNK_PP(false, 4);
 #undef MNK_PP
@@ -941,10 +984,10 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         double* inv16 = ls->inv16.p + (j / NBI) * 1024;
         if (ldl)
             hipLaunchKernelGGL(potrf64w_kernel<true>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p, ls->dinv.p,
-                               ls->info_dev.p, ls->pivot_tol);
+                               ls->info_dev.p, ls->pivot_tol, mnk_ls_growth_word(ls));
         else
             hipLaunchKernelGGL(potrf64w_kernel<false>, dim3(1), dim3(64), 0, s, F, ld, j, dblk, inv16, ls->dvec.p, ls->dinv.p,
-                               ls->info_dev.p, ls->pivot_tol);
+                               ls->info_dev.p, ls->pivot_tol, (unsigned long long*)nullptr);
         const int64_t M = Np - j - NBI;
         if (M <= 0) break;
         // 16-row strips per wave: one while the panel is short (more workgroups, shortest chain), two beyond
@@ -952,7 +995,8 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
         const unsigned grid = (unsigned)((M / (two ? 32 : 16) + 3) / 4);
 #define MNK_TRSM(LD, NS)                                                                                          \
     hipLaunchKernelGGL((trsm64_mfma_kernel<LD, NS>), dim3(grid), dim3(256), 0, s, F, ld, j, Np, dblk, inv16,    \
-                       ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0, j - ko, ls->info_dev.p)
+                       ls->dinv.p, LD ? wbase : (double*)nullptr, LD ? ls->ldw : (int64_t)0, j - ko, ls->info_dev.p,  \
+                       mnk_ls_growth_word(ls))
         if (ldl) { if (two) MNK_TRSM(true, 2); else MNK_TRSM(true, 1); }
         else { if (two) MNK_TRSM(false, 2); else MNK_TRSM(false, 1); }
 #undef MNK_TRSM
@@ -1058,10 +1102,11 @@ static int run_factorization_dag(mnk_ls* ls) {
         MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
         int rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p + 4 * (size_t)task0, ntask,
                                       front, af, tprog, ntile, counter, ls->info_dev.p, ls->flag_p.p, epoch16, spin_limit,
-                                      std::min(ntask, 3 * bulk_cus), trace ? trace + 8 * (size_t)task0 : nullptr,
+                                      std::min(ntask, 3 * bulk_cus), mnk_ls_growth_word(ls), trace ? trace + 8 * (size_t)task0 : nullptr,
                                       trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
         if (rc) return rc;
-        PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr};
+        PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
+                  mnk_ls_growth_word(ls)};
         if (ldl)
             hipLaunchKernelGGL(pchain_kernel<true>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
                                ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing,
@@ -1358,16 +1403,28 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         ls->info_valid = true;
         return 0;
     }
+    // growth guard of the static-pivot tier (BUNCHKAUFMAN): max|a_ij| was recorded when the matrix was transferred
+    const bool guard = ls->algo == MNK_LDL && ls->bk_requested && ls->bk_fallback && ls->retransfer && ls->amax_dev.p != nullptr;
     if (ls->algo == MNK_LDL) {
         const int blocks = (int)std::min<int64_t>(256, (ls->N + 255) / 256);
-        hipLaunchKernelGGL(inertia_kernel, dim3(blocks), dim3(256), 0, s, ls->dvec.p, ls->N, ls->inertia_dev.p);
+        hipLaunchKernelGGL(inertia_kernel, dim3(blocks), dim3(256), 0, s, ls->dvec.p, ls->N, ls->inertia_dev.p,
+                           guard ? ls->amax_dev.p + 1 : (unsigned long long*)nullptr);
     }
-    hipLaunchKernelGGL(publish_info_kernel, dim3(1), dim3(64), 0, s, ls->inertia_dev.p, ls->info_dev.p, ls->pin_dev);
+    hipLaunchKernelGGL(publish_info_kernel, dim3(1), dim3(64), 0, s, ls->inertia_dev.p, ls->info_dev.p, ls->pin_dev,
+                       guard ? ls->amax_dev.p : (const unsigned long long*)nullptr);
     MNK_HIP(hipGetLastError());
     MNK_HIP(mnk::stream_wait(s));
     volatile unsigned long long* pw = ls->pin;
     unsigned long long h[3] = {pw[0], pw[1], pw[2]};
     int hinfo = (int)(long long)pw[3];
+    if (guard) {
+        double am, dm;
+        const unsigned long long wa = pw[4], wd = pw[5];
+        memcpy(&am, &wa, sizeof am);
+        memcpy(&dm, &wd, sizeof dm);
+        ls->last_growth = am > 0.0 ? dm / am : (dm > 0.0 ? HUGE_VAL : 0.0);
+        ls->last_sign_changes = (int64_t)pw[6];
+    }
     if (hinfo == -7 && ls->algo_now >= 4 && ls->retransfer) {
         // the persistent panel kernel gave up on a dependency (CUs shared with another process' persistent kernels):
         // factor again with one launch per panel piece, and stay there
@@ -1391,9 +1448,13 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         ls->nzero = (int64_t)h[1];
         ls->nneg = (int64_t)h[2];
         if (ls->nzero > 0 && ls->info == 0) ls->info = 1;  // LAPACK-style "singular D" signal
-        if (ls->nzero > 0 && ls->bk_requested && ls->bk_fallback && ls->retransfer) {
-            // the static-pivot factorization broke down on a matrix that is not quasi-definite in the given order:
-            // BUNCHKAUFMAN means dsytrf semantics, so factor it again with 1x1 / 2x2 pivoting
+        // (pivots that are all positive and then all negative: a positive definite leading block and a negative definite Schur
+        // complement, the quasi-definite structure of the KKT systems, whose growth |J|^2 / lambda_min(H) is in the data)
+        const double gtol = ls->last_sign_changes <= 1 ? ls->bk_growth_tol_qd : ls->bk_growth_tol;
+        if ((ls->nzero > 0 || (guard && !(ls->last_growth <= gtol))) && ls->bk_requested && ls->bk_fallback && ls->retransfer) {
+            // the static-pivot factorization broke down (a zero pivot) or grew (tiny pivots: the Schur complements left the
+            // scale of the matrix) on a matrix that is not quasi-definite in the given order: BUNCHKAUFMAN means dsytrf
+            // semantics, so factor it again with 1x1 / 2x2 pivoting
             int rc = bk_fallback(ls);
             if (rc) return rc;
             return mnk_ls_fetch_info(ls);

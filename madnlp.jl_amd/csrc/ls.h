@@ -82,11 +82,23 @@ struct mnk_ls {
     mnk::DevBuf<unsigned long long> solve_trace;  // diagnostics: 8 time stamps per 64-row block (option solve_trace)
     mnk::DevBuf<int> info_dev;
     mnk::DevBuf<unsigned long long> inertia_dev;
-    unsigned long long* pin = nullptr;  // 4 pinned, device-mapped host words: inertia counters + info are stored here by a kernel
+    unsigned long long* pin = nullptr;  // 7 pinned, device-mapped host words: inertia counters, info, max|A|, growth numerator (bit patterns), sign changes are stored here by a kernel
     unsigned long long* pin_dev = nullptr;  // the same words as the device sees them
     // Bunch-Kaufman tier (bk.hip): taken when BUNCHKAUFMAN was requested and the static-pivot factorization broke down
     bool bk_requested = false;   // mnk_ls_create was called with MNK_BUNCHKAUFMAN (MNK_LDL: static pivoting only)
     int bk_fallback = 1;         // option: 0 = never take the pivoted tier (a breakdown is reported as num_zero)
+    // Growth guard of the static-pivot tier (BUNCHKAUFMAN only).  The pivots are entries of the successive Schur complements,
+    // so max|d_k| / max|a_ij| is a lower bound of the element growth of the elimination; dsytrf's pivoting bounds the growth,
+    // static pivoting does not on a matrix that is not quasi-definite (a pivot of 1e-14 is "not zero" and the next Schur
+    // complement is 1e14 times the matrix).  Above bk_growth_tol the factor is discarded and the pivoted tier takes over.
+    // SPD matrices never trip it (growth <= 1).  Matrices whose pivots come out "all positive, then all negative" have a
+    // positive definite leading block and a negative definite Schur complement -- the quasi-definite structure of the KKT
+    // systems, for which the unpivoted factorization is the intended one and whose growth |J|^2 / lambda_min(H) is a property
+    // of the data, not of the pivot order: they get the lenient bound bk_growth_tol_qd.
+    double bk_growth_tol = 64.0, bk_growth_tol_qd = 1e8;
+    double last_growth = 0.0;    // max(|d_k|, |v_ik|) / max|a_ij| of the last static-pivot factorization (diagnostics, tests)
+    int64_t last_sign_changes = 0;
+    mnk::DevBuf<unsigned long long> amax_dev;  // [0] max|a_ij| as transferred, [1] max(|d_k|, |v_ik|) (bit patterns), [2] sign changes of the pivots
     bool bk_active = false;      // the current factor is P A P^T = L D L^T with 2x2 blocks (solves use perm / dcoup)
     int bk_count = 0;            // how many factorizations took the pivoted tier (diagnostics, tests)
     std::function<int()> retransfer;  // puts the matrix of the last factorize! call back into `fact`

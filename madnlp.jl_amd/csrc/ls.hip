@@ -7,6 +7,7 @@
 #include <atomic>
 #include <mutex>
 
+#include <cfloat>
 #include "ls.h"
 
 namespace mnk {
@@ -38,24 +39,45 @@ __global__ __launch_bounds__(256) void fill_lower_kernel(double* __restrict__ F,
 }
 
 // aug_com (lower CSC) -> dense: one thread per stored entry (coordinates precomputed).
+// max |v| over the wave -> one atomicMax on the bit pattern (non-negative doubles order like unsigned integers; NaN -> +Inf)
+__device__ __forceinline__ void wave_absmax_to(unsigned long long* word, double v) {
+    double a = fabs(v);
+    if (!(a <= DBL_MAX)) a = __longlong_as_double(0x7ff0000000000000LL);
+    for (int off = 32; off > 0; off >>= 1) a = fmax(a, __shfl_xor(a, off));
+    if ((threadIdx.x & 63) == 0 && a > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(a));
+}
+
+// (`amax`: optional, max|a_ij| of what is transferred -- the growth guard of BUNCHKAUFMAN's static-pivot tier)
 __global__ void scatter_csc_kernel(double* __restrict__ F, int64_t ld, const int32_t* __restrict__ row,
-                                   const int32_t* __restrict__ col, const double* __restrict__ nz, int64_t nnz) {
+                                   const int32_t* __restrict__ col, const double* __restrict__ nz, int64_t nnz,
+                                   unsigned long long* __restrict__ amax) {
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (k < nnz) F[row[k] + (int64_t)col[k] * ld] = nz[k];
+    double v = 0.0;
+    if (k < nnz) {
+        v = nz[k];
+        F[row[k] + (int64_t)col[k] * ld] = v;
+    }
+    if (amax != nullptr) wave_absmax_to(amax, v);
 }
 
 // dense source -> factor buffer, rows >= first row of the diagonal tile of each column.
 __global__ __launch_bounds__(256) void copy_lower_kernel(double* __restrict__ F, int64_t ld,
                                                          const double* __restrict__ A, int64_t lda, int64_t N,
-                                                         int64_t Np) {
+                                                         int64_t Np, unsigned long long* __restrict__ amax) {
     const int64_t col = blockIdx.x;
     const int64_t first = (col / PAD) * PAD;
     const int64_t r = first + (int64_t)blockIdx.y * 256 + threadIdx.x;
-    if (r >= Np) return;
-    double v = 0.0;
-    if (col < N && r < N) v = A[r + col * lda];
-    else if (r == col) v = 1.0;
-    F[r + col * ld] = v;
+    double v = 0.0, vl = 0.0;
+    if (r < Np) {
+        if (col < N && r < N) {
+            v = A[r + col * lda];
+            if (r >= col) vl = v;  // the lower triangle is the matrix ('L' storage: the rest may hold anything)
+        } else if (r == col) {
+            v = 1.0;
+        }
+        F[r + col * ld] = v;
+    }
+    if (amax != nullptr) wave_absmax_to(amax, vl);
 }
 
 __global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t N, int64_t Np) {
@@ -291,7 +313,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     } else {
         *ls->solve_abort = 0;
     }
-    if (hipHostMalloc((void**)&ls->pin, 4 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&ls->pin, 8 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void**)&ls->pin_dev, ls->pin, 0) != hipSuccess) {
         (void)hipGetLastError();
         rc |= -2;
@@ -359,6 +381,17 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
+    // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
+    if (!strcmp(key, "bk_growth_tol")) {
+        MNK_REQUIRE(value > 1.0, "bk_growth_tol must be > 1");
+        ls->bk_growth_tol = value;
+        return 0;
+    }
+    if (!strcmp(key, "bk_growth_tol_qd")) {  // the same for pivot sequences "all positive, then all negative"
+        MNK_REQUIRE(value > 1.0, "bk_growth_tol_qd must be > 1");
+        ls->bk_growth_tol_qd = value;
+        return 0;
+    }
     if (!strcmp(key, "persistent_solve")) { ls->persistent_solve = value != 0.0; return 0; }
     if (!strcmp(key, "ps_spin_limit")) {  // polls a persistent-solve wait may take before it gives up
         MNK_REQUIRE(value >= 1024.0, "ps_spin_limit must be at least 1024");
@@ -392,6 +425,14 @@ static int ensure_wbuf(mnk_ls* ls) {
     return rc;
 }
 
+// The word that receives max|a_ij| of the matrix being transferred (zeroed here), or NULL when nobody will ask for it.
+static unsigned long long* amax_word(mnk_ls* ls) {
+    if (!(ls->bk_requested && ls->bk_fallback && ls->algo == MNK_LDL)) return nullptr;
+    if (!ls->amax_dev.p && ls->amax_dev.alloc(4)) return nullptr;
+    (void)hipMemsetAsync(ls->amax_dev.p, 0, 4 * sizeof(unsigned long long), ls->ctx->stream);
+    return ls->amax_dev.p;
+}
+
 static int prepare_fill(mnk_ls* ls) {
     hipStream_t s = ls->ctx->stream;
     dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np / 2 + 255) / 256));
@@ -405,7 +446,7 @@ static int transfer_sc(mnk_ls* ls, mnk_sc* sc) {
     if (rc) return rc;
     const int64_t nnz = sc->nnz_aug;
     hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
-                       ls->fact.p, ls->ld, sc->aug_row.p, sc->aug_col.p, sc->aug_nz.p, nnz);
+                       ls->fact.p, ls->ld, sc->aug_row.p, sc->aug_col.p, sc->aug_nz.p, nnz, amax_word(ls));
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -427,7 +468,7 @@ int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
 static int transfer_dense(mnk_ls* ls, const double* Adev, int64_t lda) {
     dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np + 255) / 256));
     hipLaunchKernelGGL(copy_lower_kernel, grid, dim3(256), 0, ls->ctx->stream, ls->fact.p, ls->ld, Adev, lda,
-                       ls->N, ls->Np);
+                       ls->N, ls->Np, amax_word(ls));
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -516,7 +557,7 @@ int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowva
         if (r) return r;
         if (nnz > 0)
             hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
-                               ls->fact.p, ls->ld, drow.p, dcol.p, dnz.p, nnz);
+                               ls->fact.p, ls->ld, drow.p, dcol.p, dnz.p, nnz, amax_word(ls));
         MNK_HIP(hipGetLastError());
         return 0;
     };
@@ -642,6 +683,7 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     }
     if (!strcmp(key, "panel_algo")) { *value = ls->algo_now; return 0; }
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
+    if (!strcmp(key, "growth")) { *value = ls->last_growth; return 0; }  // BUNCHKAUFMAN: max|d_k| / max|a_ij| of the static-pivot tier
     if (!strcmp(key, "dag_ntasks")) { *value = ls->dag_ntasks; return 0; }    // task-DAG schedule: bulk tasks, ...
     if (!strcmp(key, "dag_ntasks1")) { *value = ls->dag_ntasks1; return 0; }  // ... of them in the first phase, ...
     if (!strcmp(key, "dag_js2")) { *value = ls->dag_js2; return 0; }          // ... first strip-column of the second phase
