@@ -34,7 +34,8 @@ def _stale() -> bool:
 # than 256 registers per lane, and with the flag the accumulators are pinned to the 256 architectural VGPRs and the rest
 # is shuffled through AGPRs -- hipcc 7.2 then miscompiles it (wrong pivots / memory faults that appear and disappear with
 # unrelated, never-executed code; bisected in round 2).
-FILE_FLAGS = {"gemm_f64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dag.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FILE_FLAGS = {"gemm_f64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dag.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+              "bk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -103,7 +103,7 @@ struct mnk_ls {
     int bk_count = 0;            // how many factorizations took the pivoted tier (diagnostics, tests)
     std::function<int()> retransfer;  // puts the matrix of the last factorize! call back into `fact`
     mnk::DevBuf<int> bk_perm, bk_ptype;
-    mnk::DevBuf<double> bk_doff, bk_dcoup;
+    mnk::DevBuf<double> bk_doff, bk_dcoup, bk_work;  // (bk_work: the panel's W = L D and its zero-padded copy of L, 2 x Np x 72)
     mnk::DevBuf<char> bk_state;
     bool factorized = false, info_valid = false;
     int info = 0;
