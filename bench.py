@@ -170,15 +170,18 @@ def gather_stats(vec, dist, world, device_tensor_fn):
 
 
 # ---------------------------------------------------------------------------- supplementary end-to-end IPM run
-def ipm_loop(args, ctx):
-    """IPM regular phase with every vector in HBM on the OPF-shaped convex QP of `args.case` (N = 11192 for the default):
-    iterations, factorizations, back-solves and wall clock of the second (warm) of two runs."""
+def ipm_loop(args, ctx, model="acopf"):
+    """Full interior-point run with every vector AND the model's callbacks in HBM (`DeviceMadNLPSolver`): iterations,
+    factorizations, back-solves and wall clock of the second (warm) of two runs.  model = "acopf": the polar AC-OPF NLP on
+    the synthetic grid of `args.case` (callbacks: csrc/opf_eval.hip; nonconvex, so inertia corrections refactorize);
+    "qp": the convex QP with the same sparsity (callbacks: SpMV on the KKT handle's compressed matrices)."""
     import torch
     import madnlp_jl_amd as mj
     from madnlp_jl_amd.ipm import IPMOptions
     from madnlp_jl_amd.ipm_dev import DeviceMadNLPSolver
-    from madnlp_jl_amd.problems import SparseQPModel
-    nlp = SparseQPModel(args.case)
+    from madnlp_jl_amd.problems import ACOPFModel, SparseQPModel
+    nlp = ACOPFModel(args.case) if model == "acopf" else SparseQPModel(args.case)
+    what = ("polar AC-OPF NLP on the synthetic grid" if model == "acopf" else "convex QP with the sparsity")
 
     def factory(info):
         return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J,
@@ -198,10 +201,11 @@ def ipm_loop(args, ctx):
         s.solve()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        rec = {"problem": f"convex QP with the sparsity of {args.case} (n={nlp.n}, m={nlp.m}), all vectors device-resident",
-               "status": s.status, "iterations": s.cnt.k, "factorizations": s.cnt.factorization_cnt,
+        rec = {"problem": f"{what} of {args.case} (n={nlp.n}, m={nlp.m}), vectors and callbacks device-resident",
+               "status": s.status, "objective": s.obj_val, "iterations": s.cnt.k, "factorizations": s.cnt.factorization_cnt,
                "backsolves": s.cnt.backsolve_cnt, "wall_s": wall, "ms_per_iteration": 1e3 * wall / max(1, s.cnt.k),
                "it_per_s": s.cnt.k / wall}
+        s.cb.close()
         s.K.close()
         s.kkt.close()
     return rec
@@ -539,11 +543,13 @@ def main():
                          "schedule_panel_algo": schedule},
         }
         if not args.no_ipm_loop and world == 1 and args.batch == 1:
-            # Supplementary, OUTSIDE the timed region: a complete IPM regular phase with device-resident vectors on a
-            # convex QP of the same shape (madnlp_jl_amd.ipm_dev) -- real inertia corrections, refinement and line search
-            # around the same hot path; `value` above stays the contract's synthetic step.
+            # Supplementary, OUTSIDE the timed region: complete IPM runs with device-resident vectors and callbacks
+            # (madnlp_jl_amd.ipm_dev) -- the AC-OPF NLP of the same grid, and the convex QP of the same shape: real inertia
+            # corrections, refinement and line search around the same hot path; `value` above stays the contract's
+            # synthetic step.
             try:
-                out["end_to_end_ipm"] = ipm_loop(args, ctx)
+                out["end_to_end_ipm"] = ipm_loop(args, ctx, "acopf")
+                out["end_to_end_ipm_qp"] = ipm_loop(args, ctx, "qp")
             except Exception as e:  # never let the supplement break the bench line
                 out["end_to_end_ipm"] = {"error": repr(e)[:300]}
         if not args.no_c4 and world == 1 and args.batch == 1:

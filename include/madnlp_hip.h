@@ -390,6 +390,48 @@ int mnk_dc_set_aug_RR(mnk_dc* dc, const double* x, const double* xl, const doubl
                       const double* D_R, const double* pp, const double* zp, const double* nn, const double* zn, double zeta,
                       double primal_reg, double dual_reg);
 
+/* ---- plain vector work of the solver loop on device vectors (callback half) ----------------------------
+ * The copyto! / fill! / axpy! / dot / norm calls the reference's regular! / restore! / robust! loops make on the iterate
+ * (src/IPM/solver.jl:236-291, :300-411, :413-545; src/IPM/line_search.jl:60-64, :170-176), the Richardson loop's axpy! and
+ * norms (src/LinearSolvers/backsolve.jl:27-76) and the products a dense QP model's callbacks need.  Asynchronous on the
+ * context's stream; mnk_ipm_get_* follow the batch protocol above.
+ *   mnk_ipm_get_dot / _get_sum / _get_norm2     dot(x, y), sum(v), norm(v, 2)
+ *   mnk_ipm_vec_copy / _fill / _axpby           copyto!, fill!, out = a x + b y (y = NULL: out = a x; aliasing allowed)
+ *   mnk_ipm_vec_scatter_axpy / _gather          y[idx] .+= a .* x ;  out .= a .* x[idx]   (idx: device, 0-based)
+ *   mnk_ipm_bound_dual_axpy / _fill             zl_r .+= a dzl, zu_r .+= a dzu ;  zl_r .= v, zu_r .= v
+ *   mnk_ipm_gemv                                y = alpha op(A) x + beta y, A column-major m x n */
+int mnk_ipm_get_dot(mnk_ipm* ipm, const double* x, const double* y, int64_t n, double* out);
+int mnk_ipm_get_sum(mnk_ipm* ipm, const double* v, int64_t n, double* out);
+int mnk_ipm_get_norm2(mnk_ipm* ipm, const double* v, int64_t n, double* out);
+int mnk_ipm_vec_copy(mnk_ipm* ipm, double* dst, const double* src, int64_t n);
+int mnk_ipm_vec_fill(mnk_ipm* ipm, double* v, int64_t n, double value);
+int mnk_ipm_vec_axpby(mnk_ipm* ipm, double* out, double a, const double* x, double b, const double* y, int64_t n);
+int mnk_ipm_vec_scatter_axpy(mnk_ipm* ipm, double* y, const int64_t* idx, double a, const double* x, int64_t n);
+int mnk_ipm_vec_gather(mnk_ipm* ipm, double* out, double a, const double* x, const int64_t* idx, int64_t n);
+int mnk_ipm_bound_dual_axpy(mnk_ipm* ipm, double* zl, double* zu, double a, const double* dzl, const double* dzu);
+int mnk_ipm_bound_dual_fill(mnk_ipm* ipm, double* zl, double* zu, double v);
+int mnk_ipm_gemv(mnk_ipm* ipm, int trans, int64_t m, int64_t n, double alpha, const double* A, int64_t lda, const double* x,
+                 double beta, double* y);
+
+/* ---- device evaluation of an NLP model's callbacks: polar AC optimal power flow (callback half) --------
+ * What eval_f_wrapper / eval_grad_f_wrapper! / eval_cons_wrapper! / eval_jac_wrapper! / eval_lag_hess_wrapper!
+ * (reference src/IPM/callbacks.jl:1-96) obtain from the model through NLPModels.obj / grad! / cons! / jac_coord! /
+ * hess_coord!.  The model is the polar AC-OPF the reference's GPU benchmarks solve; variable / constraint / COO order are
+ * those of `madnlp_jl_amd.problems.ACOPFModel` (see csrc/opf_eval.hip).  Index arrays are host, 0-based; arc_coef is
+ * (2 nbranch) x 6 row-major (from sides first), bus_data nbus x 4 (pd, qd, gs, bs), gen_cost ngen x 3 (c2, c1, c0).
+ * x, y and every output are device vectors; calls are asynchronous on the context's stream. */
+typedef struct mnk_opf mnk_opf;
+int mnk_opf_create(mnk_ctx* ctx, int64_t nbus, int64_t ngen, int64_t nbranch, const int32_t* fr, const int32_t* to,
+                   const int32_t* gen_bus, const double* arc_coef, const double* bus_data, const double* gen_cost,
+                   mnk_opf** out);
+int mnk_opf_destroy(mnk_opf* opf);
+int mnk_opf_sizes(mnk_opf* opf, int64_t* n, int64_t* m, int64_t* nnzj, int64_t* nnzh);
+int mnk_opf_obj_terms(mnk_opf* opf, const double* x, double* terms /* ngen; obj = sum(terms) */);
+int mnk_opf_grad(mnk_opf* opf, const double* x, double* g);
+int mnk_opf_cons(mnk_opf* opf, const double* x, double* c);
+int mnk_opf_jac_coord(mnk_opf* opf, const double* x, double* jac);
+int mnk_opf_hess_coord(mnk_opf* opf, const double* x, const double* y, double obj_weight, double* hess);
+
 /* ---- dense S stage of the Schur-complement KKT system ----------------------------------------------
  * Reference: `SchurComplementKKTSystem` src/KKT/Schur/schur.jl -- `build_kkt!` :927-1001 (phase 1: factor every
  * scenario block A_k and form A_k^-1 C_dk'; phase 2: S -= C_dk A_k^-1 C_dk'), `factorize_kkt!` :1003-1005, steps 3-5 of

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
-SOURCES = ["gemm_f64.hip", "dag.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip", "ipm_vec.hip"]
+SOURCES = ["gemm_f64.hip", "dag.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip", "ipm_vec.hip", "opf_eval.hip"]
 HEADERS = ["common.h", "ls.h", "kkt_vec.h", "gemm_tile.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
 
 MNK_HOST, MNK_DEVICE = 0, 1
@@ -165,6 +165,25 @@ SIGNATURES = {
     "mnk_ipm_set_aug_rhs_ifr": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp, _vp]),
     "mnk_ipm_set_g_ifr": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double]),
     "mnk_ipm_initialize_variables": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_double, C.c_double]),
+    "mnk_ipm_get_dot": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_sum": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_double)]),
+    "mnk_ipm_get_norm2": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_double)]),
+    "mnk_ipm_vec_copy": (C.c_int, [_vp, _vp, _vp, C.c_int64]),
+    "mnk_ipm_vec_fill": (C.c_int, [_vp, _vp, C.c_int64, C.c_double]),
+    "mnk_ipm_vec_axpby": (C.c_int, [_vp, _vp, C.c_double, _vp, C.c_double, _vp, C.c_int64]),
+    "mnk_ipm_vec_scatter_axpy": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp, C.c_int64]),
+    "mnk_ipm_vec_gather": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, C.c_int64]),
+    "mnk_ipm_bound_dual_axpy": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp, _vp]),
+    "mnk_ipm_bound_dual_fill": (C.c_int, [_vp, _vp, _vp, C.c_double]),
+    "mnk_ipm_gemv": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, C.c_double, _vp, C.c_int64, _vp, C.c_double, _vp]),
+    "mnk_opf_create": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "mnk_opf_destroy": (C.c_int, [_vp]),
+    "mnk_opf_sizes": (C.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "mnk_opf_obj_terms": (C.c_int, [_vp, _vp, _vp]),
+    "mnk_opf_grad": (C.c_int, [_vp, _vp, _vp]),
+    "mnk_opf_cons": (C.c_int, [_vp, _vp, _vp]),
+    "mnk_opf_jac_coord": (C.c_int, [_vp, _vp, _vp]),
+    "mnk_opf_hess_coord": (C.c_int, [_vp, _vp, _vp, C.c_double, _vp]),
     "mnk_sc_set_aug_RR": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double]),
     "mnk_dc_set_aug_RR": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_double]),
     "mnk_ls_bk_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, _vp]),

@@ -907,3 +907,179 @@ int mnk_ipm_initialize_variables(mnk_ipm* h, double* x, const double* xl, const 
 }
 
 }  // extern "C"
+
+// ---- plain vector work of the solver loop: the copyto! / fill! / axpy! / dot / norm / mul! calls that reference
+// src/IPM/solver.jl (:236-291 regular!, :300-411 restore!, :413-545 robust!), src/IPM/line_search.jl and
+// src/LinearSolvers/backsolve.jl:27-76 make on the iterate, and the dense products of a QP model's callbacks.  They keep
+// the whole loop on the context's stream (no second runtime in the data path).  No FMA contraction: axpby evaluates
+// a x + b y as numpy / Julia broadcast do.  HBM-bound: 8 bytes per element read / written, gemv 8 m n.
+namespace {
+struct FDot {
+    const double *x, *y;
+    __device__ double operator()(int64_t i) const { return x[i] * y[i]; }
+};
+struct FId {
+    const double* v;
+    __device__ double operator()(int64_t i) const { return v[i]; }
+};
+__global__ void vec_copy_kernel(double* __restrict__ d, const double* __restrict__ s, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) d[i] = s[i];
+}
+__global__ void vec_fill_kernel(double* __restrict__ d, double v, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) d[i] = v;
+}
+// out = a x + b y; a == 1 / b == 1 / b == 0 keep the operand exactly (x + b y, a x + y, a x); out may alias x or y
+__global__ void vec_axpby_kernel(double* out, double a, const double* x, double b, const double* y, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ax = a == 1.0 ? x[i] : a * x[i];
+    out[i] = y == nullptr ? ax : (b == 1.0 ? ax + y[i] : ax + b * y[i]);
+}
+__global__ void vec_scatter_axpy_kernel(double* __restrict__ y, const int64_t* __restrict__ idx, double a,
+                                        const double* __restrict__ x, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) y[idx[i]] += a * x[i];
+}
+__global__ void vec_scatter_fill_kernel(double* __restrict__ y, const int64_t* __restrict__ idx, double v, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) y[idx[i]] = v;
+}
+__global__ void vec_gather_kernel(double* __restrict__ out, double a, const double* __restrict__ x,
+                                  const int64_t* __restrict__ idx, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[idx[i]];
+}
+// y = alpha op(A) x + beta y, A column-major m x n.  trans = 0: one thread per row, columns walked in order (coalesced over
+// rows); trans = 1: one wavefront per column of A, lanes stride the rows, butterfly sum.
+__global__ void gemv_n_kernel(int64_t m, int64_t n, double alpha, const double* __restrict__ A, int64_t lda,
+                              const double* __restrict__ x, double beta, double* __restrict__ y) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double s = 0.0;
+    for (int64_t j = 0; j < n; ++j) s += A[i + j * lda] * x[j];
+    y[i] = beta == 0.0 ? alpha * s : alpha * s + beta * y[i];
+}
+__global__ __launch_bounds__(256) void gemv_t_kernel(int64_t m, int64_t n, double alpha, const double* __restrict__ A,
+                                                      int64_t lda, const double* __restrict__ x, double beta,
+                                                      double* __restrict__ y) {
+    const int64_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int64_t i = lane; i < m; i += 64) s += A[i + j * lda] * x[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) y[j] = beta == 0.0 ? alpha * s : alpha * s + beta * y[j];
+}
+}  // namespace
+
+extern "C" {
+
+int mnk_ipm_get_dot(mnk_ipm* h, const double* x, const double* y, int64_t n, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_dot");
+    MNK_REQUIRE(n >= 0 && (n == 0 || (x && y)), "mnk_ipm_get_dot: bad argument");
+    IPM_BASE(1);
+    int rc = enqueue<R_SUM>(h, FDot{x, y}, n, b);
+    if (rc) return rc;
+    return finish(h, b, 1, [=](const double* r) { *out = r[0]; });
+}
+
+int mnk_ipm_get_sum(mnk_ipm* h, const double* v, int64_t n, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_sum");
+    MNK_REQUIRE(n >= 0 && (n == 0 || v), "mnk_ipm_get_sum: bad argument");
+    IPM_BASE(1);
+    int rc = enqueue<R_SUM>(h, FId{v}, n, b);
+    if (rc) return rc;
+    return finish(h, b, 1, [=](const double* r) { *out = r[0]; });
+}
+
+int mnk_ipm_get_norm2(mnk_ipm* h, const double* v, int64_t n, double* out) {
+    IPM_ENTER(h, "mnk_ipm_get_norm2");
+    MNK_REQUIRE(n >= 0 && (n == 0 || v), "mnk_ipm_get_norm2: bad argument");
+    IPM_BASE(1);
+    int rc = enqueue<R_SUM>(h, FDot{v, v}, n, b);
+    if (rc) return rc;
+    return finish(h, b, 1, [=](const double* r) { *out = sqrt(r[0]); });
+}
+
+#define VEC_ENTER(cond, who)                                  \
+    MNK_REQUIRE(h != nullptr && n >= 0 && (n == 0 || (cond)), who ": bad argument"); \
+    MNK_HIP(hipSetDevice(h->ctx->device));                    \
+    if (n == 0) return 0
+
+int mnk_ipm_vec_copy(mnk_ipm* h, double* dst, const double* src, int64_t n) {
+    VEC_ENTER(dst && src, "mnk_ipm_vec_copy");
+    hipLaunchKernelGGL(vec_copy_kernel, IPM_G(n), dst, src, n);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_ipm_vec_fill(mnk_ipm* h, double* v, int64_t n, double value) {
+    VEC_ENTER(v, "mnk_ipm_vec_fill");
+    hipLaunchKernelGGL(vec_fill_kernel, IPM_G(n), v, value, n);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// out = a x + b y (y may be NULL: out = a x)
+int mnk_ipm_vec_axpby(mnk_ipm* h, double* out, double a, const double* x, double b, const double* y, int64_t n) {
+    VEC_ENTER(out && x, "mnk_ipm_vec_axpby");
+    hipLaunchKernelGGL(vec_axpby_kernel, IPM_G(n), out, a, x, b, y, n);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// y[idx[i]] += a x[i], i < n (idx: device, 0-based, distinct)
+int mnk_ipm_vec_scatter_axpy(mnk_ipm* h, double* y, const int64_t* idx, double a, const double* x, int64_t n) {
+    VEC_ENTER(y && idx && x, "mnk_ipm_vec_scatter_axpy");
+    hipLaunchKernelGGL(vec_scatter_axpy_kernel, IPM_G(n), y, idx, a, x, n);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[i] = a x[idx[i]], i < n
+int mnk_ipm_vec_gather(mnk_ipm* h, double* out, double a, const double* x, const int64_t* idx, int64_t n) {
+    VEC_ENTER(out && idx && x, "mnk_ipm_vec_gather");
+    hipLaunchKernelGGL(vec_gather_kernel, IPM_G(n), out, a, x, idx, n);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// zl_r += a dzl, zu_r += a dzu (solver.jl:282-283 axpy!(alpha_z, dual_lb(d), zl_r) ...), zl / zu full-length
+int mnk_ipm_bound_dual_axpy(mnk_ipm* h, double* zl, double* zu, double a, const double* dzl, const double* dzu) {
+    MNK_REQUIRE(h && zl && zu && (h->nlb == 0 || dzl) && (h->nub == 0 || dzu), "mnk_ipm_bound_dual_axpy: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    if (h->nlb > 0) hipLaunchKernelGGL(vec_scatter_axpy_kernel, IPM_G(h->nlb), zl, h->ind_lb.p, a, dzl, h->nlb);
+    if (h->nub > 0) hipLaunchKernelGGL(vec_scatter_axpy_kernel, IPM_G(h->nub), zu, h->ind_ub.p, a, dzu, h->nub);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// zl_r .= v, zu_r .= v (the "second chance" of filter_line_search_RR!, line_search.jl:193-196)
+int mnk_ipm_bound_dual_fill(mnk_ipm* h, double* zl, double* zu, double v) {
+    MNK_REQUIRE(h && zl && zu, "mnk_ipm_bound_dual_fill: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    if (h->nlb > 0) hipLaunchKernelGGL(vec_scatter_fill_kernel, IPM_G(h->nlb), zl, h->ind_lb.p, v, h->nlb);
+    if (h->nub > 0) hipLaunchKernelGGL(vec_scatter_fill_kernel, IPM_G(h->nub), zu, h->ind_ub.p, v, h->nub);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// y = alpha op(A) x + beta y; A: m x n column-major (lda >= m), op = A (trans = 0, y has m entries) or A' (trans = 1, n entries)
+int mnk_ipm_gemv(mnk_ipm* h, int trans, int64_t m, int64_t n, double alpha, const double* A, int64_t lda, const double* x,
+                 double beta, double* y) {
+    MNK_REQUIRE(h && m >= 0 && n >= 0 && (trans == 0 || trans == 1) && lda >= std::max<int64_t>(1, m) && y &&
+                    (m == 0 || n == 0 || (A && x)), "mnk_ipm_gemv: bad argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    if ((trans ? n : m) == 0) return 0;
+    if (trans == 0)
+        hipLaunchKernelGGL(gemv_n_kernel, IPM_G(m), m, n, alpha, A, lda, x, beta, y);
+    else
+        hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, h->ctx->stream, m, n, alpha, A, lda, x,
+                           beta, y);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

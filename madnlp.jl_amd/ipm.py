@@ -546,6 +546,12 @@ class MadNLPSolver:
 
     def _clone(self, v): return v.copy()
 
+    def _vcopy(self, dst, src): dst[:] = src         # copyto!
+
+    def _vaxpy(self, y, a, x): y += a * x            # axpy!
+
+    def _vfill(self, v, value): v[:] = value         # fill!
+
     def _theta(self, c): return float(np.abs(c).sum())
 
     def _norm_inf(self, v): return float(np.abs(v).max(initial=0.0))
@@ -741,8 +747,8 @@ class MadNLPSolver:
         while True:
             alpha_max = self.alpha_max(self._dx())
             self.alpha = min(alpha_max, self._alpha_z(self.tau))
-            self.x += self.alpha * self._dx()
-            self.y += self.alpha * self._dy()
+            self._vaxpy(self.x, self.alpha, self._dx())
+            self._vaxpy(self.y, self.alpha, self._dy())
             self._bound_dual_axpy(self.alpha)
             self.eval_cons(self.c, self.x)
             self.eval_grad(self.x)
@@ -751,9 +757,9 @@ class MadNLPSolver:
             self._jtprod()
             F_trial = self._get_F()
             if F_trial > o.soft_resto_pderror_reduction_factor * F:
-                self.x[:] = w1x
-                self.y[:] = w1y
-                self.c[:] = w2c
+                self._vcopy(self.x, w1x)
+                self._vcopy(self.y, w1y)
+                self._vcopy(self.c, w2c)
                 return "ROBUST"
             self._adjust_boundary()
             F = F_trial
@@ -837,15 +843,15 @@ class MadNLPSolver:
             st = self.filter_line_search_RR()
             if st != "LINESEARCH_SUCCEEDED":
                 return st
-            self.x[:] = self.x_trial
-            self.c[:] = self.c_trial
-            RR.pp[:] = RR.pp_trial
-            RR.nn[:] = RR.nn_trial
+            self._vcopy(self.x, self.x_trial)
+            self._vcopy(self.c, self.c_trial)
+            self._vcopy(RR.pp, RR.pp_trial)
+            self._vcopy(RR.nn, RR.nn_trial)
             RR.obj_val_R = RR.obj_val_R_trial
             self._rr_set_f()
-            self.y += self.alpha * self._dy()
-            RR.zp += self.alpha_z * RR.dzp
-            RR.zn += self.alpha_z * RR.dzn
+            self._vaxpy(self.y, self.alpha, self._dy())
+            self._vaxpy(RR.zp, self.alpha_z, RR.dzp)
+            self._vaxpy(RR.zn, self.alpha_z, RR.dzn)
             self._bound_dual_axpy(self.alpha_z)
             self._reset_bound_dual(RR.mu_R)
             self._rr_reset_slack_duals()
@@ -860,9 +866,9 @@ class MadNLPSolver:
                 self.factorize_wrapper()
                 self._solve_newton()
                 if self._norm_inf(self._dy()) > o.constr_mult_init_max:
-                    self.y[:] = 0.0
+                    self._vfill(self.y, 0.0)
                 else:
-                    self.y[:] = self._dy()
+                    self._vcopy(self.y, self._dy())
                 self.cnt.k += 1
                 self.cnt.t += 1
                 return "REGULAR"
@@ -900,12 +906,12 @@ class MadNLPSolver:
         switching = varphi_d_R < 0 and self.alpha * _pow(-varphi_d_R, o.s_phi) > o.delta * _pow(theta_R, o.s_theta)
         armijo = False
         while True:
-            self.x_trial[:] = self.x
-            self.x_trial += self.alpha * self._dx()
-            RR.pp_trial[:] = RR.pp
-            RR.pp_trial += self.alpha * RR.dpp
-            RR.nn_trial[:] = RR.nn
-            RR.nn_trial += self.alpha * RR.dnn
+            self._vcopy(self.x_trial, self.x)
+            self._vaxpy(self.x_trial, self.alpha, self._dx())
+            self._vcopy(RR.pp_trial, RR.pp)
+            self._vaxpy(RR.pp_trial, self.alpha, RR.dpp)
+            self._vcopy(RR.nn_trial, RR.nn)
+            self._vaxpy(RR.nn_trial, self.alpha, RR.dnn)
             RR.obj_val_R_trial = self._rr_obj_val(RR.pp_trial, RR.nn_trial, self.x_trial)
             self.eval_cons(self.c_trial, self.x_trial)
             theta_R_trial = self._rr_theta(self.c_trial, RR.pp_trial, RR.nn_trial)
@@ -922,7 +928,7 @@ class MadNLPSolver:
                 if self.cnt.restoration_fail_count >= 4:
                     return "RESTORATION_FAILED"
                 # the reference's "second chance": back to the regular phase from the current iterate
-                self.y[:] = 0.0
+                self._vfill(self.y, 0.0)
                 self._bound_dual_fill(1.0)
                 self.filter = [(self.theta_max, -INF)]
                 self.cnt.k += 1
@@ -980,11 +986,11 @@ class MadNLPSolver:
             st = self.filter_line_search()
             if st != "LINESEARCH_SUCCEEDED":
                 return st
-            self.x[:] = self.x_trial
-            self.c[:] = self.c_trial
+            self._vcopy(self.x, self.x_trial)
+            self._vcopy(self.c, self.c_trial)
             self.obj_val = self.obj_val_trial
             self._adjust_boundary()
-            self.y += self.alpha * self._dy()
+            self._vaxpy(self.y, self.alpha, self._dy())
             self._bound_dual_axpy(self.alpha_z)
             self._reset_bound_dual(self.mu)
             self.eval_grad(self.x)

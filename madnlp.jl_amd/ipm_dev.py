@@ -3,15 +3,19 @@ right-hand sides live in HBM; per iteration only scalars cross PCIe.  Same algor
 `madnlp_jl_amd.ipm.MadNLPSolver` (which documents the reference lines); the vector work goes through
 
   * the KKT handle:   `set_aug_diagonal!`, `regularize_diagonal!`, `build_kkt!`, `factorize!`, `solve_kkt!`, `mul!`, SpMV
-  * `mnk_ipm_*`:      the reductions and elementwise pieces of reference `src/IPM/kernels.jl`
-  * torch:            axpy-type updates and copies on the device tensors (plumbing)
+  * `mnk_ipm_*`:      the reductions and elementwise pieces of reference `src/IPM/kernels.jl`, and the loop's plain vector
+                      work (`mnk_ipm_vec_*`, `mnk_ipm_get_dot`, `mnk_ipm_gemv`)
+  * `mnk_opf_*`:      the callbacks of the polar AC-OPF model (`problems.ACOPFModel`) evaluated on the device
+  * torch:            device memory only (allocation, uploads, the final download) -- no torch kernel runs in the loop
 
 Scope: `SparseCondensedKKTSystem` (all constraints relaxed to inequalities, as the reference's preset does) and
-`DenseCondensedKKTSystem` (equalities allowed), with models whose callbacks can be evaluated on the device -- here QPs: the
-sparse one through the KKT handle's own SpMV on the compressed Jacobian / Hessian, the dense one through torch matrix-vector
-products on device copies of P and A.  Initialization runs once on the host (the base class) and is uploaded."""
+`DenseCondensedKKTSystem` (equalities allowed), with models whose callbacks can be evaluated on the device: the AC-OPF NLP
+(`DeviceOPFCallbacks`), the sparse QP through the KKT handle's own SpMV on the compressed Jacobian / Hessian, the dense QP
+through `mnk_ipm_gemv` on device copies of P and A.  Initialization runs once on the host (the base class) and is uploaded."""
 from __future__ import annotations
 
+
+import ctypes as C
 
 import numpy as np
 import torch
@@ -21,15 +25,20 @@ from .ipm import EPS, INF, IPMOptions, MadNLPSolver, _pow
 from .ipm_device import IPMDeviceKernels
 
 
+def _up(a, dev, dtype=np.float64):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
+
+
 class DeviceQPCallbacks:
     """f = 0.5 x'Hx + q'x, c = Jx with H = Symmetric(hess_com, :L) and J = jt_csc' held by the KKT handle."""
 
-    def __init__(self, nlp, kkt, dev):
-        self.kkt, self.n, self.m = kkt, nlp.n, nlp.m
-        self.q = torch.from_numpy(np.asarray(nlp.q, dtype=np.float64)).to(dev)
-        self.jv = torch.from_numpy(np.ascontiguousarray(nlp.jac_coord(None), dtype=np.float64)).to(dev)
-        self.hv = torch.from_numpy(np.ascontiguousarray(nlp.hess_coord(None, None, 1.0), dtype=np.float64)).to(dev)
-        self.hv0 = torch.zeros_like(self.hv)
+    def __init__(self, nlp, kkt, dev, K):
+        self.kkt, self.K, self.n, self.m = kkt, K, nlp.n, nlp.m
+        self.q = _up(nlp.q, dev)
+        self.jv = _up(nlp.jac_coord(None), dev)
+        self.hv = _up(nlp.hess_coord(None, None, 1.0), dev)
+        self.hv0 = torch.empty_like(self.hv)
+        K.vec_fill(self.hv0, 0.0)
         self.handle_has_H = True
         self._hx = torch.empty(self.n, dtype=torch.float64, device=dev)
 
@@ -45,11 +54,13 @@ class DeviceQPCallbacks:
 
     def obj(self, x):
         hx = self._hmul(x)
-        return float(0.5 * torch.dot(x, hx) + torch.dot(self.q, x))
+        with self.K.batch():
+            a = self.K.get_dot(x, hx)
+            b = self.K.get_dot(self.q, x)
+        return 0.5 * a[0] + b[0]
 
     def grad(self, g, x):
-        g.copy_(self._hmul(x))
-        g.add_(self.q)
+        self.K.vec_axpby(g, 1.0, self._hmul(x), 1.0, self.q)
 
     def cons(self, c, x):
         self.kkt.spmv_device(L.MNK_SC_JT, 1, 1.0, x, 0.0, c)
@@ -57,49 +68,139 @@ class DeviceQPCallbacks:
     def jtprod_x(self, out_x, y):
         self.kkt.spmv_device(L.MNK_SC_JT, 0, 1.0, y, 0.0, out_x)
 
-    def load_jac(self):
+    def load_jac(self, x=None):
         self.kkt.compress_jacobian(self.jv)
 
-    def load_hess(self, zero=False):
+    def load_hess(self, x=None, y=None, sigma=1.0):
+        zero = sigma == 0.0            # linear constraints: the Lagrangian Hessian is sigma H
         self.kkt.compress_hessian(self.hv0 if zero else self.hv)
         self.handle_has_H = not zero
+
+    def zero_hess(self):
+        self.load_hess(sigma=0.0)
+
+    def close(self):
+        pass
 
 
 class DeviceDenseQPCallbacks:
     """f = 0.5 x'Px + q'x, c = Ax with dense P, A on the device (`DenseQPModel`); Hessian / Jacobian of the KKT handle are
     loaded from these device copies (`mnk_dc_set_hess` / `mnk_dc_set_jac` with device pointers)."""
 
-    def __init__(self, nlp, kkt, dev):
-        self.kkt, self.n, self.m = kkt, nlp.n, nlp.m
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
-        self.P, self.A, self.q = t(nlp.P), t(nlp.A), t(nlp.q)
-        # column-major device images for the handle (torch is row-major: the transpose's buffer IS the column-major matrix)
-        self.P_cm = self.P.t().contiguous()
-        self.A_cm = self.A.t().contiguous()          # (n, m) row-major == (m, n) column-major
-        self.P0_cm = torch.zeros_like(self.P_cm)
+    def __init__(self, nlp, kkt, dev, K):
+        self.kkt, self.K, self.n, self.m = kkt, K, nlp.n, nlp.m
+        # column-major device images (a row-major upload of the transpose IS the column-major matrix)
+        self.P_cm = _up(np.asarray(nlp.P).T, dev)
+        self.A_cm = _up(np.asarray(nlp.A).T, dev)        # (n, m) row-major == (m, n) column-major
+        self.q = _up(nlp.q, dev)
+        self.P0_cm = torch.empty_like(self.P_cm)
+        K.vec_fill(self.P0_cm, 0.0)
         self.handle_has_H = True
+        self._px = torch.empty(self.n, dtype=torch.float64, device=dev)
+
+    def _pmul(self, x, out):
+        self.K.gemv(0, self.n, self.n, 1.0, self.P_cm, self.n, x, 0.0, out)
+        return out
 
     def obj(self, x):
-        return float(0.5 * torch.dot(x, torch.mv(self.P, x)) + torch.dot(self.q, x))
+        px = self._pmul(x, self._px)
+        with self.K.batch():
+            a = self.K.get_dot(x, px)
+            b = self.K.get_dot(self.q, x)
+        return 0.5 * a[0] + b[0]
 
     def grad(self, g, x):
-        torch.mv(self.P, x, out=g)
-        g.add_(self.q)
+        self._pmul(x, g)
+        self.K.vec_axpby(g, 1.0, g, 1.0, self.q)
 
     def cons(self, c, x):
-        torch.mv(self.A, x, out=c)
+        if self.m > 0:
+            self.K.gemv(0, self.m, self.n, 1.0, self.A_cm, self.m, x, 0.0, c)
 
     def jtprod_x(self, out_x, y):
-        torch.mv(self.A.t(), y, out=out_x)
+        if self.m > 0:
+            self.K.gemv(1, self.m, self.n, 1.0, self.A_cm, self.m, y, 0.0, out_x)
+        else:
+            self.K.vec_fill(out_x, 0.0)
 
-    def load_jac(self):
+    def load_jac(self, x=None):
         if self.m > 0:
             L.check(L.lib().mnk_dc_set_jac(self.kkt._h, self.A_cm.data_ptr(), self.m, L.MNK_DEVICE), "mnk_dc_set_jac")
 
-    def load_hess(self, zero=False):
+    def load_hess(self, x=None, y=None, sigma=1.0):
+        zero = sigma == 0.0
         src = self.P0_cm if zero else self.P_cm
         L.check(L.lib().mnk_dc_set_hess(self.kkt._h, src.data_ptr(), self.n, L.MNK_DEVICE), "mnk_dc_set_hess")
         self.handle_has_H = not zero
+
+    def zero_hess(self):
+        self.load_hess(sigma=0.0)
+
+    def close(self):
+        pass
+
+
+class DeviceOPFCallbacks:
+    """Callbacks of `problems.ACOPFModel` on the device (`mnk_opf_*`, csrc/opf_eval.hip): objective, gradient, constraints,
+    Jacobian and Lagrangian-Hessian COO values are computed from the device iterate and handed to the KKT handle's
+    compressors without leaving HBM (reference `eval_*_wrapper!`, src/IPM/callbacks.jl:1-96, with a device model)."""
+
+    def __init__(self, nlp, kkt, dev, K):
+        self.kkt, self.K, self.n, self.m = kkt, K, nlp.n, nlp.m
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)   # noqa: E731
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        fr, to, gb, coef, bus, cost = i32(nlp.fr), i32(nlp.to), i32(nlp.gen_bus), f64(nlp.arc_coef), f64(nlp.bus_data), f64(nlp.gen_cost)
+        self._h = C.c_void_p()
+        L.check(L.lib().mnk_opf_create(K.ctx.handle, nlp.nbus, nlp.ngen, nlp.nbr, fr.ctypes.data, to.ctypes.data, gb.ctypes.data,
+                                       coef.ctypes.data, bus.ctypes.data, cost.ctypes.data, C.byref(self._h)), "mnk_opf_create")
+        sz = [C.c_int64() for _ in range(4)]
+        L.check(L.lib().mnk_opf_sizes(self._h, *[C.byref(v) for v in sz]), "mnk_opf_sizes")
+        assert (sz[0].value, sz[1].value, sz[2].value, sz[3].value) == (nlp.n, nlp.m, len(nlp.jac_I), len(nlp.hess_I))
+        E = lambda k: torch.empty(k, dtype=torch.float64, device=dev)  # noqa: E731
+        self.jv, self.hv, self.hv0, self.terms = E(len(nlp.jac_I)), E(len(nlp.hess_I)), E(len(nlp.hess_I)), E(nlp.ngen)
+        K.vec_fill(self.hv0, 0.0)
+
+    def obj(self, x):
+        L.check(L.lib().mnk_opf_obj_terms(self._h, x.data_ptr(), self.terms.data_ptr()), "mnk_opf_obj_terms")
+        return self.K.get_sum(self.terms)
+
+    def grad(self, g, x):
+        L.check(L.lib().mnk_opf_grad(self._h, x.data_ptr(), g.data_ptr()), "mnk_opf_grad")
+
+    def cons(self, c, x):
+        L.check(L.lib().mnk_opf_cons(self._h, x.data_ptr(), c.data_ptr()), "mnk_opf_cons")
+
+    def jac_coord(self, x):
+        L.check(L.lib().mnk_opf_jac_coord(self._h, x.data_ptr(), self.jv.data_ptr()), "mnk_opf_jac_coord")
+        return self.jv
+
+    def hess_coord(self, x, y, sigma=1.0):
+        L.check(L.lib().mnk_opf_hess_coord(self._h, x.data_ptr(), y.data_ptr(), float(sigma), self.hv.data_ptr()),
+                "mnk_opf_hess_coord")
+        return self.hv
+
+    def jtprod_x(self, out_x, y):
+        self.kkt.spmv_device(L.MNK_SC_JT, 0, 1.0, y, 0.0, out_x)
+
+    def load_jac(self, x):
+        self.kkt.compress_jacobian(self.jac_coord(x))
+
+    def load_hess(self, x, y, sigma=1.0):
+        self.kkt.compress_hessian(self.hess_coord(x, y, sigma))
+
+    def zero_hess(self):
+        self.kkt.compress_hessian(self.hv0)
+
+    def close(self):
+        if self._h:
+            L.lib().mnk_opf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceMadNLPSolver(MadNLPSolver):
@@ -111,26 +212,28 @@ class DeviceMadNLPSolver(MadNLPSolver):
 
     # ------------------------------------------------------------------ host initialization, then upload
     def _upload(self):
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.dev)  # noqa: E731
+        ctx = self.kkt.linear_solver.ctx
         for name in ("x", "xl", "xu", "zl", "zu", "f", "y", "c", "rhs", "jacl", "x_trial", "c_trial"):
-            setattr(self, name, t(getattr(self, name)))
+            setattr(self, name, _up(getattr(self, name), self.dev))
         nt, m, nlb, nub = self.n + self.ns, self.m, len(self.ind_lb), len(self.ind_ub)
         self.nt = nt
         self._lw = nt + m + nlb + nub
-        V = lambda: torch.zeros(self._lw, dtype=torch.float64, device=self.dev)  # noqa: E731
-        self.dv, self.pv, self.w1v, self.w4v = V(), V(), V(), V()
-        self.K = IPMDeviceKernels(nt, self.ind_lb, self.ind_ub, ctx=self.kkt.linear_solver.ctx)
+        self.K = IPMDeviceKernels(nt, self.ind_lb, self.ind_ub, ctx=ctx)
         self.K.set_perturbation_sets(self.ind_llb, self.ind_uub)
-        self.cb = (DeviceQPCallbacks if self.sparse else DeviceDenseQPCallbacks)(self.nlp, self.kkt, self.dev)
-        self.ind_lb_t = torch.from_numpy(np.asarray(self.ind_lb, dtype=np.int64)).to(self.dev)
-        self.ind_ub_t = torch.from_numpy(np.asarray(self.ind_ub, dtype=np.int64)).to(self.dev)
-        self.ind_ineq_t = torch.from_numpy(np.asarray(self.ind_ineq, dtype=np.int64)).to(self.dev)
+        self.dv, self.pv, self.w1v, self.w4v = (self._new_vec(self._lw) for _ in range(4))
+        if hasattr(self.nlp, "arc_coef"):
+            assert self.sparse, "the AC-OPF callbacks feed the sparse condensed handle"
+            cls = DeviceOPFCallbacks
+        else:
+            cls = DeviceQPCallbacks if self.sparse else DeviceDenseQPCallbacks
+        self.cb = cls(self.nlp, self.kkt, self.dev, self.K)
+        self.ind_ineq_t = _up(self.ind_ineq, self.dev, np.int64)
         self.kkt.device_kkt_ops = True
         if not self.sparse:          # the dense handle reads Hessian / Jacobian from its own device copies
             self.cb.load_jac()
             self.cb.load_hess()
         self._on_device = True
-        self._sync = self.kkt.linear_solver.ctx.synchronize if hasattr(self.kkt.linear_solver.ctx, "synchronize") else None
+        self._sync = ctx.synchronize
 
     # slices of a KKT vector (reference src/KKT/rhs.jl:90-150)
     def _primal(self, v): return v[:self.nt]
@@ -148,35 +251,35 @@ class DeviceMadNLPSolver(MadNLPSolver):
         if not self._on_device:
             return super().eval_grad(x)
         self.cb.grad(self.f[:self.n], x[:self.n])
-        self.f[self.n:] = 0.0
+        self.K.vec_fill(self.f[self.n:], 0.0)
 
     def eval_cons(self, c, x):
         if not self._on_device:
             return super().eval_cons(c, x)
         self.cb.cons(c, x[:self.n])
         if self.ns == self.m:
-            c.sub_(x[self.n:])      # ind_ineq = all constraints, in order
+            self.K.vec_axpby(c, 1.0, c, -1.0, x[self.n:])      # ind_ineq = all constraints, in order
         else:
-            c[self.ind_ineq_t] -= x[self.n:]
-        c.sub_(self.rhs)
+            self.K.vec_scatter_axpy(c, self.ind_ineq_t, -1.0, x[self.n:])
+        self.K.vec_axpby(c, 1.0, c, -1.0, self.rhs)
 
     def eval_jac(self, x):
         if not self._on_device:
             return super().eval_jac(x)
-        self.cb.load_jac()
+        self.cb.load_jac(x[:self.n])
 
     def eval_lag_hess(self, x, y, is_resto=False):
         if not self._on_device:
             return super().eval_lag_hess(x, y, is_resto)
-        self.cb.load_hess(zero=is_resto)   # objective weight 0 in robust!
+        self.cb.load_hess(x[:self.n], y, 0.0 if is_resto else 1.0)   # objective weight 0 in robust!
 
     def jtprod(self, out, y):
         """`jtprod!` reference src/KKT/Sparse/condensed.jl:150-156."""
         self.cb.jtprod_x(out[:self.n], y)
         if self.ns == self.m:
-            torch.neg(y, out=out[self.n:])
+            self.K.vec_axpby(out[self.n:], -1.0, y)
         else:
-            torch.neg(y[self.ind_ineq_t], out=out[self.n:])
+            self.K.vec_gather(out[self.n:], -1.0, y, self.ind_ineq_t)
 
     # ------------------------------------------------------------------ factorization glue
     def factorize_wrapper(self):
@@ -188,21 +291,34 @@ class DeviceMadNLPSolver(MadNLPSolver):
 
     def solve_refine(self, x, b, w):
         """Richardson refinement (reference src/LinearSolvers/backsolve.jl:27-76) on device vectors."""
+        from .linear_solver import SolveException
+        try:
+            ok = self._solve_refine(x, b, w)
+            self.kkt.linear_solver.check_solve()   # the stream is idle here (the norms synchronized)
+        except SolveException:
+            # a one-launch solve gave up (its workgroups were not co-resident): the solver has switched to the stepwise
+            # solve; the refinement is repeated from the right-hand side
+            ok = self._solve_refine(x, b, w)
+            self.kkt.linear_solver.check_solve()
+        return ok
+
+    def _solve_refine(self, x, b, w):
         it = self.iterator
         norm_b = self.K.get_norms(b)[0]
         residual_ratio = 0.0
-        x.zero_()
+        K = self.K
+        K.vec_fill(x, 0.0)
         it.ir = 0
         if norm_b != 0:
-            w.copy_(b)
+            K.vec_copy(w, b)
             while True:
                 self.kkt.solve_kkt_device(w)
-                x.add_(w)
-                w.copy_(b)
+                K.vec_axpby(x, 1.0, x, 1.0, w)
+                K.vec_copy(w, b)
                 self.kkt.mul_device(w, x, -1.0, 1.0)
-                with self.K.batch():
-                    b_w = self.K.get_norms(w)
-                    b_x = self.K.get_norms(x)
+                with K.batch():
+                    b_w = K.get_norms(w)
+                    b_x = K.get_norms(x)
                 norm_w, norm_x = b_w[0], b_x[0]
                 residual_ratio = norm_w / (min(norm_x, 1e6 * norm_b) + norm_b)
                 it.ir += 1
@@ -297,7 +413,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         theta_trial = varphi_trial = 0.0
         norm_dx = None
         while True:
-            torch.add(self.x, dx, alpha=self.alpha, out=self.x_trial)
+            K.vec_axpby(self.x_trial, 1.0, self.x, self.alpha, dx)
             self.obj_val_trial = self.eval_f(self.x_trial)
             self.eval_cons(self.c_trial, self.x_trial)
             with K.batch():
@@ -322,7 +438,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
                 self.cnt.k += 1
                 return "RESTORE"
             if norm_dx is None:
-                norm_dx = float(torch.linalg.vector_norm(dx))
+                norm_dx = K.get_norm2(dx)
             if self.alpha * norm_dx < EPS * 10:
                 return "SEARCH_DIRECTION_BECOMES_TOO_SMALL"
         if unsuccessful:
@@ -342,14 +458,14 @@ class DeviceMadNLPSolver(MadNLPSolver):
         o, K = self.opt, self.K
         w1 = self.w1v
         wy = self._dual(w1)
-        torch.add(self.c_trial, self.c, alpha=alpha_max, out=wy)
+        K.vec_axpby(wy, 1.0, self.c_trial, alpha_max, self.c)
         theta_soc_old = theta_trial
         for _ in range(o.max_soc):
             self.set_aug_rhs(wy)
             self.solve_refine_wrapper(w1, self.pv, self.w4v)
             wx = self._primal(w1)
             alpha_soc = self.alpha_max(wx)
-            torch.add(self.x, wx, alpha=alpha_soc, out=self.x_trial)
+            K.vec_axpby(self.x_trial, 1.0, self.x, alpha_soc, wx)
             self.eval_cons(self.c_trial, self.x_trial)
             self.obj_val_trial = self.eval_f(self.x_trial)
             theta_soc = K.get_norms(self.c_trial)[1]
@@ -378,9 +494,21 @@ class DeviceMadNLPSolver(MadNLPSolver):
     def _dzl(self): return self._dual_lb(self.dv)
     def _dzu(self): return self._dual_ub(self.dv)
 
-    def _new_vec(self, n): return torch.zeros(n, dtype=torch.float64, device=self.dev)
+    def _new_vec(self, n):
+        v = torch.empty(n, dtype=torch.float64, device=self.dev)
+        self.K.vec_fill(v, 0.0)
+        return v
 
-    def _clone(self, v): return v.clone()
+    def _clone(self, v):
+        w = torch.empty_like(v)
+        self.K.vec_copy(w, v)
+        return w
+
+    def _vcopy(self, dst, src): self.K.vec_copy(dst, src)
+
+    def _vaxpy(self, y, a, x): self.K.vec_axpby(y, 1.0, y, a, x)
+
+    def _vfill(self, v, value): self.K.vec_fill(v, value)
 
     def _theta(self, c): return self.K.get_norms(c)[1]
 
@@ -405,13 +533,9 @@ class DeviceMadNLPSolver(MadNLPSolver):
 
     def _alpha_z(self, tau): return self.K.get_alpha_z(self.zl, self.zu, self._dzl(), self._dzu(), tau)
 
-    def _bound_dual_axpy(self, a):
-        self.zl[self.ind_lb_t] += a * self._dzl()
-        self.zu[self.ind_ub_t] += a * self._dzu()
+    def _bound_dual_axpy(self, a): self.K.bound_dual_axpy(self.zl, self.zu, a, self._dzl(), self._dzu())
 
-    def _bound_dual_fill(self, v):
-        self.zl[self.ind_lb_t] = v
-        self.zu[self.ind_ub_t] = v
+    def _bound_dual_fill(self, v): self.K.bound_dual_fill(self.zl, self.zu, v)
 
     def _adjust_boundary(self): self.K.adjust_boundary(self.x, self.xl, self.xu, self.mu)
 
@@ -430,7 +554,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         reg = pr_diag = 1, du_diag = 0, l_diag = u_diag = 1, l_lower = u_lower = 0 through the feeder (x = 0, xl = 1,
         xu = -1, zl = zu = 0, primal_reg = 1)."""
         self.kkt.initialize()
-        self.cb.load_hess(zero=True)
+        self.cb.zero_hess()
         nt = self.nt
         z = np.zeros(nt)
         self.kkt.set_aug_diagonal_device(z, np.ones(nt), -np.ones(nt), z, z, 1.0, 0.0)
@@ -443,8 +567,8 @@ class DeviceMadNLPSolver(MadNLPSolver):
     # robust restorer (`mnk_ipm_*_R`)
     def _rr_init_vectors(self, RR, mu_R, rho):
         self.K.initialize_robust_restorer(self.x, self.c, mu_R, rho, RR.x_ref, RR.D_R, RR.nn, RR.pp, RR.zp, RR.zn, self.zl, self.zu)
-        RR.f_R.zero_()
-        self.y.zero_()
+        self.K.vec_fill(RR.f_R, 0.0)
+        self.K.vec_fill(self.y, 0.0)
 
     def _rr_obj_val(self, pp, nn, x):
         RR = self.RR
@@ -512,4 +636,5 @@ class DeviceMadNLPSolver(MadNLPSolver):
 
     def host_state(self):
         """x, y, zl, zu on the host (tests, reporting)."""
+        self._sync()      # the library's stream may not be torch's: the download below must see the finished loop
         return tuple(v.cpu().numpy() for v in (self.x, self.y, self.zl, self.zu))

@@ -202,6 +202,51 @@ class IPMDeviceKernels:
         self._void("mnk_ipm_initialize_variables", _dev(x), _dev(xl), _dev(xu), int(x.numel()), float(bound_push),
                    float(bound_fac))
 
+    # ---- plain vector work of the loop (copyto! / fill! / axpy! / dot / norm / mul! of the reference's solver.jl,
+    # line_search.jl, backsolve.jl) on the context's stream
+    def get_dot(self, x, y):
+        return self._call("mnk_ipm_get_dot", _dev(x), _dev(y), int(x.numel()))
+
+    def get_sum(self, v):
+        return self._call("mnk_ipm_get_sum", _dev(v), int(v.numel()))
+
+    def get_norm2(self, v):
+        return self._call("mnk_ipm_get_norm2", _dev(v), int(v.numel()))
+
+    def vec_copy(self, dst, src):
+        assert dst.numel() == src.numel()
+        self._void("mnk_ipm_vec_copy", _dev(dst), _dev(src), int(dst.numel()))
+
+    def vec_fill(self, v, value):
+        if v.numel():
+            self._void("mnk_ipm_vec_fill", _dev(v), int(v.numel()), float(value))
+
+    def vec_axpby(self, out, a, x, b=0.0, y=None):
+        """out = a x + b y (y None: out = a x); out may alias x or y."""
+        assert out.numel() == x.numel() and (y is None or y.numel() == x.numel())
+        if out.numel():
+            self._void("mnk_ipm_vec_axpby", _dev(out), float(a), _dev(x), float(b), None if y is None else _dev(y),
+                       int(out.numel()))
+
+    def vec_scatter_axpy(self, y, idx, a, x):
+        if x.numel():
+            self._void("mnk_ipm_vec_scatter_axpy", _dev(y), idx.data_ptr(), float(a), _dev(x), int(x.numel()))
+
+    def vec_gather(self, out, a, x, idx):
+        if out.numel():
+            self._void("mnk_ipm_vec_gather", _dev(out), float(a), _dev(x), idx.data_ptr(), int(out.numel()))
+
+    def bound_dual_axpy(self, zl, zu, a, dzl, dzu):
+        self._void("mnk_ipm_bound_dual_axpy", _dev(zl), _dev(zu), float(a), _dev(dzl), _dev(dzu))
+
+    def bound_dual_fill(self, zl, zu, v):
+        self._void("mnk_ipm_bound_dual_fill", _dev(zl), _dev(zu), float(v))
+
+    def gemv(self, trans, m, n, alpha, A, lda, x, beta, y):
+        """y = alpha op(A) x + beta y, A column-major m x n on the device."""
+        self._void("mnk_ipm_gemv", int(trans), int(m), int(n), float(alpha), A.data_ptr(), int(lda), _dev(x), float(beta),
+                   _dev(y))
+
     def close(self):
         if self._h:
             L.lib().mnk_ipm_destroy(self._h)

@@ -88,10 +88,9 @@ def _random_connected_graph(rng, nbus, nbranch, max_deg=12):
     return fr, to
 
 
-def opf_shaped(case="case1354pegase", seed=None, sigma_s_decades=8.0, du=0.0, indefinite=False):
-    """OPF-shaped sparse condensed KKT inputs (all constraints are inequalities, as under
-    MadNLP's RelaxEquality preset for SparseCondensedKKTSystem, reference
-    src/IPM/options.jl:146-147)."""
+def _opf_structure(case, seed=None):
+    """Graph, variable layout and the COO patterns of the polar AC-OPF model (`opf_shaped` fills them with random values,
+    `ACOPFModel` with the power-flow derivatives).  Returns a dict and the generator `rng` after the structure draws."""
     nbus, ngen, nbr = OPF_CASES[case] if isinstance(case, str) else case
     name = case if isinstance(case, str) else f"opf{nbus}"
     if seed is None:
@@ -137,24 +136,37 @@ def opf_shaped(case="case1354pegase", seed=None, sigma_s_decades=8.0, du=0.0, in
     m = r
     jac_I = np.concatenate(rows).astype(np.int32)
     jac_J = np.concatenate(cols).astype(np.int32)
+    # Hessian of the Lagrangian: per flow row the lower triangle of the clique (vm_f, vm_t, va_f, va_t) (COO with duplicates
+    # across the 4 rows of a branch, like an AD back-end emits), then thermal p^2 / q^2, shunt vm^2 and generation-cost diagonals
+    il, jl = np.tril_indices(4)
+    clique = np.stack((vm[arc_f], vm[arc_t], va[arc_f], va[arc_t]), axis=1)  # narc x 4
+    hI = [clique[:, il].ravel(), clique[:, il].ravel(), p, q, vm, pg]
+    hJ = [clique[:, jl].ravel(), clique[:, jl].ravel(), p, q, vm, pg]
+    S = dict(name=name, seed=seed, nbus=nbus, ngen=ngen, nbr=nbr, narc=narc, n=n, m=m, fr=fr, to=to, gen_bus=gen_bus,
+             arc_f=arc_f, arc_t=arc_t, va=va, vm=vm, pg=pg, qg=qg, p=p, q=q, jac_I=jac_I, jac_J=jac_J,
+             hess_I=np.concatenate(hI).astype(np.int32), hess_J=np.concatenate(hJ).astype(np.int32), il=il, jl=jl)
+    return S, rng
+
+
+def opf_shaped(case="case1354pegase", seed=None, sigma_s_decades=8.0, du=0.0, indefinite=False):
+    """OPF-shaped sparse condensed KKT inputs (all constraints are inequalities, as under
+    MadNLP's RelaxEquality preset for SparseCondensedKKTSystem, reference
+    src/IPM/options.jl:146-147)."""
+    S, rng = _opf_structure(case, seed)
+    name, seed, nbus, ngen, nbr, narc, n, m = (S[k] for k in ("name", "seed", "nbus", "ngen", "nbr", "narc", "n", "m"))
+    pg, jac_I, jac_J, il, jl = S["pg"], S["jac_I"], S["jac_J"], S["il"], S["jl"]
     jac = np.clip(rng.standard_normal(len(jac_I)), -100, 100)
 
-    # Hessian of the Lagrangian: per flow row a rank-one PSD clique on (vm_f, vm_t, va_f, va_t)
-    # (COO with duplicates across the 4 rows of a branch, like an AD back-end emits), thermal
-    # p^2/q^2, shunt vm^2 and generation-cost diagonals.
-    hI, hJ, hV = [], [], []
-    il, jl = np.tril_indices(4)
-    for own in (p, q):
-        clique = np.stack((vm[arc_f], vm[arc_t], va[arc_f], va[arc_t]), axis=1)  # narc x 4
+    # values: per flow row a rank-one PSD clique, positive diagonals
+    hV = []
+    for _own in range(2):
         a = rng.standard_normal((narc, 4))
-        vals = a[:, il] * a[:, jl]
-        hI.append(clique[:, il].ravel()); hJ.append(clique[:, jl].ravel()); hV.append(vals.ravel())
-    hI.append(p); hJ.append(p); hV.append(rng.random(narc) + 0.1)
-    hI.append(q); hJ.append(q); hV.append(rng.random(narc) + 0.1)
-    hI.append(vm); hJ.append(vm); hV.append(rng.random(nbus) + 0.1)
-    hI.append(pg); hJ.append(pg); hV.append(rng.random(ngen) + 0.1)
-    hess_I = np.concatenate(hI).astype(np.int32)
-    hess_J = np.concatenate(hJ).astype(np.int32)
+        hV.append((a[:, il] * a[:, jl]).ravel())
+    hV.append(rng.random(narc) + 0.1)
+    hV.append(rng.random(narc) + 0.1)
+    hV.append(rng.random(nbus) + 0.1)
+    hV.append(rng.random(ngen) + 0.1)
+    hess_I, hess_J = S["hess_I"], S["hess_J"]
     hess = np.concatenate(hV)
     if indefinite:
         # negative curvature on the generator injections (each touches one balance row only, so
@@ -527,3 +539,172 @@ class SparseQPModel:
 
     def hess_coord(self, x, y, w=1.0):
         return w * self.hv
+
+
+class ACOPFModel:
+    """Polar AC optimal power flow on the synthetic grid of `_opf_structure` (PGLib case sizes; PGLib data are not available
+    offline): the model the reference's benchmarks solve (`benchmark/` runs ExaModelsPower's `opf_model` on pglib cases).
+
+      variables    va, vm per bus; pg, qg per generator; p, q per arc (two arcs per branch)
+      objective    sum_g c2 pg^2 + c1 pg + c0
+      constraints  va_ref = 0;  p_a - P_a(vm, va) = 0,  q_a - Q_a(vm, va) = 0 per arc;  angmin <= va_f - va_t <= angmax per
+                   branch;  p_a^2 + q_a^2 <= rate_a^2 per arc;  active / reactive balance per bus
+      arc flows    T(u, w, d) = alpha u^2 + u w (beta cos d + gamma sin d) with u = vm at the arc's own end, w = vm at the far
+                   end, d = va_own - va_far; `arc_coef[a] = (alpha, beta, gamma)` for P_a, `(alpha', beta', gamma')` for Q_a,
+                   derived from g, b, tap, shift and line charging as in the pi-model.
+
+    The callbacks are the host (numpy) evaluation; `csrc/opf_eval.hip` evaluates the same expressions on the device
+    (`DeviceOPFCallbacks`).  Constraint and nonzero order are those of `opf_shaped`."""
+
+    def __init__(self, case="case118", seed=None, load=1.0):
+        S, _ = _opf_structure(case, seed)
+        self.S = S
+        self.name = f"acopf_{S['name']}"
+        nbus, ngen, nbr, narc = S["nbus"], S["ngen"], S["nbr"], S["narc"]
+        self.nbus, self.ngen, self.nbr, self.narc = nbus, ngen, nbr, narc
+        self.n, self.m = S["n"], S["m"]
+        self.jac_I, self.jac_J, self.hess_I, self.hess_J = S["jac_I"], S["jac_J"], S["hess_I"], S["hess_J"]
+        self.fr, self.to, self.gen_bus, self.arc_f, self.arc_t = S["fr"], S["to"], S["gen_bus"], S["arc_f"], S["arc_t"]
+        rng = np.random.default_rng(S["seed"] + 101)
+        # branches (per unit): series impedance, line charging, a few transformers with tap / phase shift
+        r = rng.uniform(0.005, 0.03, nbr)
+        x = rng.uniform(0.03, 0.12, nbr)
+        g, b = r / (r * r + x * x), -x / (r * r + x * x)
+        bc = rng.uniform(0.0, 0.06, nbr)
+        trafo = rng.random(nbr) < 0.1
+        tap = np.where(trafo, rng.uniform(0.95, 1.05, nbr), 1.0)
+        shift = np.where(trafo & (rng.random(nbr) < 0.5), rng.uniform(-0.05, 0.05, nbr), 0.0)
+        tr, ti = tap * np.cos(shift), tap * np.sin(shift)
+        tm2 = tap * tap
+        coef = np.empty((narc, 6))
+        # from side: P = (g + g_fr)/tm2 vf^2 + (-g tr + b ti)/tm2 vf vt cos + (-b tr - g ti)/tm2 vf vt sin
+        #            Q = -(b + b_fr)/tm2 vf^2 - (-b tr - g ti)/tm2 vf vt cos + (-g tr + b ti)/tm2 vf vt sin
+        coef[:nbr, 0] = g / tm2
+        coef[:nbr, 1] = (-g * tr + b * ti) / tm2
+        coef[:nbr, 2] = (-b * tr - g * ti) / tm2
+        coef[:nbr, 3] = -(b + bc / 2) / tm2
+        coef[:nbr, 4] = -coef[:nbr, 2]
+        coef[:nbr, 5] = coef[:nbr, 1]
+        # to side (own end = the branch's to-bus): P = (g + g_to) vt^2 + (-g tr - b ti)/tm2 vt vf cos + (-b tr + g ti)/tm2 vt vf sin
+        coef[nbr:, 0] = g
+        coef[nbr:, 1] = (-g * tr - b * ti) / tm2
+        coef[nbr:, 2] = (-b * tr + g * ti) / tm2
+        coef[nbr:, 3] = -(b + bc / 2)
+        coef[nbr:, 4] = -coef[nbr:, 2]
+        coef[nbr:, 5] = coef[nbr:, 1]
+        self.arc_coef = np.ascontiguousarray(coef)
+        # buses: loads on ~70 %, a few shunts
+        pd = np.where(rng.random(nbus) < 0.7, rng.uniform(0.05, 0.4, nbus), 0.0) * load
+        qd = pd * rng.uniform(0.1, 0.4, nbus)
+        sh = rng.random(nbus) < 0.05
+        gs = np.where(sh, rng.uniform(0.0, 0.02, nbus), 0.0)
+        bs = np.where(sh, rng.uniform(-0.1, 0.2, nbus), 0.0)
+        self.bus_data = np.ascontiguousarray(np.stack((pd, qd, gs, bs), axis=1))
+        # generators: capacity 1.8 x the total load, spread unevenly; quadratic costs
+        wgt = rng.uniform(0.5, 1.5, ngen)
+        pmax = 1.8 * pd.sum() * wgt / wgt.sum()
+        qmax = 0.8 * pmax + 0.2
+        self.gen_cost = np.ascontiguousarray(np.stack((rng.uniform(1.0, 8.0, ngen) / np.maximum(pmax, 1.0),
+                                                       rng.uniform(10.0, 40.0, ngen), rng.uniform(0.0, 5.0, ngen)), axis=1))
+        rate = rng.uniform(2.0, 4.0, nbr) * max(1.0, load)
+        rate = np.concatenate((rate, rate))
+        ang = np.pi / 6
+        # bounds and start
+        va, vm, pgi, qgi, p, q = (S[k] for k in ("va", "vm", "pg", "qg", "p", "q"))
+        self.lvar, self.uvar = np.full(self.n, -np.inf), np.full(self.n, np.inf)
+        self.lvar[vm], self.uvar[vm] = 0.94, 1.06
+        self.lvar[pgi], self.uvar[pgi] = 0.0, pmax
+        self.lvar[qgi], self.uvar[qgi] = -qmax, qmax
+        self.lvar[p], self.uvar[p] = -rate, rate
+        self.lvar[q], self.uvar[q] = -rate, rate
+        self.lcon, self.ucon = np.zeros(self.m), np.zeros(self.m)
+        o = 1 + 2 * narc
+        self.lcon[o:o + nbr], self.ucon[o:o + nbr] = -ang, ang
+        o += nbr
+        self.lcon[o:o + narc], self.ucon[o:o + narc] = -np.inf, rate * rate
+        self.x0 = np.zeros(self.n)
+        self.x0[vm] = 1.0
+        self.x0[pgi] = 0.5 * pmax
+        self.y0 = np.zeros(self.m)
+        # bus -> arcs / generators incidence (balance rows)
+        import scipy.sparse as sp
+        self._A_arc = sp.csr_matrix((np.ones(narc), (self.arc_f, np.arange(narc))), shape=(nbus, narc))
+        self._A_gen = sp.csr_matrix((np.ones(ngen), (self.gen_bus, np.arange(ngen))), shape=(nbus, ngen))
+
+    # ---- pieces
+    def _split(self, x):
+        S = self.S
+        return x[S["va"]], x[S["vm"]], x[S["pg"]], x[S["qg"]], x[S["p"]], x[S["q"]]
+
+    def _arc_terms(self, x):
+        va, vm = x[self.S["va"]], x[self.S["vm"]]
+        u, w = vm[self.arc_f], vm[self.arc_t]
+        d = va[self.arc_f] - va[self.arc_t]
+        return u, w, np.cos(d), np.sin(d)
+
+    def obj(self, x):
+        pg = x[self.S["pg"]]
+        c = self.gen_cost
+        return float((c[:, 0] * pg * pg + c[:, 1] * pg + c[:, 2]).sum())
+
+    def grad(self, x):
+        g = np.zeros(self.n)
+        pg = x[self.S["pg"]]
+        g[self.S["pg"]] = 2.0 * self.gen_cost[:, 0] * pg + self.gen_cost[:, 1]
+        return g
+
+    def cons(self, x):
+        va, vm, pg, qg, p, q = self._split(x)
+        u, w, cs, sn = self._arc_terms(x)
+        k = self.arc_coef
+        c = np.empty(self.m)
+        c[0] = va[0]
+        narc, nbr = self.narc, self.nbr
+        o = 1
+        c[o:o + narc] = p - (k[:, 0] * u * u + u * w * (k[:, 1] * cs + k[:, 2] * sn)); o += narc
+        c[o:o + narc] = q - (k[:, 3] * u * u + u * w * (k[:, 4] * cs + k[:, 5] * sn)); o += narc
+        c[o:o + nbr] = va[self.fr] - va[self.to]; o += nbr
+        c[o:o + narc] = p * p + q * q; o += narc
+        pd, qd, gs, bs = self.bus_data.T
+        c[o:o + self.nbus] = pd + gs * vm * vm + self._A_arc @ p - self._A_gen @ pg; o += self.nbus
+        c[o:o + self.nbus] = qd - bs * vm * vm + self._A_arc @ q - self._A_gen @ qg
+        return c
+
+    def jac_coord(self, x):
+        va, vm, pg, qg, p, q = self._split(x)
+        u, w, cs, sn = self._arc_terms(x)
+        k = self.arc_coef
+        out = [np.ones(1)]
+        for c0 in (0, 3):
+            K = k[:, c0 + 1] * cs + k[:, c0 + 2] * sn
+            Kp = -k[:, c0 + 1] * sn + k[:, c0 + 2] * cs
+            Tu, Tw, Td = 2.0 * k[:, c0] * u + w * K, u * K, u * w * Kp
+            out.append(np.stack((np.ones(self.narc), -Tu, -Tw, -Td, Td), axis=1).ravel())
+        out.append(np.tile(np.array([1.0, -1.0]), self.nbr))
+        out.append(np.stack((2.0 * p, 2.0 * q), axis=1).ravel())
+        pd, qd, gs, bs = self.bus_data.T
+        out += [2.0 * gs * vm, np.ones(self.narc), -np.ones(self.ngen)]
+        out += [-2.0 * bs * vm, np.ones(self.narc), -np.ones(self.ngen)]
+        return np.concatenate(out)
+
+    def hess_coord(self, x, y, w=1.0):
+        u, wv, cs, sn = self._arc_terms(x)
+        k = self.arc_coef
+        narc, nbr, nbus = self.narc, self.nbr, self.nbus
+        out = []
+        for blk, c0 in enumerate((0, 3)):
+            yy = -y[1 + blk * narc:1 + (blk + 1) * narc]          # c = own - T
+            K = k[:, c0 + 1] * cs + k[:, c0 + 2] * sn
+            Kp = -k[:, c0 + 1] * sn + k[:, c0 + 2] * cs
+            uwK = u * wv * K
+            z = np.zeros(narc)
+            # lower triangle of (u, w, tf, tt): (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) (3,0) (3,1) (3,2) (3,3)
+            H = np.stack((2.0 * k[:, c0], K, z, wv * Kp, u * Kp, -uwK, -(wv * Kp), -(u * Kp), uwK, -uwK), axis=1)
+            out.append((yy[:, None] * H).ravel())
+        o = 1 + 2 * narc + nbr
+        yth = y[o:o + narc]; o += narc
+        out += [2.0 * yth, 2.0 * yth]
+        pd, qd, gs, bs = self.bus_data.T
+        out.append(2.0 * gs * y[o:o + nbus] - 2.0 * bs * y[o + nbus:o + 2 * nbus])
+        out.append(w * 2.0 * self.gen_cost[:, 0])
+        return np.concatenate(out)

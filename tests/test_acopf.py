@@ -1,0 +1,240 @@
+"""The polar AC-OPF model (`problems.ACOPFModel`) and its device evaluation (`mnk_opf_*`, csrc/opf_eval.hip), SURVEY 8(f).4
+callback half: derivative checks of the host model, host interior-point runs on the oracle back-end, then on the GPU the
+device callbacks against the host model, the loop's vector primitives against numpy, and `DeviceMadNLPSolver` (vectors and
+callbacks in HBM, HIP back-end) against the host driver on the ORACLE back-end (numpy callbacks, LAPACK Bunch-Kaufman)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from madnlp_jl_amd.problems import ACOPFModel
+
+
+def _dense_jac(M, x):
+    return sp.csr_matrix((M.jac_coord(x), (M.jac_I, M.jac_J)), shape=(M.m, M.n)).toarray()
+
+
+def _dense_hess(M, x, y, w):
+    I, J = np.maximum(M.hess_I, M.hess_J), np.minimum(M.hess_I, M.hess_J)
+    L = sp.csr_matrix((M.hess_coord(x, y, w), (I, J)), shape=(M.n, M.n)).toarray()
+    return L + np.tril(L, -1).T
+
+
+def test_acopf_derivatives_match_finite_differences():
+    M = ACOPFModel("case30")
+    rng = np.random.default_rng(0)
+    x = M.x0 + 0.05 * rng.standard_normal(M.n)
+    y = rng.standard_normal(M.m)
+    h = 1e-6
+    E = np.eye(M.n) * h
+    Jfd = np.stack([(M.cons(x + e) - M.cons(x - e)) / (2 * h) for e in E], axis=1)
+    assert np.abs(_dense_jac(M, x) - Jfd).max() <= 1e-7
+    gfd = np.array([(M.obj(x + e) - M.obj(x - e)) / (2 * h) for e in E])
+    assert np.abs(gfd - M.grad(x)).max() <= 1e-6
+
+    def lag_grad(z):
+        return 0.7 * M.grad(z) + _dense_jac(M, z).T @ y
+    Hfd = np.stack([(lag_grad(x + e) - lag_grad(x - e)) / (2 * h) for e in E], axis=1)
+    assert np.abs(_dense_hess(M, x, y, 0.7) - Hfd).max() <= 1e-6
+
+
+def test_acopf_shares_the_pattern_of_the_opf_shaped_inputs():
+    from madnlp_jl_amd.problems import opf_shaped
+    M, P = ACOPFModel("case118"), opf_shaped("case118")
+    for f in ("jac_I", "jac_J", "hess_I", "hess_J"):
+        assert np.array_equal(getattr(M, f), getattr(P, f)), f
+    assert (M.n, M.m) == (P.n, P.m)
+    assert len(M.jac_coord(M.x0)) == len(M.jac_I) and len(M.hess_coord(M.x0, M.y0)) == len(M.hess_I)
+
+
+def _options(tol=1e-6):
+    from madnlp_jl_amd.ipm import IPMOptions
+    o = IPMOptions(tol=tol)
+    o.relax_equality, o.dual_initialization = True, "zero"
+    return o
+
+
+@pytest.mark.parametrize("case,iters", [("case30", 10), ("case118", 13)])
+def test_host_ipm_solves_the_acopf_on_the_oracle_back_end(case, iters):
+    from madnlp_jl_amd.ipm import MadNLPSolver
+    from tests.test_ipm_oracle import oracle_factory
+    nlp = ACOPFModel(case)
+    s = MadNLPSolver(nlp, oracle_factory("sparse_condensed", nlp), _options(), sparse=True)
+    assert s.solve() == "SOLVE_SUCCEEDED"
+    assert s.cnt.k == iters                       # regression of the trajectory (nonconvex: inertia corrections included)
+    x = s.x[:nlp.n]
+    c = nlp.cons(x)
+    assert (c >= nlp.lcon - 1e-5).all() and (c <= nlp.ucon + 1e-5).all()
+    assert (x >= nlp.lvar - 1e-7).all() and (x <= nlp.uvar + 1e-7).all()
+    assert abs(nlp.obj(x) - s.obj_val) <= 1e-9 * abs(s.obj_val)
+
+
+# ----------------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture()
+def gpu_ctx():
+    torch = pytest.importorskip("torch")
+    import madnlp_jl_amd as mj
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    st = torch.cuda.Stream()       # NOT torch's current stream: the loop must not depend on torch's stream order
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["case30", "case118", "case1354pegase"])
+def test_device_callbacks_match_the_host_model(gpu_ctx, case):
+    import torch
+    from madnlp_jl_amd.ipm_dev import DeviceOPFCallbacks, _up
+    from madnlp_jl_amd.ipm_device import IPMDeviceKernels
+    nlp = ACOPFModel(case)
+    K = IPMDeviceKernels(nlp.n, np.arange(1), np.arange(1), ctx=gpu_ctx)
+    cb = DeviceOPFCallbacks(nlp, None, "cuda", K)
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        x = nlp.x0 + (0.0 if trial == 0 else 0.1) * rng.standard_normal(nlp.n)
+        y = rng.standard_normal(nlp.m)
+        sigma = [1.0, 0.0, 0.37][trial]
+        xd, yd = _up(x, "cuda"), _up(y, "cuda")
+        g, c = torch.empty(nlp.n, dtype=torch.float64, device="cuda"), torch.empty(nlp.m, dtype=torch.float64, device="cuda")
+        f = cb.obj(xd)
+        cb.grad(g, xd)
+        cb.cons(c, xd)
+        jv, hv = cb.jac_coord(xd), cb.hess_coord(xd, yd, sigma)
+        gpu_ctx.synchronize()
+        assert abs(f - nlp.obj(x)) <= 1e-13 * abs(nlp.obj(x))
+        assert np.array_equal(g.cpu().numpy(), nlp.grad(x))                       # no transcendental: bit-identical
+        # sin / cos come from different math libraries (<= 2 ulp each): 1e-13 relative to the row's scale
+        cr, jr, hr = nlp.cons(x), nlp.jac_coord(x), nlp.hess_coord(x, y, sigma)
+        np.testing.assert_allclose(c.cpu().numpy(), cr, rtol=0, atol=1e-13 * max(1.0, np.abs(cr).max()))
+        np.testing.assert_allclose(jv.cpu().numpy(), jr, rtol=0, atol=1e-13 * np.abs(jr).max())
+        np.testing.assert_allclose(hv.cpu().numpy(), hr, rtol=0, atol=1e-13 * np.abs(hr).max())
+        # the rows without sin / cos are bit-identical (angle differences, thermal limits, balances, linear entries)
+        o = 1 + 2 * nlp.narc
+        assert np.array_equal(c.cpu().numpy()[o:], cr[o:]) and c.cpu().numpy()[0] == cr[0]
+        oj = 1 + 10 * nlp.narc
+        assert np.array_equal(jv.cpu().numpy()[oj:], jr[oj:])
+        assert np.array_equal(hv.cpu().numpy()[20 * nlp.narc:], hr[20 * nlp.narc:])
+    cb.close()
+    K.close()
+
+
+@pytest.mark.gpu
+def test_loop_vector_primitives_match_numpy(gpu_ctx):
+    import torch
+    from madnlp_jl_amd.ipm_dev import _up
+    from madnlp_jl_amd.ipm_device import IPMDeviceKernels
+    rng = np.random.default_rng(11)
+    n = 100003
+    lb = np.sort(rng.choice(n, n // 3, replace=False))
+    ub = np.sort(rng.choice(n, n // 4, replace=False))
+    K = IPMDeviceKernels(n, lb, ub, ctx=gpu_ctx)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    xd, yd = _up(x, "cuda"), _up(y, "cuda")
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    host = lambda t: (gpu_ctx.synchronize(), t.cpu().numpy())[1]  # noqa: E731
+    K.vec_axpby(out, 1.0, xd, 0.37, yd)
+    assert np.array_equal(host(out), x + 0.37 * y)
+    K.vec_axpby(out, -1.0, xd)
+    assert np.array_equal(host(out), -x)
+    K.vec_axpby(out, 2.5, xd, 1.0, yd)
+    assert np.array_equal(host(out), 2.5 * x + y)
+    K.vec_copy(out, xd)
+    K.vec_axpby(out, 1.0, out, -1.0, yd)            # in place: x - y
+    assert np.array_equal(host(out), x - y)
+    K.vec_fill(out, 3.25)
+    assert (host(out) == 3.25).all()
+    idx = rng.permutation(n)[: n // 2].astype(np.int64)
+    idd = _up(idx, "cuda", np.int64)
+    small = rng.standard_normal(len(idx))
+    sd = _up(small, "cuda")
+    K.vec_copy(out, xd)
+    K.vec_scatter_axpy(out, idd, -1.0, sd)
+    ref = x.copy()
+    ref[idx] -= small
+    assert np.array_equal(host(out), ref)
+    g = torch.empty(len(idx), dtype=torch.float64, device="cuda")
+    K.vec_gather(g, -1.0, xd, idd)
+    assert np.array_equal(host(g), -x[idx])
+    zl, zu = _up(x, "cuda"), _up(y, "cuda")
+    dzl, dzu = rng.standard_normal(len(lb)), rng.standard_normal(len(ub))
+    K.bound_dual_axpy(zl, zu, 0.5, _up(dzl, "cuda"), _up(dzu, "cuda"))
+    rl, ru = x.copy(), y.copy()
+    rl[lb] += 0.5 * dzl
+    ru[ub] += 0.5 * dzu
+    assert np.array_equal(host(zl), rl) and np.array_equal(host(zu), ru)
+    K.bound_dual_fill(zl, zu, 1.0)
+    rl[lb] = 1.0
+    ru[ub] = 1.0
+    assert np.array_equal(host(zl), rl) and np.array_equal(host(zu), ru)
+    assert abs(K.get_dot(xd, yd) - x @ y) <= 1e-12 * np.abs(x * y).sum()
+    assert abs(K.get_sum(xd) - x.sum()) <= 1e-12 * np.abs(x).sum()
+    assert abs(K.get_norm2(xd) - np.linalg.norm(x)) <= 1e-13 * np.linalg.norm(x)
+    with K.batch():
+        a, b = K.get_dot(xd, xd), K.get_sum(yd)
+    assert abs(a[0] - x @ x) <= 1e-12 * (x @ x) and abs(b[0] - y.sum()) <= 1e-12 * np.abs(y).sum()
+    # dense products, column-major with a leading dimension larger than the row count
+    m, k, lda = 777, 1234, 800
+    A = np.zeros((lda, k), order="F")
+    A[:m] = rng.standard_normal((m, k))
+    Ad = _up(A.T, "cuda")                               # row-major image of A' == column-major A
+    v, w = rng.standard_normal(k), rng.standard_normal(m)
+    ym, yk = _up(w, "cuda"), _up(v, "cuda")
+    K.gemv(0, m, k, 1.5, Ad, lda, _up(v, "cuda"), -0.5, ym)
+    r = 1.5 * (A[:m] @ v) - 0.5 * w
+    assert np.abs(host(ym) - r).max() <= 1e-12 * np.abs(r).max()
+    K.gemv(1, m, k, 1.0, Ad, lda, _up(w, "cuda"), 0.0, yk)
+    r = A[:m].T @ w
+    assert np.abs(host(yk) - r).max() <= 1e-12 * np.abs(r).max()
+    K.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["case30", "case118"])
+def test_device_resident_acopf_run_matches_the_oracle_back_end(gpu_ctx, case):
+    """`DeviceMadNLPSolver` (iterate, callbacks, KKT path and reductions on the GPU; static-pivot LDL^T) against
+      (1) the host driver with numpy callbacks on the SAME HIP back-end: the callback / vector half in isolation -- same
+          iteration, factorization and back-solve counts, same residual history;
+      (2) the host driver with numpy callbacks on the ORACLE back-end (numpy assembly + LAPACK Bunch-Kaufman): same status,
+          same optimum.  The condensed matrices of this model have condition numbers up to ~1e19 (the relaxed equalities put
+          1e18 on the diagonal; `tools/acopf_solve_accuracy.py`: both back-ends solve to backward error <= 4e-17 and forward
+          error ~5e-2 there), so the two linear-algebra back-ends take steps that differ at noise level and the iteration
+          counts may differ by one or two -- the reference itself runs this KKT system at tol = 1e-4 for that reason
+          (src/IPM/options.jl:226)."""
+    import madnlp_jl_amd as mj
+    from madnlp_jl_amd.ipm import MadNLPSolver
+    from madnlp_jl_amd.ipm_dev import DeviceMadNLPSolver
+    from tests.test_ipm_oracle import oracle_factory
+    nlp = ACOPFModel(case)
+    so = MadNLPSolver(nlp, oracle_factory("sparse_condensed", nlp), _options(), sparse=True)
+    so.solve()
+
+    def factory(info):
+        return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J,
+                                           info["ind_ineq"], info["ind_lb"], info["ind_ub"], ctx=gpu_ctx,
+                                           opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN),
+                                           device_kkt_ops=True)
+    sh = MadNLPSolver(nlp, factory, _options(), sparse=True)
+    sh.solve()
+    sd = DeviceMadNLPSolver(nlp, factory, _options())
+    sd.solve()
+    assert sd.status == sh.status == so.status == "SOLVE_SUCCEEDED"
+    x, y, zl, zu = sd.host_state()
+    # (1) same back-end, device callbacks and vectors vs numpy ones
+    assert (sd.cnt.k, sd.cnt.factorization_cnt, sd.cnt.backsolve_cnt) == (sh.cnt.k, sh.cnt.factorization_cnt, sh.cnt.backsolve_cnt)
+    np.testing.assert_allclose(x, sh.x, rtol=0, atol=1e-7 * max(1.0, np.abs(sh.x).max()))
+    for a, b in zip(sd.history, sh.history):
+        assert a.k == b.k and a.del_w == b.del_w
+        for fld in ("inf_pr", "inf_du", "inf_compl", "mu"):
+            va, vb = getattr(a, fld), getattr(b, fld)
+            assert abs(va - vb) <= 1e-5 * abs(vb) + 1e-9, (a.k, fld, va, vb)
+    # (2) the oracle back-end: same optimum
+    assert abs(sd.cnt.k - so.cnt.k) <= 2
+    assert abs(sd.obj_val - so.obj_val) <= 1e-6 * abs(so.obj_val)
+    # (not the iterate itself: generators that share a bus have no reactive cost, their qg split is not unique)
+    pg = nlp.S["pg"]
+    np.testing.assert_allclose(x[pg], so.x[pg], rtol=0, atol=1e-4 * max(1.0, np.abs(so.x[pg]).max()))
+    xs = x[:nlp.n]
+    c = nlp.cons(xs)                                 # feasibility of the device solution, judged by the host model
+    assert (c >= nlp.lcon - 1e-5).all() and (c <= nlp.ucon + 1e-5).all()
+    assert abs(nlp.obj(xs) - sd.obj_val) <= 1e-9 * abs(sd.obj_val)
+    sd.cb.close(); sd.K.close(); sd.kkt.close(); sh.kkt.close()

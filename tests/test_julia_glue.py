@@ -28,9 +28,9 @@ def c_class(decl: str) -> str:
         "double*": "double*", "int32_t*": "int32*", "int64_t*": "int64*", "int*": "int*",
         "unsignedlonglong*": "uint64*",
     }
-    if re.match(r"^mnk_(ctx|sc|dc|ls|schur|ipm)\*\*$", t):
+    if re.match(r"^mnk_(ctx|sc|dc|ls|schur|ipm|opf)\*\*$", t):
         return "handle_out"
-    if re.match(r"^mnk_(ctx|sc|dc|ls|schur|ipm)\*$", t):
+    if re.match(r"^mnk_(ctx|sc|dc|ls|schur|ipm|opf)\*$", t):
         return "handle"
     return table[t]
 

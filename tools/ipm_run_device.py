@@ -1,6 +1,9 @@
-"""End-to-end IPM run with DEVICE-RESIDENT vectors (madnlp_jl_amd.ipm_dev) next to the host mirror on the same convex QP:
-iterations, counts, wall clock.  usage: ipm_run_device.py [case]            OPF-shaped sparse condensed (default case1354pegase)
-                                                ipm_run_device.py dense n m [n_eq]   DenseDummyQP, DenseCondensedKKTSystem (C2: 2048 512)"""
+"""End-to-end IPM run with DEVICE-RESIDENT vectors and callbacks (madnlp_jl_amd.ipm_dev) next to the host mirror on the same
+problem: iterations, counts, wall clock.
+usage: ipm_run_device.py [case]             convex QP with the OPF sparsity, sparse condensed (default case1354pegase)
+       ipm_run_device.py acopf [case]       polar AC-OPF NLP on the synthetic grid (callbacks: mnk_opf_*)
+       ipm_run_device.py dense n m [n_eq]   DenseDummyQP, DenseCondensedKKTSystem (C2: 2048 512)
+env IPM_DEVICE_ONLY=1: skip the host mirror (kernel profiles of the device-resident loop alone)"""
 import json
 import os
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -14,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import madnlp_jl_amd as mj  # noqa: E402
 from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver  # noqa: E402
 from madnlp_jl_amd.ipm_dev import DeviceMadNLPSolver  # noqa: E402
-from madnlp_jl_amd.problems import DenseQPModel, SparseQPModel  # noqa: E402
+from madnlp_jl_amd.problems import ACOPFModel, DenseQPModel, SparseQPModel  # noqa: E402
 
 case = sys.argv[1] if len(sys.argv) > 1 else "case1354pegase"
 dense = case == "dense"
@@ -23,10 +26,13 @@ if dense:
     dne = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     nlp = DenseQPModel(dn, dm, dne)
     case = f"dense n={dn} m={dm} n_eq={dne}"
+elif case == "acopf":
+    grid = sys.argv[2] if len(sys.argv) > 2 else "case1354pegase"
+    nlp = ACOPFModel(grid)
+    case = f"acopf {grid}"
 else:
     nlp = SparseQPModel(case)
-st = torch.cuda.Stream()
-torch.cuda.set_stream(st)
+st = torch.cuda.Stream()   # the library's stream; torch's current stream stays the default one (no torch kernel runs in the loop)
 ctx = mj.HipContext(0, stream=st.cuda_stream)
 
 
@@ -49,7 +55,11 @@ def options():
     return o
 
 
-for label, cls in (("host mirror (numpy vectors, device KKT ops)", MadNLPSolver), ("device-resident vectors", DeviceMadNLPSolver)):
+drivers = (("host mirror (numpy vectors and callbacks, device KKT ops)", MadNLPSolver),
+           ("device-resident vectors and callbacks", DeviceMadNLPSolver))
+if os.environ.get("IPM_DEVICE_ONLY"):
+    drivers = drivers[1:]
+for label, cls in drivers:
     for rep in range(2):  # second run: warm
         s = cls(nlp, factory, options(), sparse=not dense)
         s.initialize()
@@ -64,4 +74,8 @@ for label, cls in (("host mirror (numpy vectors, device KKT ops)", MadNLPSolver)
                "factorizations": s.cnt.factorization_cnt, "backsolves": s.cnt.backsolve_cnt, "wall_s_regular_phase": wall,
                "ms_per_iteration_wall": 1e3 * wall / max(1, s.cnt.k), "it_per_s": s.cnt.k / wall, "obj": float(s.obj_val)}
         print(json.dumps(rec), flush=True)
+        if cls is DeviceMadNLPSolver:
+            s.cb.close()
+            s.K.close()
         s.kkt.close()
+ctx.close()

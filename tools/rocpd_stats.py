@@ -6,6 +6,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "").replace("mnk::", "")
     return name[:90]
