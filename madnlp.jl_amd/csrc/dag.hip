@@ -136,8 +136,10 @@ __device__ __forceinline__ bool dag_wait_words(const DagArgs& a, const int* w0, 
 // waited for one L2 round trip per MFMA (90 us per tile measured, on the critical path of every row of tiles; ~30 us
 // staged).  (Starting the block-ja part before D_jb is published, with all operands prefetched into registers, was built
 // and measured slower: the 168-register budget of the k-loop forces the strips to run one after the other.)
+// X: the tile in that layout, X[cb][ns] = column block cb (0..7) of strip ns -- the accumulators of gemm_nt_mainloop3<2, 8>.
 template <bool LDL>
-__device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0, int64_t col0, int ja, char* smem_raw, int tid) {
+__device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0, int64_t col0, int ja, char* smem_raw, int tid,
+                                                  v4f64 (&X)[8][2]) {
     v4f64* S = reinterpret_cast<v4f64*>(smem_raw);  // up to 16 blocks x 64 lanes (32 KB of the 36 KB)
     double* F = a.F;
     const int64_t ld = a.ld;
@@ -166,26 +168,24 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
             }
             S[slot] = v;
         }
+        // D^-1 of the block's 64 columns rides along (LDL^T): read back four at a time in front of the stores -- a global
+        // load behind a possibly aliasing store would wait for it, and 16 preloaded values do not fit the registers
+        if (LDL && tid < 64) reinterpret_cast<double*>(S + 640)[tid] = a.dinv[(int64_t)64 * jk + tid];
     };
     // X <- X L_kk^-T for both strips; stores L (LDL^T: V D^-1, and V next to it), keeps V in X
-    auto trsm = [&](v4f64 (&X)[2][4], int coff) {
-        double di[4][4];  // (fetched before the first store: a load behind a possibly aliasing store waits for it)
-        if (LDL) {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) di[cb][r] = a.dinv[col0 + l4 + coff + 16 * cb + 4 * r];
-        }
+    auto trsm = [&](auto half, int coff) {
+        constexpr int h4 = 4 * decltype(half)::value;
+        const double* Sd = reinterpret_cast<const double*>(S + 640) + l4;
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            v4f64 t0 = X[0][cb], t1 = X[1][cb];
+            v4f64 t0 = X[h4 + cb][0], t1 = X[h4 + cb][1];
 #pragma unroll
             for (int ib = 0; ib < cb; ++ib) {
                 const v4f64 aop = S[(cb * (cb - 1) / 2 + ib) * 64 + lane];
 #pragma unroll
                 for (int sx = 0; sx < 4; ++sx) {
-                    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[0][ib][sx], t0, 0, 0, 0);
-                    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[1][ib][sx], t1, 0, 0, 0);
+                    t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[h4 + ib][0][sx], t0, 0, 0, 0);
+                    t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[h4 + ib][1][sx], t1, 0, 0, 0);
                 }
             }
             const v4f64 iv = S[(6 + cb) * 64 + lane];
@@ -195,37 +195,27 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
                 x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[sx], t0[sx], x0, 0, 0, 0);
                 x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(iv[sx], t1[sx], x1, 0, 0, 0);
             }
-            X[0][cb] = x0;
-            X[1][cb] = x1;
+            X[h4 + cb][0] = x0;
+            X[h4 + cb][1] = x1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (LDL) vm = fmax(vm, fmax(fabs(x0[r]), fabs(x1[r])));
                 const int64_t cc = (int64_t)(coff + 16 * cb + 4 * r) * ld;
-                Fs[cc] = LDL ? x0[r] * di[cb][r] : x0[r];
-                Fs[cc + 16] = LDL ? x1[r] * di[cb][r] : x1[r];
+                const double di = LDL ? Sd[16 * cb + 4 * r] : 1.0;
+                Fs[cc] = LDL ? x0[r] * di : x0[r];
+                Fs[cc + 16] = LDL ? x1[r] * di : x1[r];
                 if (LDL) {
                     Vs[cc] = x0[r];
                     Vs[cc + 16] = x1[r];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);  // (the whole tile is live in registers: nothing of the next block may be hoisted)
         }
     };
-    auto load_strips = [&](v4f64 (&X)[2][4], int coff) {
-#pragma unroll
-        for (int ns = 0; ns < 2; ++ns)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[ns][cb][r] = Fs[16 * ns + (int64_t)(coff + 16 * cb + 4 * r) * ld];
-    };
-
-    v4f64 Xa[2][4], Xb[2][4];
-    load_strips(Xa, 0);
     fill_diag(ja);
     __syncthreads();
-    trsm(Xa, 0);
+    trsm(std::integral_constant<int, 0>(), 0);
     __syncthreads();
-    load_strips(Xb, 64);
     {   // blocks (cb2, ib): -L(jb, ja)[16 cb2 + i][16 ib + k]
         const double* __restrict__ Lba = F + (int64_t)64 * (ja + 1) + (int64_t)64 * ja * ld;
         for (int slot = tid; slot < 1024; slot += 256) {
@@ -245,14 +235,15 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
             const v4f64 aop = S[(cb2 * 4 + ib) * 64 + lane];
 #pragma unroll
             for (int sx = 0; sx < 4; ++sx) {
-                Xb[0][cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], Xa[0][ib][sx], Xb[0][cb2], 0, 0, 0);
-                Xb[1][cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], Xa[1][ib][sx], Xb[1][cb2], 0, 0, 0);
+                X[4 + cb2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[ib][0][sx], X[4 + cb2][0], 0, 0, 0);
+                X[4 + cb2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[sx], X[ib][1][sx], X[4 + cb2][1], 0, 0, 0);
             }
+            if (ib == 3) __builtin_amdgcn_sched_barrier(0);
         }
     __syncthreads();
     fill_diag(ja + 1);
     __syncthreads();
-    trsm(Xb, 64);
+    trsm(std::integral_constant<int, 1>(), 64);
     if (LDL && a.vmax != nullptr) {
         if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
         for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
@@ -264,7 +255,10 @@ template <bool LDL>
 __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int s_val;
-    unsigned long long st_first = 0, st_wait = 0, st_tasks = 0, st_fin = 0;
+    // per-workgroup statistics of the trace option live in LDS (thread 0 only): no registers across the task loop
+    __shared__ unsigned long long s_stat[4];  // first grab, ticks waited, tasks, ticks in the finalization
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    __syncthreads();
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (keeps the thread-id arithmetic out of the task loop's live ranges, as in gemm_nt_tile)
@@ -276,11 +270,11 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
         if (t >= a.ntasks) {
             if (a.wgstat != nullptr && tid == 0) {
                 unsigned long long* w = a.wgstat + (int64_t)blockIdx.x * 8;
-                w[0] = st_first; w[1] = wall_clock64(); w[2] = st_wait; w[3] = st_tasks; w[4] = st_fin;
+                w[0] = s_stat[0]; w[1] = wall_clock64(); w[2] = s_stat[1]; w[3] = s_stat[2]; w[4] = s_stat[3];
             }
             return;
         }
-        if (a.wgstat != nullptr && tid == 0) { if (st_first == 0) st_first = wall_clock64(); ++st_tasks; }
+        if (a.wgstat != nullptr && tid == 0) { if (s_stat[0] == 0) s_stat[0] = wall_clock64(); ++s_stat[2]; }
         const int4 tk = a.tasks[t];
         const int flags = __builtin_amdgcn_readfirstlane(tk.x) & 255, q = __builtin_amdgcn_readfirstlane(tk.x) >> 8;
         const int I = __builtin_amdgcn_readfirstlane(tk.y), J = __builtin_amdgcn_readfirstlane(tk.z);
@@ -289,11 +283,6 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
         unsigned long long* tr = a.trace != nullptr && tid == 0 ? a.trace + (int64_t)t * 8 : nullptr;
         if (tr) { tr[0] = wall_clock64(); tr[6] = 0; tr[7] = 0; }
 
-        v4f64 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
         // k-tiles [0, limit) of this chunk have final operands; the gate blocks at the first k-tile of a tile column that is
         // not final yet (a rare event: the queue is sorted by readiness)
         int limit = 0;
@@ -301,34 +290,71 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             if (kt < limit) return true;
             const unsigned long long w0 = tr ? wall_clock64() : 0;
             const int r = dag_wait_front(a, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kbeg + (kt >> 4), kend, &s_val);
-            if (tr) { const unsigned long long w1 = wall_clock64(); tr[1] = w0; tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; st_wait += w1 - w0; }
+            if (tr) { const unsigned long long w1 = wall_clock64(); tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; s_stat[1] += w1 - w0; }
             if (r < 0) return false;
             limit = (__builtin_amdgcn_readfirstlane(r) - kbeg) * 16;
             return true;
         };
-        // the last chunk of a tile is on the critical path of its row (and through it of the next band): it issues first
-        if (flags & DAG_FINAL) __builtin_amdgcn_s_setprio(3);
-        if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, a.F + row0 + (int64_t)128 * kbeg * a.ld, a.ld,
-                                             (LDL ? a.V : a.F) + col0 + (int64_t)128 * kbeg * a.ld, a.ld, (kend - kbeg) * 16,
-                                             smem_raw, tid, gate))
-            return;
-        // the chunks of one tile are applied in order
-        if (!(flags & DAG_FIRST)) {
+        const double* Ak = a.F + row0 + (int64_t)128 * kbeg * a.ld;
+        const double* Bk = (LDL ? a.V : a.F) + col0 + (int64_t)128 * kbeg * a.ld;
+        auto wait_chunk_order = [&]() -> bool {   // the chunks of one tile are applied in order
+            if (flags & DAG_FIRST) return true;
             const int* word = a.tprog + (int64_t)I * a.ntile + J;
             const unsigned long long w0 = tr ? wall_clock64() : 0;
-            if (!dag_wait_words(a, word, q, word, q, &s_val)) return;
-            if (tr) st_wait += wall_clock64() - w0;
-        }
-        // C(I, J) -= acc (a diagonal tile: lower wave tiles only)
-        if (kend > kbeg)
-            gemm_nt_epilogue<2, 2, 4, 2, false>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, a.F, a.ld, nullptr, nullptr, 0, tid);
-        if (tr) tr[3] = wall_clock64();
+            if (!dag_wait_words(a, word, q, word, q, &s_val)) return false;
+            if (tr) s_stat[1] += wall_clock64() - w0;
+            return true;
+        };
         if ((flags & DAG_FINAL) && !(flags & DAG_BANDACC)) {
+            // Tile-closing task: on the critical path of its row of tiles (and through it of the band the row enters).  The
+            // last tile column is multiplied with every wave owning 32 full rows -- the register layout of the
+            // finalization -- so the tile goes from the accumulators through the two substitutions to memory ONCE:
+            // X = C - acc without a store, no reload (the round trip through memory was 14 + ~5 us of the task's ~78).
+            __builtin_amdgcn_s_setprio(3);
+            // the tile as the earlier chunks left it goes into the accumulators BEFORE the wait for the row's previous tile
+            // column: its load is off the critical path; the K-loop then subtracts (NEG)
+            if (!wait_chunk_order()) return;
+            v4f64 X[8][2];
+            {
+                const int lane = tid & 63, w = tid >> 6;
+                const double* Cs = a.F + (row0 + 32 * w + (lane & 15)) + (col0 + (lane >> 4)) * a.ld;
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double* cp = Cs + (int64_t)(16 * cb + 4 * r) * a.ld;
+                        X[cb][0][r] = cp[0];
+                        X[cb][1][r] = cp[16];
+                    }
+            }
+            if (kend > kbeg && !gate(0)) return;   // one tile column: its operands are final at once
+            (void)gemm_nt_mainloop3<2, 8, true>(X, Ak, a.ld, Bk, a.ld, (kend - kbeg) * 16, smem_raw, tid);
+            // (new live ranges: the register pressure of the finalization below must not push the accumulators of the
+            // K-loop above into scratch)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(X[i][0])); asm volatile("" : "+v"(X[i][1])); }
+            if (tr) tr[1] = tr[3] = wall_clock64();  // K-loop done = tile applied
             // the diagonal blocks of tile column J and L(2J + 1, 2J)
             if (dag_wait_front(a, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return;
-            if (tr) { tr[4] = wall_clock64(); st_wait += tr[4] - tr[3]; }
-            dag_finalize_tile<LDL>(a, row0, col0, 2 * J, smem_raw, tid);
-            if (tr) st_fin += wall_clock64() - tr[4];
+            if (tr) { tr[4] = wall_clock64(); s_stat[1] += tr[4] - tr[3]; }
+            dag_finalize_tile<LDL>(a, row0, col0, 2 * J, smem_raw, tid, X);
+            if (tr) s_stat[3] += wall_clock64() - tr[4];
+        } else {
+            v4f64 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+            // the last chunk of a band tile is on the critical path of the chain: it issues first
+            if (flags & DAG_FINAL) __builtin_amdgcn_s_setprio(3);
+            // (the two-buffer loop: the three-buffer one is ~10 % slower at three workgroups per CU -- tools/hip/time_kstep.hip)
+            if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, Ak, a.ld, Bk, a.ld, (kend - kbeg) * 16, smem_raw, tid, gate)) return;
+            if (tr) tr[1] = wall_clock64();  // K-loop done
+            if (!wait_chunk_order()) return;
+            // C(I, J) -= acc (a diagonal tile: lower wave tiles only)
+            if (kend > kbeg)
+                gemm_nt_epilogue<2, 2, 4, 2, false>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, a.F, a.ld, nullptr, nullptr, 0, tid);
+            if (tr) tr[3] = wall_clock64();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -417,7 +443,7 @@ int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<i
 
 template <bool LDL>
 static int launch_bulk_t(hipStream_t s, const DagArgs& a, int nwg) {
-    const size_t smem = 2 * 8 * ((128 + 16) + (128 + 16)) * sizeof(double);
+    const size_t smem = TILE3_LDS_BYTES;  // three k-tile buffers of the tile-closing tasks (gemm_nt_mainloop3); chunks use two, the finalization 32 KB
     auto kern = dag_bulk_kernel<LDL>;
     static std::atomic<uint64_t> attr_devs{0};
     int dev = 0;

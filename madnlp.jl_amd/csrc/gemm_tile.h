@@ -184,6 +184,101 @@ __device__ __forceinline__ bool gemm_nt_mainloop(v4f64 (&acc)[WT][WT], const dou
     return true;
 }
 
+// The same K-loop for the 128x128 tile (4 waves x 64x64, k-tiles of 8) with THREE LDS buffers: the LDS-DMA loads of k-tile
+// kt + 2 are issued before k-tile kt is multiplied, so two k-tiles are in flight instead of one.  A workgroup that has its
+// CU for itself (the tile-closing tasks of dag.hip at the end of a factorization: the rows' chains are serial) is bound by
+// the load latency of one k-tile per iteration with two buffers: 16 k-tiles x 2.6 us = 41.7 us per 128-column step
+// (measured, r03 traces) against 0.85 us of MFMA work per k-tile.
+// LDS layout: row k of a buffer sits at k * 128 + 16 * ((k + 1) / 2) doubles -- a pad of 16 in front of every ODD row only:
+// the rows (2j, 2j + 1) a half-wave reads together are 144 doubles apart (bank-conflict free, like the layout of the
+// two-buffer loop that pads every row), 3 x 2 x 1088 doubles = 52 224 B: three workgroups per CU still fit the 160 KB.
+constexpr int TILE3_ROWS = 8 * 128 + 16 * 4;             // doubles per operand per buffer
+constexpr int TILE3_LDS_BYTES = 3 * 2 * TILE3_ROWS * 8;  // 52 224
+__device__ __forceinline__ constexpr int tile3_row(int k) { return k * 128 + 16 * ((k + 1) >> 1); }
+// Wave tile: MI x NI blocks of 16x16 (MI * NI = 16): 4 x 4 = the 64x64 wave tiles of the two-buffer loop (2 x 2 waves);
+// 2 x 8 = every wave owns 32 full rows of the tile (4 x 1 waves) -- the register layout of dag.hip's finalization, so a
+// tile-closing task runs its substitutions on the accumulators without a round trip through memory.
+// NEG: acc -= A B^T (the A fragments are negated on their way to the MFMA).
+template <int MI = 4, int NI = 4, bool NEG = false, class GATE = GemmNoGate>
+__device__ __forceinline__ bool gemm_nt_mainloop3(v4f64 (&acc)[NI][MI], const double* __restrict__ Ag, int64_t lda,
+                                                  const double* __restrict__ Bg, int64_t ldb, int nk, char* smem_raw, int tid,
+                                                  GATE gate = GATE()) {
+    static_assert(MI * NI == 16 && 128 % (16 * MI) == 0, "four waves cover the 128x128 tile");
+    constexpr int BKT = 8, WSM = 16 * MI, WSN = 16 * NI, WAVES_M = 128 / WSM;
+    double* Ls = reinterpret_cast<double*>(smem_raw);  // [3][2][TILE3_ROWS]
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    auto gl_lds = [&](int kt, int buf) {
+        const int64_t k0 = (int64_t)kt * BKT;
+        double* as = Ls + buf * 2 * TILE3_ROWS;
+        double* bs = as + TILE3_ROWS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = wave * 2 + i;
+            const int off = tile3_row(k);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + (k0 + k) * lda + lane * 2),
+                                             (__attribute__((address_space(3))) void*)(as + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bg + (k0 + k) * ldb + lane * 2),
+                                             (__attribute__((address_space(3))) void*)(bs + off), 16, 0, 0);
+        }
+    };
+    if (nk <= 0) return true;
+    if (!gate(0)) return false;
+    gl_lds(0, 0);
+    if (nk > 1) {
+        if (!gate(1)) return false;
+        gl_lds(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt2 = cur == 0 ? 2 : cur - 1;  // (kt + 2) % 3: the buffer the barrier of iteration kt - 1 released
+        const bool more = kt + 2 < nk;
+        if (more) {
+            if (!gate(kt + 2)) return false;
+            gl_lds(kt + 2, nxt2);
+        }
+        const double* as = Ls + cur * 2 * TILE3_ROWS + wm * WSM + l15 + tile3_row(l4);
+        const double* bs = Ls + cur * 2 * TILE3_ROWS + TILE3_ROWS + wn * WSN + l15 + tile3_row(l4);
+#pragma unroll
+        for (int kk = 0; kk < BKT / 4; ++kk) {
+            double af[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {   // row kk * 4 + l4: tile3_row(kk * 4 + l4) = kk * 544 + tile3_row(l4)
+                af[i] = as[kk * (4 * 128 + 32) + i * 16];
+                if (NEG) af[i] = -af[i];
+            }
+#pragma unroll
+            for (int n0 = 0; n0 < NI; n0 += 4) {   // (four B fragments at a time: the 2 x 8 shape has no registers to spare)
+                double bf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bf[i] = bs[kk * (4 * 128 + 32) + (n0 + i) * 16];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[n0 + ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[n0 + ni][mi], 0, 0, 0);
+                if (NI > 4) __builtin_amdgcn_sched_barrier(0);  // (keeps the scheduler from hoisting the next fragments: registers)
+            }
+        }
+        // k-tile kt + 1 must have landed (this wave's share: its vmcnt; the others': the barrier); kt + 2 stays in flight.
+        // A bare s_barrier: __syncthreads() carries a workgroup fence that the compiler implements as vmcnt(0), which would
+        // drain the loads of k-tile kt + 2 here.  The LDS reads of this iteration were consumed by its MFMAs (lgkmcnt waits
+        // in front of them), so the buffer may be overwritten once every wave has passed the barrier.
+        if (more)
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();  // (callers reuse the LDS right away)
+    return true;
+}
+
 // Epilogue of one workgroup tile: lane (l15, l4), reg r of acc[ni][mi] is C[row0+wm*64+mi*16+l15, col0+wn*64+ni*16+l4+4r]
 template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
 __device__ __forceinline__ void gemm_nt_epilogue(const v4f64 (&acc)[WT][WT], int64_t row0, int64_t col0, int64_t M, int64_t N,

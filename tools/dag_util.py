@@ -97,5 +97,5 @@ m = (cls == 1) & (ready >= ntile // 2) & (bulk[:, 2] > 0)
 if m.sum():
     b = bulk[m]
     print(f"tile-closing tasks with chain position >= {ntile//2}: {m.sum()}; mean us: grab->front ready {(b[:,2]-b[:,0]).mean()/100:.1f}, "
-          f"front ready->tile applied (k-step + chunk order + epilogue) {(b[:,3]-b[:,2]).mean()/100:.1f}, diagonal wait {(b[:,4]-b[:,3]).mean()/100:.1f}, "
+          f"front ready->K-loop done {(b[:,1]-b[:,2]).mean()/100:.1f}, K-loop done->tile applied (chunk order + epilogue) {(b[:,3]-b[:,1]).mean()/100:.1f}, diagonal wait {(b[:,4]-b[:,3]).mean()/100:.1f}, "
           f"finalize + publish {(b[:,5]-b[:,4]).mean()/100:.1f}")
