@@ -1,6 +1,6 @@
 """Host-side mirror of the task list of the task-DAG schedule, for the trace tools."""
 
-def dag_tasks(ntile, chunk, band_tiles):
+def dag_tasks(ntile, chunk, band_tiles, js2=None):
     """Python mirror of dag_build_tasks (csrc/dag.hip): list of (ready, cls, J, I, flags, q, kbeg, kend), in queue order."""
     BAND, FINAL, FIRST = 1, 2, 4
     ts = []
@@ -29,12 +29,15 @@ def dag_tasks(ntile, chunk, band_tiles):
         if not band:
             ts.append((K, 1, J, I, FINAL | (FIRST if q == 0 else 0), q, body, K))
 
+    if js2 is None:
+        js2 = (ntile + 1) // 2
     for Jt in range(ntile):
         Js = Jt // 2
-        for I in range(2 * Js + band_tiles, ntile):
+        bt = ntile if Js >= js2 else band_tiles
+        for I in range(2 * Js + bt, ntile):
             add_tile(I, Jt, Jt, False)
         if 2 * Js - 2 > 0:
-            for I in range(max(2 * Js, Jt), min(2 * Js + band_tiles, ntile)):
+            for I in range(max(2 * Js, Jt), min(2 * Js + bt, ntile)):
                 add_tile(I, Jt, 2 * Js - 2, True)
     ts.sort(key=lambda t: (t[0], t[1], t[2], t[3]))
     return ts

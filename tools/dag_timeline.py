@@ -17,7 +17,7 @@ from dag_tasks import dag_tasks  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 11192
 alg = sys.argv[2] if len(sys.argv) > 2 else "CHOLESKY"
-chunk = int(os.environ.get("MNK_DAG_CHUNK", "8"))
+chunk = int(os.environ.get("MNK_DAG_CHUNK", "12"))
 band = int(os.environ.get("MNK_DAG_BAND", "16"))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):

@@ -62,7 +62,7 @@ span = (W[:, 1].max() - W[:, 0].min()) / 100.0
 print(f"kernel span {span:.0f} us; slot-time not waiting/finalizing: {100*(life.sum()-wait.sum()-fin.sum())/(len(W)*span):.1f} % of slots x span")
 
 # ---- waits by task class (the task list rebuilt as dag_build_tasks does)
-chunk = int(os.environ.get("MNK_DAG_CHUNK", "8"))
+chunk = int(os.environ.get("MNK_DAG_CHUNK", "12"))
 band = int(os.environ.get("MNK_DAG_BAND", "16"))
 Np = (N + 127) // 128 * 128
 ntile = Np // 128
@@ -99,3 +99,16 @@ if m.sum():
     print(f"tile-closing tasks with chain position >= {ntile//2}: {m.sum()}; mean us: grab->front ready {(b[:,2]-b[:,0]).mean()/100:.1f}, "
           f"front ready->K-loop done {(b[:,1]-b[:,2]).mean()/100:.1f}, K-loop done->tile applied (chunk order + epilogue) {(b[:,3]-b[:,1]).mean()/100:.1f}, diagonal wait {(b[:,4]-b[:,3]).mean()/100:.1f}, "
           f"finalize + publish {(b[:,5]-b[:,4]).mean()/100:.1f}")
+
+# ---- anatomy of the body chunks while the machine is saturated (1 .. 6.5 ms): time per k-step and the fixed cost per task
+klen = np.array([t[7] - t[6] for t in ts])
+sat = (cls == 2) & (grab > 1000) & (end < 6500) & (bulk[:, 1] > 0)
+print("body chunks ending in 1..6.5 ms, by length: tasks | grab->K-loop done | ->tile applied (order wait + epilogue) | ->published | us per k-step of the K-loop")
+for n in sorted(set(klen[sat])):
+    m = sat & (klen == n)
+    b = bulk[m]
+    kl = (b[:, 1] - b[:, 0]).mean() / 100
+    print(f"  {n:2d} k-steps: {m.sum():5d} | {kl:7.1f} | {(b[:,3]-b[:,1]).mean()/100:6.1f} | {(b[:,5]-b[:,3]).mean()/100:5.1f} | {kl/n:5.1f}")
+b = bulk[sat]
+print(f"  all: K-loop {((b[:,1]-b[:,0]).sum())/1e5:.0f} ms, epilogue {((b[:,3]-b[:,1]).sum())/1e5:.0f} ms, publish {((b[:,5]-b[:,3]).sum())/1e5:.0f} ms of slot-time; "
+      f"k-steps {klen[sat].sum()} -> {(b[:,5]-b[:,0]).sum()/100/klen[sat].sum():.1f} us of slot-time per k-step (41.2 = MFMA-bound at three workgroups per CU)")
