@@ -139,7 +139,16 @@ __device__ __forceinline__ bool dag_wait_words(const DagArgs& a, const int* w0, 
 // X: the tile in that layout, X[cb][ns] = column block cb (0..7) of strip ns -- the accumulators of gemm_nt_mainloop3<2, 8>.
 template <bool LDL>
 __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0, int64_t col0, int ja, char* smem_raw, int tid,
-                                                  v4f64 (&X)[8][2]) {
+                                                  v4f64 (&X)[8][2], unsigned long long* tr) {
+    // trace: six 16-bit stage times (ticks of 10 ns since entry) packed into tr[6] (stages 1..4) and tr[7] (5, 6)
+    const unsigned long long t_in = tr ? wall_clock64() : 0;
+    auto stamp = [&](int stage) {
+        if (tr) {
+            const unsigned long long d = (wall_clock64() - t_in) & 0xffff;
+            if (stage < 4) tr[6] = (stage == 0 ? 0 : tr[6]) | d << (16 * stage);
+            else tr[7] = (stage == 4 ? 0 : tr[7]) | d << (16 * (stage - 4));
+        }
+    };
     v4f64* S = reinterpret_cast<v4f64*>(smem_raw);  // up to 16 blocks x 64 lanes (32 KB of the 36 KB)
     double* F = a.F;
     const int64_t ld = a.ld;
@@ -214,8 +223,10 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
     };
     fill_diag(ja);
     __syncthreads();
+    stamp(0);
     trsm(std::integral_constant<int, 0>(), 0);
     __syncthreads();
+    stamp(1);
     {   // blocks (cb2, ib): -L(jb, ja)[16 cb2 + i][16 ib + k]
         const double* __restrict__ Lba = F + (int64_t)64 * (ja + 1) + (int64_t)64 * ja * ld;
         for (int slot = tid; slot < 1024; slot += 256) {
@@ -228,6 +239,7 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
         }
     }
     __syncthreads();
+    stamp(2);
 #pragma unroll
     for (int cb2 = 0; cb2 < 4; ++cb2)
 #pragma unroll
@@ -241,9 +253,12 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
             if (ib == 3) __builtin_amdgcn_sched_barrier(0);
         }
     __syncthreads();
+    stamp(3);
     fill_diag(ja + 1);
     __syncthreads();
+    stamp(4);
     trsm(std::integral_constant<int, 1>(), 64);
+    stamp(5);
     if (LDL && a.vmax != nullptr) {
         if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
         for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
@@ -337,7 +352,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             // the diagonal blocks of tile column J and L(2J + 1, 2J)
             if (dag_wait_front(a, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return;
             if (tr) { tr[4] = wall_clock64(); s_stat[1] += tr[4] - tr[3]; }
-            dag_finalize_tile<LDL>(a, row0, col0, 2 * J, smem_raw, tid, X);
+            dag_finalize_tile<LDL>(a, row0, col0, 2 * J, smem_raw, tid, X, tr);
             if (tr) s_stat[3] += wall_clock64() - tr[4];
         } else {
             v4f64 acc[4][4];
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             if (!wait_chunk_order()) return;
             // C(I, J) -= acc (a diagonal tile: lower wave tiles only)
             if (kend > kbeg)
-                gemm_nt_epilogue<2, 2, 4, 2, false>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, a.F, a.ld, nullptr, nullptr, 0, tid);
+                gemm_nt_epilogue<2, 2, 4, 2, false, true>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, a.F, a.ld, nullptr, nullptr, 0, tid);
             if (tr) tr[3] = wall_clock64();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

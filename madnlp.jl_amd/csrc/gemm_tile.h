@@ -280,7 +280,9 @@ __device__ __forceinline__ bool gemm_nt_mainloop3(v4f64 (&acc)[NI][MI], const do
 }
 
 // Epilogue of one workgroup tile: lane (l15, l4), reg r of acc[ni][mi] is C[row0+wm*64+mi*16+l15, col0+wn*64+ni*16+l4+4r]
-template <int WM, int WN, int WT, int MODE, bool LDL_EPI>
+// BATCH (MODE 2 / 4): all 16 loads of a column block are issued before its 16 stores -- four memory round trips per tile
+// instead of sixteen (the tasks of dag.hip are 1 .. 12 k-steps long and end with this read-modify-write: 21 us of ~230).
+template <int WM, int WN, int WT, int MODE, bool LDL_EPI, bool BATCH = false>
 __device__ __forceinline__ void gemm_nt_epilogue(const v4f64 (&acc)[WT][WT], int64_t row0, int64_t col0, int64_t M, int64_t N,
                                                  double* C, int64_t ldc, const double* __restrict__ colscale, double* C2,
                                                  int64_t ldc2, int tid) {
@@ -295,6 +297,25 @@ __device__ __forceinline__ void gemm_nt_epilogue(const v4f64 (&acc)[WT][WT], int
     // (Measured on gfx950: replacing this load/subtract/store sequence by no-return L2 atomics or by
     // batching all loads ahead of the stores does not change the kernel time -- with two workgroups
     // per CU the epilogue of one hides behind the k-loop of the other.)
+    if (BATCH && (MODE == 2 || MODE == 4)) {
+#pragma unroll
+        for (int ni = 0; ni < WT; ++ni) {
+            double cv[4][WT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double* cp = C + (wcol + ni * 16 + l4 + 4 * r) * ldc + wrow + l15;
+#pragma unroll
+                for (int mi = 0; mi < WT; ++mi) cv[r][mi] = cp[mi * 16];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* cp = C + (wcol + ni * 16 + l4 + 4 * r) * ldc + wrow + l15;
+#pragma unroll
+                for (int mi = 0; mi < WT; ++mi) cp[mi * 16] = MODE == 4 ? cv[r][mi] + acc[ni][mi][r] : cv[r][mi] - acc[ni][mi][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < WT; ++ni) {
 #pragma unroll

@@ -2,6 +2,7 @@
 #pragma once
 #include <algorithm>
 #include <functional>
+#include <memory>
 
 #include "common.h"
 
@@ -24,6 +25,9 @@ struct mnk_sc {
     // device values
     mnk::DevBuf<double> jac_coo, hess_coo, jt_nz, h_nz, aug_nz, diag_buffer, pr_diag, du_diag;
     void* extra = nullptr;  // unit-private device structures (sparse_kkt.hip), owned by the handle
+    // dies with the handle: a linear solver that keeps a way back to this handle's matrix (mnk_ls::retransfer) holds a
+    // weak reference and refuses to touch a destroyed handle
+    std::shared_ptr<int> alive = std::make_shared<int>(0);
 };
 
 struct mnk_dc {
@@ -36,6 +40,7 @@ struct mnk_dc {
     mnk::DevBuf<double> jis;  // sqrt(D)-scaled, zero-padded inequality Jacobian^T workspace
     int64_t ld_jis = 0, kpad = 0, npad = 0;
     void* extra = nullptr;  // unit-private device structures (dense_kkt.hip), owned by the handle
+    std::shared_ptr<int> alive = std::make_shared<int>(0);  // (see mnk_sc::alive)
 };
 
 struct mnk_ls {

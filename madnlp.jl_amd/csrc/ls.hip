@@ -461,7 +461,14 @@ int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
     if (rc) return rc;
     // (the KKT handle keeps aug_com until the next build_kkt!, so the pivoted tier can fetch the matrix again when
     // the inertia is asked for)
-    ls->retransfer = [ls, sc]() { return transfer_sc(ls, sc); };
+    ls->retransfer = [ls, sc, w = std::weak_ptr<int>(sc->alive)]() {
+        if (w.expired()) {
+            set_error("factorize!: the KKT handle of the last factorize! call was destroyed before its inertia was fetched; the "
+                      "matrix cannot be transferred again for the fall-back tier");
+            return -5;
+        }
+        return transfer_sc(ls, sc);
+    };
     return mnk_ls_run_factorization(ls);
 }
 
@@ -478,7 +485,7 @@ static int factorize_dense_dev(mnk_ls* ls, const double* Adev, int64_t lda) {
     if (rc) return rc;
     rc = transfer_dense(ls, Adev, lda);
     if (rc) return rc;
-    ls->retransfer = [ls, Adev, lda]() { return transfer_dense(ls, Adev, lda); };
+    ls->retransfer = [ls, Adev, lda]() { return transfer_dense(ls, Adev, lda); };  // (callers clear it when Adev's life ends)
     return mnk_ls_run_factorization(ls);
 }
 
@@ -486,7 +493,18 @@ int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc) {
     MNK_REQUIRE(ls && dc, "mnk_ls_factorize_dc: NULL argument");
     MNK_REQUIRE(dc->order == ls->N, "mnk_ls_factorize_dc: order mismatch");
     MNK_HIP(hipSetDevice(ls->ctx->device));
-    return factorize_dense_dev(ls, dc->aug.p, round_up(dc->order, PAD));
+    int rc = factorize_dense_dev(ls, dc->aug.p, round_up(dc->order, PAD));
+    // the way back goes through the handle (its buffer may be reallocated, the handle may be destroyed before the inertia
+    // of this asynchronous call is fetched)
+    ls->retransfer = [ls, dc, w = std::weak_ptr<int>(dc->alive)]() {
+        if (w.expired()) {
+            set_error("factorize!: the KKT handle of the last factorize! call was destroyed before its inertia was fetched; the "
+                      "matrix cannot be transferred again for the fall-back tier");
+            return -5;
+        }
+        return transfer_dense(ls, dc->aug.p, round_up(dc->order, PAD));
+    };
+    return rc;
 }
 
 static int finish_info(mnk_ls* ls, int* info) {

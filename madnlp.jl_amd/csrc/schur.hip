@@ -206,6 +206,7 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
             double* Tk = h->T.p;
             hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(blk * nd), Tk, blk, blk, nd, Ck, nd, nd, blk, 1);
             rc = mnk_ls_solve(ls, Tk, nd, blk, MNK_DEVICE);
+            if (!rc) rc = mnk_ls_check_solve(ls);   // (T_k feeds the Schur complement: an aborted solve must not get that far)
             if (rc) return rc;
             hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Cp.p, ndp, ndp, blkp, Ck, nd, nd, blk, 0);
             hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Tt.p, ndp, ndp, blkp, Tk, blk, blk, nd, 1);
@@ -235,6 +236,19 @@ int mnk_schur_scenario_inertia(mnk_schur* h, int64_t k, int64_t* num_pos, int64_
     return mnk_ls_inertia(h->ls_k[k], num_pos, num_zero, num_neg);
 }
 
+// The solves above run on device-resident vectors and return before the device is done.  A one-launch (persistent) solve
+// that gives up raises a pinned abort word: every stage checks its solvers once at its end (one stream synchronization) and
+// reports the failure now -- the solver has then switched to the stepwise solve, the caller repeats the stage.
+static int schur_check_solves(mnk_schur* h, bool scenarios, bool design) {
+    if (scenarios)
+        for (mnk_ls* l : h->ls_k) {
+            int rc = mnk_ls_check_solve(l);
+            if (rc) return rc;
+        }
+    if (design && h->ls_s) return mnk_ls_check_solve(h->ls_s);
+    return 0;
+}
+
 // Step 3 of solve_kkt! (reference :1040-1049): r_k <- A_k^-1 r_k for the local scenarios, and this rank's
 // contribution  -sum_k C_dk r_k  to the design right-hand side (the caller adds r_d and all-reduces).
 int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d) {
@@ -250,13 +264,14 @@ int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d) {
                            rhs_k + k * h->blk, h->nd, h->blk, -1.0);
     }
     MNK_HIP(hipGetLastError());
-    return 0;
+    return schur_check_solves(h, true, false);
 }
 
 // Step 4: S x_d = r_d (in place, device vector)
 int mnk_schur_solve_s(mnk_schur* h, double* rhs_d) {
     MNK_REQUIRE(h && rhs_d, "mnk_schur_solve_s: NULL argument");
-    return mnk_ls_solve(h->ls_s, rhs_d, 1, h->nd, MNK_DEVICE);
+    int rc = mnk_ls_solve(h->ls_s, rhs_d, 1, h->nd, MNK_DEVICE);
+    return rc ? rc : schur_check_solves(h, false, true);
 }
 
 // Step 5 (reference :1055-1058): x_k = r_k - (A_k^-1 C_dk') x_d, applied as one more solve with A_k on C_dk' x_d
@@ -273,7 +288,7 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
         hipLaunchKernelGGL(schur_sub_kernel, MNK_GRID1(h->blk), rhs_k + k * h->blk, h->tmpk.p, h->blk);
     }
     MNK_HIP(hipGetLastError());
-    return 0;
+    return schur_check_solves(h, true, false);
 }
 
 #undef MNK_GRID1

@@ -635,3 +635,24 @@ def test_blocked_bunchkaufman_at_scale(ctx, kind, N):
           f"backward error {res:.1e} (dsytrs {res_ref:.1e})")
     assert ms < 2000.0, "the blocked tier should take tens of milliseconds at this order"
     M.close()
+
+
+def test_fallback_tier_refuses_a_destroyed_kkt_handle(ctx):
+    """An asynchronous factorize! keeps a way back to the KKT handle's matrix for the pivoted tier.  If the handle is
+    destroyed before the inertia is fetched, the fall-back must fail with a message -- not read freed memory."""
+    from madnlp_jl_amd import _lib as L
+    from madnlp_jl_amd.linear_solver import InertiaException
+    rng = np.random.default_rng(4)
+    n, m = 12, 5
+    k = mj.DenseKKTSystem(n, m, [], [], [], ctx=ctx, opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+    k.jac[:] = rng.standard_normal((m, n))
+    k.pr_diag[:] = 1.0
+    k.pr_diag[:4] = 0.0            # zero pivots in the given order: the static-pivot tier breaks down
+    k.build_kkt()
+    k.linear_solver.factorize_async()
+    import ctypes
+    L.check(L.lib().mnk_dc_destroy(k._h), "mnk_dc_destroy")
+    k._h = ctypes.c_void_p()
+    with pytest.raises(InertiaException, match="destroyed"):
+        k.linear_solver.inertia()
+    k.linear_solver.close()

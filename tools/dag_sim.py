@@ -18,8 +18,8 @@ CUS = 240
 T_K_ALONE = 21.0       # one 128x128x128 k-step of a workgroup that has its CU for itself
 T_K_CU = 18.0          # the same when the CU is saturated (3 workgroups): per-CU time per k-step
 T_TASK = 6.0           # pop + epilogue read-modify-write of the tile
-T_CLOSE_K = 20.0       # the closing task's single k-step on an idle CU (operands were just written by other workgroups) ...
-T_FINAL = 25.0         # ... and its finalization (two triangular solves against the diagonal blocks); both stretch with the
+T_CLOSE_K = 22.0       # the closing task's single k-step on an idle CU (operands were just written by other workgroups) ...
+T_FINAL = 22.0         # ... and its finalization (two triangular solves against the diagonal blocks); both stretch with the
 CLOSE_LOAD = 0.5       # load of the CU: x (1 - CLOSE_LOAD + CLOSE_LOAD * slowdown) -> 42 + 31 us mid-run (measured), ~50 us in the tail
 T_STEP = 98.0          # one strip-column of the chain, diagonal blocks published at +50 / +98
 T_BANDROW = 30.0       # band rows below the diagonal ones finish this long after the last diagonal block
@@ -360,6 +360,10 @@ if __name__ == "__main__":
             g = float(o[4:])
             PRIO_FIRST = False
             PRIO = lambda k, g=g: (k["cls"] == 2, k["J"] - g * k["I"])  # noqa: E731
+        if o.startswith("dynrow"):      # closing tasks and band tiles first, chunks by row (the row the chain needs next)
+            PRIO_FIRST = False
+            w = float(o[7:]) if len(o) > 7 else 0.0
+            PRIO = lambda k, w=w: (k["cls"] == 2, k["I"] + w * k["J"])  # noqa: E731
         r = simulate(ntile, ts, verbose=len(orders) == 1, pools=assign_queues(ts, o), dyn=dyn)
         print(f"{o:12s} total {r['total_us']/1e3:7.3f} ms  chain end {r['chain_end_us']/1e3:7.3f} ms  chain stalled {r['chain_stall_us']/1e3:6.3f} ms  "
               f"compute share of slot-time {r['slot_busy']:.3f}  ({r['ntasks']} tasks, {r['ksteps']} k-steps)")

@@ -94,6 +94,7 @@ for a, b in zip(edges[:-1], edges[1:]):
 
 # ---- anatomy of the tile-closing tasks late in the factorization (the chain-bound part)
 m = (cls == 1) & (ready >= ntile // 2) & (bulk[:, 2] > 0)
+mclose = m.copy()
 if m.sum():
     b = bulk[m]
     print(f"tile-closing tasks with chain position >= {ntile//2}: {m.sum()}; mean us: grab->front ready {(b[:,2]-b[:,0]).mean()/100:.1f}, "
@@ -112,3 +113,15 @@ for n in sorted(set(klen[sat])):
 b = bulk[sat]
 print(f"  all: K-loop {((b[:,1]-b[:,0]).sum())/1e5:.0f} ms, epilogue {((b[:,3]-b[:,1]).sum())/1e5:.0f} ms, publish {((b[:,5]-b[:,3]).sum())/1e5:.0f} ms of slot-time; "
       f"k-steps {klen[sat].sum()} -> {(b[:,5]-b[:,0]).sum()/100/klen[sat].sum():.1f} us of slot-time per k-step (41.2 = MFMA-bound at three workgroups per CU)")
+
+# ---- stages of the finalization of those tile-closing tasks (six 16-bit stage times packed into words 6 and 7)
+m = mclose
+if m.sum():
+    raw = tr[: nt * 8].reshape(nt, 8)
+    w6, w7 = raw[m][:, 6], raw[m][:, 7]
+    st = [((w6 >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) / 100 for i in range(4)] + \
+         [((w7 >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(np.float64) / 100 for i in range(2)]
+    names = ["diagonal block a staged", "substitution a + stores", "L(b, a) staged", "update", "diagonal block b staged", "substitution b + stores"]
+    prev = 0.0
+    print("finalization stages (us, mean): " + ", ".join(f"{n} {s_.mean() - prev_:.1f}" for n, s_, prev_ in zip(names, st, [0.0] + [x.mean() for x in st[:-1]])),
+          f"; end of task {((bulk[m][:,5]-bulk[m][:,4])/100).mean() - st[5].mean():.1f} after the last stage")
