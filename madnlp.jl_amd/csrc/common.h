@@ -111,6 +111,7 @@ struct mnk_ctx {
     hipStream_t sp_dag2 = nullptr, su_dag2 = nullptr;
     int dag_cus2 = 0;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipStream_t s_fill = nullptr;   // background zero-fill of the spare factor buffer (mnk_ls::fact_spare), created on first use
     std::vector<hipEvent_t> ev_panel, ev_next, ev_next2, ev_bdone;
     int num_cu = 256;   // CUs this context may use (the whole device, or its partition)
     int cu_first = 0;   // first CU-mask bit of the partition

@@ -262,7 +262,10 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
     if (LDL && a.vmax != nullptr) {
         if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
         for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
-        if (lane == 0 && vm > 0.0) atomicMax(a.vmax, (unsigned long long)__double_as_longlong(vm));
+        if (lane == 0 && vm > 0.0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(vm);
+            if (bits > __hip_atomic_load(a.vmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.vmax, bits);
+        }
     }
 }
 

@@ -82,7 +82,10 @@ __device__ __forceinline__ void growth_fold(unsigned long long* word, double vm)
     if (word == nullptr) return;
     if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
     for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
-    if ((threadIdx.x & 63) == 0 && vm > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(vm));
+    if ((threadIdx.x & 63) == 0 && vm > 0.0) {   // (look first: the word saturates early, the atomic is then skipped)
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(vm);
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+    }
 }
 
 // X = B L_jj^-T (Cholesky) / V = B L_jj^-T, X = V D^-1 (LDL) for every row below the diagonal block.
@@ -793,15 +796,16 @@ __global__ __launch_bounds__(256) void pchain_kernel(double* __restrict__ F, int
 template <bool LDL>
 __global__ __launch_bounds__(256) void linv64_kernel(double* __restrict__ F, int64_t ld,
                                                       const double* __restrict__ Dblk,
-                                                      double* __restrict__ Linv, const int* __restrict__ info) {
+                                                      double* __restrict__ Linv, const int* __restrict__ info, int blk0) {
     __shared__ double Lt[64 * 64];  // Lt[k*64 + r] = L[r][k]
     __shared__ double rd[64];
     __shared__ double xk[2][64];
     if (*info != 0) return;
-    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    const int64_t blk = (int64_t)blockIdx.x + blk0;  // (the blocks may be inverted in two launches: see mnk_ls_invert_blocks)
+    const int64_t j0 = blk * 64;
     const int c = threadIdx.x & 63;
     const int p = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const double* A = Dblk + (int64_t)blockIdx.x * 4096;  // factored diagonal block, column-major 64x64
+    const double* A = Dblk + blk * 4096;  // factored diagonal block, column-major 64x64
     double* Fd = F + j0 + j0 * ld;
     // stage the block: wave p takes the columns q = 4i + p; lane = row
 #pragma unroll 4
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(256) void linv64_kernel(double* __restrict__ F, int
 #pragma unroll
     for (int i = 0; i < 16; ++i) Lt[c * 64 + 4 * i + p] = s[i];  // Lt[c*64 + r] = inv(L)[r][c]
     __syncthreads();
-    double* out = Linv + (int64_t)blockIdx.x * 4096;  // column-major 64x64: out[r + 64 c]
+    double* out = Linv + blk * 4096;  // column-major 64x64: out[r + 64 c]
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) out[c + 64 * (4 * i + p)] = Lt[c + 64 * (4 * i + p)];
 }
@@ -1034,6 +1038,22 @@ int64_t mnk_ls_effective_nbo(const mnk_ls* ls) {
     return (ls->single_rows > 0 && ls->Np <= ls->single_rows) ? ls->Np : ls->nbo;
 }
 
+// inv(L_jj) of the 64x64 diagonal blocks and the explicit inverses of the 256x256 diagonal triangles (what the solves
+// use) for the strip-columns [sc0, sc1) of 256 columns.  (The Bunch-Kaufman tier always inverts unit-lower blocks.)
+int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
+    if (sc1 <= sc0) return 0;
+    const int64_t b0 = 4 * sc0, b1 = std::min<int64_t>(4 * sc1, ls->Np / NBI);
+    const bool ldl = ls->algo == MNK_LDL || ls->bk_active;
+    if (ldl)
+        hipLaunchKernelGGL(linv64_kernel<true>, dim3((unsigned)(b1 - b0)), dim3(256), 0, s, ls->fact.p, ls->ld, ls->dblk.p,
+                           ls->linv.p, ls->info_dev.p, (int)b0);
+    else
+        hipLaunchKernelGGL(linv64_kernel<false>, dim3((unsigned)(b1 - b0)), dim3(256), 0, s, ls->fact.p, ls->ld, ls->dblk.p,
+                           ls->linv.p, ls->info_dev.p, (int)b0);
+    MNK_HIP(hipGetLastError());
+    return mnk_ls_build_inverses(ls, s, sc0, sc1);
+}
+
 // panel_algo = 5: task-DAG schedule (dag.hip).  The panel stream runs one persistent panel launch per strip-column of 256
 // columns over the BAND only (eight 64-row strips: the four diagonal strips and the four below them), each applying the
 // previous strip-column to its own rows first; ONE persistent kernel on all the other CUs computes every tile below the
@@ -1105,6 +1125,17 @@ static int run_factorization_dag(mnk_ls* ls) {
                                       std::min(ntask, 3 * bulk_cus), mnk_ls_growth_word(ls), trace ? trace + 8 * (size_t)task0 : nullptr,
                                       trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
         if (rc) return rc;
+        // Once the bulk kernel has run out of tasks every tile-closing task is done, hence every strip-column that still
+        // had rows below the band is final: its diagonal blocks are inverted for the solves here, behind the bulk kernel
+        // on its stream, while the chain works on the last strip-columns (all rows in the band: no bulk task left).
+        if (js_begin == 0 && js_end > 0) {
+            const int64_t safe = std::min<int64_t>(js_end, std::max<int64_t>(0, (ntile - ls->dag_band / 2 - 1) / 2));
+            if (strips == (unsigned)ls->dag_band && safe > 0) {
+                rc = mnk_ls_invert_blocks(ls, su, 0, safe);
+                if (rc) return rc;
+                ls->inv_done = safe;
+            }
+        }
         PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
                   mnk_ls_growth_word(ls)};
         if (ldl)
@@ -1149,6 +1180,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
         MNK_HIP(hipMemsetAsync(ls->flag_p.p, 0, (Np / NBI + 1) * sizeof(int), s));
     }
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
+    ls->inv_done = 0;
     // The persistent panel kernel keeps waiting workgroups resident.  Two of them from different contexts on the same
     // CUs can starve each other's diagonal strips (per-XCD dispatch order), so it is used only while this context is
     // the only one on the device; a wait that expires anyway (another process) falls back for good (mnk_ls_fetch_info).
@@ -1327,23 +1359,16 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
         MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
         MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
     }
-    // inverses of the diagonal blocks for the solves (batched, off the critical path of the panels)
-    if (ldl)
-        hipLaunchKernelGGL(linv64_kernel<true>, dim3((unsigned)(Np / NBI)), dim3(256), 0, s, F, ld, ls->dblk.p,
-                           ls->linv.p, ls->info_dev.p);
-    else
-        hipLaunchKernelGGL(linv64_kernel<false>, dim3((unsigned)(Np / NBI)), dim3(256), 0, s, F, ld, ls->dblk.p,
-                           ls->linv.p, ls->info_dev.p);
-    MNK_HIP(hipGetLastError());
-    // explicit inverses of the 256x256 diagonal triangles for the solves (batched, ~20 us)
+    // inverses of the diagonal blocks for the solves (batched, off the critical path of the panels); the task-DAG schedule
+    // has already inverted the strip-columns below ls->inv_done on its bulk stream, under the chain's last steps
     {
-        int rc = mnk_ls_build_inverses(ls, s);
+        int rc = mnk_ls_invert_blocks(ls, s, ls->inv_done, (Np + 255) / 256);
         if (rc) return rc;
     }
     ls->factorized = true;
     ls->info_valid = false;
     ls->bk_active = false;
-    return 0;
+    return mnk_ls_prefill_spare(ls);
 }
 
 int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows, double* Vrows, int64_t ldr, int64_t nrows) {
@@ -1372,10 +1397,7 @@ static int bk_fallback(mnk_ls* ls) {
     if (rc) return rc;
     rc = mnk_ls_run_bunchkaufman(ls);
     if (rc) return rc;
-    hipLaunchKernelGGL(linv64_kernel<true>, dim3((unsigned)(ls->Np / NBI)), dim3(256), 0, s, ls->fact.p, ls->ld,
-                       ls->dblk.p, ls->linv.p, ls->info_dev.p);
-    MNK_HIP(hipGetLastError());
-    rc = mnk_ls_build_inverses(ls, s);
+    rc = mnk_ls_invert_blocks(ls, s, 0, (ls->Np + 255) / 256);
     if (rc) return rc;
     ++ls->bk_count;
     return 0;

@@ -58,6 +58,15 @@ struct mnk_ls {
     int small_tiles_mid = 1000;  // same for the middle-level update inside an outer panel
     mnk::DevBuf<int> tile_ctr;  // one work-queue counter per outer step
     mnk::DevBuf<double> fact, wbuf[2], linv, dblk, inv16, linv256, linv256t, dvec, dinv, xwork;
+    // Sparse sources are scattered into a ZEROED dense buffer (8 Np^2 / 2 bytes of zeros per factorization: 116 us at C3,
+    // HBM-bound).  With `prefill` the zeros are written in the background into a second buffer while the current
+    // factorization / its solves run; the next factorize! swaps the two (costs a second factor buffer, so only up to
+    // prefill_max_rows).
+    mnk::DevBuf<double> fact_spare;
+    hipEvent_t ev_spare = nullptr, ev_free = nullptr;
+    bool spare_zeroed = false, spare_pending = false;
+    int prefill = 1;
+    int64_t prefill_max_rows = 24576;
     int epoch = 0;    // value the hand-off flags of the current factorization carry
     mnk::DevBuf<int> flag_p;
     int panel0_whole = 1;  // look-ahead: the first outer panel is factored on the whole chip before the streams fork
@@ -73,6 +82,7 @@ struct mnk_ls {
     mnk::DevBuf<double> vfull;    // LDL^T: V = L D of every column, same layout as `fact` (B operand of the left-looking updates)
     mnk::DevBuf<unsigned long long> dag_trace;  // diagnostics (option dag_trace): time stamps per bulk task / chain strip
     bool dag_trace_on = false;
+    int64_t inv_done = 0;         // strip-columns whose diagonal blocks the current factorization has already inverted for the solves
     int dag_band = 16;            // 64-row strips per band of the persistent pivot chain (8, 12 or 16; <= the chain's CUs)
     long dag_spin_limit = 1L << 24;  // polls (~0.5 us each) a device-side wait of the schedule may take before it gives up (info = -7)
     int dag_chunk = 12;           // tile columns (of 128) per bulk task (measured at C3 / N = 16384: 8 9.95 / 26.2 ms, 10-16 9.8 / 25.8; every task ends with a ~21 us read-modify-write of its tile)
@@ -117,9 +127,11 @@ struct mnk_ls {
 
 int64_t mnk_ls_effective_nbo(const mnk_ls* ls);
 int mnk_ls_run_factorization(mnk_ls* ls);
+int mnk_ls_prefill_spare(mnk_ls* ls);   // ls.hip: queue the background zero-fill of the spare factor buffer (if one is due)
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);
-int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s);
+int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);  // 256x256 triangles of the strip-columns [sc0, sc1)
+int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);   // 64x64 blocks + 256x256 triangles
 // Right-side triangular solve of `nrows` free-standing rows (multiple of 16) against the factored diagonal block that
 // starts at column j0: V = B L_jj^-T, X = V D^-1 (LDL) / X = B L_jj^-T (Cholesky).  B is read from / X written to
 // Xrows(:, j0:j0+64), V written to Vrows(:, j0:j0+64) (LDL only); both row blocks have leading dimension ldr.

@@ -44,7 +44,12 @@ __device__ __forceinline__ void wave_absmax_to(unsigned long long* word, double 
     double a = fabs(v);
     if (!(a <= DBL_MAX)) a = __longlong_as_double(0x7ff0000000000000LL);
     for (int off = 32; off > 0; off >>= 1) a = fmax(a, __shfl_xor(a, off));
-    if ((threadIdx.x & 63) == 0 && a > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(a));
+    // (a relaxed look first: once the word holds a large value almost every wave skips the atomic -- 80 000 atomics on
+    // one address took 390 us of a 2112-row transfer)
+    if ((threadIdx.x & 63) == 0 && a > 0.0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(a);
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+    }
 }
 
 // (`amax`: optional, max|a_ij| of what is transferred -- the growth guard of BUNCHKAUFMAN's static-pivot tier)
@@ -109,6 +114,7 @@ static void ctx_free(mnk_ctx* c) {
     if (c->su_dag) (void)hipStreamDestroy(c->su_dag);
     if (c->sp_dag2) (void)hipStreamDestroy(c->sp_dag2);
     if (c->su_dag2) (void)hipStreamDestroy(c->su_dag2);
+    if (c->s_fill) (void)hipStreamDestroy(c->s_fill);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -286,6 +292,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
+    if (const char* e = getenv("MNK_PREFILL")) ls->prefill = atoi(e) != 0;
     if (const char* e = getenv("MNK_DAG_MIN_ROWS")) ls->dag_min_rows = atol(e);
     if (const char* e = getenv("MNK_DAG_CHUNK")) ls->dag_chunk = std::max(1, atoi(e));
     if (const char* e = getenv("MNK_DAG_BAND")) ls->dag_band = std::min(16, std::max(8, atoi(e) / 4 * 4));
@@ -333,6 +340,9 @@ int mnk_ls_destroy(mnk_ls* ls) {
     (void)mnk::stream_wait(ls->ctx->stream);
     if (ls->solve_abort) (void)hipHostFree(ls->solve_abort);
     if (ls->pin) (void)hipHostFree(ls->pin);
+    if (ls->ctx->s_fill) (void)mnk::stream_wait(ls->ctx->s_fill);   // a background fill of this solver's spare buffer
+    if (ls->ev_spare) (void)hipEventDestroy(ls->ev_spare);
+    if (ls->ev_free) (void)hipEventDestroy(ls->ev_free);
     mnk_ctx* ctx = ls->ctx;
     delete ls;
     mnk_ctx_child_gone(ctx);
@@ -350,6 +360,8 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         ls->wbuf[1].release();
         return 0;
     }
+    if (!strcmp(key, "prefill")) { ls->prefill = value != 0; return 0; }   // background zero-fill into a second factor buffer
+    if (!strcmp(key, "prefill_max_rows")) { ls->prefill_max_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "single_rows")) {  // systems up to this order: one outer panel, no look-ahead (0: never)
         ls->single_rows = (int64_t)value;
         ls->wbuf[0].release();
@@ -434,12 +446,47 @@ static unsigned long long* amax_word(mnk_ls* ls) {
 }
 
 static int prepare_fill(mnk_ls* ls) {
-    hipStream_t s = ls->ctx->stream;
+    mnk_ctx* ctx = ls->ctx;
+    hipStream_t s = ctx->stream;
     dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np / 2 + 255) / 256));
-    hipLaunchKernelGGL(fill_lower_kernel, grid, dim3(256), 0, s, ls->fact.p, ls->ld, ls->N, ls->Np);
+    bool pre = ls->prefill && ls->Np <= ls->prefill_max_rows;
+    if (pre && !ls->fact_spare.p) {
+        // second factor buffer, events, side stream; if any of it cannot be had the fill stays in line
+        if (ls->fact_spare.alloc(ls->fact.n) != 0) { (void)hipGetLastError(); ls->prefill = 0; pre = false; }
+        if (pre && !ctx->s_fill && hipStreamCreateWithFlags(&ctx->s_fill, hipStreamNonBlocking) != hipSuccess) { ls->prefill = 0; pre = false; }
+        if (pre && (hipEventCreateWithFlags(&ls->ev_spare, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ls->ev_free, hipEventDisableTiming) != hipSuccess)) { ls->prefill = 0; pre = false; }
+        if (pre) MNK_HIP(hipMemsetAsync(ls->fact_spare.p, 0, ls->fact_spare.n * sizeof(double), s));  // (slack behind the matrix)
+    }
+    if (pre && ls->spare_zeroed) {
+        std::swap(ls->fact.p, ls->fact_spare.p);          // the buffer zeroed in the background becomes the factor buffer
+        MNK_HIP(hipStreamWaitEvent(s, ls->ev_spare, 0));
+    } else {
+        hipLaunchKernelGGL(fill_lower_kernel, grid, dim3(256), 0, s, ls->fact.p, ls->ld, ls->N, ls->Np);
+    }
+    ls->spare_pending = pre;   // mnk_ls_prefill_spare() zeroes the other buffer once this factorization is queued
     MNK_HIP(hipGetLastError());
     return 0;
 }
+
+// The other factor buffer (the previous factor, or fresh memory) is free once everything queued so far has run: from then
+// on it is zeroed on the side stream, behind the factorization that was just queued (whose persistent kernels want the
+// whole chip from their first microsecond) and concurrently with the inertia fetch and the solves that follow.
+}  // extern "C"
+int mnk_ls_prefill_spare(mnk_ls* ls) {
+    if (!ls->spare_pending) return 0;
+    ls->spare_pending = false;
+    mnk_ctx* ctx = ls->ctx;
+    dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np / 2 + 255) / 256));
+    MNK_HIP(hipEventRecord(ls->ev_free, ctx->stream));
+    MNK_HIP(hipStreamWaitEvent(ctx->s_fill, ls->ev_free, 0));
+    hipLaunchKernelGGL(fill_lower_kernel, grid, dim3(256), 0, ctx->s_fill, ls->fact_spare.p, ls->ld, ls->N, ls->Np);
+    MNK_HIP(hipGetLastError());
+    MNK_HIP(hipEventRecord(ls->ev_spare, ctx->s_fill));
+    ls->spare_zeroed = true;
+    return 0;
+}
+extern "C" {
 
 static int transfer_sc(mnk_ls* ls, mnk_sc* sc) {
     int rc = prepare_fill(ls);

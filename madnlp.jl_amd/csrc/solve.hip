@@ -39,11 +39,11 @@ __device__ __forceinline__ void mm64x16_acc(const double* As, const double* Bs, 
 __global__ __launch_bounds__(256) void linv256_kernel(const double* __restrict__ F, int64_t ld,
                                                       const double* __restrict__ Linv64, double* __restrict__ Inv,
                                                       double* __restrict__ InvT, int64_t Np,
-                                                      const int* __restrict__ info) {
+                                                      const int* __restrict__ info, int blk0) {
     __shared__ double As[64 * 64];
     __shared__ double Bs[16 * 64];
     if (*info != 0) return;
-    const int64_t blk = blockIdx.x;      // 256-block
+    const int64_t blk = (int64_t)blockIdx.x + blk0;  // 256-block
     const int q = blockIdx.y;            // column block of the inverse
     const int cs = blockIdx.z;           // 16-column slice of that block
     const int64_t j0 = blk * SB;
@@ -518,10 +518,11 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
 using namespace mnk;
 
 // called at the end of the factorization (after linv64_kernel)
-int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s) {
-    const int64_t nblk = (ls->Np + SB - 1) / SB;
+int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
+    const int64_t nblk = std::min<int64_t>(sc1, (ls->Np + SB - 1) / SB) - sc0;
+    if (nblk <= 0) return 0;
     hipLaunchKernelGGL(linv256_kernel, dim3((unsigned)nblk, 4, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->linv.p,
-                       ls->linv256.p, ls->linv256t.p, ls->Np, ls->info_dev.p);
+                       ls->linv256.p, ls->linv256t.p, ls->Np, ls->info_dev.p, (int)sc0);
     MNK_HIP(hipGetLastError());
     return 0;
 }
