@@ -383,6 +383,18 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     if (!strcmp(key, "pp_fuse_rows")) { ls->pp_fuse_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "dag_min_rows")) { ls->dag_min_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "dag_chunk")) {   // tile columns per bulk task of the task-DAG schedule (the task list is rebuilt)
+        MNK_REQUIRE(value >= 1.0 && value <= 64.0, "dag_chunk must be in 1..64");
+        ls->dag_chunk = (int)value;
+        ls->dag_tasks.release();
+        return 0;
+    }
+    if (!strcmp(key, "dag_band")) {    // 64-row strips of the pivot chain's band
+        MNK_REQUIRE(value == 8.0 || value == 12.0 || value == 16.0, "dag_band must be 8, 12 or 16");
+        ls->dag_band = (int)value;
+        ls->dag_tasks.release();
+        return 0;
+    }
     if (!strcmp(key, "dag_spin_limit")) {  // polls a wait of the task-DAG schedule's kernels may take before it gives up
         MNK_REQUIRE(value >= 1024.0, "dag_spin_limit must be at least 1024");
         ls->dag_spin_limit = (long)value;
@@ -749,6 +761,8 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     if (!strcmp(key, "panel_algo")) { *value = ls->algo_now; return 0; }
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
     if (!strcmp(key, "growth")) { *value = ls->last_growth; return 0; }  // BUNCHKAUFMAN: max|d_k| / max|a_ij| of the static-pivot tier
+    if (!strcmp(key, "sign_changes")) { *value = (double)ls->last_sign_changes; return 0; }  // ... and sign changes along its pivots
+    if (!strcmp(key, "bk_count")) { *value = ls->bk_count; return 0; }
     if (!strcmp(key, "dag_ntasks")) { *value = ls->dag_ntasks; return 0; }    // task-DAG schedule: bulk tasks, ...
     if (!strcmp(key, "dag_ntasks1")) { *value = ls->dag_ntasks1; return 0; }  // ... of them in the first phase, ...
     if (!strcmp(key, "dag_js2")) { *value = ls->dag_js2; return 0; }          // ... first strip-column of the second phase

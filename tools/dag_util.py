@@ -74,7 +74,8 @@ bulk = tr[: nt * 8].reshape(nt, 8).astype(np.float64)
 t0 = bulk[:, 0][bulk[:, 0] > 0].min()
 cls = np.array([t[1] for t in ts])
 ready = np.array([t[0] for t in ts])
-gatew = bulk[:, 7] / 100.0
+# (tile-closing tasks reuse words 6 / 7 for the finalization's stage stamps: their gate wait is grab -> front ready)
+gatew = np.where(cls == 1, np.where(bulk[:, 2] > 0, bulk[:, 2] - bulk[:, 0], 0.0), bulk[:, 7]) / 100.0
 diagw = np.where(cls == 1, (bulk[:, 4] - bulk[:, 3]) / 100.0, 0.0)
 dur = (bulk[:, 5] - bulk[:, 0]) / 100.0
 for c, name in ((0, "band-acc"), (1, "tile-closing"), (2, "body chunk")):

@@ -24,11 +24,14 @@ def load(dbfile):
         r = disp.setdefault(d, {"name": name, "start": s, "end": e, "c": {}})
         r["c"][c] = r["c"].get(c, 0.0) + v
     order = sorted(disp.values(), key=lambda r: r["start"])
-    starts = [i for i, r in enumerate(order) if "fill_lower" in r["name"] or "copy_lower_kernel" in r["name"]]
+    starts = [i for i, r in enumerate(order) if "scatter_csc_kernel" in r["name"] or "copy_lower_kernel" in r["name"]]
     ends = [i for i, r in enumerate(order) if "linv256_kernel" in r["name"]]
     i0 = starts[-1]
-    i1 = [e for e in ends if e > i0][0] + 1
-    return order[i0:i1]
+    i1 = [e for e in ends if e > i0][-1] + 1
+    seg = order[i0:i1]
+    # the zero-fill of the buffer belongs to the call even when it ran in the background before it
+    fills = [r for r in order[:i0] if "fill_lower" in r["name"]]
+    return (fills[-1:] if fills else []) + seg
 
 
 def per_kernel(seg, counters):

@@ -28,19 +28,22 @@ def main():
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"| {k} | {a[0]} | {a[1]/1e6:.3f} | {a[1]/a[0]/1e3:.2f} | {a[2]/1e3:.2f} | {a[3]/1e3:.2f} | {100*a[1]/tot:.1f} |")
     text = "\n".join(lines)
-    # span of every factorize! call (first densify kernel -> end of linv256_kernel): the figure that has to agree
+    # span of every factorize! call (densify kernel -> end of the last linv256_kernel): the figure that has to agree
     # with the HIP-event duration bench.py reports as ms_per_factorize
     order = sorted(rows, key=lambda r: r[1])
-    starts = [i for i, r in enumerate(order) if "fill_lower" in r[0]]
+    # (start: the kernel that densifies the matrix into the factor buffer; the zero-fill may run in the background long
+    # before it.  end: the LAST inverse launch before the next start -- the task-DAG schedule inverts in two launches)
+    starts = [i for i, r in enumerate(order) if "scatter_csc_kernel" in r[0] or "copy_lower_kernel" in r[0]]
     ends = [i for i, r in enumerate(order) if "linv256_kernel" in r[0]]
     spans = []
-    for i0 in starts:
-        e = [x for x in ends if x > i0]
+    for n, i0 in enumerate(starts):
+        nxt = starts[n + 1] if n + 1 < len(starts) else len(order)
+        e = [x for x in ends if i0 < x < nxt]
         if e:
-            spans.append((order[e[0]][2] - order[i0][1]) / 1e6)
+            spans.append((order[e[-1]][2] - order[i0][1]) / 1e6)
     if len(spans) > 1:
         sp = spans[1:]
-        text += ("\n\nSpan of one `factorize!` call in this trace (first densify kernel to the end of `linv256_kernel`, "
+        text += ("\n\nSpan of one `factorize!` call in this trace (`scatter_csc_kernel` to the end of the last `linv256_kernel`, "
                  "the two look-ahead streams overlapping inside): mean %.3f ms, min %.3f ms over %d calls "
                  "(to be compared with `ms_per_factorize` of the same run's bench.py JSON line)." % (sum(sp) / len(sp), min(sp), len(sp)))
     print(text)
