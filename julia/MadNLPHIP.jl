@@ -384,6 +384,9 @@ function MadNLP.create_kkt_system(
     check(rc, SymbolicException)
 
     _linear_solver = linear_solver(aug_com; opt = opt_linear_solver)
+    # is_inertia_correct accepts (n, 0, 0) only: "not positive definite" from the static-pivot tier is final, the pivoted
+    # tier could only confirm the rejection
+    _linear_solver isa HipLinearSolver && set_option!(_linear_solver.handle, "accept_only_pd", 1)
     return HipSparseCondensedKKTSystem(
         hess, hess_raw, hess_com, hess_csc_map,
         jac, jt_coo, jt_csc, jt_csc_map,
@@ -537,6 +540,7 @@ function MadNLP.create_kkt_system(
 
     quasi_newton = create_quasi_newton(hessian_approximation, cb, n; options = qn_options)
     _linear_solver = linear_solver(aug_com; opt = opt_linear_solver)
+    (n_eq == 0 && _linear_solver isa HipLinearSolver) && set_option!(_linear_solver.handle, "accept_only_pd", 1)
     return HipDenseCondensedKKTSystem(
         hess, jac, quasi_newton,
         reg, pr_diag, du_diag, l_diag, u_diag, l_lower, u_lower,

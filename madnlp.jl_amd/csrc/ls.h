@@ -102,6 +102,7 @@ struct mnk_ls {
     // Bunch-Kaufman tier (bk.hip): taken when BUNCHKAUFMAN was requested and the static-pivot factorization broke down
     bool bk_requested = false;   // mnk_ls_create was called with MNK_BUNCHKAUFMAN (MNK_LDL: static pivoting only)
     int bk_fallback = 1;         // option: 0 = never take the pivoted tier (a breakdown is reported as num_zero)
+    int accept_only_pd = 0;      // option: the caller accepts positive definite matrices only: "not PD" from the static tier is final
     // Growth guard of the static-pivot tier (BUNCHKAUFMAN only).  The pivots are entries of the successive Schur complements,
     // so max|d_k| / max|a_ij| is a lower bound of the element growth of the elimination; dsytrf's pivoting bounds the growth,
     // static pivoting does not on a matrix that is not quasi-definite (a pivot of 1e-14 is "not zero" and the next Schur

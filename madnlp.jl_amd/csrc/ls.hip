@@ -405,6 +405,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
+    if (!strcmp(key, "accept_only_pd")) { ls->accept_only_pd = value != 0; return 0; }  // see mnk_ls_fetch_info
     // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
     if (!strcmp(key, "bk_growth_tol")) {
         MNK_REQUIRE(value > 1.0, "bk_growth_tol must be > 1");

@@ -222,6 +222,10 @@ class SparseCondensedKKTSystem(_KKTCommon):
         self._host_h = None
         self._diag_buffer = None
         self.linear_solver = linear_solver(self.aug_com, ctx=self.ctx, opt=opt_linear_solver)
+        # is_inertia_correct accepts (n, 0, 0) only (condensed.jl:138-140): "not positive definite" from the static-pivot tier
+        # is final, the pivoted tier could only confirm the rejection
+        if hasattr(self.linear_solver, "set_option"):
+            self.linear_solver.set_option("accept_only_pd", 1)
         L.check(lib.mnk_sc_set_bounds(self._h, nlb, self.ind_lb.ctypes.data, nub, self.ind_ub.ctypes.data, 0),
                 "mnk_sc_set_bounds")
         _LIVE_OBJECTS.add(self)
@@ -603,6 +607,8 @@ class DenseCondensedKKTSystem(_DenseBase):
         self.ind_ineq_shifted = self.ind_ineq + n + ns
         self.aug_com = DeviceDense(self, self._order)
         self.linear_solver = linear_solver(self.aug_com, ctx=self.ctx, opt=opt_linear_solver)
+        if self.n_eq == 0 and hasattr(self.linear_solver, "set_option"):   # is_inertia_correct: num_zero == 0 && num_neg == n_eq
+            self.linear_solver.set_option("accept_only_pd", 1)
         self._setup_device_ops(device_kkt_ops)
 
     def num_variables(self):

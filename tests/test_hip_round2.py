@@ -656,3 +656,33 @@ def test_fallback_tier_refuses_a_destroyed_kkt_handle(ctx):
     with pytest.raises(InertiaException, match="destroyed"):
         k.linear_solver.inertia()
     k.linear_solver.close()
+
+
+def test_condensed_systems_do_not_pay_for_the_pivoted_tier(ctx):
+    """`SparseCondensedKKTSystem` accepts positive definite matrices only (`is_inertia_correct`, reference
+    src/KKT/Sparse/condensed.jl:138-140): a zero pivot of the static-pivot tier proves "not positive definite", so the solver
+    the system creates reports the static tier's counts instead of re-factoring with Bunch-Kaufman pivoting (option
+    accept_only_pd); a stand-alone BUNCHKAUFMAN solver on the same matrix still takes the pivoted tier."""
+    from madnlp_jl_amd.problems import opf_shaped
+    P = opf_shaped("case30", indefinite=True)
+    k = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                    opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+    for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+        getattr(k, f)[:] = getattr(P, f)
+    k.jac[:] = P.jac
+    k.hess[:] = P.hess
+    k.pr_diag[:] = P.pr_diag
+    k.compress_jacobian(); k.compress_hessian(); k.build_kkt()
+    k.linear_solver.factorize()
+    npos, nzero, nneg = k.linear_solver.inertia()
+    assert nneg + nzero > 0 and not k.is_inertia_correct(npos, nzero, nneg)
+    assert k.linear_solver.get_stat("bk_count") == 0          # no pivoted factorization was paid for
+    # the same matrix through a solver of its own: BUNCHKAUFMAN semantics, the pivoted tier may run (zero pivots do occur
+    # only by accident here, so only the inertia is compared)
+    A = k.aug_com.to_dense() if hasattr(k.aug_com, "to_dense") else None
+    if A is not None:
+        M = mj.HipLinearSolver(np.asfortranarray(A), ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+        M.factorize()
+        assert M.inertia() == (npos, nzero, nneg) or M.bk_info()[1] > 0
+        M.close()
+    k.close()

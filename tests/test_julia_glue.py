@@ -104,7 +104,8 @@ def test_option_keys_and_defaults_match_the_library():
     ls_hip = open(os.path.join(ROOT, "madnlp.jl_amd", "csrc", "ls.hip")).read()
     ls_h = open(os.path.join(ROOT, "madnlp.jl_amd", "csrc", "ls.h")).read()
     accepted = set(re.findall(r'!strcmp\(key, "([a-z_0-9]+)"\)', ls_hip))
-    used = set(re.findall(r'set_option!\(h\[\], "([a-z_0-9]+)"', JL))
+    used = set(re.findall(r'set_option!\([A-Za-z_.\[\]]+, "([a-z_0-9]+)"', JL))
+    assert "accept_only_pd" in used      # the condensed KKT systems tell their solver that they accept (n, 0, 0) only
     assert used and used <= accepted, used - accepted
     # every set_option! result is checked (the helper throws on rc != 0)
     assert "check(rc, SymbolicException)" in JL.split("function set_option!")[1].split("end")[0]
