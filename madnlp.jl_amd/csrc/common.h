@@ -127,6 +127,22 @@ int mnk_live_contexts(int device);  // contexts alive on this device in this pro
 void mnk_ctx_child_added(mnk_ctx* ctx);
 void mnk_ctx_child_gone(mnk_ctx* ctx);
 
+namespace mnk {
+// Task-DAG schedule (dag.hip): the launch covers only the band of its strip-column and synchronizes with the persistent
+// bulk kernel through progress counters instead of stream events.  front == nullptr: off.
+struct PpDag {
+    int* front;          // front[t]: leading 128-column tile columns for which the 64-row strip t of L is final
+    const int* af;       // "band tile (I, Jt) accumulated" flags written by the bulk kernel, [I * ntile + Jt]
+    int ntile;
+    int need_front;      // > 0: strips t >= front_from wait for front[t] >= need_front (their rows of the older columns)
+    int front_from;      // 4: one launch per strip-column (stream order covers the strips above); 0: persistent chain
+    int af_tilecol;      // >= 0: first tile column of this launch; its band tiles were pre-accumulated by the bulk kernel
+    long spin_limit;
+    unsigned long long* trace;  // diagnostics: 8 time stamps per strip of this launch
+    unsigned long long* vmax;   // growth monitor (LDL^T with the BUNCHKAUFMAN guard on): receives max|V|, see growth_fold
+};
+}  // namespace mnk
+
 // ---- kernels / launchers shared between translation units -------------------
 namespace mnk {
 

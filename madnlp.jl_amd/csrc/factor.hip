@@ -441,19 +441,6 @@ __device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int targ
     for (int i = 0; i < NB; ++i) seen[i] = v[i];
 }
 
-// Task-DAG schedule (dag.hip): the launch covers only the band of its strip-column and synchronizes with the persistent
-// bulk kernel through progress counters instead of stream events.  front == nullptr: off.
-struct PpDag {
-    int* front;          // front[t]: leading 128-column tile columns for which the 64-row strip t of L is final
-    const int* af;       // "band tile (I, Jt) accumulated" flags written by the bulk kernel, [I * ntile + Jt]
-    int ntile;
-    int need_front;      // > 0: strips t >= front_from wait for front[t] >= need_front (their rows of the older columns)
-    int front_from;      // 4: one launch per strip-column (stream order covers the strips above); 0: persistent chain
-    int af_tilecol;      // >= 0: first tile column of this launch; its band tiles were pre-accumulated by the bulk kernel
-    long spin_limit;
-    unsigned long long* trace;  // diagnostics: 8 time stamps per strip of this launch
-    unsigned long long* vmax;   // growth monitor (LDL^T with the BUNCHKAUFMAN guard on): receives max|V|, see growth_fold
-};
 
 // One strip t of one persistent panel step (the body of ppanel_kernel / pchain_kernel): every thread of the workgroup calls
 // it with the same arguments; waves may return at different times (callers that go on synchronize first).
@@ -882,7 +869,7 @@ __global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsig
 using namespace mnk;
 
 // the word the kernels fold max|V| into (zeroed with max|a_ij| when the matrix was transferred), or NULL: guard off
-static unsigned long long* mnk_ls_growth_word(mnk_ls* ls) {
+unsigned long long* mnk_ls_growth_word(mnk_ls* ls) {
     return (ls->algo == MNK_LDL && ls->bk_requested && ls->bk_fallback && ls->amax_dev.p) ? ls->amax_dev.p + 1 : nullptr;
 }
 
@@ -1054,46 +1041,8 @@ int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
     return mnk_ls_build_inverses(ls, s, sc0, sc1);
 }
 
-// panel_algo = 5: task-DAG schedule (dag.hip).  The panel stream runs one persistent panel launch per strip-column of 256
-// columns over the BAND only (eight 64-row strips: the four diagonal strips and the four below them), each applying the
-// previous strip-column to its own rows first; ONE persistent kernel on all the other CUs computes every tile below the
-// band left-looking.  The two sides meet through progress counters in device memory; no event is recorded or awaited
-// between the fork and the join.
-static int run_factorization_dag(mnk_ls* ls) {
-    mnk_ctx* ctx = ls->ctx;
-    hipStream_t s = ctx->stream;
-    const int64_t Np = ls->Np, ld = ls->ld;
-    const bool ldl = ls->algo == MNK_LDL;
-    double* F = ls->fact.p;
-    const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI), nsc = (int)((Np + 255) / 256);
-    const size_t nflags = (size_t)2 + nblk + 2 * (size_t)ntile * ntile;  // two queue counters | front | af | tprog
-    if (!ls->dag_tasks.p) {
-        // Two band shapes.  Large systems (more than dag_cus2 strips of 64 rows): a shallow band on a handful of CUs, the
-        // rows below it closed by the bulk kernel's own tasks -- the factorization is bound by the bulk work for most of its
-        // columns.  Small systems: EVERY row is a strip of the chain's band (one CU each, on a larger partition) and the
-        // bulk kernel only accumulates: they are bound by the pivot chain from the first column on, and a row of tiles that
-        // the bulk kernel closes advances one tile column per {K = 128 step + finalization} ~ 80 us against the chain's
-        // ~50 us.  (Switching from the first shape to the second in mid-factorization, once dag_cus2 strips remain, is
-        // supported by the task list -- dag_js2 -- and was measured: the deep band needs one CU per strip, the remaining bulk
-        // work of a C3-size system then no longer fits the smaller bulk partition, 10.7 vs 10.3 ms.)
-        const int64_t deep_rows = (int64_t)ctx->dag_cus2 * NBI;
-        ls->dag_js2 = (ctx->dag_cus2 > 0 && Np <= deep_rows) ? 0 : nsc;
-        if (const char* e = getenv("MNK_DAG_JS2")) ls->dag_js2 = std::min(nsc, std::max(0, atoi(e)));
-        std::vector<int> h;
-        ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h);
-        ls->dag_ntasks = (int)(h.size() / 4);
-        if (ls->dag_tasks.alloc(h.size() + 4)) return -2;
-        if (!h.empty()) MNK_HIP(hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        MNK_HIP(mnk::stream_wait(s));  // (h goes out of scope)
-        if (ls->dag_flags.alloc(nflags)) return -2;
-    }
-    if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) return -2;  // V = L D of every column (LDL^T)
-    double* V = ldl ? ls->vfull.p : nullptr;
-    MNK_HIP(hipMemsetAsync(ls->dag_flags.p, 0, nflags * sizeof(int), s));
-    int* qctr = ls->dag_flags.p;
-    int* front = qctr + 2;
-    int* af = front + nblk;
-    int* tprog = af + (size_t)ntile * ntile;
+// The persistent pivot chain of the task-DAG schedule (dag.hip's host driver launches it beside the bulk kernel).
+int mnk_launch_pchain(mnk_ls* ls, hipStream_t sp, const mnk::PpDag& dag, int js_begin, int js_end, unsigned strips) {
     {   // 96 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
         static std::atomic<uint64_t> attr_devs{0};
         int dev = 0;
@@ -1104,66 +1053,18 @@ static int run_factorization_dag(mnk_ls* ls) {
             attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
-    const long spin_limit = ls->dag_spin_limit;
-    unsigned long long* trace = nullptr;
-    if (ls->dag_trace_on) {
-        const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;  // tasks | chain strips | per-workgroup statistics (2 x 512)
-        if (!ls->dag_trace.p && ls->dag_trace.alloc(ntr)) return -2;
-        MNK_HIP(hipMemsetAsync(ls->dag_trace.p, 0, ntr * sizeof(unsigned long long), s));
-        trace = ls->dag_trace.p;
-    }
+    const bool ldl = ls->algo == MNK_LDL;
     const int epoch16 = ls->epoch * 16;
-    const int js2 = ls->dag_js2;
-    // one phase = one persistent bulk launch (update stream) beside one persistent chain launch (panel stream)
-    auto phase = [&](hipStream_t sp, hipStream_t su, int bulk_cus, int task0, int ntask, int* counter, int js_begin, int js_end,
-                     unsigned strips) -> int {
-        MNK_HIP(hipEventRecord(ctx->ev_a, s));
-        MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
-        MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
-        int rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p + 4 * (size_t)task0, ntask,
-                                      front, af, tprog, ntile, counter, ls->info_dev.p, ls->flag_p.p, epoch16, spin_limit,
-                                      std::min(ntask, 3 * bulk_cus), mnk_ls_growth_word(ls), trace ? trace + 8 * (size_t)task0 : nullptr,
-                                      trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
-        if (rc) return rc;
-        // Once the bulk kernel has run out of tasks every tile-closing task is done, hence every strip-column that still
-        // had rows below the band is final: its diagonal blocks are inverted for the solves here, behind the bulk kernel
-        // on its stream, while the chain works on the last strip-columns (all rows in the band: no bulk task left).
-        if (js_begin == 0 && js_end > 0) {
-            const int64_t safe = std::min<int64_t>(js_end, std::max<int64_t>(0, (ntile - ls->dag_band / 2 - 1) / 2));
-            if (strips == (unsigned)ls->dag_band && safe > 0) {
-                rc = mnk_ls_invert_blocks(ls, su, 0, safe);
-                if (rc) return rc;
-                ls->inv_done = safe;
-            }
-        }
-        PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
-                  mnk_ls_growth_word(ls)};
-        if (ldl)
-            hipLaunchKernelGGL(pchain_kernel<true>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
-                               ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing,
-                               dag, js_begin, js_end);
-        else
-            hipLaunchKernelGGL(pchain_kernel<false>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, F, ld, Np, ls->dblk.p, ls->inv16.p,
-                               ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16, ls->debug_pp_missing,
-                               dag, js_begin, js_end);
-        MNK_HIP(hipGetLastError());
-        MNK_HIP(hipEventRecord(ctx->ev_a, sp));
-        MNK_HIP(hipEventRecord(ctx->ev_b, su));
-        MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
-        MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
-        return 0;
-    };
-    if (js2 > 0) {
-        int rc = phase(ctx->sp_dag, ctx->su_dag, ctx->num_cu - ctx->dag_cus, 0, ls->dag_ntasks1, qctr, 0, std::min(js2, nsc),
-                       (unsigned)std::min<int64_t>(ls->dag_band, Np / NBI));
-        if (rc) return rc;
-    }
-    if (js2 < nsc) {
-        const int64_t rows2 = Np - 256 * (int64_t)js2;
-        int rc = phase(ctx->sp_dag2, ctx->su_dag2, ctx->num_cu - ctx->dag_cus2, ls->dag_ntasks1, ls->dag_ntasks - ls->dag_ntasks1,
-                       qctr + 1, js2, nsc, (unsigned)(rows2 / NBI));
-        if (rc) return rc;
-    }
+    double* V = ldl ? ls->vfull.p : nullptr;
+    if (ldl)
+        hipLaunchKernelGGL(pchain_kernel<true>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, ls->fact.p, ls->ld, ls->Np, ls->dblk.p,
+                           ls->inv16.p, ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16,
+                           ls->debug_pp_missing, dag, js_begin, js_end);
+    else
+        hipLaunchKernelGGL(pchain_kernel<false>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, ls->fact.p, ls->ld, ls->Np, ls->dblk.p,
+                           ls->inv16.p, ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16,
+                           ls->debug_pp_missing, dag, js_begin, js_end);
+    MNK_HIP(hipGetLastError());
     return 0;
 }
 
@@ -1200,7 +1101,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     const bool la = ls->lookahead && npanel > 1;
 
     if (ls->algo_now == 5) {
-        int rc = run_factorization_dag(ls);
+        int rc = mnk_ls_run_factorization_dag(ls);
         if (rc) return rc;
     } else if (!la) {
         for (int64_t ko = 0; ko < Np; ko += NBO) {

@@ -130,6 +130,9 @@ int64_t mnk_ls_effective_nbo(const mnk_ls* ls);
 int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_prefill_spare(mnk_ls* ls);   // ls.hip: queue the background zero-fill of the spare factor buffer (if one is due)
 int mnk_ls_fetch_info(mnk_ls* ls);
+int mnk_ls_run_factorization_dag(mnk_ls* ls);   // dag.hip: the task-DAG schedule (panel_algo = 5)
+int mnk_launch_pchain(mnk_ls* ls, hipStream_t sp, const mnk::PpDag& dag, int js_begin, int js_end, unsigned strips);  // factor.hip
+unsigned long long* mnk_ls_growth_word(mnk_ls* ls);  // factor.hip: where the kernels fold max(|d|, |v|) (NULL: guard off)
 int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);  // 256x256 triangles of the strip-columns [sc0, sc1)
 int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);   // 64x64 blocks + 256x256 triangles
