@@ -553,7 +553,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         // had rows below the band is final: its diagonal blocks are inverted for the solves here, behind the bulk kernel
         // on its stream, while the chain works on the last strip-columns (all rows in the band: no bulk task left).
         if (js_begin == 0 && js_end > 0) {
-            const int64_t safe = std::min<int64_t>(js_end, std::max<int64_t>(0, (ntile - ls->dag_band / 2 - 1) / 2));
+            const int64_t safe = std::min<int64_t>(js_end, std::max<int64_t>(0, (ntile - ls->dag_band / 2 - 1) / 2)) & ~(int64_t)1;  // (even: 512-row triangles)
             if (strips == (unsigned)ls->dag_band && safe > 0) {
                 rc = mnk_ls_invert_blocks(ls, su, 0, safe);
                 if (rc) return rc;

@@ -90,6 +90,9 @@ struct mnk_ls {
     int64_t dag_max_rows = 24576; // larger ones too: their trailing updates already run at the update kernel's rate (measured: 22384 +1 %, 30000 -2 %)
     int panel_algo = 5;  // 5: task-DAG schedule (dag.hip: persistent pivot chain + persistent left-looking bulk kernel); 4: persistent panel kernel per 256 columns + one trailing update per outer panel (also what 5 uses outside [dag_min_rows, dag_max_rows]); 1: one launch per piece, the fallback of 4 and 5
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
+    int solve512 = 0;          // 1: the one-launch solve steps over 512 columns (32-row blocks, 512x512 explicit inverses) from solve512_min_rows on.  C3: solve! 0.46 -> 0.33 ms, but the extra inverses cost factorize! +0.37 ms (they finish 0.3 ms after the chain): worth it from ~4 solves per factorization
+    int64_t solve512_min_rows = 4096;
+    mnk::DevBuf<double> linv512, linv512t, linv512tmp;
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
     long ps_spin_limit = 6000000;  // polls (~0.5 us each) a persistent-solve wait may take before it gives up
     int debug_pp_missing = -1;     // tests only: this diagonal strip of every persistent panel launch never publishes

@@ -293,6 +293,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
     if (const char* e = getenv("MNK_PREFILL")) ls->prefill = atoi(e) != 0;
+    if (const char* e = getenv("MNK_SOLVE512")) ls->solve512 = atoi(e) != 0;
     if (const char* e = getenv("MNK_DAG_MIN_ROWS")) ls->dag_min_rows = atol(e);
     if (const char* e = getenv("MNK_DAG_CHUNK")) ls->dag_chunk = std::max(1, atoi(e));
     if (const char* e = getenv("MNK_DAG_BAND")) ls->dag_band = std::min(16, std::max(8, atoi(e) / 4 * 4));
@@ -360,6 +361,8 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         ls->wbuf[1].release();
         return 0;
     }
+    if (!strcmp(key, "solve512")) { ls->solve512 = value != 0; return 0; }   // 512-column steps of the one-launch solve
+    if (!strcmp(key, "solve512_min_rows")) { ls->solve512_min_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "prefill")) { ls->prefill = value != 0; return 0; }   // background zero-fill into a second factor buffer
     if (!strcmp(key, "prefill_max_rows")) { ls->prefill_max_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "single_rows")) {  // systems up to this order: one outer panel, no look-ahead (0: never)

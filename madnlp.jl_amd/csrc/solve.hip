@@ -4,7 +4,7 @@
 //
 // HBM-bound: each sweep reads the lower triangle once (8*N^2/2 bytes).  Both sweeps are
 // right-looking over 256-column steps; the 256x256 diagonal triangles are applied as GEMVs
-// with their explicit inverses, which the factorization computes once (`linv256_kernel`, from
+// with their explicit inverses, which the factorization computes once (`linv_tri_kernel<256>`, from
 // the 64x64 inv(L_jj) blocks), so a step has no substitution chain at all:
 //   forward : x_j = inv(L_jj) b_j (1 workgroup) ; b[below] -= L[below, j] x_j  (64 rows per
 //             workgroup, 4 column quarters per row, coalesced down the columns)
@@ -13,6 +13,9 @@
 // Launches per solve: 4 * N/256.
 #include <mutex>
 
+#include <atomic>
+
+#include "gemm_tile.h"
 #include "ls.h"
 
 namespace mnk {
@@ -34,39 +37,41 @@ __device__ __forceinline__ void mm64x16_acc(const double* As, const double* Bs, 
     }
 }
 
-// One workgroup per (diagonal 256-block, 64-column block q of its inverse, 16-column slice cs of that block): the
+// One workgroup per (diagonal S-block, 64-column block q of its inverse, 16-column slice cs of that block): the
 // columns of an inverse are independent, so 16 workgroups share one 256x256 triangle (102 -> ~30 us critical path).
-__global__ __launch_bounds__(256) void linv256_kernel(const double* __restrict__ F, int64_t ld,
+// S = 256: the step of the stepwise solves and of the 64-row persistent solve; S = 512: the 32-row persistent solve.
+template <int S>
+__global__ __launch_bounds__(256) void linv_tri_kernel(const double* __restrict__ F, int64_t ld,
                                                       const double* __restrict__ Linv64, double* __restrict__ Inv,
                                                       double* __restrict__ InvT, int64_t Np,
                                                       const int* __restrict__ info, int blk0) {
     __shared__ double As[64 * 64];
     __shared__ double Bs[16 * 64];
     if (*info != 0) return;
-    const int64_t blk = (int64_t)blockIdx.x + blk0;  // 256-block
+    const int64_t blk = (int64_t)blockIdx.x + blk0;  // S-row diagonal block
     const int q = blockIdx.y;            // column block of the inverse
     const int cs = blockIdx.z;           // 16-column slice of that block
-    const int64_t j0 = blk * SB;
-    const int nb = (int)((Np - j0 < SB ? Np - j0 : SB) / 64);
-    double* out = Inv + blk * (int64_t)(SB * SB);
-    double* outT = InvT + blk * (int64_t)(SB * SB);
+    const int64_t j0 = blk * S;
+    const int nb = (int)((Np - j0 < S ? Np - j0 : S) / 64);
+    double* out = Inv + blk * (int64_t)(S * S);
+    double* outT = InvT + blk * (int64_t)(S * S);
     const int t = threadIdx.x, ty = t & 15, tx = t >> 4;
     const int col = 64 * q + 16 * cs + tx;  // this thread's column of the inverse
     // zero the part of the slice above the diagonal block (rows of earlier blocks)
     for (int e = t; e < 64 * q * 16; e += 256) {
         const int r = e % (64 * q), c = 64 * q + 16 * cs + e / (64 * q);
-        out[r + (int64_t)c * SB] = 0.0;
-        outT[c + (int64_t)r * SB] = 0.0;
+        out[r + (int64_t)c * S] = 0.0;
+        outT[c + (int64_t)r * S] = 0.0;
     }
     if (q >= nb) {  // padding block of a short last step: zeros
-        for (int e = t; e < 16 * SB; e += 256) {
-            const int r = e % SB, c = 64 * q + 16 * cs + e / SB;
-            out[r + (int64_t)c * SB] = 0.0;
-            outT[c + (int64_t)r * SB] = 0.0;
+        for (int e = t; e < 16 * S; e += 256) {
+            const int r = e % S, c = 64 * q + 16 * cs + e / S;
+            out[r + (int64_t)c * S] = 0.0;
+            outT[c + (int64_t)r * S] = 0.0;
         }
         return;
     }
-    for (int b = q; b < 4; ++b) {
+    for (int b = q; b < S / 64; ++b) {
         double c[4] = {0.0, 0.0, 0.0, 0.0};
         if (b < nb) {
             if (b == q) {
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void linv256_kernel(const double* __restrict__
                     }
                     for (int e = t; e < 1024; e += 256) {
                         const int k = e & 63, j = e >> 6;
-                        Bs[j * 64 + k] = out[(64 * bp + k) + (int64_t)(64 * q + 16 * cs + j) * SB];  // X_{bp,q}[k][j]
+                        Bs[j * 64 + k] = out[(64 * bp + k) + (int64_t)(64 * q + 16 * cs + j) * S];  // X_{bp,q}[k][j]
                     }
                     __syncthreads();
                     mm64x16_acc(As, Bs, c, ty, tx);
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(256) void linv256_kernel(const double* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 64 * b + 4 * ty + i;
-            out[r + (int64_t)col * SB] = c[i];
-            outT[col + (int64_t)r * SB] = c[i];
+            out[r + (int64_t)col * S] = c[i];
+            outT[col + (int64_t)r * S] = c[i];
         }
         __threadfence_block();
         __syncthreads();
@@ -513,6 +518,267 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
 #undef PS_STAMP
 }
 
+
+// ================================================================================================
+// The same solve with steps of 512 columns: half as many steps, each still two hops.  A 64 x 512 slice per thread would be
+// 32 values each for L and for the inverse -- more than the 128 registers a 1024-thread workgroup leaves per lane -- so the
+// blocks are 32 ROWS here (a 32 x 512 slice is 16 values per thread, as before): 16 blocks per step, Np / 32 blocks owned
+// round-robin by G <= #CUs workgroups, the explicit inverses are those of the 512 x 512 diagonal triangles (linv_tri_kernel
+// <512>).  Thread t: row r = t & 31 of a block, chunk q = t >> 5 (32 chunks of 16 step columns) in the forward sweep and in
+// both diagonal roles; in the backward update wave w = t >> 6 takes the 32 rows w of the step, lane (sub = lane & 7: rows
+// 4 sub .. 4 sub + 3, colq = lane >> 3: columns colq + 8 p, p < 4).
+// ================================================================================================
+constexpr int P5_RB = 32, P5_NBS = 16, P5_STEP = 512, P5_NQ = 32, P5_CW = 16;
+
+template <bool LDL>
+__global__ __launch_bounds__(PS_NT) void persistent_solve512_kernel(
+    const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv, const double* __restrict__ InvT,
+    const double* __restrict__ dinv, double* __restrict__ xio, double* __restrict__ pub, int64_t Np, int* abort_flag,
+    const int* __restrict__ info, int near_steps, int nap, long spin_limit, int missing_wg) {
+    __shared__ double run[PS_MAXOWN][P5_RB];
+    __shared__ double ysol[PS_MAXOWN][P5_RB];
+    __shared__ double xs[P5_STEP];
+    __shared__ double part[P5_NQ][P5_RB];
+    if (*info != 0) return;
+    const int t = threadIdx.x, r = t & 31, q = t >> 5;
+    const int G = gridDim.x, g = blockIdx.x;
+    const int nb = (int)(Np / P5_RB);
+    const int nsteps = (nb + P5_NBS - 1) / P5_NBS;
+    const int nown = g < nb ? (nb - g + G - 1) / G : 0;
+    if (nown == 0) return;
+    if (g == missing_wg) return;
+    double* bfin = pub;
+    double* ypub = pub + Np;
+    double* zfin = pub + 2 * Np;
+    double* xpub = pub + 3 * Np;
+    for (int e = t; e < nown * P5_RB; e += PS_NT) run[e >> 5][e & 31] = xio[(int64_t)(g + (e >> 5) * G) * P5_RB + (e & 31)];
+    __syncthreads();
+
+    double a[P5_CW], d[P5_CW];
+    auto dot_chunk = [&](const double (&v)[P5_CW], bool active) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (active) {
+            const double* xq = xs + q * P5_CW;
+#pragma unroll
+            for (int j = 0; j < P5_CW; j += 4) {
+                s0 = fma(v[j], xq[j], s0);
+                s1 = fma(v[j + 1], xq[j + 1], s1);
+                s2 = fma(v[j + 2], xq[j + 2], s2);
+                s3 = fma(v[j + 3], xq[j + 3], s3);
+            }
+        }
+        part[q][r] = (s0 + s1) + (s2 + s3);
+    };
+    auto reduce_parts = [&](int c, int n) {
+        double sm = 0.0;
+        for (int u = 0; u < n; ++u) sm += part[u][c];
+        return sm;
+    };
+    const int qb = q >> 1;  // 32-row block (within the step) that column chunk q belongs to
+
+    // ------------------------------------------------------------------ forward: L y = b
+    int m0 = 0;
+    bool have_d = false;
+    for (int k = 0; k < nsteps && m0 < nown; ++k) {
+        const int b0 = P5_NBS * k, nbk = nb - b0 < P5_NBS ? nb - b0 : P5_NBS;
+        int i = g + m0 * G;
+        if (i < b0 + nbk) {
+            const int li = i - b0;
+            if (!have_d) {
+                const double* Mk = Inv + (int64_t)k * (P5_STEP * P5_STEP) + (li * P5_RB + r) + (int64_t)(q * P5_CW) * P5_STEP;
+                if (qb <= li) {
+#pragma unroll
+                    for (int j = 0; j < P5_CW; ++j) d[j] = Mk[(int64_t)j * P5_STEP];
+                }
+                if (t < P5_RB) ps_publish(bfin + (int64_t)i * P5_RB + t, run[m0][t]);
+            }
+            if (t < P5_RB) xs[li * P5_RB + t] = run[m0][t];
+            if (!ps_gather(bfin + (int64_t)b0 * P5_RB, li * P5_RB, xs, abort_flag, spin_limit)) return;
+            dot_chunk(d, qb <= li);
+            __syncthreads();
+            if (t < P5_RB) {
+                const double v = reduce_parts(t, P5_NQ);
+                ps_publish(ypub + (int64_t)i * P5_RB + t, v);
+                ysol[m0][t] = v;
+            }
+            have_d = false;
+            ++m0;
+            if (m0 >= nown) break;
+            i = g + m0 * G;
+        }
+        const bool diag_next = i < b0 + nbk + P5_NBS;
+        {
+            const double* Fs = F + ((int64_t)i * P5_RB + r) + ((int64_t)b0 * P5_RB + q * P5_CW) * ld;
+            if (qb < nbk) {
+#pragma unroll
+                for (int j = 0; j < P5_CW; ++j) a[j] = Fs[(int64_t)j * ld];
+            }
+            if (diag_next) {
+                const int li = i - (b0 + nbk);
+                const double* Mk = Inv + (int64_t)(k + 1) * (P5_STEP * P5_STEP) + (li * P5_RB + r) + (int64_t)(q * P5_CW) * P5_STEP;
+                if (qb <= li) {
+#pragma unroll
+                    for (int j = 0; j < P5_CW; ++j) d[j] = Mk[(int64_t)j * P5_STEP];
+                }
+            }
+        }
+        if (!ps_gather(ypub + (int64_t)b0 * P5_RB, nbk * P5_RB, xs, abort_flag, spin_limit, i >= b0 + nbk + P5_NBS * near_steps, nap)) return;
+        for (int m = m0; m < nown; ++m) {
+            const int im = g + m * G;
+            if (m > m0 && qb < nbk) {
+                const double* Fs = F + ((int64_t)im * P5_RB + r) + ((int64_t)b0 * P5_RB + q * P5_CW) * ld;
+#pragma unroll
+                for (int j = 0; j < P5_CW; ++j) a[j] = Fs[(int64_t)j * ld];
+            }
+            dot_chunk(a, qb < nbk);
+            __syncthreads();
+            if (t < P5_RB) {
+                const double v = run[m][t] - reduce_parts(t, P5_NQ);
+                run[m][t] = v;
+                if (m == m0 && diag_next) ps_publish(bfin + (int64_t)im * P5_RB + t, v);
+            }
+            if (m + 1 < nown) __syncthreads();
+        }
+        have_d = diag_next;
+    }
+
+    // ------------------------------------------------------------------ backward: L^T x = D^-1 y
+    __syncthreads();
+    for (int e = t; e < nown * P5_RB; e += PS_NT) {
+        const int m = e >> 5, c = e & 31;
+        const double y = ysol[m][c];
+        run[m][c] = LDL ? y * dinv[(int64_t)(g + m * G) * P5_RB + c] : y;
+    }
+    __syncthreads();
+    const int lane = t & 63, sub = lane & 7, colq = lane >> 3, rc = t >> 6;   // update role: wave rc -> rows 32 rc .. of the step
+    int m1 = nown - 1;
+    have_d = false;
+    for (int k = nsteps - 1; k >= 0 && m1 >= 0; --k) {
+        const int b0 = P5_NBS * k, nbk = nb - b0 < P5_NBS ? nb - b0 : P5_NBS;
+        int i = g + m1 * G;
+        if (i >= b0) {
+            const int li = i - b0;
+            const bool act = qb >= li && qb < nbk;
+            if (!have_d) {
+                const double* Mk = InvT + (int64_t)k * (P5_STEP * P5_STEP) + (li * P5_RB + r) + (int64_t)(q * P5_CW) * P5_STEP;
+                if (act) {
+#pragma unroll
+                    for (int j = 0; j < P5_CW; ++j) d[j] = Mk[(int64_t)j * P5_STEP];
+                }
+                if (t < P5_RB) ps_publish(zfin + (int64_t)i * P5_RB + t, run[m1][t]);
+            }
+            if (t < P5_RB) xs[li * P5_RB + t] = run[m1][t];
+            if (!ps_gather(zfin + (int64_t)(i + 1) * P5_RB, (nbk - 1 - li) * P5_RB, xs + (li + 1) * P5_RB, abort_flag, spin_limit)) return;
+            dot_chunk(d, act);
+            __syncthreads();
+            if (t < P5_RB) {
+                const double v = reduce_parts(t, P5_NQ);
+                ps_publish(xpub + (int64_t)i * P5_RB + t, v);
+                xio[(int64_t)i * P5_RB + t] = v;
+            }
+            have_d = false;
+            --m1;
+            if (m1 < 0) break;
+            i = g + m1 * G;
+        }
+        // update role: run_i -= L[step k rows, block i columns]^T * x_k for the owned blocks before the step
+        auto load_slice = [&](int im) {
+            const double* Fs = F + ((int64_t)b0 * P5_RB + 32 * rc + 4 * sub) + ((int64_t)im * P5_RB + colq) * ld;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const v2d lo = *reinterpret_cast<const v2d*>(Fs + (int64_t)(8 * p) * ld);
+                const v2d hi = *reinterpret_cast<const v2d*>(Fs + (int64_t)(8 * p) * ld + 2);
+                a[4 * p] = lo[0];
+                a[4 * p + 1] = lo[1];
+                a[4 * p + 2] = hi[0];
+                a[4 * p + 3] = hi[1];
+            }
+        };
+        const bool diag_next = i >= b0 - P5_NBS;
+        if (rc < nbk) load_slice(i);
+        if (diag_next) {
+            const int li = i - (b0 - P5_NBS);
+            const double* Mk = InvT + (int64_t)(k - 1) * (P5_STEP * P5_STEP) + (li * P5_RB + r) + (int64_t)(q * P5_CW) * P5_STEP;
+            if (qb >= li) {  // step k-1 is a full step
+#pragma unroll
+                for (int j = 0; j < P5_CW; ++j) d[j] = Mk[(int64_t)j * P5_STEP];
+            }
+        }
+        if (!ps_gather(xpub + (int64_t)b0 * P5_RB, nbk * P5_RB, xs, abort_flag, spin_limit, i < b0 - P5_NBS * near_steps, nap)) return;
+        for (int m = m1; m >= 0; --m) {
+            const int im = g + m * G;
+            if (m < m1 && rc < nbk) load_slice(im);
+            // part[rc][col]: one partial sum per 32-row chunk of the step and column of the block
+            if (rc < nbk) {
+                const double x0 = xs[32 * rc + 4 * sub], x1 = xs[32 * rc + 4 * sub + 1], x2 = xs[32 * rc + 4 * sub + 2],
+                             x3 = xs[32 * rc + 4 * sub + 3];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    double sp = (a[4 * p] * x0 + a[4 * p + 1] * x1) + (a[4 * p + 2] * x2 + a[4 * p + 3] * x3);
+                    sp += __shfl_xor(sp, 1);
+                    sp += __shfl_xor(sp, 2);
+                    sp += __shfl_xor(sp, 4);
+                    if (sub == 0) part[rc][colq + 8 * p] = sp;
+                }
+            } else if (lane < P5_RB) {
+                part[rc][lane] = 0.0;
+            }
+            __syncthreads();
+            if (t < P5_RB) {
+                const double v = run[m][t] - reduce_parts(t, P5_NBS);
+                run[m][t] = v;
+                if (m == m1 && diag_next) ps_publish(zfin + (int64_t)im * P5_RB + t, v);
+            }
+            if (m > 0) __syncthreads();
+        }
+        have_d = diag_next;
+    }
+}
+
+
+// ---- 512 x 512 inverses from the 256 x 256 ones (see mnk_ls_build_inverses) --------------------------------------------
+// element (row, col) of triangle t0 + blockIdx.x: the diagonal quadrants are copies, the others start as zeros
+__global__ __launch_bounds__(512) void inv512_assemble_kernel(const double* __restrict__ Inv256, const double* __restrict__ InvT256,
+                                                              double* __restrict__ Inv512, double* __restrict__ InvT512, int64_t Np,
+                                                              int t0, const int* __restrict__ info) {
+    if (*info != 0) return;
+    const int64_t t = (int64_t)blockIdx.x + t0;
+    const int col = blockIdx.y, row = threadIdx.x;
+    const int64_t nblk256 = (Np + 255) / 256;
+    double v = 0.0, vt = 0.0;
+    const int qr = row >> 8, qc = col >> 8;
+    if (qr == qc && 2 * t + qr < nblk256) {
+        const int64_t off = (2 * t + qr) * 65536 + (row & 255) + (int64_t)(col & 255) * 256;
+        v = Inv256[off];
+        vt = InvT256[off];
+    }
+    Inv512[t * 262144 + row + (int64_t)col * 512] = v;
+    InvT512[t * 262144 + row + (int64_t)col * 512] = vt;
+}
+// STAGE 1: Tt = A^-T C'; STAGE 2 (blockIdx.z = 0): Inv512[lower left] -= D^-1 Tt' ; (1): InvT512[upper right] -= Tt D^-T
+template <int STAGE>
+__global__ __launch_bounds__(256, 3) void inv512_gemm_kernel(const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv256,
+                                                             const double* __restrict__ InvT256, double* __restrict__ Tt,
+                                                             double* __restrict__ Inv512, double* __restrict__ InvT512, int64_t Np,
+                                                             int t0, const int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (*info != 0) return;
+    const int64_t t = (int64_t)blockIdx.x + t0;
+    if ((2 * t + 1) * 256 >= Np) return;   // no second 256-block in this (last) triangle
+    const int tm = blockIdx.y & 1, tn = blockIdx.y >> 1;
+    const double* IA_t = InvT256 + (2 * t) * 65536;
+    const double* ID = Inv256 + (2 * t + 1) * 65536;
+    double* T = Tt + t * 65536;
+    if (STAGE == 1) {
+        const double* C = F + (512 * t + 256) + (512 * t) * ld;
+        gemm_nt_tile<2, 2, 4, 1, false, 0, 8>(tm, tn, 256, 256, 256, IA_t, 256, C, ld, T, 256, nullptr, nullptr, 0, smem_raw);
+    } else if (blockIdx.z == 0) {
+        gemm_nt_tile<2, 2, 4, 0, false, 0, 8>(tm, tn, 256, 256, 256, ID, 256, T, 256, Inv512 + t * 262144 + 256, 512, nullptr, nullptr, 0, smem_raw);
+    } else {
+        gemm_nt_tile<2, 2, 4, 0, false, 0, 8>(tm, tn, 256, 256, 256, T, 256, ID, 256, InvT512 + t * 262144 + (int64_t)256 * 512, 512, nullptr, nullptr, 0, smem_raw);
+    }
+}
+
 }  // namespace mnk
 
 using namespace mnk;
@@ -521,8 +787,43 @@ using namespace mnk;
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
     const int64_t nblk = std::min<int64_t>(sc1, (ls->Np + SB - 1) / SB) - sc0;
     if (nblk <= 0) return 0;
-    hipLaunchKernelGGL(linv256_kernel, dim3((unsigned)nblk, 4, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->linv.p,
+    hipLaunchKernelGGL(linv_tri_kernel<256>, dim3((unsigned)nblk, 4, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->linv.p,
                        ls->linv256.p, ls->linv256t.p, ls->Np, ls->info_dev.p, (int)sc0);
+    // 512-row triangles (the 32-row persistent solve): those that lie entirely inside [sc0, sc1) -- a caller that inverts in
+    // two ranges cuts at an even strip-column.  Built from the 256-row inverses on the MFMA tile kernel:
+    //   inv [A 0; C D] = [A^-1 0; -D^-1 C A^-1  D^-1],   T' = A^-T C' (stage 1),  X = -D^-1 T,  X' = -T' D^-T (stage 2)
+    // (a 512 x 512 triangle inverted block by block with the scalar kernel above costs 35 dependent 64x64x16 products:
+    // +0.63 ms on factorize! at C3, measured).
+    if (ls->solve512 && ls->Np >= ls->solve512_min_rows && ls->Np % 512 != 384 && !ls->linv512.p) {
+        const size_t ntri = (size_t)((ls->Np + 511) / 512);
+        if (ls->linv512.alloc(ntri * 512 * 512) || ls->linv512t.alloc(ntri * 512 * 512) || ls->linv512tmp.alloc(ntri * 256 * 256)) {
+            (void)hipGetLastError();
+            ls->linv512.release(); ls->linv512t.release(); ls->linv512tmp.release();
+            ls->solve512 = 0;
+        }
+    }
+    if (ls->solve512 && ls->linv512.p) {
+        const int64_t nsc = (ls->Np + SB - 1) / SB;
+        const int64_t t0 = (sc0 + 1) / 2, t1 = std::min<int64_t>(sc1, nsc) == nsc ? (ls->Np + 511) / 512 : sc1 / 2;
+        if (t1 > t0) {
+            const unsigned nt = (unsigned)(t1 - t0);
+            static std::atomic<uint64_t> attr_devs{0};
+            int dev = 0;
+            MNK_HIP(hipGetDevice(&dev));
+            const int smem = 2 * 8 * ((128 + 16) + (128 + 16)) * (int)sizeof(double);
+            if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+                MNK_HIP(hipFuncSetAttribute((const void*)inv512_gemm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                MNK_HIP(hipFuncSetAttribute((const void*)inv512_gemm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+            }
+            hipLaunchKernelGGL(inv512_assemble_kernel, dim3(nt, 512), dim3(512), 0, s, ls->linv256.p, ls->linv256t.p, ls->linv512.p,
+                               ls->linv512t.p, ls->Np, (int)t0, ls->info_dev.p);
+            hipLaunchKernelGGL(inv512_gemm_kernel<1>, dim3(nt, 4, 1), dim3(256), smem, s, ls->fact.p, ls->ld, ls->linv256.p, ls->linv256t.p,
+                               ls->linv512tmp.p, ls->linv512.p, ls->linv512t.p, ls->Np, (int)t0, ls->info_dev.p);
+            hipLaunchKernelGGL(inv512_gemm_kernel<2>, dim3(nt, 4, 2), dim3(256), smem, s, ls->fact.p, ls->ld, ls->linv256.p, ls->linv256t.p,
+                               ls->linv512tmp.p, ls->linv512.p, ls->linv512t.p, ls->Np, (int)t0, ls->info_dev.p);
+        }
+    }
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -557,6 +858,22 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
         double* pub = xdev + 2 * Np;
         hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<unsigned long long*>(pub), 4 * Np);
+        const int64_t nb32 = Np / P5_RB;
+        const int G5 = (int)std::min<int64_t>(nb32, ls->ctx->num_cu);
+        if (ls->solve512 && ls->linv512.p && (nb32 + G5 - 1) / G5 <= PS_MAXOWN && (G5 >= P5_NBS || nb32 <= G5)) {
+            // steps of 512 columns, blocks of 32 rows (half the steps, the same two hops per step)
+            if (ldl)
+                hipLaunchKernelGGL(persistent_solve512_kernel<true>, dim3(G5), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv512.p,
+                                   ls->linv512t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p, ps_near, ps_nap,
+                                   ls->ps_spin_limit, ls->debug_ps_missing);
+            else
+                hipLaunchKernelGGL(persistent_solve512_kernel<false>, dim3(G5), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv512.p,
+                                   ls->linv512t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p, ps_near, ps_nap,
+                                   ls->ps_spin_limit, ls->debug_ps_missing);
+            MNK_HIP(hipGetLastError());
+            MNK_HIP(hipEventRecord(last, s));
+            return 0;
+        }
         if (ldl)
             hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv256.p,
                                ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p,

@@ -686,3 +686,33 @@ def test_condensed_systems_do_not_pay_for_the_pivoted_tier(ctx):
         assert M.inertia() == (npos, nzero, nneg) or M.bk_info()[1] > 0
         M.close()
     k.close()
+
+
+@pytest.mark.parametrize("N,alg", [(4096, "CHOLESKY"), (5000, "LDL"), (6100, "LDL"), (11192, "LDL")])
+def test_solve_with_512_column_steps_matches_the_256_column_solve(ctx, N, alg):
+    """Option solve512: the one-launch solve with 32-row blocks, 512-column steps and 512 x 512 explicit inverses assembled from
+    the 256 x 256 ones on the MFMA tile kernel (half the steps per sweep).  Same solution as the default solve to rounding,
+    same backward error; orders whose padded size leaves a 384-row last triangle keep the 256-column steps."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(N)
+    R = torch.randn(N, 64, dtype=torch.float64, device="cuda", generator=g)
+    A = R @ R.T + torch.diag(torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 10 + 1.0)
+    if alg == "LDL":
+        h = N // 3
+        A[N - h:, N - h:] = -(A[N - h:, N - h:] + 2.0 * torch.eye(h, dtype=torch.float64, device="cuda") * N ** 0.5)
+    b = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+    xs = []
+    for s512 in (0, 1):
+        x = b.clone()
+        torch.cuda.synchronize()   # A, b, x were produced on torch's stream, the solver works on the context's
+        ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
+        ls.set_option("solve512", s512)
+        ls.factorize()
+        ls.solve_linear_system(x)
+        ctx.synchronize()
+        xs.append(x.cpu().numpy())
+        ls.close()
+    An = torch.linalg.matrix_norm(A, ord=float("inf")).item()
+    res = (torch.abs(A @ torch.from_numpy(xs[1]).cuda() - b).max() / (An * np.abs(xs[1]).max() + torch.abs(b).max())).item()
+    assert res <= 1e-14, res
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-10 * np.abs(xs[0]).max()

@@ -25,7 +25,7 @@ def load(dbfile):
         r["c"][c] = r["c"].get(c, 0.0) + v
     order = sorted(disp.values(), key=lambda r: r["start"])
     starts = [i for i, r in enumerate(order) if "scatter_csc_kernel" in r["name"] or "copy_lower_kernel" in r["name"]]
-    ends = [i for i, r in enumerate(order) if "linv256_kernel" in r["name"]]
+    ends = [i for i, r in enumerate(order) if "linv_tri_kernel" in r["name"]]
     i0 = starts[-1]
     i1 = [e for e in ends if e > i0][-1] + 1
     seg = order[i0:i1]
