@@ -244,6 +244,11 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         double aopinv[4];
+        // the finished columns of block column b (Xf[cb][tt]: pivot group tt of block (cb, b)) live OUTSIDE the accumulators:
+        // a kernel with more than 256 registers gets its MFMA accumulators in AGPRs, where overwriting one component of a
+        // block costs a round trip of the whole block through VGPRs (~50 v_accvgpr moves per pivot group, 18 % of the
+        // kernel's instructions); the finished components of Lt are dead from here on (later updates add zeros to them)
+        v4d Xf[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int t = 4 * b + tt;
@@ -311,7 +316,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
                 X[cb] = x;
                 V[cb] = v;
                 if (LDL) vm = fmax(vm, fabs(v));
-                Lt[cb][b][tt] = x;
+                Xf[cb][tt] = x;
             }
             // ---- 3. rank-4 update of the trailing blocks: acc(cb2, cb1) -= X[cb1] (V|X)[cb2]^T
 #pragma unroll
@@ -332,7 +337,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             for (int pg = 0; pg < 4; ++pg) {
                 const v4d out = __builtin_amdgcn_mfma_f64_16x16x4f64(aopinv[pg], T[pg], zero4, 0, 0, 0);
                 Y[pg] = out[pg];
-                if (pg < 3) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lt[b][b][pg], Y[pg], T, 0, 0, 0);
+                if (pg < 3) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xf[b][pg], Y[pg], T, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -345,8 +350,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
         // (l15 = i, l4 = i & 3) -- and D^-1 is the same fast_rcp of the same recorded pivot (0 recorded -> harmless pivot 1)
         {
             const int rsel = l15 >> 2;
-            const v4d dd = Lt[b][b];
-            const double dsel = rsel == 0 ? dd[0] : (rsel == 1 ? dd[1] : (rsel == 2 ? dd[2] : dd[3]));
+            const double dsel = rsel == 0 ? Xf[b][0] : (rsel == 1 ? Xf[b][1] : (rsel == 2 ? Xf[b][2] : Xf[b][3]));
             if ((l15 & 3) == l4) {
                 put<WT>(dvec + j0 + 16 * b + l15, dsel);
                 put<WT>(dinv + j0 + 16 * b + l15, LDL ? fast_rcp(dsel == 0.0 ? 1.0 : dsel) : 1.0);
@@ -357,7 +361,7 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
         for (int cb = b; cb < 4; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Lt[cb][b][r];
+                const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Xf[cb][r];
                 put<WT>(Dout + (16 * cb + l15) + 64 * (16 * b + l4 + 4 * r), v);
                 if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
             }

@@ -8,11 +8,13 @@
 namespace mnk { void set_error(const char*, ...) {} }
 using namespace mnk;
 template <int V>
-__global__ __launch_bounds__(256, 3) void k(const double* A, const double* B, double* C, int ld, unsigned long long* out, int reps) {
+__global__ __launch_bounds__(256, 3) void k(const double* A, const double* B, double* C, int ld, unsigned long long* out, int reps, int share) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int rep = 0; rep < reps; ++rep) {
-        const double* Ag = A + 128 * (size_t)blockIdx.x + (size_t)rep * 128 * ld;   // fresh 128 columns per repetition
-        const double* Bg = B + 128 * (size_t)blockIdx.x + (size_t)rep * 128 * ld;
+        // share > 0: only `share` distinct row blocks per operand (everything after the first touch is an L2 hit)
+        const size_t rb = share > 0 ? blockIdx.x % share : blockIdx.x;
+        const double* Ag = A + 128 * rb + (size_t)rep * 128 * ld;   // fresh 128 columns per repetition
+        const double* Bg = B + 128 * rb + (size_t)rep * 128 * ld;
         for (int pass = 0; pass < 2; ++pass) {
             __syncthreads();
             const unsigned long long t0 = wall_clock64();
@@ -38,10 +40,10 @@ __global__ __launch_bounds__(256, 3) void k(const double* A, const double* B, do
     }
 }
 template <int V>
-void run(const char* name, int nwg, const double* A, const double* B, double* C, int ld, unsigned long long* out, int reps) {
+void run(const char* name, int nwg, const double* A, const double* B, double* C, int ld, unsigned long long* out, int reps, int share = 0) {
     const size_t smem = V == 2 ? 2 * 8 * 288 * 8 : TILE3_LDS_BYTES;
     hipFuncSetAttribute((const void*)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k<V>, dim3(nwg), dim3(256), smem, 0, A, B, C, ld, out, reps);
+    hipLaunchKernelGGL(k<V>, dim3(nwg), dim3(256), smem, 0, A, B, C, ld, out, reps, share);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)nwg * reps * 2);
     hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
@@ -60,6 +62,11 @@ int main() {
         run<3>("three buffers, 64x64 wave tiles", nwg, A, B, C, ld, out, reps);
         hipMemset(A, 0, (size_t)ld * 128 * reps * 8); hipMemset(B, 0, (size_t)ld * 128 * reps * 8);
         run<4>("three buffers, 32x128 wave tiles", nwg, A, B, C, ld, out, reps);
+    }
+    for (int share : {1, 8, 64}) {
+        printf("operands shared by the workgroups (%d distinct row blocks):\n", share);
+        run<2>("two buffers, 64x64 wave tiles", 768, A, B, C, ld, out, reps, share);
+        run<3>("three buffers, 64x64 wave tiles", 768, A, B, C, ld, out, reps, share);
     }
     return 0;
 }
