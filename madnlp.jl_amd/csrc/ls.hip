@@ -363,6 +363,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     if (!strcmp(key, "solve512")) { ls->solve512 = value != 0; return 0; }   // 512-column steps of the one-launch solve
     if (!strcmp(key, "solve512_min_rows")) { ls->solve512_min_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "linv_mfma")) { ls->linv_mfma = value != 0.0; return 0; }
     if (!strcmp(key, "prefill")) { ls->prefill = value != 0; return 0; }   // background zero-fill into a second factor buffer
     if (!strcmp(key, "prefill_max_rows")) { ls->prefill_max_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "single_rows")) {  // systems up to this order: one outer panel, no look-ahead (0: never)

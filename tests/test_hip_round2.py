@@ -716,3 +716,29 @@ def test_solve_with_512_column_steps_matches_the_256_column_solve(ctx, N, alg):
     res = (torch.abs(A @ torch.from_numpy(xs[1]).cuda() - b).max() / (An * np.abs(xs[1]).max() + torch.abs(b).max())).item()
     assert res <= 1e-14, res
     assert np.abs(xs[0] - xs[1]).max() <= 1e-10 * np.abs(xs[0]).max()
+
+
+@pytest.mark.parametrize("N,alg", [(700, "LDL"), (2048, "CHOLESKY"), (2100, "LDL"), (5000, "CHOLESKY"), (11192, "LDL")])
+def test_inverses_from_the_matrix_cores_match_the_scalar_ones(ctx, N, alg):
+    """The 256 x 256 explicit inverses the solves apply come from an MFMA kernel that pushes identity rows through the panel
+    factorization's row operations (option linv_mfma, default) instead of the scalar block substitution: same solutions
+    (orders with a 128-row last triangle included), backward error at rounding level."""
+    rng = np.random.default_rng(N)
+    R = rng.standard_normal((N, 48))
+    A = R @ R.T + np.diag(rng.random(N) * 10 + 1.0)
+    if alg == "LDL":
+        h = N // 3
+        A[N - h:, N - h:] = -(A[N - h:, N - h:] + 2.0 * np.eye(h) * N ** 0.5)
+    b = rng.standard_normal(N)
+    xs = []
+    for mfma in (0, 1):
+        ls = mj.HipLinearSolver(np.asfortranarray(A), ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
+        ls.set_option("linv_mfma", mfma)
+        ls.factorize()
+        x = b.copy()
+        ls.solve_linear_system(x)
+        xs.append(x)
+        ls.close()
+    res = np.abs(A @ xs[1] - b).max() / (np.abs(A).sum(axis=1).max() * np.abs(xs[1]).max() + np.abs(b).max())
+    assert res <= 1e-14, res
+    assert np.abs(xs[0] - xs[1]).max() <= 1e-10 * np.abs(xs[0]).max()
