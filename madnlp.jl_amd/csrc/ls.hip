@@ -294,6 +294,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
     if (const char* e = getenv("MNK_PREFILL")) ls->prefill = atoi(e) != 0;
     if (const char* e = getenv("MNK_SOLVE512")) ls->solve512 = atoi(e) != 0;
+    if (const char* e = getenv("MNK_LINV_MFMA")) ls->linv_mfma = atoi(e) != 0;
     if (const char* e = getenv("MNK_DAG_MIN_ROWS")) ls->dag_min_rows = atol(e);
     if (const char* e = getenv("MNK_DAG_CHUNK")) ls->dag_chunk = std::max(1, atoi(e));
     if (const char* e = getenv("MNK_DAG_BAND")) ls->dag_band = std::min(16, std::max(8, atoi(e) / 4 * 4));

@@ -121,13 +121,17 @@ __global__ __launch_bounds__(256) void linv_tri_kernel(const double* __restrict_
 }
 
 // The same inverses on the matrix cores (the default).  Rows 64 q .. 64 q + 63 of Y = inv(L)^T of one 256-row triangle are
-// what the panel factorization's row operations make of 64 rows of the identity: for j = q..3  Y_j = T_j L_jj^-T (block
-// substitution with the 16x16 inverses the pivot kernel left in inv16, as in trsm64_mfma_kernel), then
-// T_c -= Y_j L_cj^T for the later column blocks c.  One workgroup per (triangle, q), wave w = 16 rows in registers (C^T
-// layout: register r of 16-column block g at lane (l15, l4) is Y[16 w + l15][16 g + l4 + 4 r]); the 64x64 blocks L_cj go
-// through LDS.  ~20 us per workgroup against ~70 of the scalar kernel above: 167 + 69 us of every factorize! at C3.
-__global__ __launch_bounds__(256) void linv256_mfma_kernel(const double* __restrict__ F, int64_t ld, const double* __restrict__ Dblk0,
-                                                           const double* __restrict__ inv16, double* __restrict__ Inv,
+// what block row operations make of 64 rows of the identity: for j = q..3  Y_j = T_j inv(L_jj)^T (one product with the 64x64
+// inverse of linv64_kernel -- the very formula of the scalar kernel above, transposed), then T_c -= Y_j L_cj^T for the later
+// column blocks c.  One workgroup per (triangle, q), wave w = 16 rows in registers (C^T layout: register r of 16-column
+// block g at lane (l15, l4) is Y[16 w + l15][16 g + l4 + 4 r]); the 64x64 blocks L_cj go through LDS.  ~25 us per
+// workgroup against ~70 of the scalar kernel: 167 + 69 us of every factorize! at C3.
+// (Block substitution with the 16x16 inverses of the pivot kernel instead of the 64x64 ones -- what the factorization's own
+// triangular solves use -- was built first and is NOT good enough here: an explicit inverse is applied to every right-hand
+// side, and on the AC-OPF systems (condition numbers ~1e19) the interior-point loop's Richardson refinement then diverged
+// in one solve out of four: case118 16 iterations / 98 back-solves instead of 13 / 48, tools/acopf_richardson_ab.py.)
+__global__ __launch_bounds__(256) void linv256_mfma_kernel(const double* __restrict__ F, int64_t ld, const double* __restrict__ Linv64,
+                                                           double* __restrict__ Inv,
                                                            double* __restrict__ InvT, int64_t Np, const int* __restrict__ info,
                                                            int blk0) {
     __shared__ v4f64 tile[1024];
@@ -149,37 +153,17 @@ __global__ __launch_bounds__(256) void linv256_mfma_kernel(const double* __restr
     auto step = [&](auto Jc) __attribute__((always_inline)) {
         constexpr int j = decltype(Jc)::value;
         if (j >= q && j < nb && q < nb) {   // (uniform)
-            const int64_t jb = (j0 >> 6) + j;
-            const double* Dblk = Dblk0 + jb * 4096;
-            const double* Iv16 = inv16 + jb * 1024;
-            {
-                double Ln[6][4], Iv[4][4];
-                int p = 0;
+            // Y_j^T = inv(L_jj) T_j^T, 16x16 block by block of the lower-triangular 64x64 inverse (descending, in place)
+            const double* Li = Linv64 + ((j0 >> 6) + j) * 4096;
 #pragma unroll
-                for (int cb = 1; cb < 4; ++cb)
+            for (int cb = 3; cb >= 0; --cb) {
+                v4f64 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int ib = 0; ib < cb; ++ib, ++p)
+                for (int ib = 0; ib <= cb; ++ib)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) Ln[p][s] = -Dblk[(16 * cb + l15) + 64 * (16 * ib + 4 * s + l4)];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) Iv[cb][s] = Iv16[cb * 256 + l15 + 16 * (4 * s + l4)];
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    v4f64 tt = X[4 * j + cb];
-#pragma unroll
-                    for (int ib = 0; ib < cb; ++ib) {
-                        const int pq = cb * (cb - 1) / 2 + ib;
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            tt = __builtin_amdgcn_mfma_f64_16x16x4f64(Ln[pq][s], X[4 * j + ib][s], tt, 0, 0, 0);
-                    }
-                    v4f64 x = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) x = __builtin_amdgcn_mfma_f64_16x16x4f64(Iv[cb][s], tt[s], x, 0, 0, 0);
-                    X[4 * j + cb] = x;
-                }
+                    for (int s = 0; s < 4; ++s)
+                        x = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[(16 * cb + l15) + 64 * (16 * ib + 4 * s + l4)], X[4 * j + ib][s], x, 0, 0, 0);
+                X[4 * j + cb] = x;
             }
             // T_c -= Y_j L_cj^T for the later column blocks (L_cj staged as in the persistent panel kernel)
 #pragma unroll
@@ -893,12 +877,12 @@ using namespace mnk;
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
     const int64_t nblk = std::min<int64_t>(sc1, (ls->Np + SB - 1) / SB) - sc0;
     if (nblk <= 0) return 0;
-    if (!ls->linv_mfma || ls->bk_active)   // (the Bunch-Kaufman tier fills dblk only: no 16x16 inverses)
+    if (!ls->linv_mfma)
         hipLaunchKernelGGL(linv_tri_kernel<256>, dim3((unsigned)nblk, 4, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->linv.p,
                            ls->linv256.p, ls->linv256t.p, ls->Np, ls->info_dev.p, (int)sc0);
     else
-        hipLaunchKernelGGL(linv256_mfma_kernel, dim3((unsigned)nblk, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->dblk.p,
-                           ls->inv16.p, ls->linv256.p, ls->linv256t.p, ls->Np, ls->info_dev.p, (int)sc0);
+        hipLaunchKernelGGL(linv256_mfma_kernel, dim3((unsigned)nblk, 4), dim3(256), 0, s, ls->fact.p, ls->ld, ls->linv.p,
+                           ls->linv256.p, ls->linv256t.p, ls->Np, ls->info_dev.p, (int)sc0);
     // 512-row triangles (the 32-row persistent solve): those that lie entirely inside [sc0, sc1) -- a caller that inverts in
     // two ranges cuts at an even strip-column.  Built from the 256-row inverses on the MFMA tile kernel:
     //   inv [A 0; C D] = [A^-1 0; -D^-1 C A^-1  D^-1],   T' = A^-T C' (stage 1),  X = -D^-1 T,  X' = -T' D^-T (stage 2)

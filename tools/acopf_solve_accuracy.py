@@ -53,12 +53,16 @@ if c is not None:
     report("LAPACK dpotrf/dpotrs", sl.cho_solve(c, b))
 st = torch.cuda.Stream()
 ctx = mj.HipContext(0, stream=st.cuda_stream)
+Kd = torch.from_numpy(np.asfortranarray(K)).cuda()
+torch.cuda.synchronize()
 for alg in (mj.BUNCHKAUFMAN, mj.LDL, mj.CHOLESKY):
+  for mfma in (1, 0):   # 256 x 256 inverses from the MFMA kernel / from the scalar block substitution
     try:
-        ls = mj.HipLinearSolver(torch.from_numpy(np.asfortranarray(K)).cuda(), ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
+        ls = mj.HipLinearSolver(Kd, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
+        ls.set_option("linv_mfma", mfma)
         ls.factorize()
         xs = ls.solve_linear_system(b.copy())
-        report(f"HipLinearSolver {alg} inertia {ls.inertia()}", xs)
+        report(f"HipLinearSolver {alg} linv_mfma={mfma} inertia {ls.inertia()}", xs)
         ls.close()
     except Exception as e:
         print(alg, "failed:", repr(e)[:200])

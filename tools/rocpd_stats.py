@@ -28,13 +28,13 @@ def main():
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"| {k} | {a[0]} | {a[1]/1e6:.3f} | {a[1]/a[0]/1e3:.2f} | {a[2]/1e3:.2f} | {a[3]/1e3:.2f} | {100*a[1]/tot:.1f} |")
     text = "\n".join(lines)
-    # span of every factorize! call (densify kernel -> end of the last linv256_kernel): the figure that has to agree
+    # span of every factorize! call (densify kernel -> end of the last inverse kernel): the figure that has to agree
     # with the HIP-event duration bench.py reports as ms_per_factorize
     order = sorted(rows, key=lambda r: r[1])
     # (start: the kernel that densifies the matrix into the factor buffer; the zero-fill may run in the background long
     # before it.  end: the LAST inverse launch before the next start -- the task-DAG schedule inverts in two launches)
     starts = [i for i, r in enumerate(order) if "scatter_csc_kernel" in r[0] or "copy_lower_kernel" in r[0]]
-    ends = [i for i, r in enumerate(order) if "linv_tri_kernel" in r[0]]
+    ends = [i for i, r in enumerate(order) if "linv_tri_kernel" in r[0] or "linv256_mfma_kernel" in r[0]]
     spans = []
     for n, i0 in enumerate(starts):
         nxt = starts[n + 1] if n + 1 < len(starts) else len(order)
@@ -43,7 +43,7 @@ def main():
             spans.append((order[e[-1]][2] - order[i0][1]) / 1e6)
     if len(spans) > 1:
         sp = spans[1:]
-        text += ("\n\nSpan of one `factorize!` call in this trace (`scatter_csc_kernel` to the end of the last `linv_tri_kernel`, "
+        text += ("\n\nSpan of one `factorize!` call in this trace (`scatter_csc_kernel` to the end of the last inverse kernel `linv256_mfma_kernel`, "
                  "the two look-ahead streams overlapping inside): mean %.3f ms, min %.3f ms over %d calls "
                  "(to be compared with `ms_per_factorize` of the same run's bench.py JSON line)." % (sum(sp) / len(sp), min(sp), len(sp)))
     print(text)
