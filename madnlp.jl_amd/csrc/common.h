@@ -39,6 +39,8 @@ constexpr int PAD = 128;
 // Rows of slack behind every dense operand buffer: tile loads may run up to one
 // wave tile past the last row (values are discarded, memory must be mapped).
 constexpr int SLACK = 256;
+// max|a_ij| of a transfer is folded into AMAX_SLOTS words 128 bytes apart behind the four result words (ls.h: amax_dev)
+constexpr int AMAX_SLOT0 = 16, AMAX_STRIDE = 16, AMAX_SLOTS = 64, AMAX_WORDS = AMAX_SLOT0 + AMAX_STRIDE * AMAX_SLOTS;
 
 // Host-side wait for a stream: hipStreamSynchronize (short spin, then an interrupt-driven sleep) by default; with
 // MNK_SPIN_WAIT=1 the stream is polled instead (one host core busy for the duration of every wait).  Round 2 chased

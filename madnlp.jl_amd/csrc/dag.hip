@@ -269,6 +269,16 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
     }
 }
 
+__global__ __launch_bounds__(256) void dag_reset_kernel(int* __restrict__ flags, int64_t n, int* __restrict__ info) {
+    int4* f4 = reinterpret_cast<int4*>(flags);   // (hipMalloc alignment; the tail is done word by word)
+    const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) f4[i] = make_int4(0, 0, 0, 0);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < (unsigned)(n - 4 * n4)) flags[4 * n4 + threadIdx.x] = 0;
+        if (threadIdx.x == 0) *info = 0;
+    }
+}
+
 template <bool LDL>
 __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -523,7 +533,9 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     }
     if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) return -2;  // V = L D of every column (LDL^T)
     double* V = ldl ? ls->vfull.p : nullptr;
-    MNK_HIP(hipMemsetAsync(ls->dag_flags.p, 0, nflags * sizeof(int), s));
+    // progress words and `info` in ONE launch (two memsets are two fill kernels, ~8 us each in front of the pivot chain)
+    hipLaunchKernelGGL(mnk::dag_reset_kernel, dim3((unsigned)std::min<size_t>((nflags + 1023) / 1024, 64)), dim3(256), 0, s,
+                       ls->dag_flags.p, (int64_t)nflags, ls->info_dev.p);
     int* qctr = ls->dag_flags.p;
     int* front = qctr + 2;
     int* af = front + nblk;
@@ -544,7 +556,12 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         MNK_HIP(hipEventRecord(ctx->ev_a, s));
         MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
         MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
-        int rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p + 4 * (size_t)task0, ntask,
+        mnk::PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
+                  mnk_ls_growth_word(ls)};
+        // (the chain first: its first diagonal block is the start of the critical path, the bulk kernel has nothing to do before it)
+        int rc = mnk_launch_pchain(ls, sp, dag, js_begin, js_end, strips);
+        if (rc) return rc;
+        rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p + 4 * (size_t)task0, ntask,
                                       front, af, tprog, ntile, counter, ls->info_dev.p, ls->flag_p.p, epoch16, spin_limit,
                                       std::min(ntask, 3 * bulk_cus), mnk_ls_growth_word(ls), trace ? trace + 8 * (size_t)task0 : nullptr,
                                       trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
@@ -560,10 +577,6 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
                 ls->inv_done = safe;
             }
         }
-        mnk::PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
-                  mnk_ls_growth_word(ls)};
-        rc = mnk_launch_pchain(ls, sp, dag, js_begin, js_end, strips);
-        if (rc) return rc;
         MNK_HIP(hipEventRecord(ctx->ev_a, sp));
         MNK_HIP(hipEventRecord(ctx->ev_b, su));
         MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));

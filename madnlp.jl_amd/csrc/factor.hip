@@ -881,10 +881,17 @@ unsigned long long* mnk_ls_growth_word(mnk_ls* ls) {
 // fills with system-scope stores: no copy engine and no staging copy between the last kernel and the host.
 __global__ void publish_info_kernel(const unsigned long long* __restrict__ inertia, const int* __restrict__ info,
                                     unsigned long long* __restrict__ host_words, const unsigned long long* __restrict__ amax = nullptr) {
+    // max|a_ij| of the transfer: the maximum over the slots its kernels folded into (one wave)
+    unsigned long long am = 0ull;
+    if (amax != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
+        for (int i = threadIdx.x; i < AMAX_SLOTS; i += 64) am = std::max(am, amax[AMAX_SLOT0 + AMAX_STRIDE * i]);
+        for (int off = 32; off > 0; off >>= 1) am = std::max(am, (unsigned long long)__shfl_xor((long long)am, off));
+        am = std::max(am, amax[0]);
+    }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int i = 0; i < 3; ++i) __hip_atomic_store(host_words + i, inertia[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (int i = 0; i < 3; ++i)  // max|a_ij|, max(|d_k|, |v_ik|), sign changes of the pivot sequence (words 4, 5, 6)
-            __hip_atomic_store(host_words + 4 + i, amax != nullptr ? amax[i] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host_words + 4 + i, amax != nullptr ? (i == 0 ? am : amax[i]) : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_words + 3, (unsigned long long)(long long)*info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -1079,7 +1086,6 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
     const int64_t NBO = mnk_ls_effective_nbo(ls);
-    MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));
     if (ls->panel_algo >= 4 && !ls->flag_p.p) {
         if (ls->flag_p.alloc(Np / NBI + 1)) return -2;
         MNK_HIP(hipMemsetAsync(ls->flag_p.p, 0, (Np / NBI + 1) * sizeof(int), s));
@@ -1092,6 +1098,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     ls->algo_now = ls->panel_algo;
     if (ls->algo_now == 5 && (ctx->dag_cus < ls->dag_band || !ls->lookahead || Np < ls->dag_min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
     if (ls->algo_now >= 4 && (ls->pp_blocked || mnk_live_contexts(ctx->device) > 1)) ls->algo_now = 1;
+    if (ls->algo_now != 5) MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));   // (the task-DAG driver resets it with its flags)
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
     // chain, not by the update: narrower outer panels (tail_nbo) then drop the middle-level update and halve
     // the depth of the (a) piece the chain waits for (measured: 355 -> ~300 us per 512 columns of the tail).

@@ -118,7 +118,7 @@ struct mnk_ls {
     double bk_growth_tol = 64.0, bk_growth_tol_qd = 1e8;
     double last_growth = 0.0;    // max(|d_k|, |v_ik|) / max|a_ij| of the last static-pivot factorization (diagnostics, tests)
     int64_t last_sign_changes = 0;
-    mnk::DevBuf<unsigned long long> amax_dev;  // [0] max|a_ij| as transferred, [1] max(|d_k|, |v_ik|) (bit patterns), [2] sign changes of the pivots
+    mnk::DevBuf<unsigned long long> amax_dev;  // [0] max|a_ij| as transferred (folded from the slots below when the info is published), [1] max(|d_k|, |v_ik|) (bit patterns), [2] sign changes of the pivots; [AMAX_SLOT0 + AMAX_STRIDE i]: partial max|a_ij| of the transfer kernels
     bool bk_active = false;      // the current factor is P A P^T = L D L^T with 2x2 blocks (solves use perm / dcoup)
     int bk_count = 0;            // how many factorizations took the pivoted tier (diagnostics, tests)
     std::function<int()> retransfer;  // puts the matrix of the last factorize! call back into `fact`

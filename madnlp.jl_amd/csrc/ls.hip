@@ -62,7 +62,7 @@ __global__ void scatter_csc_kernel(double* __restrict__ F, int64_t ld, const int
         v = nz[k];
         F[row[k] + (int64_t)col[k] * ld] = v;
     }
-    if (amax != nullptr) wave_absmax_to(amax, v);
+    if (amax != nullptr) wave_absmax_to(amax + AMAX_SLOT0 + AMAX_STRIDE * (blockIdx.x & (AMAX_SLOTS - 1)), v);
 }
 
 // dense source -> factor buffer, rows >= first row of the diagonal tile of each column.
@@ -71,18 +71,41 @@ __global__ __launch_bounds__(256) void copy_lower_kernel(double* __restrict__ F,
                                                          int64_t Np, unsigned long long* __restrict__ amax) {
     const int64_t col = blockIdx.x;
     const int64_t first = (col / PAD) * PAD;
-    const int64_t r = first + (int64_t)blockIdx.y * 256 + threadIdx.x;
-    double v = 0.0, vl = 0.0;
-    if (r < Np) {
-        if (col < N && r < N) {
-            v = A[r + col * lda];
-            if (r >= col) vl = v;  // the lower triangle is the matrix ('L' storage: the rest may hold anything)
-        } else if (r == col) {
-            v = 1.0;
+    // four rows per thread, 256 apart (coalesced, four loads in flight; a quarter of the workgroups and of the wave
+    // reductions of one row per thread: 50-70 -> ~25 us for the 2112 x 2112 matrix of config C2)
+    const int64_t r0 = first + (int64_t)blockIdx.y * 1024 + threadIdx.x;
+    if (r0 - threadIdx.x >= Np) return;   // (uniform)
+    double v[4], vl = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + 256 * i;
+        v[i] = 0.0;
+        if (r < Np) {
+            if (col < N && r < N) {
+                v[i] = A[r + col * lda];
+                if (r >= col) vl = fmax(vl, fabs(v[i]));  // the lower triangle is the matrix ('L' storage: the rest may hold anything)
+                if (r >= col && !(fabs(v[i]) <= DBL_MAX)) vl = __longlong_as_double(0x7ff0000000000000LL);
+            } else if (r == col) {
+                v[i] = 1.0;
+            }
         }
-        F[r + col * ld] = v;
     }
-    if (amax != nullptr) wave_absmax_to(amax, vl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + 256 * i;
+        if (r < Np) F[r + col * ld] = v[i];
+    }
+    if (amax != nullptr) {
+        // one fold per workgroup, spread over AMAX_SLOTS words (publish_info_kernel takes their maximum): 25 000 waves
+        // looking at ONE word cost 40 us of the 2112-row transfer
+        __shared__ double wmax[4];
+        for (int off = 32; off > 0; off >>= 1) vl = fmax(vl, __shfl_xor(vl, off));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = vl;
+        __syncthreads();
+        if (threadIdx.x < 64)
+            wave_absmax_to(amax + AMAX_SLOT0 + AMAX_STRIDE * ((blockIdx.x + 5 * blockIdx.y) & (AMAX_SLOTS - 1)),
+                           fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3])));
+    }
 }
 
 __global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t N, int64_t Np) {
@@ -458,8 +481,8 @@ static int ensure_wbuf(mnk_ls* ls) {
 // The word that receives max|a_ij| of the matrix being transferred (zeroed here), or NULL when nobody will ask for it.
 static unsigned long long* amax_word(mnk_ls* ls) {
     if (!(ls->bk_requested && ls->bk_fallback && ls->algo == MNK_LDL)) return nullptr;
-    if (!ls->amax_dev.p && ls->amax_dev.alloc(4)) return nullptr;
-    (void)hipMemsetAsync(ls->amax_dev.p, 0, 4 * sizeof(unsigned long long), ls->ctx->stream);
+    if (!ls->amax_dev.p && ls->amax_dev.alloc(AMAX_WORDS)) return nullptr;
+    (void)hipMemsetAsync(ls->amax_dev.p, 0, AMAX_WORDS * sizeof(unsigned long long), ls->ctx->stream);
     return ls->amax_dev.p;
 }
 
@@ -538,7 +561,7 @@ int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
 }
 
 static int transfer_dense(mnk_ls* ls, const double* Adev, int64_t lda) {
-    dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np + 255) / 256));
+    dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np + 1023) / 1024));
     hipLaunchKernelGGL(copy_lower_kernel, grid, dim3(256), 0, ls->ctx->stream, ls->fact.p, ls->ld, Adev, lda,
                        ls->N, ls->Np, amax_word(ls));
     MNK_HIP(hipGetLastError());
