@@ -572,8 +572,14 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     // one phase = one persistent bulk launch (update stream) beside one persistent chain launch (panel stream)
     auto phase = [&](hipStream_t sp, hipStream_t su, int bulk_cus, int task0, int ntask, int* counter, int js_begin, int js_end,
                      unsigned strips) -> int {
+        // A small system (every row a strip of the chain, one phase) runs its chain on the CALLER's stream: no fork in front
+        // of the first diagonal block, no join behind the last one, and the inverses simply follow the chain.  Its workgroups
+        // are dispatched before the bulk kernel's (which waits for the event) and need a CU each to themselves (registers);
+        // the CUs outside the bulk stream's mask -- at least as many as there are strips -- cannot be taken from them.
+        const bool small = js_begin == 0 && js_end == nsc && js2 == 0 && ls->dag_chain_inline;
+        if (small) sp = s;
         MNK_HIP(hipEventRecord(ctx->ev_a, s));
-        MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
+        if (!small) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
         MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
         mnk::PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
                   mnk_ls_growth_word(ls)};
@@ -596,15 +602,19 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
                 ls->inv_done = safe;
             }
         }
-        if (js_begin == 0 && js_end == nsc && js2 == 0) {
+        if (small) {
+            rc = mnk_ls_invert_blocks(ls, s, 0, nsc);
+            if (rc) return rc;
+            ls->inv_done = nsc;
+        } else if (js_begin == 0 && js_end == nsc && js2 == 0) {
             hipLaunchKernelGGL(mnk::dag_gate_kernel, dim3(1), dim3(1), 0, su, front + (nblk - 1), ntile, ls->info_dev.p, spin_limit);
             rc = mnk_ls_invert_blocks(ls, su, 0, nsc);
             if (rc) return rc;
             ls->inv_done = nsc;
         }
-        MNK_HIP(hipEventRecord(ctx->ev_a, sp));
+        if (!small) MNK_HIP(hipEventRecord(ctx->ev_a, sp));
         MNK_HIP(hipEventRecord(ctx->ev_b, su));
-        MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
+        if (!small) MNK_HIP(hipStreamWaitEvent(s, ctx->ev_a, 0));
         MNK_HIP(hipStreamWaitEvent(s, ctx->ev_b, 0));
         return 0;
     };

@@ -92,6 +92,7 @@ struct mnk_ls {
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int solve512 = 0;          // 1: the one-launch solve steps over 512 columns (32-row blocks, 512x512 explicit inverses) from solve512_min_rows on.  C3: solve! 0.46 -> 0.33 ms, but the extra inverses cost factorize! +0.37 ms (they finish 0.3 ms after the chain): worth it from ~4 solves per factorization
     int64_t solve512_min_rows = 4096;
+    int dag_chain_inline = 1;  // task-DAG schedule, small systems: the pivot chain runs on the caller's stream (no fork / join around it)
     int linv_mfma = 1;         // 256x256 explicit inverses on the matrix cores (0: the scalar LDS kernel, ~70 us per workgroup)
     mnk::DevBuf<double> linv512, linv512t, linv512tmp;
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)

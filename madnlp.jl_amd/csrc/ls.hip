@@ -318,6 +318,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     if (const char* e = getenv("MNK_PREFILL")) ls->prefill = atoi(e) != 0;
     if (const char* e = getenv("MNK_SOLVE512")) ls->solve512 = atoi(e) != 0;
     if (const char* e = getenv("MNK_LINV_MFMA")) ls->linv_mfma = atoi(e) != 0;
+    if (const char* e = getenv("MNK_DAG_CHAIN_INLINE")) ls->dag_chain_inline = atoi(e) != 0;
     if (const char* e = getenv("MNK_DAG_MIN_ROWS")) ls->dag_min_rows = atol(e);
     if (const char* e = getenv("MNK_DAG_CHUNK")) ls->dag_chunk = std::max(1, atoi(e));
     if (const char* e = getenv("MNK_DAG_BAND")) ls->dag_band = std::min(16, std::max(8, atoi(e) / 4 * 4));
@@ -388,6 +389,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "solve512")) { ls->solve512 = value != 0; return 0; }   // 512-column steps of the one-launch solve
     if (!strcmp(key, "solve512_min_rows")) { ls->solve512_min_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "linv_mfma")) { ls->linv_mfma = value != 0.0; return 0; }
+    if (!strcmp(key, "dag_chain_inline")) { ls->dag_chain_inline = value != 0.0; return 0; }
     if (!strcmp(key, "prefill")) { ls->prefill = value != 0; return 0; }   // background zero-fill into a second factor buffer
     if (!strcmp(key, "prefill_max_rows")) { ls->prefill_max_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "single_rows")) {  // systems up to this order: one outer panel, no look-ahead (0: never)
