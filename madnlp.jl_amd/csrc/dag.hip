@@ -60,6 +60,7 @@ struct DagArgs {
     unsigned long long* trace;  // diagnostics (option dag_trace): 8 time stamps per task
     unsigned long long* wgstat; // diagnostics: per workgroup {first grab, exit, ticks waited, tasks, ticks in finalize}
     unsigned long long* vmax;   // growth monitor of the static-pivot LDL^T (factor.hip growth_fold): receives max|V|, or NULL
+    int fake_share;             // DIAGNOSTIC (env MNK_DAG_FAKE_SHARE, wrong results): every chunk reads the operand rows of tile rows 0..n-1
 };
 
 constexpr int DAG_BANDACC = 1, DAG_FINAL = 2, DAG_FIRST = 4;  // task flags
@@ -342,8 +343,8 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             limit = (__builtin_amdgcn_readfirstlane(r) - kbeg) * 16;
             return true;
         };
-        const double* Ak = a.F + row0 + (int64_t)128 * kbeg * a.ld;
-        const double* Bk = (LDL ? a.V : a.F) + col0 + (int64_t)128 * kbeg * a.ld;
+        const double* Ak = a.F + (a.fake_share > 0 ? (int64_t)128 * (kend + I % a.fake_share) : row0) + (int64_t)128 * kbeg * a.ld;
+        const double* Bk = (LDL ? a.V : a.F) + (a.fake_share > 0 ? (int64_t)128 * (kend + J % a.fake_share) : col0) + (int64_t)128 * kbeg * a.ld;
         auto wait_chunk_order = [&]() -> bool {   // the chunks of one tile are applied in order
             if (flags & DAG_FIRST) return true;
             const int* word = a.tprog + (int64_t)I * a.ntile + J;
@@ -510,7 +511,7 @@ int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, c
                     const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* vmax, unsigned long long* trace,
                     unsigned long long* wgstat) {
     if (ntasks <= 0) return 0;
-    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace, wgstat, vmax};
+    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace, wgstat, vmax, getenv("MNK_DAG_FAKE_SHARE") ? atoi(getenv("MNK_DAG_FAKE_SHARE")) : 0};
     return ldl ? launch_bulk_t<true>(s, a, nwg) : launch_bulk_t<false>(s, a, nwg);
 }
 

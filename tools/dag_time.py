@@ -1,0 +1,24 @@
+"""Event-timed factorize! of a dense quasi-definite matrix with the task-DAG schedule (diagnostic runs: results not checked).
+usage: python tools/dag_time.py [N] [LDL|CHOLESKY]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import madnlp_jl_amd as mj  # noqa: E402
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 11192
+alg = sys.argv[2] if len(sys.argv) > 2 else "LDL"
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    ctx = mj.HipContext(0, stream=s.cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(N)
+    R = torch.randn(N, 96, dtype=torch.float64, device="cuda", generator=g)
+    A = R @ R.T + torch.diag(torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 10 + 1.0)
+    s.synchronize()
+    ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, panel_algo=5))
+    for _ in range(3):
+        ls.factorize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(10):
+        ls.factorize()
+    e1.record(s); s.synchronize()
+    print(f"N={N} {alg}: factorize {e0.elapsed_time(e1)/10:.3f} ms  panel_algo {ls.get_stat('panel_algo')}")
