@@ -63,6 +63,9 @@ struct Piv4 {
 // substitution on the condensed KKT systems -- tools/emul_block_trsm.py, 2.1e-16 either way.)
 // ---------------------------------------------------------------------------------------
 typedef double v4d __attribute__((ext_vector_type(4)));
+#ifndef MNK_DIAG_FAST_LEAF
+#define MNK_DIAG_FAST_LEAF 0
+#endif
 
 // Store of a result another CU will read after a flag.  WT (the persistent chain of the task-DAG schedule): write-through
 // (sc1), so that the publishing workgroup needs no agent-scope release fence -- that fence (buffer_wbl2) writes back EVERY
@@ -243,14 +246,16 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
     double vm = 0.0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        double aopinv[4];
+        double aopinv[4] = {0.0, 0.0, 0.0, 0.0};
         // the finished columns of block column b (Xf[cb][tt]: pivot group tt of block (cb, b)) live OUTSIDE the accumulators:
         // a kernel with more than 256 registers gets its MFMA accumulators in AGPRs, where overwriting one component of a
         // block costs a round trip of the whole block through VGPRs (~50 v_accvgpr moves per pivot group, 18 % of the
         // kernel's instructions); the finished components of Lt are dead from here on (later updates add zeros to them)
-        v4d Xf[4];
+        v4d Xf[4] = {zero4, zero4, zero4, zero4};
+        // (-DMNK_DIAG_FAST_LEAF=1: a timing-only build whose pivot kernel does no arithmetic -- results void -- to see how much
+        // of a factorization's time is the leaf's; tools/diag_fast_leaf.sh)
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < (MNK_DIAG_FAST_LEAF ? 0 : 4); ++tt) {
             const int t = 4 * b + tt;
             // ---- 1. pivot block: A[16b + 4tt + jj][16b + 4tt + kk] sits in register tt of lane (4tt + jj) + 16 kk
             const double dsrc = Lt[b][b][tt];
