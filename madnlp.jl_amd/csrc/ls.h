@@ -85,7 +85,7 @@ struct mnk_ls {
     int64_t inv_done = 0;         // strip-columns whose diagonal blocks the current factorization has already inverted for the solves
     int dag_band = 16;            // 64-row strips per band of the persistent pivot chain (8, 12 or 16; <= the chain's CUs)
     long dag_spin_limit = 1L << 24;  // polls (~0.5 us each) a device-side wait of the schedule may take before it gives up (info = -7)
-    int dag_chunk = 12;           // tile columns (of 128) per bulk task (measured at C3 / N = 16384: 8 9.95 / 26.2 ms, 10-16 9.8 / 25.8; every task ends with a ~21 us read-modify-write of its tile)
+    int dag_chunk = 64;           // tile columns (of 128) per bulk task behind the doubling taper 1, 2, 4, ... (every task ends with a read-modify-write of its tile; C3 at the end of round 3: 12 -> 9.58 ms, 48 / 64 / 88 / 128 / 1024 -> 9.30; N = 16 384: 26.3 -> 25.9 ms, N = 24 576: 82.0 / 82.5 ms; in the middle of the round, with slower closing tasks, 10-16 was the optimum)
     int64_t dag_min_rows = 1536;  // smaller systems keep the launch-per-panel schedules (measured break-even: N ~ 1500)
     int64_t dag_max_rows = 24576; // larger ones too: their trailing updates already run at the update kernel's rate (measured: 22384 +1 %, 30000 -2 %)
     int panel_algo = 5;  // 5: task-DAG schedule (dag.hip: persistent pivot chain + persistent left-looking bulk kernel); 4: persistent panel kernel per 256 columns + one trailing update per outer panel (also what 5 uses outside [dag_min_rows, dag_max_rows]); 1: one launch per piece, the fallback of 4 and 5

@@ -62,7 +62,7 @@ span = (W[:, 1].max() - W[:, 0].min()) / 100.0
 print(f"kernel span {span:.0f} us; slot-time not waiting/finalizing: {100*(life.sum()-wait.sum()-fin.sum())/(len(W)*span):.1f} % of slots x span")
 
 # ---- waits by task class (the task list rebuilt as dag_build_tasks does)
-chunk = int(os.environ.get("MNK_DAG_CHUNK", "12"))
+chunk = int(os.environ.get("MNK_DAG_CHUNK", "64"))
 band = int(os.environ.get("MNK_DAG_BAND", "16"))
 Np = (N + 127) // 128 * 128
 ntile = Np // 128
