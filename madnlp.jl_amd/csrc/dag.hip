@@ -542,7 +542,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         // work of a C3-size system then no longer fits the smaller bulk partition, 10.7 vs 10.3 ms.)
         const int64_t deep_rows = (int64_t)ctx->dag_cus2 * NBI;
         ls->dag_js2 = (ctx->dag_cus2 > 0 && Np <= deep_rows) ? 0 : nsc;
-        if (const char* e = getenv("MNK_DAG_JS2")) ls->dag_js2 = std::min(nsc, std::max(0, atoi(e)));
+        if (ls->dag_js2_override >= 0) ls->dag_js2 = std::min(nsc, ls->dag_js2_override);
         std::vector<int> h;
         ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h);
         ls->dag_ntasks = (int)(h.size() / 4);

@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <functional>
 #include <memory>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -93,6 +95,8 @@ struct mnk_ls {
     int solve512 = 0;          // 1: the one-launch solve steps over 512 columns (32-row blocks, 512x512 explicit inverses) from solve512_min_rows on.  C3: solve! 0.46 -> 0.33 ms, but the extra inverses cost factorize! +0.37 ms (they finish 0.3 ms after the chain): worth it from ~4 solves per factorization
     int64_t solve512_min_rows = 4096;
     int dag_chain_inline = 1;  // task-DAG schedule, small systems: the pivot chain runs on the caller's stream (no fork / join around it)
+    std::vector<std::string> env_keys;   // options fixed by MNK_OPTIONS for this process
+    int dag_js2_override = -1;
     int linv_mfma = 1;         // 256x256 explicit inverses on the matrix cores (0: the scalar LDS kernel, ~70 us per workgroup)
     mnk::DevBuf<double> linv512, linv512t, linv512tmp;
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)

@@ -304,28 +304,29 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     ls->N = N;
     ls->algo = algo;
     ls->bk_requested = bk_requested;
-    if (const char* e = getenv("MNK_BK_FALLBACK")) ls->bk_fallback = atoi(e);
-    if (const char* e = getenv("MNK_LOOKAHEAD")) ls->lookahead = atoi(e) != 0;  // tuning overrides
-    if (const char* e = getenv("MNK_SHARE")) ls->share = atoi(e) != 0;
-    if (const char* e = getenv("MNK_SMALL_TILES")) ls->small_tiles = atoi(e);
-    if (const char* e = getenv("MNK_SMALL_TILES_MID")) ls->small_tiles_mid = atoi(e);
-    if (const char* e = getenv("MNK_SPLIT_A")) ls->split_a = atoi(e);
-    if (const char* e = getenv("MNK_TAIL_ROWS")) ls->tail_rows = atol(e);
-    if (const char* e = getenv("MNK_SINGLE_ROWS")) ls->single_rows = atol(e);
-    if (const char* e = getenv("MNK_TAIL_NBO")) ls->tail_nbo = atol(e);
-    if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) ls->persistent_solve = atoi(e);
-    if (const char* e = getenv("MNK_PANEL_ALGO")) ls->panel_algo = atoi(e);
-    if (const char* e = getenv("MNK_PREFILL")) ls->prefill = atoi(e) != 0;
-    if (const char* e = getenv("MNK_SOLVE512")) ls->solve512 = atoi(e) != 0;
-    if (const char* e = getenv("MNK_LINV_MFMA")) ls->linv_mfma = atoi(e) != 0;
-    if (const char* e = getenv("MNK_DAG_CHAIN_INLINE")) ls->dag_chain_inline = atoi(e) != 0;
-    if (const char* e = getenv("MNK_DAG_MIN_ROWS")) ls->dag_min_rows = atol(e);
-    if (const char* e = getenv("MNK_DAG_CHUNK")) ls->dag_chunk = std::max(1, atoi(e));
-    if (const char* e = getenv("MNK_DAG_BAND")) ls->dag_band = std::min(16, std::max(8, atoi(e) / 4 * 4));
-    if (const char* e = getenv("MNK_DAG_MAX_ROWS")) ls->dag_max_rows = atol(e);
-    if (const char* e = getenv("MNK_PP_FUSE_ROWS")) ls->pp_fuse_rows = atol(e);
-    if (const char* e = getenv("MNK_OWN_COLS")) ls->own_cols = std::max<long>(64, atol(e) / 64 * 64);
-    if (const char* e = getenv("MNK_PANEL0_WHOLE")) ls->panel0_whole = atoi(e);
+    // Tuning overrides from the environment, for runs of unmodified callers: MNK_OPTIONS="key=value,key=value" with the keys
+    // of mnk_ls_set_option (plus MNK_PANEL_ALGO / MNK_PERSISTENT_SOLVE, the two a deployment may need: INTEGRATION.md).  An
+    // option set this way is not changed by later mnk_ls_set_option calls.
+    {
+        auto from_env = [&](const std::string& key, double v) {
+            if (mnk_ls_set_option(ls, key.c_str(), v) == 0) ls->env_keys.push_back(key);
+            else fprintf(stderr, "madnlp_hip: ignoring environment override '%s': %s\n", key.c_str(), mnk_last_error_string());
+        };
+        if (const char* e = getenv("MNK_PANEL_ALGO")) from_env("panel_algo", atof(e));
+        if (const char* e = getenv("MNK_PERSISTENT_SOLVE")) from_env("persistent_solve", atof(e));
+        if (const char* e = getenv("MNK_OPTIONS")) {
+            std::string all(e);
+            size_t pos = 0;
+            while (pos < all.size()) {
+                size_t end = all.find(',', pos);
+                if (end == std::string::npos) end = all.size();
+                const std::string item = all.substr(pos, end - pos);
+                const size_t eq = item.find('=');
+                if (eq != std::string::npos && eq > 0) from_env(item.substr(0, eq), atof(item.c_str() + eq + 1));
+                pos = end + 1;
+            }
+        }
+    }
     ls->Np = round_up(N, PAD);
     ls->ld = ls->Np;
     ls->ldw = ls->Np;
@@ -377,7 +378,15 @@ int mnk_ls_destroy(mnk_ls* ls) {
 
 int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     MNK_REQUIRE(ls && key, "mnk_ls_set_option: NULL argument");
+    for (const std::string& k : ls->env_keys)
+        if (k == key) return 0;   // fixed by the environment for this process (MNK_OPTIONS)
     if (!strcmp(key, "pivot_tol")) { ls->pivot_tol = value; return 0; }
+    if (!strcmp(key, "split_a")) { ls->split_a = (int)value; return 0; }
+    if (!strcmp(key, "tail_rows")) { ls->tail_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "tail_nbo")) { ls->tail_nbo = (int64_t)value; return 0; }
+    if (!strcmp(key, "own_cols")) { ls->own_cols = std::max<long>(64, (long)value / 64 * 64); return 0; }
+    if (!strcmp(key, "panel0_whole")) { ls->panel0_whole = (int)value; return 0; }
+    if (!strcmp(key, "dag_js2")) { ls->dag_js2_override = (int)value; return 0; }   // experiments: strip-column at which every row joins the band (-1: by size)
     if (!strcmp(key, "outer_block")) {
         int64_t v = (int64_t)value;
         MNK_REQUIRE(v >= NBI && v % NBI == 0, "outer_block must be a positive multiple of 64");

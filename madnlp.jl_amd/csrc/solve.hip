@@ -947,8 +947,7 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
         hipEvent_t& last = ps_last[ls->ctx->device & 63];
         if (last == nullptr) MNK_HIP(hipEventCreateWithFlags(&last, hipEventDisableTiming));
         else MNK_HIP(hipStreamWaitEvent(s, last, 0));
-        static const int ps_near = getenv("MNK_PS_NEAR") ? atoi(getenv("MNK_PS_NEAR")) : PS_NEAR;
-        static const int ps_nap = getenv("MNK_PS_NAP") ? atoi(getenv("MNK_PS_NAP")) : 6;
+        const int ps_near = PS_NEAR, ps_nap = 6;
         double* pub = xdev + 2 * Np;
         hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
                            reinterpret_cast<unsigned long long*>(pub), 4 * Np);

@@ -143,20 +143,11 @@ class HipLinearSolver:
         rc = L.lib().mnk_ls_create(self.ctx.handle, self.n, _ALGO[self.opt.lapack_algorithm], C.byref(self._h))
         if rc:
             raise SymbolicException(L.lib().mnk_last_error_string().decode())
-        import os
-        settings = [("pivot_tol", self.opt.pivot_tol), ("outer_block", self.opt.outer_block)]
-        if "MNK_LOOKAHEAD" not in os.environ:  # tuning override handled inside the library
-            settings.append(("lookahead", float(self.opt.lookahead)))
-        if "MNK_SHARE" not in os.environ:
-            settings.append(("share", float(self.opt.share)))
-        if "MNK_SMALL_TILES" not in os.environ:
-            settings.append(("small_tiles", float(self.opt.small_tiles)))
-        if "MNK_PERSISTENT_SOLVE" not in os.environ:
-            settings.append(("persistent_solve", float(self.opt.persistent_solve)))
-        if "MNK_SINGLE_ROWS" not in os.environ:
-            settings.append(("single_rows", float(self.opt.single_rows)))
-        if "MNK_PANEL_ALGO" not in os.environ:
-            settings.append(("panel_algo", float(self.opt.panel_algo)))
+        # (options fixed by the environment -- MNK_OPTIONS="key=value,..." -- are kept by the library)
+        settings = [("pivot_tol", self.opt.pivot_tol), ("outer_block", self.opt.outer_block),
+                    ("lookahead", float(self.opt.lookahead)), ("share", float(self.opt.share)),
+                    ("small_tiles", float(self.opt.small_tiles)), ("persistent_solve", float(self.opt.persistent_solve)),
+                    ("single_rows", float(self.opt.single_rows)), ("panel_algo", float(self.opt.panel_algo))]
         for key, val in settings:
             L.check(L.lib().mnk_ls_set_option(self._h, key.encode(), float(val)), "mnk_ls_set_option")
         self.info = 0

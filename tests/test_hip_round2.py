@@ -742,3 +742,25 @@ def test_inverses_from_the_matrix_cores_match_the_scalar_ones(ctx, N, alg):
     res = np.abs(A @ xs[1] - b).max() / (np.abs(A).sum(axis=1).max() * np.abs(xs[1]).max() + np.abs(b).max())
     assert res <= 1e-14, res
     assert np.abs(xs[0] - xs[1]).max() <= 1e-10 * np.abs(xs[0]).max()
+
+
+def test_environment_overrides_win_over_set_option(ctx, monkeypatch, capfd):
+    """MNK_OPTIONS="key=value,..." fixes options for unmodified callers: read at mnk_ls_create, kept against later
+    mnk_ls_set_option calls (the mirror sets its HipSolverOptions right after the constructor), unknown keys reported and
+    ignored."""
+    rng = np.random.default_rng(3)
+    N = 1700
+    R = rng.standard_normal((N, 32))
+    A = R @ R.T + np.eye(N) * 5.0
+    monkeypatch.setenv("MNK_OPTIONS", "panel_algo=1,no_such_option=3,dag_chunk=8")
+    ls = mj.HipLinearSolver(np.asfortranarray(A), ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm="CHOLESKY", panel_algo=5))
+    ls.factorize()
+    assert ls.inertia() == (N, 0, 0)
+    assert ls.get_stat("panel_algo") == 1.0
+    ls.close()
+    assert "no_such_option" in capfd.readouterr().err
+    monkeypatch.delenv("MNK_OPTIONS")
+    ls = mj.HipLinearSolver(np.asfortranarray(A), ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm="CHOLESKY", panel_algo=5))
+    ls.factorize()
+    assert ls.get_stat("panel_algo") == 5.0
+    ls.close()

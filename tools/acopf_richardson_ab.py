@@ -1,5 +1,5 @@
 """Per-iteration Richardson steps / residual ratios of the host IPM driver on the HIP back-end, scalar vs MFMA explicit
-inverses (env MNK_LINV_MFMA).  usage: MNK_LINV_MFMA=0|1 python tools/acopf_richardson_ab.py case118"""
+inverses.  usage: MNK_OPTIONS=linv_mfma=0|1 python tools/acopf_richardson_ab.py case118"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,5 +24,5 @@ def factory(info):
                                        opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN), device_kkt_ops=True)
 sh = MadNLPSolver(nlp, factory, _options(), sparse=True)
 sh.solve()
-print(case, "MNK_LINV_MFMA", os.environ.get("MNK_LINV_MFMA"), sh.status, (sh.cnt.k, sh.cnt.factorization_cnt, sh.cnt.backsolve_cnt))
+print(case, "MNK_OPTIONS", os.environ.get("MNK_OPTIONS"), sh.status, (sh.cnt.k, sh.cnt.factorization_cnt, sh.cnt.backsolve_cnt))
 print(" ".join(f"{ir}:{rr:.0e}" for ir, rr in log))

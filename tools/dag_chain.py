@@ -13,7 +13,7 @@ from madnlp_jl_amd import _lib as L  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 11192
 alg = sys.argv[2] if len(sys.argv) > 2 else "LDL"
-band = int(os.environ.get("MNK_DAG_BAND", "16"))
+band = int(os.environ.get("DAG_BAND", "16"))
 cus2 = int(os.environ.get("MNK_DAG_CUS2", "96"))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
@@ -23,6 +23,7 @@ with torch.cuda.stream(s):
     A = R @ R.T + torch.diag(torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 10 + 1.0)
     ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, panel_algo=5, single_rows=0))
     ls.set_option("dag_min_rows", 0)
+    ls.set_option("dag_band", band)
     ls.factorize(); s.synchronize()
     ls.set_option("dag_trace", 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -13,6 +13,8 @@ from madnlp_jl_amd import _lib as L  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 11192
 alg = sys.argv[2] if len(sys.argv) > 2 else "LDL"
+chunk = int(os.environ.get("DAG_CHUNK", "64"))   # (the library's defaults; other values are set on the solver below)
+band = int(os.environ.get("DAG_BAND", "16"))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
     ctx = mj.HipContext(0, stream=s.cuda_stream)
@@ -21,6 +23,8 @@ with torch.cuda.stream(s):
     A = R @ R.T + torch.diag(torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 10 + 1.0)
     ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, panel_algo=5, single_rows=0))
     ls.set_option("dag_min_rows", 0)
+    ls.set_option("dag_chunk", chunk)
+    ls.set_option("dag_band", band)
     ls.factorize(); s.synchronize()
     ls.set_option("dag_trace", 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,8 +66,6 @@ span = (W[:, 1].max() - W[:, 0].min()) / 100.0
 print(f"kernel span {span:.0f} us; slot-time not waiting/finalizing: {100*(life.sum()-wait.sum()-fin.sum())/(len(W)*span):.1f} % of slots x span")
 
 # ---- waits by task class (the task list rebuilt as dag_build_tasks does)
-chunk = int(os.environ.get("MNK_DAG_CHUNK", "64"))
-band = int(os.environ.get("MNK_DAG_BAND", "16"))
 Np = (N + 127) // 128 * 128
 ntile = Np // 128
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
