@@ -144,3 +144,15 @@ def test_bad_arguments_are_reported_not_crashed():
     bad = np.array([7], dtype=np.int32)
     rc = lib.mnk_sc_create(None, 3, 2, 1, bad.ctypes.data, bad.ctypes.data, 0, None, None, 0, C.byref(h))
     assert rc < 0 and b"out of range" in lib.mnk_last_error_string()
+
+
+def test_every_solver_option_and_statistic_is_documented():
+    """Every key `mnk_ls_set_option` / `mnk_ls_get_stat` accept (csrc/ls.hip) appears in INTEGRATION.md."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "madnlp.jl_amd", "csrc", "ls.hip")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    keys = sorted(set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', src)))
+    assert len(keys) > 30
+    missing = [k for k in keys if f"`{k}`" not in doc]
+    assert not missing, missing
