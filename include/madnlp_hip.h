@@ -464,6 +464,11 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d);
  * path (8 x 100 MHz timer values per 64-row block); this copies them out (n = number of uint64 to copy). */
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);
 
+/* Diagnostics / tests (host only): the task list of the task-DAG factorization schedule (csrc/dag.hip) for a matrix of `ntile`
+ * 128-row tiles: 4 ints per task (flags | chunk index << 8, tile row I, tile column J, kbeg | kend << 16) in queue order, at most
+ * `cap` tasks written; returns the number of tasks (negative: bad arguments). */
+int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int* out, int cap, int* first_phase);
+
 /* Diagnostics (tools/microbench_update.py): time `reps` lower-tile trailing updates C -= A*A^T under the
  * schedules the factorization uses (static tiling / tile queue; context, update, update+panel streams). */
 int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const double* A, int64_t lda,

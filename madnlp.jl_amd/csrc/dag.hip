@@ -632,3 +632,17 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     }
     return 0;
 }
+
+// Diagnostics / tests: the task list of the schedule for a matrix of `ntile` 128-row tiles (host only, no device needed).
+// out: 4 ints per task as the bulk kernel reads them (flags | chunk index << 8, I, J, kbeg | kend << 16), at most `cap`
+// tasks are written; returns the number of tasks, *first_phase receives the number of first-phase tasks.
+extern "C" int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int* out, int cap, int* first_phase) {
+    if (ntile <= 0 || chunk <= 0 || band_tiles <= 0) return -1;
+    std::vector<int> h;
+    const int n1 = mnk::dag_build_tasks(ntile, chunk, band_tiles, js2, h);
+    const int n = (int)(h.size() / 4);
+    if (first_phase != nullptr) *first_phase = n1;
+    if (out != nullptr)
+        for (int i = 0; i < std::min(n, cap) * 4; ++i) out[i] = h[i];
+    return n;
+}

@@ -1,0 +1,80 @@
+"""Host logic of the task-DAG factorization schedule (csrc/dag.hip: dag_build_tasks), without a GPU: the task list the
+persistent bulk kernel consumes IN ORDER.  Progress of the schedule rests on two properties of that list -- every task waits
+only for tasks in front of it (or for the pivot chain, which waits only for tasks whose operands the chain itself has
+already produced), and the chunks of a tile cover its columns exactly once -- checked here for several matrix orders."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from madnlp_jl_amd import _lib as L  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from dag_tasks import dag_tasks  # noqa: E402
+
+BAND, FINAL, FIRST = 1, 2, 4
+
+
+def _tasks(ntile, chunk, band_tiles, js2):
+    cap = 400000
+    out = np.zeros(4 * cap, dtype=np.int32)
+    n1 = C.c_int(0)
+    n = L.lib().mnk_debug_dag_tasks(ntile, chunk, band_tiles, js2, out.ctypes.data, cap, C.byref(n1))
+    assert 0 <= n <= cap
+    t = out[: 4 * n].reshape(n, 4)
+    return [(int(a) & 255, int(a) >> 8, int(i), int(j), int(k) & 0xffff, int(k) >> 16) for a, i, j, k in t], n1.value
+
+
+@pytest.mark.parametrize("ntile,chunk,band_tiles,js2", [(16, 64, 8, 8), (17, 12, 8, 0), (40, 64, 8, 20), (88, 64, 8, 44), (88, 12, 8, 44),
+                                                        (45, 7, 6, 10), (128, 64, 8, 64)])
+def test_task_list_covers_every_tile_once_and_waits_only_backwards(ntile, chunk, band_tiles, js2):
+    ts, n1 = _tasks(ntile, chunk, band_tiles, js2)
+    pos = {}
+    tiles = {}
+    closed = {}           # (I, J) -> queue index of the task that closes the bulk tile (publishes the row's front)
+    for idx, (flags, q, I, J, kb, ke) in enumerate(ts):
+        assert 0 <= J <= I < ntile and 0 <= kb <= ke
+        tiles.setdefault((I, J), []).append((q, kb, ke, flags, idx))
+        if (flags & FINAL) and not (flags & BAND):
+            closed[(I, J)] = idx
+    nsc = (ntile + 1) // 2
+    for (I, J), lst in tiles.items():
+        Js = J // 2
+        bt = ntile if Js >= js2 else band_tiles
+        band = I < 2 * Js + bt
+        K = (2 * Js - 2) if band else J     # band tiles: the chain applies the previous strip-column itself
+        lst.sort()
+        # chunk indices 0, 1, ... in queue order (the kernel applies the chunks of a tile in this order) and contiguous cover
+        assert [q for q, *_ in lst] == list(range(len(lst)))
+        assert [x[4] for x in lst] == sorted(x[4] for x in lst)
+        assert lst[0][1] == 0 and lst[-1][2] == K
+        for a, b in zip(lst, lst[1:]):
+            assert a[2] == b[1]
+        assert (lst[0][3] & FIRST) and all(not (x[3] & FIRST) for x in lst[1:])
+        assert (lst[-1][3] & FINAL) and all(not (x[3] & FINAL) for x in lst[:-1])
+        assert all(bool(x[3] & BAND) == band for x in lst)
+        # operands: tile columns [kb, ke) of rows I and J.  A column k of a row below the band is final once that row's tile
+        # (row, k) is closed -- by a task that must sit in FRONT of this one; rows inside the band are the chain's.
+        for q, kb, ke, flags, idx in lst:
+            for row in (I, J):
+                for k in range(kb, ke):
+                    ks = k // 2
+                    bt_k = ntile if ks >= js2 else band_tiles
+                    if row >= 2 * ks + bt_k:
+                        assert closed[(row, k)] < idx, ((I, J), row, k)
+    # every tile below the diagonal band structure appears: bulk tiles for all J, band tiles once there is something to accumulate
+    for J in range(ntile):
+        Js = J // 2
+        bt = ntile if Js >= js2 else band_tiles
+        for I in range(2 * Js + bt, ntile):
+            assert (I, J) in tiles
+        if 2 * Js - 2 > 0:
+            for I in range(max(2 * Js, J), min(2 * Js + bt, ntile)):
+                assert (I, J) in tiles
+    # first-phase tasks come first and need nothing the second phase's chain produces
+    assert all(ke <= 2 * js2 for _, _, _, _, _, ke in ts[:n1])
+    # the Python mirror the trace tools use is the same list
+    mirror = dag_tasks(ntile, chunk, band_tiles, js2)
+    assert [(f, q, I, J, kb, ke) for (_, _, J, I, f, q, kb, ke) in mirror] == ts
