@@ -467,7 +467,7 @@ int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);
 /* Diagnostics / tests (host only): the task list of the task-DAG factorization schedule (csrc/dag.hip) for a matrix of `ntile`
  * 128-row tiles: 4 ints per task (flags | chunk index << 8, tile row I, tile column J, kbeg | kend << 16) in queue order, at most
  * `cap` tasks written; returns the number of tasks (negative: bad arguments). */
-int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int* out, int cap, int* first_phase);
+int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int taper0, int* out, int cap, int* first_phase);
 
 /* Diagnostics (tools/microbench_update.py): time `reps` lower-tile trailing updates C -= A*A^T under the
  * schedules the factorization uses (static tiling / tile queue; context, update, update+panel streams). */

@@ -169,7 +169,7 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
 // ---- task-DAG schedule (dag.hip): persistent left-looking tile kernel beside the pivot chain -------------------------
 // Task list (4 ints per task, see dag.hip).  Strip-columns Js < js2 have a band of `band_tiles` tile rows, the others a band
 // that covers every remaining row; returns the number of tasks of the first phase (ready before the chain enters js2).
-int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out);
+int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out, int taper0);
 int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
                     const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
                     int* info,

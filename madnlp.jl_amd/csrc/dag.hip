@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
 // rows for the strip-columns Js < js2, every remaining row from js2 on (depends on these four only; cached by the caller).
 // 4 ints per task: flags | chunk index << 8, I, J, kbeg | kend << 16.  Returns the number of first-phase tasks: the ones
 // that are ready before the chain enters strip-column js2 (they come first in the list).
-int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out) {
+int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out, int taper0) {
     struct T { int ready, cls, J, I, flags, q, kbeg, kend; };
     std::vector<T> ts;
     // Tile (I, J), tile columns [0, K) to accumulate.  A bulk tile's last tile column is a task of its own (paced by the pivot
@@ -447,7 +447,7 @@ int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<i
         const int body = band ? K : std::max(0, K - 1);
         std::vector<int> cuts{body};  // chunk boundaries, back to front
         int e = body;
-        for (int len = 1; len < chunk && e > 0; len *= 2) { e = std::max(0, e - len); cuts.push_back(e); }   // (taper from 2 or 3: -0.5 %; factors 3 / 4: +2 / +5 %)
+        for (int len = taper0; len < chunk && e > 0; len *= 2) { e = std::max(0, e - len); cuts.push_back(e); }   // (factors 3 / 4 instead of 2: +2 / +5 %)
         const int first = 1 + (I * 5 + J * 3) % chunk;
         while (e > first) { e = std::max(first, e - chunk); cuts.push_back(e); }
         if (e > 0) cuts.push_back(0);
@@ -544,7 +544,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         ls->dag_js2 = (ctx->dag_cus2 > 0 && Np <= deep_rows) ? 0 : nsc;
         if (ls->dag_js2_override >= 0) ls->dag_js2 = std::min(nsc, ls->dag_js2_override);
         std::vector<int> h;
-        ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h);
+        ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h, ls->dag_taper0);
         ls->dag_ntasks = (int)(h.size() / 4);
         if (ls->dag_tasks.alloc(h.size() + 4)) return -2;
         if (!h.empty()) MNK_HIP(hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
@@ -636,10 +636,10 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
 // Diagnostics / tests: the task list of the schedule for a matrix of `ntile` 128-row tiles (host only, no device needed).
 // out: 4 ints per task as the bulk kernel reads them (flags | chunk index << 8, I, J, kbeg | kend << 16), at most `cap`
 // tasks are written; returns the number of tasks, *first_phase receives the number of first-phase tasks.
-extern "C" int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int* out, int cap, int* first_phase) {
-    if (ntile <= 0 || chunk <= 0 || band_tiles <= 0) return -1;
+extern "C" int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int taper0, int* out, int cap, int* first_phase) {
+    if (ntile <= 0 || chunk <= 0 || band_tiles <= 0 || taper0 <= 0) return -1;
     std::vector<int> h;
-    const int n1 = mnk::dag_build_tasks(ntile, chunk, band_tiles, js2, h);
+    const int n1 = mnk::dag_build_tasks(ntile, chunk, band_tiles, js2, h, taper0);
     const int n = (int)(h.size() / 4);
     if (first_phase != nullptr) *first_phase = n1;
     if (out != nullptr)

@@ -427,7 +427,7 @@ constexpr int PP_LDS_BYTES = 3 * 4096 * 8;  // two staging tiles (the first doub
 // that was published before ANY flag value read ahead of it, so every successful wait refreshes all nb entries and
 // later waits that are already satisfied cost nothing (no further cache invalidation).
 template <int NB>
-__device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int target, int (&seen)[NB], int* info) {
+__device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int target, int (&seen)[NB], int* info, long limit = PP_SPIN_LIMIT) {
     if (seen[c] >= target) return;
     long spins = 0;
     while (__hip_atomic_load(prog + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -436,7 +436,7 @@ __device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int targ
             // a failed factorization (or a dependency that never arrives) must not hang: carry on with whatever is
             // there -- info != 0 makes every result of this factorization void
             if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-            if (spins > PP_SPIN_LIMIT) {
+            if (spins > limit) {
                 atomicCAS(info, 0, -7);
                 break;
             }
@@ -473,6 +473,11 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
     const int64_t r0 = R + 16 * w;
     const int jmax = t < nb - 1 ? t : nb - 1;
     const bool diag_strip = t < nb;
+    // Persistent chain: a strip may wait for a diagonal block whose strip is itself waiting for the BULK kernel -- with the
+    // schedule's own (long) bound.  The short bound of the launch-per-panel schedule expired there when the bulk kernel's
+    // very first launch in a process took longer than ~0.5 s to start (code upload): info = -7, and the solver stayed on
+    // schedule 1 for good -- 12.5 instead of 9.3 ms per factorize!, seen in 2 of ~150 bench processes.
+    const long pp_limit = dag.front != nullptr ? dag.spin_limit : PP_SPIN_LIMIT;
     int seen[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) seen[c] = 0;
@@ -616,7 +621,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             return true;
         }
         // ---- wait for the diagonal block j, X = T L_jj^-T
-        pp_wait<NB>(prog, j, nb, epoch16 + j + 1, seen, info);
+        pp_wait<NB>(prog, j, nb, epoch16 + j + 1, seen, info, pp_limit);
         const int64_t jb = (p0 >> 6) + j;
         const double* Dblk = dblk0 + jb * 4096;
         const double* Iv16 = inv0 + jb * 1024;
@@ -697,7 +702,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
         v4d pre[4];
         auto prefetch = [&](int c) {
-            pp_wait<NB>(prog, c, nb, epoch16 + j + 1, seen, info);
+            pp_wait<NB>(prog, c, nb, epoch16 + j + 1, seen, info, pp_limit);
             const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 + 64 * j + w) * ld;
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib)

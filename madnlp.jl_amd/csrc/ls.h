@@ -86,6 +86,7 @@ struct mnk_ls {
     bool dag_trace_on = false;
     int64_t inv_done = 0;         // strip-columns whose diagonal blocks the current factorization has already inverted for the solves
     int dag_band = 16;            // 64-row strips per band of the persistent pivot chain (8, 12 or 16; <= the chain's CUs)
+    int dag_taper0 = 2;           // (1: -0.5 .. -1 % slower, alternating runs on two boxes) length of the last chunk in front of a tile's closing task; the chunks double from there (1, 2, 4, ...)
     long dag_spin_limit = 1L << 24;  // polls (~0.5 us each) a device-side wait of the schedule may take before it gives up (info = -7)
     int dag_chunk = 64;           // tile columns (of 128) per bulk task behind the doubling taper 1, 2, 4, ... (every task ends with a read-modify-write of its tile; C3 at the end of round 3: 12 -> 9.58 ms, 48 / 64 / 88 / 128 / 1024 -> 9.30; N = 16 384: 26.3 -> 25.9 ms, N = 24 576: 82.0 / 82.5 ms; in the middle of the round, with slower closing tasks, 10-16 was the optimum)
     int64_t dag_min_rows = 1536;  // smaller systems keep the launch-per-panel schedules (measured break-even: N ~ 1500)

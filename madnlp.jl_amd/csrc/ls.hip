@@ -422,6 +422,12 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     if (!strcmp(key, "pp_fuse_rows")) { ls->pp_fuse_rows = (int64_t)value; return 0; }
     if (!strcmp(key, "dag_min_rows")) { ls->dag_min_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "dag_taper0")) {
+        MNK_REQUIRE(value >= 1.0 && value <= 16.0, "dag_taper0 must be in 1..16");
+        ls->dag_taper0 = (int)value;
+        ls->dag_tasks.release();
+        return 0;
+    }
     if (!strcmp(key, "dag_chunk")) {   // tile columns per bulk task of the task-DAG schedule (the task list is rebuilt)
         MNK_REQUIRE(value >= 1.0 && value <= 64.0, "dag_chunk must be in 1..64");
         ls->dag_chunk = (int)value;

@@ -17,20 +17,20 @@ from dag_tasks import dag_tasks  # noqa: E402
 BAND, FINAL, FIRST = 1, 2, 4
 
 
-def _tasks(ntile, chunk, band_tiles, js2):
+def _tasks(ntile, chunk, band_tiles, js2, taper0=1):
     cap = 400000
     out = np.zeros(4 * cap, dtype=np.int32)
     n1 = C.c_int(0)
-    n = L.lib().mnk_debug_dag_tasks(ntile, chunk, band_tiles, js2, out.ctypes.data, cap, C.byref(n1))
+    n = L.lib().mnk_debug_dag_tasks(ntile, chunk, band_tiles, js2, taper0, out.ctypes.data, cap, C.byref(n1))
     assert 0 <= n <= cap
     t = out[: 4 * n].reshape(n, 4)
     return [(int(a) & 255, int(a) >> 8, int(i), int(j), int(k) & 0xffff, int(k) >> 16) for a, i, j, k in t], n1.value
 
 
-@pytest.mark.parametrize("ntile,chunk,band_tiles,js2", [(16, 64, 8, 8), (17, 12, 8, 0), (40, 64, 8, 20), (88, 64, 8, 44), (88, 12, 8, 44),
-                                                        (45, 7, 6, 10), (128, 64, 8, 64)])
-def test_task_list_covers_every_tile_once_and_waits_only_backwards(ntile, chunk, band_tiles, js2):
-    ts, n1 = _tasks(ntile, chunk, band_tiles, js2)
+@pytest.mark.parametrize("ntile,chunk,band_tiles,js2,taper0", [(16, 64, 8, 8, 1), (17, 12, 8, 0, 1), (40, 64, 8, 20, 2), (88, 64, 8, 44, 1),
+                                                               (88, 64, 8, 44, 2), (88, 12, 8, 44, 1), (45, 7, 6, 10, 3), (128, 64, 8, 64, 2)])
+def test_task_list_covers_every_tile_once_and_waits_only_backwards(ntile, chunk, band_tiles, js2, taper0):
+    ts, n1 = _tasks(ntile, chunk, band_tiles, js2, taper0)
     pos = {}
     tiles = {}
     closed = {}           # (I, J) -> queue index of the task that closes the bulk tile (publishes the row's front)
@@ -76,5 +76,5 @@ def test_task_list_covers_every_tile_once_and_waits_only_backwards(ntile, chunk,
     # first-phase tasks come first and need nothing the second phase's chain produces
     assert all(ke <= 2 * js2 for _, _, _, _, _, ke in ts[:n1])
     # the Python mirror the trace tools use is the same list
-    mirror = dag_tasks(ntile, chunk, band_tiles, js2)
+    mirror = dag_tasks(ntile, chunk, band_tiles, js2, taper0)
     assert [(f, q, I, J, kb, ke) for (_, _, J, I, f, q, kb, ke) in mirror] == ts

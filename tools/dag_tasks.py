@@ -1,6 +1,6 @@
 """Host-side mirror of the task list of the task-DAG schedule, for the trace tools."""
 
-def dag_tasks(ntile, chunk, band_tiles, js2=None):
+def dag_tasks(ntile, chunk, band_tiles, js2=None, taper0=1):
     """Python mirror of dag_build_tasks (csrc/dag.hip): list of (ready, cls, J, I, flags, q, kbeg, kend), in queue order."""
     BAND, FINAL, FIRST = 1, 2, 4
     ts = []
@@ -9,7 +9,7 @@ def dag_tasks(ntile, chunk, band_tiles, js2=None):
         body = K if band else max(0, K - 1)
         cuts = [body]
         e = body
-        ln = 1
+        ln = taper0
         while ln < chunk and e > 0:
             e = max(0, e - ln)
             cuts.append(e)

@@ -15,6 +15,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 11192
 alg = sys.argv[2] if len(sys.argv) > 2 else "LDL"
 chunk = int(os.environ.get("DAG_CHUNK", "64"))   # (the library's defaults; other values are set on the solver below)
 band = int(os.environ.get("DAG_BAND", "16"))
+taper0 = int(os.environ.get("DAG_TAPER0", "2"))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
     ctx = mj.HipContext(0, stream=s.cuda_stream)
@@ -25,6 +26,7 @@ with torch.cuda.stream(s):
     ls.set_option("dag_min_rows", 0)
     ls.set_option("dag_chunk", chunk)
     ls.set_option("dag_band", band)
+    ls.set_option("dag_taper0", taper0)
     ls.factorize(); s.synchronize()
     ls.set_option("dag_trace", 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -70,7 +72,7 @@ Np = (N + 127) // 128 * 128
 ntile = Np // 128
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from dag_tasks import dag_tasks  # noqa: E402
-ts = dag_tasks(ntile, chunk, band // 2)
+ts = dag_tasks(ntile, chunk, band // 2, taper0=taper0)
 nt = len(ts)
 bulk = tr[: nt * 8].reshape(nt, 8).astype(np.float64)
 t0 = bulk[:, 0][bulk[:, 0] > 0].min()
