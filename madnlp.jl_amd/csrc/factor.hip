@@ -1104,9 +1104,12 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     ls->inv_done = 0;
     // The persistent panel kernel keeps waiting workgroups resident.  Two of them from different contexts on the same
     // CUs can starve each other's diagonal strips (per-XCD dispatch order), so it is used only while this context is
-    // the only one on the device; a wait that expires anyway (another process) falls back for good (mnk_ls_fetch_info).
+    // the only one on the device; a wait that expires anyway (another process) falls back (mnk_ls_fetch_info) and the
+    // persistent schedule is tried again 16, then 64, 256, ... factorizations later.
     ls->algo_now = ls->panel_algo;
     if (ls->algo_now == 5 && (ctx->dag_cus < ls->dag_band || !ls->lookahead || Np < ls->dag_min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
+    ++ls->fact_count;
+    if (ls->pp_blocked && ls->fact_count >= ls->pp_retry_at) ls->pp_blocked = false;   // (a time-out may have been transient)
     if (ls->algo_now >= 4 && (ls->pp_blocked || mnk_live_contexts(ctx->device) > 1)) ls->algo_now = 1;
     if (ls->algo_now != 5) MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));   // (the task-DAG driver resets it with its flags)
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
@@ -1371,8 +1374,10 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     }
     if (hinfo == -7 && ls->algo_now >= 4 && ls->retransfer) {
         // the persistent panel kernel gave up on a dependency (CUs shared with another process' persistent kernels):
-        // factor again with one launch per panel piece, and stay there
+        // factor again with one launch per panel piece, and stay there for a while (16, 64, 256, ... factorizations)
         ls->pp_blocked = true;
+        ls->pp_retry_at = ls->fact_count + ls->pp_backoff + 1;   // (+1: the redo below counts)
+        ls->pp_backoff *= 4;
         ++ls->pp_fallbacks;
         int rc = ls->retransfer();
         if (rc) return rc;

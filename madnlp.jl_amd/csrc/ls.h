@@ -74,6 +74,7 @@ struct mnk_ls {
     int panel0_whole = 1;  // look-ahead: the first outer panel is factored on the whole chip before the streams fork
     int algo_now = 1;    // the panel algorithm of the current factorization (panel_algo, or 1 where 4 is not safe)
     bool pp_blocked = false;
+    int64_t fact_count = 0, pp_retry_at = 0, pp_backoff = 16;   // a schedule that timed out is tried again after 16, 64, 256, ... factorizations
     int pp_fallbacks = 0;
     int64_t pp_fuse_rows = 4096; // > 0: once this many rows (or fewer) remain, persistent panel launches apply the columns in front of them themselves
     int64_t own_cols = 128;   // split_a = 2: columns of the next panel that the panel stream updates itself

@@ -408,6 +408,13 @@ def test_persistent_panel_that_gives_up_is_redone_without_it(ctx, alg, N, expect
     np.testing.assert_allclose(x, x_ok, rtol=0, atol=1e-11 * np.abs(x_ok).max())
     M.factorize()                      # stays on the safe path: no second time-out
     assert M.get_stat("pp_fallbacks") == 1.0 and M.get_stat("panel_algo") == 1.0
+    # ... for 16 factorizations; then the persistent schedule gets another chance (the time-out may have been transient)
+    M.set_option("debug_pp_missing", -1)
+    for _ in range(16):
+        M.factorize()
+    assert M.get_stat("pp_fallbacks") == 1.0 and M.get_stat("panel_algo") == expect
+    x = M.solve_linear_system(b.copy())
+    np.testing.assert_allclose(x, x_ok, rtol=0, atol=1e-11 * np.abs(x_ok).max())
     M.close()
 
 
