@@ -513,6 +513,7 @@ def main():
         fact_ms = float(np.mean([a[1] for a in allms]))
         ach = flops / (fact_ms * 1e-3) / 1e12
         schedule = ls.get_stat("panel_algo")
+        fallbacks = ls.get_stat("pp_fallbacks")   # > 0: a device-side hand-off timed out and schedule 1 ran instead
         traffic, traffic_src = pmc_traffic(N, args, schedule)
         out = {
             "metric": METRIC, "value": world * args.batch * args.steps / elapsed, "unit": "it/s",
@@ -540,7 +541,7 @@ def main():
                          "traffic_source": traffic_src,
                          "kernel": "factorize! (densify + blocked LDL^T/Cholesky; N^3/3 flop per call, "
                                    "HIP-event timed on the launch stream)",
-                         "schedule_panel_algo": schedule},
+                         "schedule_panel_algo": schedule, "pp_fallbacks": fallbacks},
         }
         if not args.no_ipm_loop and world == 1 and args.batch == 1:
             # Supplementary, OUTSIDE the timed region: complete IPM runs with device-resident vectors and callbacks
