@@ -208,6 +208,19 @@ def ipm_loop(args, ctx, model="acopf"):
         s.cb.close()
         s.K.close()
         s.kkt.close()
+    if model == "acopf":
+        # checker: the same NLP solved by the host driver on the oracle back-end (numpy assembly + LAPACK Bunch-Kaufman), a
+        # committed fixture (tests/golden/make_acopf_case1354_golden.py; tests/test_acopf.py asserts the agreement)
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "acopf_case1354_oracle.json")))
+            if gold["case"] == args.case:
+                rec["oracle_golden"] = {"fixture": "tests/golden/acopf_case1354_oracle.json", "status": gold["status"],
+                                        "iterations": gold["iterations"], "factorizations": gold["factorizations"],
+                                        "objective": gold["objective"],
+                                        "objective_rel_diff": abs(rec["objective"] - gold["objective"]) / abs(gold["objective"]),
+                                        "oracle_host_wall_s": gold["host_wall_s"]}
+        except Exception:
+            pass
     return rec
 
 

@@ -108,6 +108,7 @@ struct mnk_ctx {
     int panel_cus = 0;  // > 0: sp is restricted to this many CUs and su to the others (CU masks)
     // task-DAG schedule (dag.hip): the pivot chain needs only a few CUs, the persistent bulk kernel gets all the others
     hipStream_t sp_dag = nullptr, su_dag = nullptr;
+    bool shared_dag_streams = false;   // the four task-DAG streams belong to the device's shared set (ls.hip), not to this context
     int dag_cus = 0;    // > 0: sp_dag is restricted to this many CUs and su_dag to the others
     // ... and a third pair for its second phase, where every remaining row is in the chain's band (one CU per 64 rows)
     hipStream_t sp_dag2 = nullptr, su_dag2 = nullptr;
@@ -119,6 +120,7 @@ struct mnk_ctx {
     int cu_first = 0;   // first CU-mask bit of the partition
     int total_cu = 256; // CUs of the device
     bool partitioned = false;
+    void* persist_slot = nullptr;   // partitioned contexts: their own arbiter slot (ls.hip: mnk_persist_begin)
     // Handles created on this context (solvers, KKT systems).  Garbage-collected hosts (Julia) run finalizers
     // in no particular order: destroying a context that still has children only marks it released, and the
     // last child to go frees it (mnk_ctx_child_gone).
@@ -126,6 +128,16 @@ struct mnk_ctx {
     bool released = false;
 };
 int mnk_live_contexts(int device);  // contexts alive on this device in this process
+// Device arbiter of the PERSISTENT kernels (task-DAG schedule, persistent panel launches, one-launch solve): their waiting
+// workgroups stay resident, so two of them from different contexts must never share the chip (each could hold CUs the
+// other's producers need).  Every such operation is bracketed by begin / end: `begin` makes the caller's stream wait for
+// the previous persistent operation of ANY context of this process on the device, `end` records its own completion --
+// the operations run back to back at full speed, in the order they were enqueued, whatever stream they come from
+// (reference behaviour: distinct solver instances are driven concurrently, src/KKT/Schur/schur.jl:953).  `begin` returns
+// with the arbiter's mutex held; `end` releases it (enqueue order = execution order).  Contexts confined to a CU
+// partition arbitrate among themselves only.
+int mnk_persist_begin(mnk_ctx* ctx, hipStream_t s);
+int mnk_persist_end(mnk_ctx* ctx, hipStream_t s, int rc);   // returns rc (or the error of its own event record)
 void mnk_ctx_child_added(mnk_ctx* ctx);
 void mnk_ctx_child_gone(mnk_ctx* ctx);
 

@@ -519,18 +519,24 @@ int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, c
 
 using namespace mnk;
 
-// Host driver of the task-DAG schedule (panel_algo = 5): ONE persistent pivot-chain launch (factor.hip: pchain_kernel, one
-// workgroup per 64-row strip of the band, on the chain's CU partition) beside ONE persistent bulk launch on all the other
-// CUs; the two sides meet through progress words in device memory, no event is recorded or awaited between the fork and
-// the join.  The task list is built once per matrix order.
-int mnk_ls_run_factorization_dag(mnk_ls* ls) {
+// Buffers of the task-DAG schedule: the task list (built once per matrix order and option set), the progress words and,
+// for LDL^T, V = L D of every column (a second N x N array).  Returns 0 when everything is there; non-zero when the device
+// cannot hold it -- the caller keeps schedule 4 then (round 3 returned -2 from factorize! instead).  The spare factor buffer
+// of the background zero-fill is given up first: with many solvers per GPU it can be the allocation that took V's memory.
+int mnk_ls_dag_prepare(mnk_ls* ls) {
     mnk_ctx* ctx = ls->ctx;
     hipStream_t s = ctx->stream;
     const int64_t Np = ls->Np, ld = ls->ld;
     const bool ldl = ls->algo == MNK_LDL;
-    double* F = ls->fact.p;
     const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI), nsc = (int)((Np + 255) / 256);
     const size_t nflags = (size_t)2 + nblk + 2 * (size_t)ntile * ntile;  // two queue counters | front | af | tprog
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        ls->dag_tasks.release();
+        ls->dag_flags.release();
+        ls->vfull.release();
+        return 1;
+    };
     if (!ls->dag_tasks.p) {
         // Two band shapes.  Large systems (more than dag_cus2 strips of 64 rows): a shallow band on a handful of CUs, the
         // rows below it closed by the bulk kernel's own tasks -- the factorization is bound by the bulk work for most of its
@@ -546,12 +552,43 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         std::vector<int> h;
         ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h, ls->dag_taper0);
         ls->dag_ntasks = (int)(h.size() / 4);
-        if (ls->dag_tasks.alloc(h.size() + 4)) return -2;
-        if (!h.empty()) MNK_HIP(hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        MNK_HIP(mnk::stream_wait(s));  // (h goes out of scope)
-        if (ls->dag_flags.alloc(nflags)) return -2;
+        if (ls->dag_tasks.alloc(h.size() + 4)) return give_up();
+        if (!h.empty() && hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return give_up();
+        if (mnk::stream_wait(s) != hipSuccess) return give_up();  // (h goes out of scope)
+        if (ls->dag_flags.alloc(nflags)) return give_up();
     }
-    if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) return -2;  // V = L D of every column (LDL^T)
+    if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) {   // V = L D of every column (LDL^T)
+        (void)hipGetLastError();
+        bool ok = false;
+        if (ls->fact_spare.p && !ls->spare_zeroed) {
+            // (spare_zeroed: a background fill of the spare buffer has been queued and the next transfer will swap it in)
+            ls->fact_spare.release();
+            ls->prefill = 0;
+            ls->spare_pending = false;
+            ok = ls->vfull.alloc((size_t)ld * Np + SLACK) == 0;
+        }
+        if (!ok) return give_up();
+    }
+    if (ls->dag_trace_on) {
+        const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;  // tasks | chain strips | per-workgroup statistics (2 x 512)
+        if (ls->dag_trace.n < ntr && ls->dag_trace.alloc(ntr)) return give_up();   // (the task list may have been rebuilt with more tasks)
+    }
+    return 0;
+}
+
+// Host driver of the task-DAG schedule (panel_algo = 5): ONE persistent pivot-chain launch (factor.hip: pchain_kernel, one
+// workgroup per 64-row strip of the band, on the chain's CU partition) beside ONE persistent bulk launch on all the other
+// CUs; the two sides meet through progress words in device memory, no event is recorded or awaited between the fork and
+// the join.  The buffers come from mnk_ls_dag_prepare (called by mnk_ls_run_factorization before it settles on this schedule).
+int mnk_ls_run_factorization_dag(mnk_ls* ls) {
+    mnk_ctx* ctx = ls->ctx;
+    hipStream_t s = ctx->stream;
+    const int64_t Np = ls->Np, ld = ls->ld;
+    const bool ldl = ls->algo == MNK_LDL;
+    double* F = ls->fact.p;
+    const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI), nsc = (int)((Np + 255) / 256);
+    const size_t nflags = (size_t)2 + nblk + 2 * (size_t)ntile * ntile;  // two queue counters | front | af | tprog
+    MNK_REQUIRE(ls->dag_tasks.p && ls->dag_flags.p && (!ldl || ls->vfull.p), "task-DAG schedule: mnk_ls_dag_prepare was not called");
     double* V = ldl ? ls->vfull.p : nullptr;
     // progress words and `info` in ONE launch (two memsets are two fill kernels, ~8 us each in front of the pivot chain)
     hipLaunchKernelGGL(mnk::dag_reset_kernel, dim3((unsigned)std::min<size_t>((nflags + 1023) / 1024, 64)), dim3(256), 0, s,
@@ -562,9 +599,8 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     int* tprog = af + (size_t)ntile * ntile;
     const long spin_limit = ls->dag_spin_limit;
     unsigned long long* trace = nullptr;
-    if (ls->dag_trace_on) {
-        const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;  // tasks | chain strips | per-workgroup statistics (2 x 512)
-        if (!ls->dag_trace.p && ls->dag_trace.alloc(ntr)) return -2;
+    if (ls->dag_trace_on && ls->dag_trace.p) {
+        const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;
         MNK_HIP(hipMemsetAsync(ls->dag_trace.p, 0, ntr * sizeof(unsigned long long), s));
         trace = ls->dag_trace.p;
     }

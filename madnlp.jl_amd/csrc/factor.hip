@@ -846,35 +846,72 @@ __global__ __launch_bounds__(256) void linv64_kernel(double* __restrict__ F, int
     for (int i = 0; i < 16; ++i) out[c + 64 * (4 * i + p)] = Lt[c + 64 * (4 * i + p)];
 }
 
-// Count signs of D over the first N pivots: out[0]=pos, out[1]=zero, out[2]=neg.
-// (`dmax`: optional, max|d_k| as a bit pattern -- the growth guard of BUNCHKAUFMAN's static-pivot tier)
-__global__ void inertia_kernel(const double* __restrict__ dvec, int64_t N, unsigned long long* out,
-                               unsigned long long* __restrict__ dmax) {
-    unsigned long long pos = 0, zer = 0, neg = 0;
+// The host reads the inertia counters and the info word from pinned, device-mapped memory that this one-thread kernel
+// fills with system-scope stores: no copy engine and no staging copy between the last kernel and the host.
+// (Bunch-Kaufman tier only since round 4: the static tiers publish through finish_info_kernel.)
+__global__ void publish_info_kernel(const unsigned long long* __restrict__ inertia, const int* __restrict__ info,
+                                    unsigned long long* __restrict__ host_words) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (int i = 0; i < 3; ++i) __hip_atomic_store(host_words + i, inertia[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int i = 0; i < 3; ++i) __hip_atomic_store(host_words + 4 + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 3, (unsigned long long)(long long)*info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Inertia, growth-guard words and `info` of a static-pivot factorization in ONE launch of ONE workgroup that is queued
+// right behind the factorization (round 3: a memset, inertia_kernel and publish_info_kernel, enqueued when the inertia was
+// asked for): signs of D over the first N pivots (reference inertia rule for an unpivoted LDL^T: the signs of D), max|d_k|
+// folded with the max|v_ik| the factorization's kernels recorded, sign changes along the pivot sequence, max|a_ij| of the
+// transfer -- stored to pinned host words with system scope, `info` last with release semantics.  Cholesky: `info` only
+// (N = 0).  The host then needs nothing but the stream synchronization it does anyway.
+__global__ __launch_bounds__(1024) void finish_info_kernel(const double* __restrict__ dvec, int64_t N, const int* __restrict__ info,
+                                                            unsigned long long* __restrict__ host_words,
+                                                            const unsigned long long* __restrict__ amax) {
+    __shared__ unsigned long long red[16][4];
+    __shared__ double redm[16];
+    unsigned long long pos = 0, zer = 0, neg = 0, chg = 0;
     double amx = 0.0;
-    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < N; k += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t k = threadIdx.x; k < N; k += blockDim.x) {
         const double d = dvec[k];
         if (d > 0.0) ++pos;
         else if (d < 0.0) ++neg;
         else ++zer;
         const double a = fabs(d) <= DBL_MAX ? fabs(d) : __longlong_as_double(0x7ff0000000000000LL);  // NaN / Inf pivot -> Inf
         amx = fmax(amx, a);
-        // sign changes along the pivot sequence (word dmax[1]): <= 1 means "positive pivots, then negative ones"
-        if (dmax != nullptr && k + 1 < N && ((d > 0.0) != (dvec[k + 1] > 0.0))) atomicAdd(dmax + 1, 1ull);
-    }
-    if (dmax != nullptr) {
-        for (int off = 32; off > 0; off >>= 1) amx = fmax(amx, __shfl_xor(amx, off));
-        if ((threadIdx.x & 63) == 0 && amx > 0.0) atomicMax(dmax, (unsigned long long)__double_as_longlong(amx));
+        if (k + 1 < N && ((d > 0.0) != (dvec[k + 1] > 0.0))) ++chg;   // <= 1 in total: "positive pivots, then negative ones"
     }
     for (int off = 32; off > 0; off >>= 1) {
-        pos += __shfl_down(pos, off);
-        zer += __shfl_down(zer, off);
-        neg += __shfl_down(neg, off);
+        pos += __shfl_xor((long long)pos, off);
+        zer += __shfl_xor((long long)zer, off);
+        neg += __shfl_xor((long long)neg, off);
+        chg += __shfl_xor((long long)chg, off);
+        amx = fmax(amx, __shfl_xor(amx, off));
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (pos) atomicAdd(&out[0], pos);
-        if (zer) atomicAdd(&out[1], zer);
-        if (neg) atomicAdd(&out[2], neg);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = pos; red[w][1] = zer; red[w][2] = neg; red[w][3] = chg; redm[w] = amx; }
+    __syncthreads();
+    // max|a_ij| of the transfer: the maximum over the slots its kernels folded into (one wave)
+    unsigned long long am = 0ull;
+    if (amax != nullptr && threadIdx.x < 64) {
+        for (int i = threadIdx.x; i < AMAX_SLOTS; i += 64) am = std::max(am, amax[AMAX_SLOT0 + AMAX_STRIDE * i]);
+        for (int off = 32; off > 0; off >>= 1) am = std::max(am, (unsigned long long)__shfl_xor((long long)am, off));
+        am = std::max(am, amax[0]);
+    }
+    if (threadIdx.x == 0) {
+        const int nw = (int)(blockDim.x >> 6);
+        unsigned long long t[4] = {0, 0, 0, 0};
+        double m = 0.0;
+        for (int i = 0; i < nw; ++i) {
+            for (int j = 0; j < 4; ++j) t[j] += red[i][j];
+            m = fmax(m, redm[i]);
+        }
+        for (int i = 0; i < 3; ++i) __hip_atomic_store(host_words + i, t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long gw = 0ull;
+        if (amax != nullptr) gw = std::max(amax[1], (unsigned long long)__double_as_longlong(m));   // (bit patterns of non-negative doubles order like the values)
+        __hip_atomic_store(host_words + 4, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 5, gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 6, amax != nullptr ? t[3] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 3, (unsigned long long)(long long)*info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -885,25 +922,6 @@ using namespace mnk;
 // the word the kernels fold max|V| into (zeroed with max|a_ij| when the matrix was transferred), or NULL: guard off
 unsigned long long* mnk_ls_growth_word(mnk_ls* ls) {
     return (ls->algo == MNK_LDL && ls->bk_requested && ls->bk_fallback && ls->amax_dev.p) ? ls->amax_dev.p + 1 : nullptr;
-}
-
-// The host reads the inertia counters and the info word from pinned, device-mapped memory that this one-thread kernel
-// fills with system-scope stores: no copy engine and no staging copy between the last kernel and the host.
-__global__ void publish_info_kernel(const unsigned long long* __restrict__ inertia, const int* __restrict__ info,
-                                    unsigned long long* __restrict__ host_words, const unsigned long long* __restrict__ amax = nullptr) {
-    // max|a_ij| of the transfer: the maximum over the slots its kernels folded into (one wave)
-    unsigned long long am = 0ull;
-    if (amax != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
-        for (int i = threadIdx.x; i < AMAX_SLOTS; i += 64) am = std::max(am, amax[AMAX_SLOT0 + AMAX_STRIDE * i]);
-        for (int off = 32; off > 0; off >>= 1) am = std::max(am, (unsigned long long)__shfl_xor((long long)am, off));
-        am = std::max(am, amax[0]);
-    }
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (int i = 0; i < 3; ++i) __hip_atomic_store(host_words + i, inertia[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        for (int i = 0; i < 3; ++i)  // max|a_ij|, max(|d_k|, |v_ik|), sign changes of the pivot sequence (words 4, 5, 6)
-            __hip_atomic_store(host_words + 4 + i, amax != nullptr ? (i == 0 ? am : amax[i]) : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(host_words + 3, (unsigned long long)(long long)*info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // panel_algo = 4: persistent panel launches (ppanel_kernel) of 4 blocks, recursive updates between them
@@ -1089,28 +1107,47 @@ int mnk_launch_pchain(mnk_ls* ls, hipStream_t sp, const mnk::PpDag& dag, int js_
     return 0;
 }
 
+static int run_factorization_body(mnk_ls* ls);
+
 int mnk_ls_run_factorization(mnk_ls* ls) {
     mnk_ctx* ctx = ls->ctx;
     hipStream_t s = ctx->stream;
-    const int64_t Np = ls->Np, ld = ls->ld;
-    const bool ldl = ls->algo == MNK_LDL;
-    double* F = ls->fact.p;
-    const int64_t NBO = mnk_ls_effective_nbo(ls);
+    const int64_t Np = ls->Np;
     if (ls->panel_algo >= 4 && !ls->flag_p.p) {
         if (ls->flag_p.alloc(Np / NBI + 1)) return -2;
         MNK_HIP(hipMemsetAsync(ls->flag_p.p, 0, (Np / NBI + 1) * sizeof(int), s));
     }
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
     ls->inv_done = 0;
-    // The persistent panel kernel keeps waiting workgroups resident.  Two of them from different contexts on the same
-    // CUs can starve each other's diagonal strips (per-XCD dispatch order), so it is used only while this context is
-    // the only one on the device; a wait that expires anyway (another process) falls back (mnk_ls_fetch_info) and the
+    // The persistent kernels keep waiting workgroups resident.  Two of them from different contexts on the same CUs can
+    // starve each other's diagonal strips (per-XCD dispatch order), so the persistent operations of one process take turns
+    // on the device (the arbiter below); a wait that expires anyway (another PROCESS) falls back (mnk_ls_fetch_info) and the
     // persistent schedule is tried again 16, then 64, 256, ... factorizations later.
     ls->algo_now = ls->panel_algo;
     if (ls->algo_now == 5 && (ctx->dag_cus < ls->dag_band || !ls->lookahead || Np < ls->dag_min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
     ++ls->fact_count;
     if (ls->pp_blocked && ls->fact_count >= ls->pp_retry_at) ls->pp_blocked = false;   // (a time-out may have been transient)
-    if (ls->algo_now >= 4 && (ls->pp_blocked || mnk_live_contexts(ctx->device) > 1)) ls->algo_now = 1;
+    if (ls->algo_now >= 4 && ls->pp_blocked) ls->algo_now = 1;
+    // the task-DAG schedule's buffers (task list, progress words, V = L D): a device that cannot hold them keeps schedule 4
+    if (ls->algo_now == 5 && mnk_ls_dag_prepare(ls) != 0) ls->algo_now = 4;
+    // Persistent schedules of different contexts take turns on the device (common.h: mnk_persist_begin); round 3 sent every
+    // solver to schedule 1 as soon as a second context was alive (12.4 instead of 9.3 ms at C3).
+    const bool persistent = ls->algo_now >= 4;
+    if (persistent) {
+        int rc0 = mnk_persist_begin(ctx, s);
+        if (rc0) return rc0;
+    }
+    const int rc_run = run_factorization_body(ls);
+    return persistent ? mnk_persist_end(ctx, s, rc_run) : rc_run;
+}
+
+static int run_factorization_body(mnk_ls* ls) {
+    mnk_ctx* ctx = ls->ctx;
+    hipStream_t s = ctx->stream;
+    const int64_t Np = ls->Np, ld = ls->ld;
+    const bool ldl = ls->algo == MNK_LDL;
+    double* F = ls->fact.p;
+    const int64_t NBO = mnk_ls_effective_nbo(ls);
     if (ls->algo_now != 5) MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));   // (the task-DAG driver resets it with its flags)
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
     // chain, not by the update: narrower outer panels (tail_nbo) then drop the middle-level update and halve
@@ -1293,6 +1330,13 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     ls->factorized = true;
     ls->info_valid = false;
     ls->bk_active = false;
+    {   // inertia / growth words / info go to the pinned host words right behind the factorization (mnk_ls_fetch_info only waits)
+        const bool lmode = ls->algo == MNK_LDL;
+        const int threads = lmode ? (ls->N >= 4096 ? 1024 : 256) : 64;
+        hipLaunchKernelGGL(finish_info_kernel, dim3(1), dim3(threads), 0, s, ls->dvec.p, lmode ? ls->N : (int64_t)0, ls->info_dev.p, ls->pin_dev,
+                           mnk_ls_growth_word(ls) != nullptr ? ls->amax_dev.p : (const unsigned long long*)nullptr);
+        MNK_HIP(hipGetLastError());
+    }
     return mnk_ls_prefill_spare(ls);
 }
 
@@ -1325,14 +1369,14 @@ static int bk_fallback(mnk_ls* ls) {
     rc = mnk_ls_invert_blocks(ls, s, 0, (ls->Np + 255) / 256);
     if (rc) return rc;
     ++ls->bk_count;
-    return 0;
+    return mnk_ls_prefill_spare(ls);   // (the second transfer swapped the factor buffers again: the spare one holds the discarded static factor)
 }
 
 int mnk_ls_fetch_info(mnk_ls* ls) {
     if (ls->info_valid) return 0;
     hipStream_t s = ls->ctx->stream;
-    MNK_HIP(hipMemsetAsync(ls->inertia_dev.p, 0, 3 * sizeof(unsigned long long), s));
     if (ls->bk_active) {
+        MNK_HIP(hipMemsetAsync(ls->inertia_dev.p, 0, 3 * sizeof(unsigned long long), s));
         // reference rule for a Bunch-Kaufman factor (src/LinearSolvers/lapack.jl:240-268): numzero = info > 0,
         // numneg from the 1x1 / 2x2 blocks of D (-1 if a block is exactly singular), numpos the rest
         int rc = mnk_ls_bk_inertia(ls, ls->inertia_dev.p);
@@ -1352,14 +1396,7 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     }
     // growth guard of the static-pivot tier (BUNCHKAUFMAN): max|a_ij| was recorded when the matrix was transferred
     const bool guard = ls->algo == MNK_LDL && ls->bk_requested && ls->bk_fallback && ls->retransfer && ls->amax_dev.p != nullptr;
-    if (ls->algo == MNK_LDL) {
-        const int blocks = (int)std::min<int64_t>(256, (ls->N + 255) / 256);
-        hipLaunchKernelGGL(inertia_kernel, dim3(blocks), dim3(256), 0, s, ls->dvec.p, ls->N, ls->inertia_dev.p,
-                           guard ? ls->amax_dev.p + 1 : (unsigned long long*)nullptr);
-    }
-    hipLaunchKernelGGL(publish_info_kernel, dim3(1), dim3(64), 0, s, ls->inertia_dev.p, ls->info_dev.p, ls->pin_dev,
-                       guard ? ls->amax_dev.p : (const unsigned long long*)nullptr);
-    MNK_HIP(hipGetLastError());
+    // (finish_info_kernel, queued behind the factorization, has stored everything in the pinned words)
     MNK_HIP(mnk::stream_wait(s));
     volatile unsigned long long* pw = ls->pin;
     unsigned long long h[3] = {pw[0], pw[1], pw[2]};

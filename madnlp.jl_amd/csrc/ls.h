@@ -101,6 +101,8 @@ struct mnk_ls {
     int dag_js2_override = -1;
     int linv_mfma = 1;         // 256x256 explicit inverses on the matrix cores (0: the scalar LDS kernel, ~70 us per workgroup)
     mnk::DevBuf<double> linv512, linv512t, linv512tmp;
+    int pub_next = 0;            // the one-launch solve's publication buffers (two, used alternately): the next solve polls this one ...
+    bool pub_clean[2] = {false, false};   // ... which must be all sentinel; every solve clears the other one in passing (solve.hip)
     int* solve_abort = nullptr;  // pinned host word the solve kernel raises when it gives up (host can read it without a sync)
     long ps_spin_limit = 6000000;  // polls (~0.5 us each) a persistent-solve wait may take before it gives up
     int debug_pp_missing = -1;     // tests only: this diagonal strip of every persistent panel launch never publishes
@@ -142,9 +144,10 @@ int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_prefill_spare(mnk_ls* ls);   // ls.hip: queue the background zero-fill of the spare factor buffer (if one is due)
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_factorization_dag(mnk_ls* ls);   // dag.hip: the task-DAG schedule (panel_algo = 5)
+int mnk_ls_dag_prepare(mnk_ls* ls);             // dag.hip: its buffers (0: ready; otherwise the device cannot hold them -> schedule 4)
 int mnk_launch_pchain(mnk_ls* ls, hipStream_t sp, const mnk::PpDag& dag, int js_begin, int js_end, unsigned strips);  // factor.hip
 unsigned long long* mnk_ls_growth_word(mnk_ls* ls);  // factor.hip: where the kernels fold max(|d|, |v|) (NULL: guard off)
-int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* Np, device */);
+int mnk_ls_run_solve(mnk_ls* ls, double* xdev /* the solver's work vector */, double* xuser = nullptr /* N entries on the device, or NULL: xdev holds the padded rhs */);
 int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);  // 256x256 triangles of the strip-columns [sc0, sc1)
 int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);   // 64x64 blocks + 256x256 triangles
 // Right-side triangular solve of `nrows` free-standing rows (multiple of 16) against the factored diagonal block that

@@ -108,11 +108,6 @@ __global__ __launch_bounds__(256) void copy_lower_kernel(double* __restrict__ F,
     }
 }
 
-__global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t N, int64_t Np) {
-    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (k < Np) dst[k] = k < N ? src[k] : 0.0;
-}
-
 }  // namespace mnk
 
 using namespace mnk;
@@ -121,6 +116,46 @@ static std::mutex g_ctx_mutex;
 static std::atomic<int> g_live_ctx[64];
 
 int mnk_live_contexts(int device) { return g_live_ctx[device & 63].load(std::memory_order_relaxed); }
+
+// ---- device arbiter of the persistent kernels (common.h) ----
+namespace {
+struct PersistSlot {
+    std::recursive_mutex mu;   // (recursive: a factorization that is redone inside mnk_ls_fetch_info re-enters on the same thread)
+    hipEvent_t last = nullptr;
+    bool recorded = false;
+};
+PersistSlot g_persist[64];
+PersistSlot& persist_slot_of(mnk_ctx* ctx) {
+    if (!ctx->partitioned) return g_persist[ctx->device & 63];
+    if (ctx->persist_slot == nullptr) ctx->persist_slot = new PersistSlot();   // (created before the context is shared between threads: mnk_ctx_create_partition)
+    return *static_cast<PersistSlot*>(ctx->persist_slot);
+}
+}  // namespace
+
+int mnk_persist_begin(mnk_ctx* ctx, hipStream_t s) {
+    PersistSlot& ps = persist_slot_of(ctx);
+    ps.mu.lock();
+    if (ps.last == nullptr && hipEventCreateWithFlags(&ps.last, hipEventDisableTiming) != hipSuccess) {
+        ps.last = nullptr;
+        ps.mu.unlock();
+        mnk::set_error("mnk_persist_begin: hipEventCreate failed");
+        return -2;
+    }
+    if (ps.recorded && hipStreamWaitEvent(s, ps.last, 0) != hipSuccess) {
+        ps.mu.unlock();
+        mnk::set_error("mnk_persist_begin: hipStreamWaitEvent failed");
+        return -2;
+    }
+    return 0;
+}
+
+int mnk_persist_end(mnk_ctx* ctx, hipStream_t s, int rc) {
+    PersistSlot& ps = persist_slot_of(ctx);
+    if (hipEventRecord(ps.last, s) == hipSuccess) ps.recorded = true;
+    else if (rc == 0) { mnk::set_error("mnk_persist_end: hipEventRecord failed"); rc = -2; }
+    ps.mu.unlock();
+    return rc;
+}
 
 static void ctx_free(mnk_ctx* c) {
     (void)hipSetDevice(c->device);
@@ -133,12 +168,19 @@ static void ctx_free(mnk_ctx* c) {
     for (hipEvent_t e : c->ev_bdone) (void)hipEventDestroy(e);
     if (c->sp) (void)hipStreamDestroy(c->sp);
     if (c->su) (void)hipStreamDestroy(c->su);
-    if (c->sp_dag) (void)hipStreamDestroy(c->sp_dag);
-    if (c->su_dag) (void)hipStreamDestroy(c->su_dag);
-    if (c->sp_dag2) (void)hipStreamDestroy(c->sp_dag2);
-    if (c->su_dag2) (void)hipStreamDestroy(c->su_dag2);
+    if (!c->shared_dag_streams) {   // (the per-device set of the whole-device contexts lives as long as the process)
+        if (c->sp_dag) (void)hipStreamDestroy(c->sp_dag);
+        if (c->su_dag) (void)hipStreamDestroy(c->su_dag);
+        if (c->sp_dag2) (void)hipStreamDestroy(c->sp_dag2);
+        if (c->su_dag2) (void)hipStreamDestroy(c->su_dag2);
+    }
     if (c->s_fill) (void)hipStreamDestroy(c->s_fill);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->persist_slot) {
+        PersistSlot* ps = static_cast<PersistSlot*>(c->persist_slot);
+        if (ps->last) (void)hipEventDestroy(ps->last);
+        delete ps;
+    }
     delete c;
 }
 
@@ -163,6 +205,7 @@ bool mnk_ls_take_solve_abort(mnk_ls* ls) {
     if (!ls->solve_abort || *ls->solve_abort == 0) return false;
     *ls->solve_abort = 0;
     ls->persistent_solve = 0;
+    ls->pub_clean[0] = ls->pub_clean[1] = false;
     return true;
 }
 
@@ -247,12 +290,26 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
         const int q4 = std::max(4, c->num_cu / 4);
         if (make_pair(q4, c->sp, c->su)) c->panel_cus = q4;
     }
-    // second pair for the task-DAG schedule: a handful of CUs for the pivot chain (two per XCD), the rest for the bulk kernel
+    // second pair for the task-DAG schedule: a handful of CUs for the pivot chain (two per XCD), the rest for the bulk kernel.
+    // Whole-device contexts SHARE these four streams per device: the persistent operations of a process take turns on the
+    // device anyway (mnk_persist_begin), and every stream more is one more client of the runtime's few hardware queues -- two
+    // streams whose kernels must run side by side (chain and bulk) must not end up multiplexed behind a third one.
     if (c->num_cu >= 64) {
-        const int want = getenv("MNK_DAG_CUS") ? atoi(getenv("MNK_DAG_CUS")) : 16;
-        if (make_pair(want, c->sp_dag, c->su_dag)) c->dag_cus = want;
-        const int want2 = getenv("MNK_DAG_CUS2") ? atoi(getenv("MNK_DAG_CUS2")) : 96;
-        if (c->dag_cus > 0 && make_pair(want2, c->sp_dag2, c->su_dag2)) c->dag_cus2 = want2;
+        struct DagStreams { hipStream_t sp = nullptr, su = nullptr, sp2 = nullptr, su2 = nullptr; int cus = 0, cus2 = 0; bool made = false; };
+        static DagStreams shared[64];
+        DagStreams own;
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        DagStreams& d = part ? own : shared[device & 63];
+        if (!d.made) {
+            const int want = getenv("MNK_DAG_CUS") ? atoi(getenv("MNK_DAG_CUS")) : 16;
+            if (make_pair(want, d.sp, d.su)) d.cus = want;
+            const int want2 = getenv("MNK_DAG_CUS2") ? atoi(getenv("MNK_DAG_CUS2")) : 96;
+            if (d.cus > 0 && make_pair(want2, d.sp2, d.su2)) d.cus2 = want2;
+            d.made = true;
+        }
+        c->sp_dag = d.sp; c->su_dag = d.su; c->dag_cus = d.cus;
+        c->sp_dag2 = d.sp2; c->su_dag2 = d.su2; c->dag_cus2 = d.cus2;
+        c->shared_dag_streams = !part;
     }
     if (!c->sp) {
         int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
@@ -339,7 +396,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     rc |= ls->linv256t.alloc((size_t)((ls->Np + 255) / 256) * 65536);
     rc |= ls->dvec.alloc(ls->Np);
     rc |= ls->dinv.alloc(ls->Np);
-    rc |= ls->xwork.alloc(6 * ls->Np);
+    rc |= ls->xwork.alloc(10 * ls->Np);
     if (hipHostMalloc((void**)&ls->solve_abort, sizeof(int), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         ls->solve_abort = nullptr;
@@ -379,7 +436,17 @@ int mnk_ls_destroy(mnk_ls* ls) {
 int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     MNK_REQUIRE(ls && key, "mnk_ls_set_option: NULL argument");
     for (const std::string& k : ls->env_keys)
-        if (k == key) return 0;   // fixed by the environment for this process (MNK_OPTIONS)
+        if (k == key) {   // fixed by the environment for this process (MNK_OPTIONS): the call is ignored, once per key out loud
+            static std::mutex warn_mutex;
+            static std::vector<std::string> warned;
+            std::lock_guard<std::mutex> lock(warn_mutex);
+            if (std::find(warned.begin(), warned.end(), k) == warned.end()) {
+                warned.push_back(k);
+                fprintf(stderr, "madnlp_hip: set_option('%s', %g) ignored: the option is pinned by MNK_OPTIONS / MNK_PANEL_ALGO / "
+                                "MNK_PERSISTENT_SOLVE for this process (query: get_stat(\"pinned:%s\"))\n", key, value, key);
+            }
+            return 0;
+        }
     if (!strcmp(key, "pivot_tol")) { ls->pivot_tol = value; return 0; }
     if (!strcmp(key, "split_a")) { ls->split_a = (int)value; return 0; }
     if (!strcmp(key, "tail_rows")) { ls->tail_rows = (int64_t)value; return 0; }
@@ -519,6 +586,10 @@ static int prepare_fill(mnk_ls* ls) {
     if (pre && ls->spare_zeroed) {
         std::swap(ls->fact.p, ls->fact_spare.p);          // the buffer zeroed in the background becomes the factor buffer
         MNK_HIP(hipStreamWaitEvent(s, ls->ev_spare, 0));
+        // the other buffer now holds the previous factor: it counts as zeroed again only after a COMPLETED
+        // mnk_ls_prefill_spare() (a second transfer for the same factorize! -- the pivoted tier, a redo after a time-out --
+        // would otherwise swap the old factor back in and scatter the sparse entries over it)
+        ls->spare_zeroed = false;
     } else {
         hipLaunchKernelGGL(fill_lower_kernel, grid, dim3(256), 0, s, ls->fact.p, ls->ld, ls->N, ls->Np);
     }
@@ -731,6 +802,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
         // the stepwise solve from here on
         *ls->solve_abort = 0;
         ls->persistent_solve = 0;
+        ls->pub_clean[0] = ls->pub_clean[1] = false;
         set_error("mnk_ls_solve: an earlier persistent solve on device-resident data gave up waiting for a peer "
                   "workgroup (device oversubscribed by another process?); its result is invalid -- refactorize/solve "
                   "again (persistent_solve is now off for this solver)");
@@ -741,12 +813,13 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
     double* w = ls->xwork.p;
     for (int64_t k = 0; k < nrhs; ++k) {
         double* xk = x + k * ldx;
-        if (loc == MNK_DEVICE) {
-            hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, s, w, xk, N, Np);
-        } else {
-            MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
-            MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
+        if (loc == MNK_DEVICE) {   // (the one-launch solve works on the caller's vector itself)
+            int rc = mnk_ls_run_solve(ls, w, xk);
+            if (rc) return rc;
+            continue;
         }
+        MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
+        MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
         int rc = mnk_ls_run_solve(ls, w);
         if (rc) return rc;
         if (loc != MNK_DEVICE && ls->persistent_solve) {
@@ -769,7 +842,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
 }
 
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n) {
-    if (ls && out && ls->dag_trace.p) {  // the task-DAG schedule's trace (option dag_trace) shares this read-out
+    if (ls && out && ls->dag_trace.p && ls->dag_trace_on) {  // the task-DAG schedule's trace (option dag_trace) shares this read-out
         MNK_HIP(hipSetDevice(ls->ctx->device));
         MNK_HIP(mnk::stream_wait(ls->ctx->stream));
         const int64_t cnt = std::min<int64_t>(n, (int64_t)ls->dag_trace.n);
@@ -803,6 +876,10 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     if (ls->factorized) {
         int rc = mnk_ls_fetch_info(ls);
         if (rc) return rc;
+    }
+    if (!strncmp(key, "pinned:", 7)) {   // 1 if MNK_OPTIONS & co. fixed this option for the process (set_option calls on it are ignored)
+        *value = std::find(ls->env_keys.begin(), ls->env_keys.end(), std::string(key + 7)) != ls->env_keys.end() ? 1.0 : 0.0;
+        return 0;
     }
     if (!strcmp(key, "panel_algo")) { *value = ls->algo_now; return 0; }
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }

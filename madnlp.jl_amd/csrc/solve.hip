@@ -369,6 +369,11 @@ __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst,
     return __syncthreads_or(bad) == 0;
 }
 
+__global__ void pad_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t N, int64_t Np) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k < Np) dst[k] = k < N ? src[k] : 0.0;
+}
+
 // (the abort word is cleared by the host only, after it has dealt with an abort: a solve that follows an
 // aborted one on the same stream must not hide it)
 __global__ void ps_reset_kernel(unsigned long long* pub, int64_t n) {
@@ -383,8 +388,11 @@ constexpr int PS_CW = 256 / PS_NQ;   // columns per chunk
 template <bool LDL>
 __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv, const double* __restrict__ InvT,
-    const double* __restrict__ dinv, double* __restrict__ xio /* Np: rhs in, solution out */,
-    double* __restrict__ pub /* 4*Np sentinel-filled: bfin | y | zfin | x */, int64_t Np, int* abort_flag,
+    const double* __restrict__ dinv, const double* xin /* N: right-hand side (rows N..Np-1 are zero) */,
+    double* xout /* N: solution (may alias xin) */, int64_t N,
+    double* __restrict__ pub /* 4*Np sentinel-filled: bfin | y | zfin | x */,
+    double* __restrict__ pub_other /* the buffer of the NEXT solve: this launch fills it with the sentinel (or NULL) */,
+    int64_t Np, int* abort_flag,
     const int* __restrict__ info, unsigned long long* __restrict__ trace /* optional: 8 stamps per block */,
     int near_steps, int nap, long spin_limit, int missing_wg) {
 #define PS_STAMP(blk, slot) do { if (trace != nullptr && t == 0) trace[(int64_t)(blk) * 8 + (slot)] = wall_clock64(); } while (0)
@@ -392,19 +400,30 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     __shared__ double ysol[PS_MAXOWN][64];  // forward solution of the owned blocks
     __shared__ double xs[256];              // the step's published vector
     __shared__ double part[PS_NQ][64];      // partial sums
-    if (*info != 0) return;
     const int t = threadIdx.x, r = t & 63, q = t >> 6;
     const int G = gridDim.x, g = blockIdx.x;
     const int nb = (int)(Np / 64);
     const int nsteps = (nb + 3) / 4;
     const int nown = g < nb ? (nb - g + G - 1) / G : 0;
+    // The sentinel fill for the NEXT solve (it uses the other of two publication buffers): every workgroup clears the four
+    // words of each element of its own blocks -- round 3 launched a reset kernel in front of every solve.  First thing,
+    // whatever happens to this solve.
+    if (pub_other != nullptr)
+        for (int e = t; e < nown * 256; e += PS_NT) {
+            const int m = e >> 8, arr = (e >> 6) & 3;
+            reinterpret_cast<unsigned long long*>(pub_other)[(int64_t)arr * Np + (int64_t)(g + m * G) * 64 + (e & 63)] = ~0ull;
+        }
+    if (*info != 0) return;
     if (nown == 0) return;
     if (g == missing_wg) return;  // tests: a peer that never became resident (everyone else must give up, not hang)
     double* bfin = pub;
     double* ypub = pub + Np;
     double* zfin = pub + 2 * Np;
     double* xpub = pub + 3 * Np;
-    for (int e = t; e < nown * 64; e += PS_NT) run[e >> 6][e & 63] = xio[(int64_t)(g + (e >> 6) * G) * 64 + (e & 63)];
+    for (int e = t; e < nown * 64; e += PS_NT) {
+        const int64_t row = (int64_t)(g + (e >> 6) * G) * 64 + (e & 63);
+        run[e >> 6][e & 63] = row < N ? xin[row] : 0.0;   // (the caller's vector itself: no padded staging copy)
+    }
     __syncthreads();
 
     double a[PS_CW];  // slice of L the next update multiplies
@@ -545,7 +564,7 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
             if (t < 64) {
                 const double v = reduce_parts(t);
                 ps_publish(xpub + (int64_t)i * 64 + t, v);
-                xio[(int64_t)i * 64 + t] = v;
+                if ((int64_t)i * 64 + t < N) xout[(int64_t)i * 64 + t] = v;
             }
             have_d = false;
             --m1;
@@ -922,10 +941,13 @@ int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
     return 0;
 }
 
-// xdev: 6*Np doubles; on entry xdev[0:Np] = rhs (zero padded); on exit xdev[0:Np] = solution.
-int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
+// xdev: the solver's work vector (10*Np doubles: x | y | two publication buffers of 4*Np).
+// xuser == NULL: on entry xdev[0:Np] = rhs (zero padded); on exit xdev[0:Np] = solution.
+// xuser != NULL: a device vector of N entries, rhs on entry, solution on exit; the one-launch solve reads and writes it
+// directly (ONE launch per solve: no padded staging copy, no reset kernel, no copy back), every other path stages through xdev.
+int mnk_ls_run_solve(mnk_ls* ls, double* xdev, double* xuser) {
     hipStream_t s = ls->ctx->stream;
-    const int64_t Np = ls->Np, ld = ls->ld;
+    const int64_t Np = ls->Np, ld = ls->ld, N = ls->N;
     const int ldl = ls->algo == MNK_LDL;
     const int64_t nb64 = Np / 64;
     const int G = (int)std::min<int64_t>(nb64, ls->ctx->num_cu);
@@ -933,28 +955,47 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
     // block-diagonal D^-1, scatter (a 2x2 block may straddle two 64-row blocks, which the one-launch solve's
     // block ownership does not allow)
     const bool bk = ls->bk_active;
+    const bool persistent = !bk && ls->persistent_solve && G >= 1 && (nb64 + G - 1) / G <= PS_MAXOWN && (G >= 4 || nb64 <= G);
+    const int64_t nb32 = Np / P5_RB;
+    const int G5 = (int)std::min<int64_t>(nb32, ls->ctx->num_cu);
+    const bool use512 = persistent && ls->solve512 && ls->linv512.p && (nb32 + G5 - 1) / G5 <= PS_MAXOWN && (G5 >= P5_NBS || nb32 <= G5);
+    const bool direct = persistent && !use512;
+    auto stage_in = [&]() -> int {
+        if (xuser != nullptr) hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, s, xdev, xuser, N, Np);
+        MNK_HIP(hipGetLastError());
+        return 0;
+    };
+    auto stage_out = [&]() -> int {
+        if (xuser != nullptr) MNK_HIP(hipMemcpyAsync(xuser, xdev, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        return 0;
+    };
+    if (!direct) {
+        int rc = stage_in();
+        if (rc) return rc;
+    }
     if (bk) {
         int rc = mnk_ls_bk_permute(ls, xdev, xdev + 2 * Np, true);
         if (rc) return rc;
     }
-    if (!bk && ls->persistent_solve && G >= 1 && (nb64 + G - 1) / G <= PS_MAXOWN && (G >= 4 || nb64 <= G)) {
-        // The kernel needs all its workgroups resident at once (one per CU).  Two of them launched
-        // from different contexts could each grab part of the chip and wait for the rest forever, so
-        // persistent solves of one process are chained on the device through an event.
-        static std::mutex ps_mutex;
-        static hipEvent_t ps_last[64] = {};
-        std::lock_guard<std::mutex> lock(ps_mutex);
-        hipEvent_t& last = ps_last[ls->ctx->device & 63];
-        if (last == nullptr) MNK_HIP(hipEventCreateWithFlags(&last, hipEventDisableTiming));
-        else MNK_HIP(hipStreamWaitEvent(s, last, 0));
+    if (persistent) {
+        // The kernel needs all its workgroups resident at once (one per CU).  Two of them launched from different contexts
+        // could each grab part of the chip and wait for the rest forever, and the same holds next to a persistent
+        // factorization: the persistent operations of one process take turns on the device (common.h: mnk_persist_begin).
+        int rc = mnk_persist_begin(ls->ctx, s);
+        if (rc) return rc;
         const int ps_near = PS_NEAR, ps_nap = 6;
-        double* pub = xdev + 2 * Np;
-        hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<unsigned long long*>(pub), 4 * Np);
-        const int64_t nb32 = Np / P5_RB;
-        const int G5 = (int)std::min<int64_t>(nb32, ls->ctx->num_cu);
-        if (ls->solve512 && ls->linv512.p && (nb32 + G5 - 1) / G5 <= PS_MAXOWN && (G5 >= P5_NBS || nb32 <= G5)) {
+        double* pubs[2] = {xdev + 2 * Np, xdev + 6 * Np};
+        auto ensure_clean = [&](int b) {
+            if (!ls->pub_clean[b])
+                hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, s,
+                                   reinterpret_cast<unsigned long long*>(pubs[b]), 4 * Np);
+            ls->pub_clean[b] = true;
+        };
+        if (use512) {
             // steps of 512 columns, blocks of 32 rows (half the steps, the same two hops per step)
+            ls->pub_clean[0] = false;
+            ensure_clean(0);
+            double* pub = pubs[0];
             if (ldl)
                 hipLaunchKernelGGL(persistent_solve512_kernel<true>, dim3(G5), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv512.p,
                                    ls->linv512t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p, ps_near, ps_nap,
@@ -963,22 +1004,32 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
                 hipLaunchKernelGGL(persistent_solve512_kernel<false>, dim3(G5), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv512.p,
                                    ls->linv512t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p, ps_near, ps_nap,
                                    ls->ps_spin_limit, ls->debug_ps_missing);
-            MNK_HIP(hipGetLastError());
-            MNK_HIP(hipEventRecord(last, s));
-            return 0;
+            ls->pub_clean[0] = false;
+            rc = hipGetLastError() == hipSuccess ? 0 : -2;
+            rc = mnk_persist_end(ls->ctx, s, rc);
+            return rc ? rc : stage_out();
         }
+        // two publication buffers: this solve polls `cur` (all sentinel) and fills `oth` with the sentinel for the next one
+        const int cur = ls->pub_next, oth = cur ^ 1;
+        ensure_clean(cur);
+        const double* xin = xuser != nullptr ? xuser : xdev;
+        double* xout = xuser != nullptr ? xuser : xdev;
+        const int64_t nio = xuser != nullptr ? N : Np;
         if (ldl)
             hipLaunchKernelGGL(persistent_solve_kernel<true>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld, ls->linv256.p,
-                               ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort, ls->info_dev.p,
+                               ls->linv256t.p, ls->dinv.p, xin, xout, nio, pubs[cur], pubs[oth], Np, ls->solve_abort, ls->info_dev.p,
                                ls->solve_trace.p, ps_near, ps_nap, ls->ps_spin_limit, ls->debug_ps_missing);
         else
             hipLaunchKernelGGL(persistent_solve_kernel<false>, dim3(G), dim3(PS_NT), 0, s, ls->fact.p, ld,
-                               ls->linv256.p, ls->linv256t.p, ls->dinv.p, xdev, pub, Np, ls->solve_abort,
+                               ls->linv256.p, ls->linv256t.p, ls->dinv.p, xin, xout, nio, pubs[cur], pubs[oth], Np, ls->solve_abort,
                                ls->info_dev.p, ls->solve_trace.p, ps_near, ps_nap, ls->ps_spin_limit,
                                ls->debug_ps_missing);
-        MNK_HIP(hipGetLastError());
-        MNK_HIP(hipEventRecord(last, s));
-        return 0;
+        ls->pub_clean[cur] = false;
+        // (a test's "missing" workgroup does not clear its blocks either; a solve that gives up marks both buffers dirty: mnk_ls_take_solve_abort)
+        ls->pub_clean[oth] = ls->debug_ps_missing < 0;
+        ls->pub_next = oth;
+        rc = hipGetLastError() == hipSuccess ? 0 : -2;
+        return mnk_persist_end(ls->ctx, s, rc);
     }
     double* b = xdev;       // forward: running right-hand side; backward: solution
     double* y = xdev + Np;  // forward: solution of L y = b (scaled by D^-1 for LDL); backward: running rhs
@@ -1009,6 +1060,9 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev) {
                                nrow);
     }
     MNK_HIP(hipGetLastError());
-    if (bk) return mnk_ls_bk_permute(ls, xdev, xdev + 2 * Np, false);
-    return 0;
+    if (bk) {
+        int rc = mnk_ls_bk_permute(ls, xdev, xdev + 2 * Np, false);
+        if (rc) return rc;
+    }
+    return stage_out();
 }

@@ -281,6 +281,17 @@ class HipLinearSolver:
         L.check(L.lib().mnk_ls_get_factor(self._h, Lm.ctypes.data, D.ctypes.data, L.MNK_HOST), "mnk_ls_get_factor")
         return Lm, D
 
+    def get_factor_device(self):
+        """(L, D) as torch tensors on the solver's device (column-major image in a row-major tensor is transposed back), for
+        tests at sizes whose factor should not cross PCIe."""
+        import torch
+        dev = torch.device("cuda", self.ctx.device)
+        Lt = torch.empty((self.n, self.n), dtype=torch.float64, device=dev)   # receives the column-major factor: Lt = L'
+        D = torch.empty(self.n, dtype=torch.float64, device=dev)
+        L.check(L.lib().mnk_ls_get_factor(self._h, C.c_void_p(Lt.data_ptr()), C.c_void_p(D.data_ptr()), L.MNK_DEVICE),
+                "mnk_ls_get_factor")
+        return Lt.T, D
+
     def close(self):
         if self._h:
             L.lib().mnk_ls_destroy(self._h)

@@ -357,11 +357,12 @@ def test_ipm_lootsma_hip_reproduces_reference_answers(ctx, kind):
 
 # --------------------------------------------------------------------------- persistent panel kernel: safety net
 @pytest.mark.parametrize("N,expect", [(1200, 4.0), (2300, 5.0)])
-def test_persistent_panel_is_the_default_when_the_context_is_alone_and_gives_way_otherwise(ctx, N, expect):
-    """panel_algo = 4 / 5 keep waiting workgroups resident, which is only safe while no other context of the process
-    runs persistent kernels on the same CUs: with one live context the factor comes from them (small systems: the
-    persistent panel kernel; from dag_min_rows on: the task-DAG schedule), with a second context alive the solver takes
-    the one-launch-per-piece path by itself; the factors agree to rounding."""
+def test_persistent_schedules_stay_in_use_next_to_other_contexts(ctx, N, expect):
+    """panel_algo = 4 / 5 keep waiting workgroups resident, which is only safe while no other persistent kernel runs on
+    the same CUs.  Round 3 gave the persistent schedules up as soon as a second context was alive (one launch per piece,
+    12.4 instead of 9.3 ms at C3); since round 4 the persistent operations of a process take turns on the device
+    (mnk_persist_begin), so a second live context changes nothing: same schedule (small systems: the persistent panel
+    kernel; from dag_min_rows on: the task-DAG schedule), same bits."""
     rng = np.random.default_rng(4)
     A = _spd(rng, N)
     b = rng.standard_normal(N)
@@ -370,17 +371,23 @@ def test_persistent_panel_is_the_default_when_the_context_is_alone_and_gives_way
     alone = M.get_stat("panel_algo")
     assert alone == expect
     x4 = M.solve_linear_system(b.copy())
+    L4, D4 = M.get_factor()
     other = mj.HipContext(0)
     try:
+        M2 = mj.HipLinearSolver(A, ctx=other, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
+        M2.factorize()
         M.factorize()
-        assert M.get_stat("panel_algo") == 1.0
+        assert M.get_stat("panel_algo") == alone and M2.get_stat("panel_algo") == alone
+        assert M.get_stat("pp_fallbacks") == 0.0 and M2.get_stat("pp_fallbacks") == 0.0
         x1 = M.solve_linear_system(b.copy())
+        x2 = M2.solve_linear_system(b.copy())
+        L1, D1 = M.get_factor()
+        M2.close()
     finally:
         other.close()
-    M.factorize()
-    assert M.get_stat("panel_algo") == alone
-    assert np.abs(A @ x4 - b).max() <= 1e-10 * N and np.abs(A @ x1 - b).max() <= 1e-10 * N
-    np.testing.assert_allclose(x1, x4, rtol=0, atol=1e-11 * np.abs(x4).max())
+    assert np.abs(A @ x4 - b).max() <= 1e-10 * N
+    assert np.array_equal(x1, x4) and np.array_equal(x2, x4)
+    assert np.array_equal(np.tril(L1), np.tril(L4)) and np.array_equal(D1, D4)
     M.close()
 
 
