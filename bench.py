@@ -77,6 +77,9 @@ def parse_args():
                          "back on one context, which keeps the persistent panel kernel in use (it needs the panel "
                          "CUs for itself) -- measured per GPU at batch 16: 77.4 it/s with 1 context, 58.7 with 2, "
                          "68.2 with 4 (the time-shared contexts fall back to one launch per panel piece)")
+    ap.add_argument("--no-batch-api", action="store_true",
+                    help="batch > 1: enqueue the factorizations one by one instead of through mnk_factorize_batch_begin/_end "
+                         "(one merged persistent launch for all instances of a step: they fill each other's chain-bound ends)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the supplementary config-C4 record (case9241pegase shape, ~15 s)")
     ap.add_argument("--no-ipm-loop", action="store_true",
@@ -477,11 +480,18 @@ def main():
                 din["x"].copy_(din["rhs"])
                 kb.linear_solver.solve_linear_system(din["x"])
 
+    use_batch_api = args.batch > 1 and not args.no_batch_api
+
     def step():
         # batch: every instance's assembly + factorization is enqueued before the first inertia fetch
         # blocks the host, so the contexts keep the chip busy while the host waits
-        for (_, kb, st, din) in insts:
-            step_front(kb, st, din)
+        if use_batch_api:
+            with mj.factorize_batch():
+                for (_, kb, st, din) in insts:
+                    step_front(kb, st, din)
+        else:
+            for (_, kb, st, din) in insts:
+                step_front(kb, st, din)
         for (_, kb, st, din) in insts:
             step_back(kb, st, din)
 
@@ -544,6 +554,8 @@ def main():
                                    f" per instance",
                        "algorithm": f"{args.algorithm} (device: {'Cholesky' if args.algorithm == 'CHOLESKY' else 'static-pivot LDL^T'})",
                        "outer_block": args.outer_block, "batch_per_gpu": args.batch,
+                       "batch_api": ("mnk_factorize_batch_begin/_end: one merged persistent launch per step" if use_batch_api
+                                     else ("off" if args.batch > 1 else "n/a (one instance)")),
                        "parallelism": f"{world} GPU(s) x {args.batch} independent instance(s)"},
             "ms_per_factorize": fact_ms,
             "ms_per_solve": float(np.mean([a[2] for a in allms])),

@@ -167,6 +167,16 @@ int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowva
  * mnk_ls_inertia (which synchronizes). */
 int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc);
 int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc);
+/* Batches of INDEPENDENT factorizations (scenario batches, BASELINE config C5; the reference drives distinct solver
+ * instances concurrently, `src/KKT/Schur/schur.jl:927-1001` `@blas_safe_threads for k in 1:ns`).  Between _begin and _end
+ * the factorize! calls of the calling thread (any solver, any context of one device) transfer their matrices and are
+ * queued; _end launches them together: the task queues of instances of the same order are merged into one persistent
+ * launch beside two pivot chains, so that one instance's chain-bound ends are filled with its neighbours' trailing
+ * updates (N = 11 192: ~10.7 -> ~9.x ms per instance).  Every instance's factor is bit-identical to the one a lone
+ * factorize! produces.  Any call that needs a queued solver's factor (inertia, solve, another factorize!, destroy)
+ * launches what is queued first, so a forgotten _end cannot give a stale answer.  Thread-local: one open batch per thread. */
+int mnk_factorize_batch_begin(void);
+int mnk_factorize_batch_end(void);
 
 /* inertia(M) `lapack_common.jl:96-109`, `lapack.jl:240-268`: (num_pos, num_zero, num_neg).
  * CHOLESKY: info == 0 ? (N,0,0) : (0,N,0).  LDL: signs of D. */
@@ -468,6 +478,10 @@ int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);
  * 128-row tiles: 4 ints per task (flags | chunk index << 8, tile row I, tile column J, kbeg | kend << 16) in queue order, at most
  * `cap` tasks written; returns the number of tasks (negative: bad arguments). */
 int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int taper0, int* out, int cap, int* first_phase);
+/* ... and the merged queue of a batch of `ninst` instances shifted by `period` tile columns of chain position (with the
+ * zero-fill tasks of the next factorization's buffer if `fill`): the instance index sits in bits 16.. of the second int. */
+int mnk_debug_dag_merged_tasks(int ntile, int chunk, int band_tiles, int js2, int taper0, int fill, int ninst, int period,
+                               int* out, int cap);
 
 /* Diagnostics (tools/microbench_update.py): time `reps` lower-tile trailing updates C -= A*A^T under the
  * schedules the factorization uses (static tiling / tile queue; context, update, update+panel streams). */

@@ -196,6 +196,32 @@ function MadNLP.factorize!(M::HipLinearSolver{T, <:SparseMatrixCSC}) where T
     return M
 end
 
+# Batches of INDEPENDENT solver instances (scenario batches; the reference threads over them,
+# src/KKT/Schur/schur.jl:927-1001 `@blas_safe_threads for k in 1:ns`): the factorizations are queued and launched
+# together -- instances of the same order share one persistent launch and fill each other's chain-bound ends
+# (include/madnlp_hip.h: mnk_factorize_batch_begin / _end).  `inertia` / `solve_linear_system!` of each solver
+# afterwards as usual; every factor is bit-identical to a lone factorize!.
+function factorize_async!(M::HipLinearSolver{T, <:HipAugCSC}) where T
+    rc = ccall((:mnk_ls_factorize_sc_async, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), M.handle, M.A.sc.handle)
+    check(rc, FactorizationException)
+    return M
+end
+function factorize_async!(M::HipLinearSolver{T, <:HipAugDense}) where T
+    rc = ccall((:mnk_ls_factorize_dc_async, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), M.handle, M.A.dc.handle)
+    check(rc, FactorizationException)
+    return M
+end
+function factorize_batch(f)
+    check(ccall((:mnk_factorize_batch_begin, libmadnlp_hip), Cint, ()), FactorizationException)
+    try
+        f()
+    finally
+        check(ccall((:mnk_factorize_batch_end, libmadnlp_hip), Cint, ()), FactorizationException)
+    end
+    return nothing
+end
+factorize_batch!(Ms) = (factorize_batch(() -> foreach(factorize_async!, Ms)); Ms)
+
 function MadNLP.solve_linear_system!(M::HipLinearSolver, x::Vector{Float64})
     rc = ccall((:mnk_ls_solve, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cint),
                M.handle, x, 1, length(x), MNK_HOST)

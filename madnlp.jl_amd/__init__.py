@@ -7,7 +7,7 @@ fails loudly if it has not been built (no CPU fallback).
 """
 from ._lib import build, lib, LIBPATH, HipError  # noqa: F401
 from .linear_solver import (  # noqa: F401
-    BUNCHKAUFMAN, CHOLESKY, LDL, HipContext, HipLinearSolver, HipSolverOptions,
+    BUNCHKAUFMAN, CHOLESKY, LDL, HipContext, HipLinearSolver, HipSolverOptions, factorize_batch,
     LinearSolverException, SymbolicException, FactorizationException, SolveException, InertiaException,
 )
 from .kkt import (  # noqa: F401

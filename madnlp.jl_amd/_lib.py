@@ -208,6 +208,9 @@ SIGNATURES = {
     "mnk_schur_backward": (C.c_int, [_vp, _vp, _vp]),
     "mnk_ls_debug_solve_trace": (C.c_int, [_vp, _vp, C.c_int64]),
     "mnk_debug_dag_tasks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
+    "mnk_debug_dag_merged_tasks": (C.c_int, [C.c_int] * 8 + [_vp, C.c_int]),
+    "mnk_factorize_batch_begin": (C.c_int, []),
+    "mnk_factorize_batch_end": (C.c_int, []),
     "mnk_debug_update": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int,
                                    C.POINTER(C.c_double)]),
     "mnk_gemm_nt": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp,

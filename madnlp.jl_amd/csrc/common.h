@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -62,6 +63,28 @@ inline hipError_t stream_wait(hipStream_t s) {
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// One process-wide lock around (a) the launch sequence of every group of PERSISTENT kernels (pivot chain + bulk kernel,
+// persistent panel launches, the one-launch solve: mnk_persist_begin / _end) and (b) every runtime call of this library
+// that may synchronize the whole device (hipFree, hipMalloc, stream / event destruction).  A persistent group is only
+// complete when all of its kernels are in their queues: a device-wide synchronization issued by ANOTHER host thread between
+// two of its launches waits for the resident half of the group, which waits for the half that cannot be launched while the
+// runtime is synchronizing -- seen with four host threads driving four solvers (a solver freed on one thread, a chain
+// waiting 2.5 s for its bulk kernel on another: info = -7, schedule 1).  Frees issued by code outside this library
+// (another allocator in the process) are outside this lock: INTEGRATION.md section 0.
+std::recursive_mutex& launch_mutex();   // ls.hip
+// Called with the lock held, in front of a runtime call that waits for the device to go idle (hipFree, hipHostFree, stream
+// destruction): waits until the last persistent operation of this process has completed.  The lock only keeps such a call
+// from falling BETWEEN the launches of a group; a group that is launched but not yet fully RUNNING is just as exposed --
+// stress runs with six host threads still lost a factorization to a 2.6 s stall (a chain strip waiting for a bulk kernel
+// that had been launched, at the moment another thread destroyed its solver) until frees also waited for the groups in flight.
+void quiesce_persistent();              // ls.hip
+struct LaunchLock {
+    LaunchLock() { launch_mutex().lock(); }
+    ~LaunchLock() { launch_mutex().unlock(); }
+    LaunchLock(const LaunchLock&) = delete;
+    LaunchLock& operator=(const LaunchLock&) = delete;
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -69,6 +92,7 @@ struct DevBuf {
     int alloc(size_t count) {
         release();
         if (count == 0) count = 1;
+        LaunchLock lock;   // (never between two launches of a persistent group of another thread)
         hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
         if (e != hipSuccess) {
             p = nullptr;
@@ -90,7 +114,11 @@ struct DevBuf {
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            LaunchLock lock;   // (hipFree synchronizes the device)
+            quiesce_persistent();
+            (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
     }
@@ -108,6 +136,7 @@ struct mnk_ctx {
     int panel_cus = 0;  // > 0: sp is restricted to this many CUs and su to the others (CU masks)
     // task-DAG schedule (dag.hip): the pivot chain needs only a few CUs, the persistent bulk kernel gets all the others
     hipStream_t sp_dag = nullptr, su_dag = nullptr;
+    hipStream_t sp_dagB = nullptr, su_dagB = nullptr;   // batches (dag.hip): a second chain partition (the next dag_cus mask bits) and a bulk stream on the CUs outside both
     bool shared_dag_streams = false;   // the four task-DAG streams belong to the device's shared set (ls.hip), not to this context
     int dag_cus = 0;    // > 0: sp_dag is restricted to this many CUs and su_dag to the others
     // ... and a third pair for its second phase, where every remaining row is in the chain's band (one CU per 64 rows)
@@ -127,6 +156,7 @@ struct mnk_ctx {
     int children = 0;
     bool released = false;
 };
+int mnk_dag_warmup(hipStream_t* streams, int n);   // dag.hip: first (empty) launch of the bulk kernels on these streams
 int mnk_live_contexts(int device);  // contexts alive on this device in this process
 // Device arbiter of the PERSISTENT kernels (task-DAG schedule, persistent panel launches, one-launch solve): their waiting
 // workgroups stay resident, so two of them from different contexts must never share the chip (each could hold CUs the
@@ -181,11 +211,8 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
 // ---- task-DAG schedule (dag.hip): persistent left-looking tile kernel beside the pivot chain -------------------------
 // Task list (4 ints per task, see dag.hip).  Strip-columns Js < js2 have a band of `band_tiles` tile rows, the others a band
 // that covers every remaining row; returns the number of tasks of the first phase (ready before the chain enters js2).
-int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out, int taper0);
-int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
-                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
-                    int* info,
-                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* vmax, unsigned long long* trace,
-                    unsigned long long* wgstat);
+int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out, int taper0, std::vector<int>* ready);
+int dag_add_fill_tasks(int ntile, std::vector<int>& tasks, std::vector<int>& ready, int n1);
+void dag_merge_tasks(const std::vector<int>& tasks, const std::vector<int>& ready, int ninst, int period, std::vector<int>& out);
 
 }  // namespace mnk

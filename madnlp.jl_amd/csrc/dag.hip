@@ -39,51 +39,64 @@
 
 namespace mnk {
 
-struct DagArgs {
+// What a bulk task needs to know about the factorization it belongs to.  One launch may serve SEVERAL independent
+// factorizations of the same order (mnk_factorize_batch_*: the task lists of the instances are merged into one queue, each
+// task carries its instance index), so these live in a per-instance record instead of the kernel's argument block.
+struct DagInst {
     double* F;
     int64_t ld;
     double* V;            // LDL^T: V = L D, same layout as F (the B operand of the updates); Cholesky: nullptr (V = L)
     const double* dinv;   // 1 / d_k
     const double* dblk;   // factored 64x64 diagonal blocks
     const double* inv16;  // inverses of their 16x16 diagonal sub-blocks
-    const int4* tasks;    // (flags | chunk index << 8, I, J, kbeg | kend << 16)
-    int ntasks;
     int* front;
     int* af;
     int* tprog;           // [I * ntile + J]: chunks of tile (I, J) that are in memory
+    int* info;
+    unsigned long long* vmax;   // growth monitor of the static-pivot LDL^T (factor.hip growth_fold): receives max|V|, or NULL
+    double* zfill;        // DAG_FILL tasks: the buffer that becomes the NEXT factorization's zeroed factor buffer (or NULL)
+    int64_t N;            // order of the matrix (rows / columns N .. Np - 1 are padding: unit diagonal)
+};
+
+// (read through the constant address space: the fields are uniform and never written while a bulk kernel runs, so every use
+// is a scalar load that can be repeated instead of a value that must stay live -- a by-value copy of the record in the task
+// loop cost 88 spilled registers and a scratch access inside the K-loop)
+typedef const DagInst __attribute__((address_space(4))) * DagInstP;
+
+struct DagArgs {       // (the batch kernel's; a single factorization: DagArgs1 / dag_bulk_kernel1 below)
+    const DagInst* insts; // the instance records in device memory (written by dag_reset_kernel), indexed by the task's instance field
+    const int4* tasks;    // (flags | chunk index << 8, I | instance << 16, J, kbeg | kend << 16)
+    int ntasks;
     int ntile;
     int* qctr;
-    int* info;
-    const int* prog;      // the pivot chain's per-block progress words (epoch16 + steps completed), see ppanel_kernel
-    int epoch16;
     long spin_limit;
     unsigned long long* trace;  // diagnostics (option dag_trace): 8 time stamps per task
     unsigned long long* wgstat; // diagnostics: per workgroup {first grab, exit, ticks waited, tasks, ticks in finalize}
-    unsigned long long* vmax;   // growth monitor of the static-pivot LDL^T (factor.hip growth_fold): receives max|V|, or NULL
     int fake_share;             // DIAGNOSTIC (env MNK_DAG_FAKE_SHARE, wrong results): every chunk reads the operand rows of tile rows 0..n-1
 };
 
-constexpr int DAG_BANDACC = 1, DAG_FINAL = 2, DAG_FIRST = 4;  // task flags
+constexpr int DAG_BANDACC = 1, DAG_FINAL = 2, DAG_FIRST = 4, DAG_FILL = 8;  // task flags
 
 // Wave 0 waits until min(front[s0..s3]) > c and returns that minimum (clamped to kend): tile columns [c, ret) are final
 // for all four strips.  -1: the factorization failed elsewhere or the wait expired.  Ends with an acquire + barrier.
-__device__ __forceinline__ int dag_wait_front(const DagArgs& a, int s0, int s1, int s2, int s3, int c, int kend, int* s_val) {
+template <class IP>
+__device__ __forceinline__ int dag_wait_front(IP a, long spin_limit, int s0, int s1, int s2, int s3, int c, int kend, int* s_val) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const int idx = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? s2 : s3));
         long spins = 0;
         int r;
         for (;;) {
-            int f = lane < 4 ? __hip_atomic_load(a.front + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT_MAX;
+            int f = lane < 4 ? __hip_atomic_load(a->front + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT_MAX;
             f = min(f, __shfl_xor(f, 1));
             f = min(f, __shfl_xor(f, 2));
             r = __builtin_amdgcn_readfirstlane(f);
             if (r > c) break;
             __builtin_amdgcn_s_sleep(4);
             if ((++spins & 255) == 0) {
-                if (__hip_atomic_load(a.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { r = -1; break; }
-                if (spins > a.spin_limit) {
-                    if (lane == 0) atomicCAS(a.info, 0, -7);
+                if (__hip_atomic_load(a->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { r = -1; break; }
+                if (spins > spin_limit) {
+                    if (lane == 0 && atomicCAS(a->info, 0, -7) == 0) a->info[1] = 1;   // (site 1: a bulk task waiting for operand rows)
                     r = -1;
                     break;
                 }
@@ -100,7 +113,8 @@ __device__ __forceinline__ int dag_wait_front(const DagArgs& a, int s0, int s1, 
 }
 
 // Wave 0 waits until *w0 >= t0 and *w1 >= t1 (progress words of the pivot chain); false: failed / expired.  Acquire + barrier.
-__device__ __forceinline__ bool dag_wait_words(const DagArgs& a, const int* w0, int t0, const int* w1, int t1, int* s_val) {
+template <class IP>
+__device__ __forceinline__ bool dag_wait_words(IP a, long spin_limit, const int* w0, int t0, const int* w1, int t1, int* s_val) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         long spins = 0;
@@ -110,9 +124,9 @@ __device__ __forceinline__ bool dag_wait_words(const DagArgs& a, const int* w0, 
             if (__all(v >= (lane == 0 ? t0 : (lane == 1 ? t1 : INT_MIN)))) break;
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 255) == 0) {
-                if (__hip_atomic_load(a.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
-                if (spins > a.spin_limit) {
-                    if (lane == 0) atomicCAS(a.info, 0, -7);
+                if (__hip_atomic_load(a->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (spins > spin_limit) {
+                    if (lane == 0 && atomicCAS(a->info, 0, -7) == 0) a->info[1] = 2;   // (site 2: chunk order of a tile)
                     ok = 0;
                     break;
                 }
@@ -138,8 +152,8 @@ __device__ __forceinline__ bool dag_wait_words(const DagArgs& a, const int* w0, 
 // staged).  (Starting the block-ja part before D_jb is published, with all operands prefetched into registers, was built
 // and measured slower: the 168-register budget of the k-loop forces the strips to run one after the other.)
 // X: the tile in that layout, X[cb][ns] = column block cb (0..7) of strip ns -- the accumulators of gemm_nt_mainloop3<2, 8>.
-template <bool LDL>
-__device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0, int64_t col0, int ja, char* smem_raw, int tid,
+template <bool LDL, class IP>
+__device__ __forceinline__ void dag_finalize_tile(IP a, int64_t row0, int64_t col0, int ja, char* smem_raw, int tid,
                                                   v4f64 (&X)[8][2], unsigned long long* tr) {
     // trace: six 16-bit stage times (ticks of 10 ns since entry) packed into tr[6] (stages 1..4) and tr[7] (5, 6)
     const unsigned long long t_in = tr ? wall_clock64() : 0;
@@ -151,18 +165,18 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
         }
     };
     v4f64* S = reinterpret_cast<v4f64*>(smem_raw);  // up to 16 blocks x 64 lanes (32 KB of the 36 KB)
-    double* F = a.F;
-    const int64_t ld = a.ld;
+    double* F = a->F;
+    const int64_t ld = a->ld;
     const int lane = tid & 63, w = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     double* Fs = F + (row0 + 32 * w + l15) + (col0 + l4) * ld;  // this lane's element (row of strip 0, column l4)
-    double* Vs = LDL ? a.V + (row0 + 32 * w + l15) + (col0 + l4) * ld : nullptr;
+    double* Vs = LDL ? a->V + (row0 + 32 * w + l15) + (col0 + l4) * ld : nullptr;
     double vm = 0.0;  // max|V| of this wave's strips (growth monitor)
 
     // blocks 0..5: -L_kk[cb, ib] for (cb, ib) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2); blocks 6..9: inv(L_kk[cb, cb])
     auto fill_diag = [&](int jk) {
-        const double* __restrict__ Dk = a.dblk + (int64_t)jk * 4096;
-        const double* __restrict__ Iv = a.inv16 + (int64_t)jk * 1024;
+        const double* __restrict__ Dk = a->dblk + (int64_t)jk * 4096;
+        const double* __restrict__ Iv = a->inv16 + (int64_t)jk * 1024;
         for (int slot = tid; slot < 640; slot += 256) {
             const int q = slot >> 6, i = slot & 15, k4 = (slot >> 4) & 3;
             v4f64 v;
@@ -180,7 +194,7 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
         }
         // D^-1 of the block's 64 columns rides along (LDL^T): read back four at a time in front of the stores -- a global
         // load behind a possibly aliasing store would wait for it, and 16 preloaded values do not fit the registers
-        if (LDL && tid < 64) reinterpret_cast<double*>(S + 640)[tid] = a.dinv[(int64_t)64 * jk + tid];
+        if (LDL && tid < 64) reinterpret_cast<double*>(S + 640)[tid] = a->dinv[(int64_t)64 * jk + tid];
     };
     // X <- X L_kk^-T for both strips; stores L (LDL^T: V D^-1, and V next to it), keeps V in X
     auto trsm = [&](auto half, int coff) {
@@ -260,12 +274,12 @@ __device__ __forceinline__ void dag_finalize_tile(const DagArgs& a, int64_t row0
     stamp(4);
     trsm(std::integral_constant<int, 1>(), 64);
     stamp(5);
-    if (LDL && a.vmax != nullptr) {
+    if (LDL && a->vmax != nullptr) {
         if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
         for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
         if (lane == 0 && vm > 0.0) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(vm);
-            if (bits > __hip_atomic_load(a.vmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.vmax, bits);
+            if (bits > __hip_atomic_load(a->vmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a->vmax, bits);
         }
     }
 }
@@ -282,25 +296,220 @@ __global__ void dag_gate_kernel(const int* __restrict__ word, int target, int* _
         if ((++spins & 255) == 0) {
             if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             if (spins > spin_limit) {
-                atomicCAS(info, 0, -7);
+                if (atomicCAS(info, 0, -7) == 0) info[1] = 3;   // (site 3: a gate on the bulk stream)
                 break;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void dag_reset_kernel(int* __restrict__ flags, int64_t n, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void dag_reset_kernel(int* __restrict__ flags, int64_t n, int* __restrict__ info, DagInst rec,
+                                                        DagInst* __restrict__ rec_dst) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && rec_dst != nullptr) *rec_dst = rec;   // the instance record the bulk kernel reads
     int4* f4 = reinterpret_cast<int4*>(flags);   // (hipMalloc alignment; the tail is done word by word)
     const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) f4[i] = make_int4(0, 0, 0, 0);
     if (blockIdx.x == 0) {
         if (threadIdx.x < (unsigned)(n - 4 * n4)) flags[4 * n4 + threadIdx.x] = 0;
-        if (threadIdx.x == 0) *info = 0;
+        if (threadIdx.x == 0) { info[0] = 0; info[1] = 0; }
+    }
+}
+
+// Zero one 128 x 128 tile (I >= J) of the buffer that the NEXT factorization scatters its sparse matrix into, with the unit
+// diagonal of the padding rows: the background zero-fill of ls.hip (fill_lower_kernel on a side stream, where it ran beside
+// the solves and cost the first of them ~60 us of HBM contention) as tasks of the bulk queue -- 128 KB of stores per task,
+// a few microseconds of a slot, absorbed where the matrix cores are the bound.
+template <class IP>
+__device__ __forceinline__ void dag_fill_tile(IP in, int I, int J, int tid) {
+    double* Z = in->zfill;
+    const int64_t ld = in->ld;
+    // thread: two consecutive rows (a double2) of 4 columns per pass; 64 threads cover 128 rows, 4 groups x 8 passes the 128 columns... 
+    const int r2 = (tid & 63) * 2, cg = tid >> 6;
+#pragma unroll 4
+    for (int c = cg; c < 128; c += 4) {
+        const int64_t col = (int64_t)128 * J + c, row = (int64_t)128 * I + r2;
+        double2 v = make_double2(0.0, 0.0);
+        if (I == J && col >= in->N) {
+            if (row == col) v.x = 1.0;
+            if (row + 1 == col) v.y = 1.0;
+        }
+        *reinterpret_cast<double2*>(Z + row + col * ld) = v;
     }
 }
 
 template <bool LDL>
 __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ int s_val;
+    // per-workgroup statistics of the trace option live in LDS (thread 0 only): no registers across the task loop
+    __shared__ unsigned long long s_stat[4];  // first grab, ticks waited, tasks, ticks in the finalization
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    __syncthreads();
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // (keeps the thread-id arithmetic out of the task loop's live ranges, as in gemm_nt_tile)
+        if (tid == 0) s_val = atomicAdd(a.qctr, 1);
+        __syncthreads();
+        const int t = s_val;
+        __syncthreads();
+        if (t >= a.ntasks) {
+            if (a.wgstat != nullptr && tid == 0) {
+                unsigned long long* w = a.wgstat + (int64_t)blockIdx.x * 8;
+                w[0] = s_stat[0]; w[1] = wall_clock64(); w[2] = s_stat[1]; w[3] = s_stat[2]; w[4] = s_stat[3];
+            }
+            return;
+        }
+        if (a.wgstat != nullptr && tid == 0) { if (s_stat[0] == 0) s_stat[0] = wall_clock64(); ++s_stat[2]; }
+        const int4 tk = a.tasks[t];
+        const int flags = __builtin_amdgcn_readfirstlane(tk.x) & 255, q = __builtin_amdgcn_readfirstlane(tk.x) >> 8;
+        const int I = __builtin_amdgcn_readfirstlane(tk.y) & 0xffff, inst = __builtin_amdgcn_readfirstlane(tk.y) >> 16;
+        const int J = __builtin_amdgcn_readfirstlane(tk.z);
+        const int kbeg = __builtin_amdgcn_readfirstlane(tk.w) & 0xffff, kend = __builtin_amdgcn_readfirstlane(tk.w) >> 16;
+        const int64_t row0 = (int64_t)128 * I, col0 = (int64_t)128 * J;
+        unsigned long long* tr = a.trace != nullptr && tid == 0 ? a.trace + (int64_t)t * 8 : nullptr;
+        if (tr) { tr[0] = wall_clock64(); tr[6] = 0; tr[7] = 0; }
+        // `in`: the factorization this task belongs to -- the task's instance record, read through the constant address space
+        // (uniform: scalar loads)
+        auto do_task = [&](auto in) __attribute__((always_inline)) {
+        if (flags & DAG_FILL) {   // (no dependence on anything: not even on the instance's factorization being alive)
+            if (in->zfill != nullptr) dag_fill_tile(in, I, J, tid);
+            return;
+        }
+
+        // One task; false: the instance's factorization has failed (a non-positive Cholesky pivot, an expired wait) -- the
+        // task is dropped, nothing is published, and every other task of that instance will be dropped the same way (their
+        // waits see `info`); tasks of OTHER instances of a batch are not affected.
+        auto run_task = [&]() __attribute__((always_inline)) -> bool {
+        if (__hip_atomic_load(in->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        // k-tiles [0, limit) of this chunk have final operands; the gate blocks at the first k-tile of a tile column that is
+        // not final yet (a rare event: the queue is sorted by readiness)
+        int limit = 0;
+        auto gate = [&](int kt) -> bool {
+            if (kt < limit) return true;
+            const unsigned long long w0 = tr ? wall_clock64() : 0;
+            const int r = dag_wait_front(in, a.spin_limit, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kbeg + (kt >> 4), kend, &s_val);
+            if (tr) { const unsigned long long w1 = wall_clock64(); tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; s_stat[1] += w1 - w0; }
+            if (r < 0) return false;
+            limit = (__builtin_amdgcn_readfirstlane(r) - kbeg) * 16;
+            return true;
+        };
+        const double* Ak = in->F + (a.fake_share > 0 ? (int64_t)128 * (kend + I % a.fake_share) : row0) + (int64_t)128 * kbeg * in->ld;
+        const double* Bk = (LDL ? in->V : in->F) + (a.fake_share > 0 ? (int64_t)128 * (kend + J % a.fake_share) : col0) + (int64_t)128 * kbeg * in->ld;
+        auto wait_chunk_order = [&]() -> bool {   // the chunks of one tile are applied in order
+            if (flags & DAG_FIRST) return true;
+            const int* word = in->tprog + (int64_t)I * a.ntile + J;
+            const unsigned long long w0 = tr ? wall_clock64() : 0;
+            if (!dag_wait_words(in, a.spin_limit, word, q, word, q, &s_val)) return false;
+            if (tr) s_stat[1] += wall_clock64() - w0;
+            return true;
+        };
+        if ((flags & DAG_FINAL) && !(flags & DAG_BANDACC)) {
+            // Tile-closing task: on the critical path of its row of tiles (and through it of the band the row enters).  The
+            // last tile column is multiplied with every wave owning 32 full rows -- the register layout of the
+            // finalization -- so the tile goes from the accumulators through the two substitutions to memory ONCE:
+            // X = C - acc without a store, no reload (the round trip through memory was 14 + ~5 us of the task's ~78).
+            __builtin_amdgcn_s_setprio(3);
+            // the tile as the earlier chunks left it goes into the accumulators BEFORE the wait for the row's previous tile
+            // column: its load is off the critical path; the K-loop then subtracts (NEG)
+            if (!wait_chunk_order()) return false;
+            v4f64 X[8][2];
+            {
+                const int lane = tid & 63, w = tid >> 6;
+                const double* Cs = in->F + (row0 + 32 * w + (lane & 15)) + (col0 + (lane >> 4)) * in->ld;
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double* cp = Cs + (int64_t)(16 * cb + 4 * r) * in->ld;
+                        X[cb][0][r] = cp[0];
+                        X[cb][1][r] = cp[16];
+                    }
+            }
+            if (kend > kbeg && !gate(0)) return false;   // one tile column: its operands are final at once
+            (void)gemm_nt_mainloop3<2, 8, true>(X, Ak, in->ld, Bk, in->ld, (kend - kbeg) * 16, smem_raw, tid);
+            // (new live ranges: the register pressure of the finalization below must not push the accumulators of the
+            // K-loop above into scratch)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(X[i][0])); asm volatile("" : "+v"(X[i][1])); }
+            if (tr) tr[1] = tr[3] = wall_clock64();  // K-loop done = tile applied
+            // the diagonal blocks of tile column J and L(2J + 1, 2J)
+            if (dag_wait_front(in, a.spin_limit, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return false;
+            if (tr) { tr[4] = wall_clock64(); s_stat[1] += tr[4] - tr[3]; }
+            dag_finalize_tile<LDL>(in, row0, col0, 2 * J, smem_raw, tid, X, tr);
+            if (tr) s_stat[3] += wall_clock64() - tr[4];
+        } else {
+            v4f64 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+            // the last chunk of a band tile is on the critical path of the chain: it issues first
+            if (flags & DAG_FINAL) __builtin_amdgcn_s_setprio(3);
+            // (the two-buffer loop: the three-buffer one is ~10 % slower at three workgroups per CU -- tools/hip/time_kstep.hip)
+            if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, Ak, in->ld, Bk, in->ld, (kend - kbeg) * 16, smem_raw, tid, gate)) return false;
+            if (tr) tr[1] = wall_clock64();  // K-loop done
+            if (!wait_chunk_order()) return false;
+            // C(I, J) -= acc (a diagonal tile: lower wave tiles only)
+            if (kend > kbeg)
+                gemm_nt_epilogue<2, 2, 4, 2, false, true>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, in->F, in->ld, nullptr, nullptr, 0, tid);
+            if (tr) tr[3] = wall_clock64();
+        }
+        return true;
+        };
+        const bool done = run_task();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (done && tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(flags & DAG_FINAL)) {
+                __hip_atomic_store(in->tprog + (int64_t)I * a.ntile + J, q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (!(flags & DAG_BANDACC)) {
+                __hip_atomic_store(in->front + 2 * I, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(in->front + 2 * I + 1, J + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(in->af + (int64_t)I * a.ntile + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tr) tr[5] = wall_clock64();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();  // (s_val and the LDS tiles are reused by the next task)
+        };
+        do_task((DagInstP)(uintptr_t)(a.insts + inst));
+    }
+}
+
+// The bulk kernel of a SINGLE factorization: the arguments of the one instance travel in the kernel's argument block (flat,
+// as in round 3) and the task loop below is round 3's, statement for statement, plus the DAG_FILL branch.  Not folded into
+// the batch kernel above on purpose: with the identical K-loop instructions (compared block by block in the assembly) the
+// generic body compiled to a different VGPR assignment of the MFMA operands and ran the k-steps 7 % slower (44.8 -> 48.1 us,
+// 9.20 -> 9.45 ms per factorize! at C3, same box, alternating runs) -- this loop is the one the headline number rests on.
+struct DagArgs1 {
+    double* F;
+    int64_t ld;
+    double* V;            // LDL^T: V = L D, same layout as F (the B operand of the updates); Cholesky: nullptr (V = L)
+    const double* dinv;   // 1 / d_k
+    const double* dblk;   // factored 64x64 diagonal blocks
+    const double* inv16;  // inverses of their 16x16 diagonal sub-blocks
+    const int4* tasks;    // (flags | chunk index << 8, I, J, kbeg | kend << 16)
+    int ntasks;
+    int* front;
+    int* af;
+    int* tprog;           // [I * ntile + J]: chunks of tile (I, J) that are in memory
+    int ntile;
+    int* qctr;
+    int* info;
+    long spin_limit;
+    unsigned long long* trace;  // diagnostics (option dag_trace): 8 time stamps per task
+    unsigned long long* wgstat; // diagnostics: per workgroup {first grab, exit, ticks waited, tasks, ticks in finalize}
+    unsigned long long* vmax;   // growth monitor of the static-pivot LDL^T (factor.hip growth_fold): receives max|V|, or NULL
+    int fake_share;             // DIAGNOSTIC (env MNK_DAG_FAKE_SHARE, wrong results): every chunk reads the operand rows of tile rows 0..n-1
+    double* zfill;              // DAG_FILL tasks: the buffer of the next factorization (or NULL)
+    int64_t N;
+};
+
+template <bool LDL>
+__global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ int s_val;
     // per-workgroup statistics of the trace option live in LDS (thread 0 only): no registers across the task loop
@@ -330,6 +539,10 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
         const int64_t row0 = (int64_t)128 * I, col0 = (int64_t)128 * J;
         unsigned long long* tr = a.trace != nullptr && tid == 0 ? a.trace + (int64_t)t * 8 : nullptr;
         if (tr) { tr[0] = wall_clock64(); tr[6] = 0; tr[7] = 0; }
+        if (flags & DAG_FILL) {   // zero-fill of the next factorization's buffer (see dag_fill_tile)
+            if (a.zfill != nullptr) dag_fill_tile(&a, I, J, tid);
+            continue;
+        }
 
         // k-tiles [0, limit) of this chunk have final operands; the gate blocks at the first k-tile of a tile column that is
         // not final yet (a rare event: the queue is sorted by readiness)
@@ -337,7 +550,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
         auto gate = [&](int kt) -> bool {
             if (kt < limit) return true;
             const unsigned long long w0 = tr ? wall_clock64() : 0;
-            const int r = dag_wait_front(a, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kbeg + (kt >> 4), kend, &s_val);
+            const int r = dag_wait_front(&a, a.spin_limit, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kbeg + (kt >> 4), kend, &s_val);
             if (tr) { const unsigned long long w1 = wall_clock64(); tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; s_stat[1] += w1 - w0; }
             if (r < 0) return false;
             limit = (__builtin_amdgcn_readfirstlane(r) - kbeg) * 16;
@@ -349,7 +562,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             if (flags & DAG_FIRST) return true;
             const int* word = a.tprog + (int64_t)I * a.ntile + J;
             const unsigned long long w0 = tr ? wall_clock64() : 0;
-            if (!dag_wait_words(a, word, q, word, q, &s_val)) return false;
+            if (!dag_wait_words(&a, a.spin_limit, word, q, word, q, &s_val)) return false;
             if (tr) s_stat[1] += wall_clock64() - w0;
             return true;
         };
@@ -383,9 +596,9 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(X[i][0])); asm volatile("" : "+v"(X[i][1])); }
             if (tr) tr[1] = tr[3] = wall_clock64();  // K-loop done = tile applied
             // the diagonal blocks of tile column J and L(2J + 1, 2J)
-            if (dag_wait_front(a, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return;
+            if (dag_wait_front(&a, a.spin_limit, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return;
             if (tr) { tr[4] = wall_clock64(); s_stat[1] += tr[4] - tr[3]; }
-            dag_finalize_tile<LDL>(a, row0, col0, 2 * J, smem_raw, tid, X, tr);
+            dag_finalize_tile<LDL>(&a, row0, col0, 2 * J, smem_raw, tid, X, tr);
             if (tr) s_stat[3] += wall_clock64() - tr[4];
         } else {
             v4f64 acc[4][4];
@@ -431,7 +644,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
 // rows for the strip-columns Js < js2, every remaining row from js2 on (depends on these four only; cached by the caller).
 // 4 ints per task: flags | chunk index << 8, I, J, kbeg | kend << 16.  Returns the number of first-phase tasks: the ones
 // that are ready before the chain enters strip-column js2 (they come first in the list).
-int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out, int taper0) {
+int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<int>& out, int taper0, std::vector<int>* ready) {
     struct T { int ready, cls, J, I, flags, q, kbeg, kend; };
     std::vector<T> ts;
     // Tile (I, J), tile columns [0, K) to accumulate.  A bulk tile's last tile column is a task of its own (paced by the pivot
@@ -478,15 +691,74 @@ int dag_build_tasks(int ntile, int chunk, int band_tiles, int js2, std::vector<i
     });
     out.clear();
     out.reserve(ts.size() * 4);
+    if (ready != nullptr) { ready->clear(); ready->reserve(ts.size()); }
     int n1 = 0;
     for (const T& t : ts) {
         if (t.ready <= 2 * js2) ++n1;  // needs only tile columns the first phase's chain has passed (sorted by `ready`)
+        if (ready != nullptr) ready->push_back(t.ready);
         out.push_back(t.flags | (t.q << 8));
         out.push_back(t.I);
         out.push_back(t.J);
         out.push_back(t.kbeg | (t.kend << 16));
     }
     return n1;
+}
+
+// Zero-fill tasks (DAG_FILL) for the lower tiles of the NEXT factorization's buffer, one after every few tasks of the first
+// phase: 128 KB of stores each, absorbed by the queue while the matrix cores are the bound.  `ready` gets the value of the
+// task in front (the merge of several instances keeps them where they are).  Returns the new number of first-phase tasks.
+int dag_add_fill_tasks(int ntile, std::vector<int>& tasks, std::vector<int>& ready, int n1) {
+    const int nt = (int)(tasks.size() / 4), nfill = ntile * (ntile + 1) / 2;
+    const int span = n1 > 0 ? n1 : nt;   // (spread over the first phase; a list without one: over everything)
+    if (span <= 0) return n1;
+    std::vector<int> out, rdy;
+    out.reserve(tasks.size() + 4 * (size_t)nfill);
+    rdy.reserve(ready.size() + nfill);
+    int fi = 0, fj = 0, done = 0;
+    auto emit_fill = [&](int r) {
+        out.push_back(DAG_FILL); out.push_back(fi); out.push_back(fj); out.push_back(0);
+        rdy.push_back(r);
+        if (++fi >= ntile) { ++fj; fi = fj; }
+        ++done;
+    };
+    for (int t = 0; t < nt; ++t) {
+        for (int k = 0; k < 4; ++k) out.push_back(tasks[4 * t + k]);
+        rdy.push_back(ready[t]);
+        // after task t of the span, (t + 1) * nfill / span fill tasks are out
+        if (t < span)
+            while (done < (int)((int64_t)(t + 1) * nfill / span)) emit_fill(ready[t]);
+    }
+    tasks.swap(out);
+    ready.swap(rdy);
+    return n1 > 0 ? n1 + nfill : 0;
+}
+
+// One queue for `ninst` independent factorizations of the same order (mnk_factorize_batch_*): instance i's tasks keep their
+// order and are shifted by i * period chain positions (tile columns) against instance 0's, so that an instance's
+// saturated middle runs under the chain-bound ends of its neighbours.  Two pivot chains run at a time (instances i and
+// i + 1; chain i + 2 follows chain i on its stream), hence period >= ntile / 2: every task of instance i then precedes
+// every task of instance i + 2, and a workgroup that holds a task waits only for tasks in front of it or for a chain that
+// is running or will run once tasks in front of it are done.
+void dag_merge_tasks(const std::vector<int>& tasks, const std::vector<int>& ready, int ninst, int period, std::vector<int>& out) {
+    const int nt = (int)ready.size();
+    out.clear();
+    out.reserve((size_t)ninst * nt * 4);
+    std::vector<int> pos(ninst, 0);
+    for (;;) {   // k-way merge by (i * period + ready, i); every list is sorted by `ready`
+        int best = -1;
+        long bkey = 0;
+        for (int i = 0; i < ninst; ++i) {
+            if (pos[i] >= nt) continue;
+            const long key = (long)i * period + ready[pos[i]];
+            if (best < 0 || key < bkey) { best = i; bkey = key; }
+        }
+        if (best < 0) break;
+        const int t = pos[best]++;
+        out.push_back(tasks[4 * t]);
+        out.push_back(tasks[4 * t + 1] | (best << 16));
+        out.push_back(tasks[4 * t + 2]);
+        out.push_back(tasks[4 * t + 3]);
+    }
 }
 
 template <bool LDL>
@@ -505,19 +777,81 @@ static int launch_bulk_t(hipStream_t s, const DagArgs& a, int nwg) {
     return 0;
 }
 
-int launch_dag_bulk(hipStream_t s, bool ldl, double* F, int64_t ld, double* V, const double* dinv, const double* dblk,
-                    const double* inv16, const int* tasks, int ntasks, int* front, int* af, int* tprog, int ntile, int* qctr,
-                    int* info,
-                    const int* prog, int epoch16, long spin_limit, int nwg, unsigned long long* vmax, unsigned long long* trace,
-                    unsigned long long* wgstat) {
+template <bool LDL>
+static int launch_bulk1_t(hipStream_t s, const DagArgs1& a, int nwg) {
+    const size_t smem = TILE3_LDS_BYTES;
+    auto kern = dag_bulk_kernel1<LDL>;
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    MNK_HIP(hipGetDevice(&dev));
+    if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), smem, s, a);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// `insts` == nullptr: one factorization (dag_bulk_kernel1, the record `one` flattened into its argument block); otherwise a batch
+static int launch_dag_bulk(hipStream_t s, bool ldl, const DagInst& one, const DagInst* insts, const int* tasks, int ntasks, int ntile,
+                           int* qctr, long spin_limit, int nwg, unsigned long long* trace, unsigned long long* wgstat) {
     if (ntasks <= 0) return 0;
-    DagArgs a{F, ld, V, dinv, dblk, inv16, reinterpret_cast<const int4*>(tasks), ntasks, front, af, tprog, ntile, qctr, info, prog, epoch16, spin_limit, trace, wgstat, vmax, getenv("MNK_DAG_FAKE_SHARE") ? atoi(getenv("MNK_DAG_FAKE_SHARE")) : 0};
+    static const int fake = getenv("MNK_DAG_FAKE_SHARE") ? atoi(getenv("MNK_DAG_FAKE_SHARE")) : 0;
+    if (insts == nullptr) {
+        DagArgs1 a{one.F, one.ld, one.V, one.dinv, one.dblk, one.inv16, reinterpret_cast<const int4*>(tasks), ntasks, one.front, one.af,
+                   one.tprog, ntile, qctr, one.info, spin_limit, trace, wgstat, one.vmax, fake, one.zfill, one.N};
+        return ldl ? launch_bulk1_t<true>(s, a, nwg) : launch_bulk1_t<false>(s, a, nwg);
+    }
+    DagArgs a{insts, reinterpret_cast<const int4*>(tasks), ntasks, ntile, qctr, spin_limit, trace, wgstat, fake};
     return ldl ? launch_bulk_t<true>(s, a, nwg) : launch_bulk_t<false>(s, a, nwg);
 }
 
 }  // namespace mnk
 
 using namespace mnk;
+
+// First launch of the bulk kernels on a stream, with an EMPTY queue (every workgroup leaves at once): the code objects are
+// loaded and the stream's hardware queue gets its scratch memory (these kernels spill a few registers) while nothing is
+// resident that could wait for them.  Without it the first real factorization of a process launches a pivot chain that
+// spins for a bulk kernel the runtime is still setting up -- normally microseconds, but seen to exceed the bound of the
+// device-side waits (info = -7, schedule 1 for the next 16 factorizations: round 3 met it in 2 of ~150 bench processes, this
+// round in 1 of 8 runs of tools/dag_time.py).  Called once per device when its task-DAG streams are created (ls.hip).
+int mnk_dag_warmup(hipStream_t* streams, int n) {
+    static mnk::DevBuf<int> ctr;   // (process lifetime)
+    if (!ctr.p) {
+        if (ctr.alloc(4)) return -2;
+        MNK_HIP(hipMemset(ctr.p, 0, 4 * sizeof(int)));
+    }
+    for (int i = 0; i < n; ++i) {
+        if (streams[i] == nullptr) continue;
+        mnk::DagArgs1 a1{};
+        a1.qctr = ctr.p;
+        a1.info = ctr.p + 1;
+        mnk::DagArgs a{};
+        a.qctr = ctr.p;
+        int rc = mnk::launch_bulk1_t<true>(streams[i], a1, 8);
+        if (!rc) rc = mnk::launch_bulk1_t<false>(streams[i], a1, 8);
+        if (!rc) rc = mnk::launch_bulk_t<true>(streams[i], a, 8);
+        if (!rc) rc = mnk::launch_bulk_t<false>(streams[i], a, 8);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n; ++i)
+        if (streams[i] != nullptr) MNK_HIP(mnk::stream_wait(streams[i]));
+    return 0;
+}
+
+static mnk::DagInst dag_instance(mnk_ls* ls) {
+    const int ntile = (int)(ls->Np / 128), nblk = (int)(ls->Np / NBI);
+    int* front = ls->dag_flags.p + 2;
+    int* af = front + nblk;
+    int* tprog = af + (size_t)ntile * ntile;
+    // the spare factor buffer is zeroed by the queue's DAG_FILL tasks when the NEXT transfer will want it (a sparse source was
+    // transferred for this factorization: mnk_ls::spare_pending) and no background fill of it is in flight
+    double* zfill = (ls->dag_fill && ls->dag_has_fill && ls->spare_pending && ls->fact_spare.p && !ls->spare_zeroed) ? ls->fact_spare.p : nullptr;
+    return mnk::DagInst{ls->fact.p, ls->ld, ls->algo == MNK_LDL ? ls->vfull.p : nullptr, ls->dinv.p, ls->dblk.p, ls->inv16.p,
+                        front, af, tprog, ls->info_dev.p, mnk_ls_growth_word(ls), zfill, ls->N};
+}
 
 // Buffers of the task-DAG schedule: the task list (built once per matrix order and option set), the progress words and,
 // for LDL^T, V = L D of every column (a second N x N array).  Returns 0 when everything is there; non-zero when the device
@@ -549,12 +883,15 @@ int mnk_ls_dag_prepare(mnk_ls* ls) {
         const int64_t deep_rows = (int64_t)ctx->dag_cus2 * NBI;
         ls->dag_js2 = (ctx->dag_cus2 > 0 && Np <= deep_rows) ? 0 : nsc;
         if (ls->dag_js2_override >= 0) ls->dag_js2 = std::min(nsc, ls->dag_js2_override);
-        std::vector<int> h;
-        ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h, ls->dag_taper0);
+        std::vector<int>& h = ls->dag_host_tasks;   // (kept on the host: a batch merges the lists of its instances)
+        ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h, ls->dag_taper0, &ls->dag_host_ready);
+        // zero-fill of the next factorization's buffer as tasks of the queue (sparse sources; see dag_fill_tile)
+        ls->dag_has_fill = ls->dag_fill && ls->prefill && Np <= ls->prefill_max_rows;
+        if (ls->dag_has_fill) ls->dag_ntasks1 = mnk::dag_add_fill_tasks(ntile, h, ls->dag_host_ready, ls->dag_ntasks1);
         ls->dag_ntasks = (int)(h.size() / 4);
         if (ls->dag_tasks.alloc(h.size() + 4)) return give_up();
         if (!h.empty() && hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return give_up();
-        if (mnk::stream_wait(s) != hipSuccess) return give_up();  // (h goes out of scope)
+        if (mnk::stream_wait(s) != hipSuccess) return give_up();
         if (ls->dag_flags.alloc(nflags)) return give_up();
     }
     if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) {   // V = L D of every column (LDL^T)
@@ -583,20 +920,18 @@ int mnk_ls_dag_prepare(mnk_ls* ls) {
 int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     mnk_ctx* ctx = ls->ctx;
     hipStream_t s = ctx->stream;
-    const int64_t Np = ls->Np, ld = ls->ld;
+    const int64_t Np = ls->Np;
     const bool ldl = ls->algo == MNK_LDL;
-    double* F = ls->fact.p;
     const int ntile = (int)(Np / 128), nblk = (int)(Np / NBI), nsc = (int)((Np + 255) / 256);
     const size_t nflags = (size_t)2 + nblk + 2 * (size_t)ntile * ntile;  // two queue counters | front | af | tprog
     MNK_REQUIRE(ls->dag_tasks.p && ls->dag_flags.p && (!ldl || ls->vfull.p), "task-DAG schedule: mnk_ls_dag_prepare was not called");
-    double* V = ldl ? ls->vfull.p : nullptr;
     // progress words and `info` in ONE launch (two memsets are two fill kernels, ~8 us each in front of the pivot chain)
+    const mnk::DagInst inst = dag_instance(ls);
+    ls->dag_filled = inst.zfill != nullptr;
     hipLaunchKernelGGL(mnk::dag_reset_kernel, dim3((unsigned)std::min<size_t>((nflags + 1023) / 1024, 64)), dim3(256), 0, s,
-                       ls->dag_flags.p, (int64_t)nflags, ls->info_dev.p);
+                       ls->dag_flags.p, (int64_t)nflags, ls->info_dev.p, inst, (mnk::DagInst*)nullptr);
     int* qctr = ls->dag_flags.p;
-    int* front = qctr + 2;
-    int* af = front + nblk;
-    int* tprog = af + (size_t)ntile * ntile;
+    int* front = inst.front;
     const long spin_limit = ls->dag_spin_limit;
     unsigned long long* trace = nullptr;
     if (ls->dag_trace_on && ls->dag_trace.p) {
@@ -604,7 +939,6 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         MNK_HIP(hipMemsetAsync(ls->dag_trace.p, 0, ntr * sizeof(unsigned long long), s));
         trace = ls->dag_trace.p;
     }
-    const int epoch16 = ls->epoch * 16;
     const int js2 = ls->dag_js2;
     // one phase = one persistent bulk launch (update stream) beside one persistent chain launch (panel stream)
     auto phase = [&](hipStream_t sp, hipStream_t su, int bulk_cus, int task0, int ntask, int* counter, int js_begin, int js_end,
@@ -618,19 +952,21 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         MNK_HIP(hipEventRecord(ctx->ev_a, s));
         if (!small) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
         MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
-        mnk::PpDag dag{front, af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
+        mnk::PpDag dag{front, inst.af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
                   mnk_ls_growth_word(ls)};
         // (the chain first: its first diagonal block is the start of the critical path, the bulk kernel has nothing to do before it)
         int rc = mnk_launch_pchain(ls, sp, dag, js_begin, js_end, strips);
         if (rc) return rc;
-        rc = mnk::launch_dag_bulk(su, ldl, F, ld, V, ls->dinv.p, ls->dblk.p, ls->inv16.p, ls->dag_tasks.p + 4 * (size_t)task0, ntask,
-                                      front, af, tprog, ntile, counter, ls->info_dev.p, ls->flag_p.p, epoch16, spin_limit,
-                                      std::min(ntask, 3 * bulk_cus), mnk_ls_growth_word(ls), trace ? trace + 8 * (size_t)task0 : nullptr,
-                                      trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
+        rc = mnk::launch_dag_bulk(su, ldl, inst, nullptr, ls->dag_tasks.p + 4 * (size_t)task0, ntask, ntile, counter, spin_limit,
+                                  std::min(ntask, 3 * bulk_cus), trace ? trace + 8 * (size_t)task0 : nullptr,
+                                  trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
         if (rc) return rc;
         // Once the bulk kernel has run out of tasks every tile-closing task is done, hence every strip-column that still
         // had rows below the band is final: its diagonal blocks are inverted for the solves here, behind the bulk kernel
         // on its stream, while the chain works on the last strip-columns (all rows in the band: no bulk task left).
+        // (Measured and dropped in round 4: the inverses of the LAST strip-columns one by one on this stream behind device-side
+        // gates on the chain's progress.  The bulk kernel leaves only ~130 us before the chain's end -- its last tile-closing
+        // tasks -- and every gated launch pair costs ~170 us whatever its size: C3 factorize! 9.66 -> 10.78 ms.)
         if (js_begin == 0 && js_end > 0) {
             const int64_t safe = std::min<int64_t>(js_end, std::max<int64_t>(0, (ntile - ls->dag_band / 2 - 1) / 2)) & ~(int64_t)1;  // (even: 512-row triangles)
             if (strips == (unsigned)ls->dag_band && safe > 0) {
@@ -669,16 +1005,210 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Batches of independent factorizations (mnk_factorize_batch_begin / _end; BASELINE config C5: scenario batches per GPU).
+// A single factorization of N ~ 1e4 leaves the bulk CUs nearly idle at both ends -- 0.5 ms of start-up and ~2.6 ms of a
+// tail that is bound by the pivot chain -- which no schedule of ONE matrix can fill.  Between begin and end the
+// factorize! calls of the calling thread only transfer their matrices; `end` launches them together: ONE bulk kernel
+// drains the merged task queue of all instances (dag_merge_tasks) beside TWO pivot chains on two CU partitions (even
+// instances on one, odd ones on the other), so that instance i + 1's saturated middle runs under instance i's tail.  The
+// arithmetic per instance is exactly that of a single factorization (same task list, same order per tile): bit-identical
+// factors.  Reference behaviour: distinct solver instances are driven concurrently (src/KKT/Schur/schur.jl:953).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct BatchState {
+    bool active = false;
+    std::vector<mnk_ls*> pend;
+};
+thread_local BatchState t_batch;
+
+struct BatchBuffers {   // per device, reused from batch to batch (guarded by the arbiter's mutex while in use)
+    mnk::DevBuf<int> tasks;
+    mnk::DevBuf<int> qctr;
+    mnk::DevBuf<char> insts;
+    int ntile = 0, ninst = 0, period = 0, chunk = 0, taper0 = 0, band = 0, ntasks = 0;
+    bool fill = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+BatchBuffers g_batch[64];
+}  // namespace
+
+bool mnk_batch_defer(mnk_ls* ls) {
+    if (!t_batch.active) return false;
+    const int nsc = (int)((ls->Np + 255) / 256);
+    // (the merged launch serves the large-system mode of the schedule; anything else is simply run now)
+    if (ls->algo_now != 5 || ls->dag_js2 != nsc || ls->dag_trace_on || ls->ctx->partitioned || !ls->ctx->sp_dagB) return false;
+    if (!ls->ev_defer && hipEventCreateWithFlags(&ls->ev_defer, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventRecord(ls->ev_defer, ls->ctx->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    ls->deferred = true;
+    t_batch.pend.push_back(ls);
+    return true;
+}
+
+static void batch_mark_done(mnk_ls* ls) {
+    ls->factorized = true;
+    ls->info_valid = false;
+    ls->bk_active = false;
+    ls->deferred = false;
+}
+
+// the merged launch of g.size() >= 2 deferred factorizations of one order / algorithm / option set on one device
+static int batch_run_group(std::vector<mnk_ls*>& g) {
+    mnk_ls* l0 = g[0];
+    mnk_ctx* c0 = l0->ctx;
+    hipStream_t h = c0->stream;
+    MNK_HIP(hipSetDevice(c0->device));
+    const int64_t Np = l0->Np;
+    const bool ldl = l0->algo == MNK_LDL;
+    const int ntile = (int)(Np / 128), nsc = (int)((Np + 255) / 256), ninst = (int)g.size();
+    const size_t nflags = (size_t)2 + (size_t)(Np / NBI) + 2 * (size_t)ntile * ntile;
+    for (mnk_ls* ls : g)
+        if (ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(h, ls->ev_defer, 0));
+    int rc = mnk_persist_begin(c0, h);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        BatchBuffers& B = g_batch[c0->device & 63];
+        const int period = std::max((ntile + 1) / 2, l0->batch_period > 0 ? l0->batch_period : 0);
+        if (B.ntile != ntile || B.ninst != ninst || B.period != period || B.chunk != l0->dag_chunk || B.taper0 != l0->dag_taper0 ||
+            B.band != l0->dag_band || B.fill != l0->dag_has_fill || !B.tasks.p) {
+            std::vector<int> merged;
+            mnk::dag_merge_tasks(l0->dag_host_tasks, l0->dag_host_ready, ninst, period, merged);
+            if (B.tasks.alloc(merged.size() + 4)) return -2;
+            MNK_HIP(hipMemcpy(B.tasks.p, merged.data(), merged.size() * sizeof(int), hipMemcpyHostToDevice));
+            if (!B.qctr.p && B.qctr.alloc(4)) return -2;
+            if (B.insts.alloc(sizeof(mnk::DagInst) * (size_t)ninst)) return -2;
+            for (hipEvent_t& e : B.ev)
+                if (!e) MNK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            B.ntile = ntile; B.ninst = ninst; B.period = period; B.chunk = l0->dag_chunk; B.taper0 = l0->dag_taper0;
+            B.band = l0->dag_band; B.fill = l0->dag_has_fill; B.ntasks = (int)(merged.size() / 4);
+        }
+        std::vector<mnk::DagInst> hin;
+        mnk::DagInst* insts_dev = reinterpret_cast<mnk::DagInst*>(B.insts.p);
+        for (mnk_ls* ls : g) {
+            hin.push_back(dag_instance(ls));
+            ls->dag_filled = hin.back().zfill != nullptr;
+            // (the instance's record for the bulk kernel rides along with the reset of its progress words)
+            hipLaunchKernelGGL(mnk::dag_reset_kernel, dim3((unsigned)std::min<size_t>((nflags + 1023) / 1024, 64)), dim3(256), 0, h,
+                               ls->dag_flags.p, (int64_t)nflags, ls->info_dev.p, hin.back(), insts_dev + (hin.size() - 1));
+        }
+        MNK_HIP(hipMemsetAsync(B.qctr.p, 0, 4 * sizeof(int), h));
+        hipStream_t sp[2] = {c0->sp_dag, c0->sp_dagB}, su = c0->su_dagB;
+        MNK_HIP(hipEventRecord(B.ev[0], h));
+        MNK_HIP(hipStreamWaitEvent(sp[0], B.ev[0], 0));
+        MNK_HIP(hipStreamWaitEvent(sp[1], B.ev[0], 0));
+        MNK_HIP(hipStreamWaitEvent(su, B.ev[0], 0));
+        const unsigned strips = (unsigned)std::min<int64_t>(l0->dag_band, Np / NBI);
+        for (int i = 0; i < ninst; ++i) {
+            mnk_ls* ls = g[i];
+            mnk::PpDag dag{hin[i].front, hin[i].af, ntile, 0, 0, -1, ls->dag_spin_limit, nullptr, mnk_ls_growth_word(ls)};
+            int r = mnk_launch_pchain(ls, sp[i & 1], dag, 0, nsc, strips);
+            if (r) return r;
+            // its inverses and its inertia / info words follow on the chain's stream (the next chain of this stream starts
+            // behind them; the bulk kernel has work of the other instance meanwhile)
+            r = mnk_ls_invert_blocks(ls, sp[i & 1], 0, nsc);
+            if (r) return r;
+            ls->inv_done = nsc;
+            r = mnk_ls_launch_finish_info(ls, sp[i & 1]);
+            if (r) return r;
+        }
+        const int bulk_cus = c0->num_cu - 2 * c0->dag_cus;
+        int r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p,
+                                     l0->dag_spin_limit, std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
+        if (r) return r;
+        MNK_HIP(hipEventRecord(B.ev[1], sp[0]));
+        MNK_HIP(hipEventRecord(B.ev[2], sp[1]));
+        MNK_HIP(hipEventRecord(B.ev[3], su));
+        for (int e = 1; e < 4; ++e) MNK_HIP(hipStreamWaitEvent(h, B.ev[e], 0));
+        return 0;
+    };
+    rc = body();
+    rc = mnk_persist_end(c0, h, rc);
+    if (rc) return rc;
+    // everybody's stream continues behind the batch
+    MNK_HIP(hipEventRecord(l0->ev_defer, h));
+    for (mnk_ls* ls : g) {
+        if (ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(ls->ctx->stream, l0->ev_defer, 0));
+        batch_mark_done(ls);
+        int r = mnk_ls_prefill_spare(ls);
+        if (r) return r;
+    }
+    return 0;
+}
+
+static int batch_flush() {
+    std::vector<mnk_ls*> pend;
+    pend.swap(t_batch.pend);
+    int rc_all = 0;
+    while (!pend.empty()) {
+        // group: same device, order, algorithm and schedule options as the first one pending
+        mnk_ls* l0 = pend.front();
+        std::vector<mnk_ls*> g, rest;
+        for (mnk_ls* ls : pend) {
+            const bool same = ls->ctx->device == l0->ctx->device && ls->Np == l0->Np && ls->algo == l0->algo && ls->dag_chunk == l0->dag_chunk &&
+                              ls->dag_taper0 == l0->dag_taper0 && ls->dag_band == l0->dag_band && ls->dag_has_fill == l0->dag_has_fill;
+            (same && std::find(g.begin(), g.end(), ls) == g.end() ? g : rest).push_back(ls);
+        }
+        pend.swap(rest);
+        int rc;
+        if (g.size() >= 2) {
+            rc = batch_run_group(g);
+            if (rc)   // (nothing of the group counts as factorized)
+                for (mnk_ls* ls : g) ls->deferred = false;
+        } else {
+            g[0]->deferred = false;
+            rc = mnk_ls_run_factorization_now(g[0]);
+        }
+        if (rc && !rc_all) rc_all = rc;
+    }
+    return rc_all;
+}
+
+int mnk_ls_sync_deferred(mnk_ls* ls) {
+    if (!ls->deferred) return 0;
+    if (std::find(t_batch.pend.begin(), t_batch.pend.end(), ls) == t_batch.pend.end()) {
+        set_error("a factorize! call of this solver is pending in a batch that another thread opened (mnk_factorize_batch_end must come first)");
+        return -1;
+    }
+    return batch_flush();   // (the batch stays open: later factorize! calls form the next group)
+}
+
+extern "C" int mnk_factorize_batch_begin(void) {
+    if (t_batch.active) { set_error("mnk_factorize_batch_begin: a batch is already open on this thread"); return -1; }
+    t_batch.active = true;
+    return 0;
+}
+
+extern "C" int mnk_factorize_batch_end(void) {
+    if (!t_batch.active) { set_error("mnk_factorize_batch_end: no batch is open on this thread"); return -1; }
+    t_batch.active = false;
+    return batch_flush();
+}
+
 // Diagnostics / tests: the task list of the schedule for a matrix of `ntile` 128-row tiles (host only, no device needed).
 // out: 4 ints per task as the bulk kernel reads them (flags | chunk index << 8, I, J, kbeg | kend << 16), at most `cap`
 // tasks are written; returns the number of tasks, *first_phase receives the number of first-phase tasks.
 extern "C" int mnk_debug_dag_tasks(int ntile, int chunk, int band_tiles, int js2, int taper0, int* out, int cap, int* first_phase) {
     if (ntile <= 0 || chunk <= 0 || band_tiles <= 0 || taper0 <= 0) return -1;
     std::vector<int> h;
-    const int n1 = mnk::dag_build_tasks(ntile, chunk, band_tiles, js2, h, taper0);
+    const int n1 = mnk::dag_build_tasks(ntile, chunk, band_tiles, js2, h, taper0, nullptr);
     const int n = (int)(h.size() / 4);
     if (first_phase != nullptr) *first_phase = n1;
     if (out != nullptr)
         for (int i = 0; i < std::min(n, cap) * 4; ++i) out[i] = h[i];
+    return n;
+}
+
+// Diagnostics / tests: the merged queue of `ninst` instances (with the zero-fill tasks if `fill`), 4 ints per task with the
+// instance index in the upper half of the second one; returns the number of tasks.
+extern "C" int mnk_debug_dag_merged_tasks(int ntile, int chunk, int band_tiles, int js2, int taper0, int fill, int ninst, int period,
+                                          int* out, int cap) {
+    if (ntile <= 0 || chunk <= 0 || band_tiles <= 0 || taper0 <= 0 || ninst <= 0 || period < 0) return -1;
+    std::vector<int> h, ready, merged;
+    int n1 = mnk::dag_build_tasks(ntile, chunk, band_tiles, js2, h, taper0, &ready);
+    if (fill) n1 = mnk::dag_add_fill_tasks(ntile, h, ready, n1);
+    mnk::dag_merge_tasks(h, ready, ninst, period, merged);
+    const int n = (int)(merged.size() / 4);
+    if (out != nullptr)
+        for (int i = 0; i < std::min(n, cap) * 4; ++i) out[i] = merged[i];
     return n;
 }

@@ -437,7 +437,7 @@ __device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int targ
             // there -- info != 0 makes every result of this factorization void
             if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             if (spins > limit) {
-                atomicCAS(info, 0, -7);
+                if (atomicCAS(info, 0, -7) == 0) info[1] = 4;   // (site 4: a strip waiting for a diagonal block of the chain)
                 break;
             }
         }
@@ -495,7 +495,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                     if ((++spins & 255) == 0) {
                         if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                         if (spins > dag.spin_limit) {
-                            atomicCAS(info, 0, -7);
+                            if (atomicCAS(info, 0, -7) == 0) info[1] = 5;   // (site 5: a chain strip waiting for the bulk kernel: rows / band tiles)
                             break;
                         }
                     }
@@ -911,6 +911,7 @@ __global__ __launch_bounds__(1024) void finish_info_kernel(const double* __restr
         __hip_atomic_store(host_words + 4, am, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_words + 5, gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_words + 6, amax != nullptr ? t[3] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_words + 7, (unsigned long long)(long long)info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // which bounded wait expired (info = -7)
         __hip_atomic_store(host_words + 3, (unsigned long long)(long long)*info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -1132,6 +1133,14 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     if (ls->algo_now == 5 && mnk_ls_dag_prepare(ls) != 0) ls->algo_now = 4;
     // Persistent schedules of different contexts take turns on the device (common.h: mnk_persist_begin); round 3 sent every
     // solver to schedule 1 as soon as a second context was alive (12.4 instead of 9.3 ms at C3).
+    // a batch of independent factorizations (dag.hip: mnk_factorize_batch_begin / _end) launches them together later
+    if (ls->algo_now == 5 && mnk_batch_defer(ls)) return 0;
+    return mnk_ls_run_factorization_now(ls);
+}
+
+int mnk_ls_run_factorization_now(mnk_ls* ls) {
+    mnk_ctx* ctx = ls->ctx;
+    hipStream_t s = ctx->stream;
     const bool persistent = ls->algo_now >= 4;
     if (persistent) {
         int rc0 = mnk_persist_begin(ctx, s);
@@ -1148,7 +1157,7 @@ static int run_factorization_body(mnk_ls* ls) {
     const bool ldl = ls->algo == MNK_LDL;
     double* F = ls->fact.p;
     const int64_t NBO = mnk_ls_effective_nbo(ls);
-    if (ls->algo_now != 5) MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, sizeof(int), s));   // (the task-DAG driver resets it with its flags)
+    if (ls->algo_now != 5) MNK_HIP(hipMemsetAsync(ls->info_dev.p, 0, 2 * sizeof(int), s));   // (the task-DAG driver resets it with its flags)
     // Outer panel boundaries.  Once the remaining matrix is small the factorization is bound by the panel
     // chain, not by the update: narrower outer panels (tail_nbo) then drop the middle-level update and halve
     // the depth of the (a) piece the chain waits for (measured: 355 -> ~300 us per 512 columns of the tail).
@@ -1331,13 +1340,19 @@ static int run_factorization_body(mnk_ls* ls) {
     ls->info_valid = false;
     ls->bk_active = false;
     {   // inertia / growth words / info go to the pinned host words right behind the factorization (mnk_ls_fetch_info only waits)
-        const bool lmode = ls->algo == MNK_LDL;
-        const int threads = lmode ? (ls->N >= 4096 ? 1024 : 256) : 64;
-        hipLaunchKernelGGL(finish_info_kernel, dim3(1), dim3(threads), 0, s, ls->dvec.p, lmode ? ls->N : (int64_t)0, ls->info_dev.p, ls->pin_dev,
-                           mnk_ls_growth_word(ls) != nullptr ? ls->amax_dev.p : (const unsigned long long*)nullptr);
-        MNK_HIP(hipGetLastError());
+        int rc = mnk_ls_launch_finish_info(ls, s);
+        if (rc) return rc;
     }
     return mnk_ls_prefill_spare(ls);
+}
+
+int mnk_ls_launch_finish_info(mnk_ls* ls, hipStream_t s) {
+    const bool lmode = ls->algo == MNK_LDL;
+    const int threads = lmode ? (ls->N >= 4096 ? 1024 : 256) : 64;
+    hipLaunchKernelGGL(finish_info_kernel, dim3(1), dim3(threads), 0, s, ls->dvec.p, lmode ? ls->N : (int64_t)0, ls->info_dev.p, ls->pin_dev,
+                       mnk_ls_growth_word(ls) != nullptr ? ls->amax_dev.p : (const unsigned long long*)nullptr);
+    MNK_HIP(hipGetLastError());
+    return 0;
 }
 
 int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows, double* Vrows, int64_t ldr, int64_t nrows) {
@@ -1373,6 +1388,7 @@ static int bk_fallback(mnk_ls* ls) {
 }
 
 int mnk_ls_fetch_info(mnk_ls* ls) {
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     if (ls->info_valid) return 0;
     hipStream_t s = ls->ctx->stream;
     if (ls->bk_active) {
@@ -1409,6 +1425,7 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         ls->last_growth = am > 0.0 ? dm / am : (dm > 0.0 ? HUGE_VAL : 0.0);
         ls->last_sign_changes = (int64_t)pw[6];
     }
+    if (hinfo == -7) ls->last_timeout_site = (int)(long long)pw[7];
     if (hinfo == -7 && ls->algo_now >= 4 && ls->retransfer) {
         // the persistent panel kernel gave up on a dependency (CUs shared with another process' persistent kernels):
         // factor again with one launch per panel piece, and stay there for a while (16, 64, 256, ... factorizations)

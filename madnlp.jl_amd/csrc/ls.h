@@ -76,11 +76,19 @@ struct mnk_ls {
     bool pp_blocked = false;
     int64_t fact_count = 0, pp_retry_at = 0, pp_backoff = 16;   // a schedule that timed out is tried again after 16, 64, 256, ... factorizations
     int pp_fallbacks = 0;
+    int last_timeout_site = 0;   // diagnostics: which bounded device-side wait expired (get_stat "timeout_site")
     int64_t pp_fuse_rows = 4096; // > 0: once this many rows (or fewer) remain, persistent panel launches apply the columns in front of them themselves
     int64_t own_cols = 128;   // split_a = 2: columns of the next panel that the panel stream updates itself
     // task-DAG schedule (panel_algo = 5, dag.hip)
     mnk::DevBuf<int> dag_tasks;   // 4 ints per task, built once per order
     int dag_ntasks = 0, dag_ntasks1 = 0, dag_js2 = 0;  // all tasks / tasks of the first phase / first strip-column of the second
+    std::vector<int> dag_host_tasks, dag_host_ready;   // the list on the host (4 ints per task) and the chain position that makes each task ready: merged per batch (dag.hip)
+    int dag_fill = 1;             // option: the zero-fill of the spare factor buffer (sparse sources) runs as DAG_FILL tasks of the bulk queue instead of on a side stream beside the solves
+    bool dag_has_fill = false;    // the current task list contains them
+    bool dag_filled = false;      // the factorization that was just queued zeroes the spare buffer itself (mnk_ls_prefill_spare has nothing to launch)
+    int batch_period = 0;         // option: shift between consecutive instances of a batch in the merged queue, in tile columns of chain position (0: half the matrix, the minimum)
+    hipEvent_t ev_defer = nullptr;   // batch: "matrix transferred" on this solver's stream / "batch done"
+    bool deferred = false;        // a factorize! call of this solver is pending in an open batch
     mnk::DevBuf<int> dag_flags;   // [queue counter | front: Np/64 | af: 4 * Np/128], zeroed per factorization
     mnk::DevBuf<double> vfull;    // LDL^T: V = L D of every column, same layout as `fact` (B operand of the left-looking updates)
     mnk::DevBuf<unsigned long long> dag_trace;  // diagnostics (option dag_trace): time stamps per bulk task / chain strip
@@ -141,6 +149,10 @@ struct mnk_ls {
 
 int64_t mnk_ls_effective_nbo(const mnk_ls* ls);
 int mnk_ls_run_factorization(mnk_ls* ls);
+int mnk_ls_run_factorization_now(mnk_ls* ls);      // factor.hip: the launch part (the schedule has been chosen; batches call it for leftovers)
+int mnk_ls_launch_finish_info(mnk_ls* ls, hipStream_t s);   // factor.hip: inertia / growth words / info -> pinned host words
+bool mnk_batch_defer(mnk_ls* ls);                  // dag.hip: true if the calling thread has a batch open and took the factorization into it
+int mnk_ls_sync_deferred(mnk_ls* ls);              // dag.hip: launches the open batch if this solver's factorization is pending in it
 int mnk_ls_prefill_spare(mnk_ls* ls);   // ls.hip: queue the background zero-fill of the spare factor buffer (if one is due)
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_factorization_dag(mnk_ls* ls);   // dag.hip: the task-DAG schedule (panel_algo = 5)

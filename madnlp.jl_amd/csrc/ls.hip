@@ -117,10 +117,14 @@ static std::atomic<int> g_live_ctx[64];
 
 int mnk_live_contexts(int device) { return g_live_ctx[device & 63].load(std::memory_order_relaxed); }
 
+std::recursive_mutex& mnk::launch_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 // ---- device arbiter of the persistent kernels (common.h) ----
 namespace {
-struct PersistSlot {
-    std::recursive_mutex mu;   // (recursive: a factorization that is redone inside mnk_ls_fetch_info re-enters on the same thread)
+struct PersistSlot {   // (guarded by mnk::launch_mutex(): recursive -- a factorization that is redone inside mnk_ls_fetch_info re-enters on the same thread)
     hipEvent_t last = nullptr;
     bool recorded = false;
 };
@@ -132,17 +136,30 @@ PersistSlot& persist_slot_of(mnk_ctx* ctx) {
 }
 }  // namespace
 
+void mnk::quiesce_persistent() {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < 64; ++d) {
+        PersistSlot& ps = g_persist[d];
+        if (ps.last == nullptr || !ps.recorded) continue;
+        (void)hipSetDevice(d);
+        (void)hipEventSynchronize(ps.last);
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+}
+
 int mnk_persist_begin(mnk_ctx* ctx, hipStream_t s) {
     PersistSlot& ps = persist_slot_of(ctx);
-    ps.mu.lock();
+    mnk::launch_mutex().lock();
     if (ps.last == nullptr && hipEventCreateWithFlags(&ps.last, hipEventDisableTiming) != hipSuccess) {
         ps.last = nullptr;
-        ps.mu.unlock();
+        mnk::launch_mutex().unlock();
         mnk::set_error("mnk_persist_begin: hipEventCreate failed");
         return -2;
     }
     if (ps.recorded && hipStreamWaitEvent(s, ps.last, 0) != hipSuccess) {
-        ps.mu.unlock();
+        mnk::launch_mutex().unlock();
         mnk::set_error("mnk_persist_begin: hipStreamWaitEvent failed");
         return -2;
     }
@@ -153,11 +170,13 @@ int mnk_persist_end(mnk_ctx* ctx, hipStream_t s, int rc) {
     PersistSlot& ps = persist_slot_of(ctx);
     if (hipEventRecord(ps.last, s) == hipSuccess) ps.recorded = true;
     else if (rc == 0) { mnk::set_error("mnk_persist_end: hipEventRecord failed"); rc = -2; }
-    ps.mu.unlock();
+    mnk::launch_mutex().unlock();
     return rc;
 }
 
 static void ctx_free(mnk_ctx* c) {
+    mnk::LaunchLock lock;   // (stream / event destruction may synchronize)
+    mnk::quiesce_persistent();
     (void)hipSetDevice(c->device);
     g_live_ctx[c->device & 63].fetch_sub(1, std::memory_order_relaxed);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
@@ -173,6 +192,8 @@ static void ctx_free(mnk_ctx* c) {
         if (c->su_dag) (void)hipStreamDestroy(c->su_dag);
         if (c->sp_dag2) (void)hipStreamDestroy(c->sp_dag2);
         if (c->su_dag2) (void)hipStreamDestroy(c->su_dag2);
+        if (c->sp_dagB) (void)hipStreamDestroy(c->sp_dagB);
+        if (c->su_dagB) (void)hipStreamDestroy(c->su_dagB);
     }
     if (c->s_fill) (void)hipStreamDestroy(c->s_fill);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -234,6 +255,7 @@ static bool make_masked_stream(int num_cu_total, const int* bits, int count, hip
 // whole chip (bench.py --batch) than on 2/4/8 partitions (72 vs 58/45/26 it/s).
 static int ctx_create_common(int device, void* stream, int part_first, int part_count, mnk_ctx** out) {
     MNK_REQUIRE(out != nullptr, "mnk_ctx_create: out is NULL");
+    mnk::LaunchLock lock;   // (stream / event creation: not between two launches of another thread's persistent group)
     int ndev = 0;
     MNK_HIP(hipGetDeviceCount(&ndev));
     MNK_REQUIRE(device >= 0 && device < ndev, "mnk_ctx_create: no such device");
@@ -295,7 +317,7 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
     // device anyway (mnk_persist_begin), and every stream more is one more client of the runtime's few hardware queues -- two
     // streams whose kernels must run side by side (chain and bulk) must not end up multiplexed behind a third one.
     if (c->num_cu >= 64) {
-        struct DagStreams { hipStream_t sp = nullptr, su = nullptr, sp2 = nullptr, su2 = nullptr; int cus = 0, cus2 = 0; bool made = false; };
+        struct DagStreams { hipStream_t sp = nullptr, su = nullptr, sp2 = nullptr, su2 = nullptr, spB = nullptr, suB = nullptr; int cus = 0, cus2 = 0; bool made = false; };
         static DagStreams shared[64];
         DagStreams own;
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
@@ -305,8 +327,19 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
             if (make_pair(want, d.sp, d.su)) d.cus = want;
             const int want2 = getenv("MNK_DAG_CUS2") ? atoi(getenv("MNK_DAG_CUS2")) : 96;
             if (d.cus > 0 && make_pair(want2, d.sp2, d.su2)) d.cus2 = want2;
+            // batches of independent factorizations: a second chain partition and a bulk stream on the CUs outside both
+            if (d.cus > 0 && 2 * d.cus + 32 <= c->num_cu) {
+                if (!(make_masked_stream(total, bits.data() + d.cus, d.cus, d.spB) &&
+                      make_masked_stream(total, bits.data() + 2 * d.cus, c->num_cu - 2 * d.cus, d.suB))) {
+                    if (d.spB) (void)hipStreamDestroy(d.spB);
+                    d.spB = d.suB = nullptr;
+                }
+            }
             d.made = true;
+            hipStream_t warm[3] = {d.su, d.su2, d.suB};
+            if (mnk_dag_warmup(warm, 3) != 0) (void)hipGetLastError();   // (best effort)
         }
+        c->sp_dagB = d.spB; c->su_dagB = d.suB;
         c->sp_dag = d.sp; c->su_dag = d.su; c->dag_cus = d.cus;
         c->sp_dag2 = d.sp2; c->su_dag2 = d.su2; c->dag_cus2 = d.cus2;
         c->shared_dag_streams = !part;
@@ -350,6 +383,7 @@ void* mnk_ctx_stream(mnk_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
     MNK_REQUIRE(ctx && out, "mnk_ls_create: NULL argument");
+    mnk::LaunchLock lock;   // (pinned host allocations, buffers)
     MNK_REQUIRE(N > 0, "mnk_ls_create: N must be positive");
     const bool bk_requested = algo == MNK_BUNCHKAUFMAN;
     if (bk_requested) algo = MNK_LDL;  // tier 1: static-pivot blocked LDL^T; tier 2 on breakdown: bk.hip
@@ -409,7 +443,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
         (void)hipGetLastError();
         rc |= -2;
     }
-    rc |= ls->info_dev.alloc(1);
+    rc |= ls->info_dev.alloc(2);   // info | which bounded device-side wait expired (info = -7)
     rc |= ls->inertia_dev.alloc(3);
     if (rc) { delete ls; return -2; }
     MNK_HIP(hipMemsetAsync(ls->fact.p, 0, ((size_t)ls->ld * ls->Np + SLACK) * sizeof(double), ctx->stream));
@@ -421,12 +455,16 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
 int mnk_ls_destroy(mnk_ls* ls) {
     if (!ls) return 0;
     (void)hipSetDevice(ls->ctx->device);
+    (void)mnk_ls_sync_deferred(ls);
     (void)mnk::stream_wait(ls->ctx->stream);
+    mnk::LaunchLock lock;   // (host-memory frees and event destruction below; the device buffers lock for themselves)
+    mnk::quiesce_persistent();
     if (ls->solve_abort) (void)hipHostFree(ls->solve_abort);
     if (ls->pin) (void)hipHostFree(ls->pin);
     if (ls->ctx->s_fill) (void)mnk::stream_wait(ls->ctx->s_fill);   // a background fill of this solver's spare buffer
     if (ls->ev_spare) (void)hipEventDestroy(ls->ev_spare);
     if (ls->ev_free) (void)hipEventDestroy(ls->ev_free);
+    if (ls->ev_defer) (void)hipEventDestroy(ls->ev_defer);
     mnk_ctx* ctx = ls->ctx;
     delete ls;
     mnk_ctx_child_gone(ctx);
@@ -435,6 +473,7 @@ int mnk_ls_destroy(mnk_ls* ls) {
 
 int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     MNK_REQUIRE(ls && key, "mnk_ls_set_option: NULL argument");
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     for (const std::string& k : ls->env_keys)
         if (k == key) {   // fixed by the environment for this process (MNK_OPTIONS): the call is ignored, once per key out loud
             static std::mutex warn_mutex;
@@ -512,6 +551,8 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         ls->dag_spin_limit = (long)value;
         return 0;
     }
+    if (!strcmp(key, "dag_fill")) { ls->dag_fill = value != 0.0; ls->dag_tasks.release(); return 0; }   // zero-fill of the spare buffer as tasks of the bulk queue
+    if (!strcmp(key, "batch_period")) { ls->batch_period = (int)value; return 0; }
     if (!strcmp(key, "dag_trace")) { ls->dag_trace_on = value != 0.0; return 0; }  // diagnostics: tools/dag_timeline.py
     if (!strcmp(key, "dag_max_rows")) { ls->dag_max_rows = (int64_t)value; return 0; }
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
@@ -605,6 +646,12 @@ static int prepare_fill(mnk_ls* ls) {
 int mnk_ls_prefill_spare(mnk_ls* ls) {
     if (!ls->spare_pending) return 0;
     ls->spare_pending = false;
+    if (ls->dag_filled) {   // the bulk queue of the factorization that was just queued zeroes the spare buffer (DAG_FILL tasks): stream order does the rest
+        ls->dag_filled = false;
+        MNK_HIP(hipEventRecord(ls->ev_spare, ls->ctx->stream));
+        ls->spare_zeroed = true;
+        return 0;
+    }
     mnk_ctx* ctx = ls->ctx;
     dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np / 2 + 255) / 256));
     MNK_HIP(hipEventRecord(ls->ev_free, ctx->stream));
@@ -631,6 +678,7 @@ int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
     MNK_REQUIRE(ls && sc && sc->ctx, "mnk_ls_factorize_sc: NULL argument or host-only handle");
     MNK_REQUIRE(sc->n == ls->N, "mnk_ls_factorize_sc: order mismatch");
     MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }   // (a factorize! of this solver pending in an open batch runs first)
     int rc = ensure_wbuf(ls);
     if (rc) return rc;
     rc = transfer_sc(ls, sc);
@@ -669,6 +717,7 @@ int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc) {
     MNK_REQUIRE(ls && dc, "mnk_ls_factorize_dc: NULL argument");
     MNK_REQUIRE(dc->order == ls->N, "mnk_ls_factorize_dc: order mismatch");
     MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }   // (a factorize! of this solver pending in an open batch runs first)
     int rc = factorize_dense_dev(ls, dc->aug.p, round_up(dc->order, PAD));
     // the way back goes through the handle (its buffer may be reallocated, the handle may be destroyed before the inertia
     // of this asynchronous call is fetched)
@@ -704,6 +753,7 @@ int mnk_ls_factorize_dense(mnk_ls* ls, const double* A, int64_t lda, int loc, in
     MNK_REQUIRE(ls && A, "mnk_ls_factorize_dense: NULL argument");
     MNK_REQUIRE(lda >= ls->N, "mnk_ls_factorize_dense: lda < N");
     MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }   // (a factorize! of this solver pending in an open batch runs first)
     int rc;
     if (loc == MNK_DEVICE) {
         rc = factorize_dense_dev(ls, A, lda);
@@ -728,6 +778,7 @@ int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowva
                          int index_base, int* info) {
     MNK_REQUIRE(ls && colptr && rowval && nzval, "mnk_ls_factorize_csc: NULL argument");
     MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }   // (a factorize! of this solver pending in an open batch runs first)
     const int64_t N = ls->N;
     const int64_t nnz = colptr[N] - index_base;
     std::vector<int32_t> row(nnz), col(nnz);
@@ -769,6 +820,7 @@ int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowva
 
 int mnk_ls_inertia(mnk_ls* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg) {
     MNK_REQUIRE(ls, "mnk_ls_inertia: NULL argument");
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     MNK_REQUIRE(ls->factorized, "mnk_ls_inertia: factorize first");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     int rc = mnk_ls_fetch_info(ls);
@@ -794,6 +846,7 @@ int mnk_ls_check_solve(mnk_ls* ls) {
 
 int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
     MNK_REQUIRE(ls && x, "mnk_ls_solve: NULL argument");
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     MNK_REQUIRE(ls->factorized, "mnk_ls_solve: factorize first");
     MNK_REQUIRE(nrhs >= 1 && ldx >= ls->N, "mnk_ls_solve: bad nrhs/ldx");
     MNK_HIP(hipSetDevice(ls->ctx->device));
@@ -859,6 +912,7 @@ int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n) {
 
 int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
     MNK_REQUIRE(ls && L, "mnk_ls_get_factor: NULL argument");
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     MNK_REQUIRE(ls->factorized, "mnk_ls_get_factor: factorize first");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     hipStream_t s = ls->ctx->stream;
@@ -873,6 +927,7 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
 int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     MNK_REQUIRE(ls && key && value, "mnk_ls_get_stat: NULL argument");
     MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     if (ls->factorized) {
         int rc = mnk_ls_fetch_info(ls);
         if (rc) return rc;
@@ -883,6 +938,8 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     }
     if (!strcmp(key, "panel_algo")) { *value = ls->algo_now; return 0; }
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
+    // which bounded device-side wait expired last (info = -7): 1 bulk task / operand rows, 2 bulk task / chunk order, 3 gate on the bulk stream, 4 chain strip / diagonal block, 5 chain strip / bulk kernel's rows or band tiles; 0: none
+    if (!strcmp(key, "timeout_site")) { *value = ls->last_timeout_site; return 0; }
     if (!strcmp(key, "growth")) { *value = ls->last_growth; return 0; }  // BUNCHKAUFMAN: max|d_k| / max|a_ij| of the static-pivot tier
     if (!strcmp(key, "sign_changes")) { *value = (double)ls->last_sign_changes; return 0; }  // ... and sign changes along its pivots
     if (!strcmp(key, "bk_count")) { *value = ls->bk_count; return 0; }
@@ -896,6 +953,7 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
 int mnk_ls_bk_info(mnk_ls* ls, int* active, int* count, int32_t* perm, double* doff) {
     MNK_REQUIRE(ls, "mnk_ls_bk_info: NULL argument");
     MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     if (ls->factorized) {
         int rc = mnk_ls_fetch_info(ls);  // the tier is decided when the static factorization's pivots are known
         if (rc) return rc;

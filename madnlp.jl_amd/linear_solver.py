@@ -96,6 +96,23 @@ class HipContext:
             pass
 
 
+class factorize_batch:
+    """`with factorize_batch(): ...` -- the factorize! calls of this thread inside the block transfer their matrices and are
+    queued; leaving the block launches them together (`mnk_factorize_batch_begin / _end`): instances of one order share one
+    persistent launch, each one's chain-bound ends filled with its neighbours' trailing updates.  Independent instances only
+    (scenario batches, BASELINE config C5); every factor is bit-identical to a lone factorize!."""
+
+    def __enter__(self):
+        L.check(L.lib().mnk_factorize_batch_begin(), "mnk_factorize_batch_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = L.lib().mnk_factorize_batch_end()
+        if rc and et is None:
+            raise FactorizationException(L.lib().mnk_last_error_string().decode())
+        return False
+
+
 def _ptr(a):
     """Raw pointer + location of a numpy array (host) or a torch tensor (host/device)."""
     if a is None:

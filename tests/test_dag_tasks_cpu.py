@@ -78,3 +78,53 @@ def test_task_list_covers_every_tile_once_and_waits_only_backwards(ntile, chunk,
     # the Python mirror the trace tools use is the same list
     mirror = dag_tasks(ntile, chunk, band_tiles, js2, taper0)
     assert [(f, q, I, J, kb, ke) for (_, _, J, I, f, q, kb, ke) in mirror] == ts
+
+
+FILL = 8
+
+
+def _merged(ntile, chunk, band_tiles, js2, taper0, fill, ninst, period):
+    cap = 2000000
+    out = np.zeros(4 * cap, dtype=np.int32)
+    n = L.lib().mnk_debug_dag_merged_tasks(ntile, chunk, band_tiles, js2, taper0, int(fill), ninst, period, out.ctypes.data, cap)
+    assert 0 <= n <= cap
+    t = out[: 4 * n].reshape(n, 4)
+    return [(int(a) & 255, int(a) >> 8, int(i) & 0xffff, int(i) >> 16, int(j), int(k) & 0xffff, int(k) >> 16) for a, i, j, k in t]
+
+
+@pytest.mark.parametrize("ntile,chunk,band_tiles,js2,taper0,ninst,period", [(16, 64, 8, 8, 2, 3, 8), (40, 64, 8, 20, 2, 5, 20), (88, 64, 8, 44, 2, 16, 44),
+                                                                            (45, 7, 6, 23, 3, 4, 23), (88, 64, 8, 44, 2, 2, 60)])
+def test_merged_queue_of_a_batch(ntile, chunk, band_tiles, js2, taper0, ninst, period):
+    """mnk_factorize_batch_*: ONE queue for several factorizations of the same order.  (1) Every instance's sub-sequence is the
+    single-instance list (so the arithmetic per tile, and the order of its chunks, are those of a lone factorization:
+    bit-identical factors) with the zero-fill tasks of the next factorization's buffer: every lower tile once.  (2) Two
+    pivot chains run at a time -- chain i + 2 follows chain i on its stream -- so every task of instance i must sit in front
+    of every task of instance i + 2 (a workgroup that holds a task of i + 2 may have to wait for the end of chain i, and
+    chain i for tasks of instance i: they must not be stuck behind it).  (3) The instances overlap: tasks of i + 1 start
+    before the tasks of i end."""
+    base, _ = _tasks(ntile, chunk, band_tiles, js2, taper0)
+    one = _merged(ntile, chunk, band_tiles, js2, taper0, True, 1, period)
+    assert [x[:3] + x[4:] for x in one if not (x[0] & FILL)] == base
+    fills = [(x[2], x[4]) for x in one if x[0] & FILL]
+    assert sorted(fills) == sorted((i, j) for j in range(ntile) for i in range(j, ntile)) and len(set(fills)) == len(fills)
+    assert all(x[3] == 0 for x in one)
+    # fills are spread over the first phase, not bunched: no more than a few in a row
+    run = mx = 0
+    for x in one:
+        run = run + 1 if x[0] & FILL else 0
+        mx = max(mx, run)
+    assert mx <= 1 + (len(fills) + len(base) - 1) // max(1, len(base))
+    m = _merged(ntile, chunk, band_tiles, js2, taper0, True, ninst, period)
+    assert len(m) == ninst * len(one)
+    first, last = {}, {}
+    for idx, x in enumerate(m):
+        first.setdefault(x[3], idx)
+        last[x[3]] = idx
+    for i in range(ninst):
+        sub = [x[:3] + (0,) + x[4:] for x in m if x[3] == i]
+        assert sub == one, i
+    for i in range(ninst - 2):
+        assert last[i] < first[i + 2], (i, last[i], first[i + 2])
+    if period < ntile:
+        for i in range(ninst - 1):
+            assert first[i + 1] < last[i]

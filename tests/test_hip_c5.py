@@ -97,7 +97,8 @@ def test_c5_batch_on_one_gpu_matches_oracle(nctx, nb):
         b = din["rhs"].cpu().numpy()
         assert _bwd(K, x, b) <= 1e-13
         kh.linear_solver.check_solve()
-        assert kh.linear_solver.get_stat("panel_algo") == 5.0 and kh.linear_solver.get_stat("pp_fallbacks") == 0.0   # the task-DAG schedule on every context: persistent operations take turns (device arbiter)
+        # the task-DAG schedule on every context: persistent operations take turns (device arbiter)
+        assert (kh.linear_solver.get_stat("panel_algo"), kh.linear_solver.get_stat("pp_fallbacks")) == (5.0, 0.0), kh.linear_solver.get_stat("timeout_site")
     assert len(seen) == nb, "the scenarios must be different problems"
     for (_, kh, _, _) in insts:
         kh.close()
@@ -105,3 +106,109 @@ def test_c5_batch_on_one_gpu_matches_oracle(nctx, nb):
         c.close()
 
 
+
+
+# --------------------------------------------------------------------------- batches: one merged launch
+def _make_instances(specs, ctxs, streams, dev):
+    insts = []
+    for i, (case, seed) in enumerate(specs):
+        P = opf_shaped(case, seed=seed, du=1e-8)
+        kh = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub,
+                                         ctx=ctxs[i % len(ctxs)],
+                                         opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+        din = dict(jac=torch.from_numpy(P.jac).to(dev), hess=torch.from_numpy(P.hess).to(dev),
+                   pr=torch.from_numpy(P.pr_diag).to(dev), du=torch.from_numpy(P.du_diag).to(dev),
+                   rhs=torch.from_numpy(np.random.default_rng(seed).standard_normal(P.n)).to(dev))
+        din["x"] = torch.empty_like(din["rhs"])
+        insts.append((P, kh, streams[i % len(streams)], din))
+    return insts
+
+
+def _front(kh, st, din):
+    with torch.cuda.stream(st):
+        kh.compress_jacobian(din["jac"]); kh.compress_hessian(din["hess"]); kh.build_kkt(din["pr"], din["du"])
+        kh.linear_solver.factorize_async()
+
+
+@pytest.mark.parametrize("nctx,nb", [(1, 5), (2, 6)])
+def test_batched_factorizations_are_bit_identical_to_lone_ones(nctx, nb):
+    """mnk_factorize_batch_begin / _end: the factorize! calls of a block are queued and launched
+    together -- ONE bulk kernel drains the merged task queue of all instances beside TWO pivot chains (even instances on one
+    CU partition, odd ones on the other; chain i + 2 follows chain i), each instance's chain-bound ends filled with its
+    neighbours' trailing updates.  Independent case1354pegase-shaped scenarios (N = 11 192), on one context and spread over
+    two contexts / streams; three rounds (the factor buffers alternate: from the second round on the scatter lands in the
+    buffer that the previous round's queue zeroed with its DAG_FILL tasks).  Every instance and round: the task-DAG schedule
+    ran, no fall-back, inertia (N, 0, 0), the factor's bits (L and D) equal those of a lone factorize! of the same matrix
+    on the same solver, backward error of a solve <= 1e-13 against the oracle's sparse K."""
+    dev = torch.device("cuda", 0)
+    base = OPF_CASES["case1354pegase"][0]
+    streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
+    ctxs = [mj.HipContext(0, stream=s.cuda_stream) for s in streams]
+    insts = _make_instances([("case1354pegase", base + 100 + i) for i in range(nb)], ctxs, streams, dev)
+    torch.cuda.synchronize()
+    ref = []
+    for (P, kh, st, din) in insts:      # lone factorizations first
+        _front(kh, st, din)
+        assert kh.linear_solver.inertia() == (P.n, 0, 0)
+        Lf, D = kh.linear_solver.get_factor_device()
+        ref.append((torch.tril(Lf).clone(), D.clone()))
+    for rnd in range(3):
+        with mj.factorize_batch():
+            for (_, kh, st, din) in insts:
+                _front(kh, st, din)
+        for (P, kh, st, din) in insts:
+            with torch.cuda.stream(st):
+                assert kh.linear_solver.inertia() == (P.n, 0, 0)
+                din["x"].copy_(din["rhs"])
+                kh.linear_solver.solve_linear_system(din["x"])
+        torch.cuda.synchronize()
+        for i, (P, kh, st, din) in enumerate(insts):
+            assert kh.linear_solver.get_stat("panel_algo") == 5.0 and kh.linear_solver.get_stat("pp_fallbacks") == 0.0
+            Lf, D = kh.linear_solver.get_factor_device()
+            assert torch.equal(torch.tril(Lf), ref[i][0]) and torch.equal(D, ref[i][1]), (rnd, i)
+            kh.linear_solver.check_solve()
+    for (P, kh, st, din) in insts:
+        ko = _oracle_sc(P)
+        np.testing.assert_array_equal(kh.aug_com.nzval, ko.aug_com.nzval)
+        assert _bwd(_full(ko), din["x"].cpu().numpy(), din["rhs"].cpu().numpy()) <= 1e-13
+    for (_, kh, _, _) in insts:
+        kh.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_batch_with_mixed_orders_and_a_forgotten_end():
+    """A batch groups what it can: two instances of N = 11 192 and two of N = 8400 form two merged launches, a case118-sized
+    system (below the schedule's window) is not queued at all; and a call that needs a queued solver's factor before
+    mnk_factorize_batch_end (here: `inertia`) launches what is queued instead of answering from a stale factor."""
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
+    specs = [("case1354pegase", 7), ((1000, 200, 1500), 8), ("case1354pegase", 9), ((1000, 200, 1500), 10), ("case118", 11)]
+    insts = _make_instances(specs, [ctx], [st], dev)
+    assert [P.n for (P, *_r) in insts][:4] == [11192, 8400, 11192, 8400] and insts[4][0].n < 1536
+    L.check(L.lib().mnk_factorize_batch_begin(), "begin")
+    try:
+        for (_, kh, s_, din) in insts:
+            _front(kh, s_, din)
+        # no _end yet: the inertia of a queued solver launches the queue
+        assert insts[0][1].linear_solver.inertia() == (insts[0][0].n, 0, 0)
+        for (_, kh, s_, din) in insts[:2]:     # a second round of two of them goes into the (still open) batch
+            _front(kh, s_, din)
+    finally:
+        L.check(L.lib().mnk_factorize_batch_end(), "end")
+    assert L.lib().mnk_factorize_batch_end() != 0          # no batch open: an error, not a crash
+    for (P, kh, s_, din) in insts:
+        with torch.cuda.stream(s_):
+            assert kh.linear_solver.inertia() == (P.n, 0, 0)
+            din["x"].copy_(din["rhs"])
+            kh.linear_solver.solve_linear_system(din["x"])
+    torch.cuda.synchronize()
+    for (P, kh, s_, din) in insts:
+        ko = _oracle_sc(P)
+        np.testing.assert_array_equal(kh.aug_com.nzval, ko.aug_com.nzval)
+        assert _bwd(_full(ko), din["x"].cpu().numpy(), din["rhs"].cpu().numpy()) <= 1e-13
+        if P.n > 6200:
+            assert kh.linear_solver.get_stat("panel_algo") == 5.0 and kh.linear_solver.get_stat("pp_fallbacks") == 0.0
+        kh.close()
+    ctx.close()

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4c6; rm -rf $O; mkdir -p $O
+B="bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-ipm-loop"
+for rep in 1 2; do
+for d in _r3ab .; do
+  (cd $d; timeout 200 python $B 2>> $GRAFT_REPO_ROOT/$O/err.log | grep '^{' | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('[$d]', round(d['value'],2), round(d['ms_per_step'],3), round(d['ms_per_factorize'],3), round(d['ms_per_solve'],3), round(d['ms_assemble'],4), d['roofline']['schedule_panel_algo'], d['roofline']['pp_fallbacks'])" >> $GRAFT_REPO_ROOT/$O/ab.txt)
+done
+done
+for i in 1 2 3 4 5 6; do timeout 300 python -m pytest tests/test_hip_c5.py -q -k "matches_oracle" 2>&1 | grep -v "^$" | tail -3 >> $O/t_c5_iso.log; done
+for i in 1 2; do timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -12 >> $O/t_full.log; done
+cat $O/ab.txt; grep -n "passed\|failed\|Assertion" $O/t_c5_iso.log; grep -n "passed\|failed\|Assertion\|^E  " $O/t_full.log
