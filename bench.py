@@ -331,11 +331,13 @@ def cpu_baseline(P, algorithm, nsolve, budget_s=100.0):
 
 
 def pmc_traffic(N, args, schedule):
-    """HBM bytes per factorize! call from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, two separate --pmc passes: counters cannot be
-    collected inside the timed run).  Returns (bytes or None, the profile the number came from).
-    A profile only describes the schedule it was collected on (its "panel_algo"; the round-2 files: 4)."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    """Bytes per factorize! call at the L2 -> fabric interface (Infinity Cache + HBM) from the committed counter passes of
+    this same system (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes: counters cannot be collected inside
+    the timed run).  Returns (bytes or None, the profile the number came from).  A profile only describes the schedule it
+    was collected on (its "panel_algo"; the round-2 / round-3 files: 4; round 4: 5, the schedule the bench runs)."""
+    # r04: the task-DAG schedule itself, through rocprofiler-sdk's device counting service (tools/devcount_dag.py: agent-wide
+    # sampling without dispatch serialization -- `rocprofv3 --pmc` cannot run the two persistent kernels side by side)
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if N == 11192 and args.batch == 1 and os.path.exists(path):
             try:
@@ -481,19 +483,44 @@ def main():
                 kb.linear_solver.solve_linear_system(din["x"])
 
     use_batch_api = args.batch > 1 and not args.no_batch_api
+    sbatches = []
+    if use_batch_api:
+        # one ScenarioBatch per context / stream (array entry points: one library call per phase and context instead of
+        # four to six per instance)
+        for (cctx, cst) in ctxs:
+            mine = [it for it in insts if it[2] is cst]
+            if mine:
+                sb = mj.ScenarioBatch([it[1] for it in mine])
+                sb.bind([it[3]["jac"] for it in mine], [it[3]["hess"] for it in mine], [it[3]["pr"] for it in mine],
+                        [it[3]["du"] for it in mine])
+                sbatches.append((sb, cst, mine, [it[3]["x"] for it in mine], [it[3]["rhs"] for it in mine]))
 
     def step():
         # batch: every instance's assembly + factorization is enqueued before the first inertia fetch
         # blocks the host, so the contexts keep the chip busy while the host waits
         if use_batch_api:
-            with mj.factorize_batch():
-                for (_, kb, st, din) in insts:
-                    step_front(kb, st, din)
+            with mj.factorize_batch():      # (all contexts' instances in ONE batch)
+                for (sb, cst, mine, xs, rhss) in sbatches:
+                    sb.step()
         else:
             for (_, kb, st, din) in insts:
                 step_front(kb, st, din)
-        for (_, kb, st, din) in insts:
-            step_back(kb, st, din)
+        if use_batch_api:
+            # every instance's inertia, then solve k of all instances together (mnk_solve_batch_begin / _end: up to four
+            # independent systems per launch), k = 1 .. nsolve -- the same work per instance as step_back
+            for (sb, cst, mine, xs, rhss) in sbatches:
+                for it, inertia in zip(mine, sb.inertia()):
+                    if not it[1].is_inertia_correct(*inertia):
+                        raise SystemExit(f"unexpected inertia {inertia} on the benchmark system")
+            for _ in range(args.nsolve):
+                with mj.solve_batch():      # (all contexts' instances in ONE batch)
+                    for (sb, cst, mine, xs, rhss) in sbatches:
+                        with torch.cuda.stream(cst):
+                            torch._foreach_copy_(xs, rhss)
+                        sb.solve(xs)
+        else:
+            for (_, kb, st, din) in insts:
+                step_back(kb, st, din)
 
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
     dt = lambda v: torch.tensor(v, dtype=torch.float64, device=dev)  # noqa: E731

@@ -174,9 +174,27 @@ int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc);
  * launch beside two pivot chains, so that one instance's chain-bound ends are filled with its neighbours' trailing
  * updates (N = 11 192: ~10.7 -> ~9.x ms per instance).  Every instance's factor is bit-identical to the one a lone
  * factorize! produces.  Any call that needs a queued solver's factor (inertia, solve, another factorize!, destroy)
- * launches what is queued first, so a forgotten _end cannot give a stale answer.  Thread-local: one open batch per thread. */
+ * launches what is queued first, so a forgotten _end cannot give a stale answer.  Thread-local; _begin / _end pairs nest (the
+ * outermost _end launches). */
 int mnk_factorize_batch_begin(void);
 int mnk_factorize_batch_end(void);
+/* ... and of independent solves: between _begin and _end the mnk_ls_solve calls of the calling thread with ONE right-hand
+ * side on a DEVICE vector are queued; _end runs them up to four systems per launch (one solve is bound by its chain of
+ * hops, not by HBM: four side by side take hardly longer than one; N = 11 192: 0.45 -> ~0.2 ms per solve).  The vectors must
+ * stay untouched until _end returns (asynchronously, like any device solve: mnk_ls_check_solve as usual).  Solves that do not
+ * qualify run at once; several right-hand sides of one solver keep their order (one per launch).  Results are bit-identical
+ * to lone solves.  Thread-local, like the factorization batch. */
+int mnk_solve_batch_begin(void);
+int mnk_solve_batch_end(void);
+/* Array forms for n independent instances (one call per phase of an iteration; hosts with a per-call overhead):
+ *   _step_batch    : per instance compress_jacobian! + compress_hessian! + build_kkt! + factorize! (asynchronous), the
+ *                    factorizations as ONE batch (mnk_factorize_batch_begin / _end around the loop);
+ *   _inertia_batch : inertia of every instance (each waits for its own factorization only);
+ *   _solve_batch   : one right-hand side per instance, as ONE solve batch (x[i]: N_i entries, in place). */
+int mnk_sc_step_batch(int n, mnk_sc* const* sc, mnk_ls* const* ls, const double* const* jac_coo, const double* const* hess_coo,
+                      const double* const* pr_diag, const double* const* du_diag, int loc);
+int mnk_ls_inertia_batch(int n, mnk_ls* const* ls, int64_t* num_pos, int64_t* num_zero, int64_t* num_neg);
+int mnk_ls_solve_batch(int n, mnk_ls* const* ls, double* const* x, int loc);
 
 /* inertia(M) `lapack_common.jl:96-109`, `lapack.jl:240-268`: (num_pos, num_zero, num_neg).
  * CHOLESKY: info == 0 ? (N,0,0) : (0,N,0).  LDL: signs of D. */

@@ -221,6 +221,16 @@ function factorize_batch(f)
     return nothing
 end
 factorize_batch!(Ms) = (factorize_batch(() -> foreach(factorize_async!, Ms)); Ms)
+# ... and of independent solves on device vectors (mnk_solve_batch_begin / _end): up to four systems per launch
+function solve_batch(f)
+    check(ccall((:mnk_solve_batch_begin, libmadnlp_hip), Cint, ()), SolveException)
+    try
+        f()
+    finally
+        check(ccall((:mnk_solve_batch_end, libmadnlp_hip), Cint, ()), SolveException)
+    end
+    return nothing
+end
 
 function MadNLP.solve_linear_system!(M::HipLinearSolver, x::Vector{Float64})
     rc = ccall((:mnk_ls_solve, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cint),

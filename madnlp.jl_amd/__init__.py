@@ -7,11 +7,11 @@ fails loudly if it has not been built (no CPU fallback).
 """
 from ._lib import build, lib, LIBPATH, HipError  # noqa: F401
 from .linear_solver import (  # noqa: F401
-    BUNCHKAUFMAN, CHOLESKY, LDL, HipContext, HipLinearSolver, HipSolverOptions, factorize_batch,
+    BUNCHKAUFMAN, CHOLESKY, LDL, HipContext, HipLinearSolver, HipSolverOptions, factorize_batch, solve_batch,
     LinearSolverException, SymbolicException, FactorizationException, SolveException, InertiaException,
 )
 from .kkt import (  # noqa: F401
-    UnreducedKKTVector, SparseCondensedKKTSystem, DenseCondensedKKTSystem, DenseKKTSystem,
+    UnreducedKKTVector, SparseCondensedKKTSystem, DenseCondensedKKTSystem, DenseKKTSystem, ScenarioBatch,
 )
 from .backsolve import RichardsonIterator  # noqa: F401
 

@@ -211,6 +211,11 @@ SIGNATURES = {
     "mnk_debug_dag_merged_tasks": (C.c_int, [C.c_int] * 8 + [_vp, C.c_int]),
     "mnk_factorize_batch_begin": (C.c_int, []),
     "mnk_factorize_batch_end": (C.c_int, []),
+    "mnk_solve_batch_begin": (C.c_int, []),
+    "mnk_solve_batch_end": (C.c_int, []),
+    "mnk_sc_step_batch": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "mnk_ls_inertia_batch": (C.c_int, [C.c_int, _vp, _i64p, _i64p, _i64p]),
+    "mnk_ls_solve_batch": (C.c_int, [C.c_int, _vp, _vp, C.c_int]),
     "mnk_debug_update": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int,
                                    C.POINTER(C.c_double)]),
     "mnk_gemm_nt": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int64, _vp,

@@ -1017,6 +1017,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 struct BatchState {
+    int depth = 0;             // (begin / end pairs nest: the outermost end launches)
     bool active = false;
     std::vector<mnk_ls*> pend;
 };
@@ -1098,23 +1099,38 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
         MNK_HIP(hipStreamWaitEvent(sp[1], B.ev[0], 0));
         MNK_HIP(hipStreamWaitEvent(su, B.ev[0], 0));
         const unsigned strips = (unsigned)std::min<int64_t>(l0->dag_band, Np / NBI);
-        for (int i = 0; i < ninst; ++i) {
+        const int bulk_cus = c0->num_cu - 2 * c0->dag_cus;
+        // Launch order: the first two chains, THEN the bulk kernel, then everything else -- the host needs ~3 ms for the
+        // 4 x ninst launches of the chains' streams (measured: the bulk kernel used to start 3 ms after the first chain,
+        // 2 % of a 16-instance step).  Per chain stream: chain i, its inverses for the solves and its inertia / info words
+        // (the next chain of the stream starts behind them; the bulk kernel has work of the other instance meanwhile).
+        auto launch_chain = [&](int i) -> int {
             mnk_ls* ls = g[i];
             mnk::PpDag dag{hin[i].front, hin[i].af, ntile, 0, 0, -1, ls->dag_spin_limit, nullptr, mnk_ls_growth_word(ls)};
-            int r = mnk_launch_pchain(ls, sp[i & 1], dag, 0, nsc, strips);
-            if (r) return r;
-            // its inverses and its inertia / info words follow on the chain's stream (the next chain of this stream starts
-            // behind them; the bulk kernel has work of the other instance meanwhile)
-            r = mnk_ls_invert_blocks(ls, sp[i & 1], 0, nsc);
+            return mnk_launch_pchain(ls, sp[i & 1], dag, 0, nsc, strips);
+        };
+        auto launch_tail = [&](int i) -> int {
+            mnk_ls* ls = g[i];
+            int r = mnk_ls_invert_blocks(ls, sp[i & 1], 0, nsc);
             if (r) return r;
             ls->inv_done = nsc;
-            r = mnk_ls_launch_finish_info(ls, sp[i & 1]);
+            return mnk_ls_launch_finish_info(ls, sp[i & 1]);
+        };
+        for (int i = 0; i < std::min(2, ninst); ++i) {
+            int r = launch_chain(i);
             if (r) return r;
         }
-        const int bulk_cus = c0->num_cu - 2 * c0->dag_cus;
         int r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p,
                                      l0->dag_spin_limit, std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
         if (r) return r;
+        for (int i = 0; i < ninst; ++i) {
+            r = launch_tail(i);
+            if (r) return r;
+            if (i + 2 < ninst) {
+                r = launch_chain(i + 2);
+                if (r) return r;
+            }
+        }
         MNK_HIP(hipEventRecord(B.ev[1], sp[0]));
         MNK_HIP(hipEventRecord(B.ev[2], sp[1]));
         MNK_HIP(hipEventRecord(B.ev[3], su));
@@ -1164,6 +1180,14 @@ static int batch_flush() {
 }
 
 int mnk_ls_sync_deferred(mnk_ls* ls) {
+    {   // (queued solves of this solver run before anything else touches it)
+        int rc_s = mnk_solve_sync_deferred(ls);
+        if (rc_s) return rc_s;
+    }
+    return mnk_ls_sync_deferred_fact(ls);
+}
+
+int mnk_ls_sync_deferred_fact(mnk_ls* ls) {
     if (!ls->deferred) return 0;
     if (std::find(t_batch.pend.begin(), t_batch.pend.end(), ls) == t_batch.pend.end()) {
         set_error("a factorize! call of this solver is pending in a batch that another thread opened (mnk_factorize_batch_end must come first)");
@@ -1173,13 +1197,14 @@ int mnk_ls_sync_deferred(mnk_ls* ls) {
 }
 
 extern "C" int mnk_factorize_batch_begin(void) {
-    if (t_batch.active) { set_error("mnk_factorize_batch_begin: a batch is already open on this thread"); return -1; }
+    ++t_batch.depth;
     t_batch.active = true;
     return 0;
 }
 
 extern "C" int mnk_factorize_batch_end(void) {
-    if (!t_batch.active) { set_error("mnk_factorize_batch_end: no batch is open on this thread"); return -1; }
+    if (t_batch.depth <= 0) { set_error("mnk_factorize_batch_end: no batch is open on this thread"); return -1; }
+    if (--t_batch.depth > 0) return 0;
     t_batch.active = false;
     return batch_flush();
 }

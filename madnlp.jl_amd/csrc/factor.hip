@@ -1352,6 +1352,11 @@ int mnk_ls_launch_finish_info(mnk_ls* ls, hipStream_t s) {
     hipLaunchKernelGGL(finish_info_kernel, dim3(1), dim3(threads), 0, s, ls->dvec.p, lmode ? ls->N : (int64_t)0, ls->info_dev.p, ls->pin_dev,
                        mnk_ls_growth_word(ls) != nullptr ? ls->amax_dev.p : (const unsigned long long*)nullptr);
     MNK_HIP(hipGetLastError());
+    // mnk_ls_fetch_info waits for THIS point, not for the stream: whatever the caller has queued behind the factorization
+    // (the solves of other instances of a batch, the next assembly) does not delay the inertia
+    if (!ls->ev_info) MNK_HIP(hipEventCreateWithFlags(&ls->ev_info, hipEventDisableTiming));
+    MNK_HIP(hipEventRecord(ls->ev_info, s));
+    ls->ev_info_recorded = true;
     return 0;
 }
 
@@ -1413,7 +1418,8 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
     // growth guard of the static-pivot tier (BUNCHKAUFMAN): max|a_ij| was recorded when the matrix was transferred
     const bool guard = ls->algo == MNK_LDL && ls->bk_requested && ls->bk_fallback && ls->retransfer && ls->amax_dev.p != nullptr;
     // (finish_info_kernel, queued behind the factorization, has stored everything in the pinned words)
-    MNK_HIP(mnk::stream_wait(s));
+    if (ls->ev_info_recorded) MNK_HIP(hipEventSynchronize(ls->ev_info));
+    else MNK_HIP(mnk::stream_wait(s));
     volatile unsigned long long* pw = ls->pin;
     unsigned long long h[3] = {pw[0], pw[1], pw[2]};
     int hinfo = (int)(long long)pw[3];

@@ -87,6 +87,8 @@ struct mnk_ls {
     bool dag_has_fill = false;    // the current task list contains them
     bool dag_filled = false;      // the factorization that was just queued zeroes the spare buffer itself (mnk_ls_prefill_spare has nothing to launch)
     int batch_period = 0;         // option: shift between consecutive instances of a batch in the merged queue, in tile columns of chain position (0: half the matrix, the minimum)
+    hipEvent_t ev_info = nullptr;    // recorded behind finish_info_kernel: what mnk_ls_fetch_info waits for
+    bool ev_info_recorded = false;
     hipEvent_t ev_defer = nullptr;   // batch: "matrix transferred" on this solver's stream / "batch done"
     bool deferred = false;        // a factorize! call of this solver is pending in an open batch
     mnk::DevBuf<int> dag_flags;   // [queue counter | front: Np/64 | af: 4 * Np/128], zeroed per factorization
@@ -151,8 +153,11 @@ int64_t mnk_ls_effective_nbo(const mnk_ls* ls);
 int mnk_ls_run_factorization(mnk_ls* ls);
 int mnk_ls_run_factorization_now(mnk_ls* ls);      // factor.hip: the launch part (the schedule has been chosen; batches call it for leftovers)
 int mnk_ls_launch_finish_info(mnk_ls* ls, hipStream_t s);   // factor.hip: inertia / growth words / info -> pinned host words
+bool mnk_solve_defer(mnk_ls* ls, double* xuser);   // solve.hip: true if the calling thread has a solve batch open and queued this solve
+int mnk_solve_sync_deferred(mnk_ls* ls);           // solve.hip: runs the queued solves if one of them belongs to this solver
 bool mnk_batch_defer(mnk_ls* ls);                  // dag.hip: true if the calling thread has a batch open and took the factorization into it
-int mnk_ls_sync_deferred(mnk_ls* ls);              // dag.hip: launches the open batch if this solver's factorization is pending in it
+int mnk_ls_sync_deferred(mnk_ls* ls);              // dag.hip: runs what the open batches of this thread hold for this solver (queued solves, a pending factorization)
+int mnk_ls_sync_deferred_fact(mnk_ls* ls);         // dag.hip: ... the pending factorization only
 int mnk_ls_prefill_spare(mnk_ls* ls);   // ls.hip: queue the background zero-fill of the spare factor buffer (if one is due)
 int mnk_ls_fetch_info(mnk_ls* ls);
 int mnk_ls_run_factorization_dag(mnk_ls* ls);   // dag.hip: the task-DAG schedule (panel_algo = 5)

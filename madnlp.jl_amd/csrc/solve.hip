@@ -385,8 +385,9 @@ constexpr int PS_NT = 1024;          // threads per workgroup: a 64 x 256 slice 
 constexpr int PS_NQ = PS_NT / 64;    // 16-column chunks of a step (forward) / waves (backward)
 constexpr int PS_CW = 256 / PS_NQ;   // columns per chunk
 
+// (the body of one system's solve: workgroup g of the G that share the system; the kernels below wrap it)
 template <bool LDL>
-__global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
+__device__ __forceinline__ void persistent_solve_body(
     const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv, const double* __restrict__ InvT,
     const double* __restrict__ dinv, const double* xin /* N: right-hand side (rows N..Np-1 are zero) */,
     double* xout /* N: solution (may alias xin) */, int64_t N,
@@ -394,14 +395,13 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     double* __restrict__ pub_other /* the buffer of the NEXT solve: this launch fills it with the sentinel (or NULL) */,
     int64_t Np, int* abort_flag,
     const int* __restrict__ info, unsigned long long* __restrict__ trace /* optional: 8 stamps per block */,
-    int near_steps, int nap, long spin_limit, int missing_wg) {
+    int near_steps, int nap, long spin_limit, int missing_wg, const int G, const int g) {
 #define PS_STAMP(blk, slot) do { if (trace != nullptr && t == 0) trace[(int64_t)(blk) * 8 + (slot)] = wall_clock64(); } while (0)
     __shared__ double run[PS_MAXOWN][64];   // running rhs of the owned blocks (forward: b, backward: z)
     __shared__ double ysol[PS_MAXOWN][64];  // forward solution of the owned blocks
     __shared__ double xs[256];              // the step's published vector
     __shared__ double part[PS_NQ][64];      // partial sums
     const int t = threadIdx.x, r = t & 63, q = t >> 6;
-    const int G = gridDim.x, g = blockIdx.x;
     const int nb = (int)(Np / 64);
     const int nsteps = (nb + 3) / 4;
     const int nown = g < nb ? (nb - g + G - 1) / G : 0;
@@ -626,6 +626,48 @@ __global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
     }
 #undef PS_STAMP
 }
+
+template <bool LDL>
+__global__ __launch_bounds__(PS_NT) void persistent_solve_kernel(
+    const double* __restrict__ F, int64_t ld, const double* __restrict__ Inv, const double* __restrict__ InvT,
+    const double* __restrict__ dinv, const double* xin, double* xout, int64_t N, double* __restrict__ pub,
+    double* __restrict__ pub_other, int64_t Np, int* abort_flag, const int* __restrict__ info,
+    unsigned long long* __restrict__ trace, int near_steps, int nap, long spin_limit, int missing_wg) {
+    persistent_solve_body<LDL>(F, ld, Inv, InvT, dinv, xin, xout, N, pub, pub_other, Np, abort_flag, info, trace, near_steps, nap,
+                               spin_limit, missing_wg, (int)gridDim.x, (int)blockIdx.x);
+}
+
+// Several INDEPENDENT systems of the same order in one launch (mnk_solve_batch_begin / _end; scenario batches): workgroups
+// [G i, G (i + 1)) work on system i exactly as the G workgroups of a single launch would (every workgroup of the launch must
+// be resident: Q G <= number of CUs).  One solve is bound by its chain of hops, not by HBM (0.45 ms for 1 GB at N = 11 192,
+// 2.2 TB/s): four of them side by side share the chip's bandwidth and the launch takes hardly longer than one.  Same
+// arithmetic per system as a lone solve with G workgroups (the block -> workgroup map only decides who computes what).
+struct PsSys {
+    const double* F;
+    int64_t ld;
+    const double* Inv;
+    const double* InvT;
+    const double* dinv;
+    const double* xin;
+    double* xout;
+    int64_t N;
+    double* pub;
+    double* pub_other;
+    int* abort_flag;
+    const int* info;
+};
+typedef const PsSys __attribute__((address_space(4))) * PsSysP;
+
+template <bool LDL>
+__global__ __launch_bounds__(PS_NT) void persistent_solve_multi_kernel(const PsSys* __restrict__ sys, int G, int64_t Np, int near_steps,
+                                                                      int nap, long spin_limit) {
+    const int isys = (int)blockIdx.x / G, g = (int)blockIdx.x % G;
+    const PsSysP y = (PsSysP)(uintptr_t)(sys + isys);
+    persistent_solve_body<LDL>(y->F, y->ld, y->Inv, y->InvT, y->dinv, y->xin, y->xout, y->N, y->pub, y->pub_other, Np, y->abort_flag,
+                               y->info, nullptr, near_steps, nap, spin_limit, -1, G, g);
+}
+
+__global__ void ps_set_sys_kernel(PsSys rec, PsSys* __restrict__ dst) { *dst = rec; }
 
 
 // ================================================================================================
@@ -941,6 +983,22 @@ int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
     return 0;
 }
 
+// First launch of linv256_mfma_kernel on a stream (it returns at once: `info` != 0).  The kernel spills a few registers,
+// so the stream's hardware queue needs scratch memory for it, and the runtime's first allocation of that takes ~1.6 ms
+// (seen in the kernel trace of the first factorize! behind a batch: two such gaps, +0.64 ms on a five-call average).
+int mnk_solve_warmup(hipStream_t s) {
+    static mnk::DevBuf<int> one;   // (process lifetime; holds 1)
+    if (!one.p) {
+        if (one.alloc(1)) return -2;
+        const int v = 1;
+        MNK_HIP(hipMemcpy(one.p, &v, sizeof(int), hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(linv256_mfma_kernel, dim3(1, 4), dim3(256), 0, s, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
+                       (double*)nullptr, (double*)nullptr, (int64_t)256, one.p, 0);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 // xdev: the solver's work vector (10*Np doubles: x | y | two publication buffers of 4*Np).
 // xuser == NULL: on entry xdev[0:Np] = rhs (zero padded); on exit xdev[0:Np] = solution.
 // xuser != NULL: a device vector of N entries, rhs on entry, solution on exit; the one-launch solve reads and writes it
@@ -1065,4 +1123,137 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev, double* xuser) {
         if (rc) return rc;
     }
     return stage_out();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batches of independent solves (mnk_solve_batch_begin / _end): between the two calls the single-right-hand-side solves of
+// the calling thread on DEVICE vectors are queued; `end` runs them up to four systems per launch
+// (persistent_solve_multi_kernel).  Systems of one launch belong to different solvers (a solver's second right-hand side goes
+// into the next launch: its publication buffers are in use); solves that do not qualify (host vectors, several right-hand
+// sides, the pivoted tier, the stepwise solve) run at once as usual.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct SolveReq { mnk_ls* ls; double* x; };
+struct SolveBatchState { int depth = 0; bool active = false; std::vector<SolveReq> pend; };
+thread_local SolveBatchState t_sbatch;
+struct SolveBatchBuffers { mnk::DevBuf<char> sys; hipEvent_t ev = nullptr; };
+SolveBatchBuffers g_sbatch[64];
+constexpr int PS_BATCH_MAXQ = 8;
+}  // namespace
+
+static bool solve_eligible(const mnk_ls* ls) {
+    const int64_t nb64 = ls->Np / 64;
+    const int G = (int)std::min<int64_t>(nb64, ls->ctx->num_cu);
+    return !ls->bk_active && ls->persistent_solve && !(ls->solve512 && ls->linv512.p) && !ls->ctx->partitioned &&
+           (nb64 + G - 1) / G <= PS_MAXOWN && (G >= 4 || nb64 <= G) && !(ls->solve_abort && *ls->solve_abort != 0) &&
+           ls->debug_ps_missing < 0 && !ls->solve_trace.p;
+}
+
+bool mnk_solve_defer(mnk_ls* ls, double* xuser) {
+    if (!t_sbatch.active || !solve_eligible(ls)) return false;
+    if (!ls->ev_defer && hipEventCreateWithFlags(&ls->ev_defer, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventRecord(ls->ev_defer, ls->ctx->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
+    t_sbatch.pend.push_back({ls, xuser});
+    return true;
+}
+
+// one launch: systems v[0..q) (distinct solvers of one device, order and algorithm)
+static int solve_batch_launch(const std::vector<SolveReq>& v) {
+    const int q = (int)v.size();
+    mnk_ls* l0 = v[0].ls;
+    mnk_ctx* c0 = l0->ctx;
+    hipStream_t h = c0->stream;
+    MNK_HIP(hipSetDevice(c0->device));
+    const int64_t Np = l0->Np, nb64 = Np / 64;
+    const int G = (int)std::min<int64_t>(nb64, c0->num_cu / q);
+    SolveBatchBuffers& B = g_sbatch[c0->device & 63];
+    for (const SolveReq& r : v)
+        if (r.ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(h, r.ls->ev_defer, 0));
+    int rc = mnk_persist_begin(c0, h);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        if (B.sys.n < sizeof(PsSys) * PS_BATCH_MAXQ && B.sys.alloc(sizeof(PsSys) * PS_BATCH_MAXQ)) return -2;
+        if (!B.ev) MNK_HIP(hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
+        PsSys* dsys = reinterpret_cast<PsSys*>(B.sys.p);
+        for (int i = 0; i < q; ++i) {
+            mnk_ls* ls = v[i].ls;
+            double* pubs[2] = {ls->xwork.p + 2 * Np, ls->xwork.p + 6 * Np};
+            const int cur = ls->pub_next, oth = cur ^ 1;
+            if (!ls->pub_clean[cur])
+                hipLaunchKernelGGL(ps_reset_kernel, dim3((unsigned)((4 * Np + 255) / 256)), dim3(256), 0, h,
+                                   reinterpret_cast<unsigned long long*>(pubs[cur]), 4 * Np);
+            PsSys rec{ls->fact.p, ls->ld, ls->linv256.p, ls->linv256t.p, ls->dinv.p, v[i].x, v[i].x, ls->N, pubs[cur], pubs[oth],
+                      ls->solve_abort, ls->info_dev.p};
+            hipLaunchKernelGGL(ps_set_sys_kernel, dim3(1), dim3(1), 0, h, rec, dsys + i);
+            ls->pub_clean[cur] = false;
+            ls->pub_clean[oth] = true;
+            ls->pub_next = oth;
+        }
+        const bool ldl = l0->algo == MNK_LDL;
+        if (ldl)
+            hipLaunchKernelGGL(persistent_solve_multi_kernel<true>, dim3((unsigned)(q * G)), dim3(PS_NT), 0, h, dsys, G, Np, PS_NEAR, 6, l0->ps_spin_limit);
+        else
+            hipLaunchKernelGGL(persistent_solve_multi_kernel<false>, dim3((unsigned)(q * G)), dim3(PS_NT), 0, h, dsys, G, Np, PS_NEAR, 6, l0->ps_spin_limit);
+        MNK_HIP(hipGetLastError());
+        return 0;
+    };
+    rc = body();
+    rc = mnk_persist_end(c0, h, rc);
+    if (rc) return rc;
+    bool other = false;
+    for (const SolveReq& r : v) other = other || r.ls->ctx->stream != h;
+    if (other) {
+        MNK_HIP(hipEventRecord(B.ev, h));
+        for (const SolveReq& r : v)
+            if (r.ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(r.ls->ctx->stream, B.ev, 0));
+    }
+    return 0;
+}
+
+static int solve_batch_flush() {
+    std::vector<SolveReq> pend;
+    pend.swap(t_sbatch.pend);
+    static const int maxq = []() { const char* e = getenv("MNK_SOLVE_BATCH_Q"); const int v = e ? atoi(e) : 4; return std::max(1, std::min(PS_BATCH_MAXQ, v)); }();
+    int rc_all = 0;
+    while (!pend.empty()) {
+        mnk_ls* l0 = pend.front().ls;
+        const int64_t nb64 = l0->Np / 64;
+        std::vector<SolveReq> g, rest;
+        for (const SolveReq& r : pend) {
+            bool take = (int)g.size() < maxq && r.ls->ctx->device == l0->ctx->device && r.ls->Np == l0->Np && r.ls->algo == l0->algo;
+            for (const SolveReq& t : g) take = take && t.ls != r.ls;      // (one right-hand side per solver and launch)
+            for (const SolveReq& t : rest) take = take && t.ls != r.ls;   // (and a solver's right-hand sides keep their order)
+            if (take) {   // all workgroups of the launch resident, at most PS_MAXOWN blocks each
+                const int Gq = (int)std::min<int64_t>(nb64, l0->ctx->num_cu / ((int)g.size() + 1));
+                take = Gq >= 4 && (nb64 + Gq - 1) / Gq <= PS_MAXOWN;
+            }
+            (take ? g : rest).push_back(r);
+        }
+        pend.swap(rest);
+        int rc;
+        if (g.size() >= 2) rc = solve_batch_launch(g);
+        else rc = mnk_ls_run_solve(g[0].ls, g[0].ls->xwork.p, g[0].x);
+        if (rc && !rc_all) rc_all = rc;
+    }
+    return rc_all;
+}
+
+extern "C" int mnk_solve_batch_begin(void) {
+    ++t_sbatch.depth;
+    t_sbatch.active = true;
+    return 0;
+}
+
+extern "C" int mnk_solve_batch_end(void) {
+    if (t_sbatch.depth <= 0) { mnk::set_error("mnk_solve_batch_end: no batch is open on this thread"); return -1; }
+    if (--t_sbatch.depth > 0) return 0;
+    t_sbatch.active = false;
+    return solve_batch_flush();
+}
+
+// (a solver that is destroyed, factorized again or asked for a non-batchable solve while one of its solves is queued)
+int mnk_solve_sync_deferred(mnk_ls* ls) {
+    for (const SolveReq& r : t_sbatch.pend)
+        if (r.ls == ls) return solve_batch_flush();
+    return 0;
 }

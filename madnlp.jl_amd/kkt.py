@@ -659,3 +659,50 @@ class DenseCondensedKKTSystem(_DenseBase):
         ws[:] = (ws + full[self.ind_ineq_shifted]) / Ss
         self._finish_aug_solve(w)
         return w
+
+
+class ScenarioBatch:
+    """n independent sparse condensed KKT systems driven together (BASELINE config C5: scenario batches on one GPU): one
+    library call per phase of an interior-point iteration instead of four to six per instance (`mnk_sc_step_batch`,
+    `mnk_ls_inertia_batch`, `mnk_ls_solve_batch`).  The factorizations of a step run as ONE batch (merged persistent launch),
+    the solves up to four systems per launch.  All value arguments are device tensors; the pointer tables are built once per
+    set of tensors (`bind`)."""
+
+    def __init__(self, kkts):
+        import ctypes as C
+        self.kkts = list(kkts)
+        n = self.n = len(self.kkts)
+        self._sc = (C.c_void_p * n)(*[k._h.value for k in self.kkts])
+        self._ls = (C.c_void_p * n)(*[k.linear_solver._h.value for k in self.kkts])
+        self._pos, self._zero, self._neg = (C.c_int64 * n)(), (C.c_int64 * n)(), (C.c_int64 * n)()
+        self._tabs = {}
+
+    @staticmethod
+    def _table(tensors):
+        import ctypes as C
+        return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def bind(self, jacs, hesss, prs, dus):
+        """Device tensors of the COO Jacobian / Hessian values and of pr_diag / du_diag of every instance (kept by reference:
+        the tensors must stay alive and in place)."""
+        self._keep = (list(jacs), list(hesss), list(prs), list(dus))
+        self._tabs["step"] = tuple(self._table(t) for t in self._keep)
+
+    def step(self):
+        """compress_jacobian! + compress_hessian! + build_kkt! + factorize! of every instance; asynchronous."""
+        j, h, p, d = self._tabs["step"]
+        L.check(L.lib().mnk_sc_step_batch(self.n, self._sc, self._ls, j, h, p, d, L.MNK_DEVICE), "mnk_sc_step_batch")
+        for k in self.kkts:
+            k._host_jt = k._host_h = k._diag_buffer = None
+
+    def inertia(self):
+        L.check(L.lib().mnk_ls_inertia_batch(self.n, self._ls, self._pos, self._zero, self._neg), "mnk_ls_inertia_batch")
+        return [(self._pos[i], self._zero[i], self._neg[i]) for i in range(self.n)]
+
+    def solve(self, xs):
+        """One right-hand side per instance (device tensors, in place); asynchronous."""
+        key = tuple(x.data_ptr() for x in xs)
+        tab = self._tabs.get(key)
+        if tab is None:
+            tab = self._tabs[key] = self._table(xs)
+        L.check(L.lib().mnk_ls_solve_batch(self.n, self._ls, tab, L.MNK_DEVICE), "mnk_ls_solve_batch")

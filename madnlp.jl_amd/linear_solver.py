@@ -113,6 +113,22 @@ class factorize_batch:
         return False
 
 
+class solve_batch:
+    """`with solve_batch(): ...` -- the single-right-hand-side solves of this thread on DEVICE vectors inside the block are queued
+    and run together when the block is left, up to four independent systems per launch (`mnk_solve_batch_begin / _end`).
+    The vectors hold the solutions after the block (asynchronously: `check_solve` as usual)."""
+
+    def __enter__(self):
+        L.check(L.lib().mnk_solve_batch_begin(), "mnk_solve_batch_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = L.lib().mnk_solve_batch_end()
+        if rc and et is None:
+            raise SolveException(L.lib().mnk_last_error_string().decode())
+        return False
+
+
 def _ptr(a):
     """Raw pointer + location of a numpy array (host) or a torch tensor (host/device)."""
     if a is None:

@@ -212,3 +212,147 @@ def test_batch_with_mixed_orders_and_a_forgotten_end():
             assert kh.linear_solver.get_stat("panel_algo") == 5.0 and kh.linear_solver.get_stat("pp_fallbacks") == 0.0
         kh.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("nctx", [1, 2])
+def test_batched_solves_are_bit_identical_to_lone_ones(nctx):
+    """mnk_solve_batch_begin / _end: the single-right-hand-side solves of a block on device vectors are queued and run up to
+    four independent systems per launch (one solve is bound by its chain of hops, not by HBM).  Six case1354pegase-shaped
+    instances (launches of four and two) plus a SECOND right-hand side of the first instance inside the same block (it must
+    come after the first one, in a later launch), on one context and on two: every solution's bits equal those of a lone
+    solve of the same system (the block -> workgroup map only decides who computes what), backward error <= 1e-13."""
+    dev = torch.device("cuda", 0)
+    base = OPF_CASES["case1354pegase"][0]
+    streams = [torch.cuda.Stream(dev) for _ in range(nctx)]
+    ctxs = [mj.HipContext(0, stream=s.cuda_stream) for s in streams]
+    insts = _make_instances([("case1354pegase", base + 200 + i) for i in range(6)], ctxs, streams, dev)
+    torch.cuda.synchronize()
+    lone = []
+    for (P, kh, st, din) in insts:
+        _front(kh, st, din)
+        with torch.cuda.stream(st):
+            assert kh.linear_solver.inertia() == (P.n, 0, 0)
+            din["x"].copy_(din["rhs"])
+            kh.linear_solver.solve_linear_system(din["x"])
+            kh.linear_solver.check_solve()
+            lone.append(din["x"].clone())
+    torch.cuda.synchronize()
+    rhs2 = insts[0][3]["rhs"] * 3.0 + 1.0
+    x2_ref = rhs2.clone()
+    with torch.cuda.stream(insts[0][2]):
+        insts[0][1].linear_solver.solve_linear_system(x2_ref)
+        insts[0][1].linear_solver.check_solve()
+    x2 = rhs2.clone()
+    torch.cuda.synchronize()
+    for rnd in range(3):          # (the publication buffers of every solver alternate from solve to solve)
+        for (_, kh, st, din) in insts:
+            with torch.cuda.stream(st):
+                din["x"].copy_(din["rhs"])
+        x2.copy_(rhs2)
+        torch.cuda.synchronize()
+        with mj.solve_batch():
+            for (_, kh, st, din) in insts:
+                with torch.cuda.stream(st):
+                    kh.linear_solver.solve_linear_system(din["x"])
+            with torch.cuda.stream(insts[0][2]):
+                insts[0][1].linear_solver.solve_linear_system(x2)
+        for (_, kh, st, din) in insts:
+            kh.linear_solver.check_solve()
+        torch.cuda.synchronize()
+        for i, (P, kh, st, din) in enumerate(insts):
+            assert torch.equal(din["x"], lone[i]), (rnd, i)
+        assert torch.equal(x2, x2_ref), rnd
+    for (P, kh, st, din) in insts:
+        ko = _oracle_sc(P)
+        assert _bwd(_full(ko), din["x"].cpu().numpy(), din["rhs"].cpu().numpy()) <= 1e-13
+        kh.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_batched_solves_of_small_and_mixed_systems():
+    """Orders that leave fewer 64-row blocks than a launch's share of the CUs, two different orders in one block (two groups),
+    a host-vector solve inside the block (not queued: runs at once, after the queued solves of its solver)."""
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
+    g = torch.Generator(device=dev).manual_seed(5)
+    sols, mats, refs, rhs = [], [], [], []
+    for N in (3001, 3001, 3001, 1700, 1700):
+        R = torch.randn(N, 40, dtype=torch.float64, device=dev, generator=g)
+        A = R @ R.T
+        A.diagonal().add_(float(N))
+        n1 = 2 * N // 3
+        A[n1:, n1:].neg_()
+        mats.append(A)
+        rhs.append(torch.randn(N, dtype=torch.float64, device=dev, generator=g))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        for A, b in zip(mats, rhs):
+            M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
+            M.factorize()
+            x = b.clone()
+            M.solve_linear_system(x)
+            M.check_solve()
+            sols.append(M)
+            refs.append(x.clone())
+        xs = [b.clone() for b in rhs]
+        st.synchronize()
+        with mj.solve_batch():
+            for M, x in zip(sols, xs):
+                M.solve_linear_system(x)
+            xh = sols[1].solve_linear_system(rhs[1].cpu().numpy().copy())     # host vector: at once, behind solver 1's queued solve
+        for M in sols:
+            M.check_solve()
+        st.synchronize()
+        for x, r in zip(xs, refs):
+            assert torch.equal(x, r)
+        assert np.array_equal(xh, refs[1].cpu().numpy())
+        for M in sols:
+            M.close()
+    ctx.close()
+
+
+def test_scenario_batch_array_entry_points_match_the_per_instance_calls():
+    """`ScenarioBatch` (mnk_sc_step_batch / mnk_ls_inertia_batch / mnk_ls_solve_batch): one library call per phase of an
+    iteration for n independent instances.  Five case1354pegase-shaped scenarios, two rounds: the condensed matrix of every
+    instance bit-exact vs the oracle, inertia, the solution's bits equal those of the per-instance calls on the same solver,
+    backward error <= 1e-13."""
+    dev = torch.device("cuda", 0)
+    base = OPF_CASES["case1354pegase"][0]
+    st = torch.cuda.Stream(dev)
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
+    insts = _make_instances([("case1354pegase", base + 300 + i) for i in range(5)], [ctx], [st], dev)
+    torch.cuda.synchronize()
+    ref = []
+    for (P, kh, s_, din) in insts:
+        _front(kh, s_, din)
+        with torch.cuda.stream(s_):
+            assert kh.linear_solver.inertia() == (P.n, 0, 0)
+            din["x"].copy_(din["rhs"])
+            kh.linear_solver.solve_linear_system(din["x"])
+            kh.linear_solver.check_solve()
+            ref.append(din["x"].clone())
+    sb = mj.ScenarioBatch([it[1] for it in insts])
+    sb.bind([it[3]["jac"] for it in insts], [it[3]["hess"] for it in insts], [it[3]["pr"] for it in insts],
+            [it[3]["du"] for it in insts])
+    xs = [it[3]["x"] for it in insts]
+    for rnd in range(2):
+        sb.step()
+        assert sb.inertia() == [(P.n, 0, 0) for (P, *_r) in insts]
+        with torch.cuda.stream(st):
+            torch._foreach_copy_(xs, [it[3]["rhs"] for it in insts])
+        st.synchronize()
+        sb.solve(xs)
+        for (_, kh, _, _) in insts:
+            kh.linear_solver.check_solve()
+            assert kh.linear_solver.get_stat("panel_algo") == 5.0 and kh.linear_solver.get_stat("pp_fallbacks") == 0.0
+        torch.cuda.synchronize()
+        for x, r in zip(xs, ref):
+            assert torch.equal(x, r), rnd
+    for (P, kh, s_, din) in insts:
+        ko = _oracle_sc(P)
+        np.testing.assert_array_equal(kh.aug_com.nzval, ko.aug_com.nzval)
+        assert _bwd(_full(ko), din["x"].cpu().numpy(), din["rhs"].cpu().numpy()) <= 1e-13
+        kh.close()
+    ctx.close()

@@ -18,6 +18,8 @@ JL_CLASS = {
 
 
 def c_class(decl: str) -> str:
+    if re.search(r"\*\s*const\s*\*", decl):   # `T* const* name`: a table of pointers / handles (the batch entry points)
+        return "ptr_table"
     d = re.sub(r"\bconst\b", "", decl).strip()
     d = re.sub(r"\s+", " ", d)
     # drop the parameter name
@@ -27,7 +29,9 @@ def c_class(decl: str) -> str:
         "int": "int", "int64_t": "int64", "double": "double", "char*": "cstr", "void*": "handle",
         "double*": "double*", "int32_t*": "int32*", "int64_t*": "int64*", "int*": "int*",
         "unsignedlonglong*": "uint64*",
+        "double**": "ptr_table", "double*const*": "ptr_table",   # (arrays of pointers: the batch entry points)
     }
+ 
     if re.match(r"^mnk_(ctx|sc|dc|ls|schur|ipm|opf)\*\*$", t):
         return "handle_out"
     if re.match(r"^mnk_(ctx|sc|dc|ls|schur|ipm|opf)\*$", t):
