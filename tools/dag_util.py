@@ -28,6 +28,7 @@ with torch.cuda.stream(s):
     ls.set_option("dag_band", band)
     ls.set_option("dag_taper0", taper0)
     ls.factorize(); s.synchronize()
+    ls.set_option("dag_fill", 0)   # (the trace is indexed by task: the list without the zero-fill tasks is the one tools/dag_tasks.py mirrors)
     ls.set_option("dag_trace", 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s); ls.factorize(); e1.record(s); s.synchronize()
