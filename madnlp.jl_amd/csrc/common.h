@@ -156,6 +156,7 @@ struct mnk_ctx {
     int children = 0;
     bool released = false;
 };
+int mnk_masked_stream_pair(mnk_ctx* ctx, int chain_cus, hipStream_t* sp, hipStream_t* su);   // ls.hip
 int mnk_solve_warmup(hipStream_t s);               // solve.hip: first (no-op) launch of the inverse kernel that needs scratch
 int mnk_dag_warmup(hipStream_t* streams, int n);   // dag.hip: first (empty) launch of the bulk kernels on these streams
 int mnk_live_contexts(int device);  // contexts alive on this device in this process

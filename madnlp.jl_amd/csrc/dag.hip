@@ -887,6 +887,7 @@ int mnk_ls_dag_prepare(mnk_ls* ls) {
         ls->dag_ntasks1 = mnk::dag_build_tasks(ntile, ls->dag_chunk, ls->dag_band / 2, ls->dag_js2, h, ls->dag_taper0, &ls->dag_host_ready);
         // zero-fill of the next factorization's buffer as tasks of the queue (sparse sources; see dag_fill_tile)
         ls->dag_has_fill = ls->dag_fill && ls->prefill && Np <= ls->prefill_max_rows;
+        if (ls->dag_has_fill && h.empty()) ls->dag_has_fill = false;   // (a system of a few hundred rows has no bulk task: nothing to ride on)
         if (ls->dag_has_fill) ls->dag_ntasks1 = mnk::dag_add_fill_tasks(ntile, h, ls->dag_host_ready, ls->dag_ntasks1);
         ls->dag_ntasks = (int)(h.size() / 4);
         if (ls->dag_tasks.alloc(h.size() + 4)) return give_up();
@@ -957,6 +958,8 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         // (the chain first: its first diagonal block is the start of the critical path, the bulk kernel has nothing to do before it)
         int rc = mnk_launch_pchain(ls, sp, dag, js_begin, js_end, strips);
         if (rc) return rc;
+        // (more than three workgroups per CU -- to fill slots a shader-engine-imbalanced mask might leave empty -- measured
+        // no difference: 4 / 5 / 6 per CU 9.63-9.67 vs 9.64-9.68 ms)
         rc = mnk::launch_dag_bulk(su, ldl, inst, nullptr, ls->dag_tasks.p + 4 * (size_t)task0, ntask, ntile, counter, spin_limit,
                                   std::min(ntask, 3 * bulk_cus), trace ? trace + 8 * (size_t)task0 : nullptr,
                                   trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
@@ -1026,7 +1029,7 @@ thread_local BatchState t_batch;
 struct BatchBuffers {   // per device, reused from batch to batch (guarded by the arbiter's mutex while in use)
     mnk::DevBuf<int> tasks;
     mnk::DevBuf<int> qctr;
-    mnk::DevBuf<char> insts;
+    mnk::DevBuf<char> insts, pcsys;
     int ntile = 0, ninst = 0, period = 0, chunk = 0, taper0 = 0, band = 0, ntasks = 0;
     bool fill = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1034,11 +1037,14 @@ struct BatchBuffers {   // per device, reused from batch to batch (guarded by th
 BatchBuffers g_batch[64];
 }  // namespace
 
+bool mnk_batch_active() { return t_batch.active; }
+
 bool mnk_batch_defer(mnk_ls* ls) {
     if (!t_batch.active) return false;
     const int nsc = (int)((ls->Np + 255) / 256);
-    // (the merged launch serves the large-system mode of the schedule; anything else is simply run now)
-    if (ls->algo_now != 5 || ls->dag_js2 != nsc || ls->dag_trace_on || ls->ctx->partitioned || !ls->ctx->sp_dagB) return false;
+    // (two merged launches: the large-system mode of the schedule -- band + bulk + two alternating chains -- and the small
+    // one, every row in the chain's band, many chains side by side; a second phase in mid-factorization is simply run now)
+    if (ls->algo_now != 5 || (ls->dag_js2 != nsc && ls->dag_js2 != 0) || ls->dag_trace_on || ls->ctx->partitioned || !ls->ctx->sp_dagB) return false;
     if (!ls->ev_defer && hipEventCreateWithFlags(&ls->ev_defer, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipEventRecord(ls->ev_defer, ls->ctx->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
     ls->deferred = true;
@@ -1151,6 +1157,128 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
     return 0;
 }
 
+// Small systems (every row a strip of the chain, dag_js2 == 0): rounds of K systems whose chains run SIDE BY SIDE in one
+// launch (factor.hip: pchain_multi_kernel) on K * strips CUs, the band tiles of all of them accumulated by one bulk
+// launch on the other CUs (systems of up to 768 rows have no bulk task at all).  A system this small is bound by its own
+// pivot chain from the first column on -- 0.9 ms for N = 2048 on the whole chip, of which it uses 32 CUs.
+static int batch_run_group_small(std::vector<mnk_ls*>& g) {
+    mnk_ls* l0 = g[0];
+    mnk_ctx* c0 = l0->ctx;
+    hipStream_t h = c0->stream;
+    MNK_HIP(hipSetDevice(c0->device));
+    const int64_t Np = l0->Np;
+    const bool ldl = l0->algo == MNK_LDL;
+    const int ntile = (int)(Np / 128), nsc = (int)((Np + 255) / 256), strips = (int)(Np / NBI);
+    const size_t nflags = (size_t)2 + (size_t)(Np / NBI) + 2 * (size_t)ntile * ntile;
+    const int ntasks1 = l0->dag_ntasks;   // (single phase: all tasks)
+    const int bulk_min = ntasks1 > 0 ? std::max(32, c0->num_cu / 4) : 0;
+    // The chains' CU partition is a multiple of 32 CUs: every workgroup of the chain launch must be RESIDENT (one per CU), and
+    // the dispatcher places them all only when the mask gives every shader engine of every XCD the same number of CUs --
+    // 8 XCDs x 4 SEs = 32 (tools/hip/mask_resident.hip: masks of 32 / 64 / 96 / 192 / 256 bits hold as many 96-KB workgroups
+    // as they have bits; 40, 48, 56, 72, 104, 176 do not, e.g. 34 workgroups on a 40-bit mask: 32 resident -- five 34-strip
+    // systems on 176 CUs stalled into the schedule's time-out).
+    auto chain_cus_for = [&](int k) { return std::min(c0->num_cu, (k * strips + 31) / 32 * 32); };
+    int kmax = std::min(32, (c0->num_cu - bulk_min) / strips);
+    while (kmax > 1 && chain_cus_for(kmax) > c0->num_cu - bulk_min) --kmax;
+    if (kmax < 2) {   // (no room for two chains: one after the other, as without a batch)
+        for (mnk_ls* ls : g) {
+            ls->deferred = false;
+            int rc = mnk_ls_run_factorization_now(ls);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    for (mnk_ls* ls : g)
+        if (ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(h, ls->ev_defer, 0));
+    BatchBuffers& B = g_batch[c0->device & 63];
+    for (size_t r0 = 0; r0 < g.size(); r0 += (size_t)kmax) {
+        const int k = (int)std::min<size_t>(kmax, g.size() - r0);
+        hipStream_t sp = nullptr, su = nullptr;
+        int rc = mnk_masked_stream_pair(c0, chain_cus_for(k), &sp, &su);
+        if (rc) return rc;
+        if (ntasks1 > 0 && su == nullptr) { set_error("factorize batch: no CUs left for the bulk kernel"); return -1; }
+        rc = mnk_persist_begin(c0, h);
+        if (rc) return rc;
+        auto body = [&]() -> int {
+            if (ntasks1 > 0 && (B.ntile != ntile || B.ninst != k || B.period != 0 || B.chunk != l0->dag_chunk || B.taper0 != l0->dag_taper0 ||
+                                B.band != l0->dag_band || B.fill != l0->dag_has_fill || !B.tasks.p)) {
+                std::vector<int> merged;
+                mnk::dag_merge_tasks(l0->dag_host_tasks, l0->dag_host_ready, k, 0, merged);
+                if (B.tasks.alloc(merged.size() + 4)) return -2;
+                MNK_HIP(hipMemcpy(B.tasks.p, merged.data(), merged.size() * sizeof(int), hipMemcpyHostToDevice));
+                B.ntile = ntile; B.ninst = k; B.period = 0; B.chunk = l0->dag_chunk; B.taper0 = l0->dag_taper0;
+                B.band = l0->dag_band; B.fill = l0->dag_has_fill; B.ntasks = (int)(merged.size() / 4);
+            }
+            if (!B.qctr.p && B.qctr.alloc(4)) return -2;
+            if (B.insts.n < sizeof(mnk::DagInst) * (size_t)k && B.insts.alloc(sizeof(mnk::DagInst) * (size_t)std::max(k, 32))) return -2;
+            if (B.pcsys.n < mnk_pchain_sys_bytes() * (size_t)k && B.pcsys.alloc(mnk_pchain_sys_bytes() * (size_t)std::max(k, 32))) return -2;
+            for (hipEvent_t& e : B.ev)
+                if (!e) MNK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            std::vector<mnk::DagInst> hin;
+            std::vector<int*> fronts;
+            std::vector<const int*> afs;
+            mnk::DagInst* insts_dev = reinterpret_cast<mnk::DagInst*>(B.insts.p);
+            for (int i = 0; i < k; ++i) {
+                mnk_ls* ls = g[r0 + i];
+                hin.push_back(dag_instance(ls));
+                ls->dag_filled = hin.back().zfill != nullptr;
+                fronts.push_back(hin.back().front);
+                afs.push_back(hin.back().af);
+                hipLaunchKernelGGL(mnk::dag_reset_kernel, dim3((unsigned)std::min<size_t>((nflags + 1023) / 1024, 64)), dim3(256), 0, h,
+                                   ls->dag_flags.p, (int64_t)nflags, ls->info_dev.p, hin.back(), insts_dev + i);
+            }
+            MNK_HIP(hipMemsetAsync(B.qctr.p, 0, 4 * sizeof(int), h));
+            MNK_HIP(hipEventRecord(B.ev[0], h));
+            MNK_HIP(hipStreamWaitEvent(sp, B.ev[0], 0));
+            if (su != nullptr) MNK_HIP(hipStreamWaitEvent(su, B.ev[0], 0));
+            // (the records of the chains' table are written on the home stream before the fork)
+            int r = mnk_launch_pchain_multi(g.data() + r0, k, sp, sp, B.pcsys.p, fronts.data(), afs.data());
+            if (r) return r;
+            if (ntasks1 > 0) {
+                const int bulk_cus = c0->num_cu - chain_cus_for(k);
+                r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p, l0->dag_spin_limit,
+                                         std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
+                if (r) return r;
+                MNK_HIP(hipEventRecord(B.ev[2], su));
+                MNK_HIP(hipStreamWaitEvent(h, B.ev[2], 0));
+            }
+            MNK_HIP(hipEventRecord(B.ev[1], sp));
+            MNK_HIP(hipStreamWaitEvent(h, B.ev[1], 0));
+            if (su != nullptr) MNK_HIP(hipStreamWaitEvent(su, B.ev[1], 0));   // (all chains done: every system's factor is final)
+            if (su != nullptr) MNK_HIP(hipStreamWaitEvent(sp, B.ev[2], 0));
+            // inverses for the solves, inertia / info words: small latency-bound kernels, spread over the three streams
+            hipStream_t inv_s[3] = {h, sp, su != nullptr ? su : sp};
+            for (int i = 0; i < k; ++i) {
+                mnk_ls* ls = g[r0 + i];
+                hipStream_t si = inv_s[i % 3];
+                r = mnk_ls_invert_blocks(ls, si, 0, nsc);
+                if (r) return r;
+                ls->inv_done = nsc;
+                r = mnk_ls_launch_finish_info(ls, si);
+                if (r) return r;
+            }
+            MNK_HIP(hipEventRecord(B.ev[1], sp));
+            MNK_HIP(hipStreamWaitEvent(h, B.ev[1], 0));
+            if (su != nullptr) {
+                MNK_HIP(hipEventRecord(B.ev[2], su));
+                MNK_HIP(hipStreamWaitEvent(h, B.ev[2], 0));
+            }
+            return 0;
+        };
+        rc = body();
+        rc = mnk_persist_end(c0, h, rc);
+        if (rc) return rc;
+    }
+    MNK_HIP(hipEventRecord(l0->ev_defer, h));
+    for (mnk_ls* ls : g) {
+        if (ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(ls->ctx->stream, l0->ev_defer, 0));
+        batch_mark_done(ls);
+        int r = mnk_ls_prefill_spare(ls);
+        if (r) return r;
+    }
+    return 0;
+}
+
 static int batch_flush() {
     std::vector<mnk_ls*> pend;
     pend.swap(t_batch.pend);
@@ -1160,18 +1288,19 @@ static int batch_flush() {
         mnk_ls* l0 = pend.front();
         std::vector<mnk_ls*> g, rest;
         for (mnk_ls* ls : pend) {
-            const bool same = ls->ctx->device == l0->ctx->device && ls->Np == l0->Np && ls->algo == l0->algo && ls->dag_chunk == l0->dag_chunk &&
+            const bool same = ls->ctx->device == l0->ctx->device && ls->Np == l0->Np && ls->algo == l0->algo && ls->dag_js2 == l0->dag_js2 && ls->dag_chunk == l0->dag_chunk &&
                               ls->dag_taper0 == l0->dag_taper0 && ls->dag_band == l0->dag_band && ls->dag_has_fill == l0->dag_has_fill;
             (same && std::find(g.begin(), g.end(), ls) == g.end() ? g : rest).push_back(ls);
         }
         pend.swap(rest);
         int rc;
         if (g.size() >= 2) {
-            rc = batch_run_group(g);
+            rc = l0->dag_js2 == 0 ? batch_run_group_small(g) : batch_run_group(g);
             if (rc)   // (nothing of the group counts as factorized)
                 for (mnk_ls* ls : g) ls->deferred = false;
         } else {
             g[0]->deferred = false;
+            if (g[0]->Np < g[0]->dag_min_rows) g[0]->algo_now = 4;   // (alone, a system below the schedule's window keeps its usual one)
             rc = mnk_ls_run_factorization_now(g[0]);
         }
         if (rc && !rc_all) rc_all = rc;

@@ -790,6 +790,57 @@ __global__ __launch_bounds__(256) void pchain_kernel(double* __restrict__ F, int
     }
 }
 
+// The pivot chains of SEVERAL small systems in one launch (batches of small factorizations: the dense blocks of the Schur
+// stage, C2-size systems): workgroups [strips i, strips (i + 1)) are the strips of system i, every row of it in the chain's
+// band -- a system of a few hundred rows is nothing but its chain (the previous strip-column is applied by the strips'
+// prologue), larger ones get their band tiles accumulated by the batch's bulk kernel.  All workgroups must be resident
+// (one per CU of the launch stream's mask).  The record of a system is read through the constant address space.
+struct PcSys {
+    double* F;
+    int64_t ld;
+    int64_t Np;
+    double* dblk0;
+    double* inv0;
+    double* dvec;
+    double* dinv;
+    double* V;
+    int* info;
+    double pivot_tol;
+    int* flag_p;
+    int epoch16;
+    int* front;
+    const int* af;
+    int ntile;
+    long spin_limit;
+    unsigned long long* vmax;
+};
+typedef const PcSys __attribute__((address_space(4))) * PcSysP;
+
+template <bool LDL>
+__global__ __launch_bounds__(256) void pchain_multi_kernel(const PcSys* __restrict__ sys, int strips) {
+    extern __shared__ __attribute__((aligned(128))) char pp_smem[];
+    __shared__ int s_go;
+    const int isys = (int)blockIdx.x / strips, t = (int)blockIdx.x % strips;
+    const PcSysP y = (PcSysP)(uintptr_t)(sys + isys);
+    double* F = y->F;
+    const int64_t ld = y->ld, Np = y->Np;
+    double* V = y->V;
+    const PpDag dag{y->front, y->af, y->ntile, 0, 0, -1, y->spin_limit, nullptr, y->vmax};
+    for (int64_t Js = 0, p0 = 0; p0 + 64 * (int64_t)t < Np; p0 += 256, ++Js) {
+        const int nb = (int)((Np - p0) / 64 < 4 ? (Np - p0) / 64 : 4);
+        PpDag d = dag;
+        d.need_front = Js > 0 ? (int)(2 * Js) : 0;
+        d.front_from = 0;
+        d.af_tilecol = 2 * Js - 2 > 0 ? (int)(2 * Js) : -1;
+        const double* Vp = Js > 0 ? (LDL ? V : F) + (p0 - 256) * ld : nullptr;
+        pp_strip<LDL, 4, true>(t, F, ld, p0, nb, Np, y->dblk0, y->inv0, y->dvec, y->dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, y->info,
+                               y->pivot_tol, y->flag_p + p0 / 64, y->epoch16, -1, Vp, ld, Js > 0 ? 256 : 0, d, pp_smem, &s_go);
+        __syncthreads();  // (waves leave a strip at different times; its LDS tiles and s_go are reused)
+    }
+}
+
+__global__ void pc_set_sys_kernel(PcSys rec, PcSys* __restrict__ dst) { *dst = rec; }
+
 // inv(L_jj) of every 64x64 diagonal block (unit diagonal for LDL), for the triangular solves.
 // One workgroup of 4 waves per block: thread (c, p) solves L x = e_c for the rows r = 4i + p by column-oriented
 // substitution; the owner of row k publishes x_k through LDS (one barrier per pivot, double-buffered), so every
@@ -1110,6 +1161,40 @@ int mnk_launch_pchain(mnk_ls* ls, hipStream_t sp, const mnk::PpDag& dag, int js_
 
 static int run_factorization_body(mnk_ls* ls);
 
+// The chains of the `n` systems v[0..n) (same order and algorithm, every row in the band: `strips` = Np / 64 workgroups each)
+// in ONE launch on `sp` (its CU mask must hold n * strips CUs); `table`: device memory for n records (>= n * mnk_pchain_sys_bytes()).
+size_t mnk_pchain_sys_bytes() { return sizeof(mnk::PcSys); }
+int mnk_launch_pchain_multi(mnk_ls* const* v, int n, hipStream_t sp, hipStream_t fill_stream, void* table, int* const* front,
+                            const int* const* af) {
+    {   // 96 KB of dynamic LDS: the attribute belongs to the (kernel, device) pair
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev = 0;
+        MNK_HIP(hipGetDevice(&dev));
+        if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+        }
+    }
+    mnk::PcSys* dst = static_cast<mnk::PcSys*>(table);
+    const bool ldl = v[0]->algo == MNK_LDL;
+    const int strips = (int)(v[0]->Np / NBI);
+    for (int i = 0; i < n; ++i) {
+        mnk_ls* ls = v[i];
+        mnk::PcSys rec{ls->fact.p, ls->ld, ls->Np, ls->dblk.p, ls->inv16.p, ls->dvec.p, ls->dinv.p, ldl ? ls->vfull.p : nullptr,
+                       ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, ls->epoch * 16, front[i], af[i], (int)(ls->Np / 128),
+                       ls->dag_spin_limit, mnk_ls_growth_word(ls)};
+        hipLaunchKernelGGL(pc_set_sys_kernel, dim3(1), dim3(1), 0, fill_stream, rec, dst + i);
+    }
+    MNK_HIP(hipGetLastError());
+    if (ldl)
+        hipLaunchKernelGGL(pchain_multi_kernel<true>, dim3((unsigned)(n * strips)), dim3(256), PP_LDS_BYTES, sp, dst, strips);
+    else
+        hipLaunchKernelGGL(pchain_multi_kernel<false>, dim3((unsigned)(n * strips)), dim3(256), PP_LDS_BYTES, sp, dst, strips);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
 int mnk_ls_run_factorization(mnk_ls* ls) {
     mnk_ctx* ctx = ls->ctx;
     hipStream_t s = ctx->stream;
@@ -1125,7 +1210,9 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     // on the device (the arbiter below); a wait that expires anyway (another PROCESS) falls back (mnk_ls_fetch_info) and the
     // persistent schedule is tried again 16, then 64, 256, ... factorizations later.
     ls->algo_now = ls->panel_algo;
-    if (ls->algo_now == 5 && (ctx->dag_cus < ls->dag_band || !ls->lookahead || Np < ls->dag_min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
+    // (inside an open batch small systems take the task-DAG schedule too: their pivot chains run side by side, dag.hip)
+    const int64_t min_rows = mnk_batch_active() ? std::min<int64_t>(ls->dag_min_rows, 256) : ls->dag_min_rows;
+    if (ls->algo_now == 5 && (ctx->dag_cus < ls->dag_band || !ls->lookahead || Np < min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
     ++ls->fact_count;
     if (ls->pp_blocked && ls->fact_count >= ls->pp_retry_at) ls->pp_blocked = false;   // (a time-out may have been transient)
     if (ls->algo_now >= 4 && ls->pp_blocked) ls->algo_now = 1;

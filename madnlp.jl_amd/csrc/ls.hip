@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <atomic>
+#include <map>
 #include <mutex>
 
 #include <cfloat>
@@ -362,6 +363,36 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
 
 int mnk_ctx_create(int device, void* stream, mnk_ctx** out) { return ctx_create_common(device, stream, 0, 0, out); }
 
+}  // extern "C"
+// A pair of CU-masked streams of the whole device: `sp` on the first `chain_cus` mask bits, `su` on all the others (nullptr
+// when none are left); cached per device and size for the life of the process (masked streams are hardware queues).
+int mnk_masked_stream_pair(mnk_ctx* ctx, int chain_cus, hipStream_t* sp, hipStream_t* su) {
+    struct Pair { hipStream_t sp = nullptr, su = nullptr; };
+    static std::map<std::pair<int, int>, Pair> cache;
+    mnk::LaunchLock lock;
+    MNK_REQUIRE(!ctx->partitioned && chain_cus > 0 && chain_cus <= ctx->total_cu, "mnk_masked_stream_pair: bad size");
+    Pair& p = cache[{ctx->device, chain_cus}];
+    if (p.sp == nullptr) {
+        std::vector<int> bits;
+        for (int b = 0; b < ctx->total_cu; ++b) bits.push_back(b);
+        if (!make_masked_stream(ctx->total_cu, bits.data(), chain_cus, p.sp)) { set_error("mnk_masked_stream_pair: CU-masked streams are not available"); return -2; }
+        if (chain_cus < ctx->total_cu && !make_masked_stream(ctx->total_cu, bits.data() + chain_cus, ctx->total_cu - chain_cus, p.su)) {
+            (void)hipStreamDestroy(p.sp);
+            p.sp = nullptr;
+            set_error("mnk_masked_stream_pair: CU-masked streams are not available");
+            return -2;
+        }
+        if (p.su != nullptr) {   // (first launches of the kernels that need scratch: see mnk_dag_warmup)
+            hipStream_t w[1] = {p.su};
+            if (mnk_dag_warmup(w, 1) != 0) (void)hipGetLastError();
+        }
+    }
+    *sp = p.sp;
+    *su = p.su;
+    return 0;
+}
+extern "C" {
+
 int mnk_ctx_destroy(mnk_ctx* c) {
     if (!c) return 0;
     {
@@ -716,6 +747,17 @@ static int factorize_dense_dev(mnk_ls* ls, const double* Adev, int64_t lda) {
     ls->retransfer = [ls, Adev, lda]() { return transfer_dense(ls, Adev, lda); };  // (callers clear it when Adev's life ends)
     return mnk_ls_run_factorization(ls);
 }
+
+}  // extern "C"
+// (internal: the dense device source of the Schur stage's scenario blocks; asynchronous -- the caller keeps `Adev` alive and
+// fetches the info itself)
+int mnk_ls_factorize_dense_dev_async(mnk_ls* ls, const double* Adev, int64_t lda) {
+    MNK_REQUIRE(ls && Adev && lda >= ls->N, "mnk_ls_factorize_dense_dev_async: bad argument");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
+    return factorize_dense_dev(ls, Adev, lda);
+}
+extern "C" {
 
 int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc) {
     MNK_REQUIRE(ls && dc, "mnk_ls_factorize_dc: NULL argument");

@@ -356,3 +356,61 @@ def test_scenario_batch_array_entry_points_match_the_per_instance_calls():
         assert _bwd(_full(ko), din["x"].cpu().numpy(), din["rhs"].cpu().numpy()) <= 1e-13
         kh.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("n,m,n_eq,count", [(2048, 512, 0, 7), (2048, 512, 64, 6), (1900, 300, 60, 3), (500, 120, 0, 9), (700, 100, 30, 5)])
+def test_batched_small_factorizations(n, m, n_eq, count):
+    """Batches of SMALL systems (reference: the scenario loop `src/KKT/Schur/schur.jl:927-1001`, the uniform
+    batch of `lib/MadNLPGPU/ext/MadNLPGPUCUDAExt/cudss.jl:139-143`): a system of up to 6144 rows is bound by its own pivot
+    chain and uses Np / 64 CUs; in a batch the chains of several systems run side by side in ONE launch (pchain_multi_kernel),
+    their band tiles accumulated by one bulk launch.  Dense condensed KKT systems (DenseDummyQP shapes, with and without
+    equality rows): inertia (n, 0, n_eq); systems inside the schedule's window (N >= 1536): factor bits equal those of a lone
+    factorize!; below it (a lone factorize! takes the launch-per-panel schedule there): solutions agree to 1e-10 and the
+    backward error is <= 1e-13."""
+    from madnlp_jl_amd.problems import dense_dummy_qp
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
+    rng = np.random.default_rng(n + count)
+    ks, Ks, bs = [], [], []
+    for i in range(count):
+        P = dense_dummy_qp(n=n, m=m, n_eq=n_eq, seed=10 + i)
+        k = mj.DenseCondensedKKTSystem(P.n, P.m, P.ind_ineq, P.ind_eq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                       opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+        for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+            getattr(k, f)[:] = getattr(P, f)
+        k.hess[...] = P.hess
+        k.jac[...] = P.jac
+        k.set_aug_diagonal()
+        k.build_kkt()
+        ks.append(k)
+        bs.append(rng.standard_normal(k.linear_solver.n))
+    N = ks[0].linear_solver.n
+    lone = []
+    for k, b in zip(ks, bs):
+        k.linear_solver.factorize_async()
+        assert k.linear_solver.inertia() == (n, 0, n_eq)
+        Lf, D = k.linear_solver.get_factor_device()
+        lone.append((torch.tril(Lf).clone(), D.clone(), k.linear_solver.solve_linear_system(b.copy())))
+        Ks.append(k.aug_com.to_host())
+    for rnd in range(2):
+        with mj.factorize_batch():
+            for k in ks:
+                k.linear_solver.factorize_async()
+        for i, (k, b) in enumerate(zip(ks, bs)):
+            assert k.linear_solver.inertia() == (n, 0, n_eq), (rnd, i)
+            assert k.linear_solver.get_stat("panel_algo") == 5.0 and k.linear_solver.get_stat("pp_fallbacks") == 0.0
+            x = k.linear_solver.solve_linear_system(b.copy())
+            Kl = np.tril(Ks[i])
+            Kf = Kl + np.tril(Kl, -1).T
+            res = np.abs(Kf @ x - b).max() / (np.abs(Kf).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+            assert res <= 1e-13, (rnd, i, res)
+            Lf, D = k.linear_solver.get_factor_device()
+            if N >= 1536:
+                assert torch.equal(torch.tril(Lf), lone[i][0]) and torch.equal(D, lone[i][1]), (rnd, i)
+                assert np.array_equal(x, lone[i][2])
+            else:
+                assert np.abs(x - lone[i][2]).max() <= 1e-10 * np.abs(x).max()
+    for k in ks:
+        k.close()
+    ctx.close()
