@@ -36,6 +36,14 @@ struct mnk_schur {
     mnk_ls* ls_s = nullptr;
     std::vector<int> info_k;
     bool built = false;
+    // build_kkt!: the scenarios' forward sweeps and rank-blk updates are independent chains of ~18 small dependent launches
+    // each; they run on NLANE streams side by side (lane l: scenarios l, l + NLANE, ...; its own X / V work buffers and its own
+    // partial sum of S, added up in lane order at the end)
+    static constexpr int NLANE = 4;
+    hipStream_t lane_s[NLANE] = {nullptr, nullptr, nullptr, nullptr};   // lane 0 = the context's stream
+    hipEvent_t lane_ev[NLANE] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
+    mnk::DevBuf<double> lane_X[NLANE], lane_V[NLANE], lane_S[NLANE];    // (lane 0 uses Cp / Tt / Sp)
 };
 
 namespace mnk {
@@ -82,6 +90,12 @@ __global__ __launch_bounds__(256) void schur_gemv_t_kernel(double* __restrict__ 
     if (r < rows) s0 = fma(a[r], x[r], s0);
     y[c] = s0 + s1;
 }
+// S += P1 + P2 + P3 (the lanes' partial sums, fixed order)
+__global__ void schur_lane_sum_kernel(double* __restrict__ S, const double* __restrict__ p1, const double* __restrict__ p2,
+                                      const double* __restrict__ p3, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) S[i] = ((S[i] + p1[i]) + p2[i]) + p3[i];
+}
 // y[i] -= x[i]
 __global__ void schur_sub_kernel(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -110,9 +124,20 @@ int mnk_schur_create(mnk_ctx* ctx, int64_t ns_local, int64_t blk, int64_t nd, in
     rc |= h->T.alloc((size_t)blk * nd);
     rc |= h->Cp.alloc((size_t)h->ndp * h->Npb + SLACK);
     rc |= h->Tt.alloc((size_t)h->ndp * h->Npb + SLACK);
-    rc |= h->tmpk.alloc((size_t)h->Npb);
+    rc |= h->tmpk.alloc((size_t)h->Npb * (size_t)std::max<int64_t>(ns_local, 1));   // (one vector per scenario: their solves run as a batch)
     rc |= h->Sp.alloc((size_t)h->ndp * h->ndp + SLACK);
-    if (rc) { delete h; return -2; }
+    if (ns_local > 1) {   // lanes 1..: streams, events, work buffers (a single scenario needs none)
+        mnk::LaunchLock lock;
+        for (int l = 1; l < mnk_schur::NLANE && !rc; ++l) {
+            rc |= h->lane_X[l].alloc((size_t)h->ndp * h->Npb + SLACK);
+            rc |= h->lane_V[l].alloc((size_t)h->ndp * h->Npb + SLACK);
+            rc |= h->lane_S[l].alloc((size_t)h->ndp * h->ndp + SLACK);
+            if (hipStreamCreateWithFlags(&h->lane_s[l], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->lane_ev[l], hipEventDisableTiming) != hipSuccess) rc |= -2;
+        }
+        if (hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) rc |= -2;
+    }
+    if (rc) { (void)hipGetLastError(); delete h; return -2; }
     for (int64_t k = 0; k < ns_local && !rc; ++k) {
         mnk_ls* ls = nullptr;
         rc = mnk_ls_create(ctx, blk, algo, &ls);
@@ -137,6 +162,15 @@ int mnk_schur_destroy(mnk_schur* h) {
     (void)mnk::stream_wait(h->ctx->stream);
     for (mnk_ls* l : h->ls_k) mnk_ls_destroy(l);
     if (h->ls_s) mnk_ls_destroy(h->ls_s);
+    {
+        mnk::LaunchLock lock;
+        mnk::quiesce_persistent();
+        for (int l = 1; l < mnk_schur::NLANE; ++l) {
+            if (h->lane_s[l]) { (void)mnk::stream_wait(h->lane_s[l]); (void)hipStreamDestroy(h->lane_s[l]); }
+            if (h->lane_ev[l]) (void)hipEventDestroy(h->lane_ev[l]);
+        }
+        if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+    }
     mnk_ctx* ctx = h->ctx;
     delete h;
     mnk_ctx_child_gone(ctx);
@@ -181,37 +215,61 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         const int rc_end = mnk_factorize_batch_end();
         if (rc || rc_end) return rc ? rc : rc_end;
     }
+    // Phase 1b + 2 per scenario, on NLANE streams side by side (the tier that produced each factor is known first: the info
+    // fetch of a batch member waits for its own factorization only)
     for (int64_t k = 0; k < h->ns; ++k) {
-        // Phase 1b: T_k = A_k^-1 C_dk' (the info fetch decides the tier that produced the factor)
         int rc = mnk_ls_fetch_info(h->ls_k[k]);
         if (rc) return rc;
         h->info_k[k] = h->ls_k[k]->info;
+    }
+    const int nlane = h->lane_s[1] != nullptr ? (int)std::min<int64_t>(mnk_schur::NLANE, h->ns) : 1;
+    if (nlane > 1) {
+        MNK_HIP(hipEventRecord(h->fork_ev, s));
+        for (int l = 1; l < nlane; ++l) {
+            MNK_HIP(hipStreamWaitEvent(h->lane_s[l], h->fork_ev, 0));
+            MNK_HIP(hipMemsetAsync(h->lane_S[l].p, 0, (size_t)ndp * ndp * sizeof(double), h->lane_s[l]));
+        }
+    }
+    for (int64_t k = 0; k < h->ns; ++k) {
+        const int lane = (int)(k % nlane);
+        hipStream_t sl = lane == 0 ? s : h->lane_s[lane];
+        double* Xl = lane == 0 ? h->Cp.p : h->lane_X[lane].p;
+        double* Vl = lane == 0 ? h->Tt.p : h->lane_V[lane].p;
+        double* Sl = lane == 0 ? h->Sp.p : h->lane_S[lane].p;
+        int rc = 0;
         mnk_ls* ls = h->ls_k[k];
         const double* Ck = h->C.p + k * nd * blk;
         if (!ls->bk_active && h->info_k[k] == 0) {
             // Fast path (static-pivot factor A_k = L D L' or L L'):  C A^-1 C' = (C L^-T) D^-1 (C L^-T)', so only the
             // FORWARD sweep is needed, as a right-side triangular solve of the nd rows of C_dk -- left-looking over the
             // 64-column blocks of L: an MFMA update with the finished blocks, then block substitution on MFMA
-            // (trsm64_mfma_kernel) against the diagonal block.  X = C L^-T D^-1 lands in Cp, V = C L^-T in Tt.
+            // (trsm64_mfma_kernel) against the diagonal block.  X = C L^-T D^-1 lands in Xl, V = C L^-T in Vl.
             const int64_t Npb = h->Npb;
-            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * Npb), h->Cp.p, ndp, ndp, Npb, Ck, nd, nd, blk, 0);
+            hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)((ndp * Npb + 255) / 256)), dim3(256), 0, sl, Xl, ndp, ndp, Npb, Ck, nd, nd, blk, 0);
             const bool ldl = ls->algo == MNK_LDL;
-            double* X = h->Cp.p;
-            double* V = ldl ? h->Tt.p : h->Cp.p;
+            double* X = Xl;
+            double* V = ldl ? Vl : Xl;
             for (int64_t j0 = 0; j0 < Npb; j0 += NBI) {
                 if (j0 > 0) {
-                    rc = launch_gemm_nt(s, 0, ndp, NBI, j0, V, ndp, ls->fact.p + j0, ls->ld, X + j0 * ndp, ndp, nullptr,
+                    rc = launch_gemm_nt(sl, 0, ndp, NBI, j0, V, ndp, ls->fact.p + j0, ls->ld, X + j0 * ndp, ndp, nullptr,
                                         nullptr, 0, nullptr);
                     if (rc) return rc;
                 }
-                rc = mnk_ls_right_trsm_rows(ls, s, j0, X, ldl ? V : nullptr, ndp, ndp);
+                rc = mnk_ls_right_trsm_rows(ls, sl, j0, X, ldl ? V : nullptr, ndp, ndp);
                 if (rc) return rc;
             }
             // Phase 2 (reference :993-999): S -= X V'
-            rc = launch_gemm_nt(s, 0, ndp, ndp, Npb, X, ndp, V, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
+            rc = launch_gemm_nt(sl, 0, ndp, ndp, Npb, X, ndp, V, ndp, Sl, ndp, nullptr, nullptr, 0, nullptr);
             if (rc) return rc;
         } else {
             // Pivoted (Bunch-Kaufman tier) or failed factor: T_k = A_k^-1 C_dk' column by column, as the reference does
+            // (on the context's stream, behind everything the lanes have queued so far: the solver's own work vectors)
+            if (nlane > 1) {
+                for (int l = 1; l < nlane; ++l) {
+                    MNK_HIP(hipEventRecord(h->lane_ev[l], h->lane_s[l]));
+                    MNK_HIP(hipStreamWaitEvent(s, h->lane_ev[l], 0));
+                }
+            }
             double* Tk = h->T.p;
             hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(blk * nd), Tk, blk, blk, nd, Ck, nd, nd, blk, 1);
             rc = mnk_ls_solve(ls, Tk, nd, blk, MNK_DEVICE);
@@ -222,7 +280,25 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
             MNK_HIP(hipGetLastError());
             rc = launch_gemm_nt(s, 0, ndp, ndp, blkp, h->Cp.p, ndp, h->Tt.p, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
             if (rc) return rc;
+            if (nlane > 1) {   // (lane 0's buffers were used out of turn: the lanes continue behind this scenario)
+                MNK_HIP(hipEventRecord(h->fork_ev, s));
+                for (int l = 1; l < nlane; ++l) MNK_HIP(hipStreamWaitEvent(h->lane_s[l], h->fork_ev, 0));
+            }
         }
+    }
+    if (nlane > 1) {
+        for (int l = 1; l < nlane; ++l) {
+            MNK_HIP(hipEventRecord(h->lane_ev[l], h->lane_s[l]));
+            MNK_HIP(hipStreamWaitEvent(s, h->lane_ev[l], 0));
+        }
+        const double* p1 = h->lane_S[1].p;
+        const double* p2 = nlane > 2 ? h->lane_S[2].p : h->lane_S[1].p + 0;
+        const double* p3 = nlane > 3 ? h->lane_S[3].p : nullptr;
+        // (lanes that do not exist contribute zeros: their buffers are zero-filled below)
+        if (nlane == 2) { MNK_HIP(hipMemsetAsync(h->lane_S[2].p, 0, (size_t)ndp * ndp * sizeof(double), s)); p2 = h->lane_S[2].p; }
+        if (nlane <= 3) { MNK_HIP(hipMemsetAsync(h->lane_S[3].p, 0, (size_t)ndp * ndp * sizeof(double), s)); p3 = h->lane_S[3].p; }
+        hipLaunchKernelGGL(schur_lane_sum_kernel, MNK_GRID1(ndp * ndp), h->Sp.p, p1, p2, p3, ndp * ndp);
+        MNK_HIP(hipGetLastError());
     }
     MNK_HIP(hipMemcpy2DAsync(S_out, lds_out * sizeof(double), h->Sp.p, ndp * sizeof(double), nd * sizeof(double), nd,
                              hipMemcpyDeviceToDevice, s));
@@ -266,12 +342,15 @@ int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d) {
     MNK_HIP(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
     MNK_HIP(hipMemsetAsync(contrib_d, 0, h->nd * sizeof(double), s));
-    for (int64_t k = 0; k < h->ns; ++k) {
-        int rc = mnk_ls_solve(h->ls_k[k], rhs_k + k * h->blk, 1, h->blk, MNK_DEVICE);
-        if (rc) return rc;
+    {   // the scenarios' solves as ONE batch (solve.hip: up to 32 small systems per launch), then the contributions in order
+        int rc = mnk_solve_batch_begin();
+        for (int64_t k = 0; k < h->ns && !rc; ++k) rc = mnk_ls_solve(h->ls_k[k], rhs_k + k * h->blk, 1, h->blk, MNK_DEVICE);
+        const int rc_end = mnk_solve_batch_end();
+        if (rc || rc_end) return rc ? rc : rc_end;
+    }
+    for (int64_t k = 0; k < h->ns; ++k)
         hipLaunchKernelGGL(schur_gemv_kernel, MNK_GRID1(h->nd), contrib_d, h->C.p + k * h->nd * h->blk, h->nd,
                            rhs_k + k * h->blk, h->nd, h->blk, -1.0);
-    }
     MNK_HIP(hipGetLastError());
     return schur_check_solves(h, true, false);
 }
@@ -289,13 +368,17 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
     MNK_REQUIRE(h && x_d && (rhs_k || h->ns == 0), "mnk_schur_backward: NULL argument");
     MNK_HIP(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
-    for (int64_t k = 0; k < h->ns; ++k) {
-        hipLaunchKernelGGL(schur_gemv_t_kernel, MNK_GRID1(h->blk), h->tmpk.p, h->C.p + k * h->nd * h->blk, h->nd, x_d, h->nd,
+    for (int64_t k = 0; k < h->ns; ++k)
+        hipLaunchKernelGGL(schur_gemv_t_kernel, MNK_GRID1(h->blk), h->tmpk.p + k * h->Npb, h->C.p + k * h->nd * h->blk, h->nd, x_d, h->nd,
                            h->blk);
-        int rc = mnk_ls_solve(h->ls_k[k], h->tmpk.p, 1, h->blk, MNK_DEVICE);
-        if (rc) return rc;
-        hipLaunchKernelGGL(schur_sub_kernel, MNK_GRID1(h->blk), rhs_k + k * h->blk, h->tmpk.p, h->blk);
+    {
+        int rc = mnk_solve_batch_begin();
+        for (int64_t k = 0; k < h->ns && !rc; ++k) rc = mnk_ls_solve(h->ls_k[k], h->tmpk.p + k * h->Npb, 1, h->blk, MNK_DEVICE);
+        const int rc_end = mnk_solve_batch_end();
+        if (rc || rc_end) return rc ? rc : rc_end;
     }
+    for (int64_t k = 0; k < h->ns; ++k)
+        hipLaunchKernelGGL(schur_sub_kernel, MNK_GRID1(h->blk), rhs_k + k * h->blk, h->tmpk.p + k * h->Npb, h->blk);
     MNK_HIP(hipGetLastError());
     return schur_check_solves(h, true, false);
 }
