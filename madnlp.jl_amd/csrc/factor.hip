@@ -422,6 +422,7 @@ __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__
 // ---------------------------------------------------------------------------------------
 constexpr long PP_SPIN_LIMIT = 1L << 20;  // ~0.5 s
 constexpr int PP_LDS_BYTES = 3 * 4096 * 8;  // two staging tiles (the first doubles as the exchange buffer) + own tile
+constexpr int PC_LDS_BYTES = 4 * 4096 * 8;  // pivot-chain kernels: + the strip's NEXT diagonal block (see pp_strip, EARLY)
 
 // Wave-uniform bounded wait for prog[c] >= target.  `seen` caches the last values read: one acquire covers everything
 // that was published before ANY flag value read ahead of it, so every successful wait refreshes all nb entries and
@@ -453,22 +454,44 @@ __device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int targ
 
 // One strip t of one persistent panel step (the body of ppanel_kernel / pchain_kernel): every thread of the workgroup calls
 // it with the same arguments; waves may return at different times (callers that go on synchronize first).
-template <bool LDL, int NB, bool WT = false>
+//
+// EARLY (the pivot-chain kernels, whose workgroups keep their ROWS from one strip-column to the next: strip t + 4 of Js is
+// strip t of Js + 1): a strip 4..7 is a diagonal strip of the next strip-column, and the 256 columns it finishes here are
+// exactly what its next diagonal block is still missing.  Instead of publishing them, having the next strip-column's
+// workgroup wait for the flag, read them back and apply them in its prologue (6 us of hop + 14 us of K = 256 product in
+// front of EVERY strip-column's first diagonal block: 20 of the chain's 95 us per 256 columns), the strip sums the four
+// products Z = - sum_j V_j L_j^T for its own next diagonal block right after each substitution -- the operands are in
+// registers (V) and in LDS (`own`: L) at that moment -- in an accumulator that starts from zero (`xn`, LDS: the band tile
+// T' the bulk kernel accumulates over the older columns is not final yet at that time), and the block becomes T' + Z:
+// at the start of the last step if T' is final by then (loaded while the strip waits for the last diagonal block; state
+// 2), else in the next strip-column behind the usual wait for the band tile (state 1).  The next strip-column's strip 0
+// then starts with its diagonal step, behind the same hand-over as any other block of the chain.  ALWAYS taken by the
+// strips 4..7 (the sum order T' + (((0 - c0) - c1) - c2) - c3 differs from the prologue's ((T' - c0) - c1) ...: one
+// path per strip, the same bits in every run, and both T' + Z paths add the same two numbers).
+template <bool LDL, int NB, bool WT = false, bool EARLY = false>
 __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, int64_t ld, int64_t p0, int nb, int64_t Np,
                                          double* __restrict__ dblk0, double* __restrict__ inv0, double* __restrict__ dvec,
                                          double* __restrict__ dinv, double* __restrict__ W, int64_t ldw, int64_t wcol0,
                                          int* __restrict__ info, double pivot_tol, int* __restrict__ prog, int epoch16,
                                          int dbg_missing, const double* __restrict__ Vp, int64_t ldv, int Kp, PpDag dag,
-                                         char* pp_smem, int* s_go) {
+                                         char* pp_smem, int* s_go, int* xn_have = nullptr) {
     v4d* stage = reinterpret_cast<v4d*>(pp_smem);          // [2][1024] v4d
     v4d* own = reinterpret_cast<v4d*>(pp_smem) + 2 * 1024;  // [1024] v4d
+    v4d* xn = reinterpret_cast<v4d*>(pp_smem) + 3 * 1024;   // [1024] v4d (EARLY only: PC_LDS_BYTES)
     const int tid = threadIdx.x;
+    const int64_t R = p0 + 64 * (int64_t)t;
+    // this strip's own diagonal block was brought up to date by the previous strip-column's steps
+    const int xn_state = EARLY && xn_have != nullptr ? *xn_have : 0;   // (rewritten behind the barrier below)
+    const bool use_xn = xn_state != 0;
+    // ... and whether this strip does the same for the next strip-column
+    const bool make_xn = EARLY && xn_have != nullptr && dag.front != nullptr && t >= 4 && t < 8 && nb == 4 && R < Np && t != dbg_missing;
     if (tid == 0) *s_go = (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 0;
     __syncthreads();
-    if (!*s_go) return;
+    const int go_bits = *s_go;
+    if (EARLY && xn_have != nullptr && tid == 0) *xn_have = make_xn ? 1 : 0;   // (read again only behind the caller's barrier)
+    if (!(go_bits & 1)) return;
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t R = p0 + 64 * (int64_t)t;
     if (R >= Np || t == dbg_missing) return;
     const int64_t r0 = R + 16 * w;
     const int jmax = t < nb - 1 ? t : nb - 1;
@@ -484,7 +507,13 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
     const int tabs = (int)(p0 >> 6) + t;  // this strip's 64-row block
     unsigned long long* ptr_tr = dag.trace != nullptr && tid == 0 ? dag.trace + 8 * t : nullptr;
     if (ptr_tr) ptr_tr[0] = wall_clock64();
-    if (dag.front != nullptr && (dag.af_tilecol >= 0 || (dag.need_front > 0 && t >= dag.front_from))) {
+    if (EARLY && make_xn) {
+#pragma unroll
+        for (int cb2 = 0; cb2 < 4; ++cb2)
+            if (cb2 <= w) xn[(w * 4 + cb2) * 64 + lane] = v4d{0.0, 0.0, 0.0, 0.0};   // (wave w: its 16 rows, column blocks cb2 <= w)
+    }
+    // (strip 0 with its diagonal block complete depends on nothing but that block)
+    if (dag.front != nullptr && !(xn_state == 2 && t == 0) && (dag.af_tilecol >= 0 || (dag.need_front > 0 && t >= dag.front_from))) {
         // the strip's tiles as the bulk kernel leaves them (accumulated over the older columns), and -- rows below the
         // previous launch's band -- its rows of the previous strip-column, finalized by the bulk kernel
         if (tid == 0) {
@@ -530,8 +559,9 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
     // T[t, c] -= V[t, p0-Kp : p0] L[p0 + 64 c .., p0-Kp : p0]^T.  Used where the panel chain is the critical path (few
     // rows left): the first diagonal block is ready after Kp/64 K = 64 products of one workgroup, with no kernel
     // boundary and no cross-stream hand-over in front of the pivot chain.
-    if (Kp > 0) {
-        const int nch = Kp >> 6, ncb = jmax + 1;
+    const int ncb_pro = use_xn ? t : jmax + 1;   // (use_xn: the strip's own diagonal block -- column block t -- needs no prologue)
+    if (Kp > 0 && ncb_pro > 0) {
+        const int nch = Kp >> 6, ncb = ncb_pro;
         v4d pre[4], Bv[4], Bn[4];
         auto tile_load = [&](int kc, int c) {
             const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 - Kp + 64 * (int64_t)kc + w) * ld;
@@ -582,6 +612,19 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         }
         __syncthreads();
     }
+    if (EARLY && use_xn) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (c == t) {
+#pragma unroll
+                for (int cb2 = 0; cb2 < 4; ++cb2)
+                    if (cb2 <= w) {
+                        const v4d z = xn[(w * 4 + cb2) * 64 + lane];
+                        if (xn_state == 2) X[4 * c + cb2] = z;   // (T' + Z, summed by the previous strip-column's last step)
+                        else X[4 * c + cb2] += z;
+                    }
+            }
+    }
     if (ptr_tr) ptr_tr[4] = wall_clock64();
 
     // One step per column block.  `j` is a compile-time constant (generic lambda over integral_constant), so every
@@ -589,7 +632,33 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
     auto step = [&](auto Jc) __attribute__((always_inline)) -> bool {
         constexpr int j = decltype(Jc)::value;
         if (j > jmax) return true;
-        if (j > 0) __syncthreads();  // the LDS tiles of the previous step are free
+        bool tn_now = false;   // EARLY: the band tile T' of the next diagonal block is final and parked in the staging tile
+        if (EARLY && NB == 4 && j == 3 && make_xn) {
+            // last step of a strip 4..7 (no update loop: the staging tiles are free).  T' is read while the strip waits for the
+            // last diagonal block -- if the bulk kernel is done with it (never waited for here).
+            if (tid == 0) {
+                const int jsn = (int)(p0 >> 8) + 1;
+                bool ready = true;
+                if (2 * jsn - 2 > 0) {
+                    ready = __hip_atomic_load(dag.af + (int64_t)(tabs >> 1) * dag.ntile + 2 * jsn + ((t - 4) >> 1), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT) >= 1;
+                    if (ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                *s_go = ready ? 3 : 1;
+            }
+            __syncthreads();
+            tn_now = (*s_go & 2) != 0;
+            if (tn_now) {
+#pragma unroll
+                for (int cb2 = 0; cb2 < 4; ++cb2)
+                    if (cb2 <= w) {
+                        v4d v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = F[(r0 + l15) + (p0 + 256 + 64 * (int64_t)(t - 4) + 16 * cb2 + l4 + 4 * r) * ld];
+                        stage[(w * 4 + cb2) * 64 + lane] = v;
+                    }
+            }
+        } else if (j > 0) __syncthreads();  // the LDS tiles of the previous step are free
         if (j == t) {
             // ---- diagonal step: hand the updated 64x64 block to wave 0 (same lane mapping), factor, publish
 #pragma unroll
@@ -682,7 +751,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 }
                 put<WT>(F + row + (p0 + c) * ld, lv[r]);
             }
-            if (diag_strip) own[(w * 4 + ib) * 64 + lane] = lv;
+            if (diag_strip || (EARLY && make_xn)) own[(w * 4 + ib) * 64 + lane] = lv;
         }
         if (LDL) growth_fold(dag.vmax, vm);
         // task-DAG schedule: the strip's rows are final through a whole tile column after every second block
@@ -732,6 +801,24 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 }
             }
         }
+        if (EARLY && make_xn) {
+            // ---- the same product for the strip's diagonal block of the NEXT strip-column (its k-chunk j)
+            __syncthreads();   // `own` is complete
+#pragma unroll
+            for (int cb2 = 0; cb2 < 4; ++cb2) {
+                if (cb2 > w) break;
+                v4d acc = xn[(w * 4 + cb2) * 64 + lane];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    const v4d a = own[(cb2 * 4 + ib) * 64 + lane];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], X[4 * j + ib][s], acc, 0, 0, 0);
+                }
+                if (tn_now) acc = stage[(w * 4 + cb2) * 64 + lane] + acc;
+                xn[(w * 4 + cb2) * 64 + lane] = acc;
+            }
+            if (tn_now && tid == 0) *xn_have = 2;
+        }
         return false;
     };
     if (step(std::integral_constant<int, 0>{})) return;
@@ -775,8 +862,18 @@ __global__ __launch_bounds__(256) void pchain_kernel(double* __restrict__ F, int
                                                       PpDag dag, int js_begin, int js_end) {
     extern __shared__ __attribute__((aligned(128))) char pp_smem[];
     __shared__ int s_go;
-    const int t = blockIdx.x;
-    for (int64_t Js = js_begin, p0 = 256 * (int64_t)js_begin; Js < js_end && p0 + 64 * (int64_t)t < Np; p0 += 256, ++Js) {
+    __shared__ int s_xn;
+    // Workgroup g keeps its ROWS from one strip-column to the next (row block 4 js_begin + g, then + gridDim.x, ...): in
+    // strip-column Js it is strip (g - 4 (Js - js_begin)) mod gridDim.x of the band, the rows of a diagonal strip are still in
+    // its registers / LDS when they become the next strip-column's diagonal strip (pp_strip, EARLY), and the workgroups that
+    // are done with their diagonal blocks take the rows that enter the band.
+    const int g = blockIdx.x, G = gridDim.x;
+    if (threadIdx.x == 0) s_xn = 0;
+    __syncthreads();
+    for (int64_t Js = js_begin, p0 = 256 * (int64_t)js_begin; Js < js_end && p0 < Np; p0 += 256, ++Js) {
+        int t = (int)((g - 4 * (Js - js_begin)) % G);
+        if (t < 0) t += G;
+        if (p0 + 64 * (int64_t)t >= Np) continue;   // (no such rows; s_xn is 0: only a strip with rows sets it, and the next one consumes it)
         const int nb = (int)((Np - p0) / 64 < 4 ? (Np - p0) / 64 : 4);
         PpDag d = dag;
         d.need_front = Js > 0 ? (int)(2 * Js) : 0;
@@ -784,8 +881,8 @@ __global__ __launch_bounds__(256) void pchain_kernel(double* __restrict__ F, int
         d.af_tilecol = 2 * Js - 2 > 0 ? (int)(2 * Js) : -1;
         if (dag.trace != nullptr) d.trace = dag.trace + (Js - js_begin) * 8 * (int64_t)gridDim.x;
         const double* Vp = Js > 0 ? (LDL ? V : F) + (p0 - 256) * ld : nullptr;
-        pp_strip<LDL, 4, true>(t, F, ld, p0, nb, Np, dblk0, inv0, dvec, dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, info, pivot_tol,
-                         flag_p + p0 / 64, epoch16, dbg_missing, Vp, ld, Js > 0 ? 256 : 0, d, pp_smem, &s_go);
+        pp_strip<LDL, 4, true, true>(t, F, ld, p0, nb, Np, dblk0, inv0, dvec, dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, info, pivot_tol,
+                         flag_p + p0 / 64, epoch16, dbg_missing, Vp, ld, Js > 0 ? 256 : 0, d, pp_smem, &s_go, &s_xn);
         __syncthreads();  // (waves leave a strip at different times; its LDS tiles and s_go are reused)
     }
 }
@@ -820,21 +917,25 @@ template <bool LDL>
 __global__ __launch_bounds__(256) void pchain_multi_kernel(const PcSys* __restrict__ sys, int strips) {
     extern __shared__ __attribute__((aligned(128))) char pp_smem[];
     __shared__ int s_go;
-    const int isys = (int)blockIdx.x / strips, t = (int)blockIdx.x % strips;
+    __shared__ int s_xn;
+    const int isys = (int)blockIdx.x / strips, g = (int)blockIdx.x % strips;   // (workgroup g keeps row block g: strip g - 4 Js)
+    if (threadIdx.x == 0) s_xn = 0;
+    __syncthreads();
     const PcSysP y = (PcSysP)(uintptr_t)(sys + isys);
     double* F = y->F;
     const int64_t ld = y->ld, Np = y->Np;
     double* V = y->V;
     const PpDag dag{y->front, y->af, y->ntile, 0, 0, -1, y->spin_limit, nullptr, y->vmax};
-    for (int64_t Js = 0, p0 = 0; p0 + 64 * (int64_t)t < Np; p0 += 256, ++Js) {
+    for (int64_t Js = 0, p0 = 0; 4 * Js <= g; p0 += 256, ++Js) {
+        const int t = g - 4 * (int)Js;
         const int nb = (int)((Np - p0) / 64 < 4 ? (Np - p0) / 64 : 4);
         PpDag d = dag;
         d.need_front = Js > 0 ? (int)(2 * Js) : 0;
         d.front_from = 0;
         d.af_tilecol = 2 * Js - 2 > 0 ? (int)(2 * Js) : -1;
         const double* Vp = Js > 0 ? (LDL ? V : F) + (p0 - 256) * ld : nullptr;
-        pp_strip<LDL, 4, true>(t, F, ld, p0, nb, Np, y->dblk0, y->inv0, y->dvec, y->dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, y->info,
-                               y->pivot_tol, y->flag_p + p0 / 64, y->epoch16, -1, Vp, ld, Js > 0 ? 256 : 0, d, pp_smem, &s_go);
+        pp_strip<LDL, 4, true, true>(t, F, ld, p0, nb, Np, y->dblk0, y->inv0, y->dvec, y->dinv, LDL ? V : nullptr, LDL ? ld : 0, p0, y->info,
+                               y->pivot_tol, y->flag_p + p0 / 64, y->epoch16, -1, Vp, ld, Js > 0 ? 256 : 0, d, pp_smem, &s_go, &s_xn);
         __syncthreads();  // (waves leave a strip at different times; its LDS tiles and s_go are reused)
     }
 }
@@ -1139,8 +1240,8 @@ int mnk_launch_pchain(mnk_ls* ls, hipStream_t sp, const mnk::PpDag& dag, int js_
         int dev = 0;
         MNK_HIP(hipGetDevice(&dev));
         if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
-            MNK_HIP(hipFuncSetAttribute((const void*)pchain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-            MNK_HIP(hipFuncSetAttribute((const void*)pchain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES));
             attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
@@ -1148,11 +1249,11 @@ int mnk_launch_pchain(mnk_ls* ls, hipStream_t sp, const mnk::PpDag& dag, int js_
     const int epoch16 = ls->epoch * 16;
     double* V = ldl ? ls->vfull.p : nullptr;
     if (ldl)
-        hipLaunchKernelGGL(pchain_kernel<true>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, ls->fact.p, ls->ld, ls->Np, ls->dblk.p,
+        hipLaunchKernelGGL(pchain_kernel<true>, dim3(strips), dim3(256), PC_LDS_BYTES, sp, ls->fact.p, ls->ld, ls->Np, ls->dblk.p,
                            ls->inv16.p, ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16,
                            ls->debug_pp_missing, dag, js_begin, js_end);
     else
-        hipLaunchKernelGGL(pchain_kernel<false>, dim3(strips), dim3(256), PP_LDS_BYTES, sp, ls->fact.p, ls->ld, ls->Np, ls->dblk.p,
+        hipLaunchKernelGGL(pchain_kernel<false>, dim3(strips), dim3(256), PC_LDS_BYTES, sp, ls->fact.p, ls->ld, ls->Np, ls->dblk.p,
                            ls->inv16.p, ls->dvec.p, ls->dinv.p, V, ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, epoch16,
                            ls->debug_pp_missing, dag, js_begin, js_end);
     MNK_HIP(hipGetLastError());
@@ -1171,8 +1272,8 @@ int mnk_launch_pchain_multi(mnk_ls* const* v, int n, hipStream_t sp, hipStream_t
         int dev = 0;
         MNK_HIP(hipGetDevice(&dev));
         if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
-            MNK_HIP(hipFuncSetAttribute((const void*)pchain_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-            MNK_HIP(hipFuncSetAttribute((const void*)pchain_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES));
+            MNK_HIP(hipFuncSetAttribute((const void*)pchain_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES));
             attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
@@ -1188,9 +1289,9 @@ int mnk_launch_pchain_multi(mnk_ls* const* v, int n, hipStream_t sp, hipStream_t
     }
     MNK_HIP(hipGetLastError());
     if (ldl)
-        hipLaunchKernelGGL(pchain_multi_kernel<true>, dim3((unsigned)(n * strips)), dim3(256), PP_LDS_BYTES, sp, dst, strips);
+        hipLaunchKernelGGL(pchain_multi_kernel<true>, dim3((unsigned)(n * strips)), dim3(256), PC_LDS_BYTES, sp, dst, strips);
     else
-        hipLaunchKernelGGL(pchain_multi_kernel<false>, dim3((unsigned)(n * strips)), dim3(256), PP_LDS_BYTES, sp, dst, strips);
+        hipLaunchKernelGGL(pchain_multi_kernel<false>, dim3((unsigned)(n * strips)), dim3(256), PC_LDS_BYTES, sp, dst, strips);
     MNK_HIP(hipGetLastError());
     return 0;
 }

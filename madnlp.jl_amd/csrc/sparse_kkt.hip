@@ -30,27 +30,36 @@ __global__ void segsum_kernel(double* __restrict__ dst, const double* __restrict
     dst[s] = acc;
 }
 
-// diag_buffer = Sigma_s ./ (1 - Sigma_d .* Sigma_s)   (reference condensed.jl:364)
-__global__ void diag_buffer_kernel(double* __restrict__ D, const double* __restrict__ pr_s,
-                                   const double* __restrict__ du, int64_t m) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < m) D[i] = pr_s[i] / (1.0 - du[i] * pr_s[i]);
-}
-
-// One thread per aug_com slot: K.nz[s] = ((sum_h H.nz) + pr_diag) + sum_j D[c]*Jt[k]*Jt[l].
+// build_kkt! in ONE launch (round 3: two copies + diag_buffer_kernel + condense_kernel, host-enqueue bound at ~0.1 ms):
+//   thread i < m:      diag_buffer[i] = Sigma_s ./ (1 - Sigma_d .* Sigma_s)   (reference condensed.jl:364), kept for solve_kkt!
+//   thread i < n + m:  the handle's own copies of pr_diag / du_diag (the device-side solve_kkt! / mul! read them later)
+//   thread s < nslot:  K.nz[s] = ((sum_h H.nz) + pr_diag) + sum_j D[c]*Jt[k]*Jt[l]  with D[c] evaluated in place by the
+//                      same expression (one rounding each, so the bits equal the two-kernel version's)
 __global__ void condense_kernel(double* __restrict__ K, const double* __restrict__ Hnz,
-                                const double* __restrict__ pr_diag, const double* __restrict__ D,
+                                const double* __restrict__ pr_diag, const double* __restrict__ du,
+                                double* __restrict__ Dout, double* __restrict__ pr_keep, double* __restrict__ du_keep,
                                 const double* __restrict__ Jt, const int32_t* __restrict__ hptr,
                                 const int32_t* __restrict__ hsrc, const int32_t* __restrict__ dsrc,
                                 const int32_t* __restrict__ jptr, const int32_t* __restrict__ jc,
-                                const int32_t* __restrict__ jk, const int32_t* __restrict__ jl, int64_t nslot) {
+                                const int32_t* __restrict__ jk, const int32_t* __restrict__ jl, int64_t nslot, int64_t n,
+                                int64_t m) {
     const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const double* pr_s = pr_diag + n;
+    if (s < m) {
+        Dout[s] = pr_s[s] / (1.0 - du[s] * pr_s[s]);
+        if (du_keep != nullptr) du_keep[s] = du[s];
+    }
+    if (pr_keep != nullptr && s < n + m) pr_keep[s] = pr_diag[s];
     if (s >= nslot) return;
     double acc = 0.0;
     for (int32_t k = hptr[s]; k < hptr[s + 1]; ++k) acc += Hnz[hsrc[k]];
     const int32_t d = dsrc[s];
     if (d >= 0) acc += pr_diag[d];
-    for (int32_t k = jptr[s]; k < jptr[s + 1]; ++k) acc += (D[jc[k]] * Jt[jk[k]]) * Jt[jl[k]];
+    for (int32_t k = jptr[s]; k < jptr[s + 1]; ++k) {
+        const int32_t c = jc[k];
+        const double Dc = pr_s[c] / (1.0 - du[c] * pr_s[c]);
+        acc += (Dc * Jt[jk[k]]) * Jt[jl[k]];
+    }
     K[s] = acc;
 }
 
@@ -433,16 +442,14 @@ int mnk_sc_build(mnk_sc* sc, const double* pr_diag, const double* du_diag, int l
     int rc = stage_in(sc->ctx, sc->pr_diag.p, pr_diag, sc->n + sc->m, loc, &pr);
     rc |= stage_in(sc->ctx, sc->du_diag.p, du_diag, sc->m, loc, &du);
     if (rc) return rc;
-    if (loc == MNK_DEVICE && pr != sc->pr_diag.p) {  // keep our own copies: the device-side solve_kkt!/mul! read Sigma_s and du_diag later
-        MNK_HIP(hipMemcpyAsync(sc->pr_diag.p, pr, (sc->n + sc->m) * sizeof(double), hipMemcpyDeviceToDevice, s));
-        if (sc->m > 0) MNK_HIP(hipMemcpyAsync(sc->du_diag.p, du, sc->m * sizeof(double), hipMemcpyDeviceToDevice, s));
-    }
-    if (sc->m > 0)
-        hipLaunchKernelGGL(diag_buffer_kernel, dim3((unsigned)((sc->m + 255) / 256)), dim3(256), 0, s,
-                           sc->diag_buffer.p, pr + sc->n, du, sc->m);
-    hipLaunchKernelGGL(condense_kernel, dim3((unsigned)((sc->nnz_aug + 255) / 256)), dim3(256), 0, s, sc->aug_nz.p,
-                       sc->h_nz.p, pr, sc->diag_buffer.p, sc->jt_nz.p, sc->aug_hptr.p, sc->aug_hsrc.p,
-                       sc->aug_dsrc.p, sc->aug_jptr.p, sc->aug_jc.p, sc->aug_jk.p, sc->aug_jl.p, sc->nnz_aug);
+    // (caller's device vectors: the kernel also keeps our own copies -- the device-side solve_kkt!/mul! read Sigma_s and
+    // du_diag later)
+    const bool keep = loc == MNK_DEVICE && pr != sc->pr_diag.p;
+    const int64_t work = std::max<int64_t>(sc->nnz_aug, sc->n + sc->m);
+    hipLaunchKernelGGL(condense_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, sc->aug_nz.p, sc->h_nz.p, pr, du,
+                       sc->diag_buffer.p, keep ? sc->pr_diag.p : nullptr, keep && sc->m > 0 ? sc->du_diag.p : nullptr,
+                       sc->jt_nz.p, sc->aug_hptr.p, sc->aug_hsrc.p, sc->aug_dsrc.p, sc->aug_jptr.p, sc->aug_jc.p, sc->aug_jk.p,
+                       sc->aug_jl.p, sc->nnz_aug, sc->n, sc->m);
     MNK_HIP(hipGetLastError());
     return 0;
 }
