@@ -144,6 +144,13 @@ struct mnk_ls {
     mnk::DevBuf<int> bk_perm, bk_ptype;
     mnk::DevBuf<double> bk_doff, bk_dcoup, bk_work;  // (bk_work: the panel's W = L D and its zero-padded copy of L, 2 x Np x 72)
     mnk::DevBuf<char> bk_state;
+    // multi-workgroup panel (bk.hip): W by stored row, staging of the per-panel permutation, message ring, rowof | lists
+    mnk::DevBuf<double> bk_wv, bk_tmp;
+    mnk::DevBuf<unsigned long long> bk_msg;
+    mnk::DevBuf<int> bk_aux;
+    int bk_panel_wgs = 0;        // option: 0 = a workgroup per 256 rows of the panel, 1 = one workgroup per panel (round 3)
+    bool bk_multi_last = false, bk_mw_blocked = false;
+    int bk_mw_fallbacks = 0;
     bool factorized = false, info_valid = false;
     int info = 0;
     int64_t npos = 0, nzero = 0, nneg = 0;

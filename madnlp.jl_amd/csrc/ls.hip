@@ -593,6 +593,11 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
+    if (!strcmp(key, "bk_panel_wgs")) {   // pivoted tier: 0 = a workgroup per 256 rows of a panel, 1 = one workgroup per panel
+        MNK_REQUIRE(value == 0.0 || value == 1.0, "bk_panel_wgs must be 0 or 1");
+        ls->bk_panel_wgs = (int)value;
+        return 0;
+    }
     if (!strcmp(key, "accept_only_pd")) { ls->accept_only_pd = value != 0; return 0; }  // see mnk_ls_fetch_info
     // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
     if (!strcmp(key, "bk_growth_tol")) {
@@ -1029,6 +1034,8 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     if (!strcmp(key, "growth")) { *value = ls->last_growth; return 0; }  // BUNCHKAUFMAN: max|d_k| / max|a_ij| of the static-pivot tier
     if (!strcmp(key, "sign_changes")) { *value = (double)ls->last_sign_changes; return 0; }  // ... and sign changes along its pivots
     if (!strcmp(key, "bk_count")) { *value = ls->bk_count; return 0; }
+    if (!strcmp(key, "bk_panel_multi")) { *value = ls->bk_multi_last ? 1.0 : 0.0; return 0; }
+    if (!strcmp(key, "bk_mw_fallbacks")) { *value = ls->bk_mw_fallbacks; return 0; }
     if (!strcmp(key, "dag_ntasks")) { *value = ls->dag_ntasks; return 0; }    // task-DAG schedule: bulk tasks, ...
     if (!strcmp(key, "dag_ntasks1")) { *value = ls->dag_ntasks1; return 0; }  // ... of them in the first phase, ...
     if (!strcmp(key, "dag_js2")) { *value = ls->dag_js2; return 0; }          // ... first strip-column of the second phase

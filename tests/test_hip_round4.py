@@ -294,3 +294,82 @@ def test_options_pinned_by_the_environment_are_reported():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "PINNED 1.0 0.0" in r.stdout and "ALGO 1.0" in r.stdout
     assert "ignored" in r.stderr and "panel_algo" in r.stderr
+
+
+def _indefinite(kind, N, rng):
+    if kind == "random":
+        S = rng.standard_normal((N, N))
+        return np.asfortranarray((S + S.T) / 2)
+    n1 = 2 * N // 3                          # [[H, J'], [J, 0]] with an indefinite H: needs 2x2 pivots
+    H = rng.standard_normal((n1, n1)); H = (H + H.T) / 2
+    J = rng.standard_normal((N - n1, n1))
+    A = np.zeros((N, N)); A[:n1, :n1] = H; A[n1:, :n1] = J; A[:n1, n1:] = J.T
+    return np.asfortranarray(A)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,N", [("random", 700), ("saddle", 1000), ("random", 2500)])
+def test_multi_workgroup_bunchkaufman_panels_take_the_pivots_of_the_one_workgroup_panels(ctx, kind, N):
+    """the pivoted tier's panels are factored by a workgroup per 256 rows (virtual positions, one or
+    two message rounds per column; csrc/bk.hip, host model tools/bk_mw_model.py).  Same pivoting rule, same order of the
+    column updates: the permutation, the 1x1 / 2x2 pattern and the factor must equal the one-workgroup panels' (option
+    bk_panel_wgs = 1), and both reconstruct P A P' = L D L'."""
+    rng = np.random.default_rng(N)
+    A = _indefinite(kind, N, rng)
+    out = []
+    for wgs in (0, 1):
+        M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+        M.set_option("bk_panel_wgs", wgs)
+        M.factorize()
+        inertia = M.inertia()
+        assert M.bk_info()[0] and M.get_stat("bk_panel_multi") == (1.0 if wgs == 0 else 0.0) and M.get_stat("bk_mw_fallbacks") == 0
+        err, perm, doff = _bk_reconstruct_r4(M, A)
+        assert err <= 1e-11 * np.abs(A).max() * max(1, N / 16)
+        Lg, D = M.get_factor()
+        out.append((inertia, perm.copy(), doff.copy(), np.tril(Lg, -1), D.copy()))
+        M.close()
+    (i0, p0, o0, L0, D0), (i1, p1, o1, L1, D1) = out
+    assert i0 == i1 and np.array_equal(p0, p1) and np.array_equal(o0 != 0, o1 != 0)
+    assert np.abs(D0 - D1).max() <= 1e-9 * np.abs(D1).max() and np.abs(L0 - L1).max() <= 1e-9 * max(1.0, np.abs(L1).max())
+
+
+def _bk_reconstruct_r4(M, A):
+    active, count, perm, doff = M.bk_info()
+    assert active
+    Lg, D = M.get_factor()
+    N = A.shape[0]
+    Lu = np.tril(Lg, -1) + np.eye(N)
+    Dm = np.diag(D)
+    for k in np.nonzero(doff)[0]:
+        Dm[k + 1, k] = Dm[k, k + 1] = doff[k]
+    Af = np.tril(A) + np.tril(A, -1).T
+    return np.abs(Lu @ Dm @ Lu.T - Af[np.ix_(perm, perm)]).max(), perm, doff
+
+
+@pytest.mark.gpu
+def test_blocked_bunchkaufman_at_the_bench_order(ctx):
+    """... and at the bench's order, N = 11 192 (random symmetric indefinite: nearly every column needs the partner
+    search): inertia = dsytrf's, backward error within 1e3 x dsytrs's, and the tier's time is printed."""
+    import time
+    N = 11192
+    rng = np.random.default_rng(7)
+    A = _indefinite("random", N, rng)
+    b = rng.standard_normal(N)
+    ref = LapackCPUSolver(A, BUNCHKAUFMAN).factorize()
+    xr = ref.solve_linear_system(b.copy())
+    nrm = np.abs(A).sum(axis=1).max()
+    bwd = lambda x: np.abs(A @ x - b).max() / (nrm * np.abs(x).max() + np.abs(b).max())
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+    M.factorize()
+    assert M.inertia() == ref.inertia() and M.bk_info()[0] and M.get_stat("bk_panel_multi") == 1.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    M.factorize()
+    inertia = M.inertia()
+    ms = 1e3 * (time.perf_counter() - t0)
+    assert inertia == ref.inertia() and M.get_stat("bk_mw_fallbacks") == 0
+    x = M.solve_linear_system(b.copy())
+    assert bwd(x) <= 1e3 * bwd(xr) + 1e-15, (bwd(x), bwd(xr))
+    print(f"N={N}: transfer + static tier + pivoted tier + inertia {ms:.1f} ms; backward error {bwd(x):.1e} (dsytrs {bwd(xr):.1e})")
+    assert ms < 1000.0
+    M.close()
