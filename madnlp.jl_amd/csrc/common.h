@@ -198,6 +198,12 @@ int launch_gemm_nt(hipStream_t s, int mode, int64_t M, int64_t N, int64_t K,
                    const double* A, int64_t lda, const double* B, int64_t ldb,
                    double* C, int64_t ldc, const double* colscale, double* C2, int64_t ldc2,
                    const int* info_flag);
+// one right-hand-side block of mnk_launch_trsm64_batch (factor.hip): its rows X (and V for LDL^T, else NULL) and the factor's
+// diagonal blocks / their 16 x 16 inverses / D^-1 / info word
+struct TrsmBatchRec { double* X; double* V; const double* dblk; const double* inv16; const double* dinv; const int* info; };
+struct GemmBatchRec { const double* A; const double* B; double* C; const int* info; };   // (info != 0: the triple is skipped)
+int launch_gemm_nt_batch(hipStream_t s, int64_t M, int64_t N, int64_t K, const GemmBatchRec* recs_dev, int nbatch, int64_t lda,
+                         int64_t ldb, int64_t ldc);
 int launch_gemm_nt_lower_small(hipStream_t s, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
                                const double* B, int64_t ldb, double* C, int64_t ldc, const int* info_flag);
 int gemm_nt_lower_tiles(int64_t M, int64_t N);

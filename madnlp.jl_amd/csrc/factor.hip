@@ -96,12 +96,11 @@ __device__ __forceinline__ void growth_fold(unsigned long long* word, double vm)
 // X[row0 + l15][16 cb + l4 + 4 r] (the C^T layout of gemm_f64.hip, so register r of X^T[ib] IS the
 // B operand of k-step r in the next product and nothing is ever shuffled).
 template <bool LDL, int NS>
-__global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
-                                                           const double* __restrict__ Dblk,
-                                                           const double* __restrict__ inv16,
-                                                           const double* __restrict__ dinv, double* __restrict__ W,
-                                                           int64_t ldw, int64_t wcol, int* __restrict__ info,
-                                                           unsigned long long* __restrict__ vmax = nullptr) {
+__device__ __forceinline__ void trsm64_mfma_body(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
+                                                 const double* __restrict__ Dblk, const double* __restrict__ inv16,
+                                                 const double* __restrict__ dinv, double* __restrict__ W, int64_t ldw,
+                                                 int64_t wcol, const int* __restrict__ info,
+                                                 unsigned long long* __restrict__ vmax) {
     if (*info != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -165,6 +164,29 @@ __global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F
                 }
             }
     if (LDL) growth_fold(vmax, vm);
+}
+
+template <bool LDL, int NS>
+__global__ __launch_bounds__(256) void trsm64_mfma_kernel(double* __restrict__ F, int64_t ld, int64_t j0, int64_t Np,
+                                                           const double* __restrict__ Dblk,
+                                                           const double* __restrict__ inv16,
+                                                           const double* __restrict__ dinv, double* __restrict__ W,
+                                                           int64_t ldw, int64_t wcol, int* __restrict__ info,
+                                                           unsigned long long* __restrict__ vmax = nullptr) {
+    trsm64_mfma_body<LDL, NS>(F, ld, j0, Np, Dblk, inv16, dinv, W, ldw, wcol, info, vmax);
+}
+
+// The same block substitution for the rows of SEVERAL independent right-hand-side blocks against their own factors in one
+// launch (blockIdx.y: which one; the Schur stage's per-scenario sweeps, schur.hip): rows X_i (nrows x ., leading dimension
+// ldr) <- X_i[:, j0 : j0 + 64] L_i,jj^-T (LDL: V_i gets that, X_i gets it times D^-1).
+template <bool LDL>
+__global__ __launch_bounds__(256) void trsm64_mfma_batch_kernel(const TrsmBatchRec* __restrict__ recs, int64_t ldr, int64_t j0,
+                                                                 int64_t nrows) {
+    const TrsmBatchRec rec = recs[blockIdx.y];
+    // (the body addresses rows j0 + 64 ... of ONE matrix: shift the row blocks so that its first such row is their row 0)
+    trsm64_mfma_body<LDL, 1>(rec.X - (j0 + NBI), ldr, j0, j0 + NBI + nrows, rec.dblk + (j0 / NBI) * 4096,
+                             rec.inv16 + (j0 / NBI) * 1024, rec.dinv, rec.V != nullptr ? rec.V - (j0 + NBI) : nullptr, ldr, j0,
+                             rec.info, nullptr);
 }
 
 __device__ __forceinline__ double readlane_f64(double x, int lane) {
@@ -1563,6 +1585,17 @@ int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows,
     else
         hipLaunchKernelGGL((trsm64_mfma_kernel<false, 1>), dim3(grid), dim3(256), 0, s, Fp, ldr, j0, j0 + NBI + nrows, dblk,
                            inv16, ls->dinv.p, (double*)nullptr, (int64_t)0, (int64_t)0, ls->info_dev.p);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_launch_trsm64_batch(hipStream_t s, bool ldl, const mnk::TrsmBatchRec* recs_dev, int nbatch, int64_t j0, int64_t nrows,
+                            int64_t ldr) {
+    if (nbatch <= 0 || nrows <= 0) return 0;
+    MNK_REQUIRE(nrows % 16 == 0 && j0 % NBI == 0, "mnk_launch_trsm64_batch: 16-row multiples and a block-aligned column");
+    const dim3 grid((unsigned)((nrows / 16 + 3) / 4), (unsigned)nbatch);
+    if (ldl) hipLaunchKernelGGL(trsm64_mfma_batch_kernel<true>, grid, dim3(256), 0, s, recs_dev, ldr, j0, nrows);
+    else hipLaunchKernelGGL(trsm64_mfma_batch_kernel<false>, grid, dim3(256), 0, s, recs_dev, ldr, j0, nrows);
     MNK_HIP(hipGetLastError());
     return 0;
 }

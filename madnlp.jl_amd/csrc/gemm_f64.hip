@@ -94,6 +94,50 @@ __global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_qu
     }
 }
 
+// The same product for a BATCH of independent triples (A, B, C) of one shape in one launch: blockIdx.y is the batch index,
+// the pointers come from a record array in device memory (the Schur stage's per-scenario sweeps: schur.hip).
+template <int WM, int WN, int WT, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, tile_occ(WM, WN, WT)) void gemm_nt_batch_kernel(
+    int64_t M, int64_t N, int64_t K, const GemmBatchRec* __restrict__ recs, int64_t lda, int64_t ldb, int64_t ldc, int ntm,
+    int nc, int sw) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const GemmBatchRec rec = recs[blockIdx.y];
+    if (rec.info != nullptr && *rec.info != 0) return;
+    int tm, tn;
+    decode_tile<MODE>((int)blockIdx.x, ntm, nc, sw, tm, tn);
+    gemm_nt_tile<WM, WN, WT, MODE, false, 0, tile_bk(WM, WN, WT)>(tm, tn, M, N, K, rec.A, lda, rec.B, ldb, rec.C, ldc, nullptr,
+                                                                      nullptr, 0, smem_raw);
+}
+
+template <int WM, int WN, int WT>
+static int launch_batch_t(hipStream_t s, int64_t M, int64_t N, int64_t K, const GemmBatchRec* recs, int nbatch, int64_t lda,
+                          int64_t ldb, int64_t ldc) {
+    constexpr int BM = 16 * WT * WM, BN = 16 * WT * WN;
+    const int ntm = (int)((M + BM - 1) / BM), ntn = (int)((N + BN - 1) / BN);
+    const size_t smem = 2 * tile_bk(WM, WN, WT) * ((BM + 16) + (BN + 16)) * sizeof(double);
+    auto kern = gemm_nt_batch_kernel<WM, WN, WT, 0>;
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev = 0;
+    MNK_HIP(hipGetDevice(&dev));
+    if (!(attr_devs.load(std::memory_order_relaxed) >> (dev & 63) & 1)) {
+        MNK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn, nbatch), dim3(64 * WM * WN), smem, s, M, N, K, recs, lda, ldb, ldc, ntm,
+                       ntn < ntm ? ntn : ntm, 1);
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+// C_i -= A_i B_i^T for i < nbatch (mode 0 of launch_gemm_nt; the same tile shapes)
+int launch_gemm_nt_batch(hipStream_t s, int64_t M, int64_t N, int64_t K, const GemmBatchRec* recs, int nbatch, int64_t lda,
+                         int64_t ldb, int64_t ldc) {
+    if (M <= 0 || N <= 0 || nbatch <= 0) return 0;
+    MNK_REQUIRE(M % 64 == 0 && N % 64 == 0 && K % BK == 0 && K > 0, "gemm_nt_batch: M,N must be multiples of 64, K of 16");
+    if (N <= 64) return launch_batch_t<4, 1, 4>(s, M, N, K, recs, nbatch, lda, ldb, ldc);
+    return launch_batch_t<2, 2, 4>(s, M, N, K, recs, nbatch, lda, ldb, ldc);
+}
+
 // width of the super-columns of the lower-tile enumeration (MNK_SUPER_W overrides; 1 = column-by-column)
 static int tile_super_width() {
     static const int sw = getenv("MNK_SUPER_W") ? std::max(1, atoi(getenv("MNK_SUPER_W"))) : 8;

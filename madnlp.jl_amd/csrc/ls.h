@@ -184,6 +184,8 @@ int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);  
 // Xrows(:, j0:j0+64), V written to Vrows(:, j0:j0+64) (LDL only); both row blocks have leading dimension ldr.
 int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows, double* Vrows, int64_t ldr, int64_t nrows);
 int mnk_ls_run_bunchkaufman(mnk_ls* ls);                                  // bk.hip
+int mnk_launch_trsm64_batch(hipStream_t s, bool ldl, const mnk::TrsmBatchRec* recs_dev, int nbatch, int64_t j0, int64_t nrows,
+                            int64_t ldr);   // factor.hip
 int mnk_ls_bk_permute(mnk_ls* ls, double* x, double* tmp, bool forward);  // x <- P x (forward) / P^T x
 int mnk_ls_bk_dsolve(mnk_ls* ls, double* y);                              // y <- D^-1 y, 1x1 / 2x2 blocks
 int mnk_ls_bk_inertia(mnk_ls* ls, unsigned long long* out_dev);

@@ -36,14 +36,12 @@ struct mnk_schur {
     mnk_ls* ls_s = nullptr;
     std::vector<int> info_k;
     bool built = false;
-    // build_kkt!: the scenarios' forward sweeps and rank-blk updates are independent chains of ~18 small dependent launches
-    // each; they run on NLANE streams side by side (lane l: scenarios l, l + NLANE, ...; its own X / V work buffers and its own
-    // partial sum of S, added up in lane order at the end)
-    static constexpr int NLANE = 4;
-    hipStream_t lane_s[NLANE] = {nullptr, nullptr, nullptr, nullptr};   // lane 0 = the context's stream
-    hipEvent_t lane_ev[NLANE] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr;
-    mnk::DevBuf<double> lane_X[NLANE], lane_V[NLANE], lane_S[NLANE];    // (lane 0 uses Cp / Tt / Sp)
+    // build_kkt!: the forward sweeps of ALL scenarios with a static-pivot factor run as grouped launches (one per 64-column
+    // step: blockIdx.y = scenario) on per-scenario X / V buffers, their products X_k V_k' as one batched product into
+    // per-scenario partial sums that are added to S in scenario order (the same bits whatever the timing)
+    mnk::DevBuf<double> Xall, Vall, Pall;   // ns x (ndp x Npb) | the same (LDL^T only) | ns x (ndp x ndp)
+    mnk::DevBuf<char> recs;                 // device copies of the launch records
+    mnk::DevBuf<int> fast_k;                // the scenarios on the grouped path
 };
 
 namespace mnk {
@@ -90,11 +88,22 @@ __global__ __launch_bounds__(256) void schur_gemv_t_kernel(double* __restrict__ 
     if (r < rows) s0 = fma(a[r], x[r], s0);
     y[c] = s0 + s1;
 }
-// S += P1 + P2 + P3 (the lanes' partial sums, fixed order)
-__global__ void schur_lane_sum_kernel(double* __restrict__ S, const double* __restrict__ p1, const double* __restrict__ p2,
-                                      const double* __restrict__ p3, int64_t n) {
+// S += P_0 + P_1 + ... (the scenarios' partial sums, in scenario order)
+__global__ void schur_partial_sum_kernel(double* __restrict__ S, const double* __restrict__ P, int64_t np, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) S[i] = ((S[i] + p1[i]) + p2[i]) + p3[i];
+    if (i >= n) return;
+    double v = S[i];
+    for (int64_t k = 0; k < np; ++k) v += P[k * n + i];
+    S[i] = v;
+}
+// X_i (ndp x Npb, zero padded) = C_dk of scenario k = fast_k[i]   (blockIdx.y = i)
+__global__ void schur_copy_batch_kernel(double* __restrict__ Xall, int64_t ndp, int64_t Npb, const double* __restrict__ Call,
+                                        int64_t nd, int64_t blk, const int* __restrict__ fast_k) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= ndp * Npb) return;
+    const int64_t r = e % ndp, c = e / ndp;
+    const double* src = Call + (int64_t)fast_k[blockIdx.y] * nd * blk;
+    Xall[(int64_t)blockIdx.y * ndp * Npb + e] = (r < nd && c < blk) ? src[r + c * nd] : 0.0;
 }
 // y[i] -= x[i]
 __global__ void schur_sub_kernel(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
@@ -126,16 +135,14 @@ int mnk_schur_create(mnk_ctx* ctx, int64_t ns_local, int64_t blk, int64_t nd, in
     rc |= h->Tt.alloc((size_t)h->ndp * h->Npb + SLACK);
     rc |= h->tmpk.alloc((size_t)h->Npb * (size_t)std::max<int64_t>(ns_local, 1));   // (one vector per scenario: their solves run as a batch)
     rc |= h->Sp.alloc((size_t)h->ndp * h->ndp + SLACK);
-    if (ns_local > 1) {   // lanes 1..: streams, events, work buffers (a single scenario needs none)
-        mnk::LaunchLock lock;
-        for (int l = 1; l < mnk_schur::NLANE && !rc; ++l) {
-            rc |= h->lane_X[l].alloc((size_t)h->ndp * h->Npb + SLACK);
-            rc |= h->lane_V[l].alloc((size_t)h->ndp * h->Npb + SLACK);
-            rc |= h->lane_S[l].alloc((size_t)h->ndp * h->ndp + SLACK);
-            if (hipStreamCreateWithFlags(&h->lane_s[l], hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&h->lane_ev[l], hipEventDisableTiming) != hipSuccess) rc |= -2;
-        }
-        if (hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming) != hipSuccess) rc |= -2;
+    {
+        const size_t nsl = (size_t)std::max<int64_t>(ns_local, 1);
+        const size_t nstep = (size_t)(h->Npb / NBI);
+        rc |= h->Xall.alloc(nsl * h->ndp * h->Npb + SLACK);
+        if (algo != MNK_CHOLESKY) rc |= h->Vall.alloc(nsl * h->ndp * h->Npb + SLACK);
+        rc |= h->Pall.alloc(nsl * h->ndp * h->ndp + SLACK);
+        rc |= h->recs.alloc(nsl * (sizeof(mnk::TrsmBatchRec) + nstep * sizeof(mnk::GemmBatchRec)) + 64);
+        rc |= h->fast_k.alloc(nsl);
     }
     if (rc) { (void)hipGetLastError(); delete h; return -2; }
     for (int64_t k = 0; k < ns_local && !rc; ++k) {
@@ -162,15 +169,6 @@ int mnk_schur_destroy(mnk_schur* h) {
     (void)mnk::stream_wait(h->ctx->stream);
     for (mnk_ls* l : h->ls_k) mnk_ls_destroy(l);
     if (h->ls_s) mnk_ls_destroy(h->ls_s);
-    {
-        mnk::LaunchLock lock;
-        mnk::quiesce_persistent();
-        for (int l = 1; l < mnk_schur::NLANE; ++l) {
-            if (h->lane_s[l]) { (void)mnk::stream_wait(h->lane_s[l]); (void)hipStreamDestroy(h->lane_s[l]); }
-            if (h->lane_ev[l]) (void)hipEventDestroy(h->lane_ev[l]);
-        }
-        if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
-    }
     mnk_ctx* ctx = h->ctx;
     delete h;
     mnk_ctx_child_gone(ctx);
@@ -215,90 +213,74 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         const int rc_end = mnk_factorize_batch_end();
         if (rc || rc_end) return rc ? rc : rc_end;
     }
-    // Phase 1b + 2 per scenario, on NLANE streams side by side (the tier that produced each factor is known first: the info
-    // fetch of a batch member waits for its own factorization only)
+    // (the tier that produced each factor is known first: the info fetch of a batch member waits for its own factorization)
+    std::vector<int> fast, slow;
     for (int64_t k = 0; k < h->ns; ++k) {
         int rc = mnk_ls_fetch_info(h->ls_k[k]);
         if (rc) return rc;
         h->info_k[k] = h->ls_k[k]->info;
+        const bool grouped = !h->ls_k[k]->bk_active && h->info_k[k] == 0 && h->ls_k[k]->algo == h->ls_k[0]->algo &&
+                             h->ls_k[k]->ld == h->ls_k[0]->ld;
+        (grouped ? fast : slow).push_back((int)k);
     }
-    const int nlane = h->lane_s[1] != nullptr ? (int)std::min<int64_t>(mnk_schur::NLANE, h->ns) : 1;
-    if (nlane > 1) {
-        MNK_HIP(hipEventRecord(h->fork_ev, s));
-        for (int l = 1; l < nlane; ++l) {
-            MNK_HIP(hipStreamWaitEvent(h->lane_s[l], h->fork_ev, 0));
-            MNK_HIP(hipMemsetAsync(h->lane_S[l].p, 0, (size_t)ndp * ndp * sizeof(double), h->lane_s[l]));
+    const int64_t Npb = h->Npb;
+    if (!fast.empty()) {
+        // Phase 1b, fast path (static-pivot factor A_k = L D L' or L L'):  C A^-1 C' = (C L^-T) D^-1 (C L^-T)', so only the
+        // FORWARD sweep is needed, as a right-side triangular solve of the nd rows of C_dk -- left-looking over the 64-column
+        // blocks of L: an MFMA update with the finished blocks, then block substitution on MFMA against the diagonal block.
+        // One launch of each per step for ALL these scenarios (round 3: ~20 launches per scenario, 13.3 ms for 16 of them;
+        // four streams side by side: 5.2 ms; the host's launch rate was the bound).
+        const int nf = (int)fast.size();
+        const bool ldl = h->ls_k[fast[0]]->algo == MNK_LDL;
+        const int nstep = (int)(Npb / NBI);
+        std::vector<mnk::TrsmBatchRec> tr(nf);
+        std::vector<mnk::GemmBatchRec> gr((size_t)nstep * nf);
+        for (int i = 0; i < nf; ++i) {
+            mnk_ls* ls = h->ls_k[fast[i]];
+            double* X = h->Xall.p + (size_t)i * ndp * Npb;
+            double* V = ldl ? h->Vall.p + (size_t)i * ndp * Npb : X;
+            tr[i] = {X, ldl ? V : nullptr, ls->dblk.p, ls->inv16.p, ls->dinv.p, ls->info_dev.p};
+            for (int j = 1; j < nstep; ++j)   // X[:, block j] -= V[:, 0 : 64 j] L[block j, 0 : 64 j]'
+                gr[(size_t)(j - 1) * nf + i] = {V, ls->fact.p + (int64_t)j * NBI, X + (int64_t)j * NBI * ndp, ls->info_dev.p};
+            gr[(size_t)(nstep - 1) * nf + i] = {X, V, h->Pall.p + (size_t)i * ndp * ndp, ls->info_dev.p};   // P_i -= X V'
         }
-    }
-    for (int64_t k = 0; k < h->ns; ++k) {
-        const int lane = (int)(k % nlane);
-        hipStream_t sl = lane == 0 ? s : h->lane_s[lane];
-        double* Xl = lane == 0 ? h->Cp.p : h->lane_X[lane].p;
-        double* Vl = lane == 0 ? h->Tt.p : h->lane_V[lane].p;
-        double* Sl = lane == 0 ? h->Sp.p : h->lane_S[lane].p;
+        char* rdev = h->recs.p;
+        mnk::TrsmBatchRec* tr_dev = reinterpret_cast<mnk::TrsmBatchRec*>(rdev);
+        mnk::GemmBatchRec* gr_dev = reinterpret_cast<mnk::GemmBatchRec*>(rdev + (size_t)h->ns * sizeof(mnk::TrsmBatchRec));
+        MNK_HIP(hipMemcpyAsync(tr_dev, tr.data(), tr.size() * sizeof(mnk::TrsmBatchRec), hipMemcpyHostToDevice, s));
+        MNK_HIP(hipMemcpyAsync(gr_dev, gr.data(), gr.size() * sizeof(mnk::GemmBatchRec), hipMemcpyHostToDevice, s));
+        MNK_HIP(hipMemcpyAsync(h->fast_k.p, fast.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, s));
+        MNK_HIP(mnk::stream_wait(s));   // (the host vectors go out of scope)
+        hipLaunchKernelGGL(schur_copy_batch_kernel, dim3((unsigned)((ndp * Npb + 255) / 256), (unsigned)nf), dim3(256), 0, s,
+                           h->Xall.p, ndp, Npb, h->C.p, nd, blk, h->fast_k.p);
+        const int64_t ldf = h->ls_k[fast[0]]->ld;
         int rc = 0;
-        mnk_ls* ls = h->ls_k[k];
-        const double* Ck = h->C.p + k * nd * blk;
-        if (!ls->bk_active && h->info_k[k] == 0) {
-            // Fast path (static-pivot factor A_k = L D L' or L L'):  C A^-1 C' = (C L^-T) D^-1 (C L^-T)', so only the
-            // FORWARD sweep is needed, as a right-side triangular solve of the nd rows of C_dk -- left-looking over the
-            // 64-column blocks of L: an MFMA update with the finished blocks, then block substitution on MFMA
-            // (trsm64_mfma_kernel) against the diagonal block.  X = C L^-T D^-1 lands in Xl, V = C L^-T in Vl.
-            const int64_t Npb = h->Npb;
-            hipLaunchKernelGGL(schur_copy_kernel, dim3((unsigned)((ndp * Npb + 255) / 256)), dim3(256), 0, sl, Xl, ndp, ndp, Npb, Ck, nd, nd, blk, 0);
-            const bool ldl = ls->algo == MNK_LDL;
-            double* X = Xl;
-            double* V = ldl ? Vl : Xl;
-            for (int64_t j0 = 0; j0 < Npb; j0 += NBI) {
-                if (j0 > 0) {
-                    rc = launch_gemm_nt(sl, 0, ndp, NBI, j0, V, ndp, ls->fact.p + j0, ls->ld, X + j0 * ndp, ndp, nullptr,
-                                        nullptr, 0, nullptr);
-                    if (rc) return rc;
-                }
-                rc = mnk_ls_right_trsm_rows(ls, sl, j0, X, ldl ? V : nullptr, ndp, ndp);
-                if (rc) return rc;
-            }
-            // Phase 2 (reference :993-999): S -= X V'
-            rc = launch_gemm_nt(sl, 0, ndp, ndp, Npb, X, ndp, V, ndp, Sl, ndp, nullptr, nullptr, 0, nullptr);
-            if (rc) return rc;
-        } else {
-            // Pivoted (Bunch-Kaufman tier) or failed factor: T_k = A_k^-1 C_dk' column by column, as the reference does
-            // (on the context's stream, behind everything the lanes have queued so far: the solver's own work vectors)
-            if (nlane > 1) {
-                for (int l = 1; l < nlane; ++l) {
-                    MNK_HIP(hipEventRecord(h->lane_ev[l], h->lane_s[l]));
-                    MNK_HIP(hipStreamWaitEvent(s, h->lane_ev[l], 0));
-                }
-            }
-            double* Tk = h->T.p;
-            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(blk * nd), Tk, blk, blk, nd, Ck, nd, nd, blk, 1);
-            rc = mnk_ls_solve(ls, Tk, nd, blk, MNK_DEVICE);
-            if (!rc) rc = mnk_ls_check_solve(ls);   // (T_k feeds the Schur complement: an aborted solve must not get that far)
-            if (rc) return rc;
-            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Cp.p, ndp, ndp, blkp, Ck, nd, nd, blk, 0);
-            hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Tt.p, ndp, ndp, blkp, Tk, blk, blk, nd, 1);
-            MNK_HIP(hipGetLastError());
-            rc = launch_gemm_nt(s, 0, ndp, ndp, blkp, h->Cp.p, ndp, h->Tt.p, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
-            if (rc) return rc;
-            if (nlane > 1) {   // (lane 0's buffers were used out of turn: the lanes continue behind this scenario)
-                MNK_HIP(hipEventRecord(h->fork_ev, s));
-                for (int l = 1; l < nlane; ++l) MNK_HIP(hipStreamWaitEvent(h->lane_s[l], h->fork_ev, 0));
-            }
+        for (int j = 0; j < nstep && !rc; ++j) {
+            if (j > 0) rc = launch_gemm_nt_batch(s, ndp, NBI, (int64_t)j * NBI, gr_dev + (size_t)(j - 1) * nf, nf, ndp, ldf, ndp);
+            if (!rc) rc = mnk_launch_trsm64_batch(s, ldl, tr_dev, nf, (int64_t)j * NBI, ndp, ndp);
         }
-    }
-    if (nlane > 1) {
-        for (int l = 1; l < nlane; ++l) {
-            MNK_HIP(hipEventRecord(h->lane_ev[l], h->lane_s[l]));
-            MNK_HIP(hipStreamWaitEvent(s, h->lane_ev[l], 0));
-        }
-        const double* p1 = h->lane_S[1].p;
-        const double* p2 = nlane > 2 ? h->lane_S[2].p : h->lane_S[1].p + 0;
-        const double* p3 = nlane > 3 ? h->lane_S[3].p : nullptr;
-        // (lanes that do not exist contribute zeros: their buffers are zero-filled below)
-        if (nlane == 2) { MNK_HIP(hipMemsetAsync(h->lane_S[2].p, 0, (size_t)ndp * ndp * sizeof(double), s)); p2 = h->lane_S[2].p; }
-        if (nlane <= 3) { MNK_HIP(hipMemsetAsync(h->lane_S[3].p, 0, (size_t)ndp * ndp * sizeof(double), s)); p3 = h->lane_S[3].p; }
-        hipLaunchKernelGGL(schur_lane_sum_kernel, MNK_GRID1(ndp * ndp), h->Sp.p, p1, p2, p3, ndp * ndp);
+        if (rc) return rc;
+        // Phase 2 (reference :993-999): S -= sum_k X_k V_k'
+        MNK_HIP(hipMemsetAsync(h->Pall.p, 0, (size_t)nf * ndp * ndp * sizeof(double), s));
+        rc = launch_gemm_nt_batch(s, ndp, ndp, Npb, gr_dev + (size_t)(nstep - 1) * nf, nf, ndp, ndp, ndp);
+        if (rc) return rc;
+        hipLaunchKernelGGL(schur_partial_sum_kernel, MNK_GRID1(ndp * ndp), h->Sp.p, h->Pall.p, (int64_t)nf, ndp * ndp);
         MNK_HIP(hipGetLastError());
+    }
+    for (int k : slow) {
+        // Pivoted (Bunch-Kaufman tier) or failed factor: T_k = A_k^-1 C_dk' column by column, as the reference does
+        mnk_ls* ls = h->ls_k[k];
+        const double* Ck = h->C.p + (int64_t)k * nd * blk;
+        double* Tk = h->T.p;
+        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(blk * nd), Tk, blk, blk, nd, Ck, nd, nd, blk, 1);
+        int rc = mnk_ls_solve(ls, Tk, nd, blk, MNK_DEVICE);
+        if (!rc) rc = mnk_ls_check_solve(ls);   // (T_k feeds the Schur complement: an aborted solve must not get that far)
+        if (rc) return rc;
+        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Cp.p, ndp, ndp, blkp, Ck, nd, nd, blk, 0);
+        hipLaunchKernelGGL(schur_copy_kernel, MNK_GRID1(ndp * blkp), h->Tt.p, ndp, ndp, blkp, Tk, blk, blk, nd, 1);
+        MNK_HIP(hipGetLastError());
+        rc = launch_gemm_nt(s, 0, ndp, ndp, blkp, h->Cp.p, ndp, h->Tt.p, ndp, h->Sp.p, ndp, nullptr, nullptr, 0, nullptr);
+        if (rc) return rc;
     }
     MNK_HIP(hipMemcpy2DAsync(S_out, lds_out * sizeof(double), h->Sp.p, ndp * sizeof(double), nd * sizeof(double), nd,
                              hipMemcpyDeviceToDevice, s));
