@@ -58,36 +58,6 @@ __global__ void schur_copy_kernel(double* __restrict__ dst, int64_t ldd, int64_t
     dst[r + c * ldd] = v;
 }
 
-// y[r] += alpha * sum_c A[r + c*lda] x[c]   (rows x cols, fixed summation order: deterministic)
-__global__ __launch_bounds__(256) void schur_gemv_kernel(double* __restrict__ y, const double* __restrict__ A, int64_t lda,
-                                                         const double* __restrict__ x, int64_t rows, int64_t cols, double alpha) {
-    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    double s0 = 0.0, s1 = 0.0;
-    int64_t c = 0;
-    for (; c + 1 < cols; c += 2) {
-        s0 = fma(A[r + c * lda], x[c], s0);
-        s1 = fma(A[r + (c + 1) * lda], x[c + 1], s1);
-    }
-    if (c < cols) s0 = fma(A[r + c * lda], x[c], s0);
-    y[r] += alpha * (s0 + s1);
-}
-
-// y[c] = sum_r A[r + c*lda] x[r]   (A is rows x cols): one thread per column, fixed order
-__global__ __launch_bounds__(256) void schur_gemv_t_kernel(double* __restrict__ y, const double* __restrict__ A, int64_t lda,
-                                                           const double* __restrict__ x, int64_t rows, int64_t cols) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    const double* a = A + c * lda;
-    double s0 = 0.0, s1 = 0.0;
-    int64_t r = 0;
-    for (; r + 1 < rows; r += 2) {
-        s0 = fma(a[r], x[r], s0);
-        s1 = fma(a[r + 1], x[r + 1], s1);
-    }
-    if (r < rows) s0 = fma(a[r], x[r], s0);
-    y[c] = s0 + s1;
-}
 // S += P_0 + P_1 + ... (the scenarios' partial sums, in scenario order)
 __global__ void schur_partial_sum_kernel(double* __restrict__ S, const double* __restrict__ P, int64_t np, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -105,10 +75,50 @@ __global__ void schur_copy_batch_kernel(double* __restrict__ Xall, int64_t ndp, 
     const double* src = Call + (int64_t)fast_k[blockIdx.y] * nd * blk;
     Xall[(int64_t)blockIdx.y * ndp * Npb + e] = (r < nd && c < blk) ? src[r + c * nd] : 0.0;
 }
-// y[i] -= x[i]
-__global__ void schur_sub_kernel(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) y[i] -= x[i];
+// The per-scenario vector kernels of a solve, scenario k = blockIdx.y, ONE launch each (ns launches of a few microseconds were
+// most of a solve).  Fixed summation orders: deterministic.
+// P[k][r] = sum_c C_k[r + c*nd] x_k[c], then y[r] = sum_k alpha P[k][r] in scenario order
+__global__ __launch_bounds__(256) void schur_gemv_batch_kernel(double* __restrict__ P, const double* __restrict__ Call, int64_t nd,
+                                                               const double* __restrict__ xall, int64_t blk) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (r >= nd) return;
+    const double* A = Call + k * nd * blk;
+    const double* x = xall + k * blk;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t c = 0;
+    for (; c + 1 < blk; c += 2) {
+        s0 = fma(A[r + c * nd], x[c], s0);
+        s1 = fma(A[r + (c + 1) * nd], x[c + 1], s1);
+    }
+    if (c < blk) s0 = fma(A[r + c * nd], x[c], s0);
+    P[k * nd + r] = s0 + s1;
+}
+__global__ void schur_contrib_sum_kernel(double* __restrict__ y, const double* __restrict__ P, int64_t ns, int64_t nd, double alpha) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= nd) return;
+    double v = 0.0;
+    for (int64_t k = 0; k < ns; ++k) v += alpha * P[k * nd + r];
+    y[r] = v;
+}
+// tmp_k[c] = sum_r C_k[r + c*nd] x_d[r]
+__global__ __launch_bounds__(256) void schur_gemv_t_batch_kernel(double* __restrict__ tmp, int64_t stride, const double* __restrict__ Call,
+                                                                 int64_t nd, const double* __restrict__ x, int64_t blk) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (c >= blk) return;
+    const double* a = Call + k * nd * blk + c * nd;
+    double s0 = 0.0, s1 = 0.0;
+    int64_t r = 0;
+    for (; r + 1 < nd; r += 2) {
+        s0 = fma(a[r], x[r], s0);
+        s1 = fma(a[r + 1], x[r + 1], s1);
+    }
+    if (r < nd) s0 = fma(a[r], x[r], s0);
+    tmp[k * stride + c] = s0 + s1;
+}
+// rhs_k[i] -= tmp_k[i]
+__global__ void schur_sub_batch_kernel(double* __restrict__ y, int64_t blk, const double* __restrict__ tmp, int64_t stride) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (i < blk) y[k * blk + i] -= tmp[k * stride + i];
 }
 
 }  // namespace mnk
@@ -323,16 +333,18 @@ int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d) {
     MNK_REQUIRE(h->built, "mnk_schur_forward: call mnk_schur_build_local first");
     MNK_HIP(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
-    MNK_HIP(hipMemsetAsync(contrib_d, 0, h->nd * sizeof(double), s));
+    if (h->ns == 0) MNK_HIP(hipMemsetAsync(contrib_d, 0, h->nd * sizeof(double), s));
     {   // the scenarios' solves as ONE batch (solve.hip: up to 32 small systems per launch), then the contributions in order
         int rc = mnk_solve_batch_begin();
         for (int64_t k = 0; k < h->ns && !rc; ++k) rc = mnk_ls_solve(h->ls_k[k], rhs_k + k * h->blk, 1, h->blk, MNK_DEVICE);
         const int rc_end = mnk_solve_batch_end();
         if (rc || rc_end) return rc ? rc : rc_end;
     }
-    for (int64_t k = 0; k < h->ns; ++k)
-        hipLaunchKernelGGL(schur_gemv_kernel, MNK_GRID1(h->nd), contrib_d, h->C.p + k * h->nd * h->blk, h->nd,
-                           rhs_k + k * h->blk, h->nd, h->blk, -1.0);
+    if (h->ns > 0) {
+        hipLaunchKernelGGL(schur_gemv_batch_kernel, dim3((unsigned)((h->nd + 255) / 256), (unsigned)h->ns), dim3(256), 0, s, h->Pall.p,
+                           h->C.p, h->nd, rhs_k, h->blk);
+        hipLaunchKernelGGL(schur_contrib_sum_kernel, MNK_GRID1(h->nd), contrib_d, h->Pall.p, h->ns, h->nd, -1.0);
+    }
     MNK_HIP(hipGetLastError());
     return schur_check_solves(h, true, false);
 }
@@ -350,17 +362,18 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
     MNK_REQUIRE(h && x_d && (rhs_k || h->ns == 0), "mnk_schur_backward: NULL argument");
     MNK_HIP(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
-    for (int64_t k = 0; k < h->ns; ++k)
-        hipLaunchKernelGGL(schur_gemv_t_kernel, MNK_GRID1(h->blk), h->tmpk.p + k * h->Npb, h->C.p + k * h->nd * h->blk, h->nd, x_d, h->nd,
-                           h->blk);
+    if (h->ns > 0)
+        hipLaunchKernelGGL(schur_gemv_t_batch_kernel, dim3((unsigned)((h->blk + 255) / 256), (unsigned)h->ns), dim3(256), 0, s, h->tmpk.p,
+                           h->Npb, h->C.p, h->nd, x_d, h->blk);
     {
         int rc = mnk_solve_batch_begin();
         for (int64_t k = 0; k < h->ns && !rc; ++k) rc = mnk_ls_solve(h->ls_k[k], h->tmpk.p + k * h->Npb, 1, h->blk, MNK_DEVICE);
         const int rc_end = mnk_solve_batch_end();
         if (rc || rc_end) return rc ? rc : rc_end;
     }
-    for (int64_t k = 0; k < h->ns; ++k)
-        hipLaunchKernelGGL(schur_sub_kernel, MNK_GRID1(h->blk), rhs_k + k * h->blk, h->tmpk.p + k * h->Npb, h->blk);
+    if (h->ns > 0)
+        hipLaunchKernelGGL(schur_sub_batch_kernel, dim3((unsigned)((h->blk + 255) / 256), (unsigned)h->ns), dim3(256), 0, s, rhs_k, h->blk,
+                           h->tmpk.p, h->Npb);
     MNK_HIP(hipGetLastError());
     return schur_check_solves(h, true, false);
 }
