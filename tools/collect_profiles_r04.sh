@@ -25,3 +25,7 @@ export ROCP_TOOL_LIBRARIES=$GRAFT_REPO_ROOT/tools/devcount/libmnk_devcount.so
 for s in mfma fetch write; do timeout 200 python tools/devcount_dag.py $s 20 > $R/dc_$s.json 2> $R/dc_$s.err; done
 unset ROCP_TOOL_LIBRARIES
 python tools/devcount_report.py $R/dc_mfma.json $R/dc_fetch.json $R/dc_write.json $R/r04_pmc_dag_C3.md $R/r04_pmc_traffic.json | tail -12
+# small-system batches, the Schur stage, the pivoted tier
+python tools/bench_small_batch.py > $R/small_batches.txt 2>&1; tail -4 $R/small_batches.txt | cut -c1-250
+python tools/bench_schur.py 2>/dev/null | grep '^{' > $R/r04_schur_stage.jsonl; python tools/bench_schur.py 128 512 256 2>/dev/null | grep '^{' >> $R/r04_schur_stage.jsonl; cut -c1-200 $R/r04_schur_stage.jsonl
+for n in 4000 11192; do for w in 0 1; do timeout 120 python tools/bk_run.py $n $w 2>/dev/null | tail -1; done; done > $R/bunchkaufman_times.txt; cat $R/bunchkaufman_times.txt
