@@ -261,7 +261,6 @@ constexpr int BKM_T = BKM_ROWS + 64; // threads: leader wave + row owners
 constexpr int BKM_F = 8;             // values per message
 constexpr int BKM_RING = 4;          // message slots in flight
 constexpr int BKM_GMAX = 256;
-constexpr long BKM_SPIN_LIMIT = 1L << 21;   // ~1 s
 
 struct BkMw {
     double* F; int64_t ld; int Np;
@@ -273,6 +272,8 @@ struct BkMw {
     int* cnt; int* cnt_next;                 // {nT, nS} of this panel / of the next one (zeroed here)
     double* dvec; double* doff; int* ptype;
     unsigned seq0;
+    long spin_limit;   // polls a message round may take (option bk_spin_limit)
+    int dbg_missing;   // tests: this workgroup never takes part (option debug_bk_missing; -1: off)
 };
 
 struct BkmCtl {
@@ -290,7 +291,8 @@ __device__ __forceinline__ void bkm_post(unsigned long long* msg, int g, unsigne
 }
 
 // leader wave: all G messages of round `seq` into mv[g * 8 + f]; false: a bounded wait expired (or another workgroup said so)
-__device__ __forceinline__ bool bkm_gather(const unsigned long long* msg, int G, unsigned seq, double* mv, int* fail_word) {
+__device__ __forceinline__ bool bkm_gather(const unsigned long long* msg, int G, unsigned seq, double* mv, int* fail_word,
+                                           long spin_limit) {
     const int lane = threadIdx.x & 63;
     const unsigned long long* base = msg + (size_t)(seq & (BKM_RING - 1)) * BKM_GMAX * BKM_F * 2;
     bool ok = true;
@@ -322,7 +324,7 @@ __device__ __forceinline__ bool bkm_gather(const unsigned long long* msg, int G,
             if (__all(all)) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255) == 0) {
-                if (spins > BKM_SPIN_LIMIT || __hip_atomic_load(fail_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                if (spins > spin_limit || __hip_atomic_load(fail_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     ok = false;
                     break;
                 }
@@ -359,6 +361,8 @@ __global__ __launch_bounds__(BKM_T) void bkp_panel_mw_kernel(BkMw a) {
         if (g == 0 && tid == 0) { st_store(&a.st->p0, p0); st_store(&a.st->kb, 0); }
         return;
     }
+    if (g == a.dbg_missing) return;   // (a peer that never became resident: everyone else must give up, not hang)
+    if (__hip_atomic_load(fail_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (an earlier panel gave up: the factor is void)
     for (int i = tid; i < 68; i += BKM_T) prow[i] = p0 + i;
     if (tid < 4) wc_row[tid] = tid == 0 ? p0 : -1;   // (the first pivot row has no W entries yet, but it is a candidate)
     const int row = p0 + g * BKM_ROWS + t;              // (row owners)
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(BKM_T) void bkp_panel_mw_kernel(BkMw a) {
                 if (lane == 6 && owner_here(n2)) val = ownv[3];
                 bkm_post(a.msg, g, seq, lane, val);
             }
-            bool ok = bkm_gather(a.msg, G, seq, mv, fail_word);
+            bool ok = bkm_gather(a.msg, G, seq, mv, fail_word, a.spin_limit);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (mv[] is read across lanes below: LDS is in order per wave)
             if (slot_q < 0) ok = false;   // (the pivot row's W entries are not in the cache: cannot happen, see the header)
             ++seq;
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(BKM_T) void bkp_panel_mw_kernel(BkMw a) {
                     if (lane == 5 && owner_here(n2)) val = ownv[3];
                     bkm_post(a.msg, g, seq, lane, val);
                 }
-                const bool ok = bkm_gather(a.msg, G, seq, mv, fail_word);
+                const bool ok = bkm_gather(a.msg, G, seq, mv, fail_word, a.spin_limit);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 ++seq;
                 double rm = -1.0;
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(256) void bkp_perm_gather_kernel(const double* __re
                                                               int* __restrict__ perm_tmp, const int* __restrict__ cnt) {
     const int y = blockIdx.y;
     const int p0 = st->p0, r0 = st->p0 + st->kb;
-    if (st->kb <= 0) return;
+    if (st->kb <= 0 || st->fail != 0) return;
     if (y < 64) {
         if (y >= cnt[0]) return;
         const int x = dlist[y], rx = rowof[x];
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(256) void bkp_perm_scatter_kernel(double* __restric
                                                                const int* __restrict__ cnt) {
     const int y = blockIdx.y;
     const int p0 = st->p0, kb = st->kb, r0 = p0 + kb;
-    if (kb <= 0) return;
+    if (kb <= 0 || st->fail != 0) return;
     if (y < 64) {
         if (y >= cnt[0]) return;
         const int x = dlist[y];
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256, 3) void bkp_update_kernel(double* __restrict__
                                                             int64_t ldw, int tile0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int kb = st->kb;
-    if (kb <= 0) return;
+    if (kb <= 0 || st->fail != 0) return;
     const int r0 = st->p0 + kb;
     // lower tiles of the square of `nt` tile rows that starts at tile0, enumerated row by row
     const int b = blockIdx.x;
@@ -901,7 +905,7 @@ static int run_bunchkaufman(mnk_ls* ls, bool multi) {
             const int G = (rows_max + BKM_ROWS - 1) / BKM_ROWS;
             if (multi && G <= gcap) {
                 BkMw a{F, ld, Np, st, W, LW, (int64_t)Np, ls->bk_wv.p, ls->bk_msg.p, rowof, dlist, nullptr, nullptr, ls->dvec.p, ls->bk_doff.p,
-                       ls->bk_ptype.p, (unsigned)(1 + 130 * p)};
+                       ls->bk_ptype.p, (unsigned)(1 + 130 * p), ls->bk_spin_limit, ls->debug_bk_missing};
                 a.cnt = cnt + 2 * (p & 1);
                 a.cnt_next = cnt + 2 * ((p + 1) & 1);
                 hipLaunchKernelGGL(bkp_panel_mw_kernel, dim3(G), dim3(BKM_T), smem_mw, s, a);

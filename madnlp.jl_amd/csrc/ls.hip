@@ -600,6 +600,12 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     if (!strcmp(key, "accept_only_pd")) { ls->accept_only_pd = value != 0; return 0; }  // see mnk_ls_fetch_info
     // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
+    if (!strcmp(key, "bk_spin_limit")) {
+        MNK_REQUIRE(value >= 1024.0, "bk_spin_limit must be at least 1024");
+        ls->bk_spin_limit = (long)value;
+        return 0;
+    }
+    if (!strcmp(key, "debug_bk_missing")) { ls->debug_bk_missing = (int)value; return 0; }
     if (!strcmp(key, "bk_growth_tol")) {
         MNK_REQUIRE(value > 1.0, "bk_growth_tol must be > 1");
         ls->bk_growth_tol = value;

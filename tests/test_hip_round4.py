@@ -373,3 +373,25 @@ def test_blocked_bunchkaufman_at_the_bench_order(ctx):
     print(f"N={N}: transfer + static tier + pivoted tier + inertia {ms:.1f} ms; backward error {bwd(x):.1e} (dsytrs {bwd(xr):.1e})")
     assert ms < 1000.0
     M.close()
+
+
+@pytest.mark.gpu
+def test_multi_workgroup_panel_that_gives_up_is_redone_with_one_workgroup_per_panel(ctx):
+    """The multi-workgroup panels wait for each other's messages with a bound (another process' kernels on the CUs): when a
+    round expires the factorization is void, the matrix is transferred again and factored with one workgroup per panel, and
+    the solver stays there.  Forced here by a workgroup that never takes part (option debug_bk_missing)."""
+    N = 700
+    A = _indefinite("random", N, np.random.default_rng(5))
+    ref = LapackCPUSolver(A, BUNCHKAUFMAN).factorize()
+    M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+    M.set_option("bk_spin_limit", 20000)
+    M.set_option("debug_bk_missing", 1)
+    M.factorize()
+    assert M.inertia() == ref.inertia()
+    assert M.bk_info()[0] and M.get_stat("bk_mw_fallbacks") == 1 and M.get_stat("bk_panel_multi") == 0.0
+    err, perm, doff = _bk_reconstruct_r4(M, A)
+    assert err <= 1e-11 * np.abs(A).max() * max(1, N / 16)
+    M.set_option("debug_bk_missing", -1)
+    M.factorize()                       # (stays on the one-workgroup panels)
+    assert M.inertia() == ref.inertia() and M.get_stat("bk_mw_fallbacks") == 1 and M.get_stat("bk_panel_multi") == 0.0
+    M.close()
