@@ -882,7 +882,8 @@ static int run_bunchkaufman(mnk_ls* ls, bool multi) {
             attr_devs.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
         }
     }
-    const int gcap = std::min(BKM_GMAX, ls->ctx->num_cu);
+    int gcap = std::min(BKM_GMAX, ls->ctx->num_cu);
+    if (ls->bk_max_wgs > 0) gcap = std::min(gcap, ls->bk_max_wgs);
     if (multi) {
         rc = mnk_persist_begin(ls->ctx, s);
         if (rc) return rc;

@@ -149,6 +149,8 @@ struct mnk_ls {
     mnk::DevBuf<unsigned long long> bk_msg;
     mnk::DevBuf<int> bk_aux;
     int bk_panel_wgs = 0;        // option: 0 = a workgroup per 256 rows of the panel, 1 = one workgroup per panel (round 3)
+    int bk_max_wgs = 0;              // option: cap on the workgroups of a multi-workgroup panel (0: one per CU); panels with more
+                                     // than 256 x this many rows are factored by the one-workgroup kernel
     long bk_spin_limit = 1L << 21;   // option: polls one of its message rounds may take (~1 s) before the tier falls back
     int debug_bk_missing = -1;       // tests: a workgroup of the multi-workgroup panel that never takes part
     bool bk_multi_last = false, bk_mw_blocked = false;

@@ -600,6 +600,11 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     if (!strcmp(key, "accept_only_pd")) { ls->accept_only_pd = value != 0; return 0; }  // see mnk_ls_fetch_info
     // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
+    if (!strcmp(key, "bk_max_wgs")) {
+        MNK_REQUIRE(value >= 0.0 && value <= 256.0, "bk_max_wgs must be in 0..256");
+        ls->bk_max_wgs = (int)value;
+        return 0;
+    }
     if (!strcmp(key, "bk_spin_limit")) {
         MNK_REQUIRE(value >= 1024.0, "bk_spin_limit must be at least 1024");
         ls->bk_spin_limit = (long)value;

@@ -347,6 +347,30 @@ def _bk_reconstruct_r4(M, A):
 
 
 @pytest.mark.gpu
+def test_pivoted_tier_that_starts_with_one_workgroup_panels_and_goes_on_with_many(ctx):
+    """Orders beyond 256 rows x the number of CUs start with one-workgroup panels (physical interchanges inside the panel)
+    and switch to the multi-workgroup kernel (virtual positions, per-panel permutation kernels) once the trailing matrix fits:
+    the two kinds must compose.  Exercised at N = 1500 with the cap bk_max_wgs = 3 (panels of more than 768 rows: one
+    workgroup): same pivots and factor as either kind alone."""
+    N = 1500
+    A = _indefinite("random", N, np.random.default_rng(11))
+    out = []
+    for cap in (3, 0):
+        M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+        M.set_option("bk_max_wgs", cap)
+        M.factorize()
+        inertia = M.inertia()
+        err, perm, doff = _bk_reconstruct_r4(M, A)
+        assert M.bk_info()[0] and err <= 1e-11 * np.abs(A).max() * max(1, N / 16)
+        Lg, D = M.get_factor()
+        out.append((inertia, perm.copy(), doff != 0, D.copy(), np.tril(Lg, -1)))
+        M.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.abs(out[0][3] - out[1][3]).max() <= 1e-9 * np.abs(out[1][3]).max()
+    assert np.abs(out[0][4] - out[1][4]).max() <= 1e-9 * max(1.0, np.abs(out[1][4]).max())
+
+
+@pytest.mark.gpu
 def test_blocked_bunchkaufman_at_the_bench_order(ctx):
     """... and at the bench's order, N = 11 192 (random symmetric indefinite: nearly every column needs the partner
     search): inertia = dsytrf's, backward error within 1e3 x dsytrs's, and the tier's time is printed."""
