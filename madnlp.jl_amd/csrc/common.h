@@ -85,6 +85,38 @@ struct LaunchLock {
     LaunchLock& operator=(const LaunchLock&) = delete;
 };
 
+// A host -> device copy from PAGEABLE memory that the runtime carries out while a persistent group of this process is in
+// flight on another stream stops that group for good: both of its kernels are running according to the kernel trace, neither
+// makes progress, the bounded waits expire (tools/first_group_probe.py: ONE such copy by a second host thread is enough;
+// pinned sources, device -> host copies, allocations, kernels and synchronizations of the other thread are harmless -- the
+// first round of a multi-threaded run met it through the other threads' task-list uploads, tools/thread_stress.py).  Every
+// host -> device copy of this library therefore holds the launch mutex (no group is launched meanwhile) and first waits for
+// the last persistent operation in flight; it must be complete (stream_wait) before the guard goes.  Copies issued by OTHER
+// code of the process are outside this protection: INTEGRATION.md section 0.
+struct H2DGuard {
+    bool held;
+    explicit H2DGuard(bool needed = true) : held(needed) {
+        if (held) { launch_mutex().lock(); quiesce_persistent(); }
+    }
+    ~H2DGuard() { if (held) launch_mutex().unlock(); }
+    H2DGuard(const H2DGuard&) = delete;
+    H2DGuard& operator=(const H2DGuard&) = delete;
+};
+
+// host (pageable or not) -> device, complete when it returns
+inline hipError_t h2d_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    H2DGuard guard;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    return e != hipSuccess ? e : stream_wait(s);
+}
+inline hipError_t h2d_copy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipStream_t s) {
+    if (width == 0 || height == 0) return hipSuccess;
+    H2DGuard guard;
+    const hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, s);
+    return e != hipSuccess ? e : stream_wait(s);
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -106,6 +138,7 @@ struct DevBuf {
         int rc = alloc(h.size());
         if (rc) return rc;
         if (!h.empty()) {
+            H2DGuard h2d;
             hipError_t e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
             if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); return -2; }
             e = stream_wait(s);
@@ -158,7 +191,7 @@ struct mnk_ctx {
 };
 int mnk_masked_stream_pair(mnk_ctx* ctx, int chain_cus, hipStream_t* sp, hipStream_t* su);   // ls.hip
 int mnk_solve_warmup(hipStream_t s);               // solve.hip: first (no-op) launch of the inverse kernel that needs scratch
-int mnk_dag_warmup(hipStream_t* streams, int n);   // dag.hip: first (empty) launch of the bulk kernels on these streams
+int mnk_dag_warmup(hipStream_t* streams, int n, int nwg);   // dag.hip: first (empty) launch of the bulk kernels on these streams
 int mnk_live_contexts(int device);  // contexts alive on this device in this process
 // Device arbiter of the PERSISTENT kernels (task-DAG schedule, persistent panel launches, one-launch solve): their waiting
 // workgroups stay resident, so two of them from different contexts must never share the chip (each could hold CUs the

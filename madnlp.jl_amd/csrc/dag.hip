@@ -817,7 +817,7 @@ using namespace mnk;
 // spins for a bulk kernel the runtime is still setting up -- normally microseconds, but seen to exceed the bound of the
 // device-side waits (info = -7, schedule 1 for the next 16 factorizations: round 3 met it in 2 of ~150 bench processes, this
 // round in 1 of 8 runs of tools/dag_time.py).  Called once per device when its task-DAG streams are created (ls.hip).
-int mnk_dag_warmup(hipStream_t* streams, int n) {
+int mnk_dag_warmup(hipStream_t* streams, int n, int nwg) {
     static mnk::DevBuf<int> ctr;   // (process lifetime)
     if (!ctr.p) {
         if (ctr.alloc(4)) return -2;
@@ -830,15 +830,32 @@ int mnk_dag_warmup(hipStream_t* streams, int n) {
         a1.info = ctr.p + 1;
         mnk::DagArgs a{};
         a.qctr = ctr.p;
-        int rc = mnk::launch_bulk1_t<true>(streams[i], a1, 8);
-        if (!rc) rc = mnk::launch_bulk1_t<false>(streams[i], a1, 8);
-        if (!rc) rc = mnk::launch_bulk_t<true>(streams[i], a, 8);
-        if (!rc) rc = mnk::launch_bulk_t<false>(streams[i], a, 8);
+        // (a FULL-size grid: the runtime sizes a queue's scratch by the dispatch that asks for it)
+        int rc = mnk::launch_bulk1_t<true>(streams[i], a1, nwg);
+        if (!rc) rc = mnk::launch_bulk1_t<false>(streams[i], a1, nwg);
+        if (!rc) rc = mnk::launch_bulk_t<true>(streams[i], a, nwg);
+        if (!rc) rc = mnk::launch_bulk_t<false>(streams[i], a, nwg);
         if (rc) return rc;
     }
     for (int i = 0; i < n; ++i)
         if (streams[i] != nullptr) MNK_HIP(mnk::stream_wait(streams[i]));
     return 0;
+}
+
+// Bound of the schedule's device-side waits, in polls of ~0.17 us.  Every wait is on work that is queued or resident, so a
+// bound only ever expires when something outside the schedule keeps a kernel of the group from running: another process'
+// kernels on the CUs, or a device-synchronizing runtime call of OTHER code in this process between the group's launches
+// (seen: four host threads, torch's lazy library initialization on one of them while another one launches -- the chain waits
+// for a bulk kernel whose launch the runtime holds back until the device is idle).  The recovery is cheap (the factorization
+// is redone with one launch per piece, the schedule is tried again 16 factorizations later), a long bound is not: 2^24 polls
+// were ~3 s of a stalled device.  ~30 x the time the factorization should take, at least 0.18 s: N = 11 192 -> 0.3 s,
+// N = 24 576 -> 3 s.
+long mnk_ls_dag_spin_limit(const mnk_ls* ls) {
+    if (ls->dag_spin_limit > 0) return ls->dag_spin_limit;
+    const double n = (double)ls->Np;
+    const double t_est = n * n * n / 3.0 / 50e12;   // seconds at ~0.64 of the fp64 peak
+    const double polls = 30.0 * t_est / 0.17e-6;
+    return (long)std::min(16777216.0, std::max(1048576.0, polls));
 }
 
 static mnk::DagInst dag_instance(mnk_ls* ls) {
@@ -891,8 +908,11 @@ int mnk_ls_dag_prepare(mnk_ls* ls) {
         if (ls->dag_has_fill) ls->dag_ntasks1 = mnk::dag_add_fill_tasks(ntile, h, ls->dag_host_ready, ls->dag_ntasks1);
         ls->dag_ntasks = (int)(h.size() / 4);
         if (ls->dag_tasks.alloc(h.size() + 4)) return give_up();
-        if (!h.empty() && hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return give_up();
-        if (mnk::stream_wait(s) != hipSuccess) return give_up();
+        {
+            mnk::H2DGuard h2d;   // (a pageable upload beside another context's persistent group would stop that group: common.h)
+            if (!h.empty() && hipMemcpyAsync(ls->dag_tasks.p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return give_up();
+            if (mnk::stream_wait(s) != hipSuccess) return give_up();
+        }
         if (ls->dag_flags.alloc(nflags)) return give_up();
     }
     if (ldl && !ls->vfull.p && ls->vfull.alloc((size_t)ld * Np + SLACK)) {   // V = L D of every column (LDL^T)
@@ -933,7 +953,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
                        ls->dag_flags.p, (int64_t)nflags, ls->info_dev.p, inst, (mnk::DagInst*)nullptr);
     int* qctr = ls->dag_flags.p;
     int* front = inst.front;
-    const long spin_limit = ls->dag_spin_limit;
+    const long spin_limit = mnk_ls_dag_spin_limit(ls);
     unsigned long long* trace = nullptr;
     if (ls->dag_trace_on && ls->dag_trace.p) {
         const size_t ntr = (size_t)ls->dag_ntasks * 8 + 4096 * 8 + 1024 * 8;
@@ -1081,7 +1101,7 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
             std::vector<int> merged;
             mnk::dag_merge_tasks(l0->dag_host_tasks, l0->dag_host_ready, ninst, period, merged);
             if (B.tasks.alloc(merged.size() + 4)) return -2;
-            MNK_HIP(hipMemcpy(B.tasks.p, merged.data(), merged.size() * sizeof(int), hipMemcpyHostToDevice));
+            { mnk::H2DGuard h2d; MNK_HIP(hipMemcpy(B.tasks.p, merged.data(), merged.size() * sizeof(int), hipMemcpyHostToDevice)); }
             if (!B.qctr.p && B.qctr.alloc(4)) return -2;
             if (B.insts.alloc(sizeof(mnk::DagInst) * (size_t)ninst)) return -2;
             for (hipEvent_t& e : B.ev)
@@ -1112,7 +1132,7 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
         // (the next chain of the stream starts behind them; the bulk kernel has work of the other instance meanwhile).
         auto launch_chain = [&](int i) -> int {
             mnk_ls* ls = g[i];
-            mnk::PpDag dag{hin[i].front, hin[i].af, ntile, 0, 0, -1, ls->dag_spin_limit, nullptr, mnk_ls_growth_word(ls)};
+            mnk::PpDag dag{hin[i].front, hin[i].af, ntile, 0, 0, -1, mnk_ls_dag_spin_limit(ls), nullptr, mnk_ls_growth_word(ls)};
             return mnk_launch_pchain(ls, sp[i & 1], dag, 0, nsc, strips);
         };
         auto launch_tail = [&](int i) -> int {
@@ -1127,7 +1147,7 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
             if (r) return r;
         }
         int r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p,
-                                     l0->dag_spin_limit, std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
+                                     mnk_ls_dag_spin_limit(l0), std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
         if (r) return r;
         for (int i = 0; i < ninst; ++i) {
             r = launch_tail(i);
@@ -1205,7 +1225,7 @@ static int batch_run_group_small(std::vector<mnk_ls*>& g) {
                 std::vector<int> merged;
                 mnk::dag_merge_tasks(l0->dag_host_tasks, l0->dag_host_ready, k, 0, merged);
                 if (B.tasks.alloc(merged.size() + 4)) return -2;
-                MNK_HIP(hipMemcpy(B.tasks.p, merged.data(), merged.size() * sizeof(int), hipMemcpyHostToDevice));
+                { mnk::H2DGuard h2d; MNK_HIP(hipMemcpy(B.tasks.p, merged.data(), merged.size() * sizeof(int), hipMemcpyHostToDevice)); }
                 B.ntile = ntile; B.ninst = k; B.period = 0; B.chunk = l0->dag_chunk; B.taper0 = l0->dag_taper0;
                 B.band = l0->dag_band; B.fill = l0->dag_has_fill; B.ntasks = (int)(merged.size() / 4);
             }
@@ -1236,7 +1256,7 @@ static int batch_run_group_small(std::vector<mnk_ls*>& g) {
             if (r) return r;
             if (ntasks1 > 0) {
                 const int bulk_cus = c0->num_cu - chain_cus_for(k);
-                r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p, l0->dag_spin_limit,
+                r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p, mnk_ls_dag_spin_limit(l0),
                                          std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
                 if (r) return r;
                 MNK_HIP(hipEventRecord(B.ev[2], su));

@@ -314,9 +314,11 @@ int64_t mnk_dc_order(mnk_dc* dc) { return dc ? dc->order : -1; }
 static int copy_in_2d(mnk_ctx* ctx, double* dst, int64_t rows, int64_t cols, const double* src, int64_t ld, int loc) {
     if (rows == 0 || cols == 0) return 0;
     MNK_REQUIRE(ld >= rows, "leading dimension smaller than the number of rows");
-    MNK_HIP(hipMemcpy2DAsync(dst, rows * sizeof(double), src, ld * sizeof(double), rows * sizeof(double), cols,
-                             loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(ctx->stream));
+    if (loc == MNK_DEVICE)
+        MNK_HIP(hipMemcpy2DAsync(dst, rows * sizeof(double), src, ld * sizeof(double), rows * sizeof(double), cols,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        MNK_HIP(mnk::h2d_copy_2d(dst, rows * sizeof(double), src, ld * sizeof(double), rows * sizeof(double), cols, ctx->stream));
     return 0;
 }
 
@@ -342,10 +344,13 @@ int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int l
         MNK_REQUIRE(ex0 != nullptr && ex0->have_diag, "mnk_dc_build: no diagonals given and mnk_dc_set_aug_diagonal was not called");
     } else {
         MNK_REQUIRE(pr_diag && (du_diag || dc->m == 0), "mnk_dc_build: NULL argument");
-        const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-        MNK_HIP(hipMemcpyAsync(dc->pr_diag.p, pr_diag, (dc->n + dc->ns) * sizeof(double), kind, s));
-        if (dc->m > 0) MNK_HIP(hipMemcpyAsync(dc->du_diag.p, du_diag, dc->m * sizeof(double), kind, s));
-        if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(s));
+        if (loc == MNK_DEVICE) {
+            MNK_HIP(hipMemcpyAsync(dc->pr_diag.p, pr_diag, (dc->n + dc->ns) * sizeof(double), hipMemcpyDeviceToDevice, s));
+            if (dc->m > 0) MNK_HIP(hipMemcpyAsync(dc->du_diag.p, du_diag, dc->m * sizeof(double), hipMemcpyDeviceToDevice, s));
+        } else {
+            MNK_HIP(mnk::h2d_copy(dc->pr_diag.p, pr_diag, (dc->n + dc->ns) * sizeof(double), s));
+            if (dc->m > 0) MNK_HIP(mnk::h2d_copy(dc->du_diag.p, du_diag, dc->m * sizeof(double), s));
+        }
     }
     const int64_t ordpad = round_up(dc->order, PAD);
     const int64_t ldk = ordpad;
@@ -486,11 +491,11 @@ int mnk_dc_set_barrier_terms(mnk_dc* dc, const double* reg, const double* l_diag
     mnk_dc_extra* ex = extra_of(dc);
     MNK_REQUIRE(ex != nullptr && ex->have_bounds, "mnk_dc_set_barrier_terms: call mnk_dc_set_bounds first");
     hipStream_t s = dc->ctx->stream;
-    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     auto put = [&](double* dst, const double* src, int64_t cnt) -> int {
         if (cnt <= 0) return 0;
         MNK_REQUIRE(src != nullptr, "mnk_dc_set_barrier_terms: NULL vector");
-        MNK_HIP(hipMemcpyAsync(dst, src, cnt * sizeof(double), kind, s));
+        if (loc == MNK_DEVICE) MNK_HIP(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+        else MNK_HIP(mnk::h2d_copy(dst, src, cnt * sizeof(double), s));
         return 0;
     };
     int rc = put(ex->reg.p, reg, dc->n + dc->ns);
@@ -521,7 +526,7 @@ int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc) {
         double* d = w;
         if (loc != MNK_DEVICE) {
             d = ex->wdev.p;
-            MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+            MNK_HIP(mnk::h2d_copy(d, w, lw * sizeof(double), s));
         }
         double *ws = d + n, *dual = d + n + ns, *wl = dual + m, *wu = wl + nlb;
         if (nlb > 0) hipLaunchKernelGGL(reduce_rhs_kernel, MNK_GRID(nlb), d, ex->ind_lb.p, wl, ex->l_diag.p, nlb);
@@ -578,8 +583,8 @@ int mnk_dc_mul(mnk_dc* dc, double* w, const double* x, double alpha, double beta
     const double* dx = x;
     if (loc != MNK_DEVICE) {
         dw = ex->wdev.p;
-        MNK_HIP(hipMemcpyAsync(ex->wdev.p, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
-        MNK_HIP(hipMemcpyAsync(ex->xdev.p, x, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        MNK_HIP(mnk::h2d_copy(ex->wdev.p, w, lw * sizeof(double), s));
+        MNK_HIP(mnk::h2d_copy(ex->xdev.p, x, lw * sizeof(double), s));
         dx = ex->xdev.p;
     }
     // wx = alpha Sym(H) xx + beta wx ; wx += alpha jac' dual(x) ; dual(w) = alpha jac xx + beta dual(w)

@@ -1306,7 +1306,7 @@ int mnk_launch_pchain_multi(mnk_ls* const* v, int n, hipStream_t sp, hipStream_t
         mnk_ls* ls = v[i];
         mnk::PcSys rec{ls->fact.p, ls->ld, ls->Np, ls->dblk.p, ls->inv16.p, ls->dvec.p, ls->dinv.p, ldl ? ls->vfull.p : nullptr,
                        ls->info_dev.p, ls->pivot_tol, ls->flag_p.p, ls->epoch * 16, front[i], af[i], (int)(ls->Np / 128),
-                       ls->dag_spin_limit, mnk_ls_growth_word(ls)};
+                       mnk_ls_dag_spin_limit(ls), mnk_ls_growth_word(ls)};
         hipLaunchKernelGGL(pc_set_sys_kernel, dim3(1), dim3(1), 0, fill_stream, rec, dst + i);
     }
     MNK_HIP(hipGetLastError());

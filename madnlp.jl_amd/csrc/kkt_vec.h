@@ -82,7 +82,7 @@ static inline int kkt_set_aug_diagonal(const AugDiagView& v, const double* x, co
             if (rc) return rc;
         }
         for (int k = 0; k < 5; ++k) {
-            MNK_HIP(hipMemcpyAsync(v.feed->p + k * v.npr, in[k], v.npr * sizeof(double), hipMemcpyHostToDevice, s));
+            MNK_HIP(mnk::h2d_copy(v.feed->p + k * v.npr, in[k], v.npr * sizeof(double), s));
             in[k] = v.feed->p + k * v.npr;
         }
         MNK_HIP(mnk::stream_wait(s));  // the caller's arrays are only valid for the duration of the call

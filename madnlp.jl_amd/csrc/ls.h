@@ -98,7 +98,8 @@ struct mnk_ls {
     int64_t inv_done = 0;         // strip-columns whose diagonal blocks the current factorization has already inverted for the solves
     int dag_band = 16;            // 64-row strips per band of the persistent pivot chain (8, 12 or 16; <= the chain's CUs)
     int dag_taper0 = 2;           // (1: -0.5 .. -1 % slower, alternating runs on two boxes) length of the last chunk in front of a tile's closing task; the chunks double from there (1, 2, 4, ...)
-    long dag_spin_limit = 1L << 24;  // polls (~0.5 us each) a device-side wait of the schedule may take before it gives up (info = -7)
+    long dag_spin_limit = 0;  // option: polls (~0.17 us each) a device-side wait of the schedule may take before it gives up
+                              // (info = -7); 0 = by the order of the matrix (mnk_ls_dag_spin_limit)
     int dag_chunk = 64;           // tile columns (of 128) per bulk task behind the doubling taper 1, 2, 4, ... (every task ends with a read-modify-write of its tile; C3 at the end of round 3: 12 -> 9.58 ms, 48 / 64 / 88 / 128 / 1024 -> 9.30; N = 16 384: 26.3 -> 25.9 ms, N = 24 576: 82.0 / 82.5 ms; in the middle of the round, with slower closing tasks, 10-16 was the optimum)
     int64_t dag_min_rows = 1536;  // smaller systems keep the launch-per-panel schedules (measured break-even: N ~ 1500)
     int64_t dag_max_rows = 24576; // larger ones too: their trailing updates already run at the update kernel's rate (measured: 22384 +1 %, 30000 -2 %)
@@ -188,6 +189,7 @@ int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);  
 // Xrows(:, j0:j0+64), V written to Vrows(:, j0:j0+64) (LDL only); both row blocks have leading dimension ldr.
 int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows, double* Vrows, int64_t ldr, int64_t nrows);
 int mnk_ls_run_bunchkaufman(mnk_ls* ls);                                  // bk.hip
+long mnk_ls_dag_spin_limit(const mnk_ls* ls);   // dag.hip
 int mnk_launch_trsm64_batch(hipStream_t s, bool ldl, const mnk::TrsmBatchRec* recs_dev, int nbatch, int64_t j0, int64_t nrows,
                             int64_t ldr);   // factor.hip
 int mnk_ls_bk_permute(mnk_ls* ls, double* x, double* tmp, bool forward);  // x <- P x (forward) / P^T x

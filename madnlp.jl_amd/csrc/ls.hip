@@ -338,7 +338,7 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
             }
             d.made = true;
             hipStream_t warm[3] = {d.su, d.su2, d.suB};
-            if (mnk_dag_warmup(warm, 3) != 0) (void)hipGetLastError();   // (best effort)
+            if (mnk_dag_warmup(warm, 3, 3 * c->num_cu) != 0) (void)hipGetLastError();   // (best effort)
             for (hipStream_t w : {d.su, d.su2, d.sp, d.spB})              // (where the inverses for the solves are launched)
                 if (w != nullptr && mnk_solve_warmup(w) != 0) (void)hipGetLastError();
         }
@@ -384,7 +384,7 @@ int mnk_masked_stream_pair(mnk_ctx* ctx, int chain_cus, hipStream_t* sp, hipStre
         }
         if (p.su != nullptr) {   // (first launches of the kernels that need scratch: see mnk_dag_warmup)
             hipStream_t w[1] = {p.su};
-            if (mnk_dag_warmup(w, 1) != 0) (void)hipGetLastError();
+            if (mnk_dag_warmup(w, 1, 3 * ctx->num_cu) != 0) (void)hipGetLastError();
         }
     }
     *sp = p.sp;
@@ -823,8 +823,8 @@ int mnk_ls_factorize_dense(mnk_ls* ls, const double* A, int64_t lda, int loc, in
         DevBuf<double> tmp;
         rc = tmp.alloc((size_t)ls->N * ls->N);
         if (rc) return rc;
-        MNK_HIP(hipMemcpy2DAsync(tmp.p, ls->N * sizeof(double), A, lda * sizeof(double), ls->N * sizeof(double),
-                                 ls->N, hipMemcpyHostToDevice, ls->ctx->stream));
+        MNK_HIP(mnk::h2d_copy_2d(tmp.p, ls->N * sizeof(double), A, lda * sizeof(double), ls->N * sizeof(double), ls->N,
+                                 ls->ctx->stream));
         rc = factorize_dense_dev(ls, tmp.p, ls->N);
         MNK_HIP(mnk::stream_wait(ls->ctx->stream));
         if (!rc) rc = finish_info(ls, info);  // (a breakdown is handled while the staging buffer is alive)
@@ -939,7 +939,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
         }
         { int rc_q = mnk_solve_sync_deferred(ls); if (rc_q) return rc_q; }
         MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
-        MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
+        MNK_HIP(mnk::h2d_copy(w, xk, N * sizeof(double), s));
         int rc = mnk_ls_run_solve(ls, w);
         if (rc) return rc;
         if (loc != MNK_DEVICE && ls->persistent_solve) {
@@ -949,7 +949,7 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
             MNK_HIP(mnk::stream_wait(s));
             if (mnk_ls_take_solve_abort(ls)) {
                 MNK_HIP(hipMemsetAsync(w, 0, Np * sizeof(double), s));
-                MNK_HIP(hipMemcpyAsync(w, xk, N * sizeof(double), hipMemcpyHostToDevice, s));
+                MNK_HIP(mnk::h2d_copy(w, xk, N * sizeof(double), s));
                 rc = mnk_ls_run_solve(ls, w);
                 if (rc) return rc;
             }

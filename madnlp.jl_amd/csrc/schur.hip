@@ -190,12 +190,17 @@ int mnk_schur_set_block(mnk_schur* h, int64_t k, const double* A_kk, int64_t lda
     MNK_REQUIRE(k >= 0 && k < h->ns && lda >= h->blk && ldc >= h->nd, "mnk_schur_set_block: bad scenario index / leading dimension");
     MNK_HIP(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
-    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    MNK_HIP(hipMemcpy2DAsync(h->A.p + k * h->blk * h->blk, h->blk * sizeof(double), A_kk, lda * sizeof(double),
-                             h->blk * sizeof(double), h->blk, kind, s));
-    MNK_HIP(hipMemcpy2DAsync(h->C.p + k * h->nd * h->blk, h->nd * sizeof(double), C_dk, ldc * sizeof(double),
-                             h->nd * sizeof(double), h->blk, kind, s));
-    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(s));
+    if (loc == MNK_DEVICE) {
+        MNK_HIP(hipMemcpy2DAsync(h->A.p + k * h->blk * h->blk, h->blk * sizeof(double), A_kk, lda * sizeof(double),
+                                 h->blk * sizeof(double), h->blk, hipMemcpyDeviceToDevice, s));
+        MNK_HIP(hipMemcpy2DAsync(h->C.p + k * h->nd * h->blk, h->nd * sizeof(double), C_dk, ldc * sizeof(double),
+                                 h->nd * sizeof(double), h->blk, hipMemcpyDeviceToDevice, s));
+    } else {
+        MNK_HIP(mnk::h2d_copy_2d(h->A.p + k * h->blk * h->blk, h->blk * sizeof(double), A_kk, lda * sizeof(double),
+                                 h->blk * sizeof(double), h->blk, s));
+        MNK_HIP(mnk::h2d_copy_2d(h->C.p + k * h->nd * h->blk, h->nd * sizeof(double), C_dk, ldc * sizeof(double),
+                                 h->nd * sizeof(double), h->blk, s));
+    }
     h->built = false;
     return 0;
 }
@@ -210,9 +215,13 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
     const int64_t nd = h->nd, blk = h->blk, ndp = h->ndp, blkp = h->blkp;
     // S <- S0 (or 0), zero padded
     MNK_HIP(hipMemsetAsync(h->Sp.p, 0, (size_t)ndp * ndp * sizeof(double), s));
-    if (S0 != nullptr)
-        MNK_HIP(hipMemcpy2DAsync(h->Sp.p, ndp * sizeof(double), S0, lds0 * sizeof(double), nd * sizeof(double), nd,
-                                 loc_s0 == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    if (S0 != nullptr) {
+        if (loc_s0 == MNK_DEVICE)
+            MNK_HIP(hipMemcpy2DAsync(h->Sp.p, ndp * sizeof(double), S0, lds0 * sizeof(double), nd * sizeof(double), nd,
+                                     hipMemcpyDeviceToDevice, s));
+        else
+            MNK_HIP(mnk::h2d_copy_2d(h->Sp.p, ndp * sizeof(double), S0, lds0 * sizeof(double), nd * sizeof(double), nd, s));
+    }
     // Phase 1a (reference :955-990, `@blas_safe_threads for k in 1:ns`): the scenario blocks are factored TOGETHER -- one
     // batch (dag.hip): the pivot chains of up to 32 blocks side by side in one launch instead of one whole-chip factorization
     // and one host synchronization per scenario (a 512-row block is chain-bound at 0.03 of the peak on its own)
@@ -257,10 +266,9 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         char* rdev = h->recs.p;
         mnk::TrsmBatchRec* tr_dev = reinterpret_cast<mnk::TrsmBatchRec*>(rdev);
         mnk::GemmBatchRec* gr_dev = reinterpret_cast<mnk::GemmBatchRec*>(rdev + (size_t)h->ns * sizeof(mnk::TrsmBatchRec));
-        MNK_HIP(hipMemcpyAsync(tr_dev, tr.data(), tr.size() * sizeof(mnk::TrsmBatchRec), hipMemcpyHostToDevice, s));
-        MNK_HIP(hipMemcpyAsync(gr_dev, gr.data(), gr.size() * sizeof(mnk::GemmBatchRec), hipMemcpyHostToDevice, s));
-        MNK_HIP(hipMemcpyAsync(h->fast_k.p, fast.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, s));
-        MNK_HIP(mnk::stream_wait(s));   // (the host vectors go out of scope)
+        MNK_HIP(mnk::h2d_copy(tr_dev, tr.data(), tr.size() * sizeof(mnk::TrsmBatchRec), s));
+        MNK_HIP(mnk::h2d_copy(gr_dev, gr.data(), gr.size() * sizeof(mnk::GemmBatchRec), s));
+        MNK_HIP(mnk::h2d_copy(h->fast_k.p, fast.data(), (size_t)nf * sizeof(int), s));
         hipLaunchKernelGGL(schur_copy_batch_kernel, dim3((unsigned)((ndp * Npb + 255) / 256), (unsigned)nf), dim3(256), 0, s,
                            h->Xall.p, ndp, Npb, h->C.p, nd, blk, h->fast_k.p);
         const int64_t ldf = h->ls_k[fast[0]]->ld;

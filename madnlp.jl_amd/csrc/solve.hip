@@ -991,7 +991,7 @@ int mnk_solve_warmup(hipStream_t s) {
     if (!one.p) {
         if (one.alloc(1)) return -2;
         const int v = 1;
-        MNK_HIP(hipMemcpy(one.p, &v, sizeof(int), hipMemcpyHostToDevice));
+        { mnk::H2DGuard h2d; MNK_HIP(hipMemcpy(one.p, &v, sizeof(int), hipMemcpyHostToDevice)); }
     }
     hipLaunchKernelGGL(linv256_mfma_kernel, dim3(1, 4), dim3(256), 0, s, (const double*)nullptr, (int64_t)0, (const double*)nullptr,
                        (double*)nullptr, (double*)nullptr, (int64_t)256, one.p, 0);

@@ -392,8 +392,7 @@ int mnk_sc_get_ptrs(mnk_sc* sc, int32_t* d_dst, int32_t* d_src, int32_t* h_dst, 
 static int stage_in(mnk_ctx* ctx, double* dev, const double* src, int64_t n, int loc, const double** use) {
     if (loc == MNK_DEVICE) { *use = src; return 0; }
     if (n > 0) {
-        MNK_HIP(hipMemcpyAsync(dev, src, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        MNK_HIP(mnk::stream_wait(ctx->stream));  // caller's buffer is only valid for the duration of the call
+        MNK_HIP(mnk::h2d_copy(dev, src, n * sizeof(double), ctx->stream));  // (complete on return: the caller's buffer is only valid for the duration of the call)
     }
     *use = dev;
     return 0;
@@ -535,8 +534,8 @@ int mnk_sc_set_bounds(mnk_sc* sc, int64_t nlb, const int64_t* ind_lb, int64_t nu
 static int copy_in(mnk_ctx* ctx, double* dst, const double* src, int64_t n, int loc) {
     if (n <= 0) return 0;
     MNK_REQUIRE(src != nullptr, "NULL vector");
-    MNK_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                           ctx->stream));
+    if (loc == MNK_DEVICE) MNK_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    else MNK_HIP(mnk::h2d_copy(dst, src, n * sizeof(double), ctx->stream));
     return 0;
 }
 
@@ -627,7 +626,7 @@ int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc) {
         double* d = w;
         if (loc != MNK_DEVICE) {
             d = sp->wdev.p;
-            MNK_HIP(hipMemcpyAsync(d, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
+            MNK_HIP(mnk::h2d_copy(d, w, lw * sizeof(double), s));
         }
         double *ws = d + n, *wz = d + n + m, *wl = d + n + 2 * m, *wu = wl + nlb;
         const double* Ss = sc->pr_diag.p + n;
@@ -670,8 +669,8 @@ int mnk_sc_mul(mnk_sc* sc, double* w, const double* x, double alpha, double beta
     const double* dx = x;
     if (loc != MNK_DEVICE) {
         dw = sp->wdev.p;
-        MNK_HIP(hipMemcpyAsync(sp->wdev.p, w, lw * sizeof(double), hipMemcpyHostToDevice, s));
-        MNK_HIP(hipMemcpyAsync(sp->xdev.p, x, lw * sizeof(double), hipMemcpyHostToDevice, s));
+        MNK_HIP(mnk::h2d_copy(sp->wdev.p, w, lw * sizeof(double), s));
+        MNK_HIP(mnk::h2d_copy(sp->xdev.p, x, lw * sizeof(double), s));
         dx = sp->xdev.p;
     }
     // wx = alpha Sym(H) xx + beta wx ; wx += alpha Jt xz ; wz = alpha Jt' xx + beta wz

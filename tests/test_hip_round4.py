@@ -296,6 +296,49 @@ def test_options_pinned_by_the_environment_are_reported():
     assert "ignored" in r.stderr and "panel_algo" in r.stderr
 
 
+@pytest.mark.gpu
+def test_first_factorizations_of_several_threads_with_the_large_system_schedule(ctx):
+    """The first round of a multi-threaded run: every thread's solver uploads its task list (a host -> device copy from
+    pageable memory) while another thread's persistent group may be in flight -- such a copy stops the group for good
+    (tools/first_group_probe.py), so the library's own uploads take the launch mutex and wait for the operation in flight
+    (common.h: H2DGuard).  Three threads, order 6400 (band + bulk + tile-closing structure, unlike the 4100 of the test
+    above), host right-hand sides on top: no fall-back, correct solves."""
+    import threading
+    dev = torch.device("cuda", 0)
+    N = 6400
+    A, n1 = _dev_matrix(N, mj.LDL, dev)
+    Ah = A.cpu().numpy()
+    anorm = np.abs(Ah).sum(axis=1).max()
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream(dev)
+            c = mj.HipContext(0, stream=st.cuda_stream)
+            with torch.cuda.stream(st):
+                M = mj.HipLinearSolver(A, ctx=c, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
+                rng = np.random.default_rng(100 + i)
+                for rep in range(3):
+                    M.factorize()
+                    assert (M.get_stat("panel_algo"), M.get_stat("pp_fallbacks")) == (5.0, 0.0), (i, rep, M.get_stat("timeout_site"))
+                    b = rng.standard_normal(N)
+                    x = M.solve_linear_system(b.copy())        # (a HOST vector: uploaded by the library)
+                    bwd = np.abs(Ah @ x - b).max() / (anorm * np.abs(x).max() + np.abs(b).max())
+                    assert bwd <= 1e-13, (i, rep, bwd)
+                M.close()
+            c.close()
+        except BaseException as e:  # noqa: BLE001  (reported by the main thread)
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
 def _indefinite(kind, N, rng):
     if kind == "random":
         S = rng.standard_normal((N, N))

@@ -19,8 +19,12 @@ A = Rm @ Rm.T
 A.diagonal().add_(float(N))
 n1 = 2 * N // 3
 A[n1:, n1:].neg_()
+if "--warm-torch" in sys.argv:   # torch's lazy initialization (first GEMV / randn) before the solver threads start: see INTEGRATION.md section 0
+    _b = torch.randn(N, dtype=torch.float64, device=dev, generator=g)
+    _ = (A @ _b).abs().max().item()
 torch.cuda.synchronize()
 res = []
+first_done = threading.Event()
 
 
 def worker(i):
@@ -31,7 +35,13 @@ def worker(i):
         M = mj.HipLinearSolver(A, ctx=c, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
         gg = torch.Generator(device=dev).manual_seed(100 + i)
         for rep in range(R):
+            if "--first-alone" in sys.argv and rep == 0:   # (diagnostic: thread 0's first factorization has the device to itself)
+                if i > 0:
+                    first_done.wait()
             M.factorize()
+            if "--first-alone" in sys.argv and rep == 0 and i == 0:
+                st.synchronize()
+                first_done.set()
             f = M.get_stat("pp_fallbacks")
             if f != fb:
                 sites.append((rep, int(M.get_stat("timeout_site"))))
