@@ -947,7 +947,7 @@ int mnk_ls_run_bunchkaufman(mnk_ls* ls) {
     // mnk_ls_fetch_info, which waits for the stream anyway.)
     MNK_HIP(mnk::stream_wait(ls->ctx->stream));
     int fail = 0;
-    MNK_HIP(hipMemcpy(&fail, &reinterpret_cast<BkState*>(ls->bk_state.p)->fail, sizeof(int), hipMemcpyDeviceToHost));
+    MNK_HIP(mnk::d2h_copy(&fail, &reinterpret_cast<BkState*>(ls->bk_state.p)->fail, sizeof(int), ls->ctx->stream));
     if (fail == 0) return 0;
     // (another process' kernels on the CUs, as for the persistent schedules of factor.hip: redo with one workgroup per panel
     // and stay there)

@@ -85,12 +85,13 @@ struct LaunchLock {
     LaunchLock& operator=(const LaunchLock&) = delete;
 };
 
-// A host -> device copy from PAGEABLE memory that the runtime carries out while a persistent group of this process is in
-// flight on another stream stops that group for good: both of its kernels are running according to the kernel trace, neither
+// A copy between PAGEABLE host memory and the device (either direction) that the runtime carries out while a persistent group
+// of this process is in flight on another stream stops that group for good: both of its kernels are running according to the kernel trace, neither
 // makes progress, the bounded waits expire (tools/first_group_probe.py: ONE such copy by a second host thread is enough;
-// pinned sources, device -> host copies, allocations, kernels and synchronizations of the other thread are harmless -- the
-// first round of a multi-threaded run met it through the other threads' task-list uploads, tools/thread_stress.py).  Every
-// host -> device copy of this library therefore holds the launch mutex (no group is launched meanwhile) and first waits for
+// copies from / to PINNED host memory, allocations, kernels and synchronizations of the other thread are harmless -- the first
+// round of a multi-threaded run met it through the other threads' task-list uploads, tools/thread_stress.py; a solve with a
+// host right-hand side through its copy back).  Every copy of this library between the device and host memory it does not
+// know to be pinned therefore holds the launch mutex (no group is launched meanwhile) and first waits for
 // the last persistent operation in flight; it must be complete (stream_wait) before the guard goes.  Copies issued by OTHER
 // code of the process are outside this protection: INTEGRATION.md section 0.
 struct H2DGuard {
@@ -114,6 +115,20 @@ inline hipError_t h2d_copy_2d(void* dst, size_t dpitch, const void* src, size_t 
     if (width == 0 || height == 0) return hipSuccess;
     H2DGuard guard;
     const hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, s);
+    return e != hipSuccess ? e : stream_wait(s);
+}
+
+// device -> host (pageable or not), complete when it returns
+inline hipError_t d2h_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    H2DGuard guard;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : stream_wait(s);
+}
+inline hipError_t d2h_copy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipStream_t s) {
+    if (width == 0 || height == 0) return hipSuccess;
+    H2DGuard guard;
+    const hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, s);
     return e != hipSuccess ? e : stream_wait(s);
 }
 

@@ -304,7 +304,11 @@ __global__ void dag_gate_kernel(const int* __restrict__ word, int target, int* _
 }
 
 __global__ __launch_bounds__(256) void dag_reset_kernel(int* __restrict__ flags, int64_t n, int* __restrict__ info, DagInst rec,
-                                                        DagInst* __restrict__ rec_dst) {
+                                                        DagInst* __restrict__ rec_dst, const SmallSysRec* __restrict__ recs = nullptr) {
+    if (recs != nullptr) {   // (a batch of small systems: blockIdx.y = system; the instance records are uploaded by the host)
+        const SmallSysRec r = recs[blockIdx.y];
+        flags = r.flags; n = r.nflags; info = r.info;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0 && rec_dst != nullptr) *rec_dst = rec;   // the instance record the bulk kernel reads
     int4* f4 = reinterpret_cast<int4*>(flags);   // (hipMalloc alignment; the tail is done word by word)
     const int64_t n4 = n / 4, stride = (int64_t)gridDim.x * blockDim.x;
@@ -848,14 +852,15 @@ int mnk_dag_warmup(hipStream_t* streams, int n, int nwg) {
 // (seen: four host threads, torch's lazy library initialization on one of them while another one launches -- the chain waits
 // for a bulk kernel whose launch the runtime holds back until the device is idle).  The recovery is cheap (the factorization
 // is redone with one launch per piece, the schedule is tried again 16 factorizations later), a long bound is not: 2^24 polls
-// were ~3 s of a stalled device.  ~30 x the time the factorization should take, at least 0.18 s: N = 11 192 -> 0.3 s,
-// N = 24 576 -> 3 s.
+// were ~3 s of a stalled device.  ~100 x the time the factorization should take, at least 1 s: a bound of 30 x (0.3 s at
+// N = 11 192) was tried first and expired about once in 1000 factorizations of tools/c5_loop.py on transient stalls that a
+// longer bound sits out -- harmless for the result, but a fall-back where none is needed.
 long mnk_ls_dag_spin_limit(const mnk_ls* ls) {
     if (ls->dag_spin_limit > 0) return ls->dag_spin_limit;
     const double n = (double)ls->Np;
     const double t_est = n * n * n / 3.0 / 50e12;   // seconds at ~0.64 of the fp64 peak
-    const double polls = 30.0 * t_est / 0.17e-6;
-    return (long)std::min(16777216.0, std::max(1048576.0, polls));
+    const double polls = 100.0 * t_est / 0.17e-6;
+    return (long)std::min(16777216.0, std::max(6000000.0, polls));
 }
 
 static mnk::DagInst dag_instance(mnk_ls* ls) {
@@ -1049,7 +1054,10 @@ thread_local BatchState t_batch;
 struct BatchBuffers {   // per device, reused from batch to batch (guarded by the arbiter's mutex while in use)
     mnk::DevBuf<int> tasks;
     mnk::DevBuf<int> qctr;
-    mnk::DevBuf<char> insts, pcsys;
+    mnk::DevBuf<char> insts, pcsys, aux;
+    char* stage = nullptr;        // pinned host memory: the records of one batch (instances | chain table | small-system records)
+    size_t stage_bytes = 0;
+    hipEvent_t stage_ev = nullptr;   // recorded behind the last upload from `stage`
     int ntile = 0, ninst = 0, period = 0, chunk = 0, taper0 = 0, band = 0, ntasks = 0;
     bool fill = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1234,25 +1242,52 @@ static int batch_run_group_small(std::vector<mnk_ls*>& g) {
             if (B.pcsys.n < mnk_pchain_sys_bytes() * (size_t)k && B.pcsys.alloc(mnk_pchain_sys_bytes() * (size_t)std::max(k, 32))) return -2;
             for (hipEvent_t& e : B.ev)
                 if (!e) MNK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            // The records of this round (instances for the bulk kernel, the chains' table, what the kernels around them
+            // need) go through pinned host memory in ONE piece each: a kernel launch per record and per small kernel made the
+            // host the bound of a batch of many small systems (~8 launches per system).
             std::vector<mnk::DagInst> hin;
             std::vector<int*> fronts;
             std::vector<const int*> afs;
             mnk::DagInst* insts_dev = reinterpret_cast<mnk::DagInst*>(B.insts.p);
+            const size_t pc_bytes = mnk_pchain_sys_bytes();
+            const size_t need = (size_t)k * (sizeof(mnk::DagInst) + pc_bytes + sizeof(mnk::SmallSysRec));
+            if (B.aux.n < sizeof(mnk::SmallSysRec) * (size_t)k && B.aux.alloc(sizeof(mnk::SmallSysRec) * (size_t)std::max(k, 32))) return -2;
+            if (B.stage_ev == nullptr) MNK_HIP(hipEventCreateWithFlags(&B.stage_ev, hipEventDisableTiming));
+            else MNK_HIP(hipEventSynchronize(B.stage_ev));   // (the previous round's uploads have left the staging memory)
+            if (B.stage_bytes < need) {
+                mnk::LaunchLock lock;
+                if (B.stage) { mnk::quiesce_persistent(); (void)hipHostFree(B.stage); B.stage = nullptr; }
+                const size_t cap = (size_t)std::max(k, 32) * (sizeof(mnk::DagInst) + pc_bytes + sizeof(mnk::SmallSysRec));
+                MNK_HIP(hipHostMalloc((void**)&B.stage, cap, hipHostMallocDefault));
+                B.stage_bytes = cap;
+            }
+            mnk::DagInst* st_inst = reinterpret_cast<mnk::DagInst*>(B.stage);
+            char* st_pc = B.stage + (size_t)k * sizeof(mnk::DagInst);
+            mnk::SmallSysRec* st_aux = reinterpret_cast<mnk::SmallSysRec*>(st_pc + (size_t)k * pc_bytes);
+            const bool batch_aux = l0->linv_mfma && !l0->solve512;   // (the other inverse kernels have no batched form)
             for (int i = 0; i < k; ++i) {
                 mnk_ls* ls = g[r0 + i];
                 hin.push_back(dag_instance(ls));
                 ls->dag_filled = hin.back().zfill != nullptr;
                 fronts.push_back(hin.back().front);
                 afs.push_back(hin.back().af);
-                hipLaunchKernelGGL(mnk::dag_reset_kernel, dim3((unsigned)std::min<size_t>((nflags + 1023) / 1024, 64)), dim3(256), 0, h,
-                                   ls->dag_flags.p, (int64_t)nflags, ls->info_dev.p, hin.back(), insts_dev + i);
+                st_inst[i] = hin.back();
+                mnk_pchain_fill_sys(ls, st_pc + (size_t)i * pc_bytes, hin.back().front, hin.back().af);
+                mnk_ls_fill_small_rec(ls, st_aux + i);
             }
+            MNK_HIP(hipMemcpyAsync(B.insts.p, st_inst, (size_t)k * sizeof(mnk::DagInst), hipMemcpyHostToDevice, h));
+            MNK_HIP(hipMemcpyAsync(B.pcsys.p, st_pc, (size_t)k * pc_bytes, hipMemcpyHostToDevice, h));
+            MNK_HIP(hipMemcpyAsync(B.aux.p, st_aux, (size_t)k * sizeof(mnk::SmallSysRec), hipMemcpyHostToDevice, h));
+            MNK_HIP(hipEventRecord(B.stage_ev, h));
+            const mnk::SmallSysRec* aux_dev = reinterpret_cast<const mnk::SmallSysRec*>(B.aux.p);
+            hipLaunchKernelGGL(mnk::dag_reset_kernel, dim3((unsigned)std::min<size_t>((nflags + 1023) / 1024, 64), (unsigned)k), dim3(256), 0, h,
+                               (int*)nullptr, (int64_t)0, (int*)nullptr, hin[0], (mnk::DagInst*)nullptr, aux_dev);
             MNK_HIP(hipMemsetAsync(B.qctr.p, 0, 4 * sizeof(int), h));
             MNK_HIP(hipEventRecord(B.ev[0], h));
             MNK_HIP(hipStreamWaitEvent(sp, B.ev[0], 0));
             if (su != nullptr) MNK_HIP(hipStreamWaitEvent(su, B.ev[0], 0));
             // (the records of the chains' table are written on the home stream before the fork)
-            int r = mnk_launch_pchain_multi(g.data() + r0, k, sp, sp, B.pcsys.p, fronts.data(), afs.data());
+            int r = mnk_launch_pchain_multi(g.data() + r0, k, sp, nullptr, B.pcsys.p, fronts.data(), afs.data());
             if (r) return r;
             if (ntasks1 > 0) {
                 const int bulk_cus = c0->num_cu - chain_cus_for(k);
@@ -1267,6 +1302,21 @@ static int batch_run_group_small(std::vector<mnk_ls*>& g) {
             if (su != nullptr) MNK_HIP(hipStreamWaitEvent(su, B.ev[1], 0));   // (all chains done: every system's factor is final)
             if (su != nullptr) MNK_HIP(hipStreamWaitEvent(sp, B.ev[2], 0));
             // inverses for the solves, inertia / info words: small latency-bound kernels, spread over the three streams
+            if (batch_aux) {
+                // ONE launch each for all systems of the round: 64 x 64 inverses, 256 x 256 inverses, inertia / info words
+                r = mnk_ls_invert_blocks_batch(h, ldl, aux_dev, k, Np);
+                if (r) return r;
+                r = mnk_ls_finish_info_batch(h, aux_dev, k, ldl ? (l0->N >= 4096 ? 1024 : 256) : 64);
+                if (r) return r;
+                for (int i = 0; i < k; ++i) {
+                    mnk_ls* ls = g[r0 + i];
+                    ls->inv_done = nsc;
+                    if (!ls->ev_info) MNK_HIP(hipEventCreateWithFlags(&ls->ev_info, hipEventDisableTiming));
+                    MNK_HIP(hipEventRecord(ls->ev_info, h));
+                    ls->ev_info_recorded = true;
+                }
+                return 0;
+            }
             hipStream_t inv_s[3] = {h, sp, su != nullptr ? su : sp};
             for (int i = 0; i < k; ++i) {
                 mnk_ls* ls = g[r0 + i];

@@ -388,10 +388,12 @@ int mnk_dc_get_aug(mnk_dc* dc, double* out, int loc) {
     MNK_REQUIRE(dc && out, "mnk_dc_get_aug: NULL argument");
     MNK_HIP(hipSetDevice(dc->ctx->device));
     const int64_t ldk = round_up(dc->order, PAD);
-    MNK_HIP(hipMemcpy2DAsync(out, dc->order * sizeof(double), dc->aug.p, ldk * sizeof(double),
-                             dc->order * sizeof(double), dc->order,
-                             loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, dc->ctx->stream));
-    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(dc->ctx->stream));
+    if (loc == MNK_DEVICE)
+        MNK_HIP(hipMemcpy2DAsync(out, dc->order * sizeof(double), dc->aug.p, ldk * sizeof(double), dc->order * sizeof(double),
+                                 dc->order, hipMemcpyDeviceToDevice, dc->ctx->stream));
+    else
+        MNK_HIP(mnk::d2h_copy_2d(out, dc->order * sizeof(double), dc->aug.p, ldk * sizeof(double), dc->order * sizeof(double),
+                                 dc->order, dc->ctx->stream));
     return 0;
 }
 
@@ -563,8 +565,7 @@ int mnk_dc_solve_kkt(mnk_dc* dc, mnk_ls* ls, double* w, int loc) {
         if (loc == MNK_DEVICE) break;
         MNK_HIP(mnk::stream_wait(s));
         if (attempt == 0 && mnk_ls_take_solve_abort(ls)) continue;
-        MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(mnk::stream_wait(s));
+        MNK_HIP(mnk::d2h_copy(w, d, lw * sizeof(double), s));
         break;
     }
     return 0;
@@ -605,8 +606,7 @@ int mnk_dc_mul(mnk_dc* dc, double* w, const double* x, double alpha, double beta
                            ex->ind_ub.p, ex->u_lower.p, ex->u_diag.p, alpha, beta, nub, 1);
     MNK_HIP(hipGetLastError());
     if (loc != MNK_DEVICE) {
-        MNK_HIP(hipMemcpyAsync(w, dw, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(mnk::stream_wait(s));
+        MNK_HIP(mnk::d2h_copy(w, dw, lw * sizeof(double), s));
     }
     return 0;
 }

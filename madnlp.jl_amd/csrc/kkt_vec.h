@@ -147,7 +147,7 @@ static inline int kkt_get_diagonals(const AugDiagView& v, double* pr_diag, doubl
                                     double* u_diag, double* l_lower, double* u_lower) {
     hipStream_t s = v.ctx->stream;
     auto get = [&](double* dst, const double* src, int64_t n) -> int {
-        if (dst && n > 0) MNK_HIP(hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (dst && n > 0) MNK_HIP(mnk::d2h_copy(dst, src, n * sizeof(double), s));
         return 0;
     };
     int rc = get(pr_diag, v.pr_diag, v.npr) | get(du_diag, v.du_diag, v.ndu) | get(reg, v.reg, v.npr) |

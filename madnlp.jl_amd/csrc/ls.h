@@ -157,6 +157,8 @@ struct mnk_ls {
     bool bk_multi_last = false, bk_mw_blocked = false;
     int bk_mw_fallbacks = 0;
     bool factorized = false, info_valid = false;
+    bool spare_by_dag = false;   // the spare buffer's zero-fill was left to the DAG_FILL tasks of the factorization queued last: it
+                                 // only happened if that factorization ran to its end (info == 0)
     int info = 0;
     int64_t npos = 0, nzero = 0, nneg = 0;
 };
@@ -190,6 +192,21 @@ int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1);  
 int mnk_ls_right_trsm_rows(mnk_ls* ls, hipStream_t s, int64_t j0, double* Xrows, double* Vrows, int64_t ldr, int64_t nrows);
 int mnk_ls_run_bunchkaufman(mnk_ls* ls);                                  // bk.hip
 long mnk_ls_dag_spin_limit(const mnk_ls* ls);   // dag.hip
+namespace mnk {
+// One system of a batch of SMALL factorizations (dag.hip: batch_run_group_small): what the kernels around the shared chain
+// launch need, so that they are ONE launch per batch round instead of one per system (blockIdx.z / .y / .x = system; the
+// host's launch rate was the bound: ~8 launches per system, 9 of the 10.9 ms of a 128-scenario Schur build).
+struct SmallSysRec {
+    int* flags; int64_t nflags; int* info;                 // progress words to zero, the info words (dag_reset_kernel)
+    double* F; int64_t ld; const double* dblk; double* linv; double* linv256; double* linv256t; int64_t Np;   // inverses for the solves
+    const double* dvec; int64_t ninertia; unsigned long long* pin_dev; const unsigned long long* amax;       // finish_info_kernel
+};
+}  // namespace mnk
+int mnk_ls_invert_blocks_batch(hipStream_t s, bool ldl, const mnk::SmallSysRec* recs_dev, int n, int64_t Np);   // factor.hip (+ solve.hip)
+int mnk_ls_build_inverses_batch(hipStream_t s, const mnk::SmallSysRec* recs_dev, int n, int64_t Np);           // solve.hip
+int mnk_ls_finish_info_batch(hipStream_t s, const mnk::SmallSysRec* recs_dev, int n, int threads);             // factor.hip
+void mnk_ls_fill_small_rec(mnk_ls* ls, mnk::SmallSysRec* rec);                                                  // factor.hip
+void mnk_pchain_fill_sys(mnk_ls* ls, void* rec_host, int* front, const int* af);                               // factor.hip (one PcSys record)
 int mnk_launch_trsm64_batch(hipStream_t s, bool ldl, const mnk::TrsmBatchRec* recs_dev, int nbatch, int64_t j0, int64_t nrows,
                             int64_t ldr);   // factor.hip
 int mnk_ls_bk_permute(mnk_ls* ls, double* x, double* tmp, bool forward);  // x <- P x (forward) / P^T x

@@ -675,6 +675,12 @@ static int prepare_fill(mnk_ls* ls) {
                     hipEventCreateWithFlags(&ls->ev_free, hipEventDisableTiming) != hipSuccess)) { ls->prefill = 0; pre = false; }
         if (pre) MNK_HIP(hipMemsetAsync(ls->fact_spare.p, 0, ls->fact_spare.n * sizeof(double), s));  // (slack behind the matrix)
     }
+    if (pre && ls->spare_zeroed && ls->spare_by_dag && !ls->info_valid) {
+        // The zero-fill was left to the task queue of the previous factorization, and nobody has looked at its `info` yet: a
+        // factorization that fails (a time-out, a Cholesky breakdown) drops the rest of its queue, fill tasks included.
+        ls->spare_zeroed = false;
+        ls->spare_by_dag = false;
+    }
     if (pre && ls->spare_zeroed) {
         std::swap(ls->fact.p, ls->fact_spare.p);          // the buffer zeroed in the background becomes the factor buffer
         MNK_HIP(hipStreamWaitEvent(s, ls->ev_spare, 0));
@@ -701,8 +707,10 @@ int mnk_ls_prefill_spare(mnk_ls* ls) {
         ls->dag_filled = false;
         MNK_HIP(hipEventRecord(ls->ev_spare, ls->ctx->stream));
         ls->spare_zeroed = true;
+        ls->spare_by_dag = true;
         return 0;
     }
+    ls->spare_by_dag = false;
     mnk_ctx* ctx = ls->ctx;
     dim3 grid((unsigned)ls->Np, (unsigned)((ls->Np / 2 + 255) / 256));
     MNK_HIP(hipEventRecord(ls->ev_free, ctx->stream));
@@ -954,9 +962,8 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
                 if (rc) return rc;
             }
         }
-        MNK_HIP(hipMemcpyAsync(xk, w, N * sizeof(double),
-                               loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
-        if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(s));
+        if (loc == MNK_DEVICE) MNK_HIP(hipMemcpyAsync(xk, w, N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        else MNK_HIP(mnk::d2h_copy(xk, w, N * sizeof(double), s));
     }
     return 0;
 }
@@ -1001,14 +1008,14 @@ int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n) {
         MNK_HIP(hipSetDevice(ls->ctx->device));
         MNK_HIP(mnk::stream_wait(ls->ctx->stream));
         const int64_t cnt = std::min<int64_t>(n, (int64_t)ls->dag_trace.n);
-        MNK_HIP(hipMemcpy(out, ls->dag_trace.p, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        MNK_HIP(mnk::d2h_copy(out, ls->dag_trace.p, cnt * sizeof(unsigned long long), ls->ctx->stream));
         return 0;
     }
     MNK_REQUIRE(ls && out && ls->solve_trace.p, "mnk_ls_debug_solve_trace: tracing is off (option solve_trace)");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     MNK_HIP(mnk::stream_wait(ls->ctx->stream));
     const int64_t cnt = std::min<int64_t>(n, (ls->Np / 64) * 8);
-    MNK_HIP(hipMemcpy(out, ls->solve_trace.p, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    MNK_HIP(mnk::d2h_copy(out, ls->solve_trace.p, cnt * sizeof(unsigned long long), ls->ctx->stream));
     return 0;
 }
 
@@ -1018,11 +1025,15 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
     MNK_REQUIRE(ls->factorized, "mnk_ls_get_factor: factorize first");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     hipStream_t s = ls->ctx->stream;
-    const hipMemcpyKind kind = loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    MNK_HIP(hipMemcpy2DAsync(L, ls->N * sizeof(double), ls->fact.p, ls->ld * sizeof(double),
-                             ls->N * sizeof(double), ls->N, kind, s));
-    if (D) MNK_HIP(hipMemcpyAsync(D, ls->dvec.p, ls->N * sizeof(double), kind, s));
-    MNK_HIP(mnk::stream_wait(s));
+    if (loc == MNK_DEVICE) {
+        MNK_HIP(hipMemcpy2DAsync(L, ls->N * sizeof(double), ls->fact.p, ls->ld * sizeof(double), ls->N * sizeof(double), ls->N,
+                                 hipMemcpyDeviceToDevice, s));
+        if (D) MNK_HIP(hipMemcpyAsync(D, ls->dvec.p, ls->N * sizeof(double), hipMemcpyDeviceToDevice, s));
+        MNK_HIP(mnk::stream_wait(s));
+    } else {
+        MNK_HIP(mnk::d2h_copy_2d(L, ls->N * sizeof(double), ls->fact.p, ls->ld * sizeof(double), ls->N * sizeof(double), ls->N, s));
+        if (D) MNK_HIP(mnk::d2h_copy(D, ls->dvec.p, ls->N * sizeof(double), s));
+    }
     return 0;
 }
 
@@ -1066,9 +1077,8 @@ int mnk_ls_bk_info(mnk_ls* ls, int* active, int* count, int32_t* perm, double* d
     if (count) *count = ls->bk_count;
     if (ls->bk_active && (perm || doff)) {
         hipStream_t s = ls->ctx->stream;
-        if (perm) MNK_HIP(hipMemcpyAsync(perm, ls->bk_perm.p, ls->N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        if (doff) MNK_HIP(hipMemcpyAsync(doff, ls->bk_doff.p, ls->N * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(mnk::stream_wait(s));
+        if (perm) MNK_HIP(mnk::d2h_copy(perm, ls->bk_perm.p, ls->N * sizeof(int32_t), s));
+        if (doff) MNK_HIP(mnk::d2h_copy(doff, ls->bk_doff.p, ls->N * sizeof(double), s));
     }
     return 0;
 }
@@ -1168,7 +1178,7 @@ int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const doub
     *ms = (double)t;
     if (variant == 20 || variant == 21) {  // report the probe's ticks (10 ns each) instead
         unsigned long long h = 0;
-        MNK_HIP(hipMemcpy(&h, probe.p, sizeof(h), hipMemcpyDeviceToHost));
+        { mnk::H2DGuard guard; MNK_HIP(hipMemcpy(&h, probe.p, sizeof(h), hipMemcpyDeviceToHost)); }
         *ms = (double)h;
     }
     (void)hipEventDestroy(e0);

@@ -133,8 +133,12 @@ __global__ __launch_bounds__(256) void linv_tri_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void linv256_mfma_kernel(const double* __restrict__ F, int64_t ld, const double* __restrict__ Linv64,
                                                            double* __restrict__ Inv,
                                                            double* __restrict__ InvT, int64_t Np, const int* __restrict__ info,
-                                                           int blk0) {
+                                                           int blk0, const mnk::SmallSysRec* __restrict__ recs = nullptr) {
     __shared__ v4f64 tile[1024];
+    if (recs != nullptr) {   // (a batch of small systems: blockIdx.z = system)
+        const mnk::SmallSysRec r = recs[blockIdx.z];
+        F = r.F; ld = r.ld; Linv64 = r.linv; Inv = r.linv256; InvT = r.linv256t; Np = r.Np; info = r.info;
+    }
     if (*info != 0) return;
     const int64_t blk = (int64_t)blockIdx.x + blk0;
     const int q = blockIdx.y;
@@ -979,6 +983,14 @@ int mnk_ls_build_inverses(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
                                ls->linv512tmp.p, ls->linv512.p, ls->linv512t.p, ls->Np, (int)t0, ls->info_dev.p);
         }
     }
+    MNK_HIP(hipGetLastError());
+    return 0;
+}
+
+int mnk_ls_build_inverses_batch(hipStream_t s, const mnk::SmallSysRec* recs_dev, int n, int64_t Np) {
+    const unsigned nblk = (unsigned)((Np + SB - 1) / SB);
+    hipLaunchKernelGGL(linv256_mfma_kernel, dim3(nblk, 4, (unsigned)n), dim3(256), 0, s, (const double*)nullptr, (int64_t)0,
+                       (const double*)nullptr, (double*)nullptr, (double*)nullptr, (int64_t)0, (const int*)nullptr, 0, recs_dev);
     MNK_HIP(hipGetLastError());
     return 0;
 }

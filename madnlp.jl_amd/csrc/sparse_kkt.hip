@@ -462,10 +462,10 @@ int mnk_sc_get_values(mnk_sc* sc, int which, double* out, int loc) {
     else if (which == MNK_SC_AUG) { src = sc->aug_nz.p; cnt = sc->nnz_aug; }
     else if (which == MNK_SC_DIAGBUF) { src = sc->diag_buffer.p; cnt = sc->m; }
     else { set_error("mnk_sc_get_values: bad selector %d", which); return -1; }
-    if (cnt > 0)
-        MNK_HIP(hipMemcpyAsync(out, src, cnt * sizeof(double),
-                               loc == MNK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, sc->ctx->stream));
-    if (loc != MNK_DEVICE) MNK_HIP(mnk::stream_wait(sc->ctx->stream));
+    if (cnt > 0) {
+        if (loc == MNK_DEVICE) MNK_HIP(hipMemcpyAsync(out, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, sc->ctx->stream));
+        else MNK_HIP(mnk::d2h_copy(out, src, cnt * sizeof(double), sc->ctx->stream));
+    }
     return 0;
 }
 
@@ -650,8 +650,7 @@ int mnk_sc_solve_kkt(mnk_sc* sc, mnk_ls* ls, double* w, int loc) {
         if (loc == MNK_DEVICE) break;  // device-resident caller: mnk_ls_check_solve() reports an abort
         MNK_HIP(mnk::stream_wait(s));
         if (attempt == 0 && mnk_ls_take_solve_abort(ls)) continue;  // redo with the stepwise solve
-        MNK_HIP(hipMemcpyAsync(w, d, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(mnk::stream_wait(s));
+        MNK_HIP(mnk::d2h_copy(w, d, lw * sizeof(double), s));
         break;
     }
     return 0;
@@ -691,8 +690,7 @@ int mnk_sc_mul(mnk_sc* sc, double* w, const double* x, double alpha, double beta
                            sp->ind_ub.p, sp->u_lower.p, sp->u_diag.p, alpha, beta, nub, 1);
     MNK_HIP(hipGetLastError());
     if (loc != MNK_DEVICE) {
-        MNK_HIP(hipMemcpyAsync(w, dw, lw * sizeof(double), hipMemcpyDeviceToHost, s));
-        MNK_HIP(mnk::stream_wait(s));
+        MNK_HIP(mnk::d2h_copy(w, dw, lw * sizeof(double), s));
     }
     return 0;
 }

@@ -80,9 +80,11 @@ def test_c5_batch_on_one_gpu_matches_oracle(nctx, nb):
             with torch.cuda.stream(st):
                 kh.compress_jacobian(din["jac"]); kh.compress_hessian(din["hess"]); kh.build_kkt(din["pr"], din["du"])
                 kh.linear_solver.factorize_async()
-        for (P, kh, st, din) in insts:
+        for idx, (P, kh, st, din) in enumerate(insts):
             with torch.cuda.stream(st):
-                assert kh.linear_solver.inertia() == (P.n, 0, 0)
+                M = kh.linear_solver
+                assert M.inertia() == (P.n, 0, 0), (rep, idx, M.get_stat("panel_algo"), M.get_stat("pp_fallbacks"),
+                                                    M.get_stat("timeout_site"), M.get_stat("growth"), M.bk_info()[:2])
                 din["x"].copy_(din["rhs"])
                 kh.linear_solver.solve_linear_system(din["x"])
     torch.cuda.synchronize()

@@ -69,7 +69,7 @@ def test_default_schedule_across_its_range(ctx, N, alg):
     torch.cuda.synchronize()   # A, b, x were produced on torch's stream, the solver works on the context's
     M = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg))
     M.factorize()
-    assert (M.get_stat("panel_algo"), M.get_stat("pp_fallbacks")) == (5.0, 0.0)
+    assert (M.get_stat("panel_algo"), M.get_stat("pp_fallbacks")) == (5.0, 0.0), M.get_stat("timeout_site")
     want = (n1, 0, N - n1)
     assert M.inertia() == want
     if N <= 9000:
@@ -296,49 +296,6 @@ def test_options_pinned_by_the_environment_are_reported():
     assert "ignored" in r.stderr and "panel_algo" in r.stderr
 
 
-@pytest.mark.gpu
-def test_first_factorizations_of_several_threads_with_the_large_system_schedule(ctx):
-    """The first round of a multi-threaded run: every thread's solver uploads its task list (a host -> device copy from
-    pageable memory) while another thread's persistent group may be in flight -- such a copy stops the group for good
-    (tools/first_group_probe.py), so the library's own uploads take the launch mutex and wait for the operation in flight
-    (common.h: H2DGuard).  Three threads, order 6400 (band + bulk + tile-closing structure, unlike the 4100 of the test
-    above), host right-hand sides on top: no fall-back, correct solves."""
-    import threading
-    dev = torch.device("cuda", 0)
-    N = 6400
-    A, n1 = _dev_matrix(N, mj.LDL, dev)
-    Ah = A.cpu().numpy()
-    anorm = np.abs(Ah).sum(axis=1).max()
-    torch.cuda.synchronize()
-    errors = []
-
-    def worker(i):
-        try:
-            st = torch.cuda.Stream(dev)
-            c = mj.HipContext(0, stream=st.cuda_stream)
-            with torch.cuda.stream(st):
-                M = mj.HipLinearSolver(A, ctx=c, opt=mj.HipSolverOptions(lapack_algorithm=mj.LDL))
-                rng = np.random.default_rng(100 + i)
-                for rep in range(3):
-                    M.factorize()
-                    assert (M.get_stat("panel_algo"), M.get_stat("pp_fallbacks")) == (5.0, 0.0), (i, rep, M.get_stat("timeout_site"))
-                    b = rng.standard_normal(N)
-                    x = M.solve_linear_system(b.copy())        # (a HOST vector: uploaded by the library)
-                    bwd = np.abs(Ah @ x - b).max() / (anorm * np.abs(x).max() + np.abs(b).max())
-                    assert bwd <= 1e-13, (i, rep, bwd)
-                M.close()
-            c.close()
-        except BaseException as e:  # noqa: BLE001  (reported by the main thread)
-            errors.append((i, repr(e)))
-
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert not errors, errors
-
-
 def _indefinite(kind, N, rng):
     if kind == "random":
         S = rng.standard_normal((N, N))
@@ -462,3 +419,35 @@ def test_multi_workgroup_panel_that_gives_up_is_redone_with_one_workgroup_per_pa
     M.factorize()                       # (stays on the one-workgroup panels)
     assert M.inertia() == ref.inertia() and M.get_stat("bk_mw_fallbacks") == 1 and M.get_stat("bk_panel_multi") == 0.0
     M.close()
+
+
+@pytest.mark.gpu
+def test_time_out_of_the_task_dag_schedule_with_a_sparse_source_is_redone_on_a_clean_buffer(ctx):
+    """The zero-fill of the second factor buffer rides on the task queue of the factorization (DAG_FILL tasks) -- and a
+    factorization whose `info` becomes non-zero drops the rest of its queue.  The redo after a time-out transfers the matrix
+    again: it must not swap the half-zeroed buffer (the previous factor) in.  case1354pegase-shaped condensed system through
+    its KKT handle: a good factorization (the buffers now hold a factor), then one whose chain gives up (option
+    debug_pp_missing) -- the redo's inertia and solve must be right, and so must the next factorization's."""
+    from madnlp_jl_amd.problems import OPF_CASES, opf_shaped
+    P = opf_shaped("case1354pegase", seed=OPF_CASES["case1354pegase"][0] + 7, du=1e-8)
+    k = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                    opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+    k.jac[:] = P.jac; k.hess[:] = P.hess; k.pr_diag[:] = P.pr_diag; k.du_diag[:] = P.du_diag
+    k.compress_jacobian(); k.compress_hessian(); k.build_kkt()
+    M = k.linear_solver
+    M.set_option("dag_spin_limit", 1 << 17)
+    a = k.aug_com
+    Kl = sp.csc_matrix((a.nzval.copy(), a.rowval, a.colptr), shape=(P.n, P.n))
+    K = (Kl + sp.tril(Kl, -1).T).tocsr()
+    b = np.random.default_rng(3).standard_normal(P.n)
+    knorm = abs(K).sum(axis=1).max()
+    bwd = lambda x: np.abs(K @ x - b).max() / (knorm * np.abs(x).max() + np.abs(b).max())
+    for rnd, missing in enumerate((-1, -1, 5, -1, -1)):
+        M.set_option("debug_pp_missing", missing)
+        k.build_kkt()
+        M.factorize()
+        assert M.inertia() == (P.n, 0, 0), (rnd, M.inertia(), M.get_stat("pp_fallbacks"))
+        x = M.solve_linear_system(b.copy())
+        assert bwd(x) <= 1e-13, (rnd, bwd(x))
+        assert M.get_stat("pp_fallbacks") == (0.0 if rnd < 2 else 1.0)
+    k.close()

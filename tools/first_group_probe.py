@@ -76,6 +76,17 @@ def t1():
                 if not keep:
                     keep.append(torch.from_numpy(np.ones(1 << 16)).to(dev))
                 time.sleep(0.005)
+            elif act in ("d2h_raw", "h2d_raw"):   # hipMemcpy itself on a plain numpy buffer (no staging by torch)
+                import ctypes
+                if not keep:
+                    keep.append(ctypes.CDLL("libamdhip64.so"))
+                    keep.append(torch.ones(1 << 16, dtype=torch.float64, device=dev))
+                    keep.append(np.ones(1 << 16))
+                hip, dten, harr = keep
+                if act == "d2h_raw":
+                    hip.hipMemcpy(ctypes.c_void_p(harr.ctypes.data), ctypes.c_void_p(dten.data_ptr()), ctypes.c_size_t(harr.nbytes), 2)
+                else:
+                    hip.hipMemcpy(ctypes.c_void_p(dten.data_ptr()), ctypes.c_void_p(harr.ctypes.data), ctypes.c_size_t(harr.nbytes), 1)
             elif act == "sync":
                 st.synchronize()
             else:

@@ -47,10 +47,14 @@ def worker(i):
                 sites.append((rep, int(M.get_stat("timeout_site"))))
                 fb = f
             b = torch.randn(N, dtype=torch.float64, device=dev, generator=gg)
-            x = b.clone()
-            st.synchronize()
-            M.solve_linear_system(x)
-            M.check_solve()
+            if "--host-rhs" in sys.argv:   # (a HOST vector: uploaded and fetched back by the library, pageable memory)
+                xh = M.solve_linear_system(b.cpu().numpy().copy())
+                x = torch.from_numpy(xh).to(dev)
+            else:
+                x = b.clone()
+                st.synchronize()
+                M.solve_linear_system(x)
+                M.check_solve()
             if ((A @ x - b).abs().max() / (A.abs().sum(dim=1).max() * x.abs().max())).item() > 1e-13:
                 bad += 1
         M.close()
