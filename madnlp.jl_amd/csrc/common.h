@@ -205,6 +205,10 @@ struct mnk_ctx {
     bool released = false;
 };
 int mnk_masked_stream_pair(mnk_ctx* ctx, int chain_cus, hipStream_t* sp, hipStream_t* su);   // ls.hip
+// CU-masked streams that are made when a caller first needs them (every one is a hardware queue of the device): ls.hip
+int mnk_ctx_ensure_panel_streams(mnk_ctx* ctx);   // ctx->sp / su: look-ahead streams of the launch-per-panel schedules
+int mnk_ctx_ensure_dag2(mnk_ctx* ctx);            // ctx->sp_dag2 / su_dag2: deep-band pair of the task-DAG schedule
+int mnk_ctx_ensure_batch_streams(mnk_ctx* ctx);   // ctx->sp_dagB / su_dagB: second chain partition + bulk stream of batches
 int mnk_solve_warmup(hipStream_t s);               // solve.hip: first (no-op) launch of the inverse kernel that needs scratch
 int mnk_dag_warmup(hipStream_t* streams, int n, int nwg);   // dag.hip: first (empty) launch of the bulk kernels on these streams
 int mnk_live_contexts(int device);  // contexts alive on this device in this process

@@ -1026,6 +1026,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     }
     if (js2 < nsc) {
         const int64_t rows2 = Np - 256 * (int64_t)js2;
+        MNK_REQUIRE(ctx->sp_dag2 != nullptr, "task-DAG schedule: the deep-band streams are missing");   // (mnk_ls_run_factorization made them)
         int rc = phase(ctx->sp_dag2, ctx->su_dag2, ctx->num_cu - ctx->dag_cus2, ls->dag_ntasks1, ls->dag_ntasks - ls->dag_ntasks1,
                        qctr + 1, js2, nsc, (unsigned)(rows2 / NBI));
         if (rc) return rc;
@@ -1072,7 +1073,9 @@ bool mnk_batch_defer(mnk_ls* ls) {
     const int nsc = (int)((ls->Np + 255) / 256);
     // (two merged launches: the large-system mode of the schedule -- band + bulk + two alternating chains -- and the small
     // one, every row in the chain's band, many chains side by side; a second phase in mid-factorization is simply run now)
-    if (ls->algo_now != 5 || (ls->dag_js2 != nsc && ls->dag_js2 != 0) || ls->dag_trace_on || ls->ctx->partitioned || !ls->ctx->sp_dagB) return false;
+    if (ls->algo_now != 5 || (ls->dag_js2 != nsc && ls->dag_js2 != 0) || ls->dag_trace_on || ls->ctx->partitioned) return false;
+    if (mnk_ctx_ensure_batch_streams(ls->ctx) != 0) (void)hipGetLastError();   // (made with the first batch of a process)
+    if (!ls->ctx->sp_dagB) return false;
     if (!ls->ev_defer && hipEventCreateWithFlags(&ls->ev_defer, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipEventRecord(ls->ev_defer, ls->ctx->stream) != hipSuccess) { (void)hipGetLastError(); return false; }
     ls->deferred = true;
@@ -1205,7 +1208,9 @@ static int batch_run_group_small(std::vector<mnk_ls*>& g) {
     // 8 XCDs x 4 SEs = 32 (tools/hip/mask_resident.hip: masks of 32 / 64 / 96 / 192 / 256 bits hold as many 96-KB workgroups
     // as they have bits; 40, 48, 56, 72, 104, 176 do not, e.g. 34 workgroups on a 40-bit mask: 32 resident -- five 34-strip
     // systems on 176 CUs stalled into the schedule's time-out).
-    auto chain_cus_for = [&](int k) { return std::min(c0->num_cu, (k * strips + 31) / 32 * 32); };
+    // (... and of 64, so that a process ends up with three such stream pairs at most: every masked stream is a hardware queue,
+    // and the device runs only so many of them side by side -- ls.hip, ctx_create_common)
+    auto chain_cus_for = [&](int k) { return std::min(c0->num_cu, (k * strips + 63) / 64 * 64); };
     int kmax = std::min(32, (c0->num_cu - bulk_min) / strips);
     while (kmax > 1 && chain_cus_for(kmax) > c0->num_cu - bulk_min) --kmax;
     if (kmax < 2) {   // (no room for two chains: one after the other, as without a batch)

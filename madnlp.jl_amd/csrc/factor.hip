@@ -1363,6 +1363,10 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     if (ls->algo_now >= 4 && ls->pp_blocked) ls->algo_now = 1;
     // the task-DAG schedule's buffers (task list, progress words, V = L D): a device that cannot hold them keeps schedule 4
     if (ls->algo_now == 5 && mnk_ls_dag_prepare(ls) != 0) ls->algo_now = 4;
+    if (ls->algo_now == 5 && ls->dag_js2 < (Np + 255) / 256) {   // (the deep-band stream pair: made with the first such factorization)
+        if (mnk_ctx_ensure_dag2(ctx) != 0) (void)hipGetLastError();
+        if (ctx->sp_dag2 == nullptr) ls->algo_now = 4;
+    }
     // Persistent schedules of different contexts take turns on the device (common.h: mnk_persist_begin); round 3 sent every
     // solver to schedule 1 as soon as a second context was alive (12.4 instead of 9.3 ms at C3).
     // a batch of independent factorizations (dag.hip: mnk_factorize_batch_begin / _end) launches them together later
@@ -1424,6 +1428,7 @@ static int run_factorization_body(mnk_ls* ls) {
         // One CU partition for every size: a quarter of the CUs for the panel stream.  (A second pair with an
         // eighth, for "update-bound" sizes, measured slower at every N once the panel stream's CUs join the
         // trailing update: N = 30 000 156 vs 178 ms, N = 11 192 +0.5 ms per step taken on it.)
+        { int rc_s = mnk_ctx_ensure_panel_streams(ctx); if (rc_s) return rc_s; }   // (made with the first factorization that takes this schedule)
         hipStream_t sp = ctx->sp, su = ctx->su;
         if ((int64_t)ctx->ev_panel.size() < npanel + 1) {
             const size_t old = ctx->ev_panel.size();

@@ -248,6 +248,103 @@ static bool make_masked_stream(int num_cu_total, const int* bits, int count, hip
     return false;
 }
 
+}  // extern "C"
+// The CU-masked stream pairs of the task-DAG schedule that whole-device contexts share per device (process lifetime).  Only
+// the first pair (pivot chain | bulk kernel) is made with the first context; the others when a caller first needs them --
+// every masked stream is a hardware queue (see ctx_create_common).
+namespace {
+struct DagStreams { hipStream_t sp = nullptr, su = nullptr, sp2 = nullptr, su2 = nullptr, spB = nullptr, suB = nullptr; int cus = 0; bool made = false; };
+DagStreams g_dag_streams[64];
+std::vector<int> ctx_bits(const mnk_ctx* c) {
+    std::vector<int> bits;
+    for (int b = 0; b < c->num_cu; ++b) bits.push_back(c->cu_first + b);
+    return bits;
+}
+}  // namespace
+
+// the deep-band pair (every row of a small system in the chain's band: dag_cus2 chain CUs | the others)
+int mnk_ctx_ensure_dag2(mnk_ctx* c) {
+    if (c->sp_dag2 != nullptr || c->dag_cus2 <= 0 || !c->shared_dag_streams) return 0;
+    mnk::LaunchLock lock;   // (stream creation may synchronize the device)
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    DagStreams& d = g_dag_streams[c->device & 63];
+    if (d.sp2 == nullptr) {
+        mnk::quiesce_persistent();
+        MNK_HIP(hipSetDevice(c->device));
+        const std::vector<int> bits = ctx_bits(c);
+        if (!(make_masked_stream(c->total_cu, bits.data(), c->dag_cus2, d.sp2) &&
+              make_masked_stream(c->total_cu, bits.data() + c->dag_cus2, c->num_cu - c->dag_cus2, d.su2))) {
+            if (d.sp2) (void)hipStreamDestroy(d.sp2);
+            d.sp2 = d.su2 = nullptr;
+            return -2;
+        }
+        hipStream_t warm[1] = {d.su2};
+        if (mnk_dag_warmup(warm, 1, 3 * c->num_cu) != 0) (void)hipGetLastError();
+        if (mnk_solve_warmup(d.su2) != 0) (void)hipGetLastError();
+    }
+    c->sp_dag2 = d.sp2; c->su_dag2 = d.su2;
+    return 0;
+}
+
+// batches of independent factorizations: a second chain partition and a bulk stream on the CUs outside both
+int mnk_ctx_ensure_batch_streams(mnk_ctx* c) {
+    if (c->sp_dagB != nullptr || c->dag_cus <= 0 || !c->shared_dag_streams || 2 * c->dag_cus + 32 > c->num_cu) return 0;
+    mnk::LaunchLock lock;
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    DagStreams& d = g_dag_streams[c->device & 63];
+    if (d.spB == nullptr) {
+        mnk::quiesce_persistent();
+        MNK_HIP(hipSetDevice(c->device));
+        const std::vector<int> bits = ctx_bits(c);
+        if (!(make_masked_stream(c->total_cu, bits.data() + c->dag_cus, c->dag_cus, d.spB) &&
+              make_masked_stream(c->total_cu, bits.data() + 2 * c->dag_cus, c->num_cu - 2 * c->dag_cus, d.suB))) {
+            if (d.spB) (void)hipStreamDestroy(d.spB);
+            d.spB = d.suB = nullptr;
+            return -2;
+        }
+        hipStream_t warm[1] = {d.suB};
+        if (mnk_dag_warmup(warm, 1, 3 * c->num_cu) != 0) (void)hipGetLastError();
+        for (hipStream_t w : {d.suB, d.spB})
+            if (mnk_solve_warmup(w) != 0) (void)hipGetLastError();
+    }
+    c->sp_dagB = d.spB; c->su_dagB = d.suB;
+    return 0;
+}
+
+// the look-ahead streams of the launch-per-panel schedules (1, 4): a quarter of the CUs for the panel stream, the rest for the
+// update stream (measured, profiles/; MNK_PANEL_CUS overrides); stream priorities where masks are not to be had
+int mnk_ctx_ensure_panel_streams(mnk_ctx* c) {
+    if (c->sp != nullptr) return 0;
+    mnk::LaunchLock lock;
+    mnk::quiesce_persistent();
+    MNK_HIP(hipSetDevice(c->device));
+    const std::vector<int> bits = ctx_bits(c);
+    auto make_pair = [&](int want) -> bool {
+        if (want <= 0 || want >= c->num_cu) return false;
+        if (make_masked_stream(c->total_cu, bits.data(), want, c->sp) &&
+            make_masked_stream(c->total_cu, bits.data() + want, c->num_cu - want, c->su))
+            return true;
+        if (c->sp) { (void)hipStreamDestroy(c->sp); c->sp = nullptr; }
+        c->su = nullptr;
+        return false;
+    };
+    if (const char* e = getenv("MNK_PANEL_CUS")) {
+        const int want = atoi(e);
+        if (make_pair(want)) c->panel_cus = want;
+    } else if (c->num_cu >= 16) {
+        const int q4 = std::max(4, c->num_cu / 4);
+        if (make_pair(q4)) c->panel_cus = q4;
+    }
+    if (!c->sp) {
+        int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
+        MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        MNK_HIP(hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, prio_hi));
+        MNK_HIP(hipStreamCreateWithPriority(&c->su, hipStreamNonBlocking, prio_lo));
+    }
+    return 0;
+}
+
+extern "C" {
 // `part_first/part_count` confine the context to a contiguous range of CU-mask bits.  Kept for experiments
 // only (no public entry point): partitions run MFMA-bound kernels side by side at full rate, but the
 // latency-bound panel chain of one instance slows ~2x next to the updates of the others -- every partition
@@ -292,10 +389,11 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
         MNK_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    // Look-ahead streams.  The panel stream runs small latency-bound kernels; sharing SIMDs
-    // with the MFMA-saturating trailing update slows them 4-5x (measured), so the two streams
-    // get disjoint CU sets: the panel stream the first `panel_cus` mask bits of the context's
-    // range, the update stream all the others.  Fallback: stream priorities.
+    // (The look-ahead streams of the launch-per-panel schedules are created when such a schedule first runs:
+    // mnk_ctx_ensure_panel_streams.  Every CU-masked stream is a hardware queue of its own, and the hardware runs only so
+    // many queues of a device side by side -- all processes together: with four idle contexts in a PARENT process, each
+    // holding its masked pair, a child's chain and bulk kernels were no longer scheduled together and every run of
+    // tools/parent_child_probe.py lost factorizations to their bounded waits; without the pairs, none.)
     auto make_pair = [&](int want, hipStream_t& sp, hipStream_t& su) -> bool {
         if (want <= 0 || want >= c->num_cu) return false;
         if (make_masked_stream(total, bits.data(), want, sp) &&
@@ -305,53 +403,30 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
         su = nullptr;
         return false;
     };
-    // default partition (measured, profiles/): a quarter of the CUs for the panel stream; MNK_PANEL_CUS overrides.
-    if (const char* e = getenv("MNK_PANEL_CUS")) {
-        const int want = atoi(e);
-        if (make_pair(want, c->sp, c->su)) c->panel_cus = want;
-    } else if (c->num_cu >= 16) {
-        const int q4 = std::max(4, c->num_cu / 4);
-        if (make_pair(q4, c->sp, c->su)) c->panel_cus = q4;
-    }
     // second pair for the task-DAG schedule: a handful of CUs for the pivot chain (two per XCD), the rest for the bulk kernel.
     // Whole-device contexts SHARE these four streams per device: the persistent operations of a process take turns on the
     // device anyway (mnk_persist_begin), and every stream more is one more client of the runtime's few hardware queues -- two
     // streams whose kernels must run side by side (chain and bulk) must not end up multiplexed behind a third one.
     if (c->num_cu >= 64) {
-        struct DagStreams { hipStream_t sp = nullptr, su = nullptr, sp2 = nullptr, su2 = nullptr, spB = nullptr, suB = nullptr; int cus = 0, cus2 = 0; bool made = false; };
-        static DagStreams shared[64];
         DagStreams own;
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
-        DagStreams& d = part ? own : shared[device & 63];
+        DagStreams& d = part ? own : g_dag_streams[device & 63];
         if (!d.made) {
             const int want = getenv("MNK_DAG_CUS") ? atoi(getenv("MNK_DAG_CUS")) : 16;
             if (make_pair(want, d.sp, d.su)) d.cus = want;
-            const int want2 = getenv("MNK_DAG_CUS2") ? atoi(getenv("MNK_DAG_CUS2")) : 96;
-            if (d.cus > 0 && make_pair(want2, d.sp2, d.su2)) d.cus2 = want2;
-            // batches of independent factorizations: a second chain partition and a bulk stream on the CUs outside both
-            if (d.cus > 0 && 2 * d.cus + 32 <= c->num_cu) {
-                if (!(make_masked_stream(total, bits.data() + d.cus, d.cus, d.spB) &&
-                      make_masked_stream(total, bits.data() + 2 * d.cus, c->num_cu - 2 * d.cus, d.suB))) {
-                    if (d.spB) (void)hipStreamDestroy(d.spB);
-                    d.spB = d.suB = nullptr;
-                }
-            }
             d.made = true;
-            hipStream_t warm[3] = {d.su, d.su2, d.suB};
-            if (mnk_dag_warmup(warm, 3, 3 * c->num_cu) != 0) (void)hipGetLastError();   // (best effort)
-            for (hipStream_t w : {d.su, d.su2, d.sp, d.spB})              // (where the inverses for the solves are launched)
+            hipStream_t warm[1] = {d.su};
+            if (mnk_dag_warmup(warm, 1, 3 * c->num_cu) != 0) (void)hipGetLastError();   // (best effort)
+            for (hipStream_t w : {d.su, d.sp})              // (where the inverses for the solves are launched)
                 if (w != nullptr && mnk_solve_warmup(w) != 0) (void)hipGetLastError();
         }
-        c->sp_dagB = d.spB; c->su_dagB = d.suB;
         c->sp_dag = d.sp; c->su_dag = d.su; c->dag_cus = d.cus;
-        c->sp_dag2 = d.sp2; c->su_dag2 = d.su2; c->dag_cus2 = d.cus2;
+        c->dag_cus2 = d.cus > 0 ? (getenv("MNK_DAG_CUS2") ? atoi(getenv("MNK_DAG_CUS2")) : 96) : 0;   // (its streams: mnk_ctx_ensure_dag2)
+        if (c->dag_cus2 <= 0 || c->dag_cus2 >= c->num_cu) c->dag_cus2 = 0;
         c->shared_dag_streams = !part;
-    }
-    if (!c->sp) {
-        int prio_lo = 0, prio_hi = 0;  // numerically lower = higher priority
-        MNK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        MNK_HIP(hipStreamCreateWithPriority(&c->sp, hipStreamNonBlocking, prio_hi));
-        MNK_HIP(hipStreamCreateWithPriority(&c->su, hipStreamNonBlocking, prio_lo));
+        if (part) {   // (a partition's streams are its own: made now, destroyed with it)
+            if (c->dag_cus2 > 0 && !make_pair(c->dag_cus2, c->sp_dag2, c->su_dag2)) c->dag_cus2 = 0;
+        }
     }
     MNK_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     MNK_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
@@ -1115,6 +1190,7 @@ int mnk_debug_update(mnk_ctx* ctx, int variant, int64_t M, int64_t K, const doub
                      double* C2, int64_t ldc, int reps, double* ms) {
     MNK_REQUIRE(ctx && A && C && ms, "mnk_debug_update: NULL argument");
     MNK_HIP(hipSetDevice(ctx->device));
+    { int rc_s = mnk_ctx_ensure_panel_streams(ctx); if (rc_s) return rc_s; }
     hipStream_t s = ctx->stream, su = ctx->su, sp = ctx->sp;
     MNK_REQUIRE(su && sp, "mnk_debug_update: no look-ahead streams");
     DevBuf<int> ctr;
