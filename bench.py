@@ -563,7 +563,8 @@ def main():
         fact_ms = float(np.mean([a[1] for a in allms]))
         ach = flops / (fact_ms * 1e-3) / 1e12
         schedule = ls.get_stat("panel_algo")
-        fallbacks = ls.get_stat("pp_fallbacks")   # > 0: a device-side hand-off timed out and schedule 1 ran instead
+        # > 0: a device-side hand-off timed out and schedule 1 ran instead; summed over every instance of this rank
+        fallbacks = float(sum(it[1].linear_solver.get_stat("pp_fallbacks") for it in insts))
         traffic, traffic_src = pmc_traffic(N, args, schedule)
         out = {
             "metric": METRIC, "value": world * args.batch * args.steps / elapsed, "unit": "it/s",
