@@ -492,6 +492,12 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d);
  * path (8 x 100 MHz timer values per 64-row block); this copies them out (n = number of uint64 to copy). */
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);
 
+/* Diagnostics: with option "dag_debug" = 1 a factorization of the task-DAG schedule that runs into its bounded waits keeps the
+ * schedule's progress words (two queue counters | front[Np / 64] | af[ntile^2] | tprog[ntile^2]) and 8 words per pivot-chain
+ * strip saying what it was waiting for ({site, strip-column, strip, word, target, value, spins >> 20, 0}) as the time-out left
+ * them, before the factorization is redone.  Copies up to `nflags` / `nchain` ints; *have = 1 if a time-out was recorded. */
+int mnk_ls_debug_dag_state(mnk_ls* ls, int* flags, int64_t nflags, int* chain, int64_t nchain, int* have);
+
 /* Diagnostics / tests (host only): the task list of the task-DAG factorization schedule (csrc/dag.hip) for a matrix of `ntile`
  * 128-row tiles: 4 ints per task (flags | chunk index << 8, tile row I, tile column J, kbeg | kend << 16) in queue order, at most
  * `cap` tasks written; returns the number of tasks (negative: bad arguments). */

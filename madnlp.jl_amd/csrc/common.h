@@ -238,6 +238,9 @@ struct PpDag {
     long spin_limit;
     unsigned long long* trace;  // diagnostics: 8 time stamps per strip of this launch
     unsigned long long* vmax;   // growth monitor (LDL^T with the BUNCHKAUFMAN guard on): receives max|V|, see growth_fold
+    int* dbg;            // diagnostics (option dag_debug): 8 words per strip of the chain -- what a strip that has been waiting for
+                         // a long time waits for: {site, strip-column, strip, word index (front: block; af: -1 - tile index),
+                         // target, value seen, spins >> 20, 0}
 };
 }  // namespace mnk
 

@@ -979,7 +979,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         if (!small) MNK_HIP(hipStreamWaitEvent(sp, ctx->ev_a, 0));
         MNK_HIP(hipStreamWaitEvent(su, ctx->ev_a, 0));
         mnk::PpDag dag{front, inst.af, ntile, 0, 0, -1, spin_limit, trace ? trace + (size_t)ls->dag_ntasks * 8 + (size_t)js_begin * 8 * 16 : nullptr,
-                  mnk_ls_growth_word(ls)};
+                  mnk_ls_growth_word(ls), ls->dag_debug ? ls->dag_dbg.p : nullptr};
         // (the chain first: its first diagonal block is the start of the critical path, the bulk kernel has nothing to do before it)
         int rc = mnk_launch_pchain(ls, sp, dag, js_begin, js_end, strips);
         if (rc) return rc;

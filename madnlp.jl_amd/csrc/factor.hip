@@ -452,13 +452,18 @@ constexpr int PC_LDS_BYTES = 4 * 4096 * 8;  // pivot-chain kernels: + the strip'
 // Wave-uniform bounded wait for prog[c] >= target.  `seen` caches the last values read: one acquire covers everything
 // that was published before ANY flag value read ahead of it, so every successful wait refreshes all nb entries and
 // later waits that are already satisfied cost nothing (no further cache invalidation).
-template <int NB>
-__device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int target, int (&seen)[NB], int* info, long limit = PP_SPIN_LIMIT) {
+template <int NB, bool DBG = false>
+__device__ __forceinline__ void pp_wait(const int* prog, int c, int nb, int target, int (&seen)[NB], int* info, long limit = PP_SPIN_LIMIT,
+                                        int* dbg = nullptr, int dbg_js = 0, int dbg_t = 0) {
     if (seen[c] >= target) return;
     long spins = 0;
     while (__hip_atomic_load(prog + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023) == 0) {
+            if (DBG && dbg != nullptr && threadIdx.x == 0 && (spins & 0xfffff) == 0) {   // (a long wait: say what for)
+                dbg[0] = 4; dbg[1] = dbg_js; dbg[2] = dbg_t; dbg[3] = c; dbg[4] = target;
+                dbg[5] = __hip_atomic_load(prog + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); dbg[6] = (int)(spins >> 20);
+            }
             // a failed factorization (or a dependency that never arrives) must not hang: carry on with whatever is
             // there -- info != 0 makes every result of this factorization void
             if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
@@ -547,6 +552,14 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                     __builtin_amdgcn_s_sleep(2);
                     if ((++spins & 255) == 0) {
+                        if (LDL && dag.dbg != nullptr && (spins & 0xfffff) == 0) {   // (a long wait: say what for; the LDL^T build only --
+                                                                                     // the Cholesky kernel has no register to spare)
+                            int* d8 = dag.dbg + 8 * t;
+                            const bool is_front = word < dag.af;   // (the words are laid out front | af | tprog)
+                            d8[0] = 5; d8[1] = (int)(p0 >> 8); d8[2] = t;
+                            d8[3] = is_front ? (int)(word - dag.front) : -1 - (int)(word - dag.af);
+                            d8[4] = target; d8[5] = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d8[6] = (int)(spins >> 20);
+                        }
                         if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                         if (spins > dag.spin_limit) {
                             if (atomicCAS(info, 0, -7) == 0) info[1] = 5;   // (site 5: a chain strip waiting for the bulk kernel: rows / band tiles)
@@ -715,7 +728,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             return true;
         }
         // ---- wait for the diagonal block j, X = T L_jj^-T
-        pp_wait<NB>(prog, j, nb, epoch16 + j + 1, seen, info, pp_limit);
+        pp_wait<NB, LDL>(prog, j, nb, epoch16 + j + 1, seen, info, pp_limit, dag.dbg != nullptr ? dag.dbg + 8 * t : nullptr, (int)(p0 >> 8), t);
         const int64_t jb = (p0 >> 6) + j;
         const double* Dblk = dblk0 + jb * 4096;
         const double* Iv16 = inv0 + jb * 1024;
@@ -796,7 +809,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
         v4d pre[4];
         auto prefetch = [&](int c) {
-            pp_wait<NB>(prog, c, nb, epoch16 + j + 1, seen, info, pp_limit);
+            pp_wait<NB, LDL>(prog, c, nb, epoch16 + j + 1, seen, info, pp_limit, dag.dbg != nullptr ? dag.dbg + 8 * t : nullptr, (int)(p0 >> 8), t);
             const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 + 64 * j + w) * ld;
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib)
@@ -1709,6 +1722,15 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         ls->last_sign_changes = (int64_t)pw[6];
     }
     if (hinfo == -7) ls->last_timeout_site = (int)(long long)pw[7];
+    if (hinfo == -7 && ls->dag_debug && ls->dag_flags.p && ls->dag_dbg.p) {
+        // diagnostics: the schedule's progress words and what the chain's strips were waiting for, as the time-out left them
+        MNK_HIP(mnk::stream_wait(s));
+        const int64_t ntile = ls->Np / 128;
+        ls->dbg_flags.resize((size_t)(2 + ls->Np / NBI + 2 * ntile * ntile));
+        ls->dbg_chain.resize(ls->dag_dbg.n);
+        MNK_HIP(mnk::d2h_copy(ls->dbg_flags.data(), ls->dag_flags.p, ls->dbg_flags.size() * sizeof(int), s));
+        MNK_HIP(mnk::d2h_copy(ls->dbg_chain.data(), ls->dag_dbg.p, ls->dbg_chain.size() * sizeof(int), s));
+    }
     if (hinfo != 0 && ls->spare_by_dag) {
         // The spare factor buffer was to be zeroed by the DAG_FILL tasks of this factorization's queue -- which its
         // workgroups dropped when `info` became non-zero.  Found as an intermittent wrong matrix behind a time-out: the redo

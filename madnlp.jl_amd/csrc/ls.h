@@ -157,6 +157,9 @@ struct mnk_ls {
     bool bk_multi_last = false, bk_mw_blocked = false;
     int bk_mw_fallbacks = 0;
     bool factorized = false, info_valid = false;
+    int dag_debug = 0;           // option: keep the progress words of a factorization that timed out (mnk_ls_debug_dag_state)
+    mnk::DevBuf<int> dag_dbg;    // 8 words per chain strip (PpDag::dbg)
+    std::vector<int> dbg_flags, dbg_chain;
     bool spare_by_dag = false;   // the spare buffer's zero-fill was left to the DAG_FILL tasks of the factorization queued last: it
                                  // only happened if that factorization ran to its end (info == 0)
     int info = 0;

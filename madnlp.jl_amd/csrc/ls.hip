@@ -675,6 +675,14 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     }
     if (!strcmp(key, "accept_only_pd")) { ls->accept_only_pd = value != 0; return 0; }  // see mnk_ls_fetch_info
     // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
+    if (!strcmp(key, "dag_debug")) {
+        ls->dag_debug = value != 0.0;
+        if (ls->dag_debug && !ls->dag_dbg.p) {
+            if (ls->dag_dbg.alloc(8 * 128)) return -2;
+            MNK_HIP(hipMemset(ls->dag_dbg.p, 0, 8 * 128 * sizeof(int)));
+        }
+        return 0;
+    }
     if (!strcmp(key, "bk_max_wgs")) {
         MNK_REQUIRE(value >= 0.0 && value <= 256.0, "bk_max_wgs must be in 0..256");
         ls->bk_max_wgs = (int)value;
@@ -1076,6 +1084,14 @@ int mnk_ls_solve_batch(int n, mnk_ls* const* ls, double* const* x, int loc) {
     for (int i = 0; i < n && !rc; ++i) rc = mnk_ls_solve(ls[i], x[i], 1, ls[i]->N, loc);
     const int rc_end = mnk_solve_batch_end();
     return rc ? rc : rc_end;
+}
+
+int mnk_ls_debug_dag_state(mnk_ls* ls, int* flags, int64_t nflags, int* chain, int64_t nchain, int* have) {
+    MNK_REQUIRE(ls && have, "mnk_ls_debug_dag_state: NULL argument");
+    *have = ls->dbg_flags.empty() ? 0 : 1;
+    if (flags) memcpy(flags, ls->dbg_flags.data(), sizeof(int) * (size_t)std::min<int64_t>(nflags, (int64_t)ls->dbg_flags.size()));
+    if (chain) memcpy(chain, ls->dbg_chain.data(), sizeof(int) * (size_t)std::min<int64_t>(nchain, (int64_t)ls->dbg_chain.size()));
+    return 0;
 }
 
 int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n) {
