@@ -210,6 +210,7 @@ int mnk_ctx_ensure_panel_streams(mnk_ctx* ctx);   // ctx->sp / su: look-ahead st
 int mnk_ctx_ensure_dag2(mnk_ctx* ctx);            // ctx->sp_dag2 / su_dag2: deep-band pair of the task-DAG schedule
 int mnk_ctx_ensure_batch_streams(mnk_ctx* ctx);   // ctx->sp_dagB / su_dagB: second chain partition + bulk stream of batches
 int mnk_solve_warmup(hipStream_t s);               // solve.hip: first (no-op) launch of the inverse kernel that needs scratch
+int mnk_ctx_bulk_wgs(const mnk_ctx* ctx, int first, int per_cu);   // ls.hip: workgroups the mask {CUs first.. of the context} holds AT ONCE
 int mnk_dag_warmup(hipStream_t* streams, int n, int nwg);   // dag.hip: first (empty) launch of the bulk kernels on these streams
 int mnk_live_contexts(int device);  // contexts alive on this device in this process
 // Device arbiter of the PERSISTENT kernels (task-DAG schedule, persistent panel launches, one-launch solve): their waiting

@@ -75,12 +75,15 @@ struct DagArgs {       // (the batch kernel's; a single factorization: DagArgs1 
     int fake_share;             // DIAGNOSTIC (env MNK_DAG_FAKE_SHARE, wrong results): every chunk reads the operand rows of tile rows 0..n-1
 };
 
+#ifndef MNK_DIAG_BULK_DBG
+#define MNK_DIAG_BULK_DBG 0   // DIAGNOSTIC build (tools/stall_hunt.py): every workgroup of dag_bulk_kernel1 records its task and its long waits
+#endif
 constexpr int DAG_BANDACC = 1, DAG_FINAL = 2, DAG_FIRST = 4, DAG_FILL = 8;  // task flags
 
 // Wave 0 waits until min(front[s0..s3]) > c and returns that minimum (clamped to kend): tile columns [c, ret) are final
 // for all four strips.  -1: the factorization failed elsewhere or the wait expired.  Ends with an acquire + barrier.
 template <class IP>
-__device__ __forceinline__ int dag_wait_front(IP a, long spin_limit, int s0, int s1, int s2, int s3, int c, int kend, int* s_val) {
+__device__ __forceinline__ int dag_wait_front(IP a, long spin_limit, int s0, int s1, int s2, int s3, int c, int kend, int* s_val, int* d8 = nullptr) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         const int idx = lane == 0 ? s0 : (lane == 1 ? s1 : (lane == 2 ? s2 : s3));
@@ -88,13 +91,28 @@ __device__ __forceinline__ int dag_wait_front(IP a, long spin_limit, int s0, int
         int r;
         for (;;) {
             int f = lane < 4 ? __hip_atomic_load(a->front + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT_MAX;
+#if MNK_DIAG_BULK_DBG
+            const int f_raw = f;
+#endif
             f = min(f, __shfl_xor(f, 1));
             f = min(f, __shfl_xor(f, 2));
             r = __builtin_amdgcn_readfirstlane(f);
             if (r > c) break;
             __builtin_amdgcn_s_sleep(4);
             if ((++spins & 255) == 0) {
-                if (__hip_atomic_load(a->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { r = -1; break; }
+#if MNK_DIAG_BULK_DBG
+                if (d8 != nullptr && (spins & 0x3ffff) == 0) {
+                    if (lane < 4) d8[8 + lane] = f_raw;   // (the four words as this workgroup sees them)
+                    if (lane == 0) { d8[1] = 2; d8[2] = s0 | (s2 << 16); d8[3] = c; d8[4] = r; d8[5] = (int)(spins >> 18); }
+                }
+#endif
+                if (__hip_atomic_load(a->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+#if MNK_DIAG_BULK_DBG
+                    if (d8 != nullptr && lane == 0) { const unsigned long long now = wall_clock64(); d8[1] |= 16; d8[14] = (int)(unsigned)now; d8[15] = (int)(unsigned)(now >> 32); }
+#endif
+                    r = -1;
+                    break;
+                }
                 if (spins > spin_limit) {
                     if (lane == 0 && atomicCAS(a->info, 0, -7) == 0) a->info[1] = 1;   // (site 1: a bulk task waiting for operand rows)
                     r = -1;
@@ -114,7 +132,7 @@ __device__ __forceinline__ int dag_wait_front(IP a, long spin_limit, int s0, int
 
 // Wave 0 waits until *w0 >= t0 and *w1 >= t1 (progress words of the pivot chain); false: failed / expired.  Acquire + barrier.
 template <class IP>
-__device__ __forceinline__ bool dag_wait_words(IP a, long spin_limit, const int* w0, int t0, const int* w1, int t1, int* s_val) {
+__device__ __forceinline__ bool dag_wait_words(IP a, long spin_limit, const int* w0, int t0, const int* w1, int t1, int* s_val, int* d8 = nullptr) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         long spins = 0;
@@ -124,7 +142,16 @@ __device__ __forceinline__ bool dag_wait_words(IP a, long spin_limit, const int*
             if (__all(v >= (lane == 0 ? t0 : (lane == 1 ? t1 : INT_MIN)))) break;
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 255) == 0) {
-                if (__hip_atomic_load(a->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+#if MNK_DIAG_BULK_DBG
+                if (d8 != nullptr && (spins & 0x3ffff) == 0 && lane == 0) { d8[1] = 3; d8[2] = 0; d8[3] = t0; d8[4] = v; d8[5] = (int)(spins >> 18); }
+#endif
+                if (__hip_atomic_load(a->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+#if MNK_DIAG_BULK_DBG
+                    if (d8 != nullptr && lane == 0) { const unsigned long long now = wall_clock64(); d8[1] |= 16; d8[14] = (int)(unsigned)now; d8[15] = (int)(unsigned)(now >> 32); }
+#endif
+                    ok = 0;
+                    break;
+                }
                 if (spins > spin_limit) {
                     if (lane == 0 && atomicCAS(a->info, 0, -7) == 0) a->info[1] = 2;   // (site 2: chunk order of a tile)
                     ok = 0;
@@ -510,7 +537,17 @@ struct DagArgs1 {
     int fake_share;             // DIAGNOSTIC (env MNK_DAG_FAKE_SHARE, wrong results): every chunk reads the operand rows of tile rows 0..n-1
     double* zfill;              // DAG_FILL tasks: the buffer of the next factorization (or NULL)
     int64_t N;
+#if MNK_DIAG_BULK_DBG
+    int* bdbg;                  // 16 words per workgroup: {task, stage, words, target, value, spins >> 18, tasks done, -, the 4 front words seen}
+#endif
 };
+
+#if MNK_DIAG_BULK_DBG
+#define MNK_BDBG(a) ((a).bdbg != nullptr ? (a).bdbg + 16 * blockIdx.x : nullptr)
+int* g_diag_bdbg = nullptr;   // (set by the host side before a launch; diagnostic builds only)
+#else
+#define MNK_BDBG(a) nullptr
+#endif
 
 template <bool LDL>
 __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
@@ -536,6 +573,16 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
             return;
         }
         if (a.wgstat != nullptr && tid == 0) { if (s_stat[0] == 0) s_stat[0] = wall_clock64(); ++s_stat[2]; }
+#if MNK_DIAG_BULK_DBG
+        if (a.bdbg != nullptr && tid == 0) {
+            int* d8 = a.bdbg + 16 * blockIdx.x;
+            d8[0] = t; d8[1] = 1; d8[6] += 1;
+            // where the workgroup runs (HW_ID: cu [11:8], sh [12], se [15:13]; XCC_ID [3:0]) and when it took the task (100 MHz)
+            d8[7] = (int)((__builtin_amdgcn_s_getreg(63492) & 0xffffu) | ((__builtin_amdgcn_s_getreg(63508) & 15u) << 16));
+            const unsigned long long now = wall_clock64();
+            d8[12] = (int)(unsigned)now; d8[13] = (int)(unsigned)(now >> 32);
+        }
+#endif
         const int4 tk = a.tasks[t];
         const int flags = __builtin_amdgcn_readfirstlane(tk.x) & 255, q = __builtin_amdgcn_readfirstlane(tk.x) >> 8;
         const int I = __builtin_amdgcn_readfirstlane(tk.y), J = __builtin_amdgcn_readfirstlane(tk.z);
@@ -554,7 +601,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
         auto gate = [&](int kt) -> bool {
             if (kt < limit) return true;
             const unsigned long long w0 = tr ? wall_clock64() : 0;
-            const int r = dag_wait_front(&a, a.spin_limit, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kbeg + (kt >> 4), kend, &s_val);
+            const int r = dag_wait_front(&a, a.spin_limit, 2 * I, 2 * I + 1, 2 * J, 2 * J + 1, kbeg + (kt >> 4), kend, &s_val, MNK_BDBG(a));
             if (tr) { const unsigned long long w1 = wall_clock64(); tr[2] = w1; tr[6] += 1; tr[7] += w1 - w0; s_stat[1] += w1 - w0; }
             if (r < 0) return false;
             limit = (__builtin_amdgcn_readfirstlane(r) - kbeg) * 16;
@@ -566,7 +613,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
             if (flags & DAG_FIRST) return true;
             const int* word = a.tprog + (int64_t)I * a.ntile + J;
             const unsigned long long w0 = tr ? wall_clock64() : 0;
-            if (!dag_wait_words(&a, a.spin_limit, word, q, word, q, &s_val)) return false;
+            if (!dag_wait_words(&a, a.spin_limit, word, q, word, q, &s_val, MNK_BDBG(a))) return false;
             if (tr) s_stat[1] += wall_clock64() - w0;
             return true;
         };
@@ -600,7 +647,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
             for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(X[i][0])); asm volatile("" : "+v"(X[i][1])); }
             if (tr) tr[1] = tr[3] = wall_clock64();  // K-loop done = tile applied
             // the diagonal blocks of tile column J and L(2J + 1, 2J)
-            if (dag_wait_front(&a, a.spin_limit, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val) < 0) return;
+            if (dag_wait_front(&a, a.spin_limit, 2 * J, 2 * J + 1, 2 * J, 2 * J + 1, J, J + 1, &s_val, MNK_BDBG(a)) < 0) return;
             if (tr) { tr[4] = wall_clock64(); s_stat[1] += tr[4] - tr[3]; }
             dag_finalize_tile<LDL>(&a, row0, col0, 2 * J, smem_raw, tid, X, tr);
             if (tr) s_stat[3] += wall_clock64() - tr[4];
@@ -635,6 +682,13 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
                 __hip_atomic_store(a.af + (int64_t)I * a.ntile + J, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (tr) tr[5] = wall_clock64();
+#if MNK_DIAG_BULK_DBG
+            if (a.bdbg != nullptr) {   // published, and when
+                int* d8 = a.bdbg + 16 * blockIdx.x;
+                const unsigned long long now = wall_clock64();
+                d8[1] = 4; d8[14] = (int)(unsigned)now; d8[15] = (int)(unsigned)(now >> 32);
+            }
+#endif
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // (s_val and the LDS tiles are reused by the next task)
@@ -805,6 +859,9 @@ static int launch_dag_bulk(hipStream_t s, bool ldl, const DagInst& one, const Da
     if (insts == nullptr) {
         DagArgs1 a{one.F, one.ld, one.V, one.dinv, one.dblk, one.inv16, reinterpret_cast<const int4*>(tasks), ntasks, one.front, one.af,
                    one.tprog, ntile, qctr, one.info, spin_limit, trace, wgstat, one.vmax, fake, one.zfill, one.N};
+#if MNK_DIAG_BULK_DBG
+        a.bdbg = g_diag_bdbg;
+#endif
         return ldl ? launch_bulk1_t<true>(s, a, nwg) : launch_bulk1_t<false>(s, a, nwg);
     }
     DagArgs a{insts, reinterpret_cast<const int4*>(tasks), ntasks, ntile, qctr, spin_limit, trace, wgstat, fake};
@@ -967,7 +1024,7 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
     }
     const int js2 = ls->dag_js2;
     // one phase = one persistent bulk launch (update stream) beside one persistent chain launch (panel stream)
-    auto phase = [&](hipStream_t sp, hipStream_t su, int bulk_cus, int task0, int ntask, int* counter, int js_begin, int js_end,
+    auto phase = [&](hipStream_t sp, hipStream_t su, int chain_cus, int task0, int ntask, int* counter, int js_begin, int js_end,
                      unsigned strips) -> int {
         // A small system (every row a strip of the chain, one phase) runs its chain on the CALLER's stream: no fork in front
         // of the first diagonal block, no join behind the last one, and the inverses simply follow the chain.  Its workgroups
@@ -985,8 +1042,11 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         if (rc) return rc;
         // (more than three workgroups per CU -- to fill slots a shader-engine-imbalanced mask might leave empty -- measured
         // no difference: 4 / 5 / 6 per CU 9.63-9.67 vs 9.64-9.68 ms)
+#if MNK_DIAG_BULK_DBG
+        mnk::g_diag_bdbg = ls->dag_debug && ls->dag_dbg.p ? ls->dag_dbg.p + 8 * 128 : nullptr;
+#endif
         rc = mnk::launch_dag_bulk(su, ldl, inst, nullptr, ls->dag_tasks.p + 4 * (size_t)task0, ntask, ntile, counter, spin_limit,
-                                  std::min(ntask, 3 * bulk_cus), trace ? trace + 8 * (size_t)task0 : nullptr,
+                                  std::min(ntask, mnk_ctx_bulk_wgs(ctx, chain_cus, 3)), trace ? trace + 8 * (size_t)task0 : nullptr,
                                   trace ? trace + (size_t)ls->dag_ntasks * 8 + 4096 * 8 + (task0 > 0 ? 512 * 8 : 0) : nullptr);
         if (rc) return rc;
         // Once the bulk kernel has run out of tasks every tile-closing task is done, hence every strip-column that still
@@ -1020,14 +1080,14 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
         return 0;
     };
     if (js2 > 0) {
-        int rc = phase(ctx->sp_dag, ctx->su_dag, ctx->num_cu - ctx->dag_cus, 0, ls->dag_ntasks1, qctr, 0, std::min(js2, nsc),
+        int rc = phase(ctx->sp_dag, ctx->su_dag, ctx->dag_cus, 0, ls->dag_ntasks1, qctr, 0, std::min(js2, nsc),
                        (unsigned)std::min<int64_t>(ls->dag_band, Np / NBI));
         if (rc) return rc;
     }
     if (js2 < nsc) {
         const int64_t rows2 = Np - 256 * (int64_t)js2;
         MNK_REQUIRE(ctx->sp_dag2 != nullptr, "task-DAG schedule: the deep-band streams are missing");   // (mnk_ls_run_factorization made them)
-        int rc = phase(ctx->sp_dag2, ctx->su_dag2, ctx->num_cu - ctx->dag_cus2, ls->dag_ntasks1, ls->dag_ntasks - ls->dag_ntasks1,
+        int rc = phase(ctx->sp_dag2, ctx->su_dag2, ctx->dag_cus2, ls->dag_ntasks1, ls->dag_ntasks - ls->dag_ntasks1,
                        qctr + 1, js2, nsc, (unsigned)(rows2 / NBI));
         if (rc) return rc;
     }
@@ -1136,7 +1196,7 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
         MNK_HIP(hipStreamWaitEvent(sp[1], B.ev[0], 0));
         MNK_HIP(hipStreamWaitEvent(su, B.ev[0], 0));
         const unsigned strips = (unsigned)std::min<int64_t>(l0->dag_band, Np / NBI);
-        const int bulk_cus = c0->num_cu - 2 * c0->dag_cus;
+        const int bulk_wgs = mnk_ctx_bulk_wgs(c0, 2 * c0->dag_cus, 3);   // (the grid that is resident at launch: see ls.hip)
         // Launch order: the first two chains, THEN the bulk kernel, then everything else -- the host needs ~3 ms for the
         // 4 x ninst launches of the chains' streams (measured: the bulk kernel used to start 3 ms after the first chain,
         // 2 % of a 16-instance step).  Per chain stream: chain i, its inverses for the solves and its inertia / info words
@@ -1158,7 +1218,7 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
             if (r) return r;
         }
         int r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p,
-                                     mnk_ls_dag_spin_limit(l0), std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
+                                     mnk_ls_dag_spin_limit(l0), std::min(B.ntasks, bulk_wgs), nullptr, nullptr);
         if (r) return r;
         for (int i = 0; i < ninst; ++i) {
             r = launch_tail(i);
@@ -1295,9 +1355,9 @@ static int batch_run_group_small(std::vector<mnk_ls*>& g) {
             int r = mnk_launch_pchain_multi(g.data() + r0, k, sp, nullptr, B.pcsys.p, fronts.data(), afs.data());
             if (r) return r;
             if (ntasks1 > 0) {
-                const int bulk_cus = c0->num_cu - chain_cus_for(k);
+                const int bulk_wgs = mnk_ctx_bulk_wgs(c0, chain_cus_for(k), 3);
                 r = mnk::launch_dag_bulk(su, ldl, hin[0], insts_dev, B.tasks.p, B.ntasks, ntile, B.qctr.p, mnk_ls_dag_spin_limit(l0),
-                                         std::min(B.ntasks, 3 * bulk_cus), nullptr, nullptr);
+                                         std::min(B.ntasks, bulk_wgs), nullptr, nullptr);
                 if (r) return r;
                 MNK_HIP(hipEventRecord(B.ev[2], su));
                 MNK_HIP(hipStreamWaitEvent(h, B.ev[2], 0));

@@ -559,6 +559,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                             d8[0] = 5; d8[1] = (int)(p0 >> 8); d8[2] = t;
                             d8[3] = is_front ? (int)(word - dag.front) : -1 - (int)(word - dag.af);
                             d8[4] = target; d8[5] = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d8[6] = (int)(spins >> 20);
+                            d8[7] = (int)((__builtin_amdgcn_s_getreg(63492) & 0xffffu) | ((__builtin_amdgcn_s_getreg(63508) & 15u) << 16));   // (which CU: HW_ID, XCC_ID)
                         }
                         if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                         if (spins > dag.spin_limit) {

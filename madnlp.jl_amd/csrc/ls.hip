@@ -262,6 +262,31 @@ std::vector<int> ctx_bits(const mnk_ctx* c) {
 }
 }  // namespace
 
+// Size of a persistent grid on the CUs [first, num_cu) of the context (`per_cu` workgroups fit on a CU): the number of
+// workgroups the hardware places AT LAUNCH.  The dispatcher deals the workgroups of a grid out evenly -- XCD by XCD, and
+// inside an XCD shader engine by shader engine (mask bit b is CU b / 8 of XCD b % 8, shader engine (b / 8) % 4) -- whatever
+// the mask left of an engine, so the engine with the fewest CUs bounds what is resident at once: 16 chain CUs take one CU
+// from engines 0 and 1 of every XCD, which then hold 7 x 3 = 21 workgroups each, and of a grid of 3 x 240 = 720 exactly
+// 32 x 21 = 672 start (tools/stall_hunt.py on a diagnostic build: 21 / 21 / 22 / 21-22 workgroups per engine, 35 CUs of
+// engines 2 and 3 holding two).  The others are placed LATER, in mid-kernel, when the hardware finds room -- and a workgroup
+// placed in mid-kernel is what the one-in-~3000 time-out of the task-DAG schedule was: in both captured
+// events 6 resp. 12 workgroups with block ids 672..686 had all just been started, within 0.2 ms of each other, took a task
+// each, and then did nothing for the ~965 ms until the time-out sent the others home -- at which point each ran its whole
+// task at the usual 13 us per tile column.  Tasks they held were ones the pivot chain needed.  (They were never in a wait of
+// their own, and polling with a back-off changed nothing.  Why the hardware stalls them is not known; a persistent grid
+// simply must not exceed what is co-resident at launch.)  Those workgroups did 0.9 % of the tasks.
+int mnk_ctx_bulk_wgs(const mnk_ctx* c, int first, int per_cu) {
+    int per_engine[32] = {0};
+    for (int b = std::max(first, 0); b < c->num_cu; ++b) {
+        const int bit = c->cu_first + b;
+        ++per_engine[(bit % 8) * 4 + (bit / 8) % 4];
+    }
+    int engines = 0, least = INT_MAX;
+    for (int e = 0; e < 32; ++e)
+        if (per_engine[e] > 0) { ++engines; least = std::min(least, per_engine[e]); }
+    return engines > 0 ? per_cu * least * engines : per_cu;
+}
+
 // the deep-band pair (every row of a small system in the chain's band: dag_cus2 chain CUs | the others)
 int mnk_ctx_ensure_dag2(mnk_ctx* c) {
     if (c->sp_dag2 != nullptr || c->dag_cus2 <= 0 || !c->shared_dag_streams) return 0;
@@ -678,8 +703,9 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "dag_debug")) {
         ls->dag_debug = value != 0.0;
         if (ls->dag_debug && !ls->dag_dbg.p) {
-            if (ls->dag_dbg.alloc(8 * 128)) return -2;
-            MNK_HIP(hipMemset(ls->dag_dbg.p, 0, 8 * 128 * sizeof(int)));
+            // (8 words per chain strip, then -- diagnostic builds with MNK_DIAG_BULK_DBG -- 16 words per bulk workgroup)
+            if (ls->dag_dbg.alloc(8 * 128 + 16 * 1024)) return -2;
+            MNK_HIP(hipMemset(ls->dag_dbg.p, 0, (8 * 128 + 16 * 1024) * sizeof(int)));
         }
         return 0;
     }
@@ -1149,6 +1175,7 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     if (!strcmp(key, "bk_count")) { *value = ls->bk_count; return 0; }
     if (!strcmp(key, "bk_panel_multi")) { *value = ls->bk_multi_last ? 1.0 : 0.0; return 0; }
     if (!strcmp(key, "bk_mw_fallbacks")) { *value = ls->bk_mw_fallbacks; return 0; }
+    if (!strcmp(key, "dag_bulk_wgs")) { *value = ls->ctx->dag_cus > 0 ? mnk_ctx_bulk_wgs(ls->ctx, ls->ctx->dag_cus, 3) : 0; return 0; }   // grid of the bulk kernel beside the 16-CU chain
     if (!strcmp(key, "dag_ntasks")) { *value = ls->dag_ntasks; return 0; }    // task-DAG schedule: bulk tasks, ...
     if (!strcmp(key, "dag_ntasks1")) { *value = ls->dag_ntasks1; return 0; }  // ... of them in the first phase, ...
     if (!strcmp(key, "dag_js2")) { *value = ls->dag_js2; return 0; }          // ... first strip-column of the second phase

@@ -451,3 +451,41 @@ def test_time_out_of_the_task_dag_schedule_with_a_sparse_source_is_redone_on_a_c
         assert bwd(x) <= 1e-13, (rnd, bwd(x))
         assert M.get_stat("pp_fallbacks") == (0.0 if rnd < 2 else 1.0)
     k.close()
+
+
+@pytest.mark.gpu
+def test_every_workgroup_of_the_bulk_grid_is_resident_at_launch(ctx):
+    """A persistent grid must not exceed what the hardware places at launch: workgroups the dispatcher starts in mid-kernel
+    were what the one-in-~3000 time-out of the task-DAG schedule came from (csrc/ls.hip
+    mnk_ctx_bulk_wgs).  With the 16-CU chain mask two shader engines of every XCD keep 7 of their 8 CUs, and the grid is
+    3 x 7 x 32 = 672 -- not 3 x 240.  Checked on the device with the schedule's own per-workgroup statistics (option
+    dag_trace): every workgroup of the grid takes its first task within 2 ms of the first one (the late ones of the old
+    grid started 3.6 and 7 ms into the 9 ms kernel, or never), every one works, and no slot beyond the grid is used."""
+    import ctypes as C
+
+    from madnlp_jl_amd import _lib as L
+    N = 11192
+    A, _ = _dev_matrix(N, mj.BUNCHKAUFMAN, torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN, panel_algo=5))
+    ls.set_option("dag_fill", 0)
+    ls.factorize()
+    nwg = int(ls.get_stat("dag_bulk_wgs"))
+    props = torch.cuda.get_device_properties(0)
+    if props.multi_processor_count == 256:
+        assert nwg == 672
+    assert 0 < nwg <= 3 * (props.multi_processor_count - 16)
+    ls.set_option("dag_trace", 1)
+    ls.factorize()
+    assert ls.inertia() == (N, 0, 0) and ls.get_stat("panel_algo") == 5.0 and ls.get_stat("pp_fallbacks") == 0.0
+    ntasks = int(ls.get_stat("dag_ntasks"))
+    tr = np.zeros(ntasks * 8 + 4096 * 8 + 1024 * 8, dtype=np.uint64)
+    L.check(L.lib().mnk_ls_debug_solve_trace(ls._h, tr.ctypes.data, tr.size), "trace")
+    w = tr[ntasks * 8 + 4096 * 8:].reshape(1024, 8).astype(np.int64)   # {first task taken, exit, ticks waited, tasks, ...} at 100 MHz
+    assert np.all(w[:nwg, 3] > 0), f"workgroups without a task: {np.nonzero(w[:nwg, 3] == 0)[0][:8]}"
+    assert not w[nwg:].any()
+    first = w[:nwg, 0]
+    late_ms = (first - first.min()) / 1e5
+    assert late_ms.max() <= 2.0, f"workgroups {np.nonzero(late_ms > 2.0)[0][:8]} started {late_ms.max():.2f} ms after the first"
+    ls.set_option("dag_trace", 0)
+    ls.close()

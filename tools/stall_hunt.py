@@ -55,12 +55,16 @@ with torch.cuda.stream(st):
                 ntile = Np // 128
                 nflags = 2 + Np // 64 + 2 * ntile * ntile
                 flags = np.zeros(nflags, dtype=np.int32)
-                chain = np.zeros(8 * 128, dtype=np.int32)
+                chain = np.zeros(8 * 128 + 16 * 1024, dtype=np.int32)
                 have = C.c_int(0)
                 L.check(L.lib().mnk_ls_debug_dag_state(M._h, flags.ctypes.data, nflags, chain.ctypes.data, chain.size, C.byref(have)), "state")
                 rec = {"round": rnd, "instance": idx, "N": P.n, "Np": Np, "ntile": ntile, "site": M.get_stat("timeout_site"),
                        "have": have.value, "inertia": inertia, "dag_ntasks": M.get_stat("dag_ntasks"),
-                       "flags": flags.tolist(), "chain": chain.reshape(-1, 8)[:16].tolist()}
+                       "flags": flags.tolist(), "chain": chain[:128].reshape(-1, 8).tolist(),
+                       # (a diagnostic build -DMNK_DIAG_BULK_DBG=1 only, zeros otherwise: 16 words per bulk workgroup --
+                       # task, stage (1 grabbed / 2 waiting for rows / 3 waiting for the chunk order / 4 published), the waited
+                       # words, target, value seen, polls >> 18, tasks grabbed, -, the four front words as seen)
+                       "bulk": chain[8 * 128:].reshape(-1, 16).tolist()}
                 path = os.path.join(out_dir, f"state_{events}.json")
                 json.dump(rec, open(path, "w"))
                 print(f"round {rnd} instance {idx}: time-out at site {rec['site']}, state -> {path}; chain strips waiting: "
