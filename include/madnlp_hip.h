@@ -498,6 +498,13 @@ int mnk_ls_debug_solve_trace(mnk_ls* ls, unsigned long long* out, int64_t n);
  * them, before the factorization is redone.  Copies up to `nflags` / `nchain` ints; *have = 1 if a time-out was recorded. */
 int mnk_ls_debug_dag_state(mnk_ls* ls, int* flags, int64_t nflags, int* chain, int64_t nchain, int* have);
 
+/* Size of a persistent grid on the CU-mask bits [cu_first + first, cu_first + num_cu) with `per_cu` workgroups per CU: the
+ * workgroups the hardware places AT LAUNCH (the dispatcher deals a grid out evenly per XCD and shader engine -- mask bit b is
+ * CU b / 8 of XCD b % 8, shader engine (b / 8) % 4 --, so the engine the mask leaves the fewest CUs bounds it).  Pure host
+ * arithmetic (no device needed); the task-DAG schedule sizes its bulk kernel with it: 672 beside the 16-CU chain of a 256-CU
+ * part, not 3 x 240 (workgroups placed in mid-kernel were the schedule's rare time-out). */
+int mnk_debug_grid_at_launch(int cu_first, int num_cu, int first, int per_cu);
+
 /* Diagnostics / tests (host only): the task list of the task-DAG factorization schedule (csrc/dag.hip) for a matrix of `ntile`
  * 128-row tiles: 4 ints per task (flags | chunk index << 8, tile row I, tile column J, kbeg | kend << 16) in queue order, at most
  * `cap` tasks written; returns the number of tasks (negative: bad arguments). */

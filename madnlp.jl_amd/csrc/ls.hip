@@ -275,10 +275,10 @@ std::vector<int> ctx_bits(const mnk_ctx* c) {
 // task at the usual 13 us per tile column.  Tasks they held were ones the pivot chain needed.  (They were never in a wait of
 // their own, and polling with a back-off changed nothing.  Why the hardware stalls them is not known; a persistent grid
 // simply must not exceed what is co-resident at launch.)  Those workgroups did 0.9 % of the tasks.
-int mnk_ctx_bulk_wgs(const mnk_ctx* c, int first, int per_cu) {
+extern "C" int mnk_debug_grid_at_launch(int cu_first, int num_cu, int first, int per_cu) {
     int per_engine[32] = {0};
-    for (int b = std::max(first, 0); b < c->num_cu; ++b) {
-        const int bit = c->cu_first + b;
+    for (int b = std::max(first, 0); b < num_cu; ++b) {
+        const int bit = cu_first + b;
         ++per_engine[(bit % 8) * 4 + (bit / 8) % 4];
     }
     int engines = 0, least = INT_MAX;
@@ -286,6 +286,7 @@ int mnk_ctx_bulk_wgs(const mnk_ctx* c, int first, int per_cu) {
         if (per_engine[e] > 0) { ++engines; least = std::min(least, per_engine[e]); }
     return engines > 0 ? per_cu * least * engines : per_cu;
 }
+int mnk_ctx_bulk_wgs(const mnk_ctx* c, int first, int per_cu) { return mnk_debug_grid_at_launch(c->cu_first, c->num_cu, first, per_cu); }
 
 // the deep-band pair (every row of a small system in the chain's band: dag_cus2 chain CUs | the others)
 int mnk_ctx_ensure_dag2(mnk_ctx* c) {

@@ -128,3 +128,20 @@ def test_merged_queue_of_a_batch(ntile, chunk, band_tiles, js2, taper0, ninst, p
     if period < ntile:
         for i in range(ninst - 1):
             assert first[i + 1] < last[i]
+
+
+def test_persistent_grids_are_sized_by_what_is_placed_at_launch():
+    """`mnk_debug_grid_at_launch` (host arithmetic behind the bulk kernel's grid, csrc/ls.hip): the dispatcher deals a grid out
+    evenly per (XCD, shader engine) -- mask bit b is XCD b % 8, engine (b / 8) % 4 -- so the engine with the fewest CUs under the
+    mask bounds what starts at launch.  Workgroups placed later, in mid-kernel, were the rare time-out of the task-DAG schedule
+    (DESIGN.md section 8 item -1)."""
+    f = L.lib().mnk_debug_grid_at_launch
+    assert f(0, 256, 16, 3) == 3 * 7 * 32 == 672      # beside the 16-CU chain: engines 0 and 1 of every XCD keep 7 CUs
+    assert f(0, 256, 32, 3) == 3 * 224                # the batch mask (two chain partitions): one CU of every engine, balanced
+    assert f(0, 256, 96, 3) == 3 * 160                # the deep-band mask: three CUs of every engine
+    assert f(0, 256, 64, 3) == 3 * 192 and f(0, 256, 128, 3) == 3 * 128   # small-batch partitions: multiples of 64
+    assert f(0, 256, 0, 1) == 256
+    assert f(128, 128, 16, 3) == 3 * 3 * 32           # a half-device partition (CUs 16..31 of every XCD) with its own chain
+    assert f(0, 256, 8, 3) == 3 * 7 * 32              # one engine short of a CU is enough
+    assert f(0, 64, 16, 3) == 3 * 1 * 32              # a 64-CU partition: engines 0 and 1 are left ONE CU each
+    assert f(0, 256, 256, 3) == 3                     # (an empty mask: never zero)
