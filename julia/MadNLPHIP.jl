@@ -678,4 +678,96 @@ function regularize_diagonal_device!(kkt::HipDenseCondensedKKTSystem, primal::Fl
     return
 end
 
+"What ran: `get_stat(M, \"panel_algo\")`, `\"pp_fallbacks\"`, `\"growth\"`, ... (the keys of `mnk_ls_get_stat`, INTEGRATION.md)."
+function get_stat(M::HipLinearSolver, key::AbstractString)
+    v = Ref{Cdouble}(0.0)
+    rc = ccall((:mnk_ls_get_stat, libmadnlp_hip), Cint, (Ptr{Cvoid}, Cstring, Ptr{Cdouble}), M.handle, key, v)
+    check(rc, SymbolicException)
+    return v[]
+end
+
+# ------------------------------------------------------------------ dense S stage of the Schur-complement KKT system
+# Reference: `SchurComplementKKTSystem`, src/KKT/Schur/schur.jl -- `build_kkt!` :927-1001 (factor every scenario block,
+# S = S0 - sum_k C_dk A_k^-1 C_dk'), `factorize_kkt!` :1003-1005, steps 3-5 of `solve_kkt!` :1040-1058, `is_inertia_correct`
+# :901-903.  The scenario blocks arrive dense (the reference factors them with a sparse solver per scenario, outside this
+# path).  One handle holds the scenarios of ONE rank; the two sums over ranks (S, and the nd-vector of the forward sweep)
+# are the caller's all-reduces (RCCL through the MPI / AMDGPU layer of the application).  `S`, `rhs_k` (blk x ns_local,
+# column k = scenario k), `rhs_d` and `contrib_d` are DEVICE buffers, passed as raw pointers (`pointer(::ROCArray)`):
+# the glue does not depend on AMDGPU.jl.
+mutable struct HipSchurStage
+    handle::Ptr{Cvoid}
+    ctx::HipContext
+    ns_local::Int
+    blk::Int
+    nd::Int
+end
+function HipSchurStage(ns_local::Integer, blk::Integer, nd::Integer; ctx::HipContext = HipContext(),
+                       lapack_algorithm::LinearFactorization = BUNCHKAUFMAN)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:mnk_schur_create, libmadnlp_hip), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Cint, Ptr{Ptr{Cvoid}}),
+               ctx.handle, ns_local, blk, nd, MNK_ALGO[lapack_algorithm], h)
+    check(rc, SymbolicException)
+    st = HipSchurStage(h[], ctx, ns_local, blk, nd)
+    finalizer(st) do x
+        x.handle == C_NULL || ccall((:mnk_schur_destroy, libmadnlp_hip), Cint, (Ptr{Cvoid},), x.handle)
+        x.handle = C_NULL
+    end
+    return st
+end
+"Scenario block k (0-based): `A_kk` blk x blk (lower triangle read), `C_dk` nd x blk, host matrices."
+function set_block!(st::HipSchurStage, k::Integer, A_kk::Matrix{Float64}, C_dk::Matrix{Float64})
+    rc = ccall((:mnk_schur_set_block, libmadnlp_hip), Cint, (Ptr{Cvoid}, Int64, Ptr{Cdouble}, Int64, Ptr{Cdouble}, Int64, Cint),
+               st.handle, k, A_kk, size(A_kk, 1), C_dk, size(C_dk, 1), MNK_HOST)
+    check(rc, SymbolicException)
+    return st
+end
+"`build_kkt!`: S_out (device, nd x nd) = S0 - sum over the local scenarios; `S0` (host) on the rank that owns it, `nothing` elsewhere."
+function build_local!(st::HipSchurStage, S0::Union{Nothing, Matrix{Float64}}, S_out::Ptr{Cdouble})
+    rc = ccall((:mnk_schur_build_local, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Cint, Ptr{Cdouble}, Int64),
+               st.handle, S0 === nothing ? C_NULL : S0, st.nd, MNK_HOST, S_out, st.nd)
+    check(rc, FactorizationException)
+    return st
+end
+"`factorize_kkt!`: factor the (all-reduced) S, a device buffer."
+function factorize_s!(st::HipSchurStage, S::Ptr{Cdouble})
+    info = Ref{Cint}(0)
+    rc = ccall((:mnk_schur_factorize_s, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Cint, Ptr{Cint}),
+               st.handle, S, st.nd, MNK_DEVICE, info)
+    check(rc, FactorizationException)
+    return st
+end
+function inertia_s(st::HipSchurStage)
+    p = Ref{Int64}(0); z = Ref{Int64}(0); n = Ref{Int64}(0)
+    rc = ccall((:mnk_schur_inertia_s, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}), st.handle, p, z, n)
+    check(rc, InertiaException)
+    return (Int(p[]), Int(z[]), Int(n[]))
+end
+function scenario_inertia(st::HipSchurStage, k::Integer)
+    p = Ref{Int64}(0); z = Ref{Int64}(0); n = Ref{Int64}(0)
+    rc = ccall((:mnk_schur_scenario_inertia, libmadnlp_hip), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}),
+               st.handle, k, p, z, n)
+    check(rc, InertiaException)
+    return (Int(p[]), Int(z[]), Int(n[]))
+end
+"The reference's test on S (schur.jl:901-903): positive definite of order nd."
+is_inertia_correct(st::HipSchurStage) = inertia_s(st) == (st.nd, 0, 0)
+"Step 3: r_k <- A_k^-1 r_k and contrib_d = -sum_k C_dk r_k (the caller adds r_d and all-reduces the nd doubles)."
+function forward!(st::HipSchurStage, rhs_k::Ptr{Cdouble}, contrib_d::Ptr{Cdouble})
+    rc = ccall((:mnk_schur_forward, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), st.handle, rhs_k, contrib_d)
+    check(rc, SolveException)
+    return st
+end
+"Step 4: S x_d = r_d, in place."
+function solve_s!(st::HipSchurStage, rhs_d::Ptr{Cdouble})
+    rc = ccall((:mnk_schur_solve_s, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), st.handle, rhs_d)
+    check(rc, SolveException)
+    return st
+end
+"Step 5: x_k = r_k - (A_k^-1 C_dk') x_d, in place in `rhs_k`."
+function backward!(st::HipSchurStage, rhs_k::Ptr{Cdouble}, x_d::Ptr{Cdouble})
+    rc = ccall((:mnk_schur_backward, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}), st.handle, rhs_k, x_d)
+    check(rc, SolveException)
+    return st
+end
+
 end # module
