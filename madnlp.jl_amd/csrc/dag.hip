@@ -1431,12 +1431,14 @@ static int batch_flush() {
         int rc;
         if (g.size() >= 2) {
             rc = l0->dag_js2 == 0 ? batch_run_group_small(g) : batch_run_group(g);
-            if (rc)   // (nothing of the group counts as factorized)
-                for (mnk_ls* ls : g) ls->deferred = false;
+            if (rc)   // (nothing of the group counts as factorized: the factor buffers already hold the NEW, unfactored matrices, so
+                      // a solve or an inertia call that ignores this error must not find the previous factorization's flag)
+                for (mnk_ls* ls : g) { ls->deferred = false; ls->factorized = false; ls->info_valid = false; }
         } else {
             g[0]->deferred = false;
             if (g[0]->Np < g[0]->dag_min_rows) g[0]->algo_now = 4;   // (alone, a system below the schedule's window keeps its usual one)
             rc = mnk_ls_run_factorization_now(g[0]);
+            if (rc) { g[0]->factorized = false; g[0]->info_valid = false; }
         }
         if (rc && !rc_all) rc_all = rc;
     }
@@ -1449,6 +1451,11 @@ int mnk_ls_sync_deferred(mnk_ls* ls) {
         if (rc_s) return rc_s;
     }
     return mnk_ls_sync_deferred_fact(ls);
+}
+
+// true: a factorize! call of this solver is queued in a batch that ANOTHER thread opened (its thread-local list holds the pointer)
+bool mnk_ls_pending_elsewhere(const mnk_ls* ls) {
+    return ls->deferred && std::find(t_batch.pend.begin(), t_batch.pend.end(), ls) == t_batch.pend.end();
 }
 
 int mnk_ls_sync_deferred_fact(mnk_ls* ls) {

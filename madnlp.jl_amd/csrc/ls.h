@@ -172,7 +172,9 @@ int mnk_ls_run_factorization_now(mnk_ls* ls);      // factor.hip: the launch par
 int mnk_ls_launch_finish_info(mnk_ls* ls, hipStream_t s);   // factor.hip: inertia / growth words / info -> pinned host words
 bool mnk_solve_defer(mnk_ls* ls, double* xuser);   // solve.hip: true if the calling thread has a solve batch open and queued this solve
 int mnk_solve_sync_deferred(mnk_ls* ls);           // solve.hip: runs the queued solves if one of them belongs to this solver
+int mnk_solve_batch_flush_pending(void);           // solve.hip: runs every solve the calling thread has queued (nested batches: schur.hip)
 int mnk_ls_factorize_dense_dev_async(mnk_ls* ls, const double* Adev, int64_t lda);   // ls.hip
+bool mnk_ls_pending_elsewhere(const mnk_ls* ls);   // dag.hip: queued in a factorization batch of ANOTHER thread
 bool mnk_batch_active();                           // dag.hip: the calling thread has a factorization batch open
 size_t mnk_pchain_sys_bytes();                     // factor.hip: size of one record of mnk_launch_pchain_multi's table
 int mnk_launch_pchain_multi(mnk_ls* const* v, int n, hipStream_t sp, hipStream_t fill_stream, void* table, int* const* front,

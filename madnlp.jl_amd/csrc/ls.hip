@@ -590,6 +590,12 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
 int mnk_ls_destroy(mnk_ls* ls) {
     if (!ls) return 0;
     (void)hipSetDevice(ls->ctx->device);
+    if (mnk_ls_pending_elsewhere(ls)) {
+        // the other thread's batch still holds this pointer and will launch on it at its end: deleting now would leave it dangling
+        set_error("mnk_ls_destroy: a factorize! call of this solver is pending in a batch that another thread opened "
+                  "(that thread's mnk_factorize_batch_end must come first); the solver was NOT destroyed");
+        return -1;
+    }
     (void)mnk_ls_sync_deferred(ls);
     (void)mnk::stream_wait(ls->ctx->stream);
     mnk::LaunchLock lock;   // (host-memory frees and event destruction below; the device buffers lock for themselves)

@@ -345,7 +345,9 @@ int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d) {
     {   // the scenarios' solves as ONE batch (solve.hip: up to 32 small systems per launch), then the contributions in order
         int rc = mnk_solve_batch_begin();
         for (int64_t k = 0; k < h->ns && !rc; ++k) rc = mnk_ls_solve(h->ls_k[k], rhs_k + k * h->blk, 1, h->blk, MNK_DEVICE);
-        const int rc_end = mnk_solve_batch_end();
+        int rc_end = mnk_solve_batch_end();
+        // (inside a batch the CALLER opened the end above is a no-op: the contributions below need the solutions now)
+        if (!rc && !rc_end) rc_end = mnk_solve_batch_flush_pending();
         if (rc || rc_end) return rc ? rc : rc_end;
     }
     if (h->ns > 0) {
@@ -376,7 +378,8 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
     {
         int rc = mnk_solve_batch_begin();
         for (int64_t k = 0; k < h->ns && !rc; ++k) rc = mnk_ls_solve(h->ls_k[k], h->tmpk.p + k * h->Npb, 1, h->blk, MNK_DEVICE);
-        const int rc_end = mnk_solve_batch_end();
+        int rc_end = mnk_solve_batch_end();
+        if (!rc && !rc_end) rc_end = mnk_solve_batch_flush_pending();   // (as in the forward stage)
         if (rc || rc_end) return rc ? rc : rc_end;
     }
     if (h->ns > 0)

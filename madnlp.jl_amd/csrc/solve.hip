@@ -1044,6 +1044,9 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev, double* xuser) {
         if (rc) return rc;
     }
     if (bk) {
+        // (the permutation's scratch is the first publication buffer of the one-launch solve: it no longer holds the sentinel --
+        // a later solve on the static-pivot tier must reset it before it polls it)
+        ls->pub_clean[0] = false;
         int rc = mnk_ls_bk_permute(ls, xdev, xdev + 2 * Np, true);
         if (rc) return rc;
     }
@@ -1131,6 +1134,7 @@ int mnk_ls_run_solve(mnk_ls* ls, double* xdev, double* xuser) {
     }
     MNK_HIP(hipGetLastError());
     if (bk) {
+        ls->pub_clean[0] = false;
         int rc = mnk_ls_bk_permute(ls, xdev, xdev + 2 * Np, false);
         if (rc) return rc;
     }
@@ -1267,6 +1271,11 @@ extern "C" int mnk_solve_batch_end(void) {
     t_sbatch.active = false;
     return solve_batch_flush();
 }
+
+// Library-internal consumers of a solve batch (schur.hip) read the solutions right behind their own begin / end pair.  When
+// the CALLER already has a batch open on this thread the inner end is a no-op (pairs nest, the outermost end launches) and
+// the solves would still be queued: this runs whatever the thread has queued, now, and leaves the caller's batch open.
+int mnk_solve_batch_flush_pending(void) { return t_sbatch.pend.empty() ? 0 : solve_batch_flush(); }
 
 // (a solver that is destroyed, factorized again or asked for a non-batchable solve while one of its solves is queued)
 int mnk_solve_sync_deferred(mnk_ls* ls) {
