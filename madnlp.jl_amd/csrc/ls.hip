@@ -683,7 +683,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         return 0;
     }
     if (!strcmp(key, "dag_band")) {    // 64-row strips of the pivot chain's band
-        MNK_REQUIRE(value == 8.0 || value == 12.0 || value == 16.0, "dag_band must be 8, 12 or 16");
+        MNK_REQUIRE(value >= 8.0 && value <= 64.0 && (int)value % 4 == 0 && (double)(int)value == value, "dag_band must be a multiple of 4 in 8..64");
         ls->dag_band = (int)value;
         ls->dag_tasks.release();
         return 0;

@@ -14,6 +14,8 @@ with torch.cuda.stream(s):
     A = R @ R.T + torch.diag(torch.rand(N, dtype=torch.float64, device="cuda", generator=g) * 10 + 1.0)
     s.synchronize()
     ls = mj.HipLinearSolver(A, ctx=ctx, opt=mj.HipSolverOptions(lapack_algorithm=alg, panel_algo=5))
+    if os.environ.get("DAG_BAND"):
+        ls.set_option("dag_band", int(os.environ["DAG_BAND"]))
     for _ in range(3):
         ls.factorize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,4 +23,4 @@ with torch.cuda.stream(s):
     for _ in range(10):
         ls.factorize()
     e1.record(s); s.synchronize()
-    print(f"N={N} {alg}: factorize {e0.elapsed_time(e1)/10:.3f} ms  panel_algo {ls.get_stat('panel_algo')}")
+    print(f"N={N} {alg} band={os.environ.get('DAG_BAND','16')} cus={os.environ.get('MNK_DAG_CUS','16')}: factorize {e0.elapsed_time(e1)/10:.3f} ms  panel_algo {ls.get_stat('panel_algo')} fallbacks {ls.get_stat('pp_fallbacks')} bulk_wgs {ls.get_stat('dag_bulk_wgs')}")

@@ -36,12 +36,42 @@ __host__ __device__ inline Layout layout(int tilemajor) {
     return tilemajor ? Layout{128, (int64_t)NTILE * 16384, 16384} : Layout{LD, 128, 128 * LD};
 }
 
+// reference: MFMAs from registers only (no LDS, no memory), three workgroups per CU -- the sustained rate of the matrix cores and
+// the clock they run at under that load
+__global__ __launch_bounds__(256, 3) void lab_mfma_only(double* Cw, int iters, unsigned long long* clk) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
+    v4f64 acc[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0, 0, 0, 0};
+    double af[4], bf[4];
+    for (int i = 0; i < 4; ++i) { af[i] = 1e-3 * (threadIdx.x + i); bf[i] = 1e-3 * (threadIdx.x * 3 + i); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    v4f64 sm = v4f64{0, 0, 0, 0};
+    for (auto& row : acc) for (auto& v : row) sm += v;
+    if (sm[0] + sm[1] + sm[2] + sm[3] == 12345.678) Cw[threadIdx.x] = sm[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
+}
+
 template <int V>   // 2: two-buffer 128 x 128, 3: three-buffer 128 x 128
-__global__ __launch_bounds__(256, 3) void lab_base(const double* F, const double* Vb, double* Cw, const int4* tasks, int ntask, int epi, int tilemajor) {
+__global__ __launch_bounds__(256, 3) void lab_base(const double* F, const double* Vb, double* Cw, const int4* tasks, int ntask, int epi, int tilemajor, int* qctr, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_t;
     const Layout lo = layout(tilemajor);
-    for (int t = 0; t < ntask; ++t) {
-        const int4 tk = tasks[(size_t)blockIdx.x * ntask + t];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
+    for (;;) {
+        if (threadIdx.x == 0) s_t = qctr ? atomicAdd(qctr, 1) : -1;
+        __syncthreads();
+        const int t = s_t;
+        __syncthreads();
+        if (t < 0 || t >= ntask) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
+            return;
+        }
+        const int4 tk = tasks[t];
         const int I = __builtin_amdgcn_readfirstlane(tk.x), J = __builtin_amdgcn_readfirstlane(tk.y);
         const int kb = __builtin_amdgcn_readfirstlane(tk.z), kl = __builtin_amdgcn_readfirstlane(tk.w);
         int tid = threadIdx.x;
@@ -60,11 +90,21 @@ __global__ __launch_bounds__(256, 3) void lab_base(const double* F, const double
 }
 
 template <int RT, int NS>
-__global__ __launch_bounds__(MacroCfg<RT>::NT, 1) void lab_macro(const double* F, const double* Vb, double* Cw, const int4* tasks, int ntask, int epi, int tilemajor) {
+__global__ __launch_bounds__(MacroCfg<RT>::NT, 1) void lab_macro(const double* F, const double* Vb, double* Cw, const int4* tasks, int ntask, int epi, int tilemajor, int* qctr, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_t;
     const Layout lo = layout(tilemajor);
-    for (int t = 0; t < ntask; ++t) {
-        const int4 tk = tasks[(size_t)blockIdx.x * ntask + t];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter(); clk[1] = wall_clock64(); }
+    for (;;) {
+        if (threadIdx.x == 0) s_t = qctr ? atomicAdd(qctr, 1) : -1;
+        __syncthreads();
+        const int t = s_t;
+        __syncthreads();
+        if (t < 0 || t >= ntask) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) { clk[2] = __builtin_readcyclecounter(); clk[3] = wall_clock64(); }
+            return;
+        }
+        const int4 tk = tasks[t];
         const int I = __builtin_amdgcn_readfirstlane(tk.x), J = __builtin_amdgcn_readfirstlane(tk.y);
         const int kb = __builtin_amdgcn_readfirstlane(tk.z), kl = __builtin_amdgcn_readfirstlane(tk.w);
         int tid = threadIdx.x;
@@ -83,6 +123,8 @@ __global__ __launch_bounds__(MacroCfg<RT>::NT, 1) void lab_macro(const double* F
 
 static double *F, *Vb, *Cw;
 static int4* dtasks;
+static int* dq;
+static unsigned long long* dclk;   // {shader cycles, 100 MHz ticks} at start and end of workgroup 0
 static int g_cus = 256;
 
 // tasks of `rt` tiles each: J in [8, 80), klen in [klo, khi], kbeg + klen <= J, I (first tile row) in (J, NTILE - rt]
@@ -99,6 +141,8 @@ static double make_tasks(int nwg, int ntask, int rt, int klo, int khi, unsigned 
         t = make_int4(I, J, kb, kl);
         ksteps += (double)kl * rt;
     }
+    // (the last tenth of the queue in order of decreasing length: the kernel ends within a short task of its last pop)
+    std::sort(h.begin() + (h.size() - h.size() / 10), h.end(), [](const int4& a, const int4& b) { return a.w > b.w; });
     hipMemcpy(dtasks, h.data(), h.size() * sizeof(int4), hipMemcpyHostToDevice);
     return ksteps;
 }
@@ -112,32 +156,38 @@ static void timeit(const char* name, K kern, int nthreads, int nwg, size_t lds, 
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
+        hipMemsetAsync(dq, 0, 4, 0);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(kern, dim3(nwg), dim3(nthreads), lds, 0, F, Vb, Cw, dtasks, ntask, epi, tilemajor);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(nthreads), lds, 0, F, Vb, Cw, dtasks, nwg * ntask, epi, tilemajor, dq, dclk);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         if (rep > 0 && ms < best) best = ms;
     }
+    unsigned long long hc[4];
+    hipMemcpy(hc, dclk, sizeof(hc), hipMemcpyDeviceToHost);
+    const double mhz = (double)(hc[2] - hc[0]) / (double)(hc[3] - hc[1]) * 100.0;
     hipError_t err = hipGetLastError();
     const double flops = ksteps * 2.0 * 128.0 * 128.0 * 128.0;
     const double tf = flops / (best * 1e-3) / 1e12;
     // one k-step of a CU's three 128 x 128 workgroups = 3 x 128^3 x 2 flop at the chip's rate / #CUs
     const double us_kstep = 3.0 * 2.0 * 128.0 * 128.0 * 128.0 / (tf * 1e12 / cus_used) * 1e6;
-    printf("%-44s wgs %4d epi %d tm %d klen %2d-%2d: %8.3f ms  %6.2f TFLOP/s  (%.3f of the %d CUs' peak)  k-step %.1f us %s\n", name, nwg, epi, tilemajor, klo, khi, best, tf,
-           tf / (78.6 * cus_used / 256.0), cus_used, us_kstep, err == hipSuccess ? "" : hipGetErrorString(err));
+    printf("%-44s wgs %4d epi %d tm %d klen %2d-%2d: %8.3f ms  %6.2f TFLOP/s  (%.3f of the %d CUs' peak)  k-step %.1f us  shader clock %.0f MHz -> %.3f of the MFMA rate at that clock %s\n", name, nwg, epi, tilemajor, klo, khi, best, tf,
+           tf / (78.6 * cus_used / 256.0), cus_used, us_kstep, mhz, tf / (cus_used * 4 * 32.0 * mhz * 1e6 / 1e12), err == hipSuccess ? "" : hipGetErrorString(err));
     fflush(stdout);
 }
 
 int main(int argc, char** argv) {
-    const int ntask = argc > 1 ? atoi(argv[1]) : 24;
+    const int ntask = argc > 1 ? atoi(argv[1]) : 96;
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     g_cus = prop.multiProcessorCount;
     const size_t n = (size_t)LD * LD + 4096;
     hipMalloc(&F, n * 8); hipMalloc(&Vb, n * 8); hipMalloc(&Cw, n * 8);
     hipMalloc(&dtasks, (size_t)4096 * 256 * sizeof(int4));
+    hipMalloc(&dq, 64);
+    hipMalloc(&dclk, 64);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, F, n, 1u);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, Vb, n, 2u);
     hipMemset(Cw, 0, n * 8);
@@ -155,7 +205,8 @@ int main(int argc, char** argv) {
             hipMemset(Cw, 0, n * 8);
             hipMemcpy(dtasks, one.data(), sizeof(int4), hipMemcpyHostToDevice);
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, 0, F, Vb, Cw, dtasks, 1, 1, tm);
+            hipMemset(dq, 0, 4);
+            hipLaunchKernelGGL(kern, dim3(1), dim3(nthreads), lds, 0, F, Vb, Cw, dtasks, 1, 1, tm, dq, dclk);
             hipDeviceSynchronize();
             grab(got);
             hipMemset(Cw, 0, n * 8);
@@ -163,7 +214,8 @@ int main(int argc, char** argv) {
             for (int b = 0; b < rt; ++b) per.push_back(make_int4(I + b, J, kb, kl));
             hipMemcpy(dtasks, per.data(), per.size() * sizeof(int4), hipMemcpyHostToDevice);
             hipFuncSetAttribute((const void*)lab_base<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 288 * 8);
-            hipLaunchKernelGGL(lab_base<2>, dim3(rt), dim3(256), 2 * 8 * 288 * 8, 0, F, Vb, Cw, dtasks, 1, 1, tm);
+            hipMemset(dq, 0, 4);
+            hipLaunchKernelGGL(lab_base<2>, dim3(rt), dim3(256), 2 * 8 * 288 * 8, 0, F, Vb, Cw, dtasks, rt, 1, tm, dq, dclk);
             hipDeviceSynchronize();
             grab(ref);
             size_t bad = 0; double mx = 0;
@@ -179,20 +231,37 @@ int main(int argc, char** argv) {
         hipMemset(Cw, 0, n * 8);
     }
     const int C = g_cus;
+    for (int nw : {3 * C, 2 * C, C}) {   // MFMAs only
+        const int iters = 40000;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(lab_mfma_only, dim3(nw), dim3(256), 0, 0, Cw, iters, dclk);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        }
+        unsigned long long hc[4];
+        hipMemcpy(hc, dclk, sizeof(hc), hipMemcpyDeviceToHost);
+        const double mhz = (double)(hc[2] - hc[0]) / (double)(hc[3] - hc[1]) * 100.0;
+        const double tf = (double)nw * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
+        printf("MFMA from registers only, %4d workgroups: %8.3f ms  %6.2f TFLOP/s  shader clock %.0f MHz -> %.3f of the MFMA rate at that clock\n", nw, ms, tf, mhz,
+               tf / (C * 4 * 32.0 * mhz * 1e6 / 1e12));
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const int klo = pass == 0 ? 2 : 8, khi = pass == 0 ? 16 : 40;
-        for (int epi = 1; epi >= 0; --epi)
-            for (int tm = 0; tm < 2; ++tm) {
-                if (epi == 0 && tm == 1) continue;
-                timeit("128x128 two buffers, 3 wg/CU", lab_base<2>, 256, 3 * C, 2 * 8 * 288 * 8, 1, ntask, epi, tm, klo, khi);
-                timeit("128x128 three buffers, 3 wg/CU", lab_base<3>, 256, 3 * C, TILE3_LDS_BYTES, 1, ntask, epi, tm, klo, khi);
-                timeit("macro 256x128 (8 waves), 3 stages", lab_macro<2, 3>, 512, C, macro_lds_bytes<2, 3>(), 2, ntask, epi, tm, klo, khi);
-                timeit("macro 256x128 (8 waves), 4 stages", lab_macro<2, 4>, 512, C, macro_lds_bytes<2, 4>(), 2, ntask, epi, tm, klo, khi);
-                timeit("macro 384x128 (12 waves), 3 stages", lab_macro<3, 3>, 768, C, macro_lds_bytes<3, 3>(), 3, ntask, epi, tm, klo, khi);
-                timeit("macro 384x128 (12 waves), 4 stages", lab_macro<3, 4>, 768, C, macro_lds_bytes<3, 4>(), 3, ntask, epi, tm, klo, khi);
-            }
+        for (int mode = 0; mode < 3; ++mode) {   // (epilogue, layout): (1, column-major), (1, tile-major), (0, column-major)
+            const int epi = mode < 2, tm = mode == 1;
+            timeit("128x128 two buffers, 3 wg/CU", lab_base<2>, 256, 3 * C, 2 * 8 * 288 * 8, 1, ntask, epi, tm, klo, khi);
+            timeit("128x128 three buffers, 3 wg/CU", lab_base<3>, 256, 3 * C, TILE3_LDS_BYTES, 1, ntask, epi, tm, klo, khi);
+            timeit("macro 256x128 (8 waves), 3 stages", lab_macro<2, 3>, 512, C, macro_lds_bytes<2, 3>(), 2, ntask * 3 / 2, epi, tm, klo, khi);
+            timeit("macro 256x128 (8 waves), 4 stages", lab_macro<2, 4>, 512, C, macro_lds_bytes<2, 4>(), 2, ntask * 3 / 2, epi, tm, klo, khi);
+            timeit("macro 384x128 (12 waves), 3 stages", lab_macro<3, 3>, 768, C, macro_lds_bytes<3, 3>(), 3, ntask, epi, tm, klo, khi);
+            timeit("macro 384x128 (12 waves), 4 stages", lab_macro<3, 4>, 768, C, macro_lds_bytes<3, 4>(), 3, ntask, epi, tm, klo, khi);
+        }
     }
     // the same loops on a grid that leaves 16 CUs out (224 CUs' worth, as beside the pivot chain): per-CU rates should not move
+    for (int nw : {2 * C, 2 * C + C / 4, 2 * C + C / 2})
+        timeit("128x128 two buffers, fewer workgroups", lab_base<2>, 256, nw, 2 * 8 * 288 * 8, 1, ntask, 1, 0, 2, 16);
     timeit("128x128 two buffers, 672 wgs", lab_base<2>, 256, 672, 2 * 8 * 288 * 8, 1, ntask, 1, 0, 2, 16, 224);
     timeit("macro 384x128, 4 stages, 224 wgs", lab_macro<3, 4>, 768, 224, macro_lds_bytes<3, 4>(), 3, ntask, 1, 0, 2, 16, 224);
     timeit("macro 256x128, 4 stages, 224 wgs", lab_macro<2, 4>, 512, 224, macro_lds_bytes<2, 4>(), 2, ntask, 1, 0, 2, 16, 224);
