@@ -73,10 +73,10 @@ def parse_args():
                          "configuration the metric is quoted on), 16 at --gpus N > 1 (BASELINE config C5: "
                          "128 scenarios sharded 16 per GPU, seeds 1354 + i)")
     ap.add_argument("--concurrency", type=int, default=1,
-                    help="contexts (stream sets) the batch is spread over.  Default 1: the instances run back to "
-                         "back on one context, which keeps the persistent panel kernel in use (it needs the panel "
-                         "CUs for itself) -- measured per GPU at batch 16: 77.4 it/s with 1 context, 58.7 with 2, "
-                         "68.2 with 4 (the time-shared contexts fall back to one launch per panel piece)")
+                    help="contexts (stream sets) the batch is spread over.  Default 1.  The persistent operations of all "
+                         "contexts of a process take turns on the device (the arbiter of csrc/common.h) and stay on the "
+                         "task-DAG schedule: measured per GPU at batch 16 with the batch API, 107-109 it/s with 1 context and "
+                         "with 4 (profiles/r04_config_C5_*.json)")
     ap.add_argument("--no-batch-api", action="store_true",
                     help="batch > 1: enqueue the factorizations one by one instead of through mnk_factorize_batch_begin/_end "
                          "(one merged persistent launch for all instances of a step: they fill each other's chain-bound ends)")

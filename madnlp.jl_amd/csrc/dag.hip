@@ -905,19 +905,21 @@ int mnk_dag_warmup(hipStream_t* streams, int n, int nwg) {
 
 // Bound of the schedule's device-side waits, in polls of ~0.17 us.  Every wait is on work that is queued or resident, so a
 // bound only ever expires when something outside the schedule keeps a kernel of the group from running: another process'
-// kernels on the CUs, or a device-synchronizing runtime call of OTHER code in this process between the group's launches
-// (seen: four host threads, torch's lazy library initialization on one of them while another one launches -- the chain waits
-// for a bulk kernel whose launch the runtime holds back until the device is idle).  The recovery is cheap (the factorization
-// is redone with one launch per piece, the schedule is tried again 16 factorizations later), a long bound is not: 2^24 polls
-// were ~3 s of a stalled device.  ~100 x the time the factorization should take, at least 1 s: a bound of 30 x (0.3 s at
-// N = 11 192) was tried first and expired about once in 1000 factorizations of tools/c5_loop.py on transient stalls that a
-// longer bound sits out -- harmless for the result, but a fall-back where none is needed.
+// kernels on the CUs, a copy between pageable host memory and the device by OTHER code of this process, a device-synchronizing
+// runtime call between the group's launches.  The recovery is cheap (the factorization is redone
+// with one launch per piece, the schedule is tried again 16 factorizations later), a long bound is not: whatever stops the
+// group costs the bound.  History: 2^24 polls (~3 s) in round 3; ~100 x the factorization's time, at least 1 s, in round 4 --
+// a bound of 0.3 s then expired about once in 1000 factorizations on transient stalls, which turned out to be the workgroups of
+// an oversized bulk grid that the hardware placed in mid-kernel (grid 720 -> 672).  With that
+// grid, round 5 ran 3 x 10 240 factorizations of the C3 system at bounds of 0.05 / 0.1 / 0.3 s without a single expiry
+// (profiles/r05_spin_bound_sweep.txt): the default is now ~10 x the time the factorization should take, at least 0.1 s -- the
+// longest legitimate wait is a fraction of one factorization (a chain strip waiting for its band tiles: ~0.3 ms at N = 11 192).
 long mnk_ls_dag_spin_limit(const mnk_ls* ls) {
     if (ls->dag_spin_limit > 0) return ls->dag_spin_limit;
     const double n = (double)ls->Np;
     const double t_est = n * n * n / 3.0 / 50e12;   // seconds at ~0.64 of the fp64 peak
-    const double polls = 100.0 * t_est / 0.17e-6;
-    return (long)std::min(16777216.0, std::max(6000000.0, polls));
+    const double polls = 10.0 * t_est / 0.17e-6;
+    return (long)std::min(16777216.0, std::max(588000.0, polls));
 }
 
 static mnk::DagInst dag_instance(mnk_ls* ls) {

@@ -22,7 +22,9 @@
 // (LAPACK stops at the failing column; we cannot stop the host without a sync).
 #include <atomic>
 #include <type_traits>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -1268,6 +1270,13 @@ int64_t mnk_ls_effective_nbo(const mnk_ls* ls) {
 
 // inv(L_jj) of the 64x64 diagonal blocks and the explicit inverses of the 256x256 diagonal triangles (what the solves
 // use) for the strip-columns [sc0, sc1) of 256 columns.  (The Bunch-Kaufman tier always inverts unit-lower blocks.)
+double mnk_host_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static std::atomic<long long> g_stall_us{0};
+void mnk_add_process_stall_ms(double ms) { g_stall_us.fetch_add((long long)(ms * 1e3), std::memory_order_relaxed); }
+double mnk_process_stall_ms() { return (double)g_stall_us.load(std::memory_order_relaxed) * 1e-3; }
+
 int mnk_ls_invert_blocks(mnk_ls* ls, hipStream_t s, int64_t sc0, int64_t sc1) {
     if (sc1 <= sc0) return 0;
     const int64_t b0 = 4 * sc0, b1 = std::min<int64_t>(4 * sc1, ls->Np / NBI);
@@ -1364,6 +1373,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     }
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
     ls->inv_done = 0;
+    ls->t_fact_launch_ms = mnk_host_ms();
     // The persistent kernels keep waiting workgroups resident.  Two of them from different contexts on the same CUs can
     // starve each other's diagonal strips (per-XCD dispatch order), so the persistent operations of one process take turns
     // on the device (the arbiter below); a wait that expires anyway (another PROCESS) falls back (mnk_ls_fetch_info) and the
@@ -1747,6 +1757,11 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         ls->pp_retry_at = ls->fact_count + ls->pp_backoff + 1;   // (+1: the redo below counts)
         ls->pp_backoff *= 4;
         ++ls->pp_fallbacks;
+        {   // what the expired wait cost: from the launch of that factorization to this moment (the redo below comes on top)
+            const double lost = std::max(0.0, mnk_host_ms() - ls->t_fact_launch_ms);
+            ls->stall_ms_total += lost;
+            mnk_add_process_stall_ms(lost);
+        }
         int rc = ls->retransfer();
         if (rc) return rc;
         rc = mnk_ls_run_factorization(ls);

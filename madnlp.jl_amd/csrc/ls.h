@@ -77,6 +77,8 @@ struct mnk_ls {
     int64_t fact_count = 0, pp_retry_at = 0, pp_backoff = 16;   // a schedule that timed out is tried again after 16, 64, 256, ... factorizations
     int pp_fallbacks = 0;
     int last_timeout_site = 0;   // diagnostics: which bounded device-side wait expired (get_stat "timeout_site")
+    double stall_ms_total = 0.0; // host time between the launch of a factorization whose bounded wait expired and the moment the expiry was seen: what the fall-backs of this solver have cost (get_stat "stall_ms_total"; "stall_ms_process": all solvers)
+    double t_fact_launch_ms = 0.0;   // host clock (ms) when the current factorization was enqueued
     int64_t pp_fuse_rows = 4096; // > 0: once this many rows (or fewer) remain, persistent panel launches apply the columns in front of them themselves
     int64_t own_cols = 128;   // split_a = 2: columns of the next panel that the panel stream updates itself
     // task-DAG schedule (panel_algo = 5, dag.hip)
@@ -174,6 +176,9 @@ bool mnk_solve_defer(mnk_ls* ls, double* xuser);   // solve.hip: true if the cal
 int mnk_solve_sync_deferred(mnk_ls* ls);           // solve.hip: runs the queued solves if one of them belongs to this solver
 int mnk_solve_batch_flush_pending(void);           // solve.hip: runs every solve the calling thread has queued (nested batches: schur.hip)
 int mnk_ls_factorize_dense_dev_async(mnk_ls* ls, const double* Adev, int64_t lda);   // ls.hip
+double mnk_host_ms();                               // factor.hip: steady host clock in ms
+void mnk_add_process_stall_ms(double ms);           // factor.hip: time lost to expired device-side waits, all solvers of the process
+double mnk_process_stall_ms();
 bool mnk_ls_pending_elsewhere(const mnk_ls* ls);   // dag.hip: queued in a factorization batch of ANOTHER thread
 bool mnk_batch_active();                           // dag.hip: the calling thread has a factorization batch open
 size_t mnk_pchain_sys_bytes();                     // factor.hip: size of one record of mnk_launch_pchain_multi's table

@@ -1177,6 +1177,8 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
     // which bounded device-side wait expired last (info = -7): 1 bulk task / operand rows, 2 bulk task / chunk order, 3 gate on the bulk stream, 4 chain strip / diagonal block, 5 chain strip / bulk kernel's rows or band tiles; 0: none
     if (!strcmp(key, "timeout_site")) { *value = ls->last_timeout_site; return 0; }
+    if (!strcmp(key, "stall_ms_total")) { *value = ls->stall_ms_total; return 0; }      // what this solver's expired waits (fall-backs) have cost, host ms
+    if (!strcmp(key, "stall_ms_process")) { *value = mnk_process_stall_ms(); return 0; }  // ... all solvers of the process
     if (!strcmp(key, "growth")) { *value = ls->last_growth; return 0; }  // BUNCHKAUFMAN: max|d_k| / max|a_ij| of the static-pivot tier
     if (!strcmp(key, "sign_changes")) { *value = (double)ls->last_sign_changes; return 0; }  // ... and sign changes along its pivots
     if (!strcmp(key, "bk_count")) { *value = ls->bk_count; return 0; }

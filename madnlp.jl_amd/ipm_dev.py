@@ -355,6 +355,8 @@ class DeviceMadNLPSolver(MadNLPSolver):
     def alpha_max(self, dx):
         return self.K.get_alpha_max(self.x, self.xl, self.xu, dx, self.tau)
 
+    on_trial = None   # diagnostics: callable(solver, n_trial, inertia, inertia_correct, accepted) after every trial of inertia_correction
+
     def inertia_correction(self):
         o, k = self.opt, self.kkt
         n_trial = 0
@@ -362,7 +364,10 @@ class DeviceMadNLPSolver(MadNLPSolver):
         self.del_w = self.del_c = 0.0
         self.factorize_wrapper()
         inertia = k.linear_solver.inertia()
-        ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if k.is_inertia_correct(*inertia) else False
+        correct = k.is_inertia_correct(*inertia)
+        ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if correct else False
+        if self.on_trial is not None:
+            self.on_trial(self, n_trial, inertia, correct, ok)
         while not ok:
             if n_trial == 0:
                 self.del_w = (o.first_hessian_perturbation if self.del_w_last == 0 else
@@ -378,8 +383,11 @@ class DeviceMadNLPSolver(MadNLPSolver):
             dw_prev, dc_prev = self.del_w, self.del_c
             self.factorize_wrapper()
             inertia = k.linear_solver.inertia()
-            ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if k.is_inertia_correct(*inertia) else False
+            correct = k.is_inertia_correct(*inertia)
+            ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if correct else False
             n_trial += 1
+            if self.on_trial is not None:
+                self.on_trial(self, n_trial, inertia, correct, ok)
         if self.del_w != 0:
             self.del_w_last = self.del_w
         return True

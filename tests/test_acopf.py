@@ -260,6 +260,7 @@ def test_device_resident_case1354_run_matches_the_oracle_golden(gpu_ctx):
     gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "acopf_case1354_oracle.json")))
     nlp = ACOPFModel(gold["case"])
     assert (nlp.n, nlp.m) == (gold["n"], gold["m"])
+    nlp_n_cond = nlp.n   # (the condensed system has the order of the primal variables)
 
     def factory(info):
         return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J,
@@ -267,9 +268,56 @@ def test_device_resident_case1354_run_matches_the_oracle_golden(gpu_ctx):
                                            opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN),
                                            device_kkt_ops=True)
     sd = DeviceMadNLPSolver(nlp, factory, _options(gold["tol"]))
+    # every trial of inertia_correction! (reference src/IPM/solver.jl:611-670): del_w, the inertia verdict, whether the step was
+    # accepted -- and the condensed matrices of the first two iterations that need a correction, for the replay below
+    trials, mats = [], []
+
+    def on_trial(solver, n_trial, inertia, correct, ok):
+        trials.append(dict(k=solver.cnt.k, trial=n_trial, del_w=solver.del_w, inertia=tuple(int(v) for v in inertia), correct=bool(correct),
+                           ok=bool(ok), bk=bool(solver.kkt.linear_solver.bk_info()[0])))
+        if len({m[0] for m in mats} | {solver.cnt.k}) <= 2 and (n_trial > 0 or not ok):
+            A = solver.kkt.aug_com
+            mats.append((solver.cnt.k, n_trial, bool(ok), tuple(int(v) for v in inertia),
+                         sp.csc_matrix((A.nzval.copy(), np.asarray(A.rowval).copy(), np.asarray(A.colptr).copy()), shape=(A.n, A.n))))
+    sd.on_trial = on_trial
     sd.solve()
     assert sd.status == gold["status"] == "SOLVE_SUCCEEDED"
     assert abs(sd.cnt.k - gold["iterations"]) <= 2, (sd.cnt.k, gold["iterations"])
+    # ---- the trajectory the fixture stores: record k + 1 of either history holds the state
+    # after iteration k and the del_w that iteration accepted.  While the two runs are at the same point (inf_pr and inf_du
+    # equal to 1e-4 relative: the back-ends' steps differ at the level of their solves' residuals) they must take the same decision: the same del_w, exactly.  They stay together through the
+    # iterations whose negative curvature is real (profiles/r05_acopf_trajectory.txt: k = 0 .. 8) and part ways where the
+    # verdict hangs on one pivot at rounding level -- condensed matrices with max|K| ~ 1e17 against del_w ~ 1e-8 ... 1e-10: the
+    # static-pivot LDL' and dsytrf then disagree about a SINGLE eigenvalue in either direction (replayed in the profile).
+    gh = {r["k"]: r for r in gold["history"]}
+    hh = {r.k: r for r in sd.history}
+    together = 0
+    for kk in range(0, min(sd.cnt.k, gold["iterations"])):
+        a, b = hh.get(kk + 1), gh.get(kk + 1)
+        if a is None or b is None:
+            break
+        if abs(a.inf_pr - b["inf_pr"]) > 1e-4 * abs(b["inf_pr"]) or abs(a.inf_du - b["inf_du"]) > 1e-4 * abs(b["inf_du"]):
+            break
+        assert abs(a.del_w - b["del_w"]) <= 1e-12 * max(1.0, abs(b["del_w"])), (kk, a.del_w, b["del_w"])
+        together = kk + 1
+    assert together >= 6, f"the device run left the golden's trajectory after {together} iterations"
+    # every rejection is an inertia verdict (never a failed refinement), the static-pivot tier produced every factor, and the
+    # corrections cost at most a handful of factorizations more than the oracle back-end's
+    assert all(t["correct"] or not t["ok"] for t in trials)
+    assert not any(t["correct"] and not t["ok"] for t in trials), "a Richardson refinement failed"
+    assert not any(t["bk"] for t in trials)
+    assert sd.cnt.factorization_cnt <= gold["factorizations"] + 10, (sd.cnt.factorization_cnt, gold["factorizations"])
+    # ---- replay: the matrices of the first two corrected iterations, as the device assembled them, through dsytrf -- where
+    # the curvature is real the two back-ends give the same verdict (rejected: not positive definite; accepted: (n, 0, 0))
+    from oracle.lapack_cpu import BUNCHKAUFMAN as O_BK, LapackCPUSolver
+    assert len(mats) >= 2
+    for (kk, n_trial, ok, ine_hip, Kl) in mats:
+        dense = np.asfortranarray((Kl + sp.tril(Kl, -1).T).toarray())
+        ine_ref = tuple(int(v) for v in LapackCPUSolver(dense, O_BK).factorize().inertia())
+        if ok:
+            assert ine_hip == ine_ref == (nlp_n_cond, 0, 0), (kk, n_trial, ine_hip, ine_ref)
+        else:
+            assert ine_hip[2] >= 1 and ine_ref[2] >= 1, (kk, n_trial, ine_hip, ine_ref)
     assert abs(sd.obj_val - gold["objective"]) <= 1e-6 * abs(gold["objective"]), (sd.obj_val, gold["objective"])
     x, y, zl, zu = sd.host_state()
     pg = nlp.S["pg"]

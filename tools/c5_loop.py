@@ -64,7 +64,8 @@ with torch.cuda.stream(st):
                 bad += 1
                 print(f"round {rnd} instance {idx}: inertia {ine} backward error {bw:.2e} panel_algo {M.get_stat('panel_algo')} "
                       f"fallbacks {M.get_stat('pp_fallbacks')} site {M.get_stat('timeout_site')} growth {M.get_stat('growth'):.3g}", flush=True)
+fb = sum(int(kh.linear_solver.get_stat("pp_fallbacks")) for (_, kh, _d) in insts)
 w = np.array(walls[2:])
 slow = [(i + 2, round(float(v), 1)) for i, v in enumerate(w) if v > 1.3 * np.median(w)]
-print(f"rounds {rounds} x {nb} instances, options {opts}: {bad} bad results; round wall time median {np.median(w):.1f} ms, max {w.max():.1f} ms, "
+print(f"rounds {rounds} x {nb} instances, options {opts}: {bad} bad results; fall-backs to schedule 1 (bounded waits that expired): {fb}; round wall time median {np.median(w):.1f} ms, max {w.max():.1f} ms, "
       f"rounds slower than 1.3 x median: {slow}")
