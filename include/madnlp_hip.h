@@ -186,6 +186,12 @@ int mnk_factorize_batch_end(void);
  * to lone solves.  Thread-local, like the factorization batch. */
 int mnk_solve_batch_begin(void);
 int mnk_solve_batch_end(void);
+/* A process that goes idle next to OTHER GPU processes: destroys the CU-masked streams (= hardware queues) this library keeps
+ * per device for its persistent schedules -- a device runs only so many queues side by side, all processes together, and a
+ * process that merely holds a dozen idle ones can keep another process' pivot chain and bulk kernel from being scheduled
+ * together.  Every stream is made again by the first operation that needs it (~ms, once).  The
+ * last context of a device to be destroyed does the same.  No equivalent in the reference (its solvers hold no queues). */
+int mnk_release_idle_streams(int device);
 /* Array forms for n independent instances (one call per phase of an iteration; hosts with a per-call overhead):
  *   _step_batch    : per instance compress_jacobian! + compress_hessian! + build_kkt! + factorize! (asynchronous), the
  *                    factorizations as ONE batch (mnk_factorize_batch_begin / _end around the loop);

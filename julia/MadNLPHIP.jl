@@ -211,26 +211,49 @@ function factorize_async!(M::HipLinearSolver{T, <:HipAugDense}) where T
     check(rc, FactorizationException)
     return M
 end
+# (The batch is THREAD-LOCAL state of the library.  A Julia task may migrate to another OS thread at any yield point inside
+# f() -- I/O, a lock, a GC safepoint with a task switch -- and the `_end` call would then find no batch open on its thread while
+# the first thread keeps one open for good.  The task is therefore made sticky for the duration of the block.)
 function factorize_batch(f)
+    t = current_task()
+    was_sticky = t.sticky
+    t.sticky = true
     check(ccall((:mnk_factorize_batch_begin, libmadnlp_hip), Cint, ()), FactorizationException)
     try
         f()
     finally
-        check(ccall((:mnk_factorize_batch_end, libmadnlp_hip), Cint, ()), FactorizationException)
+        rc = ccall((:mnk_factorize_batch_end, libmadnlp_hip), Cint, ())
+        t.sticky = was_sticky
+        check(rc, FactorizationException)
     end
     return nothing
 end
 factorize_batch!(Ms) = (factorize_batch(() -> foreach(factorize_async!, Ms)); Ms)
 # ... and of independent solves on device vectors (mnk_solve_batch_begin / _end): up to four systems per launch
 function solve_batch(f)
+    t = current_task()
+    was_sticky = t.sticky
+    t.sticky = true          # (thread-local batch: see factorize_batch)
     check(ccall((:mnk_solve_batch_begin, libmadnlp_hip), Cint, ()), SolveException)
     try
         f()
     finally
-        check(ccall((:mnk_solve_batch_end, libmadnlp_hip), Cint, ()), SolveException)
+        rc = ccall((:mnk_solve_batch_end, libmadnlp_hip), Cint, ())
+        t.sticky = was_sticky
+        check(rc, SolveException)
     end
     return nothing
 end
+
+"""
+    release_idle_streams(device = 0)
+
+Give the device's hardware queues back while this process has nothing to factorize (`mnk_release_idle_streams`): the CU-masked
+streams of the persistent schedules are destroyed and made again by the first operation that needs them.  For a host process
+that stays alive next to other GPU processes (INTEGRATION.md section 0).
+"""
+release_idle_streams(device::Integer = 0) =
+    (check(ccall((:mnk_release_idle_streams, libmadnlp_hip), Cint, (Cint,), device), SymbolicException); nothing)
 
 function MadNLP.solve_linear_system!(M::HipLinearSolver, x::Vector{Float64})
     rc = ccall((:mnk_ls_solve, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Int64, Cint),

@@ -7,7 +7,7 @@ fails loudly if it has not been built (no CPU fallback).
 """
 from ._lib import build, lib, LIBPATH, HipError  # noqa: F401
 from .linear_solver import (  # noqa: F401
-    BUNCHKAUFMAN, CHOLESKY, LDL, HipContext, HipLinearSolver, HipSolverOptions, factorize_batch, solve_batch,
+    BUNCHKAUFMAN, CHOLESKY, LDL, HipContext, HipLinearSolver, HipSolverOptions, factorize_batch, solve_batch, release_idle_streams,
     LinearSolverException, SymbolicException, FactorizationException, SolveException, InertiaException,
 )
 from .kkt import (  # noqa: F401

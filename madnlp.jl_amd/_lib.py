@@ -215,6 +215,7 @@ SIGNATURES = {
     "mnk_factorize_batch_end": (C.c_int, []),
     "mnk_solve_batch_begin": (C.c_int, []),
     "mnk_solve_batch_end": (C.c_int, []),
+    "mnk_release_idle_streams": (C.c_int, [C.c_int]),
     "mnk_sc_step_batch": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int]),
     "mnk_ls_inertia_batch": (C.c_int, [C.c_int, _vp, _i64p, _i64p, _i64p]),
     "mnk_ls_solve_batch": (C.c_int, [C.c_int, _vp, _vp, C.c_int]),

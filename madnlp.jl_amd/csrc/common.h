@@ -207,6 +207,7 @@ struct mnk_ctx {
 int mnk_masked_stream_pair(mnk_ctx* ctx, int chain_cus, hipStream_t* sp, hipStream_t* su);   // ls.hip
 // CU-masked streams that are made when a caller first needs them (every one is a hardware queue of the device): ls.hip
 int mnk_ctx_ensure_panel_streams(mnk_ctx* ctx);   // ctx->sp / su: look-ahead streams of the launch-per-panel schedules
+int mnk_ctx_ensure_dag(mnk_ctx* ctx);             // ctx->sp_dag / su_dag again after mnk_release_idle_streams took them
 int mnk_ctx_ensure_dag2(mnk_ctx* ctx);            // ctx->sp_dag2 / su_dag2: deep-band pair of the task-DAG schedule
 int mnk_ctx_ensure_batch_streams(mnk_ctx* ctx);   // ctx->sp_dagB / su_dagB: second chain partition + bulk stream of batches
 int mnk_solve_warmup(hipStream_t s);               // solve.hip: first (no-op) launch of the inverse kernel that needs scratch

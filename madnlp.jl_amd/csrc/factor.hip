@@ -1382,6 +1382,8 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     // (inside an open batch small systems take the task-DAG schedule too: their pivot chains run side by side, dag.hip)
     const int64_t min_rows = mnk_batch_active() ? std::min<int64_t>(ls->dag_min_rows, 256) : ls->dag_min_rows;
     if (ls->algo_now == 5 && (ctx->dag_cus < ls->dag_band || !ls->lookahead || Np < min_rows || Np > ls->dag_max_rows)) ls->algo_now = 4;
+    if (ls->algo_now == 5 && ctx->sp_dag == nullptr && mnk_ctx_ensure_dag(ctx) != 0) { (void)hipGetLastError(); ls->algo_now = 4; }   // (released while idle)
+    if (ls->algo_now == 5 && ctx->sp_dag == nullptr) ls->algo_now = 4;
     ++ls->fact_count;
     if (ls->pp_blocked && ls->fact_count >= ls->pp_retry_at) ls->pp_blocked = false;   // (a time-out may have been transient)
     if (ls->algo_now >= 4 && ls->pp_blocked) ls->algo_now = 1;

@@ -115,6 +115,7 @@ using namespace mnk;
 
 static std::mutex g_ctx_mutex;
 static std::atomic<int> g_live_ctx[64];
+static std::vector<mnk_ctx*> g_ctx_list[64];   // live whole-device contexts per device (g_ctx_mutex): mnk_release_idle_streams
 
 int mnk_live_contexts(int device) { return g_live_ctx[device & 63].load(std::memory_order_relaxed); }
 
@@ -175,11 +176,53 @@ int mnk_persist_end(mnk_ctx* ctx, hipStream_t s, int rc) {
     return rc;
 }
 
+// ---- CU-masked streams the whole-device contexts of a process share per device ----
+namespace {
+struct DagStreams { hipStream_t sp = nullptr, su = nullptr, sp2 = nullptr, su2 = nullptr, spB = nullptr, suB = nullptr; int cus = 0; bool made = false; };
+DagStreams g_dag_streams[64];
+struct MaskedPair { hipStream_t sp = nullptr, su = nullptr; };
+std::map<std::pair<int, int>, MaskedPair> g_pair_cache;   // (device, chain CUs) -> pair (mnk_masked_stream_pair)
+}  // namespace
+
+// Destroys the masked streams of `device` that are shared between contexts -- the deep-band, batch and small-batch pairs, the
+// look-ahead pairs of the live contexts, and with `primary` the task-DAG schedule's first pair as well -- and forgets them in
+// every live context: each is made again by the first operation that needs it (mnk_ctx_ensure_*).  Why: every CU-masked stream
+// is a hardware queue, the device runs only so many of them side by side -- ALL PROCESSES TOGETHER -- and a process that
+// merely holds a dozen idle ones was seen to keep ANOTHER process' pivot chain and bulk kernel from being scheduled together
+// (tools/parent_child_probe.py).  Caller holds the launch mutex; nothing persistent is in flight.
+static void release_shared_streams_locked(int device, bool primary) {
+    mnk::quiesce_persistent();
+    (void)hipSetDevice(device);
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    DagStreams& d = g_dag_streams[device & 63];
+    auto kill = [](hipStream_t& st) { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); st = nullptr; } };
+    kill(d.sp2); kill(d.su2); kill(d.spB); kill(d.suB);
+    if (primary) { kill(d.sp); kill(d.su); d.made = false; d.cus = 0; }
+    for (auto it = g_pair_cache.begin(); it != g_pair_cache.end();) {
+        if (it->first.first == device) { kill(it->second.sp); kill(it->second.su); it = g_pair_cache.erase(it); }
+        else ++it;
+    }
+    for (mnk_ctx* c : g_ctx_list[device & 63]) {
+        if (!c->shared_dag_streams) continue;
+        c->sp_dag2 = c->su_dag2 = c->sp_dagB = c->su_dagB = nullptr;
+        if (primary) c->sp_dag = c->su_dag = nullptr;
+        kill(c->sp); kill(c->su);
+    }
+    (void)hipGetLastError();
+}
+
 static void ctx_free(mnk_ctx* c) {
     mnk::LaunchLock lock;   // (stream / event destruction may synchronize)
     mnk::quiesce_persistent();
     (void)hipSetDevice(c->device);
-    g_live_ctx[c->device & 63].fetch_sub(1, std::memory_order_relaxed);
+    const int live_left = g_live_ctx[c->device & 63].fetch_sub(1, std::memory_order_relaxed) - 1;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        auto& v = g_ctx_list[c->device & 63];
+        v.erase(std::remove(v.begin(), v.end(), c), v.end());
+    }
+    // the last context of a device: the process keeps no CU-masked stream (= hardware queue) of that device behind
+    if (live_left <= 0 && !c->partitioned) release_shared_streams_locked(c->device, true);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
@@ -253,8 +296,6 @@ static bool make_masked_stream(int num_cu_total, const int* bits, int count, hip
 // the first pair (pivot chain | bulk kernel) is made with the first context; the others when a caller first needs them --
 // every masked stream is a hardware queue (see ctx_create_common).
 namespace {
-struct DagStreams { hipStream_t sp = nullptr, su = nullptr, sp2 = nullptr, su2 = nullptr, spB = nullptr, suB = nullptr; int cus = 0; bool made = false; };
-DagStreams g_dag_streams[64];
 std::vector<int> ctx_bits(const mnk_ctx* c) {
     std::vector<int> bits;
     for (int b = 0; b < c->num_cu; ++b) bits.push_back(c->cu_first + b);
@@ -334,6 +375,39 @@ int mnk_ctx_ensure_batch_streams(mnk_ctx* c) {
             if (mnk_solve_warmup(w) != 0) (void)hipGetLastError();
     }
     c->sp_dagB = d.spB; c->su_dagB = d.suB;
+    return 0;
+}
+
+// the task-DAG schedule's first pair (pivot chain | bulk kernel) after mnk_release_idle_streams has taken it away
+int mnk_ctx_ensure_dag(mnk_ctx* c) {
+    if (c->sp_dag != nullptr || c->dag_cus <= 0 || !c->shared_dag_streams) return 0;
+    mnk::LaunchLock lock;
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    DagStreams& d = g_dag_streams[c->device & 63];
+    if (d.sp == nullptr) {
+        mnk::quiesce_persistent();
+        MNK_HIP(hipSetDevice(c->device));
+        const std::vector<int> bits = ctx_bits(c);
+        if (!(make_masked_stream(c->total_cu, bits.data(), c->dag_cus, d.sp) &&
+              make_masked_stream(c->total_cu, bits.data() + c->dag_cus, c->num_cu - c->dag_cus, d.su))) {
+            if (d.sp) (void)hipStreamDestroy(d.sp);
+            d.sp = d.su = nullptr;
+            return -2;
+        }
+        d.cus = c->dag_cus; d.made = true;
+        hipStream_t warm[1] = {d.su};
+        if (mnk_dag_warmup(warm, 1, 3 * c->num_cu) != 0) (void)hipGetLastError();
+        for (hipStream_t w : {d.su, d.sp})
+            if (mnk_solve_warmup(w) != 0) (void)hipGetLastError();
+    }
+    c->sp_dag = d.sp; c->su_dag = d.su;
+    return 0;
+}
+
+extern "C" int mnk_release_idle_streams(int device) {
+    MNK_REQUIRE(device >= 0 && device < 64, "mnk_release_idle_streams: bad device");
+    mnk::LaunchLock lock;   // (no persistent group is being launched; the ones in flight are waited for)
+    release_shared_streams_locked(device, true);
     return 0;
 }
 
@@ -446,6 +520,7 @@ static int ctx_create_common(int device, void* stream, int part_first, int part_
             for (hipStream_t w : {d.su, d.sp})              // (where the inverses for the solves are launched)
                 if (w != nullptr && mnk_solve_warmup(w) != 0) (void)hipGetLastError();
         }
+        if (!part) g_ctx_list[device & 63].push_back(c);
         c->sp_dag = d.sp; c->su_dag = d.su; c->dag_cus = d.cus;
         c->dag_cus2 = d.cus > 0 ? (getenv("MNK_DAG_CUS2") ? atoi(getenv("MNK_DAG_CUS2")) : 96) : 0;   // (its streams: mnk_ctx_ensure_dag2)
         if (c->dag_cus2 <= 0 || c->dag_cus2 >= c->num_cu) c->dag_cus2 = 0;
@@ -466,13 +541,12 @@ int mnk_ctx_create(int device, void* stream, mnk_ctx** out) { return ctx_create_
 
 }  // extern "C"
 // A pair of CU-masked streams of the whole device: `sp` on the first `chain_cus` mask bits, `su` on all the others (nullptr
-// when none are left); cached per device and size for the life of the process (masked streams are hardware queues).
+// when none are left); cached per device and size until mnk_release_idle_streams / the device's last context goes (masked
+// streams are hardware queues).
 int mnk_masked_stream_pair(mnk_ctx* ctx, int chain_cus, hipStream_t* sp, hipStream_t* su) {
-    struct Pair { hipStream_t sp = nullptr, su = nullptr; };
-    static std::map<std::pair<int, int>, Pair> cache;
     mnk::LaunchLock lock;
     MNK_REQUIRE(!ctx->partitioned && chain_cus > 0 && chain_cus <= ctx->total_cu, "mnk_masked_stream_pair: bad size");
-    Pair& p = cache[{ctx->device, chain_cus}];
+    MaskedPair& p = g_pair_cache[{ctx->device, chain_cus}];
     if (p.sp == nullptr) {
         std::vector<int> bits;
         for (int b = 0; b < ctx->total_cu; ++b) bits.push_back(b);

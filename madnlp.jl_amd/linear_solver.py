@@ -113,6 +113,12 @@ class factorize_batch:
         return False
 
 
+def release_idle_streams(device: int = 0):
+    """`mnk_release_idle_streams`: give the device's hardware queues back while this process has nothing to factorize (the
+    CU-masked streams of the persistent schedules are made again on demand)."""
+    L.check(L.lib().mnk_release_idle_streams(int(device)), "mnk_release_idle_streams")
+
+
 class solve_batch:
     """`with solve_batch(): ...` -- the single-right-hand-side solves of this thread on DEVICE vectors inside the block are queued
     and run together when the block is left, up to four independent systems per launch (`mnk_solve_batch_begin / _end`).
