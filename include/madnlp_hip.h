@@ -493,6 +493,12 @@ int mnk_schur_scenario_inertia(mnk_schur* h, int64_t k, int64_t* num_pos, int64_
 int mnk_schur_forward(mnk_schur* h, double* rhs_k, double* contrib_d);
 int mnk_schur_solve_s(mnk_schur* h, double* rhs_d);
 int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d);
+/* Single-rank conveniences for callers that keep no device memory of their own (the host-driven KKT type of the Julia glue):
+ *   mnk_schur_s_buffer  a device buffer of nd x nd doubles owned by the handle (S_out of _build_local, S of _factorize_s);
+ *   mnk_schur_solve     steps 3-5 of solve_kkt! (reference :1078-1092) in one call, host (loc = MNK_HOST) or device vectors:
+ *                       rhs_k = ns x blk (scenario k at k * blk), rhs_d = nd, both overwritten with the solution. */
+void* mnk_schur_s_buffer(mnk_schur* h);
+int mnk_schur_solve(mnk_schur* h, double* rhs_k, double* rhs_d, int loc);
 
 /* Diagnostics: with option "solve_trace" = 1 the persistent solve kernel stamps the forward sweep's critical
  * path (8 x 100 MHz timer values per 64-row block); this copies them out (n = number of uint64 to copy). */

@@ -793,4 +793,180 @@ function backward!(st::HipSchurStage, rhs_k::Ptr{Cdouble}, x_d::Ptr{Cdouble})
     return st
 end
 
+# ------------------------------------------------------------------ SchurComplementKKTSystem on the HIP stage
+# Reference: `SchurComplementKKTSystem` (src/KKT/Schur/schur.jl:72-1146).  The host side of that type -- COO / CSC copies of the
+# Hessian and the Jacobian, the per-scenario index maps of `_build_schur_symbolic` (:140-700), the scatter of the callback
+# values into the scenario blocks `A_kk` / `C_dk` and into S (:935-972, :993-996), the vector algebra of `solve_kkt!`
+# (:1040-1110), `mul!` / `jtprod!` -- is exactly the reference's: this type WRAPS a reference system (built with a scenario
+# solver that does nothing) and replaces what the reference does with one sparse solver per scenario and a host LAPACK call:
+# the ns block factorizations (one batch on the device), `S -= sum_k C_dk A_k^-1 C_dk'` (matrix cores), the factorization of S,
+# and steps 3-5 of the solve (`mnk_schur_build_local`, `_factorize_s`, `_solve`).  `madnlp(nlp; kkt_system =
+# HipSchurComplementKKTSystem, linear_solver = HipLinearSolver, kkt_options = schur_opts(; ns, nv, nd, nc))`.
+"A scenario solver that is never asked to factorize (the device stage owns the blocks)."
+struct HipNoScenarioSolver{T} <: AbstractLinearSolver{T}
+    A::SparseMatrixCSC{T, Int32}
+end
+HipNoScenarioSolver(A::SparseMatrixCSC{T, Int32}; kwargs...) where T = HipNoScenarioSolver{T}(A)
+MadNLP.factorize!(M::HipNoScenarioSolver) = M
+MadNLP.introduce(::HipNoScenarioSolver) = "none (HIP Schur stage)"
+
+"The solver of the design block S as the interior-point loop sees it: `factorize!` / `inertia` of the stage's S."
+mutable struct HipSchurDesignSolver{T} <: AbstractLinearSolver{T}
+    stage::HipSchurStage
+    S::Ptr{Cdouble}            # device buffer of the stage (mnk_schur_s_buffer)
+end
+HipSchurDesignSolver(A::AbstractMatrix; kwargs...) = error("HipSchurDesignSolver is created by HipSchurComplementKKTSystem")
+MadNLP.factorize!(M::HipSchurDesignSolver) = (factorize_s!(M.stage, M.S); M)
+MadNLP.is_inertia(::HipSchurDesignSolver) = true
+MadNLP.inertia(M::HipSchurDesignSolver) = inertia_s(M.stage)
+MadNLP.improve!(::HipSchurDesignSolver) = false
+MadNLP.introduce(::HipSchurDesignSolver) = "HIP-MI355X Schur stage (batched scenario blocks + dense S)"
+
+struct HipSchurComplementKKTSystem{T, VT, MT, QN, K <: MadNLP.SchurComplementKKTSystem{T, VT, MT, QN}} <:
+       AbstractCondensedKKTSystem{T, VT, MT, QN}
+    inner::K                       # the reference system: buffers, maps, host-side algebra
+    stage::HipSchurStage
+    linear_solver::HipSchurDesignSolver{T}
+    Akk_dense::Matrix{T}           # blk x blk staging of one scenario block
+    S0::Matrix{T}                  # nd x nd: the design block before the Schur products
+    rhs_all::Matrix{T}             # blk x ns: the scenarios' right-hand sides, column k = scenario k
+end
+# every field the generic IPM code reads by name (KKTsystem.jl:210-234, kernels.jl) lives in the reference system
+function Base.getproperty(kkt::HipSchurComplementKKTSystem, f::Symbol)
+    f in (:inner, :stage, :linear_solver, :Akk_dense, :S0, :rhs_all) && return getfield(kkt, f)
+    return getproperty(getfield(kkt, :inner), f)
+end
+
+function MadNLP.create_kkt_system(
+    ::Type{HipSchurComplementKKTSystem}, cb::SparseCallback{T, VT}, linear_solver::Type;
+    opt_linear_solver = default_options(linear_solver), hessian_approximation = ExactHessian, qn_options = QuasiNewtonOptions(),
+    schur_ns::Int = 0, schur_nv::Int = 0, schur_nd::Int = 0, schur_nc::Int = 0, device::Integer = 0,
+) where {T <: Float64, VT <: Vector{T}}
+    inner = MadNLP.create_kkt_system(MadNLP.SchurComplementKKTSystem, cb, MadNLP.LapackCPUSolver;
+                                     hessian_approximation = hessian_approximation, qn_options = qn_options,
+                                     schur_ns = schur_ns, schur_nv = schur_nv, schur_nd = schur_nd, schur_nc = schur_nc,
+                                     schur_scenario_linear_solver = HipNoScenarioSolver)
+    ctx = HipContext(device)
+    alg = hasproperty(opt_linear_solver, :lapack_algorithm) ? opt_linear_solver.lapack_algorithm : BUNCHKAUFMAN
+    stage = HipSchurStage(inner.ns, inner.blk_size, inner.nd; ctx = ctx, lapack_algorithm = alg)
+    Sdev = Ptr{Cdouble}(ccall((:mnk_schur_s_buffer, libmadnlp_hip), Ptr{Cvoid}, (Ptr{Cvoid},), stage.handle))
+    Sdev == C_NULL && throw(SymbolicException())
+    return HipSchurComplementKKTSystem(inner, stage, HipSchurDesignSolver{T}(stage, Sdev), zeros(T, inner.blk_size, inner.blk_size),
+                                       zeros(T, inner.nd, inner.nd), zeros(T, inner.blk_size, inner.ns))
+end
+
+MadNLP.num_variables(kkt::HipSchurComplementKKTSystem) = MadNLP.num_variables(kkt.inner)
+MadNLP.get_slack_regularization(kkt::HipSchurComplementKKTSystem) = MadNLP.get_slack_regularization(kkt.inner)
+MadNLP.is_inertia_correct(kkt::HipSchurComplementKKTSystem, num_pos, num_zero, num_neg) =
+    (num_zero == 0) && (num_pos == kkt.inner.nd)                                          # schur.jl:901-903
+MadNLP.should_regularize_dual(::HipSchurComplementKKTSystem, num_pos, num_zero, num_neg) = true   # :905
+MadNLP.jtprod!(y::AbstractVector, kkt::HipSchurComplementKKTSystem, x::AbstractVector) = MadNLP.jtprod!(y, kkt.inner, x)
+MadNLP.compress_jacobian!(kkt::HipSchurComplementKKTSystem) = MadNLP.compress_jacobian!(kkt.inner)
+MadNLP.compress_hessian!(kkt::HipSchurComplementKKTSystem) = MadNLP.compress_hessian!(kkt.inner)
+MadNLP.nnz_jacobian(kkt::HipSchurComplementKKTSystem) = MadNLP.nnz_jacobian(kkt.inner)
+MadNLP.get_jacobian(kkt::HipSchurComplementKKTSystem) = kkt.inner.jac
+MadNLP.get_hessian(kkt::HipSchurComplementKKTSystem) = kkt.inner.hess
+MadNLP.initialize!(kkt::HipSchurComplementKKTSystem) = MadNLP.initialize!(kkt.inner)
+Base.size(kkt::HipSchurComplementKKTSystem, n::Int) = kkt.inner.nd
+mul!(w::AbstractKKTVector{T}, kkt::HipSchurComplementKKTSystem, x::AbstractKKTVector, alpha = one(T), beta = zero(T)) where T =
+    mul!(w, kkt.inner, x, alpha, beta)
+MadNLP.mul_hess_blk!(wx, kkt::HipSchurComplementKKTSystem, t) = MadNLP.mul_hess_blk!(wx, kkt.inner, t)
+
+# build_kkt! (schur.jl:927-1001): the reference's scatter of the callback values into A_kk / C_dk / S, then the device stage
+function MadNLP.build_kkt!(kkt::HipSchurComplementKKTSystem{T}) where T
+    k0 = kkt.inner
+    ns, nv, nd, n = k0.ns, k0.nv, k0.nd, MadNLP.num_variables(k0)
+    if k0.n_ineq > 0
+        Sigma_s = view(k0.pr_diag, n+1:n+k0.n_ineq)
+        Sigma_d = @view(k0.du_diag[k0.ind_ineq])
+        k0.diag_buffer .= Sigma_s ./ (one(T) .- Sigma_d .* Sigma_s)
+    end
+    S0 = kkt.S0
+    fill!(S0, zero(T))
+    MadNLP._scatter_add!(S0, k0.hess, k0.hess_S_coo, k0.hess_S_row, k0.hess_S_col)
+    @inbounds for i in 1:nd
+        S0[i, i] += k0.pr_diag[ns*nv+i]
+    end
+    Ad = kkt.Akk_dense
+    for k in 1:ns
+        bm = k0.block_maps[k]
+        A_kk = k0.A_kk[k]; C_dk = k0.C_dk[k]; nz = A_kk.nzval
+        fill!(nz, zero(T)); fill!(C_dk, zero(T))
+        MadNLP._scatter_add!(nz,   k0.hess,    bm.hess_Akk_coo,   bm.hess_Akk_nzpos)
+        MadNLP._scatter_add!(C_dk, k0.hess,    bm.hess_Cdk_coo,   bm.hess_Cdk_row, bm.hess_Cdk_col)
+        MadNLP._scatter_add!(nz,   k0.pr_diag, bm.pr_diag_global, bm.pr_diag_nzpos)
+        MadNLP._scatter_add!(nz,   k0.du_diag, bm.du_diag_global, bm.du_diag_nzpos)
+        MadNLP._scatter_add!(nz,   k0.jac,     bm.jeq_Akk_coo,    bm.jeq_Akk_nzpos)
+        MadNLP._scatter_add!(C_dk, k0.jac,     bm.jeq_Cdk_coo,    bm.jeq_Cdk_row, bm.jeq_Cdk_col)
+        MadNLP._scatter_quad_add!(nz,   k0.jac, k0.diag_buffer, bm.ineq_Akk_nzpos, bm.ineq_Akk_jcoo1, bm.ineq_Akk_jcoo2, bm.ineq_Akk_bufidx)
+        MadNLP._scatter_quad_add!(C_dk, k0.jac, k0.diag_buffer, bm.ineq_Cdk_row, bm.ineq_Cdk_col, bm.ineq_Cdk_jcoo_d, bm.ineq_Cdk_jcoo_v,
+                                  bm.ineq_Cdk_bufidx)
+        MadNLP._scatter_quad_add!(S0,   k0.jac, k0.diag_buffer, bm.ineq_S_row, bm.ineq_S_col, bm.ineq_S_jcoo1, bm.ineq_S_jcoo2, bm.ineq_S_bufidx)
+        # the lower-triangular sparse block as a dense one (the stage reads the lower triangle)
+        fill!(Ad, zero(T))
+        @inbounds for j in 1:size(A_kk, 2), p in A_kk.colptr[j]:(A_kk.colptr[j+1]-1)
+            Ad[A_kk.rowval[p], j] = nz[p]
+        end
+        set_block!(kkt.stage, k - 1, Ad, C_dk)
+    end
+    build_local!(kkt.stage, S0, kkt.linear_solver.S)      # blocks factored as one batch, S = S0 - sum_k C_dk A_k^-1 C_dk'
+    return
+end
+
+MadNLP.factorize_kkt!(kkt::HipSchurComplementKKTSystem) = MadNLP.factorize!(kkt.linear_solver)
+
+# solve_kkt! (schur.jl:1040-1110): the reference's steps 1-2 and 6-7 on the host, steps 3-5 in one device call
+function MadNLP.solve_kkt!(kkt::HipSchurComplementKKTSystem, w::AbstractKKTVector{T}) where T
+    k0 = kkt.inner
+    ns, nv, nd, n, blk, nc_eq = k0.ns, k0.nv, k0.nd, MadNLP.num_variables(k0), k0.blk_size, k0.nc_eq_per_s
+    wx = view(full(w), 1:n)
+    ws = view(full(w), n+1:n+k0.n_ineq)
+    wy = dual(w)
+    Sigma_s = MadNLP.get_slack_regularization(k0)
+    MadNLP.reduce_rhs!(k0, w)
+    fill!(k0.buffer, zero(T))
+    if k0.n_ineq > 0
+        k0.buffer[k0.ind_ineq] .= k0.diag_buffer .* (wy[k0.ind_ineq] .+ ws ./ Sigma_s)
+        mul!(wx, k0.jt_csc, k0.buffer, one(T), one(T))
+    end
+    R = kkt.rhs_all
+    @inbounds for k in 1:ns
+        for i in 1:nv
+            R[i, k] = wx[(k-1)*nv + i]
+        end
+        for ci in 1:nc_eq
+            R[nv+ci, k] = wy[k0.eq_global_indices[(k-1)*nc_eq + ci]]
+        end
+    end
+    @inbounds for i in 1:nd
+        k0.rhs_d[i] = wx[ns*nv+i]
+    end
+    rc = ccall((:mnk_schur_solve, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+               kkt.stage.handle, R, k0.rhs_d, MNK_HOST)
+    check(rc, SolveException)
+    @inbounds for k in 1:ns
+        for i in 1:nv
+            wx[(k-1)*nv + i] = R[i, k]
+        end
+        for ci in 1:nc_eq
+            wy[k0.eq_global_indices[(k-1)*nc_eq + ci]] = R[nv+ci, k]
+        end
+    end
+    @inbounds for i in 1:nd
+        wx[ns*nv+i] = k0.rhs_d[i]
+    end
+    if k0.n_ineq > 0
+        copyto!(k0.wy_eq_buf, view(wy, k0.ind_eq))
+        mul!(wy, k0.jt_csc', wx)
+        view(wy, k0.ind_eq) .= k0.wy_eq_buf
+        @inbounds for idx in 1:length(k0.ind_ineq)
+            gi = k0.ind_ineq[idx]
+            wy[gi] = k0.diag_buffer[idx] * wy[gi] - k0.buffer[gi]
+        end
+        ws .= (ws .+ view(wy, k0.ind_ineq)) ./ Sigma_s
+    end
+    MadNLP.finish_aug_solve!(k0, w)
+    return w
+end
+
 end # module

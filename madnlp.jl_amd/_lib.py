@@ -206,6 +206,8 @@ SIGNATURES = {
     "mnk_schur_forward": (C.c_int, [_vp, _vp, _vp]),
     "mnk_schur_solve_s": (C.c_int, [_vp, _vp]),
     "mnk_schur_backward": (C.c_int, [_vp, _vp, _vp]),
+    "mnk_schur_s_buffer": (C.c_void_p, [_vp]),
+    "mnk_schur_solve": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mnk_ls_debug_solve_trace": (C.c_int, [_vp, _vp, C.c_int64]),
     "mnk_ls_debug_dag_state": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "mnk_debug_grid_at_launch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -42,6 +42,8 @@ struct mnk_schur {
     mnk::DevBuf<double> Xall, Vall, Pall;   // ns x (ndp x Npb) | the same (LDL^T only) | ns x (ndp x ndp)
     mnk::DevBuf<char> recs;                 // device copies of the launch records
     mnk::DevBuf<int> fast_k;                // the scenarios on the grouped path
+    mnk::DevBuf<double> Sown;               // nd x nd: the handle's own copy of S (mnk_schur_s_buffer: callers without device memory of their own)
+    mnk::DevBuf<double> hostrk, hostrd;     // mnk_schur_solve with host vectors: ns x blk | 2 nd (right-hand side, contribution)
 };
 
 namespace mnk {
@@ -119,6 +121,12 @@ __global__ __launch_bounds__(256) void schur_gemv_t_batch_kernel(double* __restr
 __global__ void schur_sub_batch_kernel(double* __restrict__ y, int64_t blk, const double* __restrict__ tmp, int64_t stride) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, k = blockIdx.y;
     if (i < blk) y[k * blk + i] -= tmp[k * stride + i];
+}
+
+// y += x (the design right-hand side receives the scenarios' contribution)
+__global__ void schur_axpy_kernel(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i];
 }
 
 }  // namespace mnk
@@ -387,6 +395,48 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
                            h->tmpk.p, h->Npb);
     MNK_HIP(hipGetLastError());
     return schur_check_solves(h, true, false);
+}
+
+// A device buffer of nd x nd doubles owned by the handle: `S_out` of mnk_schur_build_local and `S` of mnk_schur_factorize_s for
+// callers that keep no device memory themselves (the Julia glue's host-driven KKT system, julia/MadNLPHIP.jl).
+void* mnk_schur_s_buffer(mnk_schur* h) {
+    if (!h) return nullptr;
+    (void)hipSetDevice(h->ctx->device);
+    if (!h->Sown.p && h->Sown.alloc((size_t)h->nd * h->nd + 8)) { (void)hipGetLastError(); return nullptr; }
+    return h->Sown.p;
+}
+
+// Steps 3-5 of solve_kkt! in one call on ONE rank (reference :1078-1092): rhs_k (ns x blk, scenario k's vector at k * blk) and
+// rhs_d (nd) are overwritten with the solution; host or device vectors.  (Several ranks: forward / all-reduce / solve_s /
+// backward separately, as above.)
+int mnk_schur_solve(mnk_schur* h, double* rhs_k, double* rhs_d, int loc) {
+    MNK_REQUIRE(h && rhs_d && (rhs_k || h->ns == 0), "mnk_schur_solve: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    const size_t nk = (size_t)h->ns * h->blk;
+    if (!h->hostrd.p && h->hostrd.alloc(2 * (size_t)h->nd + 8)) return -2;
+    double* rk = rhs_k;
+    double* rd = rhs_d;
+    double* contrib = h->hostrd.p + h->nd;
+    if (loc != MNK_DEVICE) {
+        if (nk > 0 && !h->hostrk.p && h->hostrk.alloc(nk + 8)) return -2;
+        rk = h->hostrk.p;
+        rd = h->hostrd.p;
+        if (nk > 0) MNK_HIP(mnk::h2d_copy(rk, rhs_k, nk * sizeof(double), s));
+        MNK_HIP(mnk::h2d_copy(rd, rhs_d, (size_t)h->nd * sizeof(double), s));
+    }
+    int rc = mnk_schur_forward(h, rk, contrib);
+    if (rc) return rc;
+    hipLaunchKernelGGL(schur_axpy_kernel, dim3((unsigned)((h->nd + 255) / 256)), dim3(256), 0, s, rd, contrib, h->nd);
+    MNK_HIP(hipGetLastError());
+    rc = mnk_schur_solve_s(h, rd);
+    if (!rc) rc = mnk_schur_backward(h, rk, rd);
+    if (rc) return rc;
+    if (loc != MNK_DEVICE) {
+        if (nk > 0) MNK_HIP(mnk::d2h_copy(rhs_k, rk, nk * sizeof(double), s));
+        MNK_HIP(mnk::d2h_copy(rhs_d, rd, (size_t)h->nd * sizeof(double), s));
+    }
+    return 0;
 }
 
 #undef MNK_GRID1

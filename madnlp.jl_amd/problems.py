@@ -708,3 +708,89 @@ class ACOPFModel:
         out.append(2.0 * gs * y[o:o + nbus] - 2.0 * bs * y[o + nbus:o + 2 * nbus])
         out.append(w * 2.0 * self.gen_cost[:, 0])
         return np.concatenate(out)
+
+
+class TwoStageQPModel:
+    """Diagonal-Hessian two-stage stochastic QP -- the reference's `TwoStageQP` / `build_twostage_qp`
+    (lib/MadNLPTests/src/Instances/twostage_qp.jl:1-175), the instance its `SchurComplementKKTSystem` tests run on
+    (test/schur_test.jl).  Variables `x = [v_1 .. v_ns (nv each), d (nd)]`, constraints `c = [c_1 .. c_ns (nc each)]`,
+    `min 0.5 x' diag(H) x + g' x  s.t.  lcon <= A x <= ucon, lvar <= x <= uvar`; constraint row i of scenario k touches the
+    scenario's own variables and the design variables only (the block-arrow structure the Schur system needs).
+    Argument shapes as in the reference, with the scenario index LAST: hess_v, g_v, lvar_v, uvar_v (nv, ns); hess_d, g_d,
+    lvar_d, uvar_d (nd,); A_v (nc, nv, ns); A_d (nc, nd, ns); lcon, ucon (nc, ns)."""
+
+    def __init__(self, ns, nv, nd, nc, hess_v, hess_d, g_v, g_d, A_v, A_d, lcon, ucon, lvar_v, uvar_v, lvar_d, uvar_d):
+        f = lambda a, shape: np.asarray(a, dtype=float).reshape(shape)  # noqa: E731
+        hess_v, g_v, lvar_v, uvar_v = (f(a, (nv, ns)) for a in (hess_v, g_v, lvar_v, uvar_v))
+        hess_d, g_d, lvar_d, uvar_d = (f(a, (nd,)) for a in (hess_d, g_d, lvar_d, uvar_d))
+        A_v, A_d = f(A_v, (nc, nv, ns)), f(A_d, (nc, nd, ns))
+        lcon, ucon = f(lcon, (nc, ns)), f(ucon, (nc, ns))
+        self.ns, self.nv, self.nd, self.nc = ns, nv, nd, nc
+        n, m, off = ns * nv + nd, ns * nc, ns * nv
+        self.n, self.m = n, m
+        # (column-major flattening of the (j, k) arrays = scenario-major vectors)
+        self.H_diag = np.concatenate((hess_v.T.ravel(), hess_d))
+        self.g0 = np.concatenate((g_v.T.ravel(), g_d))
+        self.lvar = np.concatenate((lvar_v.T.ravel(), lvar_d))
+        self.uvar = np.concatenate((uvar_v.T.ravel(), uvar_d))
+        self.lcon, self.ucon = lcon.T.ravel().copy(), ucon.T.ravel().copy()
+        A = np.zeros((m, n))
+        rows, cols = [], []
+        for k in range(ns):
+            for i in range(nc):
+                r = k * nc + i
+                A[r, k * nv:(k + 1) * nv] = A_v[i, :, k]
+                A[r, off:] = A_d[i, :, k]
+                rows += [r] * (nv + nd)
+                cols += list(range(k * nv, (k + 1) * nv)) + list(range(off, n))
+        self.A = A
+        self.jac_I, self.jac_J = np.array(rows, dtype=np.int64), np.array(cols, dtype=np.int64)
+        self.jvals = A[self.jac_I, self.jac_J]
+        self.hess_I = self.hess_J = np.arange(n, dtype=np.int64)
+        self.x0, self.y0 = np.zeros(n), np.zeros(m)
+
+    def schur_opts(self):
+        """the reference's `schur_opts(; ns, nv, nd, nc)` (twostage_qp.jl:189-191)."""
+        return dict(ns=self.ns, nv=self.nv, nd=self.nd, nc=self.nc)
+
+    def obj(self, x):
+        return 0.5 * x @ (self.H_diag * x) + self.g0 @ x
+
+    def grad(self, x):
+        return self.H_diag * x + self.g0
+
+    def cons(self, x):
+        return self.A @ x
+
+    def jac_coord(self, x):
+        return self.jvals
+
+    def jac_dense(self, x):
+        return self.A
+
+    def hess_coord(self, x, y, w=1.0):
+        return w * self.H_diag
+
+    def hess_dense(self, x, y, w=1.0):
+        return w * np.diag(self.H_diag)
+
+
+def random_twostage_qp(ns=8, nv=40, nd=12, nc=10, nc_eq=4, seed=0):
+    """A larger `TwoStageQPModel` with the first `nc_eq` constraints of every scenario equalities and the rest two-sided
+    inequalities around a strictly feasible point (so that both kinds of rows of the Schur system's blocks are exercised)."""
+    rng = np.random.default_rng(seed)
+    hess_v = rng.uniform(0.5, 4.0, (nv, ns))
+    hess_d = rng.uniform(0.5, 4.0, nd)
+    g_v, g_d = rng.standard_normal((nv, ns)), rng.standard_normal(nd)
+    A_v = rng.standard_normal((nc, nv, ns)) * (rng.random((nc, nv, ns)) < 0.4)
+    for k in range(ns):                       # full row rank of the equality rows
+        for i in range(nc):
+            A_v[i, (3 * i + k) % nv, k] += 2.0
+    A_d = rng.standard_normal((nc, nd, ns)) * 0.5
+    xs_v, xs_d = rng.uniform(-0.5, 0.5, (nv, ns)), rng.uniform(-0.5, 0.5, nd)
+    c = np.einsum("ijk,jk->ik", A_v, xs_v) + np.einsum("ijk,j->ik", A_d, xs_d)
+    lcon, ucon = c - rng.uniform(0.2, 1.0, (nc, ns)), c + rng.uniform(0.2, 1.0, (nc, ns))
+    lcon[:nc_eq], ucon[:nc_eq] = c[:nc_eq], c[:nc_eq]
+    return TwoStageQPModel(ns, nv, nd, nc, hess_v, hess_d, g_v, g_d, A_v, A_d, lcon, ucon,
+                           xs_v - rng.uniform(1, 3, (nv, ns)), xs_v + rng.uniform(1, 3, (nv, ns)),
+                           xs_d - rng.uniform(1, 3, nd), xs_d + rng.uniform(1, 3, nd))

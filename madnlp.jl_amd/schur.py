@@ -33,16 +33,26 @@ class SchurDenseStage:
         self._h = C.c_void_p()
         L.check(L.lib().mnk_schur_create(self.ctx.handle, self.ns, self.blk, self.nd, _ALGO[algorithm], C.byref(self._h)),
                 "mnk_schur_create")
-        for k in range(self.ns):
-            a = np.asfortranarray(A[k], dtype=np.float64)
-            c = np.asfortranarray(C_dk[k], dtype=np.float64)
-            L.check(L.lib().mnk_schur_set_block(self._h, k, a.ctypes.data, self.blk, c.ctypes.data, self.nd, L.MNK_HOST),
-                    "mnk_schur_set_block")
-        self.S0 = None if S0 is None else np.asfortranarray(S0, dtype=np.float64)
+        self.S0 = None
+        self.set_blocks(A, C_dk, S0)
         dev = torch.device("cuda", self.ctx.device)
         self.S = torch.zeros(self.nd * self.nd, dtype=torch.float64, device=dev)   # column-major nd x nd
         self._contrib = torch.zeros(self.nd, dtype=torch.float64, device=dev)
         _LIVE_OBJECTS.add(self)
+
+    def set_blocks(self, A, C_dk, S0):
+        """New values of the scenario blocks (`build_kkt!` assembles them every iteration: reference :955-972) and of the design
+        block; entries of `A` / `C_dk` that are None keep their block."""
+        assert len(A) == self.ns and len(C_dk) == self.ns
+        for k in range(self.ns):
+            if A[k] is None:
+                continue
+            a = np.asfortranarray(A[k], dtype=np.float64)
+            c = np.asfortranarray(C_dk[k], dtype=np.float64)
+            assert a.shape == (self.blk, self.blk) and c.shape == (self.nd, self.blk)
+            L.check(L.lib().mnk_schur_set_block(self._h, k, a.ctypes.data, self.blk, c.ctypes.data, self.nd, L.MNK_HOST),
+                    "mnk_schur_set_block")
+        self.S0 = None if S0 is None else np.asfortranarray(S0, dtype=np.float64)
 
     def _allreduce(self, t):
         if self.dist is not None:
@@ -94,6 +104,14 @@ class SchurDenseStage:
         if L.lib().mnk_schur_solve_s(self._h, rhs_d.data_ptr()) or L.lib().mnk_schur_backward(self._h, rk, rhs_d.data_ptr()):
             raise SolveException(L.lib().mnk_last_error_string().decode())
         self.ctx.synchronize()
+        return rhs_k, rhs_d
+
+    def solve_host(self, rhs_k, rhs_d):
+        """Steps 3-5 on ONE rank with host vectors (`mnk_schur_solve`): rhs_k (ns, blk) C-contiguous, rhs_d (nd), in place."""
+        assert self.dist is None and rhs_k.flags.c_contiguous and rhs_d.flags.c_contiguous
+        rc = L.lib().mnk_schur_solve(self._h, rhs_k.ctypes.data if self.ns else None, rhs_d.ctypes.data, L.MNK_HOST)
+        if rc:
+            raise SolveException(L.lib().mnk_last_error_string().decode())
         return rhs_k, rhs_d
 
     def close(self):

@@ -1,0 +1,230 @@
+"""`SchurComplementKKTSystem` (reference `src/KKT/Schur/schur.jl`) driven by the interior-point loop on the reference's own
+two-stage instance (`TwoStageQP`, lib/MadNLPTests/src/Instances/twostage_qp.jl) -- VERDICT r4 "missing" 1.
+
+CPU: the ORACLE restatement (`oracle/schur_kkt.py`) is pinned to the answers the reference's tests hold
+(`/root/reference/test/schur_test.jl`): the analytic optimum of the coupled quadratic (:10-41), agreement with the monolithic
+formulation on the same QP (:43-80: objective 1e-6, solution 1e-4), convergence with several recourse / design variables
+(:82-108), the inactive-constraint solution (:110-139); the layout checks of the product's symbolic phase reject what the
+reference rejects (:176-236).
+GPU: the HIP system (`madnlp_jl_amd.schur_kkt`: host assembly of the blocks, factorizations / Schur products / solves in the
+`S` stage of csrc/schur.hip) on the same instances and on a larger random two-stage QP with equality AND inequality rows,
+against the oracle system and against the dense-condensed HIP formulation of the same QP: same iteration count, objective
+1e-8 relative, solution 1e-6 (fp64; the three formulations solve the same Newton systems to Richardson's tolerance)."""
+import numpy as np
+import pytest
+
+from madnlp_jl_amd.ipm import IPMOptions, MadNLPSolver
+from madnlp_jl_amd.problems import TwoStageQPModel, random_twostage_qp
+from oracle.dense import DenseCondensedKKTSystem as OracleDenseCondensed
+from oracle.lapack_cpu import BUNCHKAUFMAN, LapackCPUSolver
+from oracle.schur_kkt import SchurComplementKKTSystem as OracleSchur
+
+
+def coupled_quadratic(theta, d_target=1.0, lcon=0.0, ucon=0.0, bound=100.0):
+    """min sum_k (v_k - theta_k)^2 + (d - d_target)^2  s.t.  lcon <= v_k + d <= ucon  (schur_test.jl:10-26, :110-127)."""
+    ns = len(theta)
+    return TwoStageQPModel(ns, 1, 1, 1, hess_v=np.full((1, ns), 2.0), hess_d=[2.0], g_v=-2.0 * np.asarray(theta, float).reshape(1, ns),
+                           g_d=[-2.0 * d_target], A_v=np.ones((1, 1, ns)), A_d=np.ones((1, 1, ns)), lcon=np.full((1, ns), lcon),
+                           ucon=np.full((1, ns), ucon), lvar_v=np.full((1, ns), -bound), uvar_v=np.full((1, ns), bound),
+                           lvar_d=[-bound], uvar_d=[bound])
+
+
+def two_by_two():
+    """min sum_{k,j} (v_{k,j} - theta_{j,k})^2 + d^2  s.t.  v_{k,1} + v_{k,2} + d = 0  (schur_test.jl:43-66)."""
+    theta = np.array([[1.0, 3.0], [2.0, 4.0]])
+    return TwoStageQPModel(2, 2, 1, 1, hess_v=np.full((2, 2), 2.0), hess_d=[2.0], g_v=-2.0 * theta, g_d=[0.0], A_v=np.ones((1, 2, 2)),
+                           A_d=np.ones((1, 1, 2)), lcon=np.zeros((1, 2)), ucon=np.zeros((1, 2)), lvar_v=np.full((2, 2), -50.0),
+                           uvar_v=np.full((2, 2), 50.0), lvar_d=[-50.0], uvar_d=[50.0])
+
+
+def several_recourse_and_design():
+    """min sum_{k,j} theta_k v_{k,j}^2 + sum_j d_j^2  s.t.  v_{k,1} + v_{k,2} + d_1 + d_2 = 1  (schur_test.jl:82-108)."""
+    H_v = np.array([[2.0, 4.0], [2.0, 4.0]])
+    return TwoStageQPModel(2, 2, 2, 1, hess_v=H_v, hess_d=[2.0, 2.0], g_v=np.zeros((2, 2)), g_d=np.zeros(2), A_v=np.ones((1, 2, 2)),
+                           A_d=np.ones((1, 2, 2)), lcon=np.ones((1, 2)), ucon=np.ones((1, 2)), lvar_v=np.full((2, 2), -50.0),
+                           uvar_v=np.full((2, 2), 50.0), lvar_d=[-50.0, -50.0], uvar_d=[50.0, 50.0])
+
+
+def oracle_schur(nlp):
+    def make(info):
+        return OracleSchur(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J, info["ind_ineq"], info["ind_eq"],
+                           info["ind_lb"], info["ind_ub"], **nlp.schur_opts())
+    return make
+
+
+def oracle_dense_condensed(nlp):
+    def make(info):
+        return OracleDenseCondensed(info["n"], info["m"], info["ind_ineq"], info["ind_eq"], info["ind_lb"], info["ind_ub"],
+                                    lambda A: LapackCPUSolver(A, BUNCHKAUFMAN))
+    return make
+
+
+def solve(nlp, factory, sparse=True, **kw):
+    s = MadNLPSolver(nlp, factory, IPMOptions(**kw), sparse=sparse)
+    s.solve()
+    return s
+
+
+# --------------------------------------------------------------------------- CPU: the oracle against the reference's answers
+def test_oracle_schur_reaches_the_analytic_optimum_of_the_coupled_quadratic():
+    theta = [4.0, 6.0, 8.0]
+    s = solve(coupled_quadratic(theta), oracle_schur(coupled_quadratic(theta)))
+    assert s.status == "SOLVE_SUCCEEDED"
+    d_star = (1.0 - sum(theta)) / (len(theta) + 1)          # schur_test.jl:37
+    assert abs(s.x[3] - d_star) <= 1e-3 and np.abs(s.x[:3] + d_star).max() <= 1e-3
+
+
+def test_oracle_schur_matches_the_monolithic_formulation():
+    nlp = two_by_two()
+    ref = solve(nlp, oracle_dense_condensed(nlp), sparse=False)
+    sch = solve(nlp, oracle_schur(nlp))
+    assert ref.status == sch.status == "SOLVE_SUCCEEDED"
+    assert abs(sch.obj_val - ref.obj_val) <= 1e-6                      # schur_test.jl:78-79
+    assert np.abs(sch.x[:nlp.n] - ref.x[:nlp.n]).max() <= 1e-4
+    assert sch.cnt.k == ref.cnt.k
+
+
+def test_oracle_schur_with_several_recourse_and_design_variables():
+    nlp = several_recourse_and_design()
+    s = solve(nlp, oracle_schur(nlp))
+    assert s.status == "SOLVE_SUCCEEDED"
+    assert np.abs(nlp.cons(s.x[:nlp.n]) - 1.0).max() <= 1e-6
+
+
+def test_oracle_schur_with_inactive_inequalities():
+    theta = [3.0, 7.0]
+    nlp = coupled_quadratic(theta, d_target=5.0, lcon=-100.0, ucon=100.0)
+    s = solve(nlp, oracle_schur(nlp))
+    assert s.status == "SOLVE_SUCCEEDED"
+    assert np.abs(s.x[:3] - np.array([3.0, 7.0, 5.0])).max() <= 1e-3   # schur_test.jl:136-138
+
+
+def test_oracle_schur_equals_dense_condensed_on_a_random_two_stage_qp():
+    nlp = random_twostage_qp(ns=3, nv=6, nd=3, nc=4, nc_eq=2, seed=4)
+    ref = solve(nlp, oracle_dense_condensed(nlp), sparse=False)
+    sch = solve(nlp, oracle_schur(nlp))
+    assert ref.status == sch.status == "SOLVE_SUCCEEDED"
+    assert sch.cnt.k == ref.cnt.k
+    assert abs(sch.obj_val - ref.obj_val) <= 1e-8 * max(1.0, abs(ref.obj_val))
+    assert np.abs(sch.x[:nlp.n] - ref.x[:nlp.n]).max() <= 1e-6
+
+
+def test_schur_layout_validation_rejects_what_the_reference_rejects():
+    """schur_test.jl:176-236 (0-based here)."""
+    from madnlp_jl_amd.schur_kkt import build_schur_symbolic
+    ns, nv, nd, nc = 2, 1, 1, 1
+    n, m = ns * nv + nd, ns * nc
+    hI, hJ = [0, 1, 2], [0, 1, 2]
+    jI, jJ = [0, 0, 1, 1], [0, 2, 1, 2]
+    ok = build_schur_symbolic(n, m, ns, nv, nd, nc, hI, hJ, jI, jJ, [0, 1], [])
+    assert ok["nc_eq"] == 1 and ok["nc_ineq"] == 0
+    with pytest.raises(ValueError):     # cross-scenario Hessian coupling
+        build_schur_symbolic(n, m, ns, nv, nd, nc, [0, 1, 2, 1], [0, 1, 2, 0], jI, jJ, [0, 1], [])
+    with pytest.raises(ValueError):     # c_1 reaches v_2
+        build_schur_symbolic(n, m, ns, nv, nd, nc, hI, hJ, [0, 0, 0, 1, 1], [0, 1, 2, 1, 2], [0, 1], [])
+    with pytest.raises(ValueError):     # c_1 equality, c_2 inequality
+        build_schur_symbolic(n, m, ns, nv, nd, nc, hI, hJ, jI, jJ, [0], [1])
+    with pytest.raises(ValueError):     # scenario 2 has an off-diagonal Hessian entry scenario 1 lacks (nv = 2)
+        build_schur_symbolic(5, 2, 2, 2, 1, 1, [0, 1, 2, 3, 3, 4], [0, 1, 2, 3, 2, 4], [0, 0, 0, 1, 1, 1], [0, 1, 4, 2, 3, 4], [0, 1], [])
+    with pytest.raises(ValueError):     # sizes that do not match the layout
+        build_schur_symbolic(n + 1, m, ns, nv, nd, nc, hI, hJ, jI, jJ, [0, 1], [])
+
+
+# --------------------------------------------------------------------------- GPU: the HIP system
+def hip_schur(nlp, ctx):
+    import madnlp_jl_amd as mj
+    from madnlp_jl_amd.schur_kkt import SchurComplementKKTSystem
+
+    def make(info):
+        return SchurComplementKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J, info["ind_ineq"],
+                                        info["ind_eq"], info["ind_lb"], info["ind_ub"], ctx=ctx, **nlp.schur_opts())
+    return make
+
+
+def hip_dense_condensed(nlp, ctx):
+    import madnlp_jl_amd as mj
+
+    def make(info):
+        return mj.DenseCondensedKKTSystem(info["n"], info["m"], info["ind_ineq"], info["ind_eq"], info["ind_lb"], info["ind_ub"], ctx=ctx,
+                                          opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+    return make
+
+
+@pytest.fixture(scope="module")
+def gctx():
+    torch = pytest.importorskip("torch")
+    import madnlp_jl_amd as mj
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    c = mj.HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_hip_schur_blocks_equal_the_oracle_blocks(gctx):
+    """`build_kkt!` piece by piece: the scenario blocks, the coupling blocks and the Schur complement of one assembled system
+    with equality and inequality rows, HIP system vs the oracle's entry-by-entry scatter (blocks 1e-13 relative -- two
+    summation orders of the condensation terms --, S 1e-11 relative: two factorizations of indefinite blocks)."""
+    nlp = random_twostage_qp(ns=4, nv=20, nd=6, nc=7, nc_eq=3, seed=11)
+    so = MadNLPSolver(nlp, oracle_schur(nlp), IPMOptions(), sparse=True)
+    sh = MadNLPSolver(nlp, hip_schur(nlp, gctx), IPMOptions(), sparse=True)
+    for s in (so, sh):
+        s.initialize()
+        s.set_aug_diagonal() if hasattr(s, "set_aug_diagonal") else None
+        s.kkt.build_kkt()
+    A, Cd, S0 = sh.kkt.assemble_blocks()
+    for k in range(nlp.ns):
+        assert np.abs(A[k] - so.kkt.A_kk[k]).max() <= 1e-13 * np.abs(so.kkt.A_kk[k]).max()
+        assert np.abs(Cd[k] - so.kkt.C_dk[k]).max() <= 1e-13 * max(1.0, np.abs(so.kkt.C_dk[k]).max())
+    S_h = sh.kkt.aug_com.cpu().numpy().reshape((nlp.nd, nlp.nd), order="F")
+    assert np.abs(S_h - so.kkt.aug_com).max() <= 1e-11 * np.abs(so.kkt.aug_com).max()
+    sh.kkt.factorize_kkt(); so.kkt.factorize_kkt()
+    assert sh.kkt.linear_solver.inertia() == tuple(so.kkt.linear_solver.inertia()) == (nlp.nd, 0, 0)
+    # one solve_kkt! of the same right-hand side
+    rng = np.random.default_rng(2)
+    wo, wh = so.d.copy(), sh.d.copy()
+    wo.values[:] = rng.standard_normal(wo.values.shape)
+    wh.values[:] = wo.values
+    so.kkt.solve_kkt(wo); sh.kkt.solve_kkt(wh)
+    assert np.abs(wh.values - wo.values).max() <= 1e-9 * np.abs(wo.values).max()
+    sh.kkt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["coupled", "two_by_two", "several", "inactive"])
+def test_hip_schur_on_the_reference_instances(gctx, which):
+    """The reference's four `SchurComplementKKTSystem` runs (test/schur_test.jl) through the HIP system: status, the known
+    solutions, and the oracle system's iteration count and solution."""
+    nlp = {"coupled": lambda: coupled_quadratic([4.0, 6.0, 8.0]), "two_by_two": two_by_two, "several": several_recourse_and_design,
+           "inactive": lambda: coupled_quadratic([3.0, 7.0], d_target=5.0, lcon=-100.0, ucon=100.0)}[which]()
+    so = solve(nlp, oracle_schur(nlp))
+    sh = solve(nlp, hip_schur(nlp, gctx))
+    assert sh.status == so.status == "SOLVE_SUCCEEDED"
+    assert sh.cnt.k == so.cnt.k
+    assert np.abs(sh.x[:nlp.n] - so.x[:nlp.n]).max() <= 1e-6
+    if which == "coupled":
+        d_star = (1.0 - 18.0) / 4.0
+        assert abs(sh.x[3] - d_star) <= 1e-3 and np.abs(sh.x[:3] + d_star).max() <= 1e-3
+    if which == "inactive":
+        assert np.abs(sh.x[:3] - np.array([3.0, 7.0, 5.0])).max() <= 1e-3
+    sh.kkt.close()
+
+
+@pytest.mark.gpu
+def test_hip_schur_equals_hip_dense_condensed_on_a_larger_two_stage_qp(gctx):
+    """8 scenarios x (40 recourse variables, 4 equality + 6 inequality rows), 12 design variables: the Schur system (blocks of
+    order 44 factored as a batch, S of order 12) and the dense-condensed system (one matrix of order 364) of the SAME QP take the
+    same iterations to the same point; the oracle Schur system agrees."""
+    nlp = random_twostage_qp(ns=8, nv=40, nd=12, nc=10, nc_eq=4, seed=7)
+    ref = solve(nlp, hip_dense_condensed(nlp, gctx), sparse=False)
+    sch = solve(nlp, hip_schur(nlp, gctx))
+    orc = solve(nlp, oracle_schur(nlp))
+    assert ref.status == sch.status == orc.status == "SOLVE_SUCCEEDED"
+    assert sch.cnt.k == ref.cnt.k == orc.cnt.k
+    assert abs(sch.obj_val - ref.obj_val) <= 1e-8 * max(1.0, abs(ref.obj_val))
+    assert np.abs(sch.x[:nlp.n] - ref.x[:nlp.n]).max() <= 1e-6
+    assert np.abs(sch.x[:nlp.n] - orc.x[:nlp.n]).max() <= 1e-6
+    xs = sch.x[:nlp.n]
+    c = nlp.cons(xs)
+    assert (c >= nlp.lcon - 1e-6).all() and (c <= nlp.ucon + 1e-6).all()
+    sch.kkt.close(); ref.kkt.close()
