@@ -13,8 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libmadnlp_hip.so")
+_LIB_OVERRIDE = os.environ.get("MNK_LIBPATH")   # A/B runs of a diagnostic build of the same ABI (tools/ab_*.sh); never a fallback
 SOURCES = ["gemm_f64.hip", "dag.hip", "factor.hip", "solve.hip", "ls.hip", "sparse_kkt.hip", "dense_kkt.hip", "bk.hip", "schur.hip", "ipm_vec.hip", "opf_eval.hip"]
-HEADERS = ["common.h", "ls.h", "kkt_vec.h", "gemm_tile.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
+HEADERS = ["common.h", "ls.h", "kkt_vec.h", "gemm_tile.h", "leaf64.h", "gemm_macro.h", os.path.join("..", "..", "include", "madnlp_hip.h")]
 
 MNK_HOST, MNK_DEVICE = 0, 1
 MNK_BUNCHKAUFMAN, MNK_LU, MNK_QR, MNK_CHOLESKY, MNK_LDL, MNK_EVD = 1, 2, 3, 4, 5, 6
@@ -243,7 +244,7 @@ def lib():
         import torch  # noqa: F401
     except Exception:
         pass
-    l = C.CDLL(LIBPATH)
+    l = C.CDLL(_LIB_OVERRIDE if _LIB_OVERRIDE and os.path.exists(_LIB_OVERRIDE) else LIBPATH)
     for name, (res, args) in SIGNATURES.items():
         f = getattr(l, name)  # AttributeError if the symbol is not exported
         f.restype = res

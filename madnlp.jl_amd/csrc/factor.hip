@@ -29,29 +29,9 @@
 #include <cstdlib>
 
 #include "ls.h"
+#include "leaf64.h"
 
 namespace mnk {
-
-__device__ __forceinline__ double fast_rsqrt(double x) {
-    // v_rsq_f64 seed + two Newton steps in fma form: ~1 ulp, no division / software sqrt on
-    // the pivot chain
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-(x * y), y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-(x * y), y, 1.0);
-    y = fma(0.5 * y, e, y);
-    return y;
-}
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
-struct Piv4 {
-    double c10, c20, c30, c21, c31, c32, s0, s1, s2, s3;
-};
 
 // ---------------------------------------------------------------------------------------
 // Split panel step (the default): potrf64_kernel + trsm64_mfma_kernel replace the fused elimination
@@ -64,35 +44,6 @@ struct Piv4 {
 // (Block substitution with 16x16 inverses: backward error indistinguishable from row-by-row
 // substitution on the condensed KKT systems -- tools/emul_block_trsm.py, 2.1e-16 either way.)
 // ---------------------------------------------------------------------------------------
-typedef double v4d __attribute__((ext_vector_type(4)));
-#ifndef MNK_DIAG_FAST_LEAF
-#define MNK_DIAG_FAST_LEAF 0
-#endif
-
-// Store of a result another CU will read after a flag.  WT (the persistent chain of the task-DAG schedule): write-through
-// (sc1), so that the publishing workgroup needs no agent-scope release fence -- that fence (buffer_wbl2) writes back EVERY
-// dirty line of the XCD's L2, and with a dozen strips per XCD storing their rows it grew the pivot chain's step from 24 to
-// 38 us per block (measured: the step time followed the number of resident strips).
-template <bool WT>
-__device__ __forceinline__ void put(double* p, double v) {
-    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
-// Growth monitor of the static-pivot LDL^T (the guard of BUNCHKAUFMAN's first tier, ls.h): the entries of V = L D are the
-// entries of the successive Schur complements at the moment their column is eliminated, so max|v_ik| / max|a_ij| is the
-// element growth of the elimination as far as it can be seen without extra passes.  Every kernel that produces V folds
-// |v| into one word: max over the wave, one atomicMax on the bit pattern (NaN / Inf -> +Inf).
-__device__ __forceinline__ void growth_fold(unsigned long long* word, double vm) {
-    if (word == nullptr) return;
-    if (!(vm <= DBL_MAX)) vm = __longlong_as_double(0x7ff0000000000000LL);
-    for (int off = 32; off > 0; off >>= 1) vm = fmax(vm, __shfl_xor(vm, off));
-    if ((threadIdx.x & 63) == 0 && vm > 0.0) {   // (look first: the word saturates early, the atomic is then skipped)
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(vm);
-        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
-    }
-}
-
 // X = B L_jj^-T (Cholesky) / V = B L_jj^-T, X = V D^-1 (LDL) for every row below the diagonal block.
 // Wave = NS strips of 16 rows; lane (l15, l4): accumulator register r of column block cb holds
 // X[row0 + l15][16 cb + l4 + 4 r] (the C^T layout of gemm_f64.hip, so register r of X^T[ib] IS the
@@ -191,213 +142,6 @@ __global__ __launch_bounds__(256) void trsm64_mfma_batch_kernel(const TrsmBatchR
                              rec.info, nullptr);
 }
 
-__device__ __forceinline__ double readlane_f64(double x, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// ---------------------------------------------------------------------------------------
-// potrf64 on the matrix cores, ONE wave, no LDS, no barriers (the default diagonal-block kernel).
-// The lower triangle of the 64x64 block lives in accumulator registers as ten 16x16 blocks in the
-// transposed ("C^T") layout of gemm_f64.hip: register r of block (cb, b) at lane (l15, l4) holds
-// A[16 cb + l15][16 b + l4 + 4 r].  In this layout register s of a block IS both the A operand
-// (lane (i, k) <-> M[i][4 s + k]) and the B operand (lane (j, k) <-> M^T[4 s + k][j]) of a K = 4
-// v_mfma_f64_16x16x4 product, so the whole factorization proceeds in 16 steps of 4 pivots without
-// ever shuffling data between lanes:
-//   1. the 4x4 pivot block is broadcast (v_readlane, 10 values) and factored redundantly by every
-//      lane -- the same dependent rsqrt/rcp chain as the fused elimination kernel, the only serial part;
-//   2. X_t^T = inv(L44) A_t^T for every block of the block column: one MFMA per block, the 4x4 inverse
-//      supplied as the A operand on the rows of the pivot group;
-//   3. rank-4 update of every trailing block: acc(cb2, cb1) -= X_t[cb1] X_t[cb2]^T, one MFMA per block;
-// and after the four steps of a block column the inverse of its 16x16 diagonal block (needed by
-// trsm64_mfma_kernel) by block forward substitution, again on MFMA (7 products).
-// Measured against the 256-thread LDS/barrier kernel (potrf64_kernel): see DESIGN.md section 5.
-// ---------------------------------------------------------------------------------------
-template <bool LDL>
-__device__ __forceinline__ void factor_piv4_vals(const double p00, const double p10, const double p11,
-                                                 const double p20, const double p21, const double p22,
-                                                 const double p30, const double p31, const double p32,
-                                                 const double p33, const double pivot_tol, Piv4& P, double (&dg)[4],
-                                                 int& fail) {
-    fail = 0;
-    if (LDL) {
-        auto piv = [&](double d, double& sc, double& rec) {
-            const bool zero = !(fabs(d) > pivot_tol) || !(fabs(d) <= DBL_MAX);
-            sc = fast_rcp(zero ? 1.0 : d);  // harmless pivot; dvec records the zero
-            rec = zero ? 0.0 : d;
-        };
-        piv(p00, P.s0, dg[0]);
-        P.c10 = p10; P.c20 = p20; P.c30 = p30;
-        const double x10 = p10 * P.s0, x20 = p20 * P.s0, x30 = p30 * P.s0;
-        piv(fma(-x10, P.c10, p11), P.s1, dg[1]);
-        P.c21 = fma(-x20, P.c10, p21);
-        P.c31 = fma(-x30, P.c10, p31);
-        const double x21 = P.c21 * P.s1, x31 = P.c31 * P.s1;
-        piv(fma(-x21, P.c21, fma(-x20, P.c20, p22)), P.s2, dg[2]);
-        P.c32 = fma(-x31, P.c21, fma(-x30, P.c20, p32));
-        const double x32 = P.c32 * P.s2;
-        piv(fma(-x32, P.c32, fma(-x31, P.c31, fma(-x30, P.c30, p33))), P.s3, dg[3]);
-    } else {
-        auto piv = [&](double t, double& sc, double& rec, int k) {
-            const bool bad = !(t > 0.0) || !(t <= DBL_MAX);  // not positive definite / NaN / Inf
-            fail = (bad && fail == 0) ? k + 1 : fail;
-            sc = fast_rsqrt(bad ? 1.0 : t);
-            rec = bad ? 1.0 : t * sc;
-        };
-        piv(p00, P.s0, dg[0], 0);
-        P.c10 = p10 * P.s0; P.c20 = p20 * P.s0; P.c30 = p30 * P.s0;
-        piv(fma(-P.c10, P.c10, p11), P.s1, dg[1], 1);
-        P.c21 = fma(-P.c20, P.c10, p21) * P.s1;
-        P.c31 = fma(-P.c30, P.c10, p31) * P.s1;
-        piv(fma(-P.c21, P.c21, fma(-P.c20, P.c20, p22)), P.s2, dg[2], 2);
-        P.c32 = fma(-P.c31, P.c21, fma(-P.c30, P.c20, p32)) * P.s2;
-        piv(fma(-P.c32, P.c32, fma(-P.c31, P.c31, fma(-P.c30, P.c30, p33))), P.s3, dg[3], 3);
-    }
-}
-
-// (one wave; `Lsh` / `Ish`: optional LDS copies of the factored block and of its four 16x16 inverses)
-// potrf64w_core: the block is already in registers (Lt[cb][b], b <= cb, strict upper triangle of the diagonal
-// 16x16 blocks zeroed); potrf64w_body loads it from the factor matrix first.
-template <bool LDL, bool WT = false>
-__device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, double* __restrict__ Dout,
-                                              double* __restrict__ inv16, double* __restrict__ dvec,
-                                              double* __restrict__ dinv, int* __restrict__ info, double pivot_tol,
-                                              double* Lsh, double* Ish, unsigned long long* __restrict__ vmax = nullptr) {
-    const int lane = threadIdx.x & 63;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
-    double vm = 0.0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        double aopinv[4] = {0.0, 0.0, 0.0, 0.0};
-        // the finished columns of block column b (Xf[cb][tt]: pivot group tt of block (cb, b)) live OUTSIDE the accumulators:
-        // a kernel with more than 256 registers gets its MFMA accumulators in AGPRs, where overwriting one component of a
-        // block costs a round trip of the whole block through VGPRs (~50 v_accvgpr moves per pivot group, 18 % of the
-        // kernel's instructions); the finished components of Lt are dead from here on (later updates add zeros to them)
-        v4d Xf[4] = {zero4, zero4, zero4, zero4};
-        // (-DMNK_DIAG_FAST_LEAF=1: a timing-only build whose pivot kernel does no arithmetic -- results void -- to see how much
-        // of a factorization's time is the leaf's; tools/diag_fast_leaf.sh)
-#pragma unroll
-        for (int tt = 0; tt < (MNK_DIAG_FAST_LEAF ? 0 : 4); ++tt) {
-            const int t = 4 * b + tt;
-            // ---- 1. pivot block: A[16b + 4tt + jj][16b + 4tt + kk] sits in register tt of lane (4tt + jj) + 16 kk
-            const double dsrc = Lt[b][b][tt];
-            const double p00 = readlane_f64(dsrc, 4 * tt + 0);
-            const double p10 = readlane_f64(dsrc, 4 * tt + 1), p11 = readlane_f64(dsrc, 4 * tt + 1 + 16);
-            const double p20 = readlane_f64(dsrc, 4 * tt + 2), p21 = readlane_f64(dsrc, 4 * tt + 2 + 16),
-                         p22 = readlane_f64(dsrc, 4 * tt + 2 + 32);
-            const double p30 = readlane_f64(dsrc, 4 * tt + 3), p31 = readlane_f64(dsrc, 4 * tt + 3 + 16),
-                         p32 = readlane_f64(dsrc, 4 * tt + 3 + 32), p33 = readlane_f64(dsrc, 4 * tt + 3 + 48);
-            Piv4 P;
-            double dg[4];
-            int fail;
-            factor_piv4_vals<LDL>(p00, p10, p11, p20, p21, p22, p30, p31, p32, p33, pivot_tol, P, dg, fail);
-            if (!LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
-            // entries of the 4x4 factor: l = L (unit lower for LDL), cv = d_k L (LDL) / L (Cholesky)
-            const double l10 = LDL ? P.c10 * P.s0 : P.c10, l20 = LDL ? P.c20 * P.s0 : P.c20,
-                         l30 = LDL ? P.c30 * P.s0 : P.c30, l21 = LDL ? P.c21 * P.s1 : P.c21,
-                         l31 = LDL ? P.c31 * P.s1 : P.c31, l32 = LDL ? P.c32 * P.s2 : P.c32;
-            const double rd0 = LDL ? 1.0 : P.s0, rd1 = LDL ? 1.0 : P.s1, rd2 = LDL ? 1.0 : P.s2, rd3 = LDL ? 1.0 : P.s3;
-            // inverse of the 4x4 factor (forward substitution, uniform values)
-            const double y00 = rd0, y11 = rd1, y22 = rd2, y33 = rd3;
-            const double y10 = -(l10 * y00) * rd1;
-            const double y20 = -fma(l21, y10, l20 * y00) * rd2;
-            const double y30 = -fma(l32, y20, fma(l31, y10, l30 * y00)) * rd3;
-            const double y21 = -(l21 * y11) * rd2;
-            const double y31 = -fma(l32, y21, l31 * y11) * rd3;
-            const double y32 = -(l32 * y22) * rd3;
-            // A operand of step 2: lane (i, k) holds inv(L44)[i - 4tt][k] on the rows of the pivot group, else 0
-            const int ii = l15 - 4 * tt;
-            // entry (ii, l4) of a lower-triangular 4x4 matrix of uniform values for lane (ii, l4): the strictly lower part
-            // by column then row (5 selections), the diagonal by column (3), zero elsewhere (2) -- instead of four row
-            // vectors and a 4-way choice between them (13-14)
-            const bool r1 = ii == 1, r2 = ii == 2, on_diag = ii == l4, below = (l4 < ii) & (ii < 4);  // (& not &&: no branch)
-            auto sel44 = [&](double d0, double d1, double d2, double d3, double e10, double e20, double e30, double e21,
-                             double e31, double e32, bool unit) {
-                const double c0v = r1 ? e10 : (r2 ? e20 : e30), c1v = r2 ? e21 : e31;
-                const double off = l4 == 0 ? c0v : (l4 == 1 ? c1v : e32);
-                const double dia = unit ? 1.0 : (l4 == 0 ? d0 : (l4 == 1 ? d1 : (l4 == 2 ? d2 : d3)));
-                const double lo = below ? off : 0.0;
-                return on_diag ? dia : lo;
-            };
-            const double aop = sel44(y00, y11, y22, y33, y10, y20, y30, y21, y31, y32, LDL);
-            aopinv[tt] = aop;
-            const double ssel = l4 == 0 ? P.s0 : (l4 == 1 ? P.s1 : (l4 == 2 ? P.s2 : P.s3));
-            // exact entries of the pivot rows of the diagonal block (from the scalar factorization)
-            // (Cholesky: c IS l, one selection tree.  LDL^T: v = c by selection; l_ik = c_ik * s_k is the very product the
-            // scalar factorization forms, so l comes from v with one multiplication -- bit-identical, 11 selections fewer)
-            const double vpiv = sel44(dg[0], dg[1], dg[2], dg[3], P.c10, P.c20, P.c30, P.c21, P.c31, P.c32, false);
-            const double lpiv = LDL ? (l4 < ii ? vpiv * ssel : vpiv) : vpiv;
-            // ---- 2. X_t^T = inv(L44) A_t^T for every block of block column b
-            double X[4], V[4];
-#pragma unroll
-            for (int cb = b; cb < 4; ++cb) {
-                const v4d out = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, Lt[cb][b][tt], zero4, 0, 0, 0);
-                double v = out[tt];
-                double x = LDL ? v * ssel : v;
-                if (cb == b) {
-                    // rows above the pivot group: not part of the lower triangle; the pivot rows: exact values
-                    // (lpiv / vpiv are already zero on the rows above the group: one selection each)
-                    x = ii < 4 ? lpiv : x;
-                    v = ii < 4 ? (LDL ? vpiv : lpiv) : v;
-                }
-                X[cb] = x;
-                V[cb] = v;
-                if (LDL) vm = fmax(vm, fabs(v));
-                Xf[cb][tt] = x;
-            }
-            // ---- 3. rank-4 update of the trailing blocks: acc(cb2, cb1) -= X[cb1] (V|X)[cb2]^T
-#pragma unroll
-            for (int cb1 = b; cb1 < 4; ++cb1) {
-                // columns up to the pivot group of block column b are final: no update (zero rows of the A operand)
-                const double na = (cb1 == b && l15 < 4 * tt + 4) ? 0.0 : -X[cb1];
-#pragma unroll
-                for (int cb2 = cb1; cb2 < 4; ++cb2)
-                    Lt[cb2][cb1] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, LDL ? V[cb2] : X[cb2], Lt[cb2][cb1], 0, 0, 0);
-            }
-        }
-        // ---- inverse of the 16x16 diagonal block (unit diagonal for LDL): Y = inv(L16), block forward substitution
-        {
-            v4d T, Y;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) T[r] = (l15 == l4 + 4 * r) ? 1.0 : 0.0;
-#pragma unroll
-            for (int pg = 0; pg < 4; ++pg) {
-                const v4d out = __builtin_amdgcn_mfma_f64_16x16x4f64(aopinv[pg], T[pg], zero4, 0, 0, 0);
-                Y[pg] = out[pg];
-                if (pg < 3) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xf[b][pg], Y[pg], T, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                put<WT>(inv16 + b * 256 + (l4 + 4 * r) + 16 * l15, Y[r]);
-                if (Ish != nullptr) Ish[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
-            }
-        }
-        // ---- D and D^-1 of the 16 pivots of this block column, once per block column instead of once per pivot group by
-        // lane 0: the pivots sit on the diagonal of the factored block -- entry (i, i) in register i >> 2 of lane
-        // (l15 = i, l4 = i & 3) -- and D^-1 is the same fast_rcp of the same recorded pivot (0 recorded -> harmless pivot 1)
-        {
-            const int rsel = l15 >> 2;
-            const double dsel = rsel == 0 ? Xf[b][0] : (rsel == 1 ? Xf[b][1] : (rsel == 2 ? Xf[b][2] : Xf[b][3]));
-            if ((l15 & 3) == l4) {
-                put<WT>(dvec + j0 + 16 * b + l15, dsel);
-                put<WT>(dinv + j0 + 16 * b + l15, LDL ? fast_rcp(dsel == 0.0 ? 1.0 : dsel) : 1.0);
-            }
-        }
-        // ---- store block column b of the factored block (column-major 64x64, lower part)
-#pragma unroll
-        for (int cb = b; cb < 4; ++cb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Xf[cb][r];
-                put<WT>(Dout + (16 * cb + l15) + 64 * (16 * b + l4 + 4 * r), v);
-                if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
-            }
-    }
-    if (LDL) growth_fold(vmax, vm);
-}
-
 template <bool LDL>
 __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
                                               double* __restrict__ Dout, double* __restrict__ inv16,
@@ -445,6 +189,12 @@ __global__ __launch_bounds__(64) void potrf64w_kernel(const double* __restrict__
 // update of its diagonal block from LDS, exchange to wave 0 -> potrf: no kernel boundaries and no idle launches.
 // ---------------------------------------------------------------------------------------
 constexpr long PP_SPIN_LIMIT = 1L << 20;  // ~0.5 s
+#ifndef MNK_LEAF_WAVES
+#define MNK_LEAF_WAVES 1   // waves that factor a 64x64 diagonal block of the pivot chain.  1: potrf64w_core on wave 0 (the shipped leaf).  4: potrf64q_core,
+                           // every wave its own block row -- built and measured in round 5: the same bits, 0.89 vs 0.86 ms at N = 2048 (tools/leaf_ab.sh,
+                           // profiles/r05_leaf_lab.txt): the scalar 4x4 factorizations, 57 % of the leaf, are repeated by every wave and the
+                           // exchanges through LDS cost what the split of the MFMAs saves.  Diagnostic builds only.
+#endif
 #ifndef MNK_DIAG_NO_EARLY
 #define MNK_DIAG_NO_EARLY 0   // (-DMNK_DIAG_NO_EARLY=1: a diagnostic build without the chain's early diagonal update)
 #endif
@@ -700,8 +450,33 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                     }
             }
         } else if (j > 0) __syncthreads();  // the LDS tiles of the previous step are free
+        if (j == t && MNK_LEAF_WAVES == 4) {
+            // ---- diagonal step, four waves: every wave factors its own block row of the 64x64 block (potrf64q_core); the
+            // stores of all four are complete before one lane publishes the block
+            const int64_t jb = (p0 >> 6) + j;
+            v4d Lq[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Lq[b][r] = (b == w && l15 < l4 + 4 * r) ? 0.0 : X[4 * j + b][r];
+            potrf64q_core<LDL, WT>(Lq, w, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol,
+                                   reinterpret_cast<double*>(stage), dag.vmax);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(prog + j, epoch16 + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (its last step: the strip's rows are final through the tile column of block j)
+                if (dag.front != nullptr)
+                    __hip_atomic_store(dag.front + tabs, (int)(p0 >> 7) + (j >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dag.trace != nullptr) dag.trace[8 * t + 2] = wall_clock64();
+            }
+            return true;
+        }
         if (j == t) {
-            // ---- diagonal step: hand the updated 64x64 block to wave 0 (same lane mapping), factor, publish
+            // ---- diagonal step, one wave (MNK_LEAF_WAVES = 1: rounds 2-4): hand the updated 64x64 block to wave 0 (same
+            // lane mapping), factor, publish
 #pragma unroll
             for (int b = 0; b < 4; ++b)
                 if (b <= w) stage[(w * (w + 1) / 2 + b) * 64 + lane] = X[4 * j + b];
