@@ -42,6 +42,7 @@ struct mnk_schur {
     mnk::DevBuf<double> Xall, Vall, Pall;   // ns x (ndp x Npb) | the same (LDL^T only) | ns x (ndp x ndp)
     mnk::DevBuf<char> recs;                 // device copies of the launch records
     mnk::DevBuf<int> fast_k;                // the scenarios on the grouped path
+    int64_t chunk = 32;                     // scenarios per pass of the grouped build (their X / V / P buffers are reused)
     mnk::DevBuf<double> Sown;               // nd x nd: the handle's own copy of S (mnk_schur_s_buffer: callers without device memory of their own)
     mnk::DevBuf<double> hostrk, hostrd;     // mnk_schur_solve with host vectors: ns x blk | 2 nd (right-hand side, contribution)
 };
@@ -156,9 +157,19 @@ int mnk_schur_create(mnk_ctx* ctx, int64_t ns_local, int64_t blk, int64_t nd, in
     {
         const size_t nsl = (size_t)std::max<int64_t>(ns_local, 1);
         const size_t nstep = (size_t)(h->Npb / NBI);
-        rc |= h->Xall.alloc(nsl * h->ndp * h->Npb + SLACK);
-        if (algo != MNK_CHOLESKY) rc |= h->Vall.alloc(nsl * h->ndp * h->Npb + SLACK);
-        rc |= h->Pall.alloc(nsl * h->ndp * h->ndp + SLACK);
+        //  the grouped build works on CHUNKS of at most `chunk` scenarios -- X / V / P buffers of that many, reused
+        // from chunk to chunk, the partial sums added to S chunk by chunk in scenario order (the same additions in the same
+        // order as one pass over all of them: the same bits) -- instead of ns x nd^2 doubles for P alone (ns = 128, nd = 4096:
+        // 17 GB); the solves' per-scenario vectors need ns x nd doubles of P
+        // chunk size: as many scenarios as ~4 GB of X / V / P hold, at least 32 (every chunk costs three record uploads with a
+        // stream synchronization each: ns = 128, blk = 512, nd = 256 in chunks of 32 built in 10.2 instead of 4.6-7.9 ms)
+        const size_t per_scen = (size_t)h->ndp * h->ndp * 8 + 2 * (size_t)h->ndp * h->Npb * 8;
+        const size_t by_mem = std::max<size_t>(32, ((size_t)4 << 30) / std::max<size_t>(per_scen, 1));
+        h->chunk = (int64_t)std::min<size_t>(nsl, getenv("MNK_SCHUR_CHUNK") ? (size_t)std::max(1, atoi(getenv("MNK_SCHUR_CHUNK"))) : by_mem);
+        const size_t nch = (size_t)h->chunk;
+        rc |= h->Xall.alloc(nch * h->ndp * h->Npb + SLACK);
+        if (algo != MNK_CHOLESKY) rc |= h->Vall.alloc(nch * h->ndp * h->Npb + SLACK);
+        rc |= h->Pall.alloc(std::max(nch * h->ndp * h->ndp, nsl * (size_t)h->ndp) + SLACK);
         rc |= h->recs.alloc(nsl * (sizeof(mnk::TrsmBatchRec) + nstep * sizeof(mnk::GemmBatchRec)) + 64);
         rc |= h->fast_k.alloc(nsl);
     }
@@ -251,19 +262,20 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         (grouped ? fast : slow).push_back((int)k);
     }
     const int64_t Npb = h->Npb;
-    if (!fast.empty()) {
-        // Phase 1b, fast path (static-pivot factor A_k = L D L' or L L'):  C A^-1 C' = (C L^-T) D^-1 (C L^-T)', so only the
-        // FORWARD sweep is needed, as a right-side triangular solve of the nd rows of C_dk -- left-looking over the 64-column
-        // blocks of L: an MFMA update with the finished blocks, then block substitution on MFMA against the diagonal block.
-        // One launch of each per step for ALL these scenarios (round 3: ~20 launches per scenario, 13.3 ms for 16 of them;
-        // four streams side by side: 5.2 ms; the host's launch rate was the bound).
-        const int nf = (int)fast.size();
-        const bool ldl = h->ls_k[fast[0]]->algo == MNK_LDL;
+    // Phase 1b, fast path (static-pivot factor A_k = L D L' or L L'):  C A^-1 C' = (C L^-T) D^-1 (C L^-T)', so only the
+    // FORWARD sweep is needed, as a right-side triangular solve of the nd rows of C_dk -- left-looking over the 64-column
+    // blocks of L: an MFMA update with the finished blocks, then block substitution on MFMA against the diagonal block.
+    // One launch of each per step for ALL scenarios of a chunk (round 3: ~20 launches per scenario, 13.3 ms for 16 of them;
+    // four streams side by side: 5.2 ms; the host's launch rate was the bound).
+    for (size_t c0 = 0; c0 < fast.size(); c0 += (size_t)h->chunk) {
+        const int nf = (int)std::min<size_t>((size_t)h->chunk, fast.size() - c0);
+        const int* fk = fast.data() + c0;
+        const bool ldl = h->ls_k[fk[0]]->algo == MNK_LDL;
         const int nstep = (int)(Npb / NBI);
         std::vector<mnk::TrsmBatchRec> tr(nf);
         std::vector<mnk::GemmBatchRec> gr((size_t)nstep * nf);
         for (int i = 0; i < nf; ++i) {
-            mnk_ls* ls = h->ls_k[fast[i]];
+            mnk_ls* ls = h->ls_k[fk[i]];
             double* X = h->Xall.p + (size_t)i * ndp * Npb;
             double* V = ldl ? h->Vall.p + (size_t)i * ndp * Npb : X;
             tr[i] = {X, ldl ? V : nullptr, ls->dblk.p, ls->inv16.p, ls->dinv.p, ls->info_dev.p};
@@ -276,10 +288,10 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         mnk::GemmBatchRec* gr_dev = reinterpret_cast<mnk::GemmBatchRec*>(rdev + (size_t)h->ns * sizeof(mnk::TrsmBatchRec));
         MNK_HIP(mnk::h2d_copy(tr_dev, tr.data(), tr.size() * sizeof(mnk::TrsmBatchRec), s));
         MNK_HIP(mnk::h2d_copy(gr_dev, gr.data(), gr.size() * sizeof(mnk::GemmBatchRec), s));
-        MNK_HIP(mnk::h2d_copy(h->fast_k.p, fast.data(), (size_t)nf * sizeof(int), s));
+        MNK_HIP(mnk::h2d_copy(h->fast_k.p, fk, (size_t)nf * sizeof(int), s));
         hipLaunchKernelGGL(schur_copy_batch_kernel, dim3((unsigned)((ndp * Npb + 255) / 256), (unsigned)nf), dim3(256), 0, s,
                            h->Xall.p, ndp, Npb, h->C.p, nd, blk, h->fast_k.p);
-        const int64_t ldf = h->ls_k[fast[0]]->ld;
+        const int64_t ldf = h->ls_k[fk[0]]->ld;
         int rc = 0;
         for (int j = 0; j < nstep && !rc; ++j) {
             if (j > 0) rc = launch_gemm_nt_batch(s, ndp, NBI, (int64_t)j * NBI, gr_dev + (size_t)(j - 1) * nf, nf, ndp, ldf, ndp);

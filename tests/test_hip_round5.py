@@ -452,3 +452,34 @@ def test_first_factorizations_of_several_threads_next_to_a_process_full_of_conte
         M.close()
     for (st, c) in keep:
         c.close()
+
+
+def test_schur_build_in_chunks_gives_the_same_bits(ctx):
+    """the grouped Schur build works on chunks of scenarios with reused X / V / P buffers (memory no longer
+    grows with ns x nd^2); the partial sums are added to S chunk by chunk in scenario order -- the same additions in the same
+    order, so S must come out bit-identical whatever the chunk size (own process per size: MNK_SCHUR_CHUNK is read at creation)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+import madnlp_jl_amd as mj
+from madnlp_jl_amd.schur import SchurDenseStage
+from tests.test_schur import two_stage_blocks
+A, Cs, S0, blk = two_stage_blocks(11, 150, 50, 70, seed=23)
+st = SchurDenseStage(A, Cs, S0, 70, blk, ctx=mj.HipContext(0))
+S = st.build_kkt().cpu().numpy()
+st.factorize_kkt()
+print("SHA", hashlib.sha256(S.tobytes()).hexdigest(), st.inertia())
+''' % root
+    out = []
+    for chunk in ("3", "4", "64"):
+        env = dict(os.environ, MNK_SCHUR_CHUNK=chunk)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1500:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0])
+    assert out[0] == out[1] == out[2], out
+    assert "(70, 0, 0)" in out[0]
