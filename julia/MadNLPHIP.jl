@@ -446,6 +446,9 @@ function MadNLP.create_kkt_system(
     # is_inertia_correct accepts (n, 0, 0) only: "not positive definite" from the static-pivot tier is final, the pivoted
     # tier could only confirm the rejection
     _linear_solver isa HipLinearSolver && set_option!(_linear_solver.handle, "accept_only_pd", 1)
+    # ... and `should_regularize_dual` is `true` whatever the counts (:141): only "positive definite or not" is read from this
+    # system's inertia, so the factorization of a matrix that is not may stop at its first non-positive pivot (as dpotrf does)
+    _linear_solver isa HipLinearSolver && set_option!(_linear_solver.handle, "early_reject", 1)
     return HipSparseCondensedKKTSystem(
         hess, hess_raw, hess_com, hess_csc_map,
         jac, jt_coo, jt_csc, jt_csc_map,

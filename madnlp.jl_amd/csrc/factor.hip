@@ -849,6 +849,8 @@ __global__ __launch_bounds__(1024) void finish_info_kernel(const double* __restr
     }
     unsigned long long pos = 0, zer = 0, neg = 0, chg = 0;
     double amx = 0.0;
+    // (an early rejection, info = -9: D is valid through pivot info[1] only -- what lies behind is the previous factorization's)
+    if (N > 0 && *info == -9) N = info[1] + 1 < N ? info[1] + 1 : N;
     for (int64_t k = threadIdx.x; k < N; k += blockDim.x) {
         const double d = dvec[k];
         if (d > 0.0) ++pos;
@@ -1149,6 +1151,13 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
     ls->inv_done = 0;
     ls->t_fact_launch_ms = mnk_host_ms();
+    {   // info[2]: the leaf stops the factorization at the first pivot that is not positive (leaf64.h: early rejection)
+        const int want = (ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL) ? 1 : 0;
+        if (want != ls->reject_on_device) {
+            MNK_HIP(hipMemsetAsync(ls->info_dev.p + 2, want, sizeof(int), s));
+            ls->reject_on_device = want;
+        }
+    }
     // The persistent kernels keep waiting workgroups resident.  Two of them from different contexts on the same CUs can
     // starve each other's diagonal strips (per-XCD dispatch order), so the persistent operations of one process take turns
     // on the device (the arbiter below); a wait that expires anyway (another PROCESS) falls back (mnk_ls_fetch_info) and the
@@ -1544,6 +1553,23 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         rc = mnk_ls_run_factorization(ls);
         if (rc) return rc;
         return mnk_ls_fetch_info(ls);
+    }
+    ls->factor_invalid = false;
+    if (hinfo == -9) {
+        // EARLY REJECTION (option early_reject with accept_only_pd; leaf64.h): the static-pivot LDL^T met a pivot that is not
+        // positive and every kernel behind that diagonal block dropped its work.  The matrix is not positive definite -- all the
+        // caller asked.  Reported: the signs of the pivots that were computed, everything behind them counted as negative
+        // (num_neg >= 1 is the statement; the reference's Cholesky path reports a failed factorization as (0, n, 0) in the
+        // same spirit, lapack_common.jl:96-98).  The factor is not usable: solve / get_factor refuse it.
+        ls->info = 1;
+        ls->npos = (int64_t)h[0];
+        ls->nzero = (int64_t)h[1];
+        ls->nneg = ls->N - ls->npos - ls->nzero;
+        ls->factor_invalid = true;
+        ++ls->early_rejects;
+        ls->early_reject_col = (int64_t)(long long)pw[7];
+        ls->info_valid = true;
+        return 0;
     }
     if (hinfo < 0) {
         // a bounded device-side wait expired and there is no way to redo the factorization (no source to transfer again)

@@ -141,6 +141,12 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
     const int l15 = lane & 15, l4 = lane >> 4;
     const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
     double vm = 0.0;
+    // EARLY REJECTION (round 5, option early_reject; info[2] != 0): the caller accepts POSITIVE DEFINITE matrices only (the sparse
+    // condensed KKT system: reference src/KKT/Sparse/condensed.jl:138-141), so the first pivot that is not positive settles
+    // `is_inertia_correct` -- info = -9, and every kernel behind this block drops its work (they all look at `info`): the
+    // interior-point loop's rejected trials of inertia_correction! (19 of the 39 factorizations of the AC-OPF run of the bench
+    // line) stop where LAPACK's dpotrf would, instead of running to the end as dsytrf does.  info[1] = last pivot whose D is valid.
+    const int reject = LDL ? __hip_atomic_load(info + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         double aopinv[4] = {0.0, 0.0, 0.0, 0.0};
@@ -167,6 +173,10 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
             int fail;
             factor_piv4_vals<LDL>(p00, p10, p11, p20, p21, p22, p30, p31, p32, p33, pivot_tol, P, dg, fail);
             if (!LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
+            if (LDL && reject != 0) {   // (uniform: dg are the recorded pivots, 0 for a zero / non-finite one)
+                const bool bad = !(dg[0] > 0.0) | !(dg[1] > 0.0) | !(dg[2] > 0.0) | !(dg[3] > 0.0);
+                if (bad && lane == 0 && atomicCAS(info, 0, -9) == 0) info[1] = (int)(j0 + 63);
+            }
             // entries of the 4x4 factor: l = L (unit lower for LDL), cv = d_k L (LDL) / L (Cholesky)
             const double l10 = LDL ? P.c10 * P.s0 : P.c10, l20 = LDL ? P.c20 * P.s0 : P.c20,
                          l30 = LDL ? P.c30 * P.s0 : P.c30, l21 = LDL ? P.c21 * P.s1 : P.c21,

@@ -652,7 +652,7 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out) {
         (void)hipGetLastError();
         rc |= -2;
     }
-    rc |= ls->info_dev.alloc(2);   // info | which bounded device-side wait expired (info = -7)
+    rc |= ls->info_dev.alloc(4);   // info | which bounded device-side wait expired (info = -7) / last valid pivot (info = -9) | early-rejection switch | -
     rc |= ls->inertia_dev.alloc(3);
     if (rc) { delete ls; return -2; }
     MNK_HIP(hipMemsetAsync(ls->fact.p, 0, ((size_t)ls->ld * ls->Np + SLACK) * sizeof(double), ctx->stream));
@@ -780,6 +780,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         return 0;
     }
     if (!strcmp(key, "accept_only_pd")) { ls->accept_only_pd = value != 0; return 0; }  // see mnk_ls_fetch_info
+    if (!strcmp(key, "early_reject")) { ls->early_reject = value != 0; return 0; }      // with accept_only_pd: stop at the first non-positive pivot (leaf64.h)
     // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
     if (!strcmp(key, "dag_debug")) {
         ls->dag_debug = value != 0.0;
@@ -1109,6 +1110,8 @@ int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
     MNK_REQUIRE(ls && x, "mnk_ls_solve: NULL argument");
     { int rc_d = mnk_ls_sync_deferred_fact(ls); if (rc_d) return rc_d; }
     MNK_REQUIRE(ls->factorized, "mnk_ls_solve: factorize first");
+    if (ls->reject_on_device == 1) { int rc_i = mnk_ls_fetch_info(ls); if (rc_i) return rc_i; }   // (early rejection: known when the pivots are)
+    MNK_REQUIRE(!ls->factor_invalid, "mnk_ls_solve: the last factorization was stopped at its first non-positive pivot (early_reject): the matrix is not positive definite and there is no factor to solve with");
     MNK_REQUIRE(nrhs >= 1 && ldx >= ls->N, "mnk_ls_solve: bad nrhs/ldx");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     if (ls->solve_abort && *ls->solve_abort != 0) {
@@ -1221,6 +1224,8 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
     MNK_REQUIRE(ls && L, "mnk_ls_get_factor: NULL argument");
     { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     MNK_REQUIRE(ls->factorized, "mnk_ls_get_factor: factorize first");
+    if (ls->reject_on_device == 1) { int rc_i = mnk_ls_fetch_info(ls); if (rc_i) return rc_i; }
+    MNK_REQUIRE(!ls->factor_invalid, "mnk_ls_get_factor: the last factorization was stopped at its first non-positive pivot (early_reject): there is no factor");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     hipStream_t s = ls->ctx->stream;
     if (loc == MNK_DEVICE) {
@@ -1251,6 +1256,8 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
     // which bounded device-side wait expired last (info = -7): 1 bulk task / operand rows, 2 bulk task / chunk order, 3 gate on the bulk stream, 4 chain strip / diagonal block, 5 chain strip / bulk kernel's rows or band tiles; 0: none
     if (!strcmp(key, "timeout_site")) { *value = ls->last_timeout_site; return 0; }
+    if (!strcmp(key, "early_rejects")) { *value = (double)ls->early_rejects; return 0; }       // factorizations stopped at their first non-positive pivot
+    if (!strcmp(key, "early_reject_col")) { *value = (double)ls->early_reject_col; return 0; } // ... the last valid pivot of the latest one
     if (!strcmp(key, "stall_ms_total")) { *value = ls->stall_ms_total; return 0; }      // what this solver's expired waits (fall-backs) have cost, host ms
     if (!strcmp(key, "stall_ms_process")) { *value = mnk_process_stall_ms(); return 0; }  // ... all solvers of the process
     if (!strcmp(key, "growth")) { *value = ls->last_growth; return 0; }  // BUNCHKAUFMAN: max|d_k| / max|a_ij| of the static-pivot tier

@@ -175,10 +175,12 @@ class SparseCondensedKKTSystem(_KKTCommon):
 
     def __init__(self, n, m, jac_I, jac_J, hess_I, hess_J, ind_ineq, ind_lb, ind_ub,
                  ctx: HipContext | None = None, linear_solver=HipLinearSolver,
-                 opt_linear_solver: HipSolverOptions | None = None, device_kkt_ops: bool = False):
+                 opt_linear_solver: HipSolverOptions | None = None, device_kkt_ops: bool = False, early_reject: bool = True):
         """`device_kkt_ops`: run `solve_kkt!` and `mul!` entirely on the device (`mnk_sc_solve_kkt`,
         `mnk_sc_mul`): the primal-dual vector makes one round trip per call instead of the host doing the
-        vector algebra around a device solve."""
+        vector algebra around a device solve.  `early_reject`: a matrix that is not positive definite is reported as such from
+        its first non-positive pivot on, without finishing its factorization (its inertia is then a lower bound on num_neg,
+        it has no usable factor; `False`: every factorization runs to the end and reports the signs of all pivots)."""
         if len(ind_ineq) != m:
             raise ValueError("SparseCondensedKKTSystem does not support equality constrained NLPs.")
         self.device_kkt_ops = bool(device_kkt_ops)
@@ -226,6 +228,10 @@ class SparseCondensedKKTSystem(_KKTCommon):
         # is final, the pivoted tier could only confirm the rejection
         if hasattr(self.linear_solver, "set_option"):
             self.linear_solver.set_option("accept_only_pd", 1)
+            # ... and since should_regularize_dual is `true` whatever the counts (condensed.jl:141), nothing but "positive
+            # definite or not" is ever read from the inertia of this system: the factorization of a matrix that is not may stop
+            # at its first non-positive pivot (as dpotrf does) instead of running to the end (as dsytrf does)
+            self.linear_solver.set_option("early_reject", 1 if early_reject else 0)
         L.check(lib.mnk_sc_set_bounds(self._h, nlb, self.ind_lb.ctypes.data, nub, self.ind_ub.ctypes.data, 0),
                 "mnk_sc_set_bounds")
         _LIVE_OBJECTS.add(self)

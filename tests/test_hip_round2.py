@@ -679,8 +679,10 @@ def test_condensed_systems_do_not_pay_for_the_pivoted_tier(ctx):
     accept_only_pd); a stand-alone BUNCHKAUFMAN solver on the same matrix still takes the pivoted tier."""
     from madnlp_jl_amd.problems import opf_shaped
     P = opf_shaped("case30", indefinite=True)
+    # (early_reject off: this test is about the COUNTS the static tier reports; with it the factorization stops at the first
+    # non-positive pivot and the counts are a lower bound -- tests/test_hip_round5.py)
     k = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
-                                    opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+                                    opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN), early_reject=False)
     for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
         getattr(k, f)[:] = getattr(P, f)
     k.jac[:] = P.jac
@@ -691,6 +693,7 @@ def test_condensed_systems_do_not_pay_for_the_pivoted_tier(ctx):
     npos, nzero, nneg = k.linear_solver.inertia()
     assert nneg + nzero > 0 and not k.is_inertia_correct(npos, nzero, nneg)
     assert k.linear_solver.get_stat("bk_count") == 0          # no pivoted factorization was paid for
+    assert k.linear_solver.get_stat("early_rejects") == 0
     # the same matrix through a solver of its own: BUNCHKAUFMAN semantics, the pivoted tier may run (zero pivots do occur
     # only by accident here, so only the inertia is compared)
     A = k.aug_com.to_dense() if hasattr(k.aug_com, "to_dense") else None

@@ -483,3 +483,72 @@ print("SHA", hashlib.sha256(S.tobytes()).hexdigest(), st.inertia())
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0])
     assert out[0] == out[1] == out[2], out
     assert "(70, 0, 0)" in out[0]
+
+
+@pytest.mark.parametrize("case", ["case118", "case1354pegase"])
+def test_early_rejection_of_matrices_that_are_not_positive_definite(ctx, case):
+    """Round 5: the sparse condensed KKT system accepts positive definite matrices only and regularizes its dual block whatever
+    the counts (reference src/KKT/Sparse/condensed.jl:138-141), so the static-pivot LDL' of a matrix that is NOT positive
+    definite may stop at its first non-positive pivot, as dpotrf does (option early_reject, on for this KKT type), instead of
+    running to the end as dsytrf does.  On OPF-shaped systems with an indefinite Hessian block: the verdict
+    (`is_inertia_correct`) equals LAPACK's for every regularization of a ladder; a rejected matrix reports num_neg >= 1 and no
+    usable factor (solve raises); it costs less than a full factorization; and the next positive definite matrix on the SAME
+    solver factors and solves as if nothing had happened (bit-identical to a solver that never rejected anything)."""
+    import time
+    from tests.test_hip_c5 import _hip_sc
+    P = opf_shaped(case, indefinite=True, sigma_s_decades=2.0, du=1e-8)
+    ko = _oracle_sc(P, BUNCHKAUFMAN)
+    kh = _hip_sc(P, ctx, mj.BUNCHKAUFMAN)                 # early_reject on (the default of the KKT type)
+    kf = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                     opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN), early_reject=False)
+    for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+        getattr(kf, f)[:] = getattr(P, f)
+    kf.jac[:] = P.jac
+    kf.hess[:] = P.hess
+    from oracle import kernels as okern
+    for k in (kh, kf):
+        k.compress_jacobian(); k.compress_hessian(); k.set_aug_diagonal()
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(P.n)
+    dw_prev, seen_reject, seen_accept = 0.0, 0, 0
+    t_rej, t_full = [], []
+    for dw in (0.0, 1e-4, 1e-2, 1.0, 1e2, 1e4):
+        okern.regularize_diagonal(ko, dw - dw_prev, 0.0)
+        for k in (kh, kf):
+            k.regularize_diagonal(dw - dw_prev, 0.0)
+        dw_prev = dw
+        ko.build_kkt(); ko.linear_solver.factorize()
+        ok_ref = ko.is_inertia_correct(*ko.linear_solver.inertia())
+        verdicts = []
+        for k, tl in ((kh, t_rej), (kf, t_full)):
+            k.build_kkt()
+            k.linear_solver.factorize()            # (warm)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            k.linear_solver.factorize()
+            ine = k.linear_solver.inertia()
+            tl.append(time.perf_counter() - t0)
+            verdicts.append((k.is_inertia_correct(*ine), ine))
+        (ok_h, ine_h), (ok_f, ine_f) = verdicts
+        assert ok_h == ok_f == ok_ref, (dw, ine_h, ine_f, ko.linear_solver.inertia())
+        assert sum(ine_h) == sum(ine_f) == P.n
+        if ok_ref:
+            seen_accept += 1
+            assert ine_h == ine_f == (P.n, 0, 0)
+            xh, xf = kh.linear_solver.solve_linear_system(b.copy()), kf.linear_solver.solve_linear_system(b.copy())
+            assert np.array_equal(xh, xf), dw          # the same factor, bit for bit, after any number of rejections
+            K = _full(ko)
+            assert _bwd(K, xh, b) <= 1e-13
+        else:
+            seen_reject += 1
+            assert ine_h[2] >= 1 and ine_f[2] + ine_f[1] >= 1
+            assert ine_h[0] <= ine_f[0] + 64            # (pivots behind the stopping block count as negative)
+            with pytest.raises(mj.SolveException):
+                kh.linear_solver.solve_linear_system(b.copy())
+    assert seen_reject >= 1 and seen_accept >= 1
+    assert kh.linear_solver.get_stat("early_rejects") >= seen_reject and kf.linear_solver.get_stat("early_rejects") == 0
+    assert kh.linear_solver.get_stat("pp_fallbacks") == 0
+    if case == "case1354pegase":    # at N = 11 192 the saving is visible in wall time (rejections stop somewhere in the matrix)
+        rej = [t for t, (dw) in zip(t_rej, range(len(t_rej)))][:seen_reject]
+        full = t_full[:seen_reject]
+        assert sum(rej) <= sum(full) * 1.02, (rej, full)
+    kh.close(); kf.close()

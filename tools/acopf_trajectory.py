@@ -37,7 +37,7 @@ def factory(info):
     return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J, info["ind_ineq"],
                                        info["ind_lb"], info["ind_ub"], ctx=ctx,
                                        opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN),
-                                       device_kkt_ops=True)
+                                       device_kkt_ops=True, early_reject=os.environ.get("EARLY_REJECT", "1") != "0")
 
 
 class Traced(DeviceMadNLPSolver):
@@ -57,7 +57,8 @@ class Traced(DeviceMadNLPSolver):
         self.trials.append(dict(k=self.cnt.k, trial=n_trial, del_w=self.del_w, del_c=self.del_c, inertia=tuple(int(v) for v in inertia),
                                 correct=bool(correct), ok=bool(ok), ir=int(self.iterator.ir) if correct else 0,
                                 rr=float(self.iterator.residual_ratio) if correct else float("nan"), bk=bool(M.bk_info()[0]),
-                                growth=M.get_stat("growth"), algo=M.get_stat("panel_algo"), mat=mat))
+                                growth=M.get_stat("growth"), algo=M.get_stat("panel_algo"), mat=mat,
+                                stop=int(M.get_stat("early_reject_col")) if not correct else -1))
 
 
 o = IPMOptions(tol=gold["tol"] if gold else 1e-6)
@@ -83,7 +84,8 @@ for kk in sorted(by_k):
     cells = []
     for t in tr:
         verdict = "ok" if t["ok"] else ("WRONG-INERTIA" if not t["correct"] else "REFINE-FAIL")
-        cells.append(f"{t['del_w']:.3g}: {t['inertia']} {'BK' if t['bk'] else 'static'} g={t['growth']:.2g} R={t['ir']}/{t['rr']:.1e} {verdict}")
+        stop = f" stopped at pivot {t['stop']} of {nlp.n}" if t.get("stop", -1) >= 0 and not t["correct"] else ""
+        cells.append(f"{t['del_w']:.3g}: {t['inertia']} {'BK' if t['bk'] else 'static'} g={t['growth']:.2g} R={t['ir']}/{t['rr']:.1e} {verdict}{stop}")
     # the history record written AFTER iteration kk's step is record kk + 1; del_w of iteration kk is stored there
     hrec, grec = hist.get(kk + 1), gh.get(kk + 1)
     dw_h = tr[-1]["del_w"]
