@@ -42,6 +42,16 @@ namespace mnk {
 // What a bulk task needs to know about the factorization it belongs to.  One launch may serve SEVERAL independent
 // factorizations of the same order (mnk_factorize_batch_*: the task lists of the instances are merged into one queue, each
 // task carries its instance index), so these live in a per-instance record instead of the kernel's argument block.
+// Diagonal tiles are accumulated in SUBTRACT order (gemm_tile.h: gemm_nt_load_neg_lower): C - t_1 - t_2 ... with the tile in
+// the accumulators from the first chunk on, instead of a sum of products that grows from zero and is subtracted at the end.
+// Both are backward stable; the difference shows on condensed KKT matrices whose pivots are the difference of numbers of
+// size 1e13 that agree to 15 digits (AC-OPF case1354): the pivot chain saw -0.031 where the exact
+// value is +0.0195, the interior-point run needed 10 Richardson steps per solve and left LAPACK's trajectory at iteration 9;
+// with the subtract order it follows it to three digits through all 20 iterations (47 -> 30 back-solves).  Cost: a tile's
+// chunks run one after the other (+0.5 % at N = 11 192, tools/diag_sub_ab.sh).  0 = the old order (A/B builds).
+#ifndef MNK_DAG_DIAG_SUB
+#define MNK_DAG_DIAG_SUB 1
+#endif
 struct DagInst {
     double* F;
     int64_t ld;
@@ -468,7 +478,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             if (tr) { tr[4] = wall_clock64(); s_stat[1] += tr[4] - tr[3]; }
             dag_finalize_tile<LDL>(in, row0, col0, 2 * J, smem_raw, tid, X, tr);
             if (tr) s_stat[3] += wall_clock64() - tr[4];
-        } else {
+        } else if (!(MNK_DAG_DIAG_SUB && I == J && kend > kbeg)) {
             v4f64 acc[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -480,9 +490,24 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
             if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, Ak, in->ld, Bk, in->ld, (kend - kbeg) * 16, smem_raw, tid, gate)) return false;
             if (tr) tr[1] = wall_clock64();  // K-loop done
             if (!wait_chunk_order()) return false;
-            // C(I, J) -= acc (a diagonal tile: lower wave tiles only)
+            // C(I, J) -= acc
             if (kend > kbeg)
                 gemm_nt_epilogue<2, 2, 4, 2, false, true>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, in->F, in->ld, nullptr, nullptr, 0, tid);
+            if (tr) tr[3] = wall_clock64();
+        } else {
+            // A chunk of a DIAGONAL tile, accumulated in subtract order (gemm_nt_load_neg_lower; its chunks run one after the
+            // other).  A branch of its own: the body chunks' K-loop below must keep the registers it was tuned with.
+            v4f64 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+            __builtin_amdgcn_s_setprio(3);   // (every chunk: the next one of the tile -- in the end the chain -- waits for it)
+            if (!wait_chunk_order()) return false;
+            gemm_nt_load_neg_lower<2, 2, 4>(acc, row0, col0, in->F, in->ld, tid);
+            if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, Ak, in->ld, Bk, in->ld, (kend - kbeg) * 16, smem_raw, tid, gate)) return false;
+            if (tr) tr[1] = wall_clock64();  // K-loop done
+            gemm_nt_store_neg_lower<2, 2, 4>(acc, row0, col0, in->F, in->ld, tid);
             if (tr) tr[3] = wall_clock64();
         }
         return true;
@@ -651,7 +676,7 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
             if (tr) { tr[4] = wall_clock64(); s_stat[1] += tr[4] - tr[3]; }
             dag_finalize_tile<LDL>(&a, row0, col0, 2 * J, smem_raw, tid, X, tr);
             if (tr) s_stat[3] += wall_clock64() - tr[4];
-        } else {
+        } else if (!(MNK_DAG_DIAG_SUB && I == J && kend > kbeg)) {
             v4f64 acc[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -663,9 +688,24 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel1(DagArgs1 a) {
             if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, Ak, a.ld, Bk, a.ld, (kend - kbeg) * 16, smem_raw, tid, gate)) return;
             if (tr) tr[1] = wall_clock64();  // K-loop done
             if (!wait_chunk_order()) return;
-            // C(I, J) -= acc (a diagonal tile: lower wave tiles only)
+            // C(I, J) -= acc
             if (kend > kbeg)
                 gemm_nt_epilogue<2, 2, 4, 2, false, true>(acc, row0, col0, (int64_t)1 << 40, (int64_t)1 << 40, a.F, a.ld, nullptr, nullptr, 0, tid);
+            if (tr) tr[3] = wall_clock64();
+        } else {
+            // A chunk of a DIAGONAL tile, accumulated in subtract order (gemm_nt_load_neg_lower; its chunks run one after the
+            // other).  A branch of its own: the body chunks' K-loop below must keep the registers it was tuned with.
+            v4f64 acc[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = v4f64{0.0, 0.0, 0.0, 0.0};
+            __builtin_amdgcn_s_setprio(3);   // (every chunk: the next one of the tile -- in the end the chain -- waits for it)
+            if (!wait_chunk_order()) return;
+            gemm_nt_load_neg_lower<2, 2, 4>(acc, row0, col0, a.F, a.ld, tid);
+            if (!gemm_nt_mainloop<2, 2, 4, 0, 8>(acc, Ak, a.ld, Bk, a.ld, (kend - kbeg) * 16, smem_raw, tid, gate)) return;
+            if (tr) tr[1] = wall_clock64();  // K-loop done
+            gemm_nt_store_neg_lower<2, 2, 4>(acc, row0, col0, a.F, a.ld, tid);
             if (tr) tr[3] = wall_clock64();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1152,7 +1152,7 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     ls->inv_done = 0;
     ls->t_fact_launch_ms = mnk_host_ms();
     {   // info[2]: the leaf stops the factorization at the first pivot that is not positive (leaf64.h: early rejection)
-        const int want = (ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL) ? 1 : 0;
+        const int want = (ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL && ls->src_persistent) ? 1 : 0;
         if (want != ls->reject_on_device) {
             MNK_HIP(hipMemsetAsync(ls->info_dev.p + 2, want, sizeof(int), s));
             ls->reject_on_device = want;

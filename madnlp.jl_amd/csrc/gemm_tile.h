@@ -346,6 +346,45 @@ __device__ __forceinline__ void gemm_nt_epilogue(const v4f64 (&acc)[WT][WT], int
     }
 }
 
+// A diagonal tile accumulated in SUBTRACT order: acc = -C before the K-loop, C = -acc after it (the lower wave tiles; the
+// register layout of gemm_nt_epilogue).  The partial results are then C - (the products so far), which shrink as the
+// cancellation proceeds, instead of a sum that grows from zero to |C| and is subtracted at the end: a pivot that is the
+// difference of two numbers of size 1e13 agreeing to 15 digits keeps its sign (dag.hip).
+template <int WM, int WN, int WT>
+__device__ __forceinline__ void gemm_nt_load_neg_lower(v4f64 (&acc)[WT][WT], int64_t row0, int64_t col0, const double* C, int64_t ldc, int tid) {
+    constexpr int WS = 16 * WT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t wrow = row0 + wm * WS, wcol = col0 + wn * WS;
+    if (wrow + WS <= wcol) return;
+#pragma unroll
+    for (int ni = 0; ni < WT; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double* cp = C + (wcol + ni * 16 + l4 + 4 * r) * ldc + wrow + l15;
+#pragma unroll
+            for (int mi = 0; mi < WT; ++mi) acc[ni][mi][r] = -cp[mi * 16];
+        }
+}
+template <int WM, int WN, int WT>
+__device__ __forceinline__ void gemm_nt_store_neg_lower(const v4f64 (&acc)[WT][WT], int64_t row0, int64_t col0, double* C, int64_t ldc, int tid) {
+    constexpr int WS = 16 * WT;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t wrow = row0 + wm * WS, wcol = col0 + wn * WS;
+    if (wrow + WS <= wcol) return;
+#pragma unroll
+    for (int ni = 0; ni < WT; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* cp = C + (wcol + ni * 16 + l4 + 4 * r) * ldc + wrow + l15;
+#pragma unroll
+            for (int mi = 0; mi < WT; ++mi) cp[mi * 16] = -acc[ni][mi][r];
+        }
+}
+
 // One workgroup tile of C.  Every thread of the workgroup must call it with the same (tm, tn).
 template <int WM, int WN, int WT, int MODE, bool LDL_EPI, int DBG = 0, int BKT = BK>
 __device__ __forceinline__ void gemm_nt_tile(

@@ -131,8 +131,9 @@ struct mnk_ls {
     int early_reject = 0;        // option (with accept_only_pd): stop the static-pivot LDL^T at the first pivot that is not positive (leaf64.h); the factor
                                  // of a rejected matrix is then not usable and its inertia is a lower bound on num_neg
     int reject_on_device = -1;   // what info[2] on the device currently says
+    bool src_persistent = false; // the source of the last factorize! call outlives the call (KKT handles): a rejected factorization can be completed later
     bool factor_invalid = false; // the last factorization was rejected early: solve / get_factor refuse
-    int64_t early_rejects = 0, early_reject_col = -1;   // statistics ("early_rejects", "early_reject_col")
+    int64_t early_rejects = 0, early_reject_col = -1, early_reject_redone = 0;   // statistics ("early_rejects", "early_reject_col")
     int accept_only_pd = 0;      // option: the caller accepts positive definite matrices only: "not PD" from the static tier is final
     // Growth guard of the static-pivot tier (BUNCHKAUFMAN only).  The pivots are entries of the successive Schur complements,
     // so max|d_k| / max|a_ij| is a lower bound of the element growth of the elimination; dsytrf's pivoting bounds the growth,

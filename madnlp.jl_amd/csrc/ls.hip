@@ -935,6 +935,7 @@ int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
     if (rc) return rc;
     // (the KKT handle keeps aug_com until the next build_kkt!, so the pivoted tier can fetch the matrix again when
     // the inertia is asked for)
+    ls->src_persistent = true;   // (the handle keeps aug_com until the next build_kkt!)
     ls->retransfer = [ls, sc, w = std::weak_ptr<int>(sc->alive)]() {
         if (w.expired()) {
             set_error("factorize!: the KKT handle of the last factorize! call was destroyed before its inertia was fetched; the "
@@ -954,11 +955,12 @@ static int transfer_dense(mnk_ls* ls, const double* Adev, int64_t lda) {
     return 0;
 }
 
-static int factorize_dense_dev(mnk_ls* ls, const double* Adev, int64_t lda) {
+static int factorize_dense_dev(mnk_ls* ls, const double* Adev, int64_t lda, bool src_persistent = false) {
     int rc = ensure_wbuf(ls);
     if (rc) return rc;
     rc = transfer_dense(ls, Adev, lda);
     if (rc) return rc;
+    ls->src_persistent = src_persistent;   // (early rejection needs a source that outlives the call: ensure_complete_factor)
     ls->retransfer = [ls, Adev, lda]() { return transfer_dense(ls, Adev, lda); };  // (callers clear it when Adev's life ends)
     return mnk_ls_run_factorization(ls);
 }
@@ -979,7 +981,7 @@ int mnk_ls_factorize_dc_async(mnk_ls* ls, mnk_dc* dc) {
     MNK_REQUIRE(dc->order == ls->N, "mnk_ls_factorize_dc: order mismatch");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }   // (a factorize! of this solver pending in an open batch runs first)
-    int rc = factorize_dense_dev(ls, dc->aug.p, round_up(dc->order, PAD));
+    int rc = factorize_dense_dev(ls, dc->aug.p, round_up(dc->order, PAD), true);
     // the way back goes through the handle (its buffer may be reallocated, the handle may be destroyed before the inertia
     // of this asynchronous call is fetched)
     ls->retransfer = [ls, dc, w = std::weak_ptr<int>(dc->alive)]() {
@@ -1069,6 +1071,7 @@ int mnk_ls_factorize_csc(mnk_ls* ls, const int32_t* colptr, const int32_t* rowva
     };
     rc = transfer();
     if (rc) return rc;
+    ls->src_persistent = false;
     ls->retransfer = transfer;
     rc = mnk_ls_run_factorization(ls);
     if (!rc) {
@@ -1106,12 +1109,35 @@ int mnk_ls_check_solve(mnk_ls* ls) {
     return 0;
 }
 
+// A factorization that was stopped at its first non-positive pivot (early_reject) left no factor.  A caller that solves all the
+// same did not ask for the inertia, or overrules its own test: MadNLP does where it initializes the multipliers by least
+// squares and in the restoration phases' first steps (reference src/IPM/solver.jl:147-190, src/IPM/restoration.jl: factorize_wrapper!
+// followed by solve_refine_wrapper! without inertia_correction!).  The matrix is then factored again, to the end: early
+// rejection is an optimization of the rejected trials, never a change of what the solver can do.
+static int ensure_complete_factor(mnk_ls* ls, const char* who) {
+    if (ls->reject_on_device == 1) { int rc_i = mnk_ls_fetch_info(ls); if (rc_i) return rc_i; }   // (known when the pivots are)
+    if (!ls->factor_invalid) return 0;
+    if (!ls->retransfer) {
+        set_error("%s: the last factorization was stopped at its first non-positive pivot (early_reject) and its source is gone: "
+                  "there is no factor", who);
+        return -1;
+    }
+    const int keep = ls->early_reject;
+    ls->early_reject = 0;
+    int rc = ls->retransfer();
+    if (!rc) rc = mnk_ls_run_factorization(ls);
+    if (!rc) rc = mnk_ls_fetch_info(ls);
+    ls->early_reject = keep;
+    ++ls->early_reject_redone;
+    return rc;
+}
+
 int mnk_ls_solve(mnk_ls* ls, double* x, int64_t nrhs, int64_t ldx, int loc) {
     MNK_REQUIRE(ls && x, "mnk_ls_solve: NULL argument");
     { int rc_d = mnk_ls_sync_deferred_fact(ls); if (rc_d) return rc_d; }
     MNK_REQUIRE(ls->factorized, "mnk_ls_solve: factorize first");
-    if (ls->reject_on_device == 1) { int rc_i = mnk_ls_fetch_info(ls); if (rc_i) return rc_i; }   // (early rejection: known when the pivots are)
-    MNK_REQUIRE(!ls->factor_invalid, "mnk_ls_solve: the last factorization was stopped at its first non-positive pivot (early_reject): the matrix is not positive definite and there is no factor to solve with");
+    MNK_HIP(hipSetDevice(ls->ctx->device));
+    { int rc_f = ensure_complete_factor(ls, "mnk_ls_solve"); if (rc_f) return rc_f; }
     MNK_REQUIRE(nrhs >= 1 && ldx >= ls->N, "mnk_ls_solve: bad nrhs/ldx");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     if (ls->solve_abort && *ls->solve_abort != 0) {
@@ -1224,8 +1250,7 @@ int mnk_ls_get_factor(mnk_ls* ls, double* L, double* D, int loc) {
     MNK_REQUIRE(ls && L, "mnk_ls_get_factor: NULL argument");
     { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     MNK_REQUIRE(ls->factorized, "mnk_ls_get_factor: factorize first");
-    if (ls->reject_on_device == 1) { int rc_i = mnk_ls_fetch_info(ls); if (rc_i) return rc_i; }
-    MNK_REQUIRE(!ls->factor_invalid, "mnk_ls_get_factor: the last factorization was stopped at its first non-positive pivot (early_reject): there is no factor");
+    { int rc_f = ensure_complete_factor(ls, "mnk_ls_get_factor"); if (rc_f) return rc_f; }
     MNK_HIP(hipSetDevice(ls->ctx->device));
     hipStream_t s = ls->ctx->stream;
     if (loc == MNK_DEVICE) {
@@ -1257,6 +1282,7 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     // which bounded device-side wait expired last (info = -7): 1 bulk task / operand rows, 2 bulk task / chunk order, 3 gate on the bulk stream, 4 chain strip / diagonal block, 5 chain strip / bulk kernel's rows or band tiles; 0: none
     if (!strcmp(key, "timeout_site")) { *value = ls->last_timeout_site; return 0; }
     if (!strcmp(key, "early_rejects")) { *value = (double)ls->early_rejects; return 0; }       // factorizations stopped at their first non-positive pivot
+    if (!strcmp(key, "early_reject_redone")) { *value = (double)ls->early_reject_redone; return 0; }   // ... rejected factorizations completed after all because the caller solved
     if (!strcmp(key, "early_reject_col")) { *value = (double)ls->early_reject_col; return 0; } // ... the last valid pivot of the latest one
     if (!strcmp(key, "stall_ms_total")) { *value = ls->stall_ms_total; return 0; }      // what this solver's expired waits (fall-backs) have cost, host ms
     if (!strcmp(key, "stall_ms_process")) { *value = mnk_process_stall_ms(); return 0; }  // ... all solvers of the process

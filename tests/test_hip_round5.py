@@ -491,8 +491,8 @@ def test_early_rejection_of_matrices_that_are_not_positive_definite(ctx, case):
     the counts (reference src/KKT/Sparse/condensed.jl:138-141), so the static-pivot LDL' of a matrix that is NOT positive
     definite may stop at its first non-positive pivot, as dpotrf does (option early_reject, on for this KKT type), instead of
     running to the end as dsytrf does.  On OPF-shaped systems with an indefinite Hessian block: the verdict
-    (`is_inertia_correct`) equals LAPACK's for every regularization of a ladder; a rejected matrix reports num_neg >= 1 and no
-    usable factor (solve raises); it costs less than a full factorization; and the next positive definite matrix on the SAME
+    (`is_inertia_correct`) equals LAPACK's for every regularization of a ladder; a rejected matrix reports num_neg >= 1, and a
+    solve with it completes the factorization first (the full run's bits); it costs less than a full factorization; and the next positive definite matrix on the SAME
     solver factors and solves as if nothing had happened (bit-identical to a solver that never rejected anything)."""
     import time
     from tests.test_hip_c5 import _hip_sc
@@ -542,8 +542,13 @@ def test_early_rejection_of_matrices_that_are_not_positive_definite(ctx, case):
             seen_reject += 1
             assert ine_h[2] >= 1 and ine_f[2] + ine_f[1] >= 1
             assert ine_h[0] <= ine_f[0] + 64            # (pivots behind the stopping block count as negative)
-            with pytest.raises(mj.SolveException):
-                kh.linear_solver.solve_linear_system(b.copy())
+            # a caller that solves all the same (MadNLP's multiplier initialization and restoration phases factorize and solve
+            # without asking for the inertia) gets the factorization completed behind its back: the full run's bits
+            redone = kh.linear_solver.get_stat("early_reject_redone")
+            xh, xf = kh.linear_solver.solve_linear_system(b.copy()), kf.linear_solver.solve_linear_system(b.copy())
+            assert np.array_equal(xh, xf), dw
+            assert kh.linear_solver.get_stat("early_reject_redone") == redone + 1
+            assert kh.linear_solver.inertia() == ine_f      # and the complete counts
     assert seen_reject >= 1 and seen_accept >= 1
     assert kh.linear_solver.get_stat("early_rejects") >= seen_reject and kf.linear_solver.get_stat("early_rejects") == 0
     assert kh.linear_solver.get_stat("pp_fallbacks") == 0

@@ -6,7 +6,9 @@ and printed next to the golden's history (`tests/golden/acopf_case1354_oracle.js
 every trial that the HIP back-end REJECTED (wrong inertia or refinement failure), and of every trial of an iteration whose
 del_w differs from the golden's, is copied to the host and factorized by dsytrf (the oracle's LapackCPUSolver): the two
 inertia verdicts side by side.
-usage: [REPLAY=1] python tools/acopf_trajectory.py [case] > profiles/r05_acopf_trajectory.txt"""
+With PIVOTS=1 (and REPLAY=1, EARLY_REJECT=0) the first matrix on which the static tier counts one negative pivot and dsytrf
+none is taken apart: the pivot in question from the HIP factor, from an unpivoted LDL' in numpy fp64 and in 80-bit long double.
+usage: [REPLAY=1 [PIVOTS=1 EARLY_REJECT=0]] python tools/acopf_trajectory.py [case] > profiles/r05_acopf_trajectory.txt"""
 import json
 import os
 for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
@@ -117,4 +119,59 @@ if replay:
         print(f"k={t['k']} trial {t['trial']} del_w={t['del_w']:.3g}: HIP {t['inertia']} ({'pivoted' if t['bk'] else 'static'} tier, "
               f"{'wrong inertia' if not t['correct'] else 'refinement failed'}) | dsytrf {tuple(int(v) for v in ine)} "
               f"({time.perf_counter() - t1:.1f} s) | max|K| {np.abs(nz).max():.3e} min|diag| {np.abs(Kl.diagonal()).min():.3e}")
+
+def ldl_nopivot(A, dtype):
+    """Unpivoted LDL' of a dense symmetric matrix in `dtype`, right-looking by 64-column blocks (the static order of the
+    HIP tier, another summation order); returns D."""
+    A = np.array(A, dtype=dtype, order="F")
+    n = A.shape[0]
+    d = np.zeros(n, dtype=dtype)
+    for j0 in range(0, n, 64):
+        j1 = min(n, j0 + 64)
+        for j in range(j0, j1):
+            d[j] = A[j, j]
+            A[j + 1:, j] /= d[j]
+            if j + 1 < j1:
+                A[j + 1:, j + 1:j1] -= np.outer(A[j + 1:, j] * d[j], A[j + 1:j1, j])
+        if j1 < n:
+            W = A[j1:, j0:j1] * d[j0:j1]
+            A[j1:, j1:] -= W @ A[j1:, j0:j1].T
+    return d
+
+
+if os.environ.get("PIVOTS", "0") != "0" and replay:
+    # The two pivots side by side: the first rejected matrix on which the static tier counts ONE negative pivot and dsytrf none.
+    from oracle.lapack_cpu import BUNCHKAUFMAN, LapackCPUSolver
+    import scipy.linalg as sla
+    for t in sd.trials:
+        if t["mat"] is None or t["inertia"][2] != 1 or t["inertia"][1] != 0:
+            continue
+        colptr, rowval, nz = t["mat"]
+        n = len(colptr) - 1
+        Kl = sp.csc_matrix((nz, rowval, colptr), shape=(n, n))
+        dense = np.asfortranarray((Kl + sp.tril(Kl, -1).T).toarray())
+        if tuple(int(v) for v in LapackCPUSolver(dense, BUNCHKAUFMAN).factorize().inertia()) != (n, 0, 0):
+            continue
+        ls = mj.HipLinearSolver(dense, ctx, mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+        ls.set_option("accept_only_pd", 1); ls.set_option("early_reject", 0)
+        ls.factorize()
+        Lh, Dh = ls.get_factor()
+        pv = int(np.argmin(Dh))
+        lead = dense[:pv + 1, :pv + 1]
+        d64 = ldl_nopivot(lead, np.float64)
+        t1 = time.perf_counter()
+        d80 = ldl_nopivot(lead, np.longdouble)
+        sub = float(np.sum(Lh[pv, :pv] ** 2 * Dh[:pv]))
+        ev = sla.eigvalsh(lead, subset_by_index=[0, 1])
+        print(f"# pivots side by side: k={t['k']} trial {t['trial']} del_w={t['del_w']:.3g}; static order, pivot index {pv} of {n} "
+              f"(variable block: {'qg' if pv >= 2 * nlp.nbus + nlp.ngen else 'pg' if pv >= 2 * nlp.nbus else 'vm' if pv >= nlp.nbus else 'va'})")
+        print(f"#   K[p,p] = {dense[pv, pv]:.17e}   sum_j L[p,j]^2 D[j] (HIP factor) = {sub:.17e}   max|K| = {np.abs(nz).max():.3e}")
+        print(f"#   D[p]: HIP static LDL' (fp64 MFMA, left-looking 128-tiles) {Dh[pv]:+.6e} | numpy fp64 right-looking {float(d64[pv]):+.6e} | "
+              f"80-bit long double right-looking {float(d80[pv]):+.6e} ({time.perf_counter() - t1:.0f} s) | dsytrf: all {n} pivots positive")
+        print(f"#   negative D entries: HIP {int((Dh < 0).sum())}, numpy fp64 {int((d64 < 0).sum())}, long double {int((d80 < 0).sum())} (leading block); "
+              f"two smallest eigenvalues of the leading {pv + 1} x {pv + 1} block (dsyevr): {ev[0]:+.3e}, {ev[1]:+.3e}")
+        np.savez_compressed(os.path.join(ROOT, "gpurun_out", f"acopf_k{t['k']}_trial{t['trial']}_matrix.npz"), colptr=colptr, rowval=rowval, nz=nz,
+                            pivot=pv, d_hip=Dh[pv], d_fp64=float(d64[pv]), d_ld=float(d80[pv]))
+        ls.close()
+        break
 sd.cb.close(); sd.K.close(); sd.kkt.close()
