@@ -361,6 +361,7 @@ int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int l
         hipLaunchKernelGGL(dense_aug_kernel, egrid, dim3(256), 0, s, dc->aug.p, ldk, ordpad, dc->hess.p, dc->jac.p,
                            dc->m, dc->n, dc->ns, dc->d_ind_ineq.p, ex->ineq_slot.p, dc->pr_diag.p, dc->du_diag.p);
         MNK_HIP(hipGetLastError());
+        dc->mirror_pending = false;
         return 0;
     }
     if (dc->ns > 0) {
@@ -378,8 +379,9 @@ int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int l
                                 dc->aug.p, ldk, nullptr, nullptr, 0, nullptr);
         if (rc) return rc;
     }
-    dim3 mgrid((unsigned)((dc->order + 31) / 32), (unsigned)((dc->order + 31) / 32));
-    hipLaunchKernelGGL(mirror_kernel, mgrid, dim3(256), 0, s, dc->aug.p, ldk, dc->order);
+    // (the upper triangle: nothing on the path reads it -- the factorization copies the lower one -- so it is written when
+    // somebody asks for the matrix, mnk_dc_get_aug)
+    dc->mirror_pending = true;
     MNK_HIP(hipGetLastError());
     return 0;
 }
@@ -388,6 +390,12 @@ int mnk_dc_get_aug(mnk_dc* dc, double* out, int loc) {
     MNK_REQUIRE(dc && out, "mnk_dc_get_aug: NULL argument");
     MNK_HIP(hipSetDevice(dc->ctx->device));
     const int64_t ldk = round_up(dc->order, PAD);
+    if (dc->mirror_pending) {
+        dim3 mgrid((unsigned)((dc->order + 31) / 32), (unsigned)((dc->order + 31) / 32));
+        hipLaunchKernelGGL(mirror_kernel, mgrid, dim3(256), 0, dc->ctx->stream, dc->aug.p, ldk, dc->order);
+        MNK_HIP(hipGetLastError());
+        dc->mirror_pending = false;
+    }
     if (loc == MNK_DEVICE)
         MNK_HIP(hipMemcpy2DAsync(out, dc->order * sizeof(double), dc->aug.p, ldk * sizeof(double), dc->order * sizeof(double),
                                  dc->order, hipMemcpyDeviceToDevice, dc->ctx->stream));

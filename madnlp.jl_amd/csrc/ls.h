@@ -35,6 +35,7 @@ struct mnk_sc {
 struct mnk_dc {
     mnk_ctx* ctx = nullptr;
     int condensed = 1;
+    bool mirror_pending = false;   // build_kkt! wrote the lower triangle only (all the factorization reads); mnk_dc_get_aug mirrors it on demand
     int64_t n = 0, m = 0, ns = 0, n_eq = 0, order = 0;
     std::vector<int64_t> ind_ineq, ind_eq;
     mnk::DevBuf<int64_t> d_ind_ineq, d_ind_eq;

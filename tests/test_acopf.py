@@ -300,13 +300,21 @@ def test_device_resident_case1354_run_matches_the_oracle_golden(gpu_ctx):
             break
         assert abs(a.del_w - b["del_w"]) <= 1e-12 * max(1.0, abs(b["del_w"])), (kk, a.del_w, b["del_w"])
         together = kk + 1
-    assert together >= 6, f"the device run left the golden's trajectory after {together} iterations"
+    assert together >= 8, f"the device run left the golden's trajectory after {together} iterations"
+    # Round 5: with the diagonal tiles accumulated in subtract order the run follows the golden's trajectory to
+    # the end -- primal infeasibility within 2 % at EVERY iteration (measured: <= 0.5 %; the build before it was off by a
+    # factor of six at k = 9 and needed 10 Richardson steps per solve from there) -- with one or two refinement steps per solve
+    for kk in range(0, min(sd.cnt.k, gold["iterations"])):
+        a, b = hh.get(kk + 1), gh.get(kk + 1)
+        if a is not None and b is not None:
+            assert abs(a.inf_pr - b["inf_pr"]) <= 2e-2 * abs(b["inf_pr"]) + 1e-9, (kk, a.inf_pr, b["inf_pr"])
+    assert sd.cnt.backsolve_cnt <= 40, sd.cnt.backsolve_cnt
     # every rejection is an inertia verdict (never a failed refinement), the static-pivot tier produced every factor, and the
     # corrections cost at most a handful of factorizations more than the oracle back-end's
     assert all(t["correct"] or not t["ok"] for t in trials)
     assert not any(t["correct"] and not t["ok"] for t in trials), "a Richardson refinement failed"
     assert not any(t["bk"] for t in trials)
-    assert sd.cnt.factorization_cnt <= gold["factorizations"] + 10, (sd.cnt.factorization_cnt, gold["factorizations"])
+    assert sd.cnt.factorization_cnt <= gold["factorizations"] + 8, (sd.cnt.factorization_cnt, gold["factorizations"])
     # ---- replay: the matrices of the first two corrected iterations, as the device assembled them, through dsytrf -- where
     # the curvature is real the two back-ends give the same verdict (rejected: not positive definite; accepted: (n, 0, 0))
     from oracle.lapack_cpu import BUNCHKAUFMAN as O_BK, LapackCPUSolver
