@@ -195,6 +195,9 @@ constexpr long PP_SPIN_LIMIT = 1L << 20;  // ~0.5 s
                            // profiles/r05_leaf_lab.txt): the scalar 4x4 factorizations, 57 % of the leaf, are repeated by every wave and the
                            // exchanges through LDS cost what the split of the MFMAs saves.  Diagnostic builds only.
 #endif
+#ifndef MNK_DIAG_RACY_PUB
+#define MNK_DIAG_RACY_PUB 0
+#endif
 #ifndef MNK_DIAG_NO_EARLY
 #define MNK_DIAG_NO_EARLY 0   // (-DMNK_DIAG_NO_EARLY=1: a diagnostic build without the chain's early diagonal update)
 #endif
@@ -573,8 +576,14 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         // task-DAG schedule: the strip's rows are final through a whole tile column after every second block
         const bool pub_front = dag.front != nullptr && ((j & 1) != 0 || j == jmax);
         if (diag_strip || pub_front) {
+#if MNK_DIAG_RACY_PUB   // (timing only, results void: what the stores' completion in front of the publication costs the chain)
+            if (!diag_strip) {
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#if MNK_DIAG_RACY_PUB
+            }
+#endif
             if (tid == 0) {
                 if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
