@@ -43,6 +43,9 @@ struct mnk_schur {
     mnk::DevBuf<char> recs;                 // device copies of the launch records
     mnk::DevBuf<int> fast_k;                // the scenarios on the grouped path
     int64_t chunk = 32;                     // scenarios per pass of the grouped build (their X / V / P buffers are reused)
+    char* stage = nullptr;                  // pinned host memory: the launch records + scenario list of one pass (no synchronizing upload)
+    size_t stage_bytes = 0;
+    hipEvent_t stage_ev = nullptr;          // recorded behind the last upload from `stage`
     mnk::DevBuf<double> Sown;               // nd x nd: the handle's own copy of S (mnk_schur_s_buffer: callers without device memory of their own)
     mnk::DevBuf<double> hostrk, hostrd;     // mnk_schur_solve with host vectors: ns x blk | 2 nd (right-hand side, contribution)
 };
@@ -199,6 +202,8 @@ int mnk_schur_destroy(mnk_schur* h) {
     for (mnk_ls* l : h->ls_k) mnk_ls_destroy(l);
     if (h->ls_s) mnk_ls_destroy(h->ls_s);
     mnk_ctx* ctx = h->ctx;
+    if (h->stage) { mnk::LaunchLock lock; mnk::quiesce_persistent(); (void)hipHostFree(h->stage); }
+    if (h->stage_ev) (void)hipEventDestroy(h->stage_ev);
     delete h;
     mnk_ctx_child_gone(ctx);
     return 0;
@@ -272,8 +277,23 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         const int* fk = fast.data() + c0;
         const bool ldl = h->ls_k[fk[0]]->algo == MNK_LDL;
         const int nstep = (int)(Npb / NBI);
-        std::vector<mnk::TrsmBatchRec> tr(nf);
-        std::vector<mnk::GemmBatchRec> gr((size_t)nstep * nf);
+        // the records of this pass go through pinned host memory, laid out like the device buffer: one asynchronous copy (a
+        // pageable source costs the launch mutex and a stream synchronization per upload -- three per pass)
+        const size_t gr_off = (size_t)h->ns * sizeof(mnk::TrsmBatchRec);
+        const size_t fk_off = gr_off + (size_t)nstep * h->chunk * sizeof(mnk::GemmBatchRec);
+        const size_t need = fk_off + (size_t)h->chunk * sizeof(int);
+        if (h->stage_ev == nullptr) MNK_HIP(hipEventCreateWithFlags(&h->stage_ev, hipEventDisableTiming));
+        else MNK_HIP(hipEventSynchronize(h->stage_ev));   // (the previous pass' upload has left the staging memory)
+        if (h->stage_bytes < need) {
+            mnk::LaunchLock lock;
+            if (h->stage) { mnk::quiesce_persistent(); (void)hipHostFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+            MNK_HIP(hipHostMalloc((void**)&h->stage, need, hipHostMallocDefault));
+            h->stage_bytes = need;
+        }
+        mnk::TrsmBatchRec* tr = reinterpret_cast<mnk::TrsmBatchRec*>(h->stage);
+        mnk::GemmBatchRec* gr = reinterpret_cast<mnk::GemmBatchRec*>(h->stage + gr_off);
+        int* fk_st = reinterpret_cast<int*>(h->stage + fk_off);
+        for (int i = 0; i < nf; ++i) fk_st[i] = fk[i];
         for (int i = 0; i < nf; ++i) {
             mnk_ls* ls = h->ls_k[fk[i]];
             double* X = h->Xall.p + (size_t)i * ndp * Npb;
@@ -286,9 +306,9 @@ int mnk_schur_build_local(mnk_schur* h, const double* S0, int64_t lds0, int loc_
         char* rdev = h->recs.p;
         mnk::TrsmBatchRec* tr_dev = reinterpret_cast<mnk::TrsmBatchRec*>(rdev);
         mnk::GemmBatchRec* gr_dev = reinterpret_cast<mnk::GemmBatchRec*>(rdev + (size_t)h->ns * sizeof(mnk::TrsmBatchRec));
-        MNK_HIP(mnk::h2d_copy(tr_dev, tr.data(), tr.size() * sizeof(mnk::TrsmBatchRec), s));
-        MNK_HIP(mnk::h2d_copy(gr_dev, gr.data(), gr.size() * sizeof(mnk::GemmBatchRec), s));
-        MNK_HIP(mnk::h2d_copy(h->fast_k.p, fk, (size_t)nf * sizeof(int), s));
+        MNK_HIP(hipMemcpyAsync(rdev, h->stage, gr_off + (size_t)nstep * nf * sizeof(mnk::GemmBatchRec), hipMemcpyHostToDevice, s));
+        MNK_HIP(hipMemcpyAsync(h->fast_k.p, fk_st, (size_t)nf * sizeof(int), hipMemcpyHostToDevice, s));
+        MNK_HIP(hipEventRecord(h->stage_ev, s));
         hipLaunchKernelGGL(schur_copy_batch_kernel, dim3((unsigned)((ndp * Npb + 255) / 256), (unsigned)nf), dim3(256), 0, s,
                            h->Xall.p, ndp, Npb, h->C.p, nd, blk, h->fast_k.p);
         const int64_t ldf = h->ls_k[fk[0]]->ld;
