@@ -495,6 +495,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                     for (int r = 0; r < 4; ++r) Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v[r];
                 }
             const int64_t jb = (p0 >> 6) + j;
+            if (ptr_tr) ptr_tr[7] = wall_clock64();   // (trace: the leaf starts)
             potrf64w_core<LDL, WT>(Lt, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol, nullptr,
                                    nullptr, dag.vmax);
             if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -510,6 +511,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         }
         // ---- wait for the diagonal block j, X = T L_jj^-T
         pp_wait<NB, LDL>(prog, j, nb, epoch16 + j + 1, seen, info, pp_limit, dag.dbg != nullptr ? dag.dbg + 8 * t : nullptr, (int)(p0 >> 8), t);
+        if (ptr_tr && j == t - 1) ptr_tr[6] = wall_clock64();   // (trace, tools/chain_steps.py: the block in front of this strip's own seen)
         const int64_t jb = (p0 >> 6) + j;
         const double* Dblk = dblk0 + jb * 4096;
         const double* Iv16 = inv0 + jb * 1024;
