@@ -68,8 +68,11 @@ def test_gemm_nt_tiles(ctx, mode, M, N, K):
         ref = P
     else:
         ref = C0 - P if mode == 2 else C0 + P
-        # only 64x64 wave tiles touching the lower triangle are defined
-        bi, bj = np.arange(M)[:, None] // 64, np.arange(N)[None, :] // 64
+        # only the wave tiles touching the lower triangle are defined: 64 x 64 (mode 2; mode 4 on large matrices), 32 x 32 where
+        # mode 4 takes the 64 x 64 workgroup tiling (few tiles: the Gram product of the dense condensed system) -- the 32-row
+        # rule is the part both tilings define
+        g = 64 if mode == 2 else 32
+        bi, bj = np.arange(M)[:, None] // g, np.arange(N)[None, :] // g
         mask = bi >= bj
         got, ref = np.where(mask, got, 0.0), np.where(mask, ref, 0.0)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * K)
