@@ -1163,7 +1163,11 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     ls->inv_done = 0;
     ls->t_fact_launch_ms = mnk_host_ms();
     {   // info[2]: the leaf stops the factorization at the first pivot that is not positive (leaf64.h: early rejection)
-        const int want = (ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL && ls->src_persistent) ? 1 : 0;
+        // NOT inside an open factorization batch: there the instances share ONE bulk launch, and an instance that dies early
+        // was seen to corrupt its neighbours (tools/dbg_batch_reject.py: spurious rejections and wrong tiles in ~1 of 3
+        // rounds, once a memory fault; none in 12 rounds with the rejected instances running to their end) -- cause not found,
+        // so a batch factors every instance completely, as rounds 3-4 did.
+        const int want = (ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL && ls->src_persistent && !mnk_batch_active()) ? 1 : 0;
         if (want != ls->reject_on_device) {
             MNK_HIP(hipMemsetAsync(ls->info_dev.p + 2, want, sizeof(int), s));
             ls->reject_on_device = want;

@@ -1117,6 +1117,7 @@ int mnk_ls_check_solve(mnk_ls* ls) {
 static int ensure_complete_factor(mnk_ls* ls, const char* who) {
     if (ls->reject_on_device == 1) { int rc_i = mnk_ls_fetch_info(ls); if (rc_i) return rc_i; }   // (known when the pivots are)
     if (!ls->factor_invalid) return 0;
+    { static const bool peek = getenv("MNK_DBG_NO_REDO") != nullptr; if (peek) return 0; }   // (diagnostics: look at what a rejected factorization left)
     if (!ls->retransfer) {
         set_error("%s: the last factorization was stopped at its first non-positive pivot (early_reject) and its source is gone: "
                   "there is no factor", who);

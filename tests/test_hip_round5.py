@@ -557,3 +557,57 @@ def test_early_rejection_of_matrices_that_are_not_positive_definite(ctx, case):
         full = t_full[:seen_reject]
         assert sum(rej) <= sum(full) * 1.02, (rej, full)
     kh.close(); kf.close()
+
+
+def test_a_batch_in_which_some_instances_are_indefinite():
+    """A factorization batch (mnk_factorize_batch_begin / _end: the C5 shape with real interior-point loops) in which some
+    scenarios' trial matrices are indefinite while their neighbours' are fine.  Six case1354pegase-shaped instances on one
+    context, two of them with an indefinite Hessian block, alternating rounds.  Early rejection is NOT armed inside a batch
+    (csrc/factor.hip: an instance dying early in the merged launch corrupted its neighbours -- found by this test's first
+    version, tools/dbg_batch_reject.py): the indefinite instances are factored to the end and report their negative pivots,
+    the other four are factored as if they were alone -- the task-DAG schedule, no fall-back, L and D bit-identical to lone
+    factorizations -- in every round, and the two get positive definite values on the SAME solvers in between."""
+    from tests.test_hip_c5 import _front
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
+    bad = {1, 4}
+    insts = []
+    for i in range(6):
+        # (the indefinite variant has Hessian entries of its own: a "bad" instance lives on that pattern, and its positive
+        # definite values are the same matrix with delta_w = 100 on the primal diagonal -- K is indefinite below ~50)
+        P = opf_shaped("case1354pegase", seed=4000 + i, du=1e-8, **(dict(indefinite=True, sigma_s_decades=2.0) if i in bad else {}))
+        kh = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                         opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+        mk = lambda pr: dict(jac=torch.from_numpy(P.jac).to(dev), hess=torch.from_numpy(P.hess).to(dev),  # noqa: E731
+                             pr=torch.from_numpy(pr).to(dev), du=torch.from_numpy(P.du_diag).to(dev))
+        insts.append(dict(n=P.n, kh=kh, good=mk(P.pr_diag + 100.0 if i in bad else P.pr_diag), bad=mk(P.pr_diag) if i in bad else None))
+    torch.cuda.synchronize()
+    ref = []
+    for it in insts:      # lone factorizations of the positive definite values
+        _front(it["kh"], st, it["good"])
+        assert it["kh"].linear_solver.inertia() == (it["n"], 0, 0)
+        Lf, D = it["kh"].linear_solver.get_factor_device()
+        ref.append((torch.tril(Lf).clone(), D.clone()))
+    for rnd in range(6):
+        use_bad = rnd % 2 == 0
+        before = [it["kh"].linear_solver.get_stat("early_rejects") for it in insts]
+        with mj.factorize_batch():
+            for it in insts:
+                _front(it["kh"], st, it["bad"] if (use_bad and it["bad"] is not None) else it["good"])
+        for i, it in enumerate(insts):
+            M = it["kh"].linear_solver
+            with torch.cuda.stream(st):
+                ine = M.inertia()
+            assert M.get_stat("panel_algo") == 5.0 and M.get_stat("pp_fallbacks") == 0.0, (rnd, i)
+            if use_bad and i in bad:
+                assert not it["kh"].is_inertia_correct(*ine) and ine[2] >= 1 and sum(ine) == it["n"], (rnd, i, ine)
+                assert M.get_stat("early_rejects") == before[i]       # (run to the end: not armed in a batch)
+            else:
+                assert ine == (it["n"], 0, 0), (rnd, i, ine)
+                assert M.get_stat("early_rejects") == before[i]
+                Lf, D = M.get_factor_device()
+                assert torch.equal(torch.tril(Lf), ref[i][0]) and torch.equal(D, ref[i][1]), (rnd, i)
+    for it in insts:
+        it["kh"].close()
+    ctx.close()
