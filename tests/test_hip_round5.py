@@ -559,14 +559,18 @@ def test_early_rejection_of_matrices_that_are_not_positive_definite(ctx, case):
     kh.close(); kf.close()
 
 
-def test_a_batch_in_which_some_instances_are_indefinite():
+@pytest.mark.parametrize("alg", ["BUNCHKAUFMAN", "CHOLESKY"])
+def test_a_batch_in_which_some_instances_are_indefinite(alg):
     """A factorization batch (mnk_factorize_batch_begin / _end: the C5 shape with real interior-point loops) in which some
     scenarios' trial matrices are indefinite while their neighbours' are fine.  Six case1354pegase-shaped instances on one
     context, two of them with an indefinite Hessian block, alternating rounds.  Early rejection is NOT armed inside a batch
     (csrc/factor.hip: an instance dying early in the merged launch corrupted its neighbours -- found by this test's first
     version, tools/dbg_batch_reject.py): the indefinite instances are factored to the end and report their negative pivots,
     the other four are factored as if they were alone -- the task-DAG schedule, no fall-back, L and D bit-identical to lone
-    factorizations -- in every round, and the two get positive definite values on the SAME solvers in between."""
+    factorizations -- in every round, and the two get positive definite values on the SAME solvers in between.
+    CHOLESKY: the indefinite members break down and die early (nothing can be done about that); the first look at any
+    member's result then finds a dead member and the surviving members are factored again on their own (statistic
+    `batch_redone`), to the same bits."""
     from tests.test_hip_c5 import _front
     dev = torch.device("cuda", 0)
     st = torch.cuda.Stream(dev)
@@ -578,7 +582,7 @@ def test_a_batch_in_which_some_instances_are_indefinite():
         # definite values are the same matrix with delta_w = 100 on the primal diagonal -- K is indefinite below ~50)
         P = opf_shaped("case1354pegase", seed=4000 + i, du=1e-8, **(dict(indefinite=True, sigma_s_decades=2.0) if i in bad else {}))
         kh = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
-                                         opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+                                         opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=getattr(mj, alg)))
         mk = lambda pr: dict(jac=torch.from_numpy(P.jac).to(dev), hess=torch.from_numpy(P.hess).to(dev),  # noqa: E731
                              pr=torch.from_numpy(pr).to(dev), du=torch.from_numpy(P.du_diag).to(dev))
         insts.append(dict(n=P.n, kh=kh, good=mk(P.pr_diag + 100.0 if i in bad else P.pr_diag), bad=mk(P.pr_diag) if i in bad else None))
@@ -601,11 +605,16 @@ def test_a_batch_in_which_some_instances_are_indefinite():
                 ine = M.inertia()
             assert M.get_stat("panel_algo") == 5.0 and M.get_stat("pp_fallbacks") == 0.0, (rnd, i)
             if use_bad and i in bad:
-                assert not it["kh"].is_inertia_correct(*ine) and ine[2] >= 1 and sum(ine) == it["n"], (rnd, i, ine)
-                assert M.get_stat("early_rejects") == before[i]       # (run to the end: not armed in a batch)
+                assert not it["kh"].is_inertia_correct(*ine) and sum(ine) == it["n"], (rnd, i, ine)
+                assert ine[2] >= 1 or alg == "CHOLESKY"               # (a Cholesky breakdown reports (0, n, 0))
+                assert M.get_stat("early_rejects") == before[i] or alg == "CHOLESKY"   # (LDL': run to the end, not armed in a batch)
             else:
                 assert ine == (it["n"], 0, 0), (rnd, i, ine)
                 assert M.get_stat("early_rejects") == before[i]
+                if alg == "CHOLESKY":   # a member died in this round <=> the survivors were redone
+                    assert M.get_stat("batch_redone") == (rnd // 2 + 1 if use_bad else (rnd + 1) // 2), (rnd, i, M.get_stat("batch_redone"))
+                else:
+                    assert M.get_stat("batch_redone") == 0
                 Lf, D = M.get_factor_device()
                 assert torch.equal(torch.tril(Lf), ref[i][0]) and torch.equal(D, ref[i][1]), (rnd, i)
     for it in insts:

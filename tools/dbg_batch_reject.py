@@ -15,7 +15,7 @@ insts = []
 for i in range(6):
     P = opf_shaped("case1354pegase", seed=4000 + i, du=1e-8, **(dict(indefinite=True, sigma_s_decades=2.0) if i in bad else {}))
     kh = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub, ctx=ctx,
-                                     opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN), early_reject=early)
+                                     opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=getattr(mj, os.environ.get("ALG", "BUNCHKAUFMAN"))), early_reject=early)
     mk = lambda pr, P=P: dict(jac=torch.from_numpy(P.jac).to(dev), hess=torch.from_numpy(P.hess).to(dev), pr=torch.from_numpy(pr).to(dev), du=torch.from_numpy(P.du_diag).to(dev))
     insts.append(dict(n=P.n, kh=kh, good=mk(P.pr_diag + 100.0 if i in bad else P.pr_diag), bad=mk(P.pr_diag) if i in bad else None))
 torch.cuda.synchronize()
@@ -70,4 +70,12 @@ for rnd in range(rounds):
                   "rejects", M.get_stat("early_rejects"), "fallbacks", M.get_stat("pp_fallbacks"), "site", M.get_stat("timeout_site"),
                   "| differing tiles", len(rows), "first (row, col)", (int(rows[0]), int(cols[0])) if len(rows) else None,
                   "tile cols", sorted(set(cols.tolist()))[:12], "tile rows", sorted(set(rows.tolist()))[:12])
+            if 0 < len(rows) <= 8:
+                for (tr, tc) in zip(rows.tolist(), cols.tolist()):
+                    got = Lt[tr * 128:(tr + 1) * 128, tc * 128:(tc + 1) * 128]
+                    dd = dL[tr * 128:(tr + 1) * 128, tc * 128:(tc + 1) * 128] > 0
+                    rr = dd.any(dim=1).nonzero().flatten().tolist(); cc = dd.any(dim=0).nonzero().flatten().tolist()
+                    close = [float((got - ref[k][0][tr * 128:(tr + 1) * 128, tc * 128:(tc + 1) * 128]).abs().max()) for k in range(len(ref))]
+                    print(f"     tile ({tr},{tc}): rows {rr[0]}..{rr[-1]} ({len(rr)}) cols {cc[0]}..{cc[-1]} ({len(cc)}) of the tile differ; max|got - ref_k| for k=0..5: "
+                          + " ".join(f"{c:.2e}" for c in close) + f"; nan {int(torch.isnan(got).sum())} zeros {int((got == 0).sum())} of {got.numel()}")
 print(f"EARLY={int(early)}: {rounds} rounds, {anomalies} anomalies")
