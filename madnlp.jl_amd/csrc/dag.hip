@@ -32,8 +32,6 @@
 #include <atomic>
 #include <cfloat>
 #include <climits>
-#include <memory>
-#include <mutex>
 #include <vector>
 
 #include "gemm_tile.h"
@@ -422,8 +420,16 @@ __global__ __launch_bounds__(256, 3) void dag_bulk_kernel(DagArgs a) {
         // One task; false: the instance's factorization has failed (a non-positive Cholesky pivot, an expired wait) -- the
         // task is dropped, nothing is published, and every other task of that instance will be dropped the same way (their
         // waits see `info`); tasks of OTHER instances of a batch are not affected.
+        // (`dead` must be the same for every wave of the workgroup: ONE thread looks and the answer goes through LDS.  Round 4
+        // let every thread look for itself -- a member of a batch that died between two waves' looks sent some waves of the
+        // workgroup into the task and the others on to the next one, sharing the LDS tiles and s_val: wrong tiles in OTHER
+        // members, spurious breakdowns, once a memory fault; found in round 5, tools/dbg_batch_reject.py.)
+        if (tid == 0) s_val = __hip_atomic_load(in->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 1 : 0;
+        __syncthreads();
+        const bool dead = s_val != 0;
+        __syncthreads();
         auto run_task = [&]() __attribute__((always_inline)) -> bool {
-        if (__hip_atomic_load(in->info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (dead) return false;
         // k-tiles [0, limit) of this chunk have final operands; the gate blocks at the first k-tile of a tile column that is
         // not final yet (a rare event: the queue is sorted by readiness)
         int limit = 0;
@@ -1148,50 +1154,6 @@ int mnk_ls_run_factorization_dag(mnk_ls* ls) {
 // arithmetic per instance is exactly that of a single factorization (same task list, same order per tile): bit-identical
 // factors.  Reference behaviour: distinct solver instances are driven concurrently (src/KKT/Schur/schur.jl:953).
 // ---------------------------------------------------------------------------------------------------------------------
-// The members of one merged launch.  A member whose factorization DIES early in the launch -- a Cholesky breakdown, an expired
-// wait -- was seen to corrupt its neighbours (round 5, tools/dbg_batch_reject.py: wrong tiles and spurious breakdowns of positive
-// definite neighbours in one of three rounds with a dying member, none in 22 rounds without; cause not found).  So the first
-// look at any member's result looks at ALL members' status words, and if one died, every member is factored again on its own
-// (mnk_ls_fetch_info).  Costs a batch without failures nothing but the wait for its slowest member.
-struct mnk_batch_group {
-    std::mutex m;
-    std::vector<mnk_ls*> members;
-    bool checked = false, poisoned = false;
-};
-void mnk_batch_group_leave(mnk_ls* ls) {
-    std::shared_ptr<mnk_batch_group> grp = ls->bgroup;
-    if (!grp) return;
-    {
-        std::lock_guard<std::mutex> lk(grp->m);
-        grp->members.erase(std::remove(grp->members.begin(), grp->members.end(), ls), grp->members.end());
-    }
-    ls->bgroup.reset();
-}
-int mnk_batch_group_check(mnk_ls* ls, bool* redo) {
-    *redo = false;
-    std::shared_ptr<mnk_batch_group> grp = ls->bgroup;
-    if (!grp) return 0;
-    {
-        std::lock_guard<std::mutex> lk(grp->m);
-        if (!grp->checked) {
-            for (mnk_ls* mbr : grp->members) {
-                MNK_HIP(hipSetDevice(mbr->ctx->device));
-                if (mbr->ev_info_recorded) MNK_HIP(hipEventSynchronize(mbr->ev_info));
-                else MNK_HIP(mnk::stream_wait(mbr->ctx->stream));
-                const int hinfo = (int)(long long)((volatile unsigned long long*)mbr->pin)[3];
-                if (hinfo < 0 || (hinfo > 0 && mbr->algo == MNK_CHOLESKY)) grp->poisoned = true;   // (died before its end)
-            }
-            grp->checked = true;
-            MNK_HIP(hipSetDevice(ls->ctx->device));
-        }
-        // EVERY member is redone: a neighbour that was made to break down looks like the member that broke down by itself (the
-        // latter fails again, early, on its own)
-        *redo = grp->poisoned;
-    }
-    mnk_batch_group_leave(ls);
-    return 0;
-}
-
 namespace {
 struct BatchState {
     int depth = 0;             // (begin / end pairs nest: the outermost end launches)
@@ -1327,11 +1289,6 @@ static int batch_run_group(std::vector<mnk_ls*>& g) {
     if (rc) return rc;
     // everybody's stream continues behind the batch
     MNK_HIP(hipEventRecord(l0->ev_defer, h));
-    {
-        auto grp = std::make_shared<mnk_batch_group>();
-        grp->members = g;
-        for (mnk_ls* ls : g) { mnk_batch_group_leave(ls); ls->bgroup = grp; }
-    }
     for (mnk_ls* ls : g) {
         if (ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(ls->ctx->stream, l0->ev_defer, 0));
         batch_mark_done(ls);
@@ -1498,11 +1455,6 @@ static int batch_run_group_small(std::vector<mnk_ls*>& g) {
         if (rc) return rc;
     }
     MNK_HIP(hipEventRecord(l0->ev_defer, h));
-    {
-        auto grp = std::make_shared<mnk_batch_group>();
-        grp->members = g;
-        for (mnk_ls* ls : g) { mnk_batch_group_leave(ls); ls->bgroup = grp; }
-    }
     for (mnk_ls* ls : g) {
         if (ls->ctx->stream != h) MNK_HIP(hipStreamWaitEvent(ls->ctx->stream, l0->ev_defer, 0));
         batch_mark_done(ls);

@@ -1162,13 +1162,10 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
     ls->inv_done = 0;
     ls->t_fact_launch_ms = mnk_host_ms();
-    mnk_batch_group_leave(ls);   // (an older batch's result that nobody looked at)
     {   // info[2]: the leaf stops the factorization at the first pivot that is not positive (leaf64.h: early rejection)
-        // NOT inside an open factorization batch: there the instances share ONE bulk launch, and an instance that dies early
-        // was seen to corrupt its neighbours (tools/dbg_batch_reject.py: spurious rejections and wrong tiles in ~1 of 3
-        // rounds, once a memory fault; none in 12 rounds with the rejected instances running to their end) -- cause not found,
-        // so a batch factors every instance completely, as rounds 3-4 did.
-        const int want = (ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL && ls->src_persistent && !mnk_batch_active()) ? 1 : 0;
+        // (also inside a factorization batch: a member that stops early leaves the others alone -- dag.hip, the workgroup-uniform
+        // `dead` of the batch kernel; tests/test_hip_round5.py::test_a_batch_in_which_some_instances_are_indefinite)
+        const int want = (ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL && ls->src_persistent) ? 1 : 0;
         if (want != ls->reject_on_device) {
             MNK_HIP(hipMemsetAsync(ls->info_dev.p + 2, want, sizeof(int), s));
             ls->reject_on_device = want;
@@ -1498,24 +1495,6 @@ static int bk_fallback(mnk_ls* ls) {
 int mnk_ls_fetch_info(mnk_ls* ls) {
     { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }
     if (ls->info_valid) return 0;
-    if (ls->bgroup) {
-        // a factorization that ran in a batch: if a member of the batch died early, the others are factored again on their
-        // own (dag.hip: mnk_batch_group)
-        bool redo = false;
-        int rc_g = mnk_batch_group_check(ls, &redo);
-        if (rc_g) return rc_g;
-        if (redo) {
-            if (!ls->retransfer) {
-                set_error("factorize!: another factorization of the batch failed and this one cannot be redone (its source is gone)");
-                return -4;
-            }
-            ++ls->batch_redone;
-            int rc = ls->retransfer();
-            if (!rc) rc = mnk_ls_run_factorization(ls);
-            if (rc) return rc;
-            return mnk_ls_fetch_info(ls);
-        }
-    }
     hipStream_t s = ls->ctx->stream;
     if (ls->bk_active) {
         MNK_HIP(hipMemsetAsync(ls->inertia_dev.p, 0, 3 * sizeof(unsigned long long), s));

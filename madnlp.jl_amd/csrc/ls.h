@@ -132,8 +132,6 @@ struct mnk_ls {
     int early_reject = 0;        // option (with accept_only_pd): stop the static-pivot LDL^T at the first pivot that is not positive (leaf64.h); the factor
                                  // of a rejected matrix is then not usable and its inertia is a lower bound on num_neg
     int reject_on_device = -1;   // what info[2] on the device currently says
-    std::shared_ptr<struct mnk_batch_group> bgroup;   // the factorization batch the last factorize! ran in (dag.hip: a member that died early makes the others suspect)
-    int64_t batch_redone = 0;     // statistics: factorizations of this solver redone alone because a neighbour in their batch had failed
     bool src_persistent = false; // the source of the last factorize! call outlives the call (KKT handles): a rejected factorization can be completed later
     bool factor_invalid = false; // the last factorization was rejected early: solve / get_factor refuse
     int64_t early_rejects = 0, early_reject_col = -1, early_reject_redone = 0;   // statistics ("early_rejects", "early_reject_col")
@@ -189,8 +187,6 @@ double mnk_host_ms();                               // factor.hip: steady host c
 void mnk_add_process_stall_ms(double ms);           // factor.hip: time lost to expired device-side waits, all solvers of the process
 double mnk_process_stall_ms();
 bool mnk_ls_pending_elsewhere(const mnk_ls* ls);   // dag.hip: queued in a factorization batch of ANOTHER thread
-int mnk_batch_group_check(mnk_ls* ls, bool* redo);   // dag.hip: first look at a batched factorization's result (all members' status)
-void mnk_batch_group_leave(mnk_ls* ls);            // dag.hip
 bool mnk_batch_active();                           // dag.hip: the calling thread has a factorization batch open
 size_t mnk_pchain_sys_bytes();                     // factor.hip: size of one record of mnk_launch_pchain_multi's table
 int mnk_launch_pchain_multi(mnk_ls* const* v, int n, hipStream_t sp, hipStream_t fill_stream, void* table, int* const* front,

@@ -672,7 +672,6 @@ int mnk_ls_destroy(mnk_ls* ls) {
     }
     (void)mnk_ls_sync_deferred(ls);
     (void)mnk::stream_wait(ls->ctx->stream);
-    mnk_batch_group_leave(ls);   // (the other members of its last batch must not look at this solver's status words any more)
     mnk::LaunchLock lock;   // (host-memory frees and event destruction below; the device buffers lock for themselves)
     mnk::quiesce_persistent();
     if (ls->solve_abort) (void)hipHostFree(ls->solve_abort);
@@ -1284,7 +1283,6 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     // which bounded device-side wait expired last (info = -7): 1 bulk task / operand rows, 2 bulk task / chunk order, 3 gate on the bulk stream, 4 chain strip / diagonal block, 5 chain strip / bulk kernel's rows or band tiles; 0: none
     if (!strcmp(key, "timeout_site")) { *value = ls->last_timeout_site; return 0; }
     if (!strcmp(key, "early_rejects")) { *value = (double)ls->early_rejects; return 0; }       // factorizations stopped at their first non-positive pivot
-    if (!strcmp(key, "batch_redone")) { *value = (double)ls->batch_redone; return 0; }   // factorizations redone alone because a member of their batch had died early
     if (!strcmp(key, "early_reject_redone")) { *value = (double)ls->early_reject_redone; return 0; }   // ... rejected factorizations completed after all because the caller solved
     if (!strcmp(key, "early_reject_col")) { *value = (double)ls->early_reject_col; return 0; } // ... the last valid pivot of the latest one
     if (!strcmp(key, "stall_ms_total")) { *value = ls->stall_ms_total; return 0; }      // what this solver's expired waits (fall-backs) have cost, host ms

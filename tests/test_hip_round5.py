@@ -563,14 +563,13 @@ def test_early_rejection_of_matrices_that_are_not_positive_definite(ctx, case):
 def test_a_batch_in_which_some_instances_are_indefinite(alg):
     """A factorization batch (mnk_factorize_batch_begin / _end: the C5 shape with real interior-point loops) in which some
     scenarios' trial matrices are indefinite while their neighbours' are fine.  Six case1354pegase-shaped instances on one
-    context, two of them with an indefinite Hessian block, alternating rounds.  Early rejection is NOT armed inside a batch
-    (csrc/factor.hip: an instance dying early in the merged launch corrupted its neighbours -- found by this test's first
-    version, tools/dbg_batch_reject.py): the indefinite instances are factored to the end and report their negative pivots,
-    the other four are factored as if they were alone -- the task-DAG schedule, no fall-back, L and D bit-identical to lone
-    factorizations -- in every round, and the two get positive definite values on the SAME solvers in between.
-    CHOLESKY: the indefinite members break down and die early (nothing can be done about that); the first look at any
-    member's result then finds a dead member and the surviving members are factored again on their own (statistic
-    `batch_redone`), to the same bits."""
+    context, two of them with an indefinite Hessian block, alternating rounds.  The indefinite members DIE EARLY in the merged
+    launch -- rejected at their first non-positive pivot (BUNCHKAUFMAN: early rejection, armed in batches too) or broken down
+    (CHOLESKY) -- and their tasks of the merged bulk queue are dropped; the other four are factored as if they were alone:
+    the task-DAG schedule, no fall-back, L and D bit-identical to lone factorizations, in every round; and the two get positive
+    definite values on the SAME solvers in between.  (The first version of this test found round 4's batch kernel deciding
+    "is this member dead" per THREAD: a member dying between two waves' looks split the workgroup between two tasks -- wrong
+    tiles and spurious breakdowns in OTHER members in one round of three, once a memory fault; tools/dbg_batch_reject.py.)"""
     from tests.test_hip_c5 import _front
     dev = torch.device("cuda", 0)
     st = torch.cuda.Stream(dev)
@@ -607,14 +606,10 @@ def test_a_batch_in_which_some_instances_are_indefinite(alg):
             if use_bad and i in bad:
                 assert not it["kh"].is_inertia_correct(*ine) and sum(ine) == it["n"], (rnd, i, ine)
                 assert ine[2] >= 1 or alg == "CHOLESKY"               # (a Cholesky breakdown reports (0, n, 0))
-                assert M.get_stat("early_rejects") == before[i] or alg == "CHOLESKY"   # (LDL': run to the end, not armed in a batch)
+                assert M.get_stat("early_rejects") == before[i] + (1 if alg == "BUNCHKAUFMAN" else 0)
             else:
                 assert ine == (it["n"], 0, 0), (rnd, i, ine)
                 assert M.get_stat("early_rejects") == before[i]
-                if alg == "CHOLESKY":   # a member died in this round <=> the survivors were redone
-                    assert M.get_stat("batch_redone") == (rnd // 2 + 1 if use_bad else (rnd + 1) // 2), (rnd, i, M.get_stat("batch_redone"))
-                else:
-                    assert M.get_stat("batch_redone") == 0
                 Lf, D = M.get_factor_device()
                 assert torch.equal(torch.tril(Lf), ref[i][0]) and torch.equal(D, ref[i][1]), (rnd, i)
     for it in insts:
