@@ -615,3 +615,65 @@ def test_a_batch_in_which_some_instances_are_indefinite(alg):
     for it in insts:
         it["kh"].close()
     ctx.close()
+
+
+@pytest.mark.parametrize("n,m,count", [(2048, 512, 7), (700, 100, 5)])
+def test_a_batch_of_small_systems_in_which_one_breaks_down(n, m, count):
+    """The small-system form of the test above (pchain_multi_kernel: the members' pivot chains side by side in one launch, one
+    bulk launch for their band tiles): dense condensed KKT systems factored by CHOLESKY, member 2 with a Hessian that is not
+    positive definite in alternating rounds -- it breaks down and dies early; the others keep inertia (n, 0, 0), backward
+    error <= 1e-13 and, inside the schedule's window, the bits of their lone factorizations."""
+    from madnlp_jl_amd.problems import dense_dummy_qp
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(dev)
+    ctx = mj.HipContext(0, stream=st.cuda_stream)
+    rng = np.random.default_rng(n + count)
+    ks, Ks, bs, hess = [], [], [], []
+    for i in range(count):
+        P = dense_dummy_qp(n=n, m=m, n_eq=0, seed=30 + i)
+        k = mj.DenseCondensedKKTSystem(P.n, P.m, P.ind_ineq, P.ind_eq, P.ind_lb, P.ind_ub, ctx=ctx,
+                                       opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.CHOLESKY))
+        for f in ("reg", "l_diag", "u_diag", "l_lower", "u_lower", "du_diag"):
+            getattr(k, f)[:] = getattr(P, f)
+        k.hess[...] = P.hess
+        k.jac[...] = P.jac
+        k.set_aug_diagonal()
+        k.build_kkt()
+        ks.append(k)
+        hess.append(P.hess.copy())
+        bs.append(rng.standard_normal(k.linear_solver.n))
+    N = ks[0].linear_solver.n
+    lone = []
+    for k in ks:
+        k.linear_solver.factorize_async()
+        assert k.linear_solver.inertia() == (n, 0, 0)
+        Lf, D = k.linear_solver.get_factor_device()
+        lone.append((torch.tril(Lf).clone(), D.clone()))
+        Ks.append(k.aug_com.to_host())
+    for rnd in range(6):
+        bad = rnd % 2 == 0
+        Hb = hess[2].copy()
+        if bad:
+            Hb[n // 3, n // 3] -= 1e6          # one strongly negative direction a third of the way in
+        ks[2].hess[...] = Hb
+        ks[2].build_kkt()
+        with mj.factorize_batch():
+            for k in ks:
+                k.linear_solver.factorize_async()
+        for i, (k, b) in enumerate(zip(ks, bs)):
+            ine = k.linear_solver.inertia()
+            if bad and i == 2:
+                assert ine != (n, 0, 0) and not k.is_inertia_correct(*ine), (rnd, ine)
+                continue
+            assert ine == (n, 0, 0), (rnd, i, ine)
+            assert k.linear_solver.get_stat("pp_fallbacks") == 0.0
+            x = k.linear_solver.solve_linear_system(b.copy())
+            Kl = np.tril(Ks[i])
+            Kf = Kl + np.tril(Kl, -1).T
+            assert np.abs(Kf @ x - b).max() / (np.abs(Kf).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max()) <= 1e-13, (rnd, i)
+            if N >= 1536:
+                Lf, D = k.linear_solver.get_factor_device()
+                assert torch.equal(torch.tril(Lf), lone[i][0]) and torch.equal(D, lone[i][1]), (rnd, i)
+    for k in ks:
+        k.close()
+    ctx.close()
