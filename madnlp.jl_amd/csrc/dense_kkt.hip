@@ -19,27 +19,31 @@
 
 namespace mnk {
 
-__global__ void dc_diag_buffer_kernel(double* __restrict__ D, const double* __restrict__ pr_s,
-                                      const double* __restrict__ du, const int64_t* __restrict__ ind_ineq,
-                                      int64_t ns) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < ns) D[i] = pr_s[i] / (1.0 - du[ind_ineq[i]] * pr_s[i]);
-}
-
-// A[i + k*lda] = jac[ind_ineq[k] + i*m] * sqrt(D[k]); zero outside (i < n, k < ns).
+// A[i + k*lda] = jac[ind_ineq[k] + i*m] * sqrt(D[k]); zero outside (i < n, k < ns).  D[k] = pr_s[k] / (1 - du[ind_ineq[k]] pr_s[k])
+// (the slack block's condensation weight) is computed here and stored by the first row of blocks: one launch less per build_kkt!.
 __global__ __launch_bounds__(256) void scale_transpose_kernel(double* __restrict__ A, int64_t lda, int64_t npad,
                                                               int64_t kpad, const double* __restrict__ jac,
                                                               int64_t m, int64_t n, int64_t ns,
                                                               const int64_t* __restrict__ ind_ineq,
-                                                              const double* __restrict__ D) {
+                                                              double* __restrict__ D, const double* __restrict__ pr_s,
+                                                              const double* __restrict__ du) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int64_t k0 = (int64_t)blockIdx.x * 32, i0 = (int64_t)blockIdx.y * 32;
+    double Dk = 0.0;
+    {
+        const int64_t k = k0 + tx;
+        if (k < ns) {
+            Dk = pr_s[k] / (1.0 - du[ind_ineq[k]] * pr_s[k]);
+            if (blockIdx.y == 0 && ty == 0) D[k] = Dk;
+        }
+    }
+    const double sD = sqrt(Dk);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t k = k0 + tx, i = i0 + ty + 8 * q;
         double v = 0.0;
-        if (k < ns && i < n) v = jac[ind_ineq[k] + i * m] * sqrt(D[k]);
+        if (k < ns && i < n) v = jac[ind_ineq[k] + i * m] * sD;
         tile[ty + 8 * q][tx] = v;  // tile[i][k]
     }
     __syncthreads();
@@ -364,13 +368,9 @@ int mnk_dc_build(mnk_dc* dc, const double* pr_diag, const double* du_diag, int l
         dc->mirror_pending = false;
         return 0;
     }
-    if (dc->ns > 0) {
-        hipLaunchKernelGGL(dc_diag_buffer_kernel, dim3((unsigned)((dc->ns + 255) / 256)), dim3(256), 0, s,
-                           dc->diag_buffer.p, dc->pr_diag.p + dc->n, dc->du_diag.p, dc->d_ind_ineq.p, dc->ns);
-    }
     dim3 tgrid((unsigned)(dc->kpad + 31) / 32, (unsigned)(dc->npad + 31) / 32);
     hipLaunchKernelGGL(scale_transpose_kernel, tgrid, dim3(256), 0, s, dc->jis.p, dc->ld_jis, dc->npad, dc->kpad,
-                       dc->jac.p, dc->m, dc->n, dc->ns, dc->d_ind_ineq.p, dc->diag_buffer.p);
+                       dc->jac.p, dc->m, dc->n, dc->ns, dc->d_ind_ineq.p, dc->diag_buffer.p, dc->pr_diag.p + dc->n, dc->du_diag.p);
     hipLaunchKernelGGL(init_condensed_kernel, egrid, dim3(256), 0, s, dc->aug.p, ldk, ordpad, dc->hess.p, dc->jac.p,
                        dc->m, dc->n, dc->n_eq, dc->d_ind_eq.p, dc->pr_diag.p, dc->du_diag.p);
     MNK_HIP(hipGetLastError());
