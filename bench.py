@@ -208,6 +208,10 @@ def ipm_loop(args, ctx, model="acopf"):
                "status": s.status, "objective": s.obj_val, "iterations": s.cnt.k, "factorizations": s.cnt.factorization_cnt,
                "backsolves": s.cnt.backsolve_cnt, "wall_s": wall, "ms_per_iteration": 1e3 * wall / max(1, s.cnt.k),
                "it_per_s": s.cnt.k / wall}
+        try:   # (how many of the factorizations were trials the static-pivot tier rejected at their first non-positive pivot)
+            rec["early_rejected_trials"] = int(s.kkt.linear_solver.get_stat("early_rejects"))
+        except Exception:
+            pass
         s.cb.close()
         s.K.close()
         s.kkt.close()
