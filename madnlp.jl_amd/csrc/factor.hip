@@ -142,6 +142,10 @@ __global__ __launch_bounds__(256) void trsm64_mfma_batch_kernel(const TrsmBatchR
                              rec.info, nullptr);
 }
 
+#ifndef MNK_LEAF_V
+#define MNK_LEAF_V 1   // the pivot leaf: 1 = potrf64v_core (round 6: indicator sums, pivot tests behind the chain, 4x4x4 block solves, third-order
+                       // reciprocals), 0 = potrf64w_core (rounds 2-5) -- A/B builds (tools/leaf_ab.sh)
+#endif
 template <bool LDL>
 __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int64_t ld, int64_t j0,
                                               double* __restrict__ Dout, double* __restrict__ inv16,
@@ -161,7 +165,11 @@ __device__ __forceinline__ void potrf64w_body(const double* __restrict__ F, int6
                 // 'L' storage: the strict upper triangle of the block may hold anything (NaN included)
                 Lt[cb][b][r] = (cb == b && l15 < l4 + 4 * r) ? 0.0 : v;
             }
+#if MNK_LEAF_V
+    potrf64v_core<LDL>(Lt, j0, Dout, inv16, dvec, dinv, info, pivot_tol, Lsh, Ish, vmax);
+#else
     potrf64w_core<LDL>(Lt, j0, Dout, inv16, dvec, dinv, info, pivot_tol, Lsh, Ish, vmax);
+#endif
 }
 
 template <bool LDL>
@@ -198,11 +206,35 @@ constexpr long PP_SPIN_LIMIT = 1L << 20;  // ~0.5 s
 #ifndef MNK_DIAG_RACY_PUB
 #define MNK_DIAG_RACY_PUB 0
 #endif
+#ifndef MNK_DIAG_STEP_TRACE
+#define MNK_DIAG_STEP_TRACE 0
+#endif
 #ifndef MNK_DIAG_NO_EARLY
 #define MNK_DIAG_NO_EARLY 0   // (-DMNK_DIAG_NO_EARLY=1: a diagnostic build without the chain's early diagonal update)
 #endif
 constexpr int PP_LDS_BYTES = 3 * 4096 * 8;  // two staging tiles (the first doubles as the exchange buffer) + own tile
 constexpr int PC_LDS_BYTES = 4 * 4096 * 8;  // pivot-chain kernels: + the strip's NEXT diagonal block (see pp_strip, EARLY)
+
+// acc[cb2] += sum over ib, s of tile[(4 cb2 + ib) * 64 + lane][s] * B[ib][s] for the 16x16 blocks cb2 < ncb2 (wave-uniform) of one 64x64 tile
+// in LDS (the chain strips' tile step: 64 products per wave).  The LDS read of block q + 1 is requested before the four products of
+// block q are issued: round 5's loops read, waited for the read and only then issued two products -- an exposed LDS latency in
+// front of every pair (the register allocator, at its limit in pchain_kernel, reused one register quadruple for all 32 reads) --
+// and negated every A operand on the way (two v_xor per read): the callers negate the B operand once instead.
+__device__ __forceinline__ void tile_mac(const v4d* __restrict__ tile, const int lane, const int ncb2, const v4d* __restrict__ B, v4d* __restrict__ acc) {
+    v4d a = tile[lane];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int cb2 = q >> 2, ib = q & 3;
+        if (ib == 0 && cb2 >= ncb2) break;
+        v4d an = a;
+        if (q < 15) an = tile[(q + 1) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], B[ib][s], acc[cb2], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this block's four products
+        a = an;
+    }
+}
 
 // Wave-uniform bounded wait for prog[c] >= target.  `seen` caches the last values read: one acquire covers everything
 // that was published before ANY flag value read ahead of it, so every successful wait refreshes all nb entries and
@@ -292,6 +324,13 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
     const int tabs = (int)(p0 >> 6) + t;  // this strip's 64-row block
     unsigned long long* ptr_tr = dag.trace != nullptr && tid == 0 ? dag.trace + 8 * t : nullptr;
     if (ptr_tr) ptr_tr[0] = wall_clock64();
+#if MNK_DIAG_STEP_TRACE   // (diagnostic build: 16 more stamps per strip -- per step: block seen / substitution done / rows published / updates done;
+                          // second half of the chain's trace region, single-phase schedules of <= 64 strip-columns; tools/chain_steps2.py)
+    unsigned long long* tr2 = ptr_tr != nullptr && (p0 >> 8) < 64 ? ptr_tr + 2048 * 8 + ((p0 >> 8) * 8 * (int64_t)gridDim.x + 8 * t) : nullptr;
+#define MNK_TR2(slot) do { if (tr2) tr2[slot] = wall_clock64(); } while (0)
+#else
+#define MNK_TR2(slot) do { } while (0)
+#endif
     if (EARLY && make_xn) {
 #pragma unroll
         for (int cb2 = 0; cb2 < 4; ++cb2)
@@ -376,7 +415,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         b_load(0, Bn);
         for (int kc = 0; kc < nch; ++kc) {
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) Bv[ib] = Bn[ib];
+            for (int ib = 0; ib < 4; ++ib) Bv[ib] = -Bn[ib];   // (T -= V L^T: the sign goes into the operand that is copied anyway)
             if (kc + 1 < nch) b_load(kc + 1, Bn);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
@@ -391,17 +430,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                     if (c2 >= ncb) { c2 = 0; k2 = kc + 1; }
                     if (k2 < nch) tile_load(k2, c2);
                 }
-#pragma unroll
-                for (int cb2 = 0; cb2 < 4; ++cb2) {
-                    if (c == t && cb2 > w) break;  // own diagonal block: lower triangle only
-#pragma unroll
-                    for (int ib = 0; ib < 4; ++ib) {
-                        const v4d a = tile[(cb2 * 4 + ib) * 64 + lane];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            X[4 * c + cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], Bv[ib][s], X[4 * c + cb2], 0, 0, 0);
-                    }
-                }
+                tile_mac(tile, lane, c == t ? w + 1 : 4, Bv, &X[4 * c]);   // (own diagonal block: lower triangle only)
             }
         }
         __syncthreads();
@@ -496,8 +525,13 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 }
             const int64_t jb = (p0 >> 6) + j;
             if (ptr_tr) ptr_tr[7] = wall_clock64();   // (trace: the leaf starts)
+#if MNK_LEAF_V
+            potrf64v_core<LDL, WT>(Lt, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol, nullptr,
+                                   nullptr, dag.vmax);
+#else
             potrf64w_core<LDL, WT>(Lt, p0 + 64 * j, dblk0 + jb * 4096, inv0 + jb * 1024, dvec, dinv, info, pivot_tol, nullptr,
                                    nullptr, dag.vmax);
+#endif
             if (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) {
@@ -512,6 +546,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         // ---- wait for the diagonal block j, X = T L_jj^-T
         pp_wait<NB, LDL>(prog, j, nb, epoch16 + j + 1, seen, info, pp_limit, dag.dbg != nullptr ? dag.dbg + 8 * t : nullptr, (int)(p0 >> 8), t);
         if (ptr_tr && j == t - 1) ptr_tr[6] = wall_clock64();   // (trace, tools/chain_steps.py: the block in front of this strip's own seen)
+        MNK_TR2(4 * j + 0);
         const int64_t jb = (p0 >> 6) + j;
         const double* Dblk = dblk0 + jb * 4096;
         const double* Iv16 = inv0 + jb * 1024;
@@ -553,6 +588,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 X[4 * j + cb] = x;
             }
         }
+        MNK_TR2(4 * j + 1);
         // ---- store V (LDL: to the W panel) and L; a diagonal strip also keeps its L rows in LDS and publishes
         double vm = 0.0;
 #pragma unroll
@@ -595,6 +631,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 if (pub_front && dag.trace != nullptr) dag.trace[8 * t + (j == jmax ? 2 : 3)] = wall_clock64();
             }
         }
+        MNK_TR2(4 * j + 2);
         // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
         v4d pre[4];
         auto prefetch = [&](int c) {
@@ -606,6 +643,11 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                 for (int s = 0; s < 4; ++s) pre[ib][s] = src[(16 * ib + 4 * s) * ld];
         };
         if (j + 1 <= jmax && j + 1 != t) prefetch(j + 1 < NB ? j + 1 : 0);
+        // the block column's V (stored above, final) is the B operand of every product below: its sign is flipped once, in place
+        // (X[4 j ..] is not read again as what it was: later steps and strip-columns take the stored values)
+        v4d* const Bj = &X[4 * j];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) Bj[ib] = -Bj[ib];
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) {
             if (c > jmax) break;
@@ -616,36 +658,25 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             }
             __syncthreads();
             if (c + 1 < NB && c + 1 <= jmax && c + 1 != t) prefetch(c + 1 < NB ? c + 1 : 0);
-#pragma unroll
-            for (int cb2 = 0; cb2 < 4; ++cb2) {
-                if (c == t && cb2 > w) break;  // own diagonal block: lower triangle only
-#pragma unroll
-                for (int ib = 0; ib < 4; ++ib) {
-                    const v4d a = tile[(cb2 * 4 + ib) * 64 + lane];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        X[4 * c + cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], X[4 * j + ib][s], X[4 * c + cb2], 0, 0, 0);
-                }
-            }
+            tile_mac(tile, lane, c == t ? w + 1 : 4, Bj, &X[4 * c]);   // (own diagonal block: lower triangle only)
         }
         if (EARLY && make_xn) {
             // ---- the same product for the strip's diagonal block of the NEXT strip-column (its k-chunk j)
             __syncthreads();   // `own` is complete
+            v4d acc[4];
 #pragma unroll
-            for (int cb2 = 0; cb2 < 4; ++cb2) {
-                if (cb2 > w) break;
-                v4d acc = xn[(w * 4 + cb2) * 64 + lane];
+            for (int cb2 = 0; cb2 < 4; ++cb2)
+                if (cb2 <= w) acc[cb2] = xn[(w * 4 + cb2) * 64 + lane];
+            tile_mac(own, lane, w + 1, Bj, acc);
 #pragma unroll
-                for (int ib = 0; ib < 4; ++ib) {
-                    const v4d a = own[(cb2 * 4 + ib) * 64 + lane];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], X[4 * j + ib][s], acc, 0, 0, 0);
+            for (int cb2 = 0; cb2 < 4; ++cb2)
+                if (cb2 <= w) {
+                    if (tn_now) acc[cb2] = stage[(w * 4 + cb2) * 64 + lane] + acc[cb2];
+                    xn[(w * 4 + cb2) * 64 + lane] = acc[cb2];
                 }
-                if (tn_now) acc = stage[(w * 4 + cb2) * 64 + lane] + acc;
-                xn[(w * 4 + cb2) * 64 + lane] = acc;
-            }
             if (tn_now && tid == 0) *xn_have = 2;
         }
+        MNK_TR2(4 * j + 3);
         return false;
     };
     if (step(std::integral_constant<int, 0>{})) return;

@@ -282,6 +282,254 @@ __device__ __forceinline__ void potrf64w_core(v4d (&Lt)[4][4], int64_t j0, doubl
 }
 
 // ---------------------------------------------------------------------------------------
+// potrf64v_core (round 6): the one-wave leaf with its instruction count halved -- same recurrence, same layout, and (flags
+// RCP3 = false, M44 = false) the same bits as potrf64w_core whenever no pivot of the block is zero / non-finite.
+// tools/hip/leaf_lab.hip had the round-5 leaf at 28 780 cycles for ~4500 instructions, of which 876 are v_cndmask_b32: every
+// lane factors the 4x4 pivot block redundantly (uniform values) and then SELECTS its own entry of inv(L44), of the pivot
+// rows of V = L D and of D^-1 by comparisons (two selections of ten values + one of four per group: ~55 v_cndmask_b32 and
+// their compares), and every pivot carries its zero / non-finite test in front of its reciprocal's use.  Here:
+//   * one indicator vector per entry of the 4x4 pattern, set up once per call -- I_e(lane) = 1 on the lanes (l15 & 3, l4)
+//     that own entry e, else 0 -- turns every selection into a sum of products e_0 I_0 + e_1 I_1 + ...: ONE v_fma_f64 per
+//     candidate instead of two v_cndmask_b32 (+ compares), and the sums are exact (all terms but one are +-0).  The
+//     pattern repeats in every 4-row group of the 16 rows: the A operand of the block solve needs no zeros outside the
+//     pivot group (those rows of the product land in the three result registers nobody reads), and above the group the
+//     diagonal block's rows of X / V are strictly upper triangle -- never stored (the stores mask it), never an operand
+//     of anything that is (rows of the A operand that `na` zeroes; columns of results in the upper triangle);
+//   * the pivots' zero / non-finite tests leave the chain: the four pivots are tested TOGETHER behind it (min |d| against
+//     the tolerance, a sum that is finite iff all four are), and only a group that fails repeats its scalar factorization
+//     with the guarded code of potrf64w_core (factor_piv4_vals) -- a wave-uniform branch nobody takes on the matrices the
+//     interior-point loop accepts;
+//   * M44: the block solves X_t^T = inv(L44) A_t^T and the 4x4 steps of the 16x16 inverses on v_mfma_f64_4x4x4_4b (four 4x4x4
+//     products, 4 passes) instead of v_mfma_f64_16x16x4 (16 passes) three quarters of whose result was thrown away;
+//   * RCP3: reciprocal = v_rcp_f64 (2^-24) + ONE third-order step r (1 + e + e^2), e = 1 - d r: three dependent fma
+//     instead of four, <= 1 ulp.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp3(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
+__device__ __forceinline__ double fast_rsqrt3(double x) {
+    // v_rsq_f64 (2^-24) + one third-order step: y (1 + e/2 + 3 e^2 / 8), e = 1 - x y^2
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+__device__ __forceinline__ double min_abs(double a, double b) {   // min(|a|, |b|) of the hardware (a NaN operand loses: callers test for NaN apart)
+    double r;
+    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int or3(int a, int b, int c) {
+    int r;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (keeps a lane constant in its register: no rematerialization by compare + select; `tie`: a value of the call -- without it the
+// constants of potrf64v_core are hoisted to the top of the persistent chain kernel, spilled to scratch there and reloaded in front
+// of every leaf)
+__device__ __forceinline__ double opaque(double x, int tie = 0) {
+    asm volatile("" : "+v"(x) : "s"(tie));
+    return x;
+}
+
+template <bool LDL, bool WT = false, bool M44 = true, bool RCP3 = true, bool LOOK = false>
+__device__ __forceinline__ void potrf64v_core(v4d (&Lt)[4][4], int64_t j0, double* __restrict__ Dout,
+                                              double* __restrict__ inv16, double* __restrict__ dvec,
+                                              double* __restrict__ dinv, int* __restrict__ info, double pivot_tol,
+                                              double* Lsh, double* Ish, unsigned long long* __restrict__ vmax = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4, i4 = l15 & 3;
+    const v4d zero4 = {0.0, 0.0, 0.0, 0.0};
+    double vm = 0.0;
+    const int reject = LDL ? __hip_atomic_load(info + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    // indicator vectors of the 4x4 pattern: entry (i, k) lives on the lanes with (l15 & 3) == i, l4 == k
+    const int tie = (int)j0;
+    auto ind = [&](int i, int k) { return opaque((i4 == i && l4 == k) ? 1.0 : 0.0, tie); };
+    const double I10 = ind(1, 0), I20 = ind(2, 0), I30 = ind(3, 0), I21 = ind(2, 1), I31 = ind(3, 1), I32 = ind(3, 2);
+    const double D0 = ind(0, 0), D1 = ind(1, 1), D2 = ind(2, 2), D3 = ind(3, 3);
+    const double J0 = opaque(l4 == 0 ? 1.0 : 0.0, tie), J1 = opaque(l4 == 1 ? 1.0 : 0.0, tie), J2 = opaque(l4 == 2 ? 1.0 : 0.0, tie),
+                 J3 = opaque(l4 == 3 ? 1.0 : 0.0, tie);
+    const double Idg = opaque(i4 == l4 ? 1.0 : 0.0, tie), Ibelow = opaque(l4 < i4 ? 1.0 : 0.0, tie);
+    auto rcp = [&](double x) { return RCP3 ? fast_rcp3(x) : fast_rcp(x); };
+    auto rsq = [&](double x) { return RCP3 ? fast_rsqrt3(x) : fast_rsqrt(x); };
+    // one 4-row group of inv(L44) A^T: lane (l15, l4) <- sum_k aop(l15 & 3 .., k) a(l15, k)
+    auto solve44 = [&](double aop, double a, int tt) -> double {
+        if (M44) return __builtin_amdgcn_mfma_f64_4x4x4f64(aop, a, 0.0, 0, 0, 0);
+        const v4d out = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, a, zero4, 0, 0, 0);
+        return out[tt];
+    };
+    // LOOK: the NEXT pivot block, updated ahead of the diagonal block it belongs to by one 4x4x4 product (the diagonal 4x4
+    // blocks of X V^T are exactly what v_mfma_f64_4x4x4_4b computes from the update's own operands): the scalar chain of the
+    // next group starts 45 cycles behind this group's X instead of 96 + behind the 16x16x4 update
+    double pnext = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double aopinv[4] = {0.0, 0.0, 0.0, 0.0};
+        v4d Xf[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = 4 * b + tt;
+            const double dsrc = (LOOK && t > 0) ? pnext : Lt[b][b][tt];
+            const double p00 = readlane_f64(dsrc, 4 * tt + 0);
+            const double p10 = readlane_f64(dsrc, 4 * tt + 1), p11 = readlane_f64(dsrc, 4 * tt + 1 + 16);
+            const double p20 = readlane_f64(dsrc, 4 * tt + 2), p21 = readlane_f64(dsrc, 4 * tt + 2 + 16),
+                         p22 = readlane_f64(dsrc, 4 * tt + 2 + 32);
+            const double p30 = readlane_f64(dsrc, 4 * tt + 3), p31 = readlane_f64(dsrc, 4 * tt + 3 + 16),
+                         p32 = readlane_f64(dsrc, 4 * tt + 3 + 32), p33 = readlane_f64(dsrc, 4 * tt + 3 + 48);
+            // the unguarded chain: operation for operation that of factor_piv4_vals (LDL^T: x_ik = c_ik s_k IS l_ik)
+            double s0, s1, s2, s3, c10, c20, c30, c21, c31, c32, g0, g1, g2, g3;   // g: the recorded pivots (LDL^T: d, Cholesky: sqrt)
+            double x10 = 0.0, x20 = 0.0, x30 = 0.0, x21 = 0.0, x31 = 0.0, x32 = 0.0;   // LDL^T: l_ik = c_ik s_k
+            bool ok;
+            if (LDL) {
+                s0 = rcp(p00);
+                x10 = p10 * s0; x20 = p20 * s0; x30 = p30 * s0;
+                g1 = fma(-x10, p10, p11);
+                c21 = fma(-x20, p10, p21); c31 = fma(-x30, p10, p31);
+                s1 = rcp(g1);
+                x21 = c21 * s1; x31 = c31 * s1;
+                g2 = fma(-x21, c21, fma(-x20, p20, p22));
+                c32 = fma(-x31, c21, fma(-x30, p20, p32));
+                s2 = rcp(g2);
+                x32 = c32 * s2;
+                g3 = fma(-x32, c32, fma(-x31, c31, fma(-x30, p30, p33)));
+                s3 = rcp(g3);
+                g0 = p00; c10 = p10; c20 = p20; c30 = p30;
+                // the four pivots' tests, together: min |d| > tol; |d0| + .. + |d3| finite (NaN / Inf iff one of them is -- or the sum
+                // overflows: guarded path); early rejection: no sign bit set
+                const double amin = min_abs(min_abs(g0, g1), min_abs(g2, g3));
+                const double asum = (fabs(g0) + fabs(g1)) + (fabs(g2) + fabs(g3));
+                const int signs = or3(__double2hiint(g0), __double2hiint(g1), __double2hiint(g2)) | __double2hiint(g3);
+                ok = (amin > pivot_tol) & (asum <= DBL_MAX) & ((reject == 0) | (signs >= 0));
+            } else {
+                s0 = rsq(p00);
+                c10 = p10 * s0; c20 = p20 * s0; c30 = p30 * s0;
+                const double t1 = fma(-c10, c10, p11);
+                s1 = rsq(t1);
+                c21 = fma(-c20, c10, p21) * s1; c31 = fma(-c30, c10, p31) * s1;
+                const double t2 = fma(-c21, c21, fma(-c20, c20, p22));
+                s2 = rsq(t2);
+                c32 = fma(-c31, c21, fma(-c30, c20, p32)) * s2;
+                const double t3 = fma(-c32, c32, fma(-c31, c31, fma(-c30, c30, p33)));
+                s3 = rsq(t3);
+                g0 = p00 * s0; g1 = t1 * s1; g2 = t2 * s2; g3 = t3 * s3;
+                // (every t > 0 and finite: no sign bit, min > 0, finite sum)
+                const int signs = or3(__double2hiint(p00), __double2hiint(t1), __double2hiint(t2)) | __double2hiint(t3);
+                ok = (min_abs(min_abs(p00, t1), min_abs(t2, t3)) > 0.0) & ((fabs(p00) + fabs(t1)) + (fabs(t2) + fabs(t3)) <= DBL_MAX) & (signs >= 0);
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {   // (uniform values: all lanes or none)
+                // ---- a zero / non-finite / (Cholesky; early rejection) non-positive pivot in this group: the guarded scalar
+                // factorization of potrf64w_core (harmless pivot 1, the zero recorded); the selections below are the same
+                Piv4 P;
+                double dg[4];
+                int fail;
+                factor_piv4_vals<LDL>(p00, p10, p11, p20, p21, p22, p30, p31, p32, p33, pivot_tol, P, dg, fail);
+                if (!LDL && fail != 0 && lane == 0) atomicCAS(info, 0, (int)(j0 + 4 * t + fail));
+                if (LDL && reject != 0) {
+                    const bool bad = !(dg[0] > 0.0) | !(dg[1] > 0.0) | !(dg[2] > 0.0) | !(dg[3] > 0.0);
+                    if (bad && lane == 0 && atomicCAS(info, 0, -9) == 0) info[1] = (int)(j0 + 63);
+                }
+                s0 = P.s0; s1 = P.s1; s2 = P.s2; s3 = P.s3;
+                c10 = P.c10; c20 = P.c20; c30 = P.c30; c21 = P.c21; c31 = P.c31; c32 = P.c32;
+                g0 = dg[0]; g1 = dg[1]; g2 = dg[2]; g3 = dg[3];
+                if (LDL) { x10 = c10 * s0; x20 = c20 * s0; x30 = c30 * s0; x21 = c21 * s1; x31 = c31 * s1; x32 = c32 * s2; }
+            }
+            double aop, ssel, vpiv, lpiv;
+            // V = L D (LDL^T) / L (Cholesky) on the pivot rows: one indicator sum
+            vpiv = fma(c32, I32, fma(c31, I31, fma(c21, I21, fma(c30, I30, fma(c20, I20, fma(c10, I10,
+                   fma(g3, D3, fma(g2, D2, fma(g1, D1, g0 * D0)))))))));
+            if (LDL) {
+                // inverse of the unit lower triangular 4x4 factor: y10 = -l10, y21 = -l21, y32 = -l32, y20 = l21 l10 - l20,
+                // y31 = l32 l21 - l31, y30 = -(l32 y20 + (l30 - l31 l10)).  The entries of row 3 are linear in l32, the last value of
+                // the chain: aop = l32 G + H with G, H complete before l32 is -- ONE fma between the chain and the block solve, and
+                // in every lane the very fma that defines its entry (the same bits)
+                const double y20 = fma(x21, x10, -x20), e30 = fma(x31, -x10, x30);
+                const double G = fma(-y20, I30, fma(x21, I31, -I32));
+                const double H = fma(-e30, I30, fma(-x31, I31, fma(-x21, I21, fma(y20, I20, fma(-x10, I10, Idg)))));
+                aop = fma(x32, G, H);
+                ssel = fma(s3, J3, fma(s2, J2, fma(s1, J1, s0 * J0)));
+                lpiv = vpiv * fma(ssel, Ibelow, Idg);
+            } else {
+                // inverse of the 4x4 Cholesky factor (forward substitution as in potrf64w_core: the same products in the same order)
+                const double y10 = -(c10 * s0) * s1;
+                const double y20 = -fma(c21, y10, c20 * s0) * s2;
+                const double y30 = -fma(c32, y20, fma(c31, y10, c30 * s0)) * s3;
+                const double y21 = -(c21 * s1) * s2;
+                const double y31 = -fma(c32, y21, c31 * s1) * s3;
+                const double y32 = -(c32 * s2) * s3;
+                aop = fma(y32, I32, fma(y31, I31, fma(y21, I21, fma(y30, I30, fma(y20, I20, fma(y10, I10,
+                      fma(s3, D3, fma(s2, D2, fma(s1, D1, s0 * D0)))))))));
+                ssel = 1.0;
+                lpiv = vpiv;
+            }
+            aopinv[tt] = aop;
+            const bool done_row = l15 < 4 * tt + 4;   // rows of the diagonal block up to and including the pivot group
+            // ---- 2. X_t^T = inv(L44) A_t^T for every block of block column b
+            double X[4], V[4];
+#pragma unroll
+            for (int cb = b; cb < 4; ++cb) {
+                double v = solve44(aop, Lt[cb][b][tt], tt);
+                double x = LDL ? v * ssel : v;
+                if (cb == b) {
+                    // the pivot rows: exact values from the scalar factorization (above them: the strict upper triangle, see the header)
+                    x = done_row ? lpiv : x;
+                    v = done_row ? (LDL ? vpiv : lpiv) : v;
+                }
+                X[cb] = x;
+                V[cb] = v;
+                if (LDL) vm = fmax(vm, fabs(v));
+                Xf[cb][tt] = x;
+            }
+            if (LOOK) {
+                if (tt < 3) pnext = __builtin_amdgcn_mfma_f64_4x4x4f64(-X[b], LDL ? V[b] : X[b], Lt[b][b][tt + 1], 0, 0, 0);
+                else if (b < 3) pnext = __builtin_amdgcn_mfma_f64_4x4x4f64(-X[b + 1], LDL ? V[b + 1] : X[b + 1], Lt[b + 1][b + 1][0], 0, 0, 0);
+            }
+            // ---- 3. rank-4 update of the trailing blocks: acc(cb2, cb1) -= X[cb1] (V|X)[cb2]^T
+#pragma unroll
+            for (int cb1 = b; cb1 < 4; ++cb1) {
+                const double na = (cb1 == b && done_row) ? 0.0 : -X[cb1];
+#pragma unroll
+                for (int cb2 = cb1; cb2 < 4; ++cb2)
+                    Lt[cb2][cb1] = __builtin_amdgcn_mfma_f64_16x16x4f64(na, LDL ? V[cb2] : X[cb2], Lt[cb2][cb1], 0, 0, 0);
+            }
+        }
+        // ---- inverse of the 16x16 diagonal block (unit diagonal for LDL): Y = inv(L16), block forward substitution
+        {
+            v4d T, Y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[r] = (l15 == l4 + 4 * r) ? 1.0 : 0.0;
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {
+                Y[pg] = solve44(aopinv[pg], T[pg], pg);
+                if (pg < 3) T = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xf[b][pg], Y[pg], T, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                put<WT>(inv16 + b * 256 + (l4 + 4 * r) + 16 * l15, Y[r]);
+                if (Ish != nullptr) Ish[b * 256 + (l4 + 4 * r) + 16 * l15] = Y[r];
+            }
+        }
+        {
+            const int rsel = l15 >> 2;
+            const double dsel = rsel == 0 ? Xf[b][0] : (rsel == 1 ? Xf[b][1] : (rsel == 2 ? Xf[b][2] : Xf[b][3]));
+            if ((l15 & 3) == l4) {
+                put<WT>(dvec + j0 + 16 * b + l15, dsel);
+                put<WT>(dinv + j0 + 16 * b + l15, LDL ? fast_rcp(dsel == 0.0 ? 1.0 : dsel) : 1.0);
+            }
+        }
+#pragma unroll
+        for (int cb = b; cb < 4; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = (cb == b && l15 < l4 + 4 * r) ? 0.0 : Xf[cb][r];
+                put<WT>(Dout + (16 * cb + l15) + 64 * (16 * b + l4 + 4 * r), v);
+                if (Lsh != nullptr) Lsh[(16 * cb + l15) + 64 * (16 * b + l4 + 4 * r)] = v;
+            }
+    }
+    if (LDL) growth_fold(vmax, vm);
+}
+
+// ---------------------------------------------------------------------------------------
 // potrf64w_core with the instruction stream SOFTWARE-PIPELINED by hand (round 5): the same operations on the same operands,
 // so the same bits -- issued in a different order.  A wave issues in order, and an MFMA that finds the matrix pipe busy
 // (16 passes = 64 cycles per v_mfma_f64_16x16x4) holds back everything behind it, so the one-wave leaf above runs its two

@@ -128,6 +128,11 @@ __global__ __launch_bounds__(256) void lab(const double* A, double* scratch, uns
             else if (MODE == 3) potrf64s_core<LDL, true, 10>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr);
             else if (MODE == 4) potrf64s_core<LDL, true, 18>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr);
             else if (MODE == 5) potrf64s_core<LDL, true, 24>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr);
+            else if (MODE == 6) potrf64v_core<LDL, true, false, false>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr, nullptr, nullptr);
+            else if (MODE == 7) potrf64v_core<LDL, true, true, false>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr, nullptr, nullptr);
+            else if (MODE == 20) potrf64v_core<LDL, true, true, true, false>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr, nullptr, nullptr);
+            else if (MODE == 8) potrf64v_core<LDL, true, true, true>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr, nullptr, nullptr);
+            else if (MODE == 9) potrf64v_core<LDL, true, false, true>(Lt, 0, Dout, inv16, dvec, dinv, info, 1e-300, nullptr, nullptr, nullptr);
             else leaf_variant<LDL, MODE - 10>(Lt, Dout, 1e-300);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,6 +182,36 @@ static void run_overlap(const char* name, int threads, double* scratch, unsigned
     unsigned long long h = 0;
     hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
     printf("%-72s: %8llu cycles = %.1f per {1 MFMA + 12 FMA} slot\n", name, h, (double)h / (iters * 4.0));
+}
+
+
+// Lane layout of v_mfma_f64_4x4x4_4b: A = indicator of lane la, B = indicator of lane lb -> which lane of D is 1
+__global__ void probe44(int* map) {
+    const int lane = threadIdx.x;
+    for (int la = 0; la < 64; ++la)
+        for (int lb = 0; lb < 64; ++lb) {
+            const double d = __builtin_amdgcn_mfma_f64_4x4x4f64(lane == la ? 1.0 : 0.0, lane == lb ? 1.0 : 0.0, 0.0, 0, 0, 0);
+            if (d != 0.0) map[la * 64 + lb] = lane;
+        }
+}
+static void run_probe44() {
+    int* map; hipMalloc(&map, 4096 * 4); hipMemset(map, 0xff, 4096 * 4);
+    hipLaunchKernelGGL(probe44, dim3(1), dim3(64), 0, 0, map);
+    std::vector<int> h(4096);
+    hipMemcpy(h.data(), map, 4096 * 4, hipMemcpyDeviceToHost);
+    // the layout potrf64v_core assumes: A lane (i + 4 blk) + 16 k, B lane (j + 4 blk) + 16 k, D lane (j + 4 blk) + 16 i
+    int bad = 0, shown = 0;
+    for (int la = 0; la < 64; ++la)
+        for (int lb = 0; lb < 64; ++lb) {
+            const int ia = la & 3, ba = (la >> 2) & 3, ka = la >> 4, jb = lb & 3, bb = (lb >> 2) & 3, kb = lb >> 4;
+            const int want = (ba == bb && ka == kb) ? (jb + 4 * bb) + 16 * ia : -1;
+            if (h[la * 64 + lb] != want) {
+                ++bad;
+                if (shown++ < 24) printf("  probe44: A lane %2d x B lane %2d -> D lane %2d (assumed %2d)\n", la, lb, h[la * 64 + lb], want);
+            }
+        }
+    printf("v_mfma_f64_4x4x4_4b lane layout vs the assumed one (A (i+4blk)+16k, B (j+4blk)+16k, D (j+4blk)+16i): %d mismatches\n", bad);
+    hipFree(map);
 }
 
 template <bool LDL, int MODE>
@@ -242,5 +277,72 @@ int main() {
     run<true, 13>("one-wave copy: block solves + updates, constant pivots", A, scratch, cyc, info);
     run<false, 10>("one-wave copy, everything (no inverses / D stores)", A, scratch, cyc, info);
     run<false, 13>("one-wave copy: block solves + updates, constant pivots", A, scratch, cyc, info);
+    // ---- round 6: potrf64v_core (indicator sums instead of selections, pivot tests behind the chain, 4x4x4 block solves, third-order reciprocal)
+    run_probe44();
+    auto fetch = [&](std::vector<double>& r) { hipMemcpy(r.data(), scratch, r.size() * 8, hipMemcpyDeviceToHost); hipMemset(scratch, 0, 8192 * 8); };
+    auto cmp = [&](const char* what, const std::vector<double>& a, const std::vector<double>& b2) {
+        size_t nd = 0; double mx = 0.0;
+        auto one = [&](double x, double y) { if (x != y && !(x != x && y != y)) { ++nd; const double e = fabs(x - y) / fmax(fabs(x), 1e-300); mx = e > mx ? e : mx; } };
+        for (int j = 0; j < 64; ++j) for (int i = j; i < 64; ++i) one(a[i + 64 * j], b2[i + 64 * j]);
+        for (size_t i = 4096; i < a.size(); ++i) one(a[i], b2[i]);
+        printf("    %-52s: %zu entries differ, max relative difference %.2e\n", what, nd, mx);
+    };
+    std::vector<double> rw(4096 + 1024 + 128), rv(4096 + 1024 + 128);
+    hipMemset(scratch, 0, 8192 * 8);
+    run<true, 0>("one-wave leaf (potrf64w_core)", A, scratch, cyc, info); fetch(rw);
+    run<true, 6>("potrf64v_core (16x16x4 solves, two Newton steps)", A, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+    run<true, 7>("potrf64v_core (4x4x4 solves, two Newton steps)", A, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+    run<true, 9>("potrf64v_core (16x16x4 solves, third-order reciprocal)", A, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+    run<true, 20>("potrf64v_core (4x4x4, third-order, no look-ahead)", A, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+    run<true, 8>("potrf64v_core (4x4x4 solves, third-order reciprocal)", A, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+    {   // backward error of both against the matrix: max |A - L D L'| / max |A|
+        auto berr = [&](const std::vector<double>& r) {
+            double mx = 0.0;
+            for (int i = 0; i < 64; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    long double sacc = 0.0L;
+                    for (int k = 0; k <= j; ++k) {
+                        const long double lik = i == k ? 1.0L : (long double)r[i + 64 * k], ljk = j == k ? 1.0L : (long double)r[j + 64 * k];
+                        sacc += lik * (long double)r[4096 + 1024 + k] * ljk;
+                    }
+                    const double e = fabs((double)(sacc - (long double)h[i + 64 * j]));
+                    mx = e > mx ? e : mx;
+                }
+            return mx / 81.0;
+        };
+        printf("    backward error max|A - L D L'| / max|A|: potrf64w_core %.3e, potrf64v_core (4x4x4, third-order) %.3e\n", berr(rw), berr(rv));
+    }
+    run<false, 0>("one-wave leaf (potrf64w_core)", A, scratch, cyc, info); fetch(rw);
+    run<false, 6>("potrf64v_core (16x16x4 solves, two Newton steps)", A, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+    run<false, 8>("potrf64v_core (4x4x4 solves, third-order rsqrt)", A, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+    {   // the guarded path: a matrix with an exactly zero pivot (column 21 decoupled, zero diagonal), a negative pivot (column 40) and, for
+        // Cholesky, the breakdown it causes; early rejection armed in a second pass (info[2] = 1)
+        std::vector<double> h2 = h;
+        for (int i = 0; i < 64; ++i) { h2[i + 64 * 21] = 0.0; h2[21 + 64 * i] = 0.0; }
+        h2[40 + 64 * 40] = -3.0;
+        double* A2; hipMalloc(&A2, 4096 * 8); hipMemcpy(A2, h2.data(), 4096 * 8, hipMemcpyHostToDevice);
+        int hi[4];
+        for (int pass = 0; pass < 2; ++pass) {
+            const int arm[4] = {0, 0, pass, 0};
+            hipMemcpy(info, arm, 16, hipMemcpyHostToDevice);
+            run<true, 0>(pass ? "zero + negative pivot, early rejection armed: w" : "zero + negative pivot: potrf64w_core", A2, scratch, cyc, info); fetch(rw);
+            hipMemcpy(hi, info, 16, hipMemcpyDeviceToHost); printf("    info = %d %d\n", hi[0], hi[1]);
+            hipMemcpy(info, arm, 16, hipMemcpyHostToDevice);
+            run<true, 8>(pass ? "zero + negative pivot, early rejection armed: v" : "zero + negative pivot: potrf64v_core", A2, scratch, cyc, info); fetch(rv);
+            hipMemcpy(hi, info, 16, hipMemcpyDeviceToHost); printf("    info = %d %d\n", hi[0], hi[1]);
+            cmp("vs potrf64w_core", rw, rv);
+            hipMemcpy(info, arm, 16, hipMemcpyHostToDevice);
+            run<true, 6>("  ... potrf64v_core with the round-5 arithmetic", A2, scratch, cyc, info); fetch(rv); cmp("vs potrf64w_core", rw, rv);
+        }
+        hipMemset(info, 0, 64);
+        run<false, 0>("Cholesky of the same matrix: potrf64w_core", A2, scratch, cyc, info); fetch(rw);
+        hipMemcpy(hi, info, 16, hipMemcpyDeviceToHost); printf("    info = %d\n", hi[0]);
+        hipMemset(info, 0, 64);
+        run<false, 6>("Cholesky of the same matrix: potrf64v_core, round-5 arithmetic", A2, scratch, cyc, info); fetch(rv);
+        hipMemcpy(hi, info, 16, hipMemcpyDeviceToHost); printf("    info = %d\n", hi[0]);
+        cmp("vs potrf64w_core", rw, rv);
+        hipMemset(info, 0, 64);
+        hipFree(A2);
+    }
     return 0;
 }
