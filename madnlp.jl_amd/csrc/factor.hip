@@ -216,16 +216,19 @@ constexpr int PP_LDS_BYTES = 3 * 4096 * 8;  // two staging tiles (the first doub
 constexpr int PC_LDS_BYTES = 4 * 4096 * 8;  // pivot-chain kernels: + the strip's NEXT diagonal block (see pp_strip, EARLY)
 
 // acc[cb2] += sum over ib, s of tile[(4 cb2 + ib) * 64 + lane][s] * B[ib][s] for the 16x16 blocks cb2 < ncb2 (wave-uniform) of one 64x64 tile
-// in LDS (the chain strips' tile step: 64 products per wave).  The LDS read of block q + 1 is requested before the four products of
-// block q are issued: round 5's loops read, waited for the read and only then issued two products -- an exposed LDS latency in
-// front of every pair (the register allocator, at its limit in pchain_kernel, reused one register quadruple for all 32 reads) --
-// and negated every A operand on the way (two v_xor per read): the callers negate the B operand once instead.
+// in LDS (the chain strips' tile step: 64 products per wave).  The callers negate the B operand once per block column instead of
+// every A operand on its way from LDS (round 5: two v_xor per LDS read), and the read of block q + 1 is requested before the products
+// of block q.  Measured in the schedule (tools/chain_steps2.py, profiles/r06_chain_steps.txt): 1.79 us per tile step against the matrix
+// pipe's 1.71; the same loop as ONE inline-assembly block with every A operand requested six products ahead (ds_read_b64 into a ring
+// of eight registers) was 1.85 -- the LDS latency is not what a tile step waits for; its other 0.7 us are the 16 global loads of the
+// next tile (0.38), the arrival of this one + its way into LDS (0.26) and the barrier (0.05).
+template <bool FULL>
 __device__ __forceinline__ void tile_mac(const v4d* __restrict__ tile, const int lane, const int ncb2, const v4d* __restrict__ B, v4d* __restrict__ acc) {
     v4d a = tile[lane];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int cb2 = q >> 2, ib = q & 3;
-        if (ib == 0 && cb2 >= ncb2) break;
+        if (!FULL && ib == 0 && cb2 >= ncb2) break;
         v4d an = a;
         if (q < 15) an = tile[(q + 1) * 64 + lane];
 #pragma unroll
@@ -234,6 +237,14 @@ __device__ __forceinline__ void tile_mac(const v4d* __restrict__ tile, const int
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this block's four products
         a = an;
     }
+}
+// (a diagonal strip's own block: lower triangle only -- the 16x16 blocks cb2 <= w)
+__device__ __forceinline__ void tile_mac(const v4d* __restrict__ tile, const int lane, const bool own_block, const int w, const v4d* __restrict__ B, v4d* __restrict__ acc) {
+    if (own_block) tile_mac<false>(tile, lane, w + 1, B, acc);
+    else tile_mac<true>(tile, lane, 4, B, acc);
+}
+__device__ __forceinline__ void pin(v4d& x) {   // (the value as it is, in registers: a negation is not to be re-done at every use)
+    asm volatile("" : "+v"(x));
 }
 
 // Wave-uniform bounded wait for prog[c] >= target.  `seen` caches the last values read: one acquire covers everything
@@ -328,6 +339,11 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                           // second half of the chain's trace region, single-phase schedules of <= 64 strip-columns; tools/chain_steps2.py)
     unsigned long long* tr2 = ptr_tr != nullptr && (p0 >> 8) < 64 ? ptr_tr + 2048 * 8 + ((p0 >> 8) * 8 * (int64_t)gridDim.x + 8 * t) : nullptr;
 #define MNK_TR2(slot) do { if (tr2) tr2[slot] = wall_clock64(); } while (0)
+    // ... and eight sums over the prologue's tile steps, in shader cycles: {steps, wait for the tile's loads + LDS write, barrier, issue of the
+    // next loads, the 64 products, total}
+    unsigned long long* tr3 = ptr_tr != nullptr && (p0 >> 8) < 64 ? ptr_tr + 3072 * 8 : nullptr;
+    unsigned long long pr_n = 0, pr_vm = 0, pr_bar = 0, pr_ld = 0, pr_mac = 0;
+#define MNK_PCLK() __builtin_readcyclecounter()
 #else
 #define MNK_TR2(slot) do { } while (0)
 #endif
@@ -415,22 +431,39 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         b_load(0, Bn);
         for (int kc = 0; kc < nch; ++kc) {
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) Bv[ib] = -Bn[ib];   // (T -= V L^T: the sign goes into the operand that is copied anyway)
+            for (int ib = 0; ib < 4; ++ib) { Bv[ib] = -Bn[ib]; pin(Bv[ib]); }   // (T -= V L^T: the sign goes into the operand that is copied anyway)
             if (kc + 1 < nch) b_load(kc + 1, Bn);
 #pragma unroll
             for (int c = 0; c < NB; ++c) {
                 if (c >= ncb) break;
                 v4d* tile = stage + (it & 1) * 1024;
                 ++it;
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k0 = MNK_PCLK();
+#endif
 #pragma unroll
                 for (int ib = 0; ib < 4; ++ib) tile[((lane >> 4) * 4 + ib) * 64 + (lane & 15) + 16 * w] = pre[ib];
+#if MNK_DIAG_STEP_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long k1 = MNK_PCLK();
+#endif
                 __syncthreads();
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k2c = MNK_PCLK();
+#endif
                 {
                     int c2 = c + 1, k2 = kc;
                     if (c2 >= ncb) { c2 = 0; k2 = kc + 1; }
                     if (k2 < nch) tile_load(k2, c2);
                 }
-                tile_mac(tile, lane, c == t ? w + 1 : 4, Bv, &X[4 * c]);   // (own diagonal block: lower triangle only)
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k3 = MNK_PCLK();
+#endif
+                tile_mac(tile, lane, c == t, w, Bv, &X[4 * c]);
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k4 = MNK_PCLK();
+                pr_n += 1; pr_vm += k1 - k0; pr_bar += k2c - k1; pr_ld += k3 - k2c; pr_mac += k4 - k3;
+#endif
             }
         }
         __syncthreads();
@@ -449,6 +482,9 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             }
     }
     if (ptr_tr) ptr_tr[4] = wall_clock64();
+#if MNK_DIAG_STEP_TRACE
+    if (tr3) { tr3[0] = pr_n; tr3[1] = pr_vm; tr3[2] = pr_bar; tr3[3] = pr_ld; tr3[4] = pr_mac; }
+#endif
 
     // One step per column block.  `j` is a compile-time constant (generic lambda over integral_constant), so every
     // index into X is static from the start and the strip stays in registers; returns true when the strip is done.
@@ -647,7 +683,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         // (X[4 j ..] is not read again as what it was: later steps and strip-columns take the stored values)
         v4d* const Bj = &X[4 * j];
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib) Bj[ib] = -Bj[ib];
+        for (int ib = 0; ib < 4; ++ib) { Bj[ib] = -Bj[ib]; pin(Bj[ib]); }
 #pragma unroll
         for (int c = j + 1; c < NB; ++c) {
             if (c > jmax) break;
@@ -658,7 +694,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             }
             __syncthreads();
             if (c + 1 < NB && c + 1 <= jmax && c + 1 != t) prefetch(c + 1 < NB ? c + 1 : 0);
-            tile_mac(tile, lane, c == t ? w + 1 : 4, Bj, &X[4 * c]);   // (own diagonal block: lower triangle only)
+            tile_mac(tile, lane, c == t, w, Bj, &X[4 * c]);
         }
         if (EARLY && make_xn) {
             // ---- the same product for the strip's diagonal block of the NEXT strip-column (its k-chunk j)
@@ -667,7 +703,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
 #pragma unroll
             for (int cb2 = 0; cb2 < 4; ++cb2)
                 if (cb2 <= w) acc[cb2] = xn[(w * 4 + cb2) * 64 + lane];
-            tile_mac(own, lane, w + 1, Bj, acc);
+            tile_mac<false>(own, lane, w + 1, Bj, acc);
 #pragma unroll
             for (int cb2 = 0; cb2 < 4; ++cb2)
                 if (cb2 <= w) {

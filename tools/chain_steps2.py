@@ -51,4 +51,10 @@ for Js in show:
             elif j == t:
                 line.append(f"j={j}: leaf {us(c1[t, 7]) - (pub[j - 1] if j > 0 else pub[0]):5.1f} .. {us(c1[t, 2]) - (pub[j - 1] if j > 0 else pub[0]):5.1f} after block {max(j - 1, 0)} |")
         print(" ".join(line))
+    c3 = v[ntasks * 8 + 3072 * 8 + Js * 8 * G: ntasks * 8 + 3072 * 8 + Js * 8 * G + 8 * nst].astype(np.float64).reshape(nst, 8)
+    for t in range(nst):
+        n = c3[t, 0]
+        if n > 0:
+            print(f"  strip {t:2d} prologue: {int(n):2d} tile steps; per step (us at 2.4 GHz): loads awaited + LDS write {c3[t, 1] / n / 2400:5.2f}, barrier {c3[t, 2] / n / 2400:5.2f}, "
+                  f"next loads issued {c3[t, 3] / n / 2400:5.2f}, 64 products {c3[t, 4] / n / 2400:5.2f}, sum {(c3[t, 1:5].sum()) / n / 2400:5.2f}")
 ls.close()

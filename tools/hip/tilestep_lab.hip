@@ -18,6 +18,7 @@ __global__ void writer(double* F, int64_t n, double v) {   // the producer: writ
 // VAR 0: shipped loop (one register set, load of the next tile issued behind the barrier)
 // VAR 1: two register sets (prefetch distance 2)
 // VAR 2: no global loads at all (tiles constant in LDS): the loop's own floor
+// VAR 3: eight 16-byte loads per lane (two consecutive rows of one column) instead of sixteen 8-byte loads, two 8-byte LDS writes each
 template <int VAR>
 __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const double* __restrict__ Vp, int64_t ld, int64_t ldv, int64_t p0,
                                             int t, double* out, unsigned long long* cyc, int reps) {
@@ -34,6 +35,24 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
         __syncthreads();
         const unsigned long long t0 = lab_clock();
         v4d pre[4], pre2[4], Bv[4], Bn[4];
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d pq[8];
+        auto tile_load4 = [&](int kc, int c) {
+            const double* src = F + (p0 + 64 * (int64_t)c + 2 * (lane & 31)) + (p0 - Kp + 64 * (int64_t)kc + 2 * w + (lane >> 5)) * ld;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pq[k] = *reinterpret_cast<const v2d*>(src + (8 * k) * ld);
+        };
+        auto tile_store4 = [&](v4d* tile) {
+            double* td = reinterpret_cast<double*>(tile);
+            const int r = 2 * (lane & 31);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int cc = 8 * k + 2 * w + (lane >> 5);
+                const int idx = (((r >> 4) * 4 + (cc >> 4)) * 64 + (r & 15) + 16 * (cc & 3)) * 4 + ((cc >> 2) & 3);
+                td[idx] = pq[k][0];
+                td[idx + 4] = pq[k][1];
+            }
+        };
         auto tile_load = [&](int kc, int c, v4d (&P)[4]) {
             const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 - Kp + 64 * (int64_t)kc + w) * ld;
 #pragma unroll
@@ -50,7 +69,8 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
         };
         auto nxt = [&](int& kc, int& c) { if (++c >= ncb) { c = 0; ++kc; } };
         int it = 0;
-        if (VAR != 2) tile_load(0, 0, pre);
+        if (VAR == 3) tile_load4(0, 0);
+        else if (VAR != 2) tile_load(0, 0, pre);
         int k2 = 0, c2 = 0;
         nxt(k2, c2);
         if (VAR == 1) tile_load(k2, c2, pre2);
@@ -62,16 +82,17 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 v4d* tile = stage + (it & 1) * 1024;
-                if (VAR != 2) {
+                if (VAR == 3) tile_store4(tile);
+                else if (VAR != 2) {
 #pragma unroll
                     for (int ib = 0; ib < 4; ++ib) tile[((lane >> 4) * 4 + ib) * 64 + (lane & 15) + 16 * w] = (VAR == 1 && (it & 1)) ? pre2[ib] : pre[ib];
                 }
                 ++it;
                 __syncthreads();
-                if (VAR == 0) {
+                if (VAR == 0 || VAR == 3) {
                     int c3 = c + 1, k3 = kc;
                     if (c3 >= ncb) { c3 = 0; k3 = kc + 1; }
-                    if (k3 < nch) tile_load(k3, c3, pre);
+                    if (k3 < nch) { if (VAR == 3) tile_load4(k3, c3); else tile_load(k3, c3, pre); }
                 }
                 if (VAR == 1) {   // the tile two steps ahead, into the register set this step has just emptied
                     int c3 = c, k3 = kc;
@@ -124,6 +145,7 @@ int main() {
         run<2>("no global loads (LDS tiles as they are): the loop's floor", F, V, ld, out, cyc, cold);
         run<0>("shipped: one register set, next tile requested behind the barrier", F, V, ld, out, cyc, cold);
         run<1>("two register sets: the tile two steps ahead", F, V, ld, out, cyc, cold);
+        run<3>("eight 16-byte loads (row pairs) + 8-byte LDS writes", F, V, ld, out, cyc, cold);
     }
     return 0;
 }
