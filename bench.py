@@ -81,6 +81,8 @@ def parse_args():
                     help="batch > 1: enqueue the factorizations one by one instead of through mnk_factorize_batch_begin/_end "
                          "(one merged persistent launch for all instances of a step: they fill each other's chain-bound ends)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5-shape", action="store_true",
+                    help="skip the supplementary `c5_shape_per_gpu` record (16 instances per step on this GPU, ~15 s)")
     ap.add_argument("--no-c4", action="store_true", help="skip the supplementary config-C4 record (case9241pegase shape, ~15 s)")
     ap.add_argument("--no-ipm-loop", action="store_true",
                     help="skip the supplementary end-to-end IPM run (device-resident vectors) reported as `end_to_end_ipm`")
@@ -316,7 +318,7 @@ def cpu_baseline(P, algorithm, nsolve, budget_s=100.0):
         seen.add((alg, thr))
         # predicted cost of this leg: the slowest run of the same algorithm so far (1-thread legs: 40 s if unknown)
         prev = [r["ms_per_factorize"] for r in runs if r["algorithm"] == alg]
-        est = 1e-3 * max(prev) if prev else (40.0 if thr == 1 else 15.0)
+        est = 1e-3 * max(prev) if prev else (8.0 if thr == 1 else 4.0)   # (measured on the pool's hosts: 5.3 s at 1 thread, 1.6 s at 16)
         if runs and time.perf_counter() - t_start + est > budget_s:
             skipped.append({"algorithm": alg, "blas_threads": int(thr), "reason": "cpu-baseline time budget"})
             continue
@@ -422,6 +424,42 @@ def config_c4(ctx, torch, mj):
     return rec
 
 
+def shader_clock(local=0):
+    """Shader (sclk) and memory clock of the GPU right now, MHz -- read before and after the timed region so that a box that
+    runs the same build 2 % slower shows up in the line (9.52 ms on the driver's box against 9.28-9.35 on four
+    others).  sysfs first (pp_dpm_sclk: the level marked '*'), `rocm-smi --showclocks` as the fall-back; None if neither
+    answers (the bench never fails on this)."""
+    import glob
+    import re
+    import subprocess
+    rec = {}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        if cards:
+            path = cards[min(local, len(cards) - 1)]
+            for key, fn in (("sclk_mhz", path), ("mclk_mhz", path.replace("pp_dpm_sclk", "pp_dpm_mclk"))):
+                cur = [ln for ln in open(fn).read().splitlines() if ln.strip().endswith("*")]
+                if cur:
+                    rec[key] = float(re.search(r"(\d+)\s*Mhz", cur[0], re.I).group(1))
+            if rec:
+                rec["source"] = "sysfs pp_dpm_sclk"
+                return rec
+    except Exception:
+        pass
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(local), "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        for key, tag in (("sclk_mhz", "sclk"), ("mclk_mhz", "mclk")):
+            m = re.search(tag + r" clock level:?\s*\d*:?\s*\((\d+)Mhz\)", out, re.I)
+            if m:
+                rec[key] = float(m.group(1))
+        if rec:
+            rec["source"] = "rocm-smi --showclocks"
+            return rec
+    except Exception:
+        pass
+    return None
+
+
 # ---------------------------------------------------------------------------- main
 def main():
     args = parse_args()
@@ -452,93 +490,134 @@ def main():
     tstream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(tstream)
     ctx = mj.HipContext(local, stream=tstream.cuda_stream)
-    # independent instances: seed = base + rank * batch + b; instance 0 uses the bench stream
-    base_seed = OPF_CASES[args.case][0] + rank * args.batch
-    insts = []
-    ctxs = [(ctx, tstream)]
-    for bidx in range(args.batch):
-        slot = bidx % max(1, args.concurrency)
-        if slot >= len(ctxs):
-            st = torch.cuda.Stream(dev)
-            ctxs.append((mj.HipContext(local, stream=st.cuda_stream), st))
-        ictx, istream = ctxs[slot]
-        Pb = opf_shaped(args.case, seed=base_seed + bidx, du=1e-8)
-        kb = mj.SparseCondensedKKTSystem(
-            Pb.n, Pb.m, Pb.jac_I, Pb.jac_J, Pb.hess_I, Pb.hess_J, Pb.ind_ineq, Pb.ind_lb, Pb.ind_ub, ctx=ictx,
-            opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=args.algorithm, outer_block=args.outer_block))
-        dev_in = dict(jac=torch.from_numpy(Pb.jac).to(dev), hess=torch.from_numpy(Pb.hess).to(dev),
-                      pr=torch.from_numpy(Pb.pr_diag).to(dev), du=torch.from_numpy(Pb.du_diag).to(dev),
-                      rhs=torch.from_numpy(np.random.default_rng(base_seed + bidx).standard_normal(Pb.n)).to(dev))
-        dev_in["x"] = torch.empty_like(dev_in["rhs"])
-        insts.append((Pb, kb, istream, dev_in))
-    P, kkt = insts[0][0], insts[0][1]
-    ls = kkt.linear_solver
-    d_jac, d_hess, d_pr, d_du, d_rhs, d_x = (insts[0][3][k] for k in ("jac", "hess", "pr", "du", "rhs", "x"))
+    def make_workload(batch, concurrency):
+        """`batch` independent instances on this GPU and the step that advances every one of them by one iteration."""
+        # independent instances: seed = base + rank * batch + b (SURVEY 8e); instance 0 uses the bench stream
+        base_seed = OPF_CASES[args.case][0] + rank * batch
+        insts = []
+        ctxs = [(ctx, tstream)]
+        for bidx in range(batch):
+            slot = bidx % max(1, concurrency)
+            if slot >= len(ctxs):
+                st = torch.cuda.Stream(dev)
+                ctxs.append((mj.HipContext(local, stream=st.cuda_stream), st))
+            ictx, istream = ctxs[slot]
+            Pb = opf_shaped(args.case, seed=base_seed + bidx, du=1e-8)
+            kb = mj.SparseCondensedKKTSystem(
+                Pb.n, Pb.m, Pb.jac_I, Pb.jac_J, Pb.hess_I, Pb.hess_J, Pb.ind_ineq, Pb.ind_lb, Pb.ind_ub, ctx=ictx,
+                opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=args.algorithm, outer_block=args.outer_block))
+            dev_in = dict(jac=torch.from_numpy(Pb.jac).to(dev), hess=torch.from_numpy(Pb.hess).to(dev),
+                          pr=torch.from_numpy(Pb.pr_diag).to(dev), du=torch.from_numpy(Pb.du_diag).to(dev),
+                          rhs=torch.from_numpy(np.random.default_rng(base_seed + bidx).standard_normal(Pb.n)).to(dev))
+            dev_in["x"] = torch.empty_like(dev_in["rhs"])
+            insts.append((Pb, kb, istream, dev_in))
+        P, kkt = insts[0][0], insts[0][1]
+        ls = kkt.linear_solver
+        d_jac, d_hess, d_pr, d_du, d_rhs, d_x = (insts[0][3][k] for k in ("jac", "hess", "pr", "du", "rhs", "x"))
 
-    # One IPM iteration of the hot path.  The inertia is FETCHED inside the step (device sync + D2H of
-    # three counters): the IPM cannot decide between "solve" and "regularize + refactorize" without it
-    # (reference src/IPM/solver.jl:611-670), so a real iteration pays that synchronization.
-    def step_front(kb, st, din):
-        with torch.cuda.stream(st):
-            kb.compress_jacobian(din["jac"])
-            kb.compress_hessian(din["hess"])
-            kb.build_kkt(din["pr"], din["du"])
-            kb.linear_solver.factorize_async()
+        # One IPM iteration of the hot path.  The inertia is FETCHED inside the step (device sync + D2H of
+        # three counters): the IPM cannot decide between "solve" and "regularize + refactorize" without it
+        # (reference src/IPM/solver.jl:611-670), so a real iteration pays that synchronization.
+        def step_front(kb, st, din):
+            with torch.cuda.stream(st):
+                kb.compress_jacobian(din["jac"])
+                kb.compress_hessian(din["hess"])
+                kb.build_kkt(din["pr"], din["du"])
+                kb.linear_solver.factorize_async()
 
-    def step_back(kb, st, din):
-        with torch.cuda.stream(st):
-            inertia = kb.linear_solver.inertia()
-            if not kb.is_inertia_correct(*inertia):
-                raise SystemExit(f"unexpected inertia {inertia} on the benchmark system")
-            for _ in range(args.nsolve):
-                din["x"].copy_(din["rhs"])
-                kb.linear_solver.solve_linear_system(din["x"])
+        def step_back(kb, st, din):
+            with torch.cuda.stream(st):
+                inertia = kb.linear_solver.inertia()
+                if not kb.is_inertia_correct(*inertia):
+                    raise SystemExit(f"unexpected inertia {inertia} on the benchmark system")
+                for _ in range(args.nsolve):
+                    din["x"].copy_(din["rhs"])
+                    kb.linear_solver.solve_linear_system(din["x"])
 
-    use_batch_api = args.batch > 1 and not args.no_batch_api
-    sbatches = []
-    if use_batch_api:
-        # one ScenarioBatch per context / stream (array entry points: one library call per phase and context instead of
-        # four to six per instance)
-        for (cctx, cst) in ctxs:
-            mine = [it for it in insts if it[2] is cst]
-            if mine:
-                sb = mj.ScenarioBatch([it[1] for it in mine])
-                sb.bind([it[3]["jac"] for it in mine], [it[3]["hess"] for it in mine], [it[3]["pr"] for it in mine],
-                        [it[3]["du"] for it in mine])
-                sbatches.append((sb, cst, mine, [it[3]["x"] for it in mine], [it[3]["rhs"] for it in mine]))
-
-    def step():
-        # batch: every instance's assembly + factorization is enqueued before the first inertia fetch
-        # blocks the host, so the contexts keep the chip busy while the host waits
+        use_batch_api = batch > 1 and not args.no_batch_api
+        sbatches = []
         if use_batch_api:
-            with mj.factorize_batch():      # (all contexts' instances in ONE batch)
-                for (sb, cst, mine, xs, rhss) in sbatches:
-                    sb.step()
-        else:
-            for (_, kb, st, din) in insts:
-                step_front(kb, st, din)
-        if use_batch_api:
-            # every instance's inertia, then solve k of all instances together (mnk_solve_batch_begin / _end: up to four
-            # independent systems per launch), k = 1 .. nsolve -- the same work per instance as step_back
-            for (sb, cst, mine, xs, rhss) in sbatches:
-                for it, inertia in zip(mine, sb.inertia()):
-                    if not it[1].is_inertia_correct(*inertia):
-                        raise SystemExit(f"unexpected inertia {inertia} on the benchmark system")
-            for _ in range(args.nsolve):
-                with mj.solve_batch():      # (all contexts' instances in ONE batch)
+            # one ScenarioBatch per context / stream (array entry points: one library call per phase and context instead of
+            # four to six per instance)
+            for (cctx, cst) in ctxs:
+                mine = [it for it in insts if it[2] is cst]
+                if mine:
+                    sb = mj.ScenarioBatch([it[1] for it in mine])
+                    sb.bind([it[3]["jac"] for it in mine], [it[3]["hess"] for it in mine], [it[3]["pr"] for it in mine],
+                            [it[3]["du"] for it in mine])
+                    sbatches.append((sb, cst, mine, [it[3]["x"] for it in mine], [it[3]["rhs"] for it in mine]))
+
+        def step():
+            # batch: every instance's assembly + factorization is enqueued before the first inertia fetch
+            # blocks the host, so the contexts keep the chip busy while the host waits
+            if use_batch_api:
+                with mj.factorize_batch():      # (all contexts' instances in ONE batch)
                     for (sb, cst, mine, xs, rhss) in sbatches:
-                        with torch.cuda.stream(cst):
-                            torch._foreach_copy_(xs, rhss)
-                        sb.solve(xs)
-        else:
-            for (_, kb, st, din) in insts:
-                step_back(kb, st, din)
+                        sb.step()
+            else:
+                for (_, kb, st, din) in insts:
+                    step_front(kb, st, din)
+            if use_batch_api:
+                # every instance's inertia, then solve k of all instances together (mnk_solve_batch_begin / _end: up to four
+                # independent systems per launch), k = 1 .. nsolve -- the same work per instance as step_back
+                for (sb, cst, mine, xs, rhss) in sbatches:
+                    for it, inertia in zip(mine, sb.inertia()):
+                        if not it[1].is_inertia_correct(*inertia):
+                            raise SystemExit(f"unexpected inertia {inertia} on the benchmark system")
+                for _ in range(args.nsolve):
+                    with mj.solve_batch():      # (all contexts' instances in ONE batch)
+                        for (sb, cst, mine, xs, rhss) in sbatches:
+                            with torch.cuda.stream(cst):
+                                torch._foreach_copy_(xs, rhss)
+                            sb.solve(xs)
+            else:
+                for (_, kb, st, din) in insts:
+                    step_back(kb, st, din)
+
+        def close():
+            for (_, kb, _, _) in insts:
+                kb.close()
+            for (cctx, _) in ctxs[1:]:
+                cctx.close()
+        return {"insts": insts, "step": step, "use_batch_api": use_batch_api, "close": close, "P": P, "kkt": kkt, "ls": ls,
+                "dev_in": insts[0][3]}
+
+    wl = make_workload(args.batch, args.concurrency)
+    insts, step, use_batch_api, P, kkt, ls = wl["insts"], wl["step"], wl["use_batch_api"], wl["P"], wl["kkt"], wl["ls"]
+    d_jac, d_hess, d_pr, d_du, d_rhs, d_x = (wl["dev_in"][k] for k in ("jac", "hess", "pr", "du", "rhs", "x"))
 
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
     dt = lambda v: torch.tensor(v, dtype=torch.float64, device=dev)  # noqa: E731
 
+    def c5_shape_solo(step16, nb, steps=3):
+        """BASELINE config C5's per-GPU share on THIS GPU alone: `nb` independent instances per step through the batch API,
+        one warm-up + `steps` timed steps (device synchronization on both sides)."""
+        step16()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step16()
+        sync()
+        el = time.perf_counter() - t0
+        return {"value": nb * steps / el, "unit": "it/s per GPU", "instances_per_step": nb, "steps": steps, "ms_per_step": 1e3 * el / steps,
+                "ms_per_instance": 1e3 * el / steps / nb}
+
+    # N > 1: the denominator of the scaling curve is measured in the same run -- rank 0's GPU alone on its own 16 instances while the
+    # other ranks wait at a barrier (VERDICT r5 item 2: `--gpus 1` is config C3, one instance; its value is NOT the per-GPU share of C5)
+    solo = None
+    if dist is not None:
+        for _ in range(args.warmup):
+            step()
+        sync()
+        dist.barrier()
+        if rank == 0:
+            solo = c5_shape_solo(step, args.batch)
+        dist.barrier()
+
+    clk0 = shader_clock(local) if rank == 0 else None
     # (the inertia of every factorization is checked inside the step: wrong inertia voids the numbers)
     elapsed = timed_region(step, args.steps, args.warmup, sync, dist, dt)
+    clk1 = shader_clock(local) if rank == 0 else None
 
     # per-phase breakdown, the reference's `timing_linear_solver` protocol (src/utils.jl:185-197):
     # each phase alone between device synchronizations, HIP events on the launch stream.
@@ -552,7 +631,7 @@ def main():
             b.record()
             sync()
             out.append(a.elapsed_time(b))
-        return float(np.mean(out))
+        return out
 
     def assemble():
         kkt.compress_jacobian(d_jac)
@@ -564,8 +643,8 @@ def main():
         ls.solve_linear_system(d_x)
 
     reps = max(3, min(10, args.steps))
-    ms = {"assemble": phase_ms(assemble, reps), "factorize": phase_ms(ls.factorize_async, reps),
-          "solve": phase_ms(one_solve, reps)}
+    samples = {"assemble": phase_ms(assemble, reps), "factorize": phase_ms(ls.factorize_async, reps), "solve": phase_ms(one_solve, reps)}
+    ms = {k: float(np.mean(v)) for k, v in samples.items()}
     allms = gather_stats([ms["assemble"], ms["factorize"], ms["solve"]], dist, world, dt)
 
     out = None
@@ -598,6 +677,11 @@ def main():
                                      else ("off" if args.batch > 1 else "n/a (one instance)")),
                        "parallelism": f"{world} GPU(s) x {args.batch} independent instance(s)"},
             "ms_per_factorize": fact_ms,
+            # rank 0's own repetitions of the phase (the mean above is what `roofline` is computed from)
+            "ms_per_factorize_min": float(np.min(samples["factorize"])), "ms_per_factorize_median": float(np.median(samples["factorize"])),
+            "ms_per_factorize_samples": [float(v) for v in samples["factorize"]],
+            "ms_per_solve_min": float(np.min(samples["solve"])), "ms_per_solve_median": float(np.median(samples["solve"])),
+            "clocks": {"before_timed_region": clk0, "after_timed_region": clk1},
             "ms_per_solve": float(np.mean([a[2] for a in allms])),
             "ms_assemble": float(np.mean([a[0] for a in allms])),
             "per_rank_ms": allms,
@@ -608,6 +692,29 @@ def main():
                                    "HIP-event timed on the launch stream)",
                          "schedule_panel_algo": schedule, "pp_fallbacks": fallbacks},
         }
+        if world > 1 and solo is not None:
+            # the scaling curve's own denominator: rank 0's GPU alone on the same per-GPU share (measured above, outside the timed region)
+            out["per_gpu_value"] = out["value"] / world
+            out["c5_shape_per_gpu"] = dict(solo, workload=f"rank 0 alone: {args.batch} independent {args.case}-shaped instances per step, batch API")
+            out["efficiency_vs_c5_shape_per_gpu"] = out["per_gpu_value"] / solo["value"]
+        if world == 1 and args.batch == 1 and not args.no_c5_shape:
+            # Supplementary, OUTSIDE the timed region: BASELINE config C5's per-GPU share (16 independent instances per step through
+            # the batch API) on this GPU -- the number a `--gpus N` line's value / N is to be compared with
+            try:
+                wl16 = make_workload(16, 1)
+                rec16 = c5_shape_solo(wl16["step"], 16)
+                f16 = phase_ms(lambda: [wl16["step"]()], 1)[0]   # (one more step between events: the device's view of it)
+                rec16["ms_per_step_device"] = f16
+                rec16["workload"] = (f"BASELINE config C5 shape on one GPU: 16 independent {args.case}-shaped instances per step (seeds "
+                                     f"{OPF_CASES[args.case][0]}+i), mnk_factorize_batch_begin/_end, step = assembly + factorize + inertia + "
+                                     f"{args.nsolve} solves per instance")
+                # fp64-peak fraction of the step's factorizations if the whole step were factorization (a LOWER bound of theirs)
+                rec16["frac_lower_bound"] = 16 * flops / (rec16["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS
+                rec16["pp_fallbacks"] = float(sum(it[1].linear_solver.get_stat("pp_fallbacks") for it in wl16["insts"]))
+                wl16["close"]()
+                out["c5_shape_per_gpu"] = rec16
+            except Exception as e:  # never let the supplement break the bench line
+                out["c5_shape_per_gpu"] = {"error": repr(e)[:300]}
         if not args.no_ipm_loop and world == 1 and args.batch == 1:
             # Supplementary, OUTSIDE the timed region: complete IPM runs with device-resident vectors and callbacks
             # (madnlp_jl_amd.ipm_dev) -- the AC-OPF NLP of the same grid, and the convex QP of the same shape: real inertia
@@ -649,18 +756,34 @@ def dry_run(args):
     rank, world, local, dist = dist_setup(args.gpus, "gloo")
     dt = lambda v: torch.tensor(v, dtype=torch.float64)  # noqa: E731
     step = lambda: time.sleep(0.002 * (1 + rank))  # noqa: E731  (rank-dependent: MAX must pick the slowest)
+    solo = None
+    if dist is not None:   # (the same solo phase as the GPU path: rank 0 alone between two barriers)
+        dist.barrier()
+        if rank == 0:
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            solo = 3 / (time.perf_counter() - t0)
+        dist.barrier()
     elapsed = timed_region(step, args.steps, args.warmup, lambda: None, dist, dt)
     allms = gather_stats([1.0 + rank, 2.0 + rank, 3.0 + rank], dist, world, dt)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": world * args.steps / elapsed, "unit": "it/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                          "data": "dry-run (no kernels, not a measurement)", "per_rank_ms": allms,
-                          "config": {"workload": "cpu dry run", "batch_per_gpu": args.batch}}))
+        out = {"metric": METRIC, "value": world * args.steps / elapsed, "unit": "it/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "dry-run (no kernels, not a measurement)", "per_rank_ms": allms,
+               "ms_per_factorize": 1.0, "ms_per_factorize_min": 1.0, "ms_per_factorize_median": 1.0,
+               "clocks": {"before_timed_region": shader_clock(0), "after_timed_region": shader_clock(0)},
+               "config": {"workload": "cpu dry run", "batch_per_gpu": args.batch}}
+        if world > 1 and solo is not None:
+            out["per_gpu_value"] = out["value"] / world
+            out["c5_shape_per_gpu"] = {"value": solo, "unit": "it/s per GPU", "instances_per_step": args.batch, "steps": 3}
+            out["efficiency_vs_c5_shape_per_gpu"] = out["per_gpu_value"] / solo
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -28,6 +28,16 @@ def test_two_ranks_gloo():
     # whole-job aggregate: both ranks' units over the max time
     assert abs(out["value"] - 2 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-6 * out["value"]
     assert out["per_rank_ms"] == [[1.0, 2.0, 3.0], [2.0, 3.0, 4.0]]  # the single timing all-gather
+    # the scaling curve's own denominator, measured in the same run (rank 0 alone between two barriers), and the fields that make a
+    # slow box visible in the line
+    assert abs(out["per_gpu_value"] - out["value"] / 2) < 1e-9 * out["value"]
+    assert out["c5_shape_per_gpu"]["value"] > 0 and out["c5_shape_per_gpu"]["steps"] == 3
+    assert abs(out["efficiency_vs_c5_shape_per_gpu"] - out["per_gpu_value"] / out["c5_shape_per_gpu"]["value"]) < 1e-9
+    # rank 0 alone sleeps 2 ms per step, the pair is paced by rank 1's 4 ms: the dry run's "efficiency" is about one half
+    assert 0.3 < out["efficiency_vs_c5_shape_per_gpu"] < 0.7
+    for key in ("ms_per_factorize", "ms_per_factorize_min", "ms_per_factorize_median"):
+        assert key in out
+    assert set(out["clocks"]) == {"before_timed_region", "after_timed_region"}
 
 
 def test_single_rank_no_process_group():

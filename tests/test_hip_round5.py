@@ -377,6 +377,9 @@ def test_bench_py_on_two_gpus_over_rccl():
     rows = two["per_rank_ms"]
     assert len(rows) == 2 and rows[0] != rows[1]
     assert abs(two["value"] - 2.0 * one["value"]) <= 0.10 * 2.0 * one["value"], (one["value"], two["value"])
+    # round 6: the line carries its own denominator (rank 0's GPU alone on the same 16 instances, measured in the same run)
+    assert abs(two["per_gpu_value"] - two["value"] / 2) <= 1e-9 * two["value"]
+    assert two["efficiency_vs_c5_shape_per_gpu"] >= 0.95, (two["per_gpu_value"], two["c5_shape_per_gpu"])
     assert two["roofline"]["pp_fallbacks"] == 0.0
 
 
