@@ -211,9 +211,14 @@ def ipm_loop(args, ctx, model="acopf"):
                "backsolves": s.cnt.backsolve_cnt, "wall_s": wall, "ms_per_iteration": 1e3 * wall / max(1, s.cnt.k),
                "it_per_s": s.cnt.k / wall}
         try:   # (how many of the factorizations were trials the static-pivot tier rejected at their first non-positive pivot)
-            rec["early_rejected_trials"] = int(s.kkt.linear_solver.get_stat("early_rejects"))
+            rec["early_rejected_trials"] = int(s.kkt.linear_solver.get_stat("early_rejects") +
+                                               (s.kkt.spare_solver.get_stat("early_rejects") if getattr(s.kkt, "spare_solver", None) else 0))
         except Exception:
             pass
+        # speculative first corrections (ipm_dev.inertia_correction): trials factorized ahead of the verdict on the unperturbed
+        # matrix, in one merged launch with it; `wasted`: the unperturbed matrix was accepted after all
+        rec["speculative_factorizations"] = int(s.speculative_factorizations)
+        rec["speculative_wasted"] = int(s.speculative_wasted)
         s.cb.close()
         s.K.close()
         s.kkt.close()

@@ -276,6 +276,12 @@ int mnk_sc_set_aug_diagonal(mnk_sc* sc, const double* x, const double* xl, const
 int mnk_sc_regularize_diagonal(mnk_sc* sc, double primal, double dual);
 int mnk_sc_get_diagonals(mnk_sc* sc, double* pr_diag, double* du_diag, double* reg, double* l_diag, double* u_diag,
                          double* l_lower, double* u_lower);
+/* The bracket of a speculative trial of inertia_correction! (reference src/IPM/solver.jl:611-670; the speculation itself lives in
+ * the caller -- madnlp_jl_amd/ipm_dev.py): reg, pr_diag and du_diag are copied into a buffer of the handle
+ * before regularize_diagonal! perturbs them for the trial that is factorized AHEAD of the verdict on the unperturbed matrix, and
+ * copied back -- bit for bit -- when that matrix is accepted after all. */
+int mnk_sc_save_diagonals(mnk_sc* sc);
+int mnk_sc_restore_diagonals(mnk_sc* sc);
 
 /* The dense twins: w = [x (n); s (ns); y (m); zl; zu].  solve_kkt!(::DenseCondensedKKTSystem) reference
  * src/IPM/factorization.jl:190-229, the reduced solve of DenseKKTSystem :41-46, mul!(::AbstractDenseKKTSystem)

@@ -121,6 +121,8 @@ SIGNATURES = {
     "mnk_ls_get_factor": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mnk_sc_set_aug_diagonal": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
     "mnk_sc_regularize_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "mnk_sc_save_diagonals": (C.c_int, [_vp]),
+    "mnk_sc_restore_diagonals": (C.c_int, [_vp]),
     "mnk_sc_get_diagonals": (C.c_int, [_vp] + [_vp] * 7),
     "mnk_dc_set_aug_diagonal": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, C.c_double, C.c_int]),
     "mnk_dc_regularize_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),

@@ -176,6 +176,8 @@ struct mnk_sc_spmv_data {
     DevBuf<double> buffer, buffer2, wdev, xdev;   // m, m, len(w), len(w)
     DevBuf<double> feed;                          // staging of host iterates for mnk_sc_set_aug_diagonal
     bool have_bounds = false, have_terms = false, have_diag = false;
+    DevBuf<double> saved_diag;                    // reg | pr_diag | du_diag of mnk_sc_save_diagonals
+    bool have_saved_diag = false;
 };
 static mnk_sc_spmv_data* spmv_of(mnk_sc* sc) { return static_cast<mnk_sc_spmv_data*>(sc->extra); }
 
@@ -598,6 +600,40 @@ int mnk_sc_regularize_diagonal(mnk_sc* sc, double primal, double dual) {
     if (rc) return rc;
     MNK_REQUIRE(spmv_of(sc)->have_diag, "mnk_sc_regularize_diagonal: call mnk_sc_set_aug_diagonal first");
     return kkt_regularize_diagonal(v, primal, dual);
+}
+
+// reg, pr_diag and du_diag as they are, into a buffer of the handle / back from it (device copies on the handle's stream): the
+// bracket of a SPECULATIVE trial of inertia_correction! (madnlp_jl_amd.ipm_dev: the trial with the next perturbation is factorized
+// together with the unperturbed one; when the unperturbed matrix is accepted after all, the diagonals return to the bits they had
+// -- pr_diag + dw - dw would not)
+int mnk_sc_save_diagonals(mnk_sc* sc) {
+    AugDiagView v;
+    int rc = sc_diag_view(sc, v, "mnk_sc_save_diagonals");
+    if (rc) return rc;
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    MNK_REQUIRE(sp->have_diag, "mnk_sc_save_diagonals: call mnk_sc_set_aug_diagonal first");
+    const size_t npr = (size_t)v.npr, ndu = (size_t)v.ndu;
+    if (sp->saved_diag.n < 2 * npr + ndu && sp->saved_diag.alloc(2 * npr + ndu)) return -1;
+    hipStream_t s = sc->ctx->stream;
+    MNK_HIP(hipMemcpyAsync(sp->saved_diag.p, v.reg, npr * sizeof(double), hipMemcpyDeviceToDevice, s));
+    MNK_HIP(hipMemcpyAsync(sp->saved_diag.p + npr, v.pr_diag, npr * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (ndu > 0) MNK_HIP(hipMemcpyAsync(sp->saved_diag.p + 2 * npr, v.du_diag, ndu * sizeof(double), hipMemcpyDeviceToDevice, s));
+    sp->have_saved_diag = true;
+    return 0;
+}
+
+int mnk_sc_restore_diagonals(mnk_sc* sc) {
+    AugDiagView v;
+    int rc = sc_diag_view(sc, v, "mnk_sc_restore_diagonals");
+    if (rc) return rc;
+    mnk_sc_spmv_data* sp = spmv_of(sc);
+    MNK_REQUIRE(sp->have_saved_diag, "mnk_sc_restore_diagonals: nothing saved (mnk_sc_save_diagonals)");
+    const size_t npr = (size_t)v.npr, ndu = (size_t)v.ndu;
+    hipStream_t s = sc->ctx->stream;
+    MNK_HIP(hipMemcpyAsync(v.reg, sp->saved_diag.p, npr * sizeof(double), hipMemcpyDeviceToDevice, s));
+    MNK_HIP(hipMemcpyAsync(v.pr_diag, sp->saved_diag.p + npr, npr * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (ndu > 0) MNK_HIP(hipMemcpyAsync(v.du_diag, sp->saved_diag.p + 2 * npr, ndu * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return 0;
 }
 
 int mnk_sc_get_diagonals(mnk_sc* sc, double* pr_diag, double* du_diag, double* reg, double* l_diag, double* u_diag,

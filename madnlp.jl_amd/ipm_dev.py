@@ -367,17 +367,79 @@ class DeviceMadNLPSolver(MadNLPSolver):
 
     on_trial = None   # diagnostics: callable(solver, n_trial, inertia, inertia_correct, accepted) after every trial of inertia_correction
 
+    # SPECULATIVE first correction (round 6).  On the AC-OPF run of the bench line 17 of 20 iterations take exactly two trials: the
+    # unperturbed matrix is rejected, the first perturbation is accepted -- and that perturbation is known BEFORE the verdict on the
+    # unperturbed matrix: after an iteration that needed a correction it is max(min_hessian_perturbation, perturb_dec_fact *
+    # del_w_last) (reference src/IPM/solver.jl:633-636), and for a system whose should_regularize_dual is `true` whatever the
+    # inertia (SparseCondensedKKTSystem: src/KKT/Sparse/condensed.jl:141) del_c depends on mu alone.  Both trials are then
+    # assembled back to back and factorized as ONE batch of two (a second solver on the same KKT handle, one merged launch: the two
+    # fill each other's chain-bound ends, and trial 0 stops at its first non-positive pivot).  The speculative factor is used only
+    # if trial 0 is rejected, so the sequence of accepted perturbations -- and every bit of the accepted factors -- is the one
+    # the sequential loop produces; if trial 0 is accepted after all, reg / pr_diag / du_diag return to the bits they had
+    # (`save_diagonals_device`) and the matrix is assembled again.
+    #
+    # MEASURED, AND OFF BY DEFAULT (profiles/r06_speculative_correction.txt, tools/spec_pair_time.py): on the case1354pegase-shaped
+    # system the rejected trial stops at pivot ~2700-3100 of 11 192 -- but a right-looking elimination has done 1 - (1 - 0.25)^3 =
+    # 56 % of its flops by then: 4.4 ms alone against 9.2 for the accepted trial, and the merged pair is bulk-bound at the SUM of the
+    # two (13.3 ms against 13.7 one after the other: what it saves is one host round trip).  Every wasted speculation costs a whole
+    # factorization (+9 ms), and the AC-OPF run ends at 59.7 instead of 65 iterations/s.  The path stays for systems whose
+    # rejections come early in the pivot order; `speculate = True` on the solver object arms it.
+    speculate = False     # (only ever taken for KKT systems that offer `ensure_spare_solver`)
+    speculative_factorizations = 0
+    speculative_wasted = 0
+
+    def _can_speculate(self):
+        k = self.kkt
+        return (self._on_device and self.speculate and self.del_w_last != 0 and hasattr(k, "ensure_spare_solver")
+                and k.should_regularize_dual(0, 0, 0) and k.should_regularize_dual(0, 1, 0))
+
     def inertia_correction(self):
+        from .linear_solver import factorize_batch
         o, k = self.opt, self.kkt
         n_trial = 0
         dw_prev = dc_prev = 0.0
         self.del_w = self.del_c = 0.0
-        self.factorize_wrapper()
+        spec = self._can_speculate()
+        if spec:
+            dw1 = max(o.min_hessian_perturbation, o.perturb_dec_fact * self.del_w_last)
+            dc1 = o.jacobian_regularization_value * self.mu ** o.jacobian_regularization_exponent
+            spare = k.ensure_spare_solver()
+            k.save_diagonals_device()
+            with factorize_batch():
+                k.build_kkt_device()
+                k.linear_solver.factorize_async()       # trial 0: the matrix as it is
+                k.regularize_diagonal_device(dw1, dc1)  # trial 1: exactly the sequential loop's first correction (dw1 - 0, dc1 - 0)
+                k.build_kkt_device()
+                spare.factorize_async()
+            self.cnt.factorization_cnt += 1
+            self.speculative_factorizations += 1
+        else:
+            self.factorize_wrapper()
         inertia = k.linear_solver.inertia()
         correct = k.is_inertia_correct(*inertia)
+        if spec and correct:
+            # trial 0 stands: the handle goes back to the unperturbed system (diagonals bit for bit, matrix and condensation
+            # buffers rebuilt from them)
+            k.restore_diagonals_device()
+            k.build_kkt_device()
+            self.speculative_wasted += 1
+            spec = False
         ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if correct else False
         if self.on_trial is not None:
             self.on_trial(self, n_trial, inertia, correct, ok)
+        if spec:
+            # trial 0 rejected: the speculative factorization IS the sequential loop's next trial (the handle's diagonals and
+            # matrix are already that trial's)
+            self.del_w, self.del_c = dw1, dc1
+            dw_prev, dc_prev = dw1, dc1
+            k.swap_solvers()
+            self.cnt.factorization_cnt += 1
+            inertia = k.linear_solver.inertia()
+            correct = k.is_inertia_correct(*inertia)
+            ok = self.solve_refine_wrapper(self.dv, self.pv, self.w4v) if correct else False
+            n_trial = 1
+            if self.on_trial is not None:
+                self.on_trial(self, n_trial, inertia, correct, ok)
         while not ok:
             if n_trial == 0:
                 self.del_w = (o.first_hessian_perturbation if self.del_w_last == 0 else

@@ -234,7 +234,30 @@ class SparseCondensedKKTSystem(_KKTCommon):
             self.linear_solver.set_option("early_reject", 1 if early_reject else 0)
         L.check(lib.mnk_sc_set_bounds(self._h, nlb, self.ind_lb.ctypes.data, nub, self.ind_ub.ctypes.data, 0),
                 "mnk_sc_set_bounds")
+        self._spare_args = (linear_solver, opt_linear_solver, early_reject)
+        self.spare_solver = None
         _LIVE_OBJECTS.add(self)
+
+    # -- speculative inertia correction (madnlp_jl_amd.ipm_dev.DeviceMadNLPSolver.inertia_correction) ---------------------
+    def ensure_spare_solver(self):
+        """A second linear solver on the same `aug_com` (created on first use: one more factor in HBM): the trial of
+        `inertia_correction!` that is factorized ahead of the verdict on the unperturbed matrix, in the same merged launch."""
+        if self.spare_solver is None:
+            cls, opt, early_reject = self._spare_args
+            self.spare_solver = cls(self.aug_com, ctx=self.ctx, opt=opt)
+            self.spare_solver.set_option("accept_only_pd", 1)
+            self.spare_solver.set_option("early_reject", 1 if early_reject else 0)
+        return self.spare_solver
+
+    def swap_solvers(self):
+        """The spare solver's factor is the one the iteration goes on with."""
+        self.linear_solver, self.spare_solver = self.spare_solver, self.linear_solver
+
+    def save_diagonals_device(self):
+        L.check(L.lib().mnk_sc_save_diagonals(self._h), "mnk_sc_save_diagonals")
+
+    def restore_diagonals_device(self):
+        L.check(L.lib().mnk_sc_restore_diagonals(self._h), "mnk_sc_restore_diagonals")
 
     # -- helpers -----------------------------------------------------------------------
     def _structure(self, which, ncol, nnz):
@@ -416,6 +439,9 @@ class SparseCondensedKKTSystem(_KKTCommon):
     def close(self):
         if getattr(self, "linear_solver", None) is not None:
             self.linear_solver.close()
+        if getattr(self, "spare_solver", None) is not None:
+            self.spare_solver.close()
+            self.spare_solver = None
         if self._h:
             L.lib().mnk_sc_destroy(self._h)
             self._h = C.c_void_p()
