@@ -504,6 +504,30 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d);
  *   mnk_schur_solve     steps 3-5 of solve_kkt! (reference :1078-1092) in one call, host (loc = MNK_HOST) or device vectors:
  *                       rhs_k = ns x blk (scenario k at k * blk), rhs_d = nd, both overwritten with the solution. */
 void* mnk_schur_s_buffer(mnk_schur* h);
+/* Device-side assembly of the scenario blocks (round 6).  Reference: the scatter of the callback values through precomputed index
+ * maps in build_kkt! (src/KKT/Schur/schur.jl:935-972, maps built at :460-700) and its GPU twin's nine kernels
+ * (lib/MadNLPGPU/ext/MadNLPGPUCUDAExt/kernels_schur.jl:14-174, @atomic adds).
+ *   mnk_schur_set_structure  once: the COO patterns of the Lagrangian Hessian (any triangle: forced to the lower one) and of the
+ *                            Jacobian (row = constraint, column = variable), the rows of the inequality constraints in slack order
+ *                            (ind_ineq) and of the equality constraints (ind_eq); variable layout [v_1 .. v_ns (nv each), d (nd)],
+ *                            constraint layout [c_1 .. c_ns (nc each)].  Checks what _build_schur_symbolic checks (:140-236: a Hessian
+ *                            entry that couples two scenarios, a constraint that reaches another scenario, unequal row counts) and
+ *                            builds, per touched entry of A_k (order nv + equality rows per scenario, both triangles), C_dk (nd x blk)
+ *                            and S0 (nd x nd), the list of its sources in the reference's scatter order.  ns_global / local_scen:
+ *                            the global scenario of every local block when the scenarios are sharded over ranks (NULL: all local);
+ *                            own_design: this rank adds H_dd + Sigma_d to its S0 (exactly one rank does).
+ *   mnk_schur_assemble       per build_kkt!: hess / jac (COO values), pr_diag (n + n_ineq), du_diag (m), host or device -> A_k, C_dk of
+ *                            every local scenario and S0 (mnk_schur_s0_buffer, device) in one launch, every entry summed by one thread
+ *                            in the reference's order (the bits of a sequential scatter-add, the same in every run); then
+ *                            mnk_schur_build_local(h, mnk_schur_s0_buffer(h), nd, MNK_DEVICE, ...)
+ *   mnk_schur_get_block      host copies of one assembled block pair and / or of S0 (tests; any pointer may be NULL) */
+int mnk_schur_set_structure(mnk_schur* h, int64_t n, int64_t m, int64_t nv, int64_t nc, int64_t nnzh, const int32_t* hess_I,
+                            const int32_t* hess_J, int64_t nnzj, const int32_t* jac_I, const int32_t* jac_J, int64_t n_ineq,
+                            const int64_t* ind_ineq, int64_t n_eq, const int64_t* ind_eq, int index_base, int64_t ns_global,
+                            const int64_t* local_scen, int own_design);
+int mnk_schur_assemble(mnk_schur* h, const double* hess, const double* jac, const double* pr_diag, const double* du_diag, int loc);
+void* mnk_schur_s0_buffer(mnk_schur* h);
+int mnk_schur_get_block(mnk_schur* h, int64_t k, double* A_kk, double* C_dk, double* S0);
 int mnk_schur_solve(mnk_schur* h, double* rhs_k, double* rhs_d, int loc);
 
 /* Diagnostics: with option "solve_trace" = 1 the persistent solve kernel stamps the forward sweep's critical

@@ -754,6 +754,39 @@ function build_local!(st::HipSchurStage, S0::Union{Nothing, Matrix{Float64}}, S_
     check(rc, FactorizationException)
     return st
 end
+"""
+Once per system: the COO patterns (1-based, as the callbacks give them) of the Lagrangian Hessian and of the Jacobian (row =
+constraint), the inequality rows in slack order and the equality rows.  The library checks the two-stage layout (what
+`_build_schur_symbolic` checks, schur.jl:140-236) and builds the source list of every touched entry of `A_k` / `C_dk` / `S0`.
+"""
+function set_structure!(st::HipSchurStage, n::Integer, m::Integer, nv::Integer, nc::Integer, hess_I::Vector{Int32},
+                        hess_J::Vector{Int32}, jac_I::Vector{Int32}, jac_J::Vector{Int32}, ind_ineq::Vector{Int64},
+                        ind_eq::Vector{Int64}; ns_global::Integer = st.ns_local, local_scen::Union{Nothing, Vector{Int64}} = nothing,
+                        own_design::Bool = true)
+    rc = ccall((:mnk_schur_set_structure, libmadnlp_hip), Cint,
+               (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Int64, Ptr{Int32}, Ptr{Int32}, Int64, Ptr{Int64},
+                Int64, Ptr{Int64}, Cint, Int64, Ptr{Int64}, Cint),
+               st.handle, n, m, nv, nc, length(hess_I), hess_I, hess_J, length(jac_I), jac_I, jac_J, length(ind_ineq), ind_ineq,
+               length(ind_eq), ind_eq, 1, ns_global, local_scen === nothing ? C_NULL : local_scen, own_design ? 1 : 0)
+    check(rc, SymbolicException)
+    return st
+end
+"`build_kkt!`'s scatter (schur.jl:935-972) on the device: `A_k`, `C_dk` of every local scenario and `S0` from the callbacks' values."
+function assemble!(st::HipSchurStage, hess::Vector{Float64}, jac::Vector{Float64}, pr_diag::Vector{Float64}, du_diag::Vector{Float64})
+    rc = ccall((:mnk_schur_assemble, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint),
+               st.handle, hess, jac, pr_diag, du_diag, MNK_HOST)
+    check(rc, SymbolicException)
+    return st
+end
+"`build_kkt!` behind `assemble!`: S_out = (the assembled S0, a device buffer of the stage) - sum over the local scenarios."
+function build_local_assembled!(st::HipSchurStage, S_out::Ptr{Cdouble})
+    s0 = ccall((:mnk_schur_s0_buffer, libmadnlp_hip), Ptr{Cvoid}, (Ptr{Cvoid},), st.handle)
+    s0 == C_NULL && throw(SymbolicException())
+    rc = ccall((:mnk_schur_build_local, libmadnlp_hip), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Int64, Cint, Ptr{Cdouble}, Int64),
+               st.handle, Ptr{Cdouble}(s0), st.nd, MNK_DEVICE, S_out, st.nd)
+    check(rc, FactorizationException)
+    return st
+end
 "`factorize_kkt!`: factor the (all-reduced) S, a device buffer."
 function factorize_s!(st::HipSchurStage, S::Ptr{Cdouble})
     info = Ref{Cint}(0)
@@ -827,16 +860,14 @@ MadNLP.introduce(::HipSchurDesignSolver) = "HIP-MI355X Schur stage (batched scen
 
 struct HipSchurComplementKKTSystem{T, VT, MT, QN, K <: MadNLP.SchurComplementKKTSystem{T, VT, MT, QN}} <:
        AbstractCondensedKKTSystem{T, VT, MT, QN}
-    inner::K                       # the reference system: buffers, maps, host-side algebra
+    inner::K                       # the reference system: value buffers, diagonals, host-side algebra of solve_kkt! / mul!
     stage::HipSchurStage
     linear_solver::HipSchurDesignSolver{T}
-    Akk_dense::Matrix{T}           # blk x blk staging of one scenario block
-    S0::Matrix{T}                  # nd x nd: the design block before the Schur products
     rhs_all::Matrix{T}             # blk x ns: the scenarios' right-hand sides, column k = scenario k
 end
 # every field the generic IPM code reads by name (KKTsystem.jl:210-234, kernels.jl) lives in the reference system
 function Base.getproperty(kkt::HipSchurComplementKKTSystem, f::Symbol)
-    f in (:inner, :stage, :linear_solver, :Akk_dense, :S0, :rhs_all) && return getfield(kkt, f)
+    f in (:inner, :stage, :linear_solver, :rhs_all) && return getfield(kkt, f)
     return getproperty(getfield(kkt, :inner), f)
 end
 
@@ -854,8 +885,11 @@ function MadNLP.create_kkt_system(
     stage = HipSchurStage(inner.ns, inner.blk_size, inner.nd; ctx = ctx, lapack_algorithm = alg)
     Sdev = Ptr{Cdouble}(ccall((:mnk_schur_s_buffer, libmadnlp_hip), Ptr{Cvoid}, (Ptr{Cvoid},), stage.handle))
     Sdev == C_NULL && throw(SymbolicException())
-    return HipSchurComplementKKTSystem(inner, stage, HipSchurDesignSolver{T}(stage, Sdev), zeros(T, inner.blk_size, inner.blk_size),
-                                       zeros(T, inner.nd, inner.nd), zeros(T, inner.blk_size, inner.ns))
+    # the index maps of the scatter live in the library (built from the COO patterns the callbacks gave; jt_coo is J': I = variable)
+    set_structure!(stage, MadNLP.num_variables(inner), length(inner.du_diag), inner.nv, inner.nc,
+                   Vector{Int32}(inner.hess_raw.I), Vector{Int32}(inner.hess_raw.J), Vector{Int32}(inner.jt_coo.J),
+                   Vector{Int32}(inner.jt_coo.I), Vector{Int64}(inner.ind_ineq), Vector{Int64}(inner.ind_eq))
+    return HipSchurComplementKKTSystem(inner, stage, HipSchurDesignSolver{T}(stage, Sdev), zeros(T, inner.blk_size, inner.ns))
 end
 
 MadNLP.num_variables(kkt::HipSchurComplementKKTSystem) = MadNLP.num_variables(kkt.inner)
@@ -875,44 +909,20 @@ mul!(w::AbstractKKTVector{T}, kkt::HipSchurComplementKKTSystem, x::AbstractKKTVe
     mul!(w, kkt.inner, x, alpha, beta)
 MadNLP.mul_hess_blk!(wx, kkt::HipSchurComplementKKTSystem, t) = MadNLP.mul_hess_blk!(wx, kkt.inner, t)
 
-# build_kkt! (schur.jl:927-1001): the reference's scatter of the callback values into A_kk / C_dk / S, then the device stage
+# build_kkt! (schur.jl:927-1001).  Round 6: the scatter of the callback values into A_kk / C_dk / S0 (:935-972) is ONE call -- the
+# library sums every touched entry of the dense blocks on the device, in the reference's own order, from the four value vectors;
+# rounds 4-5 ran the reference's `_scatter_add!` / `_scatter_quad_add!` on the host, densified every sparse A_kk and uploaded
+# ns (blk^2 + nd blk) doubles per iteration.  The host keeps `diag_buffer` (the vector algebra of solve_kkt! reads it).
 function MadNLP.build_kkt!(kkt::HipSchurComplementKKTSystem{T}) where T
     k0 = kkt.inner
-    ns, nv, nd, n = k0.ns, k0.nv, k0.nd, MadNLP.num_variables(k0)
+    n = MadNLP.num_variables(k0)
     if k0.n_ineq > 0
         Sigma_s = view(k0.pr_diag, n+1:n+k0.n_ineq)
         Sigma_d = @view(k0.du_diag[k0.ind_ineq])
         k0.diag_buffer .= Sigma_s ./ (one(T) .- Sigma_d .* Sigma_s)
     end
-    S0 = kkt.S0
-    fill!(S0, zero(T))
-    MadNLP._scatter_add!(S0, k0.hess, k0.hess_S_coo, k0.hess_S_row, k0.hess_S_col)
-    @inbounds for i in 1:nd
-        S0[i, i] += k0.pr_diag[ns*nv+i]
-    end
-    Ad = kkt.Akk_dense
-    for k in 1:ns
-        bm = k0.block_maps[k]
-        A_kk = k0.A_kk[k]; C_dk = k0.C_dk[k]; nz = A_kk.nzval
-        fill!(nz, zero(T)); fill!(C_dk, zero(T))
-        MadNLP._scatter_add!(nz,   k0.hess,    bm.hess_Akk_coo,   bm.hess_Akk_nzpos)
-        MadNLP._scatter_add!(C_dk, k0.hess,    bm.hess_Cdk_coo,   bm.hess_Cdk_row, bm.hess_Cdk_col)
-        MadNLP._scatter_add!(nz,   k0.pr_diag, bm.pr_diag_global, bm.pr_diag_nzpos)
-        MadNLP._scatter_add!(nz,   k0.du_diag, bm.du_diag_global, bm.du_diag_nzpos)
-        MadNLP._scatter_add!(nz,   k0.jac,     bm.jeq_Akk_coo,    bm.jeq_Akk_nzpos)
-        MadNLP._scatter_add!(C_dk, k0.jac,     bm.jeq_Cdk_coo,    bm.jeq_Cdk_row, bm.jeq_Cdk_col)
-        MadNLP._scatter_quad_add!(nz,   k0.jac, k0.diag_buffer, bm.ineq_Akk_nzpos, bm.ineq_Akk_jcoo1, bm.ineq_Akk_jcoo2, bm.ineq_Akk_bufidx)
-        MadNLP._scatter_quad_add!(C_dk, k0.jac, k0.diag_buffer, bm.ineq_Cdk_row, bm.ineq_Cdk_col, bm.ineq_Cdk_jcoo_d, bm.ineq_Cdk_jcoo_v,
-                                  bm.ineq_Cdk_bufidx)
-        MadNLP._scatter_quad_add!(S0,   k0.jac, k0.diag_buffer, bm.ineq_S_row, bm.ineq_S_col, bm.ineq_S_jcoo1, bm.ineq_S_jcoo2, bm.ineq_S_bufidx)
-        # the lower-triangular sparse block as a dense one (the stage reads the lower triangle)
-        fill!(Ad, zero(T))
-        @inbounds for j in 1:size(A_kk, 2), p in A_kk.colptr[j]:(A_kk.colptr[j+1]-1)
-            Ad[A_kk.rowval[p], j] = nz[p]
-        end
-        set_block!(kkt.stage, k - 1, Ad, C_dk)
-    end
-    build_local!(kkt.stage, S0, kkt.linear_solver.S)      # blocks factored as one batch, S = S0 - sum_k C_dk A_k^-1 C_dk'
+    assemble!(kkt.stage, k0.hess, k0.jac, k0.pr_diag, k0.du_diag)
+    build_local_assembled!(kkt.stage, kkt.linear_solver.S)   # blocks factored as one batch, S = S0 - sum_k C_dk A_k^-1 C_dk'
     return
 end
 

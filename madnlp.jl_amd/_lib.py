@@ -210,6 +210,11 @@ SIGNATURES = {
     "mnk_schur_solve_s": (C.c_int, [_vp, _vp]),
     "mnk_schur_backward": (C.c_int, [_vp, _vp, _vp]),
     "mnk_schur_s_buffer": (C.c_void_p, [_vp]),
+    "mnk_schur_set_structure": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp, _vp, C.c_int64, _vp, _vp,
+                                          C.c_int64, _vp, C.c_int64, _vp, C.c_int, C.c_int64, _vp, C.c_int]),
+    "mnk_schur_assemble": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "mnk_schur_s0_buffer": (_vp, [_vp]),
+    "mnk_schur_get_block": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     "mnk_schur_solve": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mnk_ls_debug_solve_trace": (C.c_int, [_vp, _vp, C.c_int64]),
     "mnk_ls_debug_dag_state": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),

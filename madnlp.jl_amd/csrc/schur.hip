@@ -48,6 +48,18 @@ struct mnk_schur {
     hipEvent_t stage_ev = nullptr;          // recorded behind the last upload from `stage`
     mnk::DevBuf<double> Sown;               // nd x nd: the handle's own copy of S (mnk_schur_s_buffer: callers without device memory of their own)
     mnk::DevBuf<double> hostrk, hostrd;     // mnk_schur_solve with host vectors: ns x blk | 2 nd (right-hand side, contribution)
+    // ---- device-side assembly of A_k / C_dk / S0 from the callbacks' COO values (mnk_schur_set_structure / mnk_schur_assemble):
+    // every touched entry of the three buffers is one SEGMENT of sources, summed by one thread in a fixed order (no atomics)
+    struct {
+        bool have = false;
+        int64_t n = 0, m = 0, nv = 0, nc = 0, nnzh = 0, nnzj = 0, n_ineq = 0, nseg = 0, nsrc = 0;
+        mnk::DevBuf<int64_t> seg_dst;           // nseg: virtual offset into [A | C | S0]
+        mnk::DevBuf<int32_t> seg_ptr;           // nseg + 1
+        mnk::DevBuf<int8_t> src_kind;           // 0 hess[a], 1 jac[a], 2 pr_diag[a], 3 du_diag[a], 4 jac[a] * D[w] * jac[b]
+        mnk::DevBuf<int32_t> src_a, src_b, src_w;
+        mnk::DevBuf<int64_t> ind_ineq;          // constraint row of slack p
+        mnk::DevBuf<double> D, S0, vals;        // n_ineq | nd x nd | staging of host inputs: hess | jac | pr_diag | du_diag
+    } as;
 };
 
 namespace mnk {
@@ -133,6 +145,46 @@ __global__ void schur_axpy_kernel(double* __restrict__ y, const double* __restri
     if (i < n) y[i] += x[i];
 }
 
+}  // namespace mnk
+
+namespace mnk {
+// D = Sigma_s / (1 - Sigma_d Sigma_s) of every inequality row (reference schur.jl:929-933), rounded operation by operation
+__global__ void schur_condense_weights_kernel(double* __restrict__ D, const double* __restrict__ pr_diag, const double* __restrict__ du_diag,
+                                              const int64_t* __restrict__ ind_ineq, int64_t n, int64_t n_ineq) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= n_ineq) return;
+    const double Ss = pr_diag[n + p], Sd = du_diag[ind_ineq[p]];
+    D[p] = __ddiv_rn(Ss, __dsub_rn(1.0, __dmul_rn(Sd, Ss)));
+}
+// One thread per touched entry of [A | C | S0]: its sources in the order the reference scatters them (Hessian entries, diagonal
+// terms, equality-row Jacobian entries, the condensation pairs J' D J row by row: schur.jl:935-972), every operation rounded on
+// its own (no contraction into fma): the entry carries the bits a sequential scatter-add produces.  The reference's GPU twin
+// (lib/MadNLPGPU/ext/MadNLPGPUCUDAExt/kernels_schur.jl:14-174) adds with @atomic -- an order that changes from run to run.
+__global__ void schur_assemble_kernel(int64_t nseg, const int64_t* __restrict__ seg_dst, const int32_t* __restrict__ seg_ptr,
+                                      const int8_t* __restrict__ kind, const int32_t* __restrict__ sa, const int32_t* __restrict__ sb,
+                                      const int32_t* __restrict__ sw, const double* __restrict__ hess, const double* __restrict__ jac,
+                                      const double* __restrict__ pr_diag, const double* __restrict__ du_diag, const double* __restrict__ D,
+                                      double* __restrict__ A, int64_t sizeA, double* __restrict__ Cb, int64_t sizeC, double* __restrict__ S0) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= nseg) return;
+    double acc = 0.0;
+    for (int32_t q = seg_ptr[t]; q < seg_ptr[t + 1]; ++q) {
+        const int a = sa[q];
+        double v;
+        switch (kind[q]) {
+            case 0: v = hess[a]; break;
+            case 1: v = jac[a]; break;
+            case 2: v = pr_diag[a]; break;
+            case 3: v = du_diag[a]; break;
+            default: v = __dmul_rn(__dmul_rn(jac[a], D[sw[q]]), jac[sb[q]]); break;
+        }
+        acc = __dadd_rn(acc, v);
+    }
+    const int64_t d = seg_dst[t];
+    if (d < sizeA) A[d] = acc;
+    else if (d < sizeA + sizeC) Cb[d - sizeA] = acc;
+    else S0[d - sizeA - sizeC] = acc;
+}
 }  // namespace mnk
 
 using namespace mnk;
@@ -431,6 +483,194 @@ int mnk_schur_backward(mnk_schur* h, double* rhs_k, const double* x_d) {
 
 // A device buffer of nd x nd doubles owned by the handle: `S_out` of mnk_schur_build_local and `S` of mnk_schur_factorize_s for
 // callers that keep no device memory themselves (the Julia glue's host-driven KKT system, julia/MadNLPHIP.jl).
+int mnk_schur_set_structure(mnk_schur* h, int64_t n, int64_t m, int64_t nv, int64_t nc, int64_t nnzh, const int32_t* hess_I,
+                            const int32_t* hess_J, int64_t nnzj, const int32_t* jac_I, const int32_t* jac_J, int64_t n_ineq,
+                            const int64_t* ind_ineq, int64_t n_eq, const int64_t* ind_eq, int index_base, int64_t ns_global,
+                            const int64_t* local_scen, int own_design) {
+    MNK_REQUIRE(h, "mnk_schur_set_structure: NULL handle");
+    MNK_REQUIRE(index_base == 0 || index_base == 1, "mnk_schur_set_structure: index_base must be 0 or 1");
+    MNK_REQUIRE((nnzh == 0 || (hess_I && hess_J)) && (nnzj == 0 || (jac_I && jac_J)) && (n_ineq == 0 || ind_ineq) && (n_eq == 0 || ind_eq),
+                "mnk_schur_set_structure: NULL pattern");
+    const int64_t ns = local_scen ? ns_global : h->ns, nd = h->nd, blk = h->blk;
+    MNK_REQUIRE(ns >= h->ns && nv > 0 && nc >= 0, "mnk_schur_set_structure: bad dimensions");
+    MNK_REQUIRE(n == ns * nv + nd && m == ns * nc, "mnk_schur_set_structure: n, m do not match ns * nv + nd, ns * nc");
+    MNK_REQUIRE(n_eq + n_ineq == m && n_eq % std::max<int64_t>(ns, 1) == 0 && n_ineq % std::max<int64_t>(ns, 1) == 0,
+                "mnk_schur_set_structure: the scenarios have different numbers of equality / inequality constraints");
+    const int64_t nc_eq = ns > 0 ? n_eq / ns : 0;
+    MNK_REQUIRE(blk == nv + nc_eq, "mnk_schur_set_structure: the stage's block order is not nv + (equality rows per scenario)");
+    MNK_REQUIRE(nnzh < 2000000000 && nnzj < 2000000000 && n + n_ineq < 2000000000, "mnk_schur_set_structure: structure exceeds int32 range");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    const int64_t off = ns * nv;
+    // global scenario -> local block (or -1)
+    std::vector<int64_t> loc_of(ns, -1);
+    for (int64_t i = 0; i < h->ns; ++i) {
+        const int64_t g = local_scen ? local_scen[i] : i;
+        MNK_REQUIRE(g >= 0 && g < ns && loc_of[g] < 0, "mnk_schur_set_structure: bad local scenario list");
+        loc_of[g] = i;
+    }
+    // equality rows: local index = rank among the scenario's equality rows (ascending); inequality rows: slack index
+    std::vector<int64_t> eq_local(m, -1), slack_of(m, -1);
+    {
+        std::vector<int64_t> eq_sorted(ind_eq, ind_eq + n_eq);
+        for (auto& r : eq_sorted) r -= index_base;
+        std::sort(eq_sorted.begin(), eq_sorted.end());
+        std::vector<int64_t> cnt(ns, 0);
+        for (int64_t r : eq_sorted) {
+            MNK_REQUIRE(r >= 0 && r < m, "mnk_schur_set_structure: equality index out of range");
+            const int64_t k = nc > 0 ? r / nc : 0;
+            eq_local[r] = cnt[k]++;
+        }
+        for (int64_t k = 0; k < ns; ++k)
+            MNK_REQUIRE(cnt[k] == nc_eq, "mnk_schur_set_structure: the scenarios have different numbers of equality / inequality constraints");
+        for (int64_t p = 0; p < n_ineq; ++p) {
+            const int64_t r = ind_ineq[p] - index_base;
+            MNK_REQUIRE(r >= 0 && r < m && eq_local[r] < 0 && slack_of[r] < 0, "mnk_schur_set_structure: bad inequality index");
+            slack_of[r] = p;
+        }
+    }
+    auto scen = [&](int64_t var) -> int64_t { return var < off ? var / nv : -1; };
+    struct Src { int64_t dst; int8_t kind; int32_t a, b, w; };
+    std::vector<Src> src;
+    const int64_t sizeA = h->ns * blk * blk, sizeC = h->ns * nd * blk;
+    auto putA = [&](int64_t kl, int64_t r, int64_t c, int8_t kind, int64_t a, int64_t b = 0, int64_t w = 0) {
+        src.push_back(Src{kl * blk * blk + r + c * blk, kind, (int32_t)a, (int32_t)b, (int32_t)w});
+    };
+    auto putC = [&](int64_t kl, int64_t d, int64_t c, int8_t kind, int64_t a, int64_t b = 0, int64_t w = 0) {
+        src.push_back(Src{sizeA + kl * nd * blk + d + c * nd, kind, (int32_t)a, (int32_t)b, (int32_t)w});
+    };
+    auto putS = [&](int64_t r, int64_t c, int8_t kind, int64_t a, int64_t b = 0, int64_t w = 0) {
+        src.push_back(Src{sizeA + sizeC + r + c * nd, kind, (int32_t)a, (int32_t)b, (int32_t)w});
+    };
+    // Hessian entries (forced to the lower triangle, matrixtools.jl:129-137): scenario block, coupling block, design block
+    for (int64_t e = 0; e < nnzh; ++e) {
+        int64_t i = hess_I[e] - index_base, j = hess_J[e] - index_base;
+        MNK_REQUIRE(i >= 0 && i < n && j >= 0 && j < n, "mnk_schur_set_structure: Hessian index out of range");
+        if (j > i) std::swap(i, j);
+        const int64_t si = scen(i), sj = scen(j);
+        if (si >= 0 && sj >= 0) {
+            MNK_REQUIRE(si == sj, "mnk_schur_set_structure: a Hessian entry couples two scenarios");
+            const int64_t kl = loc_of[si];
+            if (kl < 0) continue;
+            const int64_t li = i - si * nv, lj = j - sj * nv;
+            putA(kl, li, lj, 0, e);
+            if (li != lj) putA(kl, lj, li, 0, e);
+        } else if (si < 0 && sj < 0) {
+            if (!own_design) continue;
+            putS(i - off, j - off, 0, e);
+            if (i != j) putS(j - off, i - off, 0, e);
+        } else {   // (lower triangle: the design variable is the row)
+            const int64_t kl = loc_of[sj];
+            if (kl >= 0) putC(kl, i - off, j - sj * nv, 0, e);
+        }
+    }
+    // diagonal terms
+    for (int64_t k = 0; k < ns; ++k) {
+        const int64_t kl = loc_of[k];
+        if (kl < 0) continue;
+        for (int64_t j = 0; j < nv; ++j) putA(kl, j, j, 2, k * nv + j);
+    }
+    for (int64_t r = 0; r < m; ++r)
+        if (eq_local[r] >= 0 && loc_of[r / nc] >= 0) putA(loc_of[r / nc], nv + eq_local[r], nv + eq_local[r], 3, r);
+    if (own_design)
+        for (int64_t j = 0; j < nd; ++j) putS(j, j, 2, off + j);
+    // Jacobian entries of equality rows; the entries of every inequality row in COO order
+    std::vector<std::vector<std::pair<int32_t, int64_t>>> row_entries(m);
+    for (int64_t e = 0; e < nnzj; ++e) {
+        const int64_t r = jac_I[e] - index_base, c = jac_J[e] - index_base;
+        MNK_REQUIRE(r >= 0 && r < m && c >= 0 && c < n, "mnk_schur_set_structure: Jacobian index out of range");
+        const int64_t k = r / nc;
+        MNK_REQUIRE(c >= off || c / nv == k, "mnk_schur_set_structure: a constraint reaches the variables of another scenario");
+        const int64_t kl = loc_of[k];
+        if (kl < 0) continue;
+        if (eq_local[r] >= 0) {
+            const int64_t li = eq_local[r];
+            if (c < off) { putA(kl, nv + li, c - k * nv, 1, e); putA(kl, c - k * nv, nv + li, 1, e); }
+            else putC(kl, c - off, nv + li, 1, e);
+        } else {
+            row_entries[r].push_back({(int32_t)e, c});
+        }
+    }
+    // inequality rows: J' D J over A_k, C_dk and S0, one pair of entries at a time (_scatter_quad_add!, schur.jl:966-972)
+    for (int64_t p = 0; p < n_ineq; ++p) {
+        const int64_t r = ind_ineq[p] - index_base, k = r / nc, kl = loc_of[k];
+        if (kl < 0) continue;
+        const auto& ents = row_entries[r];
+        for (const auto& e1 : ents)
+            for (const auto& e2 : ents) {
+                const int64_t c1 = e1.second, c2 = e2.second;
+                if (c1 < off && c2 < off) putA(kl, c1 - k * nv, c2 - k * nv, 4, e1.first, e2.first, p);
+                else if (c1 >= off && c2 < off) putC(kl, c1 - off, c2 - k * nv, 4, e1.first, e2.first, p);
+                else if (c1 >= off && c2 >= off) putS(c1 - off, c2 - off, 4, e1.first, e2.first, p);
+            }
+    }
+    MNK_REQUIRE(src.size() < (size_t)2000000000, "mnk_schur_set_structure: too many assembly terms");
+    std::stable_sort(src.begin(), src.end(), [](const Src& x, const Src& y) { return x.dst < y.dst; });
+    std::vector<int64_t> seg_dst;
+    std::vector<int32_t> seg_ptr, sa(src.size()), sb(src.size()), sw(src.size());
+    std::vector<int8_t> kind(src.size());
+    for (size_t q = 0; q < src.size(); ++q) {
+        if (q == 0 || src[q].dst != src[q - 1].dst) { seg_dst.push_back(src[q].dst); seg_ptr.push_back((int32_t)q); }
+        kind[q] = src[q].kind; sa[q] = src[q].a; sb[q] = src[q].b; sw[q] = src[q].w;
+    }
+    seg_ptr.push_back((int32_t)src.size());
+    auto& as = h->as;
+    as.have = false;
+    as.n = n; as.m = m; as.nv = nv; as.nc = nc; as.nnzh = nnzh; as.nnzj = nnzj; as.n_ineq = n_ineq;
+    as.nseg = (int64_t)seg_dst.size(); as.nsrc = (int64_t)src.size();
+    std::vector<int64_t> ineq0(n_ineq);
+    for (int64_t p = 0; p < n_ineq; ++p) ineq0[p] = ind_ineq[p] - index_base;
+    hipStream_t st = h->ctx->stream;
+    int rc = as.seg_dst.upload(seg_dst, st) | as.seg_ptr.upload(seg_ptr, st) | as.src_kind.upload(kind, st) | as.src_a.upload(sa, st) |
+             as.src_b.upload(sb, st) | as.src_w.upload(sw, st) | as.ind_ineq.upload(ineq0, st) | as.D.alloc((size_t)std::max<int64_t>(n_ineq, 1)) |
+             as.S0.alloc((size_t)nd * nd + 8) | as.vals.alloc((size_t)(nnzh + nnzj + n + n_ineq + m) + 8);
+    if (rc) { (void)hipGetLastError(); set_error("mnk_schur_set_structure: out of device memory"); return -2; }
+    as.have = true;
+    return 0;
+}
+
+int mnk_schur_assemble(mnk_schur* h, const double* hess, const double* jac, const double* pr_diag, const double* du_diag, int loc) {
+    MNK_REQUIRE(h && h->as.have, "mnk_schur_assemble: call mnk_schur_set_structure first");
+    auto& as = h->as;
+    MNK_REQUIRE((hess || as.nnzh == 0) && (jac || as.nnzj == 0) && pr_diag && (du_diag || as.m == 0), "mnk_schur_assemble: NULL argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    if (loc != MNK_DEVICE) {   // host callbacks: one staging buffer, four copies
+        double* v = as.vals.p;
+        if (as.nnzh > 0) MNK_HIP(mnk::h2d_copy(v, hess, (size_t)as.nnzh * sizeof(double), s));
+        if (as.nnzj > 0) MNK_HIP(mnk::h2d_copy(v + as.nnzh, jac, (size_t)as.nnzj * sizeof(double), s));
+        MNK_HIP(mnk::h2d_copy(v + as.nnzh + as.nnzj, pr_diag, (size_t)(as.n + as.n_ineq) * sizeof(double), s));
+        if (as.m > 0) MNK_HIP(mnk::h2d_copy(v + as.nnzh + as.nnzj + as.n + as.n_ineq, du_diag, (size_t)as.m * sizeof(double), s));
+        hess = v; jac = v + as.nnzh; pr_diag = v + as.nnzh + as.nnzj; du_diag = v + as.nnzh + as.nnzj + as.n + as.n_ineq;
+    }
+    const int64_t sizeA = h->ns * h->blk * h->blk, sizeC = h->ns * h->nd * h->blk;
+    if (sizeA > 0) MNK_HIP(hipMemsetAsync(h->A.p, 0, (size_t)sizeA * sizeof(double), s));
+    if (sizeC > 0) MNK_HIP(hipMemsetAsync(h->C.p, 0, (size_t)sizeC * sizeof(double), s));
+    MNK_HIP(hipMemsetAsync(as.S0.p, 0, (size_t)h->nd * h->nd * sizeof(double), s));
+    if (as.n_ineq > 0)
+        hipLaunchKernelGGL(mnk::schur_condense_weights_kernel, dim3((unsigned)((as.n_ineq + 255) / 256)), dim3(256), 0, s, as.D.p, pr_diag, du_diag,
+                           as.ind_ineq.p, as.n, as.n_ineq);
+    if (as.nseg > 0)
+        hipLaunchKernelGGL(mnk::schur_assemble_kernel, dim3((unsigned)((as.nseg + 255) / 256)), dim3(256), 0, s, as.nseg, as.seg_dst.p, as.seg_ptr.p,
+                           as.src_kind.p, as.src_a.p, as.src_b.p, as.src_w.p, hess, jac, pr_diag, du_diag, as.D.p, h->A.p, sizeA, h->C.p, sizeC,
+                           as.S0.p);
+    MNK_HIP(hipGetLastError());
+    h->built = false;
+    return 0;
+}
+
+void* mnk_schur_s0_buffer(mnk_schur* h) { return (h && h->as.have) ? (void*)h->as.S0.p : nullptr; }
+
+int mnk_schur_get_block(mnk_schur* h, int64_t k, double* A_kk, double* C_dk, double* S0) {
+    MNK_REQUIRE(h && ((k >= 0 && k < h->ns) || (!A_kk && !C_dk)) && (!S0 || h->as.have), "mnk_schur_get_block: bad argument");
+    MNK_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    if (A_kk) MNK_HIP(mnk::d2h_copy(A_kk, h->A.p + k * h->blk * h->blk, (size_t)h->blk * h->blk * sizeof(double), s));
+    if (C_dk) MNK_HIP(mnk::d2h_copy(C_dk, h->C.p + k * h->nd * h->blk, (size_t)h->nd * h->blk * sizeof(double), s));
+    if (S0) MNK_HIP(mnk::d2h_copy(S0, h->as.S0.p, (size_t)h->nd * h->nd * sizeof(double), s));
+    MNK_HIP(mnk::stream_wait(s));
+    return 0;
+}
+
 void* mnk_schur_s_buffer(mnk_schur* h) {
     if (!h) return nullptr;
     (void)hipSetDevice(h->ctx->device);

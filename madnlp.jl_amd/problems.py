@@ -719,7 +719,11 @@ class TwoStageQPModel:
     Argument shapes as in the reference, with the scenario index LAST: hess_v, g_v, lvar_v, uvar_v (nv, ns); hess_d, g_d,
     lvar_d, uvar_d (nd,); A_v (nc, nv, ns); A_d (nc, nd, ns); lcon, ucon (nc, ns)."""
 
-    def __init__(self, ns, nv, nd, nc, hess_v, hess_d, g_v, g_d, A_v, A_d, lcon, ucon, lvar_v, uvar_v, lvar_d, uvar_d):
+    def __init__(self, ns, nv, nd, nc, hess_v, hess_d, g_v, g_d, A_v, A_d, lcon, ucon, lvar_v, uvar_v, lvar_d, uvar_d,
+                 sparse_pattern=False):
+        """`sparse_pattern`: the Jacobian's COO pattern holds the nonzero entries of A_v / A_d only and A is kept as a scipy CSR
+        matrix (large instances: the dense pattern of the reference's generator has nc (nv + nd) entries per scenario and a dense
+        m x n matrix behind `cons`)."""
         f = lambda a, shape: np.asarray(a, dtype=float).reshape(shape)  # noqa: E731
         hess_v, g_v, lvar_v, uvar_v = (f(a, (nv, ns)) for a in (hess_v, g_v, lvar_v, uvar_v))
         hess_d, g_d, lvar_d, uvar_d = (f(a, (nd,)) for a in (hess_d, g_d, lvar_d, uvar_d))
@@ -734,6 +738,23 @@ class TwoStageQPModel:
         self.lvar = np.concatenate((lvar_v.T.ravel(), lvar_d))
         self.uvar = np.concatenate((uvar_v.T.ravel(), uvar_d))
         self.lcon, self.ucon = lcon.T.ravel().copy(), ucon.T.ravel().copy()
+        if sparse_pattern:
+            import scipy.sparse as sp
+            rows, cols, vals = [], [], []
+            for k in range(ns):
+                iv, jv = np.nonzero(A_v[:, :, k])
+                idd, jd = np.nonzero(A_d[:, :, k])
+                # (row-major within a scenario, recourse entries of a row before its design entries)
+                r = np.concatenate((iv, idd)); c = np.concatenate((k * nv + jv, off + jd))
+                v = np.concatenate((A_v[iv, jv, k], A_d[idd, jd, k]))
+                o = np.lexsort((c, r))
+                rows.append(k * nc + r[o]); cols.append(c[o]); vals.append(v[o])
+            self.jac_I, self.jac_J = np.concatenate(rows).astype(np.int64), np.concatenate(cols).astype(np.int64)
+            self.jvals = np.concatenate(vals)
+            self.A = sp.csr_matrix((self.jvals, (self.jac_I, self.jac_J)), shape=(m, n))
+            self.hess_I = self.hess_J = np.arange(n, dtype=np.int64)
+            self.x0, self.y0 = np.zeros(n), np.zeros(m)
+            return
         A = np.zeros((m, n))
         rows, cols = [], []
         for k in range(ns):
@@ -766,7 +787,7 @@ class TwoStageQPModel:
         return self.jvals
 
     def jac_dense(self, x):
-        return self.A
+        return self.A if isinstance(self.A, np.ndarray) else self.A.toarray()
 
     def hess_coord(self, x, y, w=1.0):
         return w * self.H_diag
@@ -775,22 +796,28 @@ class TwoStageQPModel:
         return w * np.diag(self.H_diag)
 
 
-def random_twostage_qp(ns=8, nv=40, nd=12, nc=10, nc_eq=4, seed=0):
+def random_twostage_qp(ns=8, nv=40, nd=12, nc=10, nc_eq=4, seed=0, density_v=0.4, density_d=1.0):
     """A larger `TwoStageQPModel` with the first `nc_eq` constraints of every scenario equalities and the rest two-sided
-    inequalities around a strictly feasible point (so that both kinds of rows of the Schur system's blocks are exercised)."""
+    inequalities around a strictly feasible point (so that both kinds of rows of the Schur system's blocks are exercised).
+    `density_v` / `density_d`: fraction of nonzeros in a constraint row's recourse / design part (the condensation of an
+    inequality row costs the SQUARE of its length in the reference's pair lists: large instances need sparse rows)."""
     rng = np.random.default_rng(seed)
     hess_v = rng.uniform(0.5, 4.0, (nv, ns))
     hess_d = rng.uniform(0.5, 4.0, nd)
     g_v, g_d = rng.standard_normal((nv, ns)), rng.standard_normal(nd)
-    A_v = rng.standard_normal((nc, nv, ns)) * (rng.random((nc, nv, ns)) < 0.4)
+    sparse = density_v < 0.4 or density_d < 1.0
+    # (sparse patterns: ONE mask for all scenarios -- the reference builds one symbolic block and requires the same local pattern)
+    A_v = rng.standard_normal((nc, nv, ns)) * (rng.random((nc, nv, 1) if sparse else (nc, nv, ns)) < density_v)
     for k in range(ns):                       # full row rank of the equality rows
         for i in range(nc):
-            A_v[i, (3 * i + k) % nv, k] += 2.0
+            A_v[i, (3 * i + (0 if sparse else k)) % nv, k] += 2.0
     A_d = rng.standard_normal((nc, nd, ns)) * 0.5
+    if density_d < 1.0:
+        A_d = A_d * (rng.random((nc, nd, 1)) < density_d)
     xs_v, xs_d = rng.uniform(-0.5, 0.5, (nv, ns)), rng.uniform(-0.5, 0.5, nd)
     c = np.einsum("ijk,jk->ik", A_v, xs_v) + np.einsum("ijk,j->ik", A_d, xs_d)
     lcon, ucon = c - rng.uniform(0.2, 1.0, (nc, ns)), c + rng.uniform(0.2, 1.0, (nc, ns))
     lcon[:nc_eq], ucon[:nc_eq] = c[:nc_eq], c[:nc_eq]
     return TwoStageQPModel(ns, nv, nd, nc, hess_v, hess_d, g_v, g_d, A_v, A_d, lcon, ucon,
                            xs_v - rng.uniform(1, 3, (nv, ns)), xs_v + rng.uniform(1, 3, (nv, ns)),
-                           xs_d - rng.uniform(1, 3, nd), xs_d + rng.uniform(1, 3, nd))
+                           xs_d - rng.uniform(1, 3, nd), xs_d + rng.uniform(1, 3, nd), sparse_pattern=sparse)

@@ -53,6 +53,47 @@ class SchurDenseStage:
             L.check(L.lib().mnk_schur_set_block(self._h, k, a.ctypes.data, self.blk, c.ctypes.data, self.nd, L.MNK_HOST),
                     "mnk_schur_set_block")
         self.S0 = None if S0 is None else np.asfortranarray(S0, dtype=np.float64)
+        self._assembled = False
+
+    # ---- device-side assembly (mnk_schur_set_structure / mnk_schur_assemble)
+    def set_structure(self, n, m, nv, nc, hess_I, hess_J, jac_I, jac_J, ind_ineq, ind_eq, ns_global=None, local_scen=None, own_design=True):
+        """Once: the COO patterns (0-based) from which the library builds, per touched entry of A_k / C_dk / S0, the list of its
+        sources in the reference's scatter order (schur.jl:935-972).  Raises ValueError where the reference's
+        `_build_schur_symbolic` throws (:140-236)."""
+        hI, hJ = (np.ascontiguousarray(a, dtype=np.int32) for a in (hess_I, hess_J))
+        jI, jJ = (np.ascontiguousarray(a, dtype=np.int32) for a in (jac_I, jac_J))
+        ii, ie = (np.ascontiguousarray(a, dtype=np.int64) for a in (ind_ineq, ind_eq))
+        ls = None if local_scen is None else np.ascontiguousarray(local_scen, dtype=np.int64)
+        rc = L.lib().mnk_schur_set_structure(self._h, n, m, nv, nc, len(hI), hI.ctypes.data, hJ.ctypes.data, len(jI), jI.ctypes.data,
+                                             jJ.ctypes.data, len(ii), ii.ctypes.data, len(ie), ie.ctypes.data, 0,
+                                             self.ns if ns_global is None else ns_global, None if ls is None else ls.ctypes.data,
+                                             1 if own_design else 0)
+        if rc:
+            raise ValueError(L.lib().mnk_last_error_string().decode())
+        self._assembled = False
+
+    def assemble(self, hess, jac, pr_diag, du_diag):
+        """`build_kkt!`'s scatter (reference :935-972) on the device: A_k, C_dk of every local scenario and S0 from the callbacks'
+        COO values and the diagonals (host arrays or device tensors)."""
+        from .linear_solver import _ptr
+        keep = [np.ascontiguousarray(a, dtype=np.float64) if isinstance(a, np.ndarray) else a for a in (hess, jac, pr_diag, du_diag)]
+        (ph, l0), (pj, l1), (pp, l2), (pd, l3) = (_ptr(a) for a in keep)
+        assert l0 == l1 == l2 == l3
+        L.check(L.lib().mnk_schur_assemble(self._h, ph, pj, pp, pd, l0), "mnk_schur_assemble")
+        self._assembled = True
+
+    def get_block(self, k):
+        """Host copies (blk x blk, nd x blk) of scenario k's assembled blocks -- tests."""
+        a = np.zeros((self.blk, self.blk), order="F")
+        c = np.zeros((self.nd, self.blk), order="F")
+        L.check(L.lib().mnk_schur_get_block(self._h, k, a.ctypes.data, c.ctypes.data, None), "mnk_schur_get_block")
+        return a, c
+
+    def get_s0(self):
+        """Host copy of the assembled design block S0 (before the Schur products) -- tests."""
+        s0 = np.zeros((self.nd, self.nd), order="F")
+        L.check(L.lib().mnk_schur_get_block(self._h, 0, None, None, s0.ctypes.data), "mnk_schur_get_block")
+        return s0
 
     def _allreduce(self, t):
         if self.dist is not None:
@@ -62,9 +103,13 @@ class SchurDenseStage:
 
     def build_kkt(self):
         """`build_kkt!` (:927-1001): local phases 1-2, then the all-reduce of S; returns S (device, flat column-major)."""
-        s0 = None if self.S0 is None else self.S0.ctypes.data
-        L.check(L.lib().mnk_schur_build_local(self._h, s0, self.nd, L.MNK_HOST, self.S.data_ptr(), self.nd),
-                "mnk_schur_build_local")
+        if getattr(self, "_assembled", False):   # S0 was assembled on the device together with the blocks
+            L.check(L.lib().mnk_schur_build_local(self._h, L.lib().mnk_schur_s0_buffer(self._h), self.nd, L.MNK_DEVICE, self.S.data_ptr(),
+                                                  self.nd), "mnk_schur_build_local")
+        else:
+            s0 = None if self.S0 is None else self.S0.ctypes.data
+            L.check(L.lib().mnk_schur_build_local(self._h, s0, self.nd, L.MNK_HOST, self.S.data_ptr(), self.nd),
+                    "mnk_schur_build_local")
         self._allreduce(self.S)
         self.ctx.synchronize()   # S is handed to the caller (a torch tensor on the caller's stream)
         return self.S

@@ -14,9 +14,9 @@ of order blk = nv + (equality rows per scenario) -- the scenario's INEQUALITY ro
 `solve_kkt!` (:1040-1110) runs the forward / design / backward steps of the stage between the host-side condensation and
 recovery of the inequality rows.  Inertia is judged on S alone, as the reference does (:901-903).
 
-What is host-side here: the scatter of the COO values into the dense blocks (the reference does it with precomputed index
-maps on the CPU as well; its blocks are sparse CSC, ours dense -- the stage's input format) and the vector algebra around the
-three device steps.  The product path has no CPU fallback for the factorizations and solves: they are the HIP stage's."""
+What is host-side here: the vector algebra around the three device steps.  The scatter of the COO values into the dense
+blocks (the reference: precomputed index maps on the CPU, nine @atomic kernels in its CUDA extension) runs on the device since
+round 6 (`mnk_schur_set_structure` once, `mnk_schur_assemble` per iteration).  The product path has no CPU fallback for the factorizations and solves: they are the HIP stage's."""
 from __future__ import annotations
 
 import numpy as np
@@ -94,6 +94,8 @@ class SchurComplementKKTSystem(_KKTCommon):
     """reference `src/KKT/Schur/schur.jl:72-140` (fields), `:927-1001` (`build_kkt!`), `:1040-1110` (`solve_kkt!`),
     `:1113-1146` (`mul!`, `mul_hess_blk!`)."""
 
+    device_assembly = True     # False: the host assembly of rounds 4-5 (diagnostic A/B runs)
+
     def __init__(self, n, m, jac_I, jac_J, hess_I, hess_J, ind_ineq, ind_eq, ind_lb, ind_ub, ns, nv, nd, nc, ctx=None):
         import torch
         self.torch = torch
@@ -125,6 +127,9 @@ class SchurComplementKKTSystem(_KKTCommon):
         zA = [np.eye(self.blk) for _ in range(ns)]
         zC = [np.zeros((nd, self.blk)) for _ in range(ns)]
         self.stage = SchurDenseStage(zA, zC, np.eye(nd), nd, self.blk, ctx=self.ctx)
+        # the index maps of `_build_schur_symbolic` (reference :460-700) live in the library: one source list per touched entry of
+        # A_k / C_dk / S0, built from the COO patterns once
+        self.stage.set_structure(n, m, nv, nc, self.hess_I, self.hess_J, self.jac_I, self.jac_J, self.ind_ineq, self.ind_eq)
         self.aug_com = self.stage.S
         self.linear_solver = _DesignSolver(self.stage)
         self._order = nd
@@ -159,8 +164,9 @@ class SchurComplementKKTSystem(_KKTCommon):
 
     # ---- build_kkt! (reference :927-1001)
     def assemble_blocks(self):
-        """The scenario blocks A_k, the coupling blocks C_dk and the design block before the Schur products (S0), as dense
-        host arrays -- what the reference scatters into `A_kk.nzval`, `C_dk` and `aug_com` (:935-972, :993-996)."""
+        """CHECKER ONLY since round 6 (tests; `build_kkt` assembles on the device): the scenario blocks A_k, the coupling blocks
+        C_dk and the design block before the Schur products (S0) as dense host arrays by matrix slicing -- what the reference
+        scatters into `A_kk.nzval`, `C_dk` and `aug_com` (:935-972, :993-996)."""
         n, ns, nv, nd = self.n, self.ns, self.nv, self.nd
         off = ns * nv
         if self.n_ineq > 0:
@@ -195,8 +201,19 @@ class SchurComplementKKTSystem(_KKTCommon):
         return A, Cd, S0
 
     def build_kkt(self):
-        A, Cd, S0 = self.assemble_blocks()
-        self.stage.set_blocks(A, Cd, S0)
+        """reference :927-1001.  The scatter of the callback values into A_k / C_dk / S0 runs on the device (`mnk_schur_assemble`:
+        four uploads -- hess, jac, pr_diag, du_diag -- and one launch instead of ns (blk^2 + nd blk) doubles assembled with numpy
+        and uploaded every iteration); the host keeps its copy of `diag_buffer` for the vector algebra of `solve_kkt!`."""
+        if not self.device_assembly:     # (rounds 4-5, kept for the before / after record of tools/bench_schur_kkt.py only)
+            A, Cd, S0 = self.assemble_blocks()
+            self.stage.set_blocks(A, Cd, S0)
+            self.stage.build_kkt()
+            return
+        if self.n_ineq > 0:
+            Ss = self.pr_diag[self.n:self.n + self.n_ineq]
+            Sd = self.du_diag[self.ind_ineq]
+            self.diag_buffer[:] = Ss / (1.0 - Sd * Ss)
+        self.stage.assemble(self.hess, self.jac, self.pr_diag, self.du_diag)
         self.stage.build_kkt()          # device: the ns blocks as one batch, S -= sum_k C_dk A_k^-1 C_dk'
 
     def factorize_kkt(self):

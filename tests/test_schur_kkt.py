@@ -172,10 +172,21 @@ def test_hip_schur_blocks_equal_the_oracle_blocks(gctx):
         s.initialize()
         s.set_aug_diagonal() if hasattr(s, "set_aug_diagonal") else None
         s.kkt.build_kkt()
-    A, Cd, S0 = sh.kkt.assemble_blocks()
+    # round 6: the blocks are assembled ON THE DEVICE (mnk_schur_assemble), every entry summed by one thread in the order of the
+    # oracle's (= the reference's) sequential scatter-add, every operation rounded on its own: the oracle's bits
+    so.kkt.build_kkt()                       # (the oracle factorizes its blocks in place: fresh values for the comparison)
+    Ao = [a.copy() for a in so.kkt.A_kk]; Co = [c.copy() for c in so.kkt.C_dk]
+    sh.kkt.stage.assemble(sh.kkt.hess, sh.kkt.jac, sh.kkt.pr_diag, sh.kkt.du_diag)
     for k in range(nlp.ns):
-        assert np.abs(A[k] - so.kkt.A_kk[k]).max() <= 1e-13 * np.abs(so.kkt.A_kk[k]).max()
-        assert np.abs(Cd[k] - so.kkt.C_dk[k]).max() <= 1e-13 * max(1.0, np.abs(so.kkt.C_dk[k]).max())
+        Ah, Ch = sh.kkt.stage.get_block(k)
+        assert np.array_equal(Ah, Ao[k]) and np.array_equal(Ch, Co[k]), k
+    # ... and the host checker (matrix slicing, another summation order for the condensation terms) to 1e-13
+    A, Cd, S0 = sh.kkt.assemble_blocks()
+    assert np.abs(sh.kkt.stage.get_s0() - S0).max() <= 1e-13 * np.abs(S0).max()
+    for k in range(nlp.ns):
+        assert np.abs(A[k] - Ao[k]).max() <= 1e-13 * np.abs(Ao[k]).max()
+        assert np.abs(Cd[k] - Co[k]).max() <= 1e-13 * max(1.0, np.abs(Co[k]).max())
+    sh.kkt.build_kkt()
     S_h = sh.kkt.aug_com.cpu().numpy().reshape((nlp.nd, nlp.nd), order="F")
     assert np.abs(S_h - so.kkt.aug_com).max() <= 1e-11 * np.abs(so.kkt.aug_com).max()
     sh.kkt.factorize_kkt(); so.kkt.factorize_kkt()
