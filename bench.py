@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--case", default="case1354pegase")
     ap.add_argument("--algorithm", default="BUNCHKAUFMAN", choices=["BUNCHKAUFMAN", "CHOLESKY", "LDL"])
     ap.add_argument("--nsolve", type=int, default=2)
-    ap.add_argument("--outer-block", type=int, default=512)
+    ap.add_argument("--outer-block", type=int, default=0, help="outer panel width of the factorization; 0 = the library's default (by size)")
     ap.add_argument("--batch", type=int, default=None,
                     help="independent NLP instances per GPU, each on its own context/stream; a step advances "
                          "every instance by one iteration.  Default: 1 at --gpus 1 (BASELINE config C3, the "
@@ -414,6 +414,13 @@ def config_c4(ctx, torch, mj):
            "roofline": {"bound": "mfma", "achieved": N ** 3 / 3.0 / (ms_f * 1e-3) / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                         "frac": N ** 3 / 3.0 / (ms_f * 1e-3) / 1e12 / PEAK_FP64_TFLOPS, "traffic": None},
            "schedule_panel_algo": k.linear_solver.get_stat("panel_algo"), "setup_s": setup_s}
+    try:   # bytes per factorize! at the L2 -> fabric interface: the committed counter passes of this system on this schedule
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r06_config_C4_pmc_traffic.json")))
+        if int(rec["schedule_panel_algo"]) == 4:
+            rec["roofline"].update(traffic=tr["traffic_bytes"], traffic_source="profiles/r06_config_C4_pmc_traffic.json",
+                                   traffic_over_algorithmic=tr["traffic_bytes"] / (8.0 * N * N))
+    except Exception:
+        pass
     try:
         ext = json.load(open(os.path.join(ROOT, "profiles", "r02_config_C4_cpu_extrapolation.json")))
         best = min((r for r in ext["rows"] if r["routine"] == "dsytrf" and r["N"] == max(q["N"] for q in ext["rows"])),

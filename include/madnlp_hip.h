@@ -144,7 +144,7 @@ int mnk_dc_get_aug(mnk_dc* dc, double* out, int loc);
 int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out);
 int mnk_ls_destroy(mnk_ls* ls);
 /* Options: "pivot_tol" (LDL: |d| <= pivot_tol counts as a zero pivot; default 0),
- * "outer_block" (outer panel width, multiple of 64; default 512),
+ * "outer_block" (outer panel width, multiple of 64; default 0 = by size: 512, and 1024 from 32 768 rows on),
  * "lookahead" (0/1; default 1: factor the next panel while the trailing update runs). */
 int mnk_ls_set_option(mnk_ls* ls, const char* key, double value);
 

@@ -77,7 +77,7 @@ end
 @kwdef mutable struct HipSolverOptions <: MadNLP.AbstractOptions
     lapack_algorithm::LinearFactorization = BUNCHKAUFMAN   # served by the device LDL^T
     pivot_tol::Float64 = 0.0
-    outer_block::Int = 512
+    outer_block::Int = 0             # 0: by size (512 columns; 1024 from 32 768 rows on)
     lookahead::Bool = true
     share::Int = 1                  # 0 off / 1 adaptive / 2 always: panel-stream CUs join the trailing update
     persistent_solve::Bool = true   # both triangular sweeps in one launch

@@ -1120,7 +1120,14 @@ static int factor_outer_panel(mnk_ls* ls, hipStream_t s, int64_t ko, int64_t ken
 // remaining columns, no outer trailing update, no stream hand-overs) beats the look-ahead schedule up to
 // N ~ 4.5k (measured: N = 1024 -11 %, 2048 -12 %, 3072 -8 %, 4096 -3 %; N = 6144 +3 %).
 int64_t mnk_ls_effective_nbo(const mnk_ls* ls) {
-    return (ls->single_rows > 0 && ls->Np <= ls->single_rows) ? ls->Np : ls->nbo;
+    if (ls->single_rows > 0 && ls->Np <= ls->single_rows) return ls->Np;
+    // outer_block = 0 ("by size", the default since round 6): 512 columns per trailing update, 1024 from 32 768 rows on -- the update
+    // reads and writes the whole trailing triangle once per outer panel (profiles/r06_config_C4_pmc_traffic.md: 8.3 TB at the
+    // L2 -> fabric interface per factorization at N = 85 568, 3.3 TB of it the triangle itself), so twice the width halves that part;
+    // measured on one box at N = 85 568: 512 -> 3.104 s, 768 -> 3.048, 1024 -> 3.035, 2048 -> 3.043 (0.856 -> 0.875 of the fp64 peak).
+    // Below ~3e4 rows the wider panel's own (slower) work costs more than the triangle's traffic saves (r02_knob_sweeps.md: C3).
+    if (ls->nbo_auto) return ls->Np >= 32768 ? 1024 : 512;
+    return ls->nbo;
 }
 
 // inv(L_jj) of the 64x64 diagonal blocks and the explicit inverses of the 256x256 diagonal triangles (what the solves

@@ -49,6 +49,7 @@ struct mnk_dc {
 struct mnk_ls {
     mnk_ctx* ctx = nullptr;
     int64_t N = 0, Np = 0, ld = 0, ldw = 0, nbo = 512;
+    bool nbo_auto = true;   // outer_block = 0: the width of the outer panels by size (mnk_ls_effective_nbo)
     int algo = MNK_LDL;
     double pivot_tol = 0.0;
     int lookahead = 1;

@@ -711,8 +711,9 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "dag_js2")) { ls->dag_js2_override = (int)value; return 0; }   // experiments: strip-column at which every row joins the band (-1: by size)
     if (!strcmp(key, "outer_block")) {
         int64_t v = (int64_t)value;
-        MNK_REQUIRE(v >= NBI && v % NBI == 0, "outer_block must be a positive multiple of 64");
-        ls->nbo = v;
+        MNK_REQUIRE(v == 0 || (v >= NBI && v % NBI == 0), "outer_block must be 0 (by size) or a positive multiple of 64");
+        ls->nbo_auto = v == 0;
+        if (v > 0) ls->nbo = v;
         ls->wbuf[0].release();
         ls->wbuf[1].release();
         return 0;

@@ -151,7 +151,7 @@ class HipSolverOptions:
     BUNCHKAUFMAN (the reference default) maps to the static-pivot LDL^T."""
     lapack_algorithm: str = BUNCHKAUFMAN
     pivot_tol: float = 0.0
-    outer_block: int = 512
+    outer_block: int = 0          # 0: by size (512; 1024 from 32 768 rows on)
     lookahead: bool = True
     share: int = 1          # 0 off, 1 adaptive, 2 always: panel-stream CUs join the trailing update
     small_tiles: int = 400  # (a)-updates with fewer 128x128 tiles use 64x64 workgroup tiles

@@ -115,7 +115,7 @@ def test_option_keys_and_defaults_match_the_library():
     assert "check(rc, SymbolicException)" in JL.split("function set_option!")[1].split("end")[0]
     jl_defaults = dict(re.findall(r"^\s+([a-z_]+)::[A-Za-z0-9]+ = ([^\s#]+)", JL.split("struct HipSolverOptions")[1].split("\nend")[0], flags=re.M))
     lib = {
-        "outer_block": re.search(r"nbo = (\d+)", ls_h).group(1),
+        "outer_block": "0" if re.search(r"bool nbo_auto = true", ls_h) else re.search(r"nbo = (\d+)", ls_h).group(1),   # (0: by size)
         "pivot_tol": re.search(r"pivot_tol = ([0-9.]+)", ls_h).group(1),
         "lookahead": re.search(r"int lookahead = (\d)", ls_h).group(1),
         "share": re.search(r"int share = (\d)", ls_h).group(1),

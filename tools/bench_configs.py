@@ -60,8 +60,11 @@ def c4(ctx, sync):
     t0 = time.time()
     P = opf_shaped("case9241pegase", du=1e-8)
     k = mj.SparseCondensedKKTSystem(P.n, P.m, P.jac_I, P.jac_J, P.hess_I, P.hess_J, P.ind_ineq, P.ind_lb, P.ind_ub,
-                                    ctx=ctx, opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN))
+                                    ctx=ctx, opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN,
+                                                                                       outer_block=int(os.environ.get("C4_OUTER_BLOCK", "0"))))
     setup = time.time() - t0
+    if os.environ.get("C4_DAG_MAX_ROWS"):   # (experiment: the task-DAG schedule above its shipped upper bound of 24 576 rows)
+        k.linear_solver.set_option("dag_max_rows", int(os.environ["C4_DAG_MAX_ROWS"]))
     dj, dh = torch.from_numpy(P.jac).cuda(), torch.from_numpy(P.hess).cuda()
     dp, dd = torch.from_numpy(P.pr_diag).cuda(), torch.from_numpy(P.du_diag).cuda()
 
@@ -76,7 +79,8 @@ def c4(ctx, sync):
     N = P.n
     print(json.dumps({"config": f"C4 case9241pegase-shaped sparse-condensed N={N} nnzK={k.nnz_aug} len_jptr={k.len_jptr}",
                       "setup_s": setup, "ms_assemble": ta[0], "ms_factorize": tf[0], "ms_solve": ts[0],
-                      "inertia": inertia, "fact_tflops": N ** 3 / 3 / tf[0] / 1e9,
+                      "inertia": inertia, "schedule_panel_algo": k.linear_solver.get_stat("panel_algo"), "outer_block": int(os.environ.get("C4_OUTER_BLOCK", "0")), "pp_fallbacks": k.linear_solver.get_stat("pp_fallbacks"),
+                      "fact_tflops": N ** 3 / 3 / tf[0] / 1e9,
                       "frac_fp64_peak": N ** 3 / 3 / tf[0] / 1e9 / 78.6,
                       "it_per_s_nf1_ns2": 1e3 / (ta[0] + tf[0] + 2 * ts[0])}))
     k.close()
