@@ -967,7 +967,11 @@ long mnk_ls_dag_spin_limit(const mnk_ls* ls) {
     const double n = (double)ls->Np;
     const double t_est = n * n * n / 3.0 / 50e12;   // seconds at ~0.64 of the fp64 peak
     const double polls = 10.0 * t_est / 0.17e-6;
-    return (long)std::min(16777216.0, std::max(588000.0, polls));
+    //  several contexts alive on the device: the soak runs behind the 0.1 s floor were single-context; beside other
+    // contexts' persistent groups (the case mnk_release_idle_streams exists for) short stalls are legitimate, and an expiry costs a
+    // whole redo plus 16 / 64 / 256 factorizations on the slow schedule -- the floor is the old 1 s there
+    const double floor_polls = mnk_live_contexts(ls->ctx->device) > 1 ? 5880000.0 : 588000.0;
+    return (long)std::min(16777216.0, std::max(floor_polls, polls));
 }
 
 static mnk::DagInst dag_instance(mnk_ls* ls) {

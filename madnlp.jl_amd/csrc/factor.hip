@@ -1235,6 +1235,9 @@ int mnk_ls_run_factorization(mnk_ls* ls) {
     }
     ++ls->epoch;  // the hand-off flags of this factorization carry this value (never reset)
     ls->inv_done = 0;
+    // (a verdict belongs to ONE factorization -- a new one with rejection disarmed, followed by a solve that never
+    // fetches the info word, must not meet the previous factorization's "rejected early" and refactor a valid factor)
+    ls->factor_invalid = false;
     ls->t_fact_launch_ms = mnk_host_ms();
     {   // info[2]: the leaf stops the factorization at the first pivot that is not positive (leaf64.h: early rejection)
         // (also inside a factorization batch: a member that stops early leaves the others alone -- dag.hip, the workgroup-uniform

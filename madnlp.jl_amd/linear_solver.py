@@ -333,7 +333,12 @@ class HipLinearSolver:
 
     def close(self):
         if self._h:
-            L.lib().mnk_ls_destroy(self._h)
+            rc = L.lib().mnk_ls_destroy(self._h)
+            if rc:
+                #  the solver is queued in ANOTHER thread's open factorization batch: the library refused to free it and
+                # it stays alive -- and ours: the handle is kept, so that a later close() (after that batch has ended) frees it
+                # instead of leaking a solver the other thread's batch_end would launch on
+                raise RuntimeError("HipLinearSolver.close: " + L.lib().mnk_last_error_string().decode())
             self._h = C.c_void_p()
 
     def __del__(self):
