@@ -702,7 +702,9 @@ def main():
                          "traffic_source": traffic_src,
                          "kernel": "factorize! (densify + blocked LDL^T/Cholesky; N^3/3 flop per call, "
                                    "HIP-event timed on the launch stream)",
-                         "schedule_panel_algo": schedule, "pp_fallbacks": fallbacks},
+                         "schedule_panel_algo": schedule, "pp_fallbacks": fallbacks,
+                         # host milliseconds lost to expired device-side waits in this process (0 on a healthy run)
+                         "stall_ms_process": float(ls.get_stat("stall_ms_process"))},
         }
         if world > 1 and solo is not None:
             # the scaling curve's own denominator: rank 0's GPU alone on the same per-GPU share (measured above, outside the timed region)
