@@ -356,7 +356,7 @@ def pmc_traffic(N, args, schedule):
     was collected on (its "panel_algo"; the round-2 / round-3 files: 4; round 4: 5, the schedule the bench runs)."""
     # r04: the task-DAG schedule itself, through rocprofiler-sdk's device counting service (tools/devcount_dag.py: agent-wide
     # sampling without dispatch serialization -- `rocprofv3 --pmc` cannot run the two persistent kernels side by side)
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if N == 11192 and args.batch == 1 and os.path.exists(path):
             try:

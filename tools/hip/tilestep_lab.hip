@@ -19,6 +19,7 @@ __global__ void writer(double* F, int64_t n, double v) {   // the producer: writ
 // VAR 1: two register sets (prefetch distance 2)
 // VAR 2: no global loads at all (tiles constant in LDS): the loop's own floor
 // VAR 3: eight 16-byte loads per lane (two consecutive rows of one column) instead of sixteen 8-byte loads, two 8-byte LDS writes each
+// VAR 4: the sixteen loads of the next tile issued ONE PER BLOCK of four products (the texture addresser works under the matrix pipe)
 template <int VAR>
 __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const double* __restrict__ Vp, int64_t ld, int64_t ldv, int64_t p0,
                                             int t, double* out, unsigned long long* cyc, int reps) {
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
         auto nxt = [&](int& kc, int& c) { if (++c >= ncb) { c = 0; ++kc; } };
         int it = 0;
         if (VAR == 3) tile_load4(0, 0);
-        else if (VAR != 2) tile_load(0, 0, pre);
+        else if (VAR != 2) tile_load(0, 0, pre);   // (VAR 4: the first tile as usual)
         int k2 = 0, c2 = 0;
         nxt(k2, c2);
         if (VAR == 1) tile_load(k2, c2, pre2);
@@ -99,6 +100,27 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
                     nxt(k3, c3); nxt(k3, c3);
                     if (k3 < nch) { if (it & 1) tile_load(k3, c3, pre); else tile_load(k3, c3, pre2); }
                 }
+                if (VAR == 4) {
+                    int c3 = c + 1, k3 = kc;
+                    if (c3 >= ncb) { c3 = 0; k3 = kc + 1; }
+                    const bool more = k3 < nch;
+                    const double* src = F + (p0 + 64 * (int64_t)c3 + lane) + (p0 - Kp + 64 * (int64_t)k3 + w) * ld;
+                    v4d a = tile[lane];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int cb2 = q >> 2, ib = q & 3;
+                        v4d an = a;
+                        if (q < 15) an = tile[(q + 1) * 64 + lane];
+                        if (more) pre[q >> 2][q & 3] = src[(16 * (q >> 2) + 4 * (q & 3)) * ld];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            X[4 * c + cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], Bv[ib][s], X[4 * c + cb2], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        a = an;
+                    }
+                } else {
 #pragma unroll
                 for (int cb2 = 0; cb2 < 4; ++cb2) {
 #pragma unroll
@@ -108,6 +130,7 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
                         for (int s = 0; s < 4; ++s)
                             X[4 * c + cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[s], Bv[ib][s], X[4 * c + cb2], 0, 0, 0);
                     }
+                }
                 }
             }
         }
@@ -146,6 +169,7 @@ int main() {
         run<0>("shipped: one register set, next tile requested behind the barrier", F, V, ld, out, cyc, cold);
         run<1>("two register sets: the tile two steps ahead", F, V, ld, out, cyc, cold);
         run<3>("eight 16-byte loads (row pairs) + 8-byte LDS writes", F, V, ld, out, cyc, cold);
+        run<4>("one load of the next tile per block of four products", F, V, ld, out, cyc, cold);
     }
     return 0;
 }
