@@ -626,10 +626,24 @@ def main():
             solo = c5_shape_solo(step, args.batch)
         dist.barrier()
 
-    clk0 = shader_clock(local) if rank == 0 else None
+    def clocks_now():
+        """sysfs / rocm-smi reading (the state between two steps: a box that runs 2.4 GHz under load may show its sleep state) and the
+        clock measured under fp64 MFMA load by the library (s_memtime against the 100 MHz counter, the second of two 2.5 ms launches)."""
+        rec = shader_clock(local) or {}
+        try:
+            import ctypes
+            from madnlp_jl_amd import _lib as L
+            mhz = ctypes.c_double(0.0)
+            if L.lib().mnk_debug_shader_clock(ctx.handle, ctypes.byref(mhz)) == 0:
+                rec["sclk_under_mfma_load_mhz"] = mhz.value
+        except Exception:
+            pass
+        return rec or None
+
+    clk0 = clocks_now() if rank == 0 else None
     # (the inertia of every factorization is checked inside the step: wrong inertia voids the numbers)
     elapsed = timed_region(step, args.steps, args.warmup, sync, dist, dt)
-    clk1 = shader_clock(local) if rank == 0 else None
+    clk1 = clocks_now() if rank == 0 else None
 
     # per-phase breakdown, the reference's `timing_linear_solver` protocol (src/utils.jl:185-197):
     # each phase alone between device synchronizations, HIP events on the launch stream.

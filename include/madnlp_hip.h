@@ -546,6 +546,9 @@ int mnk_ls_debug_dag_state(mnk_ls* ls, int* flags, int64_t nflags, int* chain, i
  * arithmetic (no device needed); the task-DAG schedule sizes its bulk kernel with it: 672 beside the 16-CU chain of a 256-CU
  * part, not 3 x 240 (workgroups placed in mid-kernel were the schedule's rare time-out). */
 int mnk_debug_grid_at_launch(int cu_first, int num_cu, int first, int per_cu);
+/* Diagnostics (bench.py `clocks`): the shader clock the chip sustains under fp64 MFMA load right now, MHz (s_memtime against the
+ * 100 MHz s_memrealtime over the second of two ~2.5 ms launches of MFMAs on every CU, on the context's stream). */
+int mnk_debug_shader_clock(mnk_ctx* ctx, double* mhz);
 
 /* Diagnostics / tests (host only): the task list of the task-DAG factorization schedule (csrc/dag.hip) for a matrix of `ntile`
  * 128-row tiles: 4 ints per task (flags | chunk index << 8, tile row I, tile column J, kbeg | kend << 16) in queue order, at most

@@ -219,6 +219,7 @@ SIGNATURES = {
     "mnk_ls_debug_solve_trace": (C.c_int, [_vp, _vp, C.c_int64]),
     "mnk_ls_debug_dag_state": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
     "mnk_debug_grid_at_launch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mnk_debug_shader_clock": (C.c_int, [_vp, _vp]),
     "mnk_debug_dag_tasks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "mnk_debug_dag_merged_tasks": (C.c_int, [C.c_int] * 8 + [_vp, C.c_int]),
     "mnk_factorize_batch_begin": (C.c_int, []),

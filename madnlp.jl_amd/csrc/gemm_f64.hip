@@ -293,4 +293,49 @@ int launch_gemm_nt_queue(hipStream_t s, int64_t M, int64_t N, int64_t K, const d
     return 0;
 }
 
+// Shader clock under fp64 MFMA load: every wave of a whole-chip launch issues v_mfma_f64_16x16x4 from registers and compares the
+// shader-cycle counter (s_memtime) with the 100 MHz wall counter (s_memrealtime) over the same stretch.
+__global__ __launch_bounds__(256) void shader_clock_kernel(unsigned long long* __restrict__ out, int iters, double seed) {
+    v4f64 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = v4f64{0, 0, 0, 0};
+    double a = seed * (1.0 + threadIdx.x * 0.37), b = seed * (0.7 - threadIdx.x * 0.011);
+    const unsigned long long w0 = wall_clock64(), c0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        a = -a;
+    }
+    const unsigned long long w1 = wall_clock64(), c1 = __builtin_readcyclecounter();
+    double sm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * 4 + threadIdx.x / 64;
+        out[2 * w] = w1 - w0;
+        out[2 * w + 1] = (c1 - c0) + (sm == 12345.678 ? 1 : 0);
+    }
+}
+
 }  // namespace mnk
+
+// Diagnostics (bench.py `clocks`): the shader clock the chip sustains under fp64 MFMA load right now, in MHz -- ~5 ms of every CU
+// on the context's stream (the sysfs / rocm-smi readings show the idle state between two steps: 95 MHz on a box that runs 2.4 GHz).
+extern "C" int mnk_debug_shader_clock(mnk_ctx* ctx, double* mhz) {
+    MNK_REQUIRE(ctx && mhz, "mnk_debug_shader_clock: NULL argument");
+    MNK_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int wgs = 3 * ctx->num_cu, iters = 6000;   // (~2.5 ms per launch; the first launch takes the clock's ramp, the second is read)
+    mnk::DevBuf<unsigned long long> out;
+    if (out.alloc((size_t)wgs * 8)) return -2;
+    for (int rep = 0; rep < 2; ++rep)
+        hipLaunchKernelGGL(mnk::shader_clock_kernel, dim3(wgs), dim3(256), 0, s, out.p, iters, 1.2345678901234567);
+    MNK_HIP(hipGetLastError());
+    std::vector<unsigned long long> h((size_t)wgs * 8);
+    MNK_HIP(mnk::d2h_copy(h.data(), out.p, h.size() * sizeof(unsigned long long), s));
+    MNK_HIP(mnk::stream_wait(s));
+    double wsum = 0.0, csum = 0.0;
+    for (size_t i = 0; i < h.size(); i += 2) { wsum += (double)h[i]; csum += (double)h[i + 1]; }
+    *mhz = wsum > 0.0 ? csum / wsum * 100.0 : 0.0;
+    return 0;
+}
