@@ -217,6 +217,9 @@ def ipm_loop(args, ctx, model="acopf"):
             pass
         # speculative first corrections (ipm_dev.inertia_correction): trials factorized ahead of the verdict on the unperturbed
         # matrix, in one merged launch with it; `wasted`: the unperturbed matrix was accepted after all
+        # leading-block probes (ipm_dev.inertia_correction): unperturbed matrices rejected by a factorization of their leading principal
+        # block alone / probes that passed (the full factorization followed)
+        rec["probe_hits"], rec["probe_misses"] = int(s.probe_hits), int(s.probe_misses)
         rec["speculative_factorizations"] = int(s.speculative_factorizations)
         rec["speculative_wasted"] = int(s.speculative_wasted)
         s.cb.close()

@@ -54,12 +54,14 @@ __device__ __forceinline__ void wave_absmax_to(unsigned long long* word, double 
 }
 
 // (`amax`: optional, max|a_ij| of what is transferred -- the growth guard of BUNCHKAUFMAN's static-pivot tier)
+// (`lim`: only the leading principal block of that order is transferred -- a solver of order lim on a larger KKT handle, the
+// leading-block probe of mnk_ls_factorize_sc_async)
 __global__ void scatter_csc_kernel(double* __restrict__ F, int64_t ld, const int32_t* __restrict__ row,
                                    const int32_t* __restrict__ col, const double* __restrict__ nz, int64_t nnz,
-                                   unsigned long long* __restrict__ amax) {
+                                   unsigned long long* __restrict__ amax, int32_t lim = INT32_MAX) {
     const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     double v = 0.0;
-    if (k < nnz) {
+    if (k < nnz && row[k] < lim && col[k] < lim) {
         v = nz[k];
         F[row[k] + (int64_t)col[k] * ld] = v;
     }
@@ -920,14 +922,18 @@ static int transfer_sc(mnk_ls* ls, mnk_sc* sc) {
     if (rc) return rc;
     const int64_t nnz = sc->nnz_aug;
     hipLaunchKernelGGL(scatter_csc_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ls->ctx->stream,
-                       ls->fact.p, ls->ld, sc->aug_row.p, sc->aug_col.p, sc->aug_nz.p, nnz, amax_word(ls));
+                       ls->fact.p, ls->ld, sc->aug_row.p, sc->aug_col.p, sc->aug_nz.p, nnz, amax_word(ls),
+                       ls->N < sc->n ? (int32_t)ls->N : INT32_MAX);
     MNK_HIP(hipGetLastError());
     return 0;
 }
 
 int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
     MNK_REQUIRE(ls && sc && sc->ctx, "mnk_ls_factorize_sc: NULL argument or host-only handle");
-    MNK_REQUIRE(sc->n == ls->N, "mnk_ls_factorize_sc: order mismatch");
+    // A solver of SMALLER order factors the leading principal block of the handle's matrix (round 6: the probe of
+    // madnlp_jl_amd.ipm_dev -- a matrix whose leading block is not positive definite is not positive definite, and a static-pivot
+    // elimination that stops at column c has done 1 - (1 - c/N)^3 of the full factorization's work where the block alone costs (c/N)^3)
+    MNK_REQUIRE(sc->n >= ls->N, "mnk_ls_factorize_sc: the solver's order exceeds the KKT system's");
     MNK_HIP(hipSetDevice(ls->ctx->device));
     { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }   // (a factorize! of this solver pending in an open batch runs first)
     int rc = ensure_wbuf(ls);

@@ -388,6 +388,25 @@ class DeviceMadNLPSolver(MadNLPSolver):
     speculative_factorizations = 0
     speculative_wasted = 0
 
+    # LEADING-BLOCK PROBE (round 6, on by default where the KKT system offers `probe_solver`).  On the AC-OPF run 13 of the 17 rejected
+    # trials stop in the same 64-column block (columns 3072-3135 of 11 192): the static-pivot elimination has done 1 - (1 - 0.28)^3 =
+    # 63 % of a factorization's flops by then (4.4 ms), while the leading principal block of order 3328 alone is (0.3)^3 = 2.6 % of
+    # them.  A matrix whose leading block is not positive definite is not positive definite: when the last rejection of an unperturbed
+    # matrix stopped in the first half of the columns, the next unperturbed matrix is probed first -- a solver of that order on the
+    # leading block of the same `aug_com` -- and only a matrix that passes is factorized in full.  The verdict of a probe that fails
+    # is the verdict of the full factorization in exact arithmetic (the pivots of the leading block do not depend on the rest).
+    probe = True
+    probe_hits = 0        # unperturbed matrices rejected by the probe alone
+    probe_misses = 0      # probes that passed (the full factorization followed)
+    _reject_col = None    # where the last rejected unperturbed matrix stopped
+
+    def _probe_order(self):
+        k = self.kkt
+        if not (self._on_device and self.probe and self._reject_col is not None and hasattr(k, "probe_solver")):
+            return 0
+        m = (int(self._reject_col) + 256) // 256 * 256
+        return m if 2 * m <= k.n and m >= 512 else 0
+
     def _can_speculate(self):
         k = self.kkt
         return (self._on_device and self.speculate and self.del_w_last != 0 and hasattr(k, "ensure_spare_solver")
@@ -400,6 +419,7 @@ class DeviceMadNLPSolver(MadNLPSolver):
         dw_prev = dc_prev = 0.0
         self.del_w = self.del_c = 0.0
         spec = self._can_speculate()
+        probed = False
         if spec:
             dw1 = max(o.min_hessian_perturbation, o.perturb_dec_fact * self.del_w_last)
             dc1 = o.jacobian_regularization_value * self.mu ** o.jacobian_regularization_exponent
@@ -414,8 +434,26 @@ class DeviceMadNLPSolver(MadNLPSolver):
             self.cnt.factorization_cnt += 1
             self.speculative_factorizations += 1
         else:
-            self.factorize_wrapper()
-        inertia = k.linear_solver.inertia()
+            m = self._probe_order()
+            if m:
+                ps = k.probe_solver(m)
+                k.build_kkt_device()
+                ps.factorize_async()
+                ine = ps.inertia()
+                if ine != (m, 0, 0):     # the leading block is not positive definite: neither is the matrix
+                    probed = True
+                    self.probe_hits += 1
+                    self.cnt.factorization_cnt += 1
+                    self._reject_col = int(ps.get_stat("early_reject_col"))
+                    inertia = (ine[0], 0, k.n - ine[0])
+                else:
+                    self.probe_misses += 1
+            if not probed:
+                self.factorize_wrapper()
+        if not probed:
+            inertia = k.linear_solver.inertia()
+            if self._on_device and self.probe and not k.is_inertia_correct(*inertia) and hasattr(k, "probe_solver"):
+                self._reject_col = int(k.linear_solver.get_stat("early_reject_col"))
         correct = k.is_inertia_correct(*inertia)
         if spec and correct:
             # trial 0 stands: the handle goes back to the unperturbed system (diagonals bit for bit, matrix and condensation

@@ -249,6 +249,21 @@ class SparseCondensedKKTSystem(_KKTCommon):
             self.spare_solver.set_option("early_reject", 1 if early_reject else 0)
         return self.spare_solver
 
+    def probe_solver(self, m):
+        """A solver of order `m` < n on the leading principal block of `aug_com` (cached per order): if that block is not positive
+        definite neither is the matrix, and the block costs (m / n)^3 of a factorization where the full static-pivot elimination
+        has done 1 - (1 - m / n)^3 of its work by the time it reaches column m."""
+        from .linear_solver import LeadingBlock
+        if not hasattr(self, "_probes"):
+            self._probes = {}
+        if m not in self._probes:
+            cls, opt, _ = self._spare_args
+            ps = cls(LeadingBlock(self.aug_com, m), ctx=self.ctx, opt=opt)
+            ps.set_option("accept_only_pd", 1)
+            ps.set_option("early_reject", 1)
+            self._probes[m] = ps
+        return self._probes[m]
+
     def swap_solvers(self):
         """The spare solver's factor is the one the iteration goes on with."""
         self.linear_solver, self.spare_solver = self.spare_solver, self.linear_solver
@@ -442,6 +457,9 @@ class SparseCondensedKKTSystem(_KKTCommon):
         if getattr(self, "spare_solver", None) is not None:
             self.spare_solver.close()
             self.spare_solver = None
+        for ps in getattr(self, "_probes", {}).values():
+            ps.close()
+        self._probes = {}
         if self._h:
             L.lib().mnk_sc_destroy(self._h)
             self._h = C.c_void_p()

@@ -401,6 +401,23 @@ class DeviceDense:
         return out
 
 
+class LeadingBlock(DeviceCSC):
+    """The leading principal block of order `m` of a sparse condensed system's `aug_com`: what a probe solver factors
+    (`mnk_ls_factorize_sc_async` with a solver of smaller order)."""
+
+    def __init__(self, full: DeviceCSC, m: int):
+        keep = np.repeat(np.arange(full.n), np.diff(full.colptr)) < m
+        keep &= np.asarray(full.rowval) < m
+        colptr = np.concatenate(([0], np.cumsum(np.bincount(np.repeat(np.arange(full.n), np.diff(full.colptr))[keep], minlength=full.n)[:m])))
+        super().__init__(full.owner, m, colptr.astype(np.int64), np.asarray(full.rowval)[keep])
+        self._keep = keep
+        self._full = full
+
+    @property
+    def nzval(self):
+        return self._full.nzval[self._keep]
+
+
 def _order_of(A):
     if isinstance(A, DeviceCSC):
         return A.n

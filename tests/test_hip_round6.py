@@ -52,3 +52,70 @@ def test_speculative_inertia_correction_reproduces_the_sequential_loop(ctx):
     assert seq[5] == spc[5]                                       # del_w and the residual history, bit for bit
     assert seq[4] == spc[4] and np.array_equal(seq[8], spc[8])
     assert seq[6] == 0 and spc[6] >= 10 and 0 <= spc[7] <= spc[6] // 3
+
+
+def test_a_solver_of_smaller_order_factors_the_leading_block_of_the_kkt_matrix(ctx):
+    """`mnk_ls_factorize_sc_async` with a solver of order m < n (`SparseCondensedKKTSystem.probe_solver`): the factor, the inertia
+    and a solve are those of the leading principal block K[:m, :m] -- checked against LAPACK on that block (oracle/lapack_cpu.py)
+    for a positive definite system, and the verdict "not positive definite" for an indefinite one whose full factorization is
+    rejected in the same columns."""
+    from madnlp_jl_amd.problems import opf_shaped
+    from oracle.lapack_cpu import BUNCHKAUFMAN, LapackCPUSolver
+    from tests.test_hip_c5 import _hip_sc
+    for indefinite in (False, True):
+        P = opf_shaped("case1354pegase", indefinite=indefinite, sigma_s_decades=2.0, du=1e-8)
+        k = _hip_sc(P, ctx, mj.BUNCHKAUFMAN)
+        k.compress_jacobian(); k.compress_hessian(); k.set_aug_diagonal(); k.build_kkt()
+        m = 3328
+        ps = k.probe_solver(m)
+        ps.factorize()
+        Kd = k.aug_com.to_dense()[:m, :m]
+        Kf = Kd + np.tril(Kd, -1).T
+        ref = LapackCPUSolver(np.asfortranarray(np.tril(Kf)), BUNCHKAUFMAN).factorize()
+        ine_ref = tuple(int(v) for v in ref.inertia())
+        ine = ps.inertia()
+        if not indefinite:
+            assert ine == ine_ref == (m, 0, 0)
+            b = np.random.default_rng(3).standard_normal(m)
+            x = ps.solve_linear_system(b.copy())
+            assert np.abs(Kf @ x - b).max() / (np.abs(Kf).sum(1).max() * np.abs(x).max() + np.abs(b).max()) <= 1e-13
+        else:
+            assert ine_ref[2] >= 1 and ine != (m, 0, 0) and sum(ine) == m       # rejected (early: the counts behind the stop are "negative")
+            k.linear_solver.factorize()
+            full = k.linear_solver.inertia()
+            assert not k.is_inertia_correct(*full)
+            assert ps.get_stat("early_reject_col") == k.linear_solver.get_stat("early_reject_col") < m
+        k.close()
+
+
+def test_leading_block_probes_leave_the_interior_point_run_as_it_is(ctx):
+    """`DeviceMadNLPSolver.probe` (default on): after a rejection that stopped in the first half of the columns, the next unperturbed
+    matrix is first probed through its leading principal block.  On the AC-OPF NLP of case1354pegase: same status, iterations,
+    perturbation sequence and optimum with and without the probes (a probe's verdict is the full factorization's in exact arithmetic;
+    both runs are compared to 1e-9 -- the leading block is summed in another chunk order than the same columns of the full matrix),
+    most rejections are taken by probes, and the run is not slower."""
+    from madnlp_jl_amd.ipm import IPMOptions
+    from madnlp_jl_amd.ipm_dev import DeviceMadNLPSolver
+    import time
+    nlp = ACOPFModel("case1354pegase")
+
+    def factory(info):
+        return mj.SparseCondensedKKTSystem(info["n"], info["m"], nlp.jac_I, nlp.jac_J, nlp.hess_I, nlp.hess_J, info["ind_ineq"],
+                                           info["ind_lb"], info["ind_ub"], ctx=ctx,
+                                           opt_linear_solver=mj.HipSolverOptions(lapack_algorithm=mj.BUNCHKAUFMAN), device_kkt_ops=True)
+    runs = {}
+    for probe in (False, True, False, True):
+        o = IPMOptions(tol=1e-6)
+        o.relax_equality, o.dual_initialization = True, "zero"
+        s = DeviceMadNLPSolver(nlp, factory, o)
+        s.probe = probe
+        s.initialize(); s._upload(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); s.solve(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+        runs[probe] = (s.status, s.cnt.k, s.cnt.factorization_cnt, s.obj_val, [h.del_w for h in s.history], s.probe_hits, s.probe_misses, wall)
+        s.cb.close(); s.K.close(); s.kkt.close()
+    off, on = runs[False], runs[True]
+    assert off[0] == on[0] == "SOLVE_SUCCEEDED" and off[1] == on[1]
+    assert abs(off[2] - on[2]) <= 2 and off[4] == on[4]
+    assert abs(off[3] - on[3]) <= 1e-9 * abs(off[3])
+    assert off[5] == 0 and on[5] >= 8 and on[6] <= on[5] // 2
+    assert on[7] <= 1.02 * off[7], (on[7], off[7])
