@@ -145,7 +145,11 @@ int mnk_ls_create(mnk_ctx* ctx, int64_t N, int algo, mnk_ls** out);
 int mnk_ls_destroy(mnk_ls* ls);
 /* Options: "pivot_tol" (LDL: |d| <= pivot_tol counts as a zero pivot; default 0),
  * "outer_block" (outer panel width, multiple of 64; default 0 = by size: 512, and 1024 from 32 768 rows on),
- * "lookahead" (0/1; default 1: factor the next panel while the trailing update runs). */
+ * "lookahead" (0/1; default 1: factor the next panel while the trailing update runs),
+ * "probe" (0/1; default 1, effective while "early_reject" and "accept_only_pd" are set: after an early rejection that stopped in the
+ * first half of the columns, a matrix from the same KKT handle that follows an ACCEPTED one is first factorized on its leading
+ * principal block alone -- a child solver of that order; a block that is not positive definite settles the verdict at a few
+ * percent of a factorization's work; statistics "probe_hits" / "probe_misses"). */
 int mnk_ls_set_option(mnk_ls* ls, const char* key, double value);
 
 /* factorize!(M) `src/LinearSolvers/lapack_common.jl:54-66` = transfer_matrix!

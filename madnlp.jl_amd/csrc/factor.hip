@@ -1659,6 +1659,10 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         ++ls->early_rejects;
         ls->early_reject_col = (int64_t)(long long)pw[7];
         ls->info_valid = true;
+        // (history of the leading-block probe, ls.h)
+        ls->probe_last_rejected = true;
+        if (2 * ls->early_reject_col < ls->N) { ls->probe_hint_col = ls->early_reject_col; ls->probe_since_hint = 0; }
+        else if (ls->probe_since_hint < (1 << 20)) ++ls->probe_since_hint;
         return 0;
     }
     if (hinfo < 0) {
@@ -1694,6 +1698,8 @@ int mnk_ls_fetch_info(mnk_ls* ls) {
         if (hinfo == 0) { ls->npos = ls->N; ls->nzero = 0; ls->nneg = 0; }
         else { ls->npos = 0; ls->nzero = ls->N; ls->nneg = 0; }
     }
+    ls->probe_last_rejected = false;   // (history of the leading-block probe: a verdict that is not an early rejection)
+    if (ls->probe_since_hint < (1 << 20)) ++ls->probe_since_hint;
     ls->info_valid = true;
     return 0;
 }

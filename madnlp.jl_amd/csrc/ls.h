@@ -136,6 +136,16 @@ struct mnk_ls {
     bool src_persistent = false; // the source of the last factorize! call outlives the call (KKT handles): a rejected factorization can be completed later
     bool factor_invalid = false; // the last factorization was rejected early: solve / get_factor refuse
     int64_t early_rejects = 0, early_reject_col = -1, early_reject_redone = 0;   // statistics ("early_rejects", "early_reject_col")
+    // LEADING-BLOCK PROBE (round 6; option "probe", effective while early rejection is armed): after a rejection that stopped in
+    // the first half of the columns, a matrix that follows an ACCEPTED one is first probed through its leading principal block (a
+    // child solver of that order on the same KKT handle) -- mnk_ls_factorize_sc_async
+    int probe = 1;
+    mnk_ls* probe_ls = nullptr;      // the child (order probe_order), owned
+    int64_t probe_order = 0;
+    int64_t probe_hint_col = -1;     // where the last early rejection of the first half stopped
+    int probe_since_hint = 1 << 20;  // verdicts fetched since then
+    bool probe_last_rejected = false;
+    int64_t probe_hits = 0, probe_misses = 0;   // statistics: matrices rejected by the probe alone / probes that passed
     int accept_only_pd = 0;      // option: the caller accepts positive definite matrices only: "not PD" from the static tier is final
     // Growth guard of the static-pivot tier (BUNCHKAUFMAN only).  The pivots are entries of the successive Schur complements,
     // so max|d_k| / max|a_ij| is a lower bound of the element growth of the elimination; dsytrf's pivoting bounds the growth,

@@ -674,6 +674,7 @@ int mnk_ls_destroy(mnk_ls* ls) {
     }
     (void)mnk_ls_sync_deferred(ls);
     (void)mnk::stream_wait(ls->ctx->stream);
+    if (ls->probe_ls) { (void)mnk_ls_destroy(ls->probe_ls); ls->probe_ls = nullptr; }
     mnk::LaunchLock lock;   // (host-memory frees and event destruction below; the device buffers lock for themselves)
     mnk::quiesce_persistent();
     if (ls->solve_abort) (void)hipHostFree(ls->solve_abort);
@@ -783,6 +784,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
         return 0;
     }
     if (!strcmp(key, "accept_only_pd")) { ls->accept_only_pd = value != 0; return 0; }  // see mnk_ls_fetch_info
+    if (!strcmp(key, "probe")) { ls->probe = value != 0; return 0; }   // leading-block probe in front of a factorization that is likely to be rejected early (ls.h)
     if (!strcmp(key, "early_reject")) { ls->early_reject = value != 0; return 0; }      // with accept_only_pd: stop at the first non-positive pivot (leaf64.h)
     // BUNCHKAUFMAN only: element growth max|d_k| / max|a_ij| of the static-pivot tier above which the pivoted tier takes over
     if (!strcmp(key, "dag_debug")) {
@@ -928,6 +930,55 @@ static int transfer_sc(mnk_ls* ls, mnk_sc* sc) {
     return 0;
 }
 
+// The leading-block probe (ls.h).  On the AC-OPF run of the bench line 13 of 17 rejected trials stop in the same 64 columns
+// (3072-3135 of 11 192): the static-pivot elimination has done 1 - (1 - 0.28)^3 = 63 % of a factorization's flops by then (4.4 ms),
+// the leading principal block of order 3328 alone is 2.6 % of them (1.8 ms as a factorization of its own).  A matrix whose leading
+// block is not positive definite is not positive definite, and the pivots of the block do not depend on the rest of the matrix: a
+// probe that fails gives the verdict of the full factorization.  When: early rejection armed, the previous verdict of this solver
+// was an acceptance (in inertia_correction! the matrix after a rejection is the regularized one), and a rejection that stopped in
+// the first half of the columns is at most three verdicts old -- solvers that never reject never probe.
+// Returns 0 and *rejected; on a rejection the solver's state is that of an early-rejected factorization (inertia: the block's
+// positive pivots, everything else negative; a solve that comes all the same completes the factorization from the handle).
+static int probe_leading_block(mnk_ls* ls, mnk_sc* sc, bool* rejected) {
+    *rejected = false;
+    if (!(ls->probe && ls->early_reject && ls->accept_only_pd && ls->algo == MNK_LDL && ls->N == sc->n && !mnk_batch_active())) return 0;
+    if (ls->probe_last_rejected || ls->probe_hint_col < 0 || ls->probe_since_hint > 3) return 0;
+    const int64_t m = (ls->probe_hint_col + 256) / 256 * 256;
+    if (m < 512 || 2 * m > ls->N) return 0;
+    if (ls->probe_ls == nullptr || ls->probe_order != m) {
+        if (ls->probe_ls) { (void)mnk_ls_destroy(ls->probe_ls); ls->probe_ls = nullptr; }
+        mnk_ls* child = nullptr;
+        if (mnk_ls_create(ls->ctx, m, ls->algo, &child) != 0) { (void)hipGetLastError(); return 0; }   // (no memory for it: no probe)
+        child->probe = 0;
+        child->accept_only_pd = 1;
+        child->early_reject = 1;
+        child->pivot_tol = ls->pivot_tol;
+        ls->probe_ls = child;
+        ls->probe_order = m;
+    }
+    mnk_ls* c = ls->probe_ls;
+    int rc = mnk_ls_factorize_sc_async(c, sc);
+    if (!rc) rc = mnk_ls_fetch_info(c);
+    if (rc) return rc;
+    if (c->npos == m && c->nzero == 0 && c->nneg == 0) { ++ls->probe_misses; return 0; }
+    // not positive definite: the verdict, without the full factorization
+    ++ls->probe_hits;
+    ++ls->early_rejects;
+    ls->early_reject_col = c->factor_invalid ? c->early_reject_col : m - 1;
+    ls->info = 1;
+    ls->npos = c->npos;
+    ls->nzero = c->nzero;
+    ls->nneg = ls->N - ls->npos - ls->nzero;
+    ls->factor_invalid = true;
+    ls->info_valid = true;
+    ls->factorized = true;
+    ls->bk_active = false;
+    ls->probe_last_rejected = true;
+    if (2 * ls->early_reject_col < ls->N) { ls->probe_hint_col = ls->early_reject_col; ls->probe_since_hint = 0; }
+    *rejected = true;
+    return 0;
+}
+
 int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
     MNK_REQUIRE(ls && sc && sc->ctx, "mnk_ls_factorize_sc: NULL argument or host-only handle");
     // A solver of SMALLER order factors the leading principal block of the handle's matrix (round 6: the probe of
@@ -938,8 +989,13 @@ int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
     { int rc_d = mnk_ls_sync_deferred(ls); if (rc_d) return rc_d; }   // (a factorize! of this solver pending in an open batch runs first)
     int rc = ensure_wbuf(ls);
     if (rc) return rc;
-    rc = transfer_sc(ls, sc);
+    bool probe_rejected = false;
+    rc = probe_leading_block(ls, sc, &probe_rejected);
     if (rc) return rc;
+    if (!probe_rejected) {
+        rc = transfer_sc(ls, sc);
+        if (rc) return rc;
+    }
     // (the KKT handle keeps aug_com until the next build_kkt!, so the pivoted tier can fetch the matrix again when
     // the inertia is asked for)
     ls->src_persistent = true;   // (the handle keeps aug_com until the next build_kkt!)
@@ -951,6 +1007,7 @@ int mnk_ls_factorize_sc_async(mnk_ls* ls, mnk_sc* sc) {
         }
         return transfer_sc(ls, sc);
     };
+    if (probe_rejected) return 0;   // (the verdict is in; ensure_complete_factor knows the way back to the matrix)
     return mnk_ls_run_factorization(ls);
 }
 
@@ -1289,6 +1346,8 @@ int mnk_ls_get_stat(mnk_ls* ls, const char* key, double* value) {
     if (!strcmp(key, "pp_fallbacks")) { *value = ls->pp_fallbacks; return 0; }
     // which bounded device-side wait expired last (info = -7): 1 bulk task / operand rows, 2 bulk task / chunk order, 3 gate on the bulk stream, 4 chain strip / diagonal block, 5 chain strip / bulk kernel's rows or band tiles; 0: none
     if (!strcmp(key, "timeout_site")) { *value = ls->last_timeout_site; return 0; }
+    if (!strcmp(key, "probe_hits")) { *value = (double)ls->probe_hits; return 0; }       // matrices rejected by the leading-block probe alone
+    if (!strcmp(key, "probe_misses")) { *value = (double)ls->probe_misses; return 0; }   // probes that passed (the full factorization followed)
     if (!strcmp(key, "early_rejects")) { *value = (double)ls->early_rejects; return 0; }       // factorizations stopped at their first non-positive pivot
     if (!strcmp(key, "early_reject_redone")) { *value = (double)ls->early_reject_redone; return 0; }   // ... rejected factorizations completed after all because the caller solved
     if (!strcmp(key, "early_reject_col")) { *value = (double)ls->early_reject_col; return 0; } // ... the last valid pivot of the latest one

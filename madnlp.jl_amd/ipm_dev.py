@@ -388,24 +388,21 @@ class DeviceMadNLPSolver(MadNLPSolver):
     speculative_factorizations = 0
     speculative_wasted = 0
 
-    # LEADING-BLOCK PROBE (round 6, on by default where the KKT system offers `probe_solver`).  On the AC-OPF run 13 of the 17 rejected
-    # trials stop in the same 64-column block (columns 3072-3135 of 11 192): the static-pivot elimination has done 1 - (1 - 0.28)^3 =
-    # 63 % of a factorization's flops by then (4.4 ms), while the leading principal block of order 3328 alone is (0.3)^3 = 2.6 % of
-    # them.  A matrix whose leading block is not positive definite is not positive definite: when the last rejection of an unperturbed
-    # matrix stopped in the first half of the columns, the next unperturbed matrix is probed first -- a solver of that order on the
-    # leading block of the same `aug_com` -- and only a matrix that passes is factorized in full.  The verdict of a probe that fails
-    # is the verdict of the full factorization in exact arithmetic (the pivots of the leading block do not depend on the rest).
+    # LEADING-BLOCK PROBE (round 6): lives in the library (`mnk_ls_factorize_sc_async`, option "probe", on by default while early
+    # rejection is armed) so that every caller -- this driver, the reference's own inertia_correction! through the Julia glue -- gets
+    # it: after a rejection that stopped in the first half of the columns, a matrix that follows an accepted one is first probed
+    # through its leading principal block (13 of the AC-OPF run's 17 rejections stop in the same 64 columns; the block of order
+    # 3328 is 2.6 % of a factorization's flops where the full elimination has done 63 % by that column).  `probe = False` on the
+    # solver object switches it off for A/B runs; `probe_hits` / `probe_misses` read the library's counters.
     probe = True
-    probe_hits = 0        # unperturbed matrices rejected by the probe alone
-    probe_misses = 0      # probes that passed (the full factorization followed)
-    _reject_col = None    # where the last rejected unperturbed matrix stopped
 
-    def _probe_order(self):
-        k = self.kkt
-        if not (self._on_device and self.probe and self._reject_col is not None and hasattr(k, "probe_solver")):
-            return 0
-        m = (int(self._reject_col) + 256) // 256 * 256
-        return m if 2 * m <= k.n and m >= 512 else 0
+    @property
+    def probe_hits(self):
+        return int(self.kkt.linear_solver.get_stat("probe_hits")) if hasattr(self.kkt.linear_solver, "get_stat") else 0
+
+    @property
+    def probe_misses(self):
+        return int(self.kkt.linear_solver.get_stat("probe_misses")) if hasattr(self.kkt.linear_solver, "get_stat") else 0
 
     def _can_speculate(self):
         k = self.kkt
@@ -418,8 +415,10 @@ class DeviceMadNLPSolver(MadNLPSolver):
         n_trial = 0
         dw_prev = dc_prev = 0.0
         self.del_w = self.del_c = 0.0
+        if self._on_device and getattr(self, "_probe_applied", None) != self.probe and hasattr(k.linear_solver, "set_option"):
+            k.linear_solver.set_option("probe", 1 if self.probe else 0)
+            self._probe_applied = self.probe
         spec = self._can_speculate()
-        probed = False
         if spec:
             dw1 = max(o.min_hessian_perturbation, o.perturb_dec_fact * self.del_w_last)
             dc1 = o.jacobian_regularization_value * self.mu ** o.jacobian_regularization_exponent
@@ -434,26 +433,8 @@ class DeviceMadNLPSolver(MadNLPSolver):
             self.cnt.factorization_cnt += 1
             self.speculative_factorizations += 1
         else:
-            m = self._probe_order()
-            if m:
-                ps = k.probe_solver(m)
-                k.build_kkt_device()
-                ps.factorize_async()
-                ine = ps.inertia()
-                if ine != (m, 0, 0):     # the leading block is not positive definite: neither is the matrix
-                    probed = True
-                    self.probe_hits += 1
-                    self.cnt.factorization_cnt += 1
-                    self._reject_col = int(ps.get_stat("early_reject_col"))
-                    inertia = (ine[0], 0, k.n - ine[0])
-                else:
-                    self.probe_misses += 1
-            if not probed:
-                self.factorize_wrapper()
-        if not probed:
-            inertia = k.linear_solver.inertia()
-            if self._on_device and self.probe and not k.is_inertia_correct(*inertia) and hasattr(k, "probe_solver"):
-                self._reject_col = int(k.linear_solver.get_stat("early_reject_col"))
+            self.factorize_wrapper()
+        inertia = k.linear_solver.inertia()
         correct = k.is_inertia_correct(*inertia)
         if spec and correct:
             # trial 0 stands: the handle goes back to the unperturbed system (diagonals bit for bit, matrix and condensation

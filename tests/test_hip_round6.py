@@ -89,8 +89,9 @@ def test_a_solver_of_smaller_order_factors_the_leading_block_of_the_kkt_matrix(c
 
 
 def test_leading_block_probes_leave_the_interior_point_run_as_it_is(ctx):
-    """`DeviceMadNLPSolver.probe` (default on): after a rejection that stopped in the first half of the columns, the next unperturbed
-    matrix is first probed through its leading principal block.  On the AC-OPF NLP of case1354pegase: same status, iterations,
+    """The library's leading-block probe (`mnk_ls_set_option(ls, "probe", .)`, default on while early rejection is armed;
+    `DeviceMadNLPSolver.probe` switches it): after a rejection that stopped in the first half of the columns, a matrix that follows an
+    accepted one is first probed through its leading principal block.  On the AC-OPF NLP of case1354pegase: same status, iterations,
     perturbation sequence and optimum with and without the probes (a probe's verdict is the full factorization's in exact arithmetic;
     both runs are compared to 1e-9 -- the leading block is summed in another chunk order than the same columns of the full matrix),
     most rejections are taken by probes, and the run is not slower."""
