@@ -81,6 +81,8 @@ def parse_args():
                     help="batch > 1: enqueue the factorizations one by one instead of through mnk_factorize_batch_begin/_end "
                          "(one merged persistent launch for all instances of a step: they fill each other's chain-bound ends)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="keep roofline.traffic from the committed counter record instead of measuring it in this run (two child processes, ~15 s)")
     ap.add_argument("--no-c5-shape", action="store_true",
                     help="skip the supplementary `c5_shape_per_gpu` record (16 instances per step on this GPU, ~15 s)")
     ap.add_argument("--no-c4", action="store_true", help="skip the supplementary config-C4 record (case9241pegase shape, ~15 s)")
@@ -369,6 +371,41 @@ def pmc_traffic(N, args, schedule):
             except Exception:
                 pass
     return None, None
+
+
+def live_traffic(N, schedule, calls=8, timeout_s=120):
+    """Bytes per factorize! call at the L2 -> fabric interface, MEASURED in this bench run (the replayed record
+    goes stale silently with the next tiling change): two short passes of tools/devcount_dag.py in child processes -- rocprofiler-sdk's
+    device counting service (agent-wide sampling, no dispatch serialization: the schedule's two persistent kernels run side by side
+    as in the timed region), one counter set per pass as MI355X_MICROARCH.md prescribes -- on the same C3 system, `calls` calls each.
+    FETCH_SIZE / WRITE_SIZE by their gfx950 definitions, reads x2-corrected (128-B requests tallied at 64 B).  Returns None when the
+    counting service is not to be had (no tool library, a pass fails or runs another schedule): the caller falls back to the record."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "devcount", "libmnk_devcount.so")
+    if N != 11192 or not os.path.exists(tool):
+        return None
+    env = dict(os.environ, ROCP_TOOL_LIBRARIES=tool)
+    got = {}
+    try:
+        for which in ("fetch", "write"):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "devcount_dag.py"), which, str(calls)], env=env,
+                               capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                return None
+            rec = json.loads(line[-1])
+            if int(rec["schedule_panel_algo"]) != int(schedule) or not rec["inertia_ok"] or rec["pp_fallbacks"] != 0:
+                return None
+            got[which] = rec
+        cf, cw = got["fetch"]["counters_per_call"], got["write"]["counters_per_call"]
+        rd, rd32, bub = cf["TCC_EA0_RDREQ"], cf.get("TCC_EA0_RDREQ_32B", 0.0), cf.get("TCC_BUBBLE", 0.0)
+        fetch_b = bub * 128 + (rd - bub - rd32) * 64 + rd32 * 32
+        wr, wr64 = cw["TCC_EA0_WRREQ"], cw.get("TCC_EA0_WRREQ_64B", 0.0)
+        write_b = wr64 * 64 + (wr - wr64) * 32
+        return {"traffic": 2.0 * fetch_b + write_b, "read_bytes_x2_corrected": 2.0 * fetch_b, "write_bytes": write_b,
+                "calls_per_pass": calls, "ms_per_call_under_counting": 0.5 * (got["fetch"]["ms_per_call"] + got["write"]["ms_per_call"])}
+    except Exception:
+        return None
 
 
 def config_c4(ctx, torch, mj):
@@ -723,6 +760,15 @@ def main():
                          # host milliseconds lost to expired device-side waits in this process (0 on a healthy run)
                          "stall_ms_process": float(ls.get_stat("stall_ms_process"))},
         }
+        if world == 1 and args.batch == 1 and not args.no_live_traffic:
+            # (child processes on the same GPU, after the timed region and the phase timings; ~15 s)
+            lt = live_traffic(N, schedule)
+            if lt is not None:
+                out["roofline"].update(traffic=lt["traffic"], traffic_source="measured in this run: tools/devcount_dag.py (rocprofiler-sdk device "
+                                       f"counting service), FETCH and WRITE passes of {lt['calls_per_pass']} factorize! calls each",
+                                       traffic_read_bytes=lt["read_bytes_x2_corrected"], traffic_write_bytes=lt["write_bytes"],
+                                       traffic_over_algorithmic=lt["traffic"] / (8.0 * N * N),
+                                       ms_per_call_under_counting=lt["ms_per_call_under_counting"])
         if world > 1 and solo is not None:
             # the scaling curve's own denominator: rank 0's GPU alone on the same per-GPU share (measured above, outside the timed region)
             out["per_gpu_value"] = out["value"] / world
