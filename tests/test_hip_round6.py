@@ -120,3 +120,56 @@ def test_leading_block_probes_leave_the_interior_point_run_as_it_is(ctx):
     assert abs(off[3] - on[3]) <= 1e-9 * abs(off[3])
     assert off[5] == 0 and on[5] >= 8 and on[6] <= on[5] // 2
     assert on[7] <= 1.02 * off[7], (on[7], off[7])
+
+
+def test_schur_assembly_rejects_what_the_reference_rejects_and_shards_over_ranks(ctx):
+    """`mnk_schur_set_structure`: the layout errors of the reference's `_build_schur_symbolic` (schur.jl:140-236, test/schur_test.jl:176-236)
+    come back as errors of the call; and scenarios sharded over two stages (`local_scen`, `own_design` on one of them: the partition
+    of `schur.shard`) assemble the blocks of the single-stage assembly bit for bit, their S0 parts adding up to its S0."""
+    from madnlp_jl_amd.problems import random_twostage_qp
+    from madnlp_jl_amd.schur import SchurDenseStage
+    ns, nv, nd, nc = 2, 1, 1, 1
+    n, m = ns * nv + nd, ns * nc
+    mk = lambda nsl=ns, blk=2: SchurDenseStage([np.eye(blk)] * nsl, [np.zeros((nd, blk))] * nsl, np.eye(nd), nd, blk, ctx=ctx)  # noqa: E731
+    hI, hJ, jI, jJ = [0, 1, 2], [0, 1, 2], [0, 0, 1, 1], [0, 2, 1, 2]
+    st = mk()
+    st.set_structure(n, m, nv, nc, hI, hJ, jI, jJ, [], [0, 1])                      # fine: both rows equalities
+    with pytest.raises(ValueError, match="couples two scenarios"):
+        st.set_structure(n, m, nv, nc, [0, 1, 2, 1], [0, 1, 2, 0], jI, jJ, [], [0, 1])
+    with pytest.raises(ValueError, match="another scenario"):
+        st.set_structure(n, m, nv, nc, hI, hJ, [0, 0, 0, 1, 1], [0, 1, 2, 1, 2], [], [0, 1])
+    with pytest.raises(ValueError, match="different numbers"):
+        st.set_structure(n, m, nv, nc, hI, hJ, jI, jJ, [1], [0])
+    with pytest.raises(ValueError, match="do not match"):
+        st.set_structure(n + 1, m, nv, nc, hI, hJ, jI, jJ, [], [0, 1])
+    st.close()
+    # sharding: 4 scenarios on one stage vs 2 + 2 on two
+    nlp = random_twostage_qp(ns=4, nv=12, nd=5, nc=6, nc_eq=2, seed=7)
+    rng = np.random.default_rng(0)
+    n, m, blk = nlp.n, nlp.m, nlp.nv + 2
+    ind_eq = np.array([k * nlp.nc + i for k in range(nlp.ns) for i in range(2)])
+    ind_ineq = np.array([k * nlp.nc + i for k in range(nlp.ns) for i in range(2, nlp.nc)])
+    hess = rng.uniform(0.5, 2.0, len(nlp.hess_I)); jac = nlp.jvals.copy()
+    pr = rng.uniform(0.1, 1.0, n + len(ind_ineq)); du = -rng.uniform(1e-3, 1e-2, m)
+    args = (n, m, nlp.nv, nlp.nc, nlp.hess_I, nlp.hess_J, nlp.jac_I, nlp.jac_J, ind_ineq, ind_eq)
+    one = SchurDenseStage([np.eye(blk)] * 4, [np.zeros((nlp.nd, blk))] * 4, np.eye(nlp.nd), nlp.nd, blk, ctx=ctx)
+    one.set_structure(*args)
+    one.assemble(hess, jac, pr, du)
+    parts, s0 = {}, np.zeros((nlp.nd, nlp.nd))
+    for rank in (0, 1):
+        loc = [k for k in range(4) if k % 2 == rank]
+        sh = SchurDenseStage([np.eye(blk)] * 2, [np.zeros((nlp.nd, blk))] * 2, np.eye(nlp.nd), nlp.nd, blk, ctx=ctx)
+        sh.set_structure(*args, ns_global=4, local_scen=loc, own_design=rank == 0)
+        sh.assemble(hess, jac, pr, du)
+        for i, k in enumerate(loc):
+            parts[k] = sh.get_block(i)
+        s0 += sh.get_s0()
+        sh.close()
+    for k in range(4):
+        A, Cd = one.get_block(k)
+        assert np.array_equal(A, parts[k][0]) and np.array_equal(Cd, parts[k][1]), k
+        # (both triangles are assembled; (j1 D) j2 and (j2 D) j1 round differently, as in the oracle's scatter)
+        assert np.abs(A - A.T).max() <= 4e-16 * np.abs(A).max() and np.abs(A).max() > 0
+    S0 = one.get_s0()
+    assert np.abs(s0 - S0).max() <= 1e-14 * np.abs(S0).max()
+    one.close()
