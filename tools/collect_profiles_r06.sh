@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT/gpurun_out/prof_r06
 rm -rf $R; mkdir -p $R
 cd /tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-ipm-loop --no-c4"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-ipm-loop --no-c4 --no-c5-shape --no-live-traffic"
 timeout 300 rocprofv3 --kernel-trace -d $R/bench -o p -- $B --steps 10 --warmup 2 > $R/bench_under_rocprof.log 2>&1
 db() { find $R/$1 -name "*.db" | head -1; }
 cd $GRAFT_REPO_ROOT
