@@ -1013,7 +1013,11 @@ int mnk_ls_dag_prepare(mnk_ls* ls) {
         // ~50 us.  (Switching from the first shape to the second in mid-factorization, once dag_cus2 strips remain, is
         // supported by the task list -- dag_js2 -- and was measured: the deep band needs one CU per strip, the remaining bulk
         // work of a C3-size system then no longer fits the smaller bulk partition, 10.7 vs 10.3 ms.)
-        const int64_t deep_rows = (int64_t)ctx->dag_cus2 * NBI;
+        // (round 6: the deep band pays up to ~5300 rows -- all rows in the band against band + bulk kernel throughout, LDL^T, one box:
+        // N = 4096 1.61 vs 1.73 ms, 4608 1.86 vs 1.99, 5120 2.20 vs 2.27, 5632 2.70 vs 2.59, 6144 3.24 vs 2.93 (Cholesky 5632: 2.75 vs 2.46) --
+        // above that every strip's left-looking prologue on its one CU costs more than the bulk kernel's closing tasks; the limit
+        // was the partition's 96 strips = 6144 rows: dag_deep_rows)
+        const int64_t deep_rows = std::min<int64_t>((int64_t)ctx->dag_cus2 * NBI, ls->dag_deep_rows);
         ls->dag_js2 = (ctx->dag_cus2 > 0 && Np <= deep_rows) ? 0 : nsc;
         if (ls->dag_js2_override >= 0) ls->dag_js2 = std::min(nsc, ls->dag_js2_override);
         std::vector<int>& h = ls->dag_host_tasks;   // (kept on the host: a batch merges the lists of its instances)

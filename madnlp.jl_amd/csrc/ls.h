@@ -106,6 +106,7 @@ struct mnk_ls {
                               // (info = -7); 0 = by the order of the matrix (mnk_ls_dag_spin_limit)
     int dag_chunk = 64;           // tile columns (of 128) per bulk task behind the doubling taper 1, 2, 4, ... (every task ends with a read-modify-write of its tile; C3 at the end of round 3: 12 -> 9.58 ms, 48 / 64 / 88 / 128 / 1024 -> 9.30; N = 16 384: 26.3 -> 25.9 ms, N = 24 576: 82.0 / 82.5 ms; in the middle of the round, with slower closing tasks, 10-16 was the optimum)
     int64_t dag_min_rows = 1536;  // smaller systems keep the launch-per-panel schedules (measured break-even: N ~ 1500)
+    int64_t dag_deep_rows = 5376; // systems up to this order put every row into the chain's band (and at most 64 x MNK_DAG_CUS2 rows); larger ones: band + bulk kernel
     int64_t dag_max_rows = 24576; // larger ones too: their trailing updates already run at the update kernel's rate (measured: 22384 +1 %, 30000 -2 %)
     int panel_algo = 5;  // 5: task-DAG schedule (dag.hip: persistent pivot chain + persistent left-looking bulk kernel); 4: persistent panel kernel per 256 columns + one trailing update per outer panel (also what 5 uses outside [dag_min_rows, dag_max_rows]); 1: one launch per piece, the fallback of 4 and 5
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step

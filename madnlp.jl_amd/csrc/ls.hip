@@ -775,6 +775,7 @@ int mnk_ls_set_option(mnk_ls* ls, const char* key, double value) {
     if (!strcmp(key, "batch_period")) { ls->batch_period = (int)value; return 0; }
     if (!strcmp(key, "dag_trace")) { ls->dag_trace_on = value != 0.0; return 0; }  // diagnostics: tools/dag_timeline.py
     if (!strcmp(key, "dag_max_rows")) { ls->dag_max_rows = (int64_t)value; return 0; }
+    if (!strcmp(key, "dag_deep_rows")) { ls->dag_deep_rows = (int64_t)value; ls->dag_tasks.release(); return 0; }   // largest order with every row in the chain's band
     // BUNCHKAUFMAN only: 1 (default) = refactor with the pivoted Bunch-Kaufman tier when the static-pivot
     // factorization breaks down; 0 = report the breakdown as num_zero and let the IPM regularize
     if (!strcmp(key, "bk_fallback")) { ls->bk_fallback = (int)value; return 0; }
