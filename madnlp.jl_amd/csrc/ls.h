@@ -105,9 +105,9 @@ struct mnk_ls {
     long dag_spin_limit = 0;  // option: polls (~0.17 us each) a device-side wait of the schedule may take before it gives up
                               // (info = -7); 0 = by the order of the matrix (mnk_ls_dag_spin_limit)
     int dag_chunk = 64;           // tile columns (of 128) per bulk task behind the doubling taper 1, 2, 4, ... (every task ends with a read-modify-write of its tile; C3 at the end of round 3: 12 -> 9.58 ms, 48 / 64 / 88 / 128 / 1024 -> 9.30; N = 16 384: 26.3 -> 25.9 ms, N = 24 576: 82.0 / 82.5 ms; in the middle of the round, with slower closing tasks, 10-16 was the optimum)
-    int64_t dag_min_rows = 1536;  // smaller systems keep the launch-per-panel schedules (measured break-even: N ~ 1500)
+    int64_t dag_min_rows = 1280;  // smaller systems keep the launch-per-panel schedules (round 6, LDL: N = 1024 0.441 (schedule 4) / 0.452 ms (this one), N = 1280 0.573 / 0.551; rounds 3-5: 1536)
     int64_t dag_deep_rows = 5376; // systems up to this order put every row into the chain's band (and at most 64 x MNK_DAG_CUS2 rows); larger ones: band + bulk kernel
-    int64_t dag_max_rows = 24576; // larger ones too: their trailing updates already run at the update kernel's rate (measured: 22384 +1 %, 30000 -2 %)
+    int64_t dag_max_rows = 30720; // larger ones too: their trailing updates already run at the update kernel's rate (round 6, LDL, schedule 4 / this one: N = 24 576 87.4 / 81.7 ms, 28 672 133.6 / 128.6, 32 768 188.2 / 190.2; rounds 3-5: 24 576)
     int panel_algo = 5;  // 5: task-DAG schedule (dag.hip: persistent pivot chain + persistent left-looking bulk kernel); 4: persistent panel kernel per 256 columns + one trailing update per outer panel (also what 5 uses outside [dag_min_rows, dag_max_rows]); 1: one launch per piece, the fallback of 4 and 5
     int persistent_solve = 1;  // both sweeps of a solve in one launch (solve.hip); 0: one launch per step
     int solve512 = 0;          // 1: the one-launch solve steps over 512 columns (32-row blocks, 512x512 explicit inverses) from solve512_min_rows on.  C3: solve! 0.46 -> 0.33 ms, but the extra inverses cost factorize! +0.37 ms (they finish 0.3 ms after the chain): worth it from ~4 solves per factorization

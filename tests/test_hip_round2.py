@@ -356,7 +356,7 @@ def test_ipm_lootsma_hip_reproduces_reference_answers(ctx, kind):
 
 
 # --------------------------------------------------------------------------- persistent panel kernel: safety net
-@pytest.mark.parametrize("N,expect", [(1200, 4.0), (2300, 5.0)])
+@pytest.mark.parametrize("N,expect", [(1000, 4.0), (2300, 5.0)])
 def test_persistent_schedules_stay_in_use_next_to_other_contexts(ctx, N, expect):
     """panel_algo = 4 / 5 keep waiting workgroups resident, which is only safe while no other persistent kernel runs on
     the same CUs.  Round 3 gave the persistent schedules up as soon as a second context was alive (one launch per piece,

@@ -52,9 +52,9 @@ def _dev_matrix(N, alg, dev):
 
 
 @pytest.mark.parametrize("alg", [mj.CHOLESKY, mj.LDL])
-@pytest.mark.parametrize("N", [1600, 6100, 6200, 7777, 9000, 12345, 16384, 24576])
+@pytest.mark.parametrize("N", [1280, 1600, 5376, 5400, 6100, 6200, 7777, 9000, 12345, 16384, 24576, 30720])
 def test_default_schedule_across_its_range(ctx, N, alg):
-    """panel_algo = 5 serves 1536 <= N <= 24 576: all rows in the chain's band up to 6144 rows, band + bulk + tile-closing
+    """panel_algo = 5 serves 1280 <= N <= 30 720 (round 6; 1536 ... 24 576 before): all rows in the chain's band up to 5376 rows, band + bulk + tile-closing
     tasks above.  A drop-in solver receives arbitrary N; round 3 tested the large-system mode at N = 11 192 only.  Per
     order and algorithm: the schedule that ran is 5 with no fall-back; inertia = the constructed one (and LAPACK's --
     dpotrf / dsytrf through the oracle's LapackCPUSolver -- up to N = 9000, where the host factorization takes seconds);
