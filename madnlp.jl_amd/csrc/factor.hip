@@ -212,8 +212,17 @@ constexpr long PP_SPIN_LIMIT = 1L << 20;  // ~0.5 s
 #ifndef MNK_DIAG_NO_EARLY
 #define MNK_DIAG_NO_EARLY 0   // (-DMNK_DIAG_NO_EARLY=1: a diagnostic build without the chain's early diagonal update)
 #endif
-constexpr int PP_LDS_BYTES = 3 * 4096 * 8;  // two staging tiles (the first doubles as the exchange buffer) + own tile
-constexpr int PC_LDS_BYTES = 4 * 4096 * 8;  // pivot-chain kernels: + the strip's NEXT diagonal block (see pp_strip, EARLY)
+#ifndef MNK_TILE_DMA
+#define MNK_TILE_DMA 1   // (0: the staging tiles of the chain strips go through registers, rounds 2-5)
+#endif
+// A staging tile that arrives by LDS-DMA lies k-column-major: request g' = 2 g + odd of 32 (one global_load_lds_dwordx4 = 64 lanes x 16
+// bytes = rows 0..63 of the k-columns 4 g + odd and 4 g + odd + 2) at byte 2176 g + 1152 odd -- the two k-columns a ds_read_b64 lane group
+// (lanes 0-31: l4 = 0, 1; lanes 32-63: l4 = 2, 3) reads are 1152 = 128 (mod 256) bytes apart: different bank halves.
+constexpr int KT_G = 2176, KT_ODD = 1152, KT_BYTES = 16 * KT_G;
+constexpr int KT_NULL = 2 * KT_BYTES;   // 1 KB per wave behind the staging tiles: where a step that has no next tile sends its requests (no branch in the loop)
+constexpr int PP_STAGE_BYTES = MNK_TILE_DMA ? 2 * KT_BYTES + 4096 : 2 * 4096 * 8;
+constexpr int PP_LDS_BYTES = PP_STAGE_BYTES + 4096 * 8;  // two staging tiles (the first doubles as the exchange buffer) + own tile
+constexpr int PC_LDS_BYTES = PP_STAGE_BYTES + 2 * 4096 * 8;  // pivot-chain kernels: + the strip's NEXT diagonal block (see pp_strip, EARLY)
 
 // acc[cb2] += sum over ib, s of tile[(4 cb2 + ib) * 64 + lane][s] * B[ib][s] for the 16x16 blocks cb2 < ncb2 (wave-uniform) of one 64x64 tile
 // in LDS (the chain strips' tile step: 64 products per wave).  The callers negate the B operand once per block column instead of
@@ -242,6 +251,41 @@ __device__ __forceinline__ void tile_mac(const v4d* __restrict__ tile, const int
 __device__ __forceinline__ void tile_mac(const v4d* __restrict__ tile, const int lane, const bool own_block, const int w, const v4d* __restrict__ B, v4d* __restrict__ acc) {
     if (own_block) tile_mac<false>(tile, lane, w + 1, B, acc);
     else tile_mac<true>(tile, lane, 4, B, acc);
+}
+// The same sum (same products, same order, same bits) over a staging tile in the LDS-DMA layout; `next(q)`, q = 0..7, issues this wave's
+// q-th request of the NEXT tile -- one per two blocks of four products, so that the texture addresser works under the matrix pipe and the
+// requests cost the step nothing (tools/hip/tilestep_lab.hip, profiles/r06_tilestep_lab.txt: 2.42 -> 1.96 us per tile step, the loop's
+// floor without any global load being 1.95; all eight requests in front of the products: 2.22).
+template <bool FULL, class Next>
+__device__ __forceinline__ void tile_mac_k(const char* __restrict__ tile, const int l15, const int l4, const int ncb2, const v4d* __restrict__ B,
+                                           v4d* __restrict__ acc, Next&& next) {
+    const char* tb = tile + 8 * l15 + KT_ODD * (l4 & 1) + 512 * (l4 >> 1);
+    double a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = *reinterpret_cast<const double*>(tb + KT_G * s);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // (the first block's reads; from here on: the next block's reads, this block's products)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int cb2 = q >> 2, ib = q & 3;
+        if (!FULL && ib == 0 && cb2 >= ncb2) break;
+        double an[4] = {a[0], a[1], a[2], a[3]};
+        if (q < 15) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) an[s] = *reinterpret_cast<const double*>(tb + KT_G * (4 * ((q + 1) & 3) + s) + 128 * ((q + 1) >> 2));
+        }
+        if ((q & 1) == 0) next(q >> 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], B[ib][s], acc[cb2], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the next block's four LDS reads ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then this block's four products
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a[s] = an[s];
+    }
+    if (!FULL) {
+#pragma unroll
+        for (int q2 = 0; q2 < 8; ++q2)
+            if (q2 >= 2 * ncb2) next(q2);
+    }
 }
 __device__ __forceinline__ void pin(v4d& x) {   // (the value as it is, in registers: a negation is not to be re-done at every use)
     asm volatile("" : "+v"(x));
@@ -304,8 +348,8 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
                                          int dbg_missing, const double* __restrict__ Vp, int64_t ldv, int Kp, PpDag dag,
                                          char* pp_smem, int* s_go, int* xn_have = nullptr) {
     v4d* stage = reinterpret_cast<v4d*>(pp_smem);          // [2][1024] v4d
-    v4d* own = reinterpret_cast<v4d*>(pp_smem) + 2 * 1024;  // [1024] v4d
-    v4d* xn = reinterpret_cast<v4d*>(pp_smem) + 3 * 1024;   // [1024] v4d (EARLY only: PC_LDS_BYTES)
+    v4d* own = reinterpret_cast<v4d*>(pp_smem + PP_STAGE_BYTES);  // [1024] v4d
+    v4d* xn = own + 1024;   // [1024] v4d (EARLY only: PC_LDS_BYTES)
     const int tid = threadIdx.x;
     const int64_t R = p0 + 64 * (int64_t)t;
     // this strip's own diagonal block was brought up to date by the previous strip-column's steps
@@ -411,6 +455,68 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
     const int ncb_pro = use_xn ? t : jmax + 1;   // (use_xn: the strip's own diagonal block -- column block t -- needs no prologue)
     if (Kp > 0 && ncb_pro > 0) {
         const int nch = Kp >> 6, ncb = ncb_pro;
+#if MNK_TILE_DMA
+        v4d Bv[4], Bn[4];
+        // this wave's eight requests of a tile: k-columns 16 w + 4 (q >> 1) + (q & 1) + 2 (lane >> 5), rows 2 (lane & 31), + 1
+        const double* dsrc = F + (p0 + 2 * (lane & 31)) + (p0 - Kp + 16 * w + 2 * (lane >> 5)) * ld;
+        char* const dbase = pp_smem + 4 * KT_G * w;
+        char* const dnull = pp_smem + KT_NULL + 1024 * w;
+        auto tile_dma = [&](int kc, int c, int buf, int q, bool real = true) {
+            char* dst = dbase + buf * KT_BYTES + KT_G * (q >> 1) + KT_ODD * (q & 1);
+            if (!real) dst = dnull;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + 64 * c + (64 * (int64_t)kc + 4 * (q >> 1) + (q & 1)) * ld),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        };
+        auto b_load = [&](int kc, v4d (&B)[4]) {
+            const double* src = Vp + (r0 + l15) + (64 * (int64_t)kc + l4) * ldv;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) B[ib][s] = src[(16 * ib + 4 * s) * ldv];
+        };
+        int it = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tile_dma(0, 0, 0, q);
+        b_load(0, Bn);
+        for (int kc = 0; kc < nch; ++kc) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) { Bv[ib] = -Bn[ib]; pin(Bv[ib]); }   // (T -= V L^T: the sign goes into the operand that is copied anyway)
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (c >= ncb) break;
+                const int buf = it & 1;
+                ++it;
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k0 = MNK_PCLK();
+#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the tile is in LDS ...
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k1 = MNK_PCLK();
+#endif
+                __syncthreads();                                    // ... and everybody's; the other buffer is free
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k2c = MNK_PCLK();
+#endif
+                // the next k-chunk's V behind the barrier: a step away from the wait above, and from the one that takes it
+                if (c == 0 && kc + 1 < nch) b_load(kc + 1, Bn);
+                int c2 = c + 1, k2 = kc;
+                if (c2 >= ncb) { c2 = 0; k2 = kc + 1; }
+                const bool more = k2 < nch;
+                if (!more) { k2 = kc; c2 = c; }   // (the last step asks for its own tile again, into the null region)
+                auto next = [&](int q) { tile_dma(k2, c2, buf ^ 1, q, more); };
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k3 = MNK_PCLK();
+#endif
+                if (c == t) tile_mac_k<false>(pp_smem + buf * KT_BYTES, l15, l4, w + 1, Bv, &X[4 * c], next);
+                else tile_mac_k<true>(pp_smem + buf * KT_BYTES, l15, l4, 4, Bv, &X[4 * c], next);
+#if MNK_DIAG_STEP_TRACE
+                const unsigned long long k4 = MNK_PCLK();
+                pr_n += 1; pr_vm += k1 - k0; pr_bar += k2c - k1; pr_ld += k3 - k2c; pr_mac += k4 - k3;
+#endif
+            }
+        }
+        __syncthreads();
+#else
         v4d pre[4], Bv[4], Bn[4];
         auto tile_load = [&](int kc, int c) {
             const double* src = F + (p0 + 64 * (int64_t)c + lane) + (p0 - Kp + 64 * (int64_t)kc + w) * ld;
@@ -467,6 +573,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             }
         }
         __syncthreads();
+#endif
     }
     if (EARLY && use_xn) {
 #pragma unroll
@@ -669,6 +776,44 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
         }
         MNK_TR2(4 * j + 2);
         // ---- T[t, c] -= V[t, j] L[c, j]^T for the later column blocks (software-pipelined through LDS)
+#if MNK_TILE_DMA
+        // (the tile of column block c -- rows of the diagonal strip c, k-columns of block j -- goes straight into the staging tile c & 1: the
+        // first one at once, the following ones under the products of the one before)
+        const double* dsrc = F + (p0 + 2 * (lane & 31)) + (p0 + 64 * j + 16 * w + 2 * (lane >> 5)) * ld;
+        char* const dbase = pp_smem + 4 * KT_G * w;
+        char* const dnull = pp_smem + KT_NULL + 1024 * w;
+        auto tile_dma = [&](int c, int q, bool real = true) {
+            char* dst = dbase + (c & 1) * KT_BYTES + KT_G * (q >> 1) + KT_ODD * (q & 1);
+            if (!real) dst = dnull;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + 64 * c + (4 * (q >> 1) + (q & 1)) * ld),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        };
+        auto await = [&](int c) {
+            pp_wait<NB, LDL>(prog, c, nb, epoch16 + j + 1, seen, info, pp_limit, dag.dbg != nullptr ? dag.dbg + 8 * t : nullptr, (int)(p0 >> 8), t);
+        };
+        if (j + 1 <= jmax && j + 1 != t) {
+            await(j + 1 < NB ? j + 1 : 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tile_dma(j + 1 < NB ? j + 1 : 0, q);
+        }
+        // the block column's V (stored above, final) is the B operand of every product below: its sign is flipped once, in place
+        // (X[4 j ..] is not read again as what it was: later steps and strip-columns take the stored values)
+        v4d* const Bj = &X[4 * j];
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) { Bj[ib] = -Bj[ib]; pin(Bj[ib]); }
+#pragma unroll
+        for (int c = j + 1; c < NB; ++c) {
+            if (c > jmax) break;
+            if (c != t) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool more = c + 1 < NB && c + 1 <= jmax && c + 1 != t;
+            if (more) await(c + 1 < NB ? c + 1 : 0);
+            // (no next tile: the same one again, into the null region -- no branch in the loop)
+            auto next = [&](int q) { tile_dma(more ? (c + 1 < NB ? c + 1 : 0) : c, q, more); };
+            if (c == t) tile_mac<false>(own, lane, w + 1, Bj, &X[4 * c]);   // (the block behind a strip's own one is past jmax: no next tile)
+            else tile_mac_k<true>(pp_smem + (c & 1) * KT_BYTES, l15, l4, 4, Bj, &X[4 * c], next);
+        }
+#else
         v4d pre[4];
         auto prefetch = [&](int c) {
             pp_wait<NB, LDL>(prog, c, nb, epoch16 + j + 1, seen, info, pp_limit, dag.dbg != nullptr ? dag.dbg + 8 * t : nullptr, (int)(p0 >> 8), t);
@@ -696,6 +841,7 @@ __device__ __forceinline__ void pp_strip(const int t, double* __restrict__ F, in
             if (c + 1 < NB && c + 1 <= jmax && c + 1 != t) prefetch(c + 1 < NB ? c + 1 : 0);
             tile_mac(tile, lane, c == t, w, Bj, &X[4 * c]);
         }
+#endif
         if (EARLY && make_xn) {
             // ---- the same product for the strip's diagonal block of the NEXT strip-column (its k-chunk j)
             __syncthreads();   // `own` is complete

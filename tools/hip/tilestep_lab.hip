@@ -20,6 +20,11 @@ __global__ void writer(double* F, int64_t n, double v) {   // the producer: writ
 // VAR 2: no global loads at all (tiles constant in LDS): the loop's own floor
 // VAR 3: eight 16-byte loads per lane (two consecutive rows of one column) instead of sixteen 8-byte loads, two 8-byte LDS writes each
 // VAR 4: the sixteen loads of the next tile issued ONE PER BLOCK of four products (the texture addresser works under the matrix pipe)
+// VAR 5: the next tile goes from global memory straight into LDS (global_load_lds_dwordx4: 8 wave instructions per wave and step, one =
+//        two k-columns x 64 rows = 1 KB, no registers, no LDS writes); the tile lies k-column-major in LDS, column pairs (4g, 4g + 2) and
+//        (4g + 1, 4g + 3) 1152 bytes apart so that the two k-columns a ds_read_b64 lane group reads sit on different bank halves;
+//        same products in the same order as VAR 0
+// VAR 6: as VAR 5, the eight requests of the next tile spread over the step (one per two blocks of four products)
 template <int VAR>
 __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const double* __restrict__ Vp, int64_t ld, int64_t ldv, int64_t p0,
                                             int t, double* out, unsigned long long* cyc, int reps) {
@@ -68,20 +73,57 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
 #pragma unroll
                 for (int s = 0; s < 4; ++s) B[ib][s] = src[(16 * ib + 4 * s) * ldv];
         };
+        auto tile_dma = [&](int kc, int c, char* tile, int q0, int q1) {   // (VAR 5 / 6) requests q0 .. q1 - 1 of this wave's eight
+            const int half = lane >> 5, r = 2 * (lane & 31);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (q < q0 || q >= q1) continue;
+                const int j = 8 * w + q, g = j >> 1, odd = j & 1;
+                const double* src = F + (p0 + 64 * (int64_t)c + r) + (p0 - Kp + 64 * (int64_t)kc + 4 * g + odd + 2 * half) * ld;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(tile + 2176 * g + 1152 * odd), 16, 0, 0);
+            }
+        };
         auto nxt = [&](int& kc, int& c) { if (++c >= ncb) { c = 0; ++kc; } };
         int it = 0;
         if (VAR == 3) tile_load4(0, 0);
+        else if (VAR >= 5) { }
         else if (VAR != 2) tile_load(0, 0, pre);   // (VAR 4: the first tile as usual)
         int k2 = 0, c2 = 0;
         nxt(k2, c2);
         if (VAR == 1) tile_load(k2, c2, pre2);
         b_load(0, Bn);
+        if (VAR >= 5) tile_dma(0, 0, smem, 0, 8);
         for (int kc = 0; kc < nch; ++kc) {
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) Bv[ib] = Bn[ib];
+            for (int ib = 0; ib < 4; ++ib) Bv[ib] = VAR >= 5 ? -Bn[ib] : Bn[ib];
             if (kc + 1 < nch) b_load(kc + 1, Bn);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                if (VAR >= 5) {
+                    char* tile5 = smem + (it & 1) * 34816;
+                    char* next5 = smem + ((it + 1) & 1) * 34816;
+                    ++it;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    int c3 = c + 1, k3 = kc;
+                    if (c3 >= ncb) { c3 = 0; k3 = kc + 1; }
+                    const bool more = k3 < nch;
+                    if (VAR == 5 && more) tile_dma(k3, c3, next5, 0, 8);
+                    const char* tb = tile5 + 8 * l15 + 1152 * (l4 & 1) + 512 * (l4 >> 1);
+#pragma unroll
+                    for (int qq = 0; qq < 16; ++qq) {
+                        const int cb2 = qq >> 2, ib = qq & 3;
+                        if (VAR == 6 && more && (qq & 1) == 0) tile_dma(k3, c3, next5, qq >> 1, (qq >> 1) + 1);
+                        double a[4];
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) a[s2] = *reinterpret_cast<const double*>(tb + 2176 * (4 * ib + s2) + 128 * cb2);
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            X[4 * c + cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], Bv[ib][s2], X[4 * c + cb2], 0, 0, 0);
+                    }
+                    continue;
+                }
                 v4d* tile = stage + (it & 1) * 1024;
                 if (VAR == 3) tile_store4(tile);
                 else if (VAR != 2) {
@@ -146,16 +188,21 @@ __global__ __launch_bounds__(256) void pro(const double* __restrict__ F, const d
 
 template <int VAR>
 static void run(const char* name, double* F, double* V, int64_t ld, double* out, unsigned long long* cyc, bool cold) {
-    hipFuncSetAttribute((const void*)pro<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)pro<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 34816);
     unsigned long long best = ~0ull;
     for (int i = 0; i < 8; ++i) {
         if (cold) { hipLaunchKernelGGL(writer, dim3(512), dim3(256), 0, 0, F, ld * 2048, 0.25 + i); hipLaunchKernelGGL(writer, dim3(512), dim3(256), 0, 0, V, ld * 2048, 0.5 + i); }
-        hipLaunchKernelGGL((pro<VAR>), dim3(1), dim3(256), 65536, 0, F, V, ld, ld, (int64_t)1024, 5, out, cyc, cold ? 1 : 20);
+        hipLaunchKernelGGL((pro<VAR>), dim3(1), dim3(256), 2 * 34816, 0, F, V, ld, ld, (int64_t)1024, 5, out, cyc, cold ? 1 : 20);
         hipDeviceSynchronize();
         unsigned long long h = 0;
         hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         if (h < best) best = h;
     }
+    std::vector<double> ho(256);
+    hipMemcpy(ho.data(), out, 256 * 8, hipMemcpyDeviceToHost);
+    double cs = 0;
+    for (int i = 0; i < 256; ++i) cs += ho[i] * (1.0 + 0.001 * i);
+    printf("[checksum %.17g] ", cs);
     printf("%-66s %s: %7llu cycles = %5.2f us per tile step (16 steps)  %s\n", name, cold ? "operands just written by other CUs" : "operands warm in this CU's L2      ", best,
            best / 2400.0 / 16.0, hipGetErrorString(hipGetLastError()));
 }
@@ -170,6 +217,8 @@ int main() {
         run<1>("two register sets: the tile two steps ahead", F, V, ld, out, cyc, cold);
         run<3>("eight 16-byte loads (row pairs) + 8-byte LDS writes", F, V, ld, out, cyc, cold);
         run<4>("one load of the next tile per block of four products", F, V, ld, out, cyc, cold);
+        run<5>("next tile straight into LDS (global_load_lds_dwordx4), all 8 first", F, V, ld, out, cyc, cold);
+        run<6>("next tile straight into LDS, one request per two product blocks", F, V, ld, out, cyc, cold);
     }
     return 0;
 }
