@@ -334,18 +334,26 @@ __global__ __launch_bounds__(256) void bwd_panel_kernel(const double* __restrict
 // ================================================================================================
 constexpr int PS_MAXOWN = 12;            // owned blocks per workgroup: Np <= 12 * 64 * G
 constexpr int PS_NEAR = 3;               // blocks within this many steps of the front poll eagerly
+#ifndef PS_DAHEAD
+#define PS_DAHEAD 3                      // steps between the request of a block's inverse slice and its diagonal role (1: rounds 2-5)
+#endif
 
 __device__ __forceinline__ void ps_publish(double* p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Workgroup barrier for LDS traffic only.  __syncthreads() also waits for every global load the wave has in flight (its fence names no
+// address space): in the persistent solve that is the slice of L requested on purpose a step before it is needed.
+__device__ __forceinline__ void ps_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // threads t < n poll src[t] into dst[t]; returns false (uniformly) if the solve was aborted.
+// (`s_bad`: a word in LDS, zero while the solve is alive -- the barrier is then ps_barrier, not __syncthreads)
 // `relaxed`: the caller is several steps away from the critical path -- nap between polls, so that the
 // ~170 workgroups that merely follow the front do not hammer the 16 cache lines the front is
 // publishing into (their polls queue in front of the critical stores and loads on the same channel).
 __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst, int* abort_flag, long spin_limit,
-                                          bool relaxed = false, int nap = 6) {
+                                          bool relaxed = false, int nap = 6, int* s_bad = nullptr) {
     const int t = threadIdx.x;
     int bad = 0;
     if (t < n) {
@@ -369,6 +377,11 @@ __device__ __forceinline__ bool ps_gather(const double* src, int n, double* dst,
             u = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         dst[t] = __longlong_as_double((long long)u);
+    }
+    if (s_bad != nullptr) {
+        if (bad) *s_bad = 1;
+        ps_barrier();
+        return *s_bad == 0;
     }
     return __syncthreads_or(bad) == 0;
 }
@@ -405,6 +418,7 @@ __device__ __forceinline__ void persistent_solve_body(
     __shared__ double ysol[PS_MAXOWN][64];  // forward solution of the owned blocks
     __shared__ double xs[256];              // the step's published vector
     __shared__ double part[PS_NQ][64];      // partial sums
+    __shared__ int s_bad;                   // set by a thread whose wait was given up (ps_gather)
     const int t = threadIdx.x, r = t & 63, q = t >> 6;
     const int nb = (int)(Np / 64);
     const int nsteps = (nb + 3) / 4;
@@ -428,6 +442,7 @@ __device__ __forceinline__ void persistent_solve_body(
         const int64_t row = (int64_t)(g + (e >> 6) * G) * 64 + (e & 63);
         run[e >> 6][e & 63] = row < N ? xin[row] : 0.0;   // (the caller's vector itself: no padded staging copy)
     }
+    if (t == 0) s_bad = 0;
     __syncthreads();
 
     double a[PS_CW];  // slice of L the next update multiplies
@@ -457,26 +472,32 @@ __device__ __forceinline__ void persistent_solve_body(
 
     // ------------------------------------------------------------------ forward: L y = b
     int m0 = 0;           // first owned block whose forward solution is not yet known
-    bool have_d = false;  // d holds the slice for block own[m0] and its bfin is already published
+    bool have_d = false;  // d holds the inverse's slice for block own[m0]
+    bool pub_b = false;   // ... and its final right-hand side is already published
+    // The slice of the inverse a block multiplies in its diagonal role is requested PS_DAHEAD steps before that step, not in the step
+    // right before it: a workgroup's requests go through ONE texture addresser at ~14 cycles per wave instruction, so the 128 KB of L for
+    // the last update (256 wave instructions) plus up to 128 KB of the inverse took 2.5 (first block of a step) to 4.4 us (fourth) to
+    // arrive -- longer than the step's y took to get there: the gather's barrier waited for the slices, not for the hop (round 6,
+    // tools/solve_trace.py on a build with -DMNK_DIAG_SOLVE_PREFETCH).  Same arithmetic, same bits.
     for (int k = 0; k < nsteps && m0 < nown; ++k) {
         const int b0 = 4 * k, nbk = nb - b0 < 4 ? nb - b0 : 4;
         int i = g + m0 * G;
         if (i < b0 + nbk) {
             // diagonal role: y_i = sum_{c <= li} inv(L_kk)[li, c] * bfin[b0 + c]
             const int li = i - b0;
-            if (!have_d) {  // first step, or a block that was never "next" (tiny systems)
+            if (!have_d) {  // first steps, or a block that was never near (tiny systems)
                 const double* Mk = Inv + (int64_t)k * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
                 if (qb <= li) {
 #pragma unroll
                     for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
                 }
-                if (t < 64) ps_publish(bfin + (int64_t)i * 64 + t, run[m0][t]);
             }
+            if (!pub_b && t < 64) ps_publish(bfin + (int64_t)i * 64 + t, run[m0][t]);
             if (t < 64) xs[li * 64 + t] = run[m0][t];
-            if (!ps_gather(bfin + (int64_t)b0 * 64, li * 64, xs, abort_flag, spin_limit)) return;
+            if (!ps_gather(bfin + (int64_t)b0 * 64, li * 64, xs, abort_flag, spin_limit, false, 6, &s_bad)) return;
             PS_STAMP(i, 3);
             dot_chunk(d, qb <= li);
-            __syncthreads();
+            ps_barrier();
             if (t < 64) {
                 const double v = reduce_parts(t);
                 ps_publish(ypub + (int64_t)i * 64 + t, v);
@@ -485,13 +506,14 @@ __device__ __forceinline__ void persistent_solve_body(
             PS_STAMP(i, 4);
             // (no trailing barrier: the next touch of xs / part comes behind the barrier of the next gather)
             have_d = false;
+            pub_b = false;
             ++m0;
             if (m0 >= nown) break;
             i = g + m0 * G;
         }
         // update role: run_i -= L[i, step k] * y_k for the owned blocks below the step.  Everything the
-        // critical block needs next is requested before the wait: its slice of L for this step and, if
-        // it sits in the next diagonal step, its slice of that step's inverse.
+        // critical block needs next is requested before the wait: its slice of L for this step and, PS_DAHEAD steps ahead
+        // of its diagonal step, its slice of that step's inverse.
         const bool diag_next = i < b0 + nbk + 4;
         {
             const double* Fs = F + ((int64_t)i * 64 + r) + ((int64_t)b0 * 64 + q * PS_CW) * ld;
@@ -499,17 +521,18 @@ __device__ __forceinline__ void persistent_solve_body(
 #pragma unroll
                 for (int j = 0; j < PS_CW; ++j) a[j] = Fs[(int64_t)j * ld];
             }
-            if (diag_next) {
-                const int li = i - (b0 + nbk);
-                const double* Mk = Inv + (int64_t)(k + 1) * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
+            if (!have_d && i < b0 + nbk + 4 * PS_DAHEAD) {   // (block i sits in a later, hence full, step i >> 2)
+                const int li = i & 3;
+                const double* Mk = Inv + (int64_t)(i >> 2) * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
                 if (qb <= li) {
 #pragma unroll
                     for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
                 }
+                have_d = true;
             }
         }
         if (diag_next) PS_STAMP(i, 0);
-        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, spin_limit, i >= b0 + nbk + 4 * near_steps, nap)) return;
+        if (!ps_gather(ypub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, spin_limit, i >= b0 + nbk + 4 * near_steps, nap, &s_bad)) return;
         if (diag_next) PS_STAMP(i, 1);
         for (int m = m0; m < nown; ++m) {
             const int im = g + m * G;
@@ -519,17 +542,17 @@ __device__ __forceinline__ void persistent_solve_body(
                 for (int j = 0; j < PS_CW; ++j) a[j] = Fs[(int64_t)j * ld];
             }
             dot_chunk(a, qb < nbk);
-            __syncthreads();
+            ps_barrier();
             if (t < 64) {
                 const double v = run[m][t] - reduce_parts(t);
                 run[m][t] = v;
                 if (m == m0 && diag_next) ps_publish(bfin + (int64_t)im * 64 + t, v);  // final: hand it on at once
             }
             if (m == m0 && diag_next) PS_STAMP(im, 2);
-            if (m + 1 < nown) __syncthreads();  // part is rewritten by the next owned block; after the last one the
+            if (m + 1 < nown) ps_barrier();  // part is rewritten by the next owned block; after the last one the
                                                 // next gather's barrier does it
         }
-        have_d = diag_next;
+        pub_b = diag_next;
     }
 
     // ------------------------------------------------------------------ backward: L^T x = D^-1 y
@@ -545,6 +568,7 @@ __device__ __forceinline__ void persistent_solve_body(
     const int lane = t & 63, sub = lane & 15, colq = lane >> 4, rc = q & 3, cg = q >> 2;
     int m1 = nown - 1;  // last owned block whose solution is not yet known
     have_d = false;
+    pub_b = false;
     for (int k = nsteps - 1; k >= 0 && m1 >= 0; --k) {
         const int b0 = 4 * k, nbk = nb - b0 < 4 ? nb - b0 : 4;
         int i = g + m1 * G;
@@ -558,50 +582,52 @@ __device__ __forceinline__ void persistent_solve_body(
 #pragma unroll
                     for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
                 }
-                if (t < 64) ps_publish(zfin + (int64_t)i * 64 + t, run[m1][t]);
             }
+            if (!pub_b && t < 64) ps_publish(zfin + (int64_t)i * 64 + t, run[m1][t]);
             if (t < 64) xs[li * 64 + t] = run[m1][t];
             // blocks li+1 .. nbk-1 of the step come from their owners
-            if (!ps_gather(zfin + (int64_t)(i + 1) * 64, (nbk - 1 - li) * 64, xs + (li + 1) * 64, abort_flag, spin_limit)) return;
+            if (!ps_gather(zfin + (int64_t)(i + 1) * 64, (nbk - 1 - li) * 64, xs + (li + 1) * 64, abort_flag, spin_limit, false, 6, &s_bad)) return;
             dot_chunk(d, act);
-            __syncthreads();
+            ps_barrier();
             if (t < 64) {
                 const double v = reduce_parts(t);
                 ps_publish(xpub + (int64_t)i * 64 + t, v);
                 if ((int64_t)i * 64 + t < N) xout[(int64_t)i * 64 + t] = v;
             }
             have_d = false;
+            pub_b = false;
             --m1;
             if (m1 < 0) break;
             i = g + m1 * G;
         }
         // update role: run_i -= L[step k rows, block i columns]^T * x_k for the owned blocks before the step
-        auto load_slice = [&](int im) {
-            const double* Fs = F + ((int64_t)b0 * 64 + 64 * rc + 4 * sub) + ((int64_t)im * 64 + cg * 16 + colq) * ld;
+        auto load_slice = [&](int im, double (&dst)[PS_CW], int bs) {
+            const double* Fs = F + ((int64_t)bs * 64 + 64 * rc + 4 * sub) + ((int64_t)im * 64 + cg * 16 + colq) * ld;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const v2d lo = *reinterpret_cast<const v2d*>(Fs + (int64_t)(4 * p) * ld);
                 const v2d hi = *reinterpret_cast<const v2d*>(Fs + (int64_t)(4 * p) * ld + 2);
-                a[4 * p] = lo[0];
-                a[4 * p + 1] = lo[1];
-                a[4 * p + 2] = hi[0];
-                a[4 * p + 3] = hi[1];
+                dst[4 * p] = lo[0];
+                dst[4 * p + 1] = lo[1];
+                dst[4 * p + 2] = hi[0];
+                dst[4 * p + 3] = hi[1];
             }
         };
         const bool diag_next = i >= b0 - 4;  // the critical block sits in the step right before this one
-        if (rc < nbk) load_slice(i);
-        if (diag_next) {
-            const int li = i - (b0 - 4);
-            const double* Mk = InvT + (int64_t)(k - 1) * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
-            if (qb >= li) {  // step k-1 is a full step (4 blocks)
+        if (rc < nbk) load_slice(i, a, b0);
+        if (!have_d && i >= b0 - 4 * PS_DAHEAD) {   // (block i sits in an earlier step i >> 2: a full one)
+            const int li = i & 3;
+            const double* Mk = InvT + (int64_t)(i >> 2) * (SB * SB) + (li * 64 + r) + (int64_t)(q * PS_CW) * SB;
+            if (qb >= li) {
 #pragma unroll
                 for (int j = 0; j < PS_CW; ++j) d[j] = Mk[(int64_t)j * SB];
             }
+            have_d = true;
         }
-        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, spin_limit, i < b0 - 4 * near_steps, nap)) return;
+        if (!ps_gather(xpub + (int64_t)b0 * 64, nbk * 64, xs, abort_flag, spin_limit, i < b0 - 4 * near_steps, nap, &s_bad)) return;
         for (int m = m1; m >= 0; --m) {
             const int im = g + m * G;
-            if (m < m1 && rc < nbk) load_slice(im);
+            if (m < m1 && rc < nbk) load_slice(im, a, b0);
             // part[rc * 4 + (sub >> 2)][col]: 16 partial sums per column
             if (rc < nbk) {
                 const double x0 = xs[64 * rc + 4 * sub], x1 = xs[64 * rc + 4 * sub + 1],
@@ -618,15 +644,15 @@ __device__ __forceinline__ void persistent_solve_body(
 #pragma unroll
                 for (int u = 0; u < 4; ++u) part[rc * 4 + u][cg * 16 + lane] = 0.0;
             }
-            __syncthreads();
+            ps_barrier();
             if (t < 64) {
                 const double v = run[m][t] - reduce_parts(t);
                 run[m][t] = v;
                 if (m == m1 && diag_next) ps_publish(zfin + (int64_t)im * 64 + t, v);
             }
-            if (m > 0) __syncthreads();
+            if (m > 0) ps_barrier();
         }
-        have_d = diag_next;
+        pub_b = diag_next;
     }
 #undef PS_STAMP
 }

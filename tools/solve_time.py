@@ -27,4 +27,8 @@ with torch.cuda.stream(s):
     e1.record(s); s.synchronize()
     x.copy_(b); ls.solve_linear_system(x); s.synchronize()
     res = (A @ x - b).abs().max().item() / (A.abs().sum(dim=1).max().item() * x.abs().max().item() + b.abs().max().item())
-    print(f"N={N} {alg}: solve {e0.elapsed_time(e1)/reps:.4f} ms  backward error {res:.1e}")
+    sha = ""
+    if os.environ.get("SOLVE_HASH"):
+        import hashlib
+        sha = "  solution sha " + hashlib.sha256(x.cpu().numpy().tobytes()).hexdigest()[:16]
+    print(f"N={N} {alg}: solve {e0.elapsed_time(e1)/reps:.4f} ms  backward error {res:.1e}{sha}")

@@ -33,7 +33,7 @@ with torch.cuda.stream(s):
     print("blk  wait_start  y_seen  bfin_pub  peers_seen  y_pub   (us since block 0 published y)   step period")
     prev = None
     for i in range(0, nb, 1):
-        if i % 4 in (0, 3) and (i < 24 or 80 <= i < 96 or i >= nb - 12):
+        if (i % 4 in (0, 3) and (i < 24 or i >= nb - 12)) or 80 <= i < 100:
             row = (tr[i, :5] - t0) / 100.0
             per = "" if prev is None or i % 4 else f"{row[4]-prev:6.2f}"
             print(f"{i:4d} " + " ".join(f"{v:9.2f}" for v in row) + "   " + per)
