@@ -253,9 +253,12 @@ __device__ __forceinline__ void tile_mac(const v4d* __restrict__ tile, const int
     else tile_mac<true>(tile, lane, 4, B, acc);
 }
 // The same sum (same products, same order, same bits) over a staging tile in the LDS-DMA layout; `next(q)`, q = 0..7, issues this wave's
-// q-th request of the NEXT tile -- one per two blocks of four products, so that the texture addresser works under the matrix pipe and the
-// requests cost the step nothing (tools/hip/tilestep_lab.hip, profiles/r06_tilestep_lab.txt: 2.42 -> 1.96 us per tile step, the loop's
-// floor without any global load being 1.95; all eight requests in front of the products: 2.22).
+// q-th request of the NEXT tile -- spread over the products, so that the texture addresser works under the matrix pipe and the
+// requests cost the step nothing (tools/hip/tilestep_lab.hip, profiles/r06_tilestep_lab.txt, one per two blocks of four products: 2.42 ->
+// 1.96 us per tile step, the loop's floor without any global load being 1.95; all eight requests in front of the products: 2.22).
+// Shipped: one per block over the FIRST HALF of the step -- the last request then has ~1 us of products behind it instead of 0.25, and
+// the wait at the next step's barrier is that much shorter (in the chain: N = 2048 0.778 -> 0.757 ms, 4096 1.532 -> 1.488; two per
+// block over the first quarter: the same).
 template <bool FULL, class Next>
 __device__ __forceinline__ void tile_mac_k(const char* __restrict__ tile, const int l15, const int l4, const int ncb2, const v4d* __restrict__ B,
                                            v4d* __restrict__ acc, Next&& next) {
@@ -273,7 +276,7 @@ __device__ __forceinline__ void tile_mac_k(const char* __restrict__ tile, const 
 #pragma unroll
             for (int s = 0; s < 4; ++s) an[s] = *reinterpret_cast<const double*>(tb + KT_G * (4 * ((q + 1) & 3) + s) + 128 * ((q + 1) >> 2));
         }
-        if ((q & 1) == 0) next(q >> 1);
+        if (q < 8) next(q);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[cb2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], B[ib][s], acc[cb2], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the next block's four LDS reads ...
@@ -284,7 +287,7 @@ __device__ __forceinline__ void tile_mac_k(const char* __restrict__ tile, const 
     if (!FULL) {
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2)
-            if (q2 >= 2 * ncb2) next(q2);
+            if (q2 >= 4 * ncb2) next(q2);
     }
 }
 __device__ __forceinline__ void pin(v4d& x) {   // (the value as it is, in registers: a negation is not to be re-done at every use)
