@@ -25,6 +25,7 @@ o = IPMOptions(tol=1e-6)
 o.relax_equality, o.dual_initialization = True, "zero"
 s = DeviceMadNLPSolver(nlp, factory, o)
 diag_pos = None
+last_probe = (0, 0)
 
 
 def on_trial(solver, n_trial, inertia, correct, accepted):
@@ -40,7 +41,11 @@ def on_trial(solver, n_trial, inertia, correct, accepted):
     d = vals[diag_pos]
     nneg = int((d <= 0).sum())
     ls = solver.kkt.linear_solver
-    print(f"k={solver.cnt.k:2d} trial {n_trial}: del_w={solver.del_w:9.3e} inertia {inertia} {'ok ' if correct else 'REJ'} stop col {int(ls.get_stat('early_reject_col')) if not correct else -1:6d}"
+    global last_probe
+    hm = (int(ls.get_stat("probe_hits")), int(ls.get_stat("probe_misses")))
+    probe = "probe HIT " if hm[0] > last_probe[0] else "probe miss" if hm[1] > last_probe[1] else "          "
+    last_probe = hm
+    print(f"{probe} k={solver.cnt.k:2d} trial {n_trial}: del_w={solver.del_w:9.3e} inertia {inertia} {'ok ' if correct else 'REJ'} stop col {int(ls.get_stat('early_reject_col')) if not correct else -1:6d}"
           f"  min diag {d.min():10.3e}  entries <= 0: {nneg}  first at {int(np.nonzero(d <= 0)[0][0]) if nneg else -1}", flush=True)
 
 

@@ -32,7 +32,7 @@ python tools/bench_small_batch.py > $R/r06_small_batches.txt 2>&1; tail -4 $R/r0
 ./tools/hip/mfma_dep >> $R/r06_valu_latencies.txt 2>&1
 ./tools/hip/tilestep_lab > $R/r06_tilestep_lab.txt 2>&1
 (python tools/chain_steps.py 2048 LDL; MNK_LIBPATH=madnlp.jl_amd/lib/libmadnlp_hip_leaf0.so python tools/chain_steps.py 2048 LDL) 2>&1 | grep -v amdgpu.ids | grep "mean over\|factorize" > $R/r06_chain_handover.txt
-MNK_LIBPATH=madnlp.jl_amd/lib/libmadnlp_hip_steptr.so python tools/chain_steps2.py 2048 LDL 3 2>&1 | grep -v amdgpu.ids > $R/r06_chain_steps.txt
+MNK_LIBPATH=madnlp.jl_amd/lib/libmadnlp_hip_steptr.so python tools/chain_steps2.py 2048 LDL 3 2>&1 | grep -v amdgpu.ids > $R/r06_chain_steps_dma.txt
 bash tools/leaf_ab.sh leaf0 2048 6100 11192 > /dev/null 2>&1; cp gpurun_out/leaf_ab_leaf0.txt $R/r06_leaf_ab.txt
 python tools/spec_pair_time.py 2>&1 | grep -v amdgpu.ids > $R/r06_spec_pair_time.txt
 # the device-resident IPM loop under the kernel trace: back-solve / factorization time per interior-point iteration
