@@ -13,7 +13,31 @@ STRUCTS = ["SchurComplementKKTSystem", "SparseCondensedKKTSystem", "DenseCondens
            "DenseKKTSystem", "SparseMatrixCOO", "SparseCallback", "DenseCallback", "MadNLPSolver", "MadNLPOptions", "LapackCPUSolver",
            "UnreducedKKTVector"]
 
-names, fields = set(), {}
+names, fields, arities = set(), {}, {}
+
+
+def positional_arity(src, open_idx):
+    """Number of positional parameters of the signature whose '(' is at src[open_idx] (top-level commas before ';'); None if unbalanced."""
+    depth, n, seen, i = 0, 0, False, open_idx
+    while i < len(src):
+        c = src[i]
+        if c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+            if depth == 0:
+                return n + (1 if seen else 0)
+        elif depth == 1:
+            if c == ",":
+                n += 1
+                seen = False
+            elif c == ";":
+                return n + (1 if seen else 0)
+            elif not c.isspace():
+                seen = True
+        i += 1
+    return None
+
 for root, _dirs, files in os.walk(os.path.join(REF, "src")):
     for f in files:
         if not f.endswith(".jl"):
@@ -24,6 +48,11 @@ for root, _dirs, files in os.walk(os.path.join(REF, "src")):
         src = "\n".join(lines)
         for m in re.finditer(r"\bfunction\s+(?:[A-Za-z_][A-Za-z_0-9]*\.)*([A-Za-z_][A-Za-z_0-9!]*)\s*[\({]", src):
             names.add(m.group(1))
+        # positional arities of the methods (long and short form)
+        for m in re.finditer(r"(?:\bfunction\s+|^\s*(?:@inline\s+)?)(?:[A-Za-z_][A-Za-z_0-9]*\.)*([A-Za-z_][A-Za-z_0-9!]*)(?:\{[^}\n]*\})?\(", src, flags=re.M):
+            a = positional_arity(src, m.end() - 1)
+            if a is not None:
+                arities.setdefault(m.group(1), set()).add(a)
         for m in re.finditer(r"^\s*(?:@inline\s+)?(?:[A-Za-z_][A-Za-z_0-9]*\.)*([A-Za-z_][A-Za-z_0-9!]*)\((?:[^()]|\([^()]*\))*\)(?:\s+where\s+[^=\n]+)?\s*=(?!=)", src, flags=re.M):
             names.add(m.group(1))
         for m in re.finditer(r"\b(?:abstract\s+type|primitive\s+type|mutable\s+struct|struct)\s+([A-Za-z_][A-Za-z_0-9]*)", src):
@@ -55,5 +84,6 @@ for root, _dirs, files in os.walk(os.path.join(REF, "src")):
                 fields[st] = fl
 json.dump({"source": "identifiers of /root/reference/src/**/*.jl (MadNLP.jl): defined function / type / constant / enum names, and the field names of the structs "
                      "julia/MadNLPHIP.jl reads -- names only, written by tests/golden/make_reference_api_names.py",
-           "names": sorted(names), "struct_fields": fields}, open(OUT, "w"), indent=0)
+           "names": sorted(names), "struct_fields": fields,
+           "method_arities": {k: sorted(v) for k, v in sorted(arities.items()) if k in names}}, open(OUT, "w"), indent=0)
 print(len(names), "names;", {k: len(v) for k, v in fields.items()})

@@ -263,3 +263,41 @@ def test_callback_fields_and_option_keywords_of_the_glue_exist_in_the_reference(
     kws = re.findall(r"^\s*([a-z_]+)\s*=", m.group(1), flags=re.M)
     assert kws == ["kkt_system", "linear_solver", "fixed_variable_treatment", "equality_treatment", "dual_initialization_method", "tol"]
     assert not [k for k in kws if k not in opts]
+
+
+def _positional_arity(src, open_idx):
+    depth, n, seen, i = 0, 0, False, open_idx
+    while i < len(src):
+        c = src[i]
+        if c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+            if depth == 0:
+                return n + (1 if seen else 0)
+        elif depth == 1:
+            if c == ",":
+                n += 1
+                seen = False
+            elif c == ";":
+                return n + (1 if seen else 0)
+            elif not c.isspace():
+                seen = True
+        i += 1
+    return None
+
+
+def test_methods_the_glue_adds_to_reference_functions_have_an_arity_the_reference_defines():
+    """`MadNLP.f(args...)` at the start of a statement (the methods the glue adds -- `function MadNLP.f(...)`, `MadNLP.f(...) = ...` -- and its
+    direct calls): the number of positional arguments must be one the reference itself defines a method of `f` with (fixture:
+    `method_arities`) -- `solve_linear_system!(M, x)`, `inertia(M)`, `build_kkt!(kkt)`, `create_kkt_system(T, cb, linear_solver; ...)`, ..."""
+    import json
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_api_names.json")))
+    ar = fx["method_arities"]
+    code = _julia_code_without_comments()
+    seen = 0
+    for m in re.finditer(r"(?:^|\n)\s*(?:function\s+)?MadNLP\.([A-Za-z_][A-Za-z_0-9!]*)\(", code):
+        a = _positional_arity(code, m.end() - 1)
+        assert a in ar.get(m.group(1), []), (m.group(1), a, ar.get(m.group(1)))
+        seen += 1
+    assert seen >= 30, seen
